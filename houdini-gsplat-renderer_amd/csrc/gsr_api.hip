@@ -1,0 +1,737 @@
+// gsr_api.hip -- host side of libgsplat_hip.so: context, HBM buffers, the
+// per-frame kernel pipeline and the C ABI declared in include/gsplat_hip.h.
+//
+// Pipeline per gsr_render (all on one HIP stream):
+//   K1 k_preprocess        N splats -> record/key/rect                     (HBM)
+//   depth sort             4 x {hist, scan, scatter} on (key, idx)         (HBM)
+//   K2 k_tile_counts+scan  pairs per depth rank -> offsets, D              (HBM)
+//      [D read back: 4-byte D2H + stream sync -- sizes the pair buffers]
+//   K3 k_emit_pairs        D (tile, splat) pairs in depth order            (HBM)
+//   tile sort              ceil(log2(tiles)/8) stable radix passes         (HBM)
+//   K5 k_tile_ranges
+//   K6 k_blend             per-tile front-to-back compositing       (VALU/LDS)
+// Reference counterpart: GSplatRenderer::render + the GLSL program it drives
+// (/root/reference/gsplat_plugin/src/GSplatRenderer.C:534-658).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/gsplat_hip.h"
+#include "gsr_device.h"
+#include "k_binning.h"
+#include "k_blend.h"
+#include "k_preprocess.h"
+#include "k_sort.h"
+
+#define GSR_VERSION_STR "gsplat_hip 0.1.0 (gfx950)"
+#define GSR_EVENT_SLOTS 4
+#define GSR_STAGE_EVENTS 7
+
+static thread_local char g_err[512] = "";
+
+static int set_err(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return set_err(e_ == hipErrorOutOfMemory ? GSR_E_OOM : GSR_E_HIP, "%s failed: %s (%s:%d)", #expr, \
+                           hipGetErrorString(e_), __FILE__, __LINE__);                             \
+    } while (0)
+
+struct gsr_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    // geometry (SoA of 16-byte vectors)
+    uint32_t n = 0, cap = 0;
+    bool has_sh = false;
+    float origin[3] = {0, 0, 0};
+    uint64_t geo_gen = 0;
+    float4* geoA = nullptr;
+    uint4* geoB = nullptr;
+    uint4* col = nullptr;
+    int col_chunks = 0;
+    bool uploading = false;
+    uint32_t up_total = 0, up_filled = 0;
+
+    // per-splat frame buffers
+    GsrRecord* rec = nullptr;
+    uint32_t *keyA = nullptr, *keyB = nullptr, *idxA = nullptr, *idxB = nullptr;
+    uint32_t *rect = nullptr, *cnt = nullptr, *poff = nullptr;
+    // scan / sort scratch
+    uint32_t* hist = nullptr;
+    size_t hist_cap = 0;
+    uint32_t* partial = nullptr;
+    size_t partial_cap = 0;
+    // pairs
+    uint32_t *pkA = nullptr, *pkB = nullptr, *pvA = nullptr, *pvB = nullptr;
+    size_t pair_cap = 0;
+    uint32_t* sorted_pvals = nullptr;  // which of pvA/pvB holds the tile-sorted list of the last frame
+    int32_t *tstart = nullptr, *tend = nullptr;
+    size_t tile_cap = 0;
+    float* fb = nullptr;
+    size_t fb_cap = 0;
+    // small device/host mailboxes
+    unsigned long long* counters = nullptr;  // [0] visible, [1] pairs consumed
+    uint32_t* d_total = nullptr;
+    uint32_t* h_total = nullptr;             // pinned
+    unsigned long long* h_counters = nullptr;  // pinned [2]
+
+    int shard_index = 0, shard_count = 1;
+    int opt_swizzle = 1, opt_timing = 1, opt_sort_cache = 1;
+
+    // depth-sort cache (argsortByDistance semantics)
+    bool sort_valid = false;
+    float sort_cam[3] = {0, 0, 0};
+    uint64_t sort_gen = 0;
+
+    // last frame description
+    int last_tiles_x = 0, last_local_ty = 0;
+    uint32_t last_pairs = 0;
+
+    // stats
+    gsr_stats st{};
+    hipEvent_t ev[GSR_EVENT_SLOTS][GSR_STAGE_EVENTS];
+    bool ev_pending[GSR_EVENT_SLOTS] = {false, false, false, false};
+    bool ev_ok = false;
+    uint64_t frame_no = 0;
+};
+
+template <typename T>
+static int dev_alloc(T** p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return GSR_OK;
+}
+template <typename T>
+static void dev_free(T*& p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------
+extern "C" int gsr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char* gsr_last_error(void) { return g_err; }
+extern "C" const char* gsr_version(void) { return GSR_VERSION_STR; }
+
+extern "C" int gsr_create(int device, gsr_context** out)
+{
+    if (!out) return set_err(GSR_E_INVALID, "gsr_create: out is NULL");
+    *out = nullptr;
+    int ndev = gsr_device_count();
+    if (ndev <= 0) return set_err(GSR_E_NO_DEVICE, "gsr_create: no HIP device visible");
+    if (device < 0 || device >= ndev) return set_err(GSR_E_NO_DEVICE, "gsr_create: device %d out of range (0..%d)", device, ndev - 1);
+    HIP_TRY(hipSetDevice(device));
+    gsr_context* c = new (std::nothrow) gsr_context();
+    if (!c) return set_err(GSR_E_OOM, "gsr_create: host allocation failed");
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return set_err(GSR_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    c->stream = c->own_stream;
+    bool ok = true;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&c->counters), 4 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&c->d_total), sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_total), sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), 4 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMemset(c->counters, 0, 4 * sizeof(unsigned long long)) == hipSuccess;
+    if (ok) {
+        c->ev_ok = true;
+        for (int s = 0; s < GSR_EVENT_SLOTS && ok; ++s)
+            for (int k = 0; k < GSR_STAGE_EVENTS && ok; ++k) ok = hipEventCreate(&c->ev[s][k]) == hipSuccess;
+    }
+    if (!ok) {
+        gsr_destroy(c);
+        return set_err(GSR_E_HIP, "gsr_create: allocating context mailboxes/events failed");
+    }
+    c->st.record_bytes = (int32_t)sizeof(GsrRecord);
+    c->st.pair_bytes = 4;
+    *out = c;
+    return GSR_OK;
+}
+
+static void free_geometry(gsr_context* c)
+{
+    dev_free(c->geoA); dev_free(c->geoB); dev_free(c->col);
+    dev_free(c->rec); dev_free(c->keyA); dev_free(c->keyB); dev_free(c->idxA); dev_free(c->idxB);
+    dev_free(c->rect); dev_free(c->cnt); dev_free(c->poff);
+    c->cap = 0; c->n = 0;
+}
+
+extern "C" void gsr_destroy(gsr_context* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_geometry(c);
+    dev_free(c->hist); dev_free(c->partial);
+    dev_free(c->pkA); dev_free(c->pkB); dev_free(c->pvA); dev_free(c->pvB);
+    dev_free(c->tstart); dev_free(c->tend); dev_free(c->fb);
+    dev_free(c->counters); dev_free(c->d_total);
+    if (c->h_total) (void)hipHostFree(c->h_total);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->ev_ok)
+        for (int s = 0; s < GSR_EVENT_SLOTS; ++s)
+            for (int k = 0; k < GSR_STAGE_EVENTS; ++k)
+                if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int gsr_set_stream(gsr_context* c, void* s)
+{
+    if (!c) return set_err(GSR_E_INVALID, "gsr_set_stream: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    return GSR_OK;
+}
+
+extern "C" int gsr_set_option(gsr_context* c, int option, int value)
+{
+    if (!c) return set_err(GSR_E_INVALID, "gsr_set_option: ctx is NULL");
+    switch (option) {
+    case GSR_OPT_XCD_SWIZZLE: c->opt_swizzle = value ? 1 : 0; break;
+    case GSR_OPT_STAGE_TIMING: c->opt_timing = value ? 1 : 0; break;
+    case GSR_OPT_SORT_CACHE: c->opt_sort_cache = value ? 1 : 0; c->sort_valid = false; break;
+    default: return set_err(GSR_E_INVALID, "gsr_set_option: unknown option %d", option);
+    }
+    return GSR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// geometry staging
+extern "C" int gsr_upload_begin(gsr_context* c, int64_t total, int has_sh, const float origin[3])
+{
+    if (!c) return set_err(GSR_E_INVALID, "gsr_upload_begin: ctx is NULL");
+    if (total < 0 || total > 0x7fffffffll) return set_err(GSR_E_INVALID, "gsr_upload_begin: bad splat count %lld", (long long)total);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t n = (uint32_t)total;
+    const int chunks = has_sh ? 6 : 1;
+    if (n > c->cap || chunks != c->col_chunks) {
+        free_geometry(c);
+        const size_t cap = n ? n : 1;
+        int rc;
+        if ((rc = dev_alloc(&c->geoA, cap)) || (rc = dev_alloc(&c->geoB, cap)) || (rc = dev_alloc(&c->col, cap * chunks)) ||
+            (rc = dev_alloc(&c->rec, cap)) || (rc = dev_alloc(&c->keyA, cap)) || (rc = dev_alloc(&c->keyB, cap)) ||
+            (rc = dev_alloc(&c->idxA, cap)) || (rc = dev_alloc(&c->idxB, cap)) || (rc = dev_alloc(&c->rect, cap)) ||
+            (rc = dev_alloc(&c->cnt, cap + 8)) || (rc = dev_alloc(&c->poff, cap + 8))) {
+            free_geometry(c);
+            return rc;
+        }
+        c->cap = (uint32_t)cap;
+        c->col_chunks = chunks;
+    }
+    c->n = 0;
+    c->has_sh = has_sh != 0;
+    c->up_total = n;
+    c->up_filled = 0;
+    c->uploading = true;
+    for (int k = 0; k < 3; ++k) c->origin[k] = origin ? origin[k] : 0.0f;
+    c->sort_valid = false;
+    return GSR_OK;
+}
+
+extern "C" int gsr_upload_append(gsr_context* c, int64_t n64, const float* P, const uint16_t* Cd, const float* alpha,
+                                 const uint16_t* scale, const uint16_t* orient, const uint16_t* shx,
+                                 const uint16_t* shy, const uint16_t* shz)
+{
+    if (!c || !c->uploading) return set_err(GSR_E_INVALID, "gsr_upload_append: no upload in progress");
+    if (n64 < 0 || (uint64_t)n64 + c->up_filled > c->up_total)
+        return set_err(GSR_E_INVALID, "gsr_upload_append: %lld splats exceed the %u announced", (long long)n64, c->up_total);
+    if (n64 == 0) return GSR_OK;
+    if (!P || !Cd || !alpha || !scale || !orient) return set_err(GSR_E_INVALID, "gsr_upload_append: NULL attribute array");
+    if (c->has_sh && (!shx || !shy || !shz)) return set_err(GSR_E_INVALID, "gsr_upload_append: SH announced but arrays are NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n = (uint32_t)n64;
+    // raw staging buffers (freed before return: upload is not the per-frame path)
+    float *dP = nullptr, *dA = nullptr;
+    uint16_t *dCd = nullptr, *dS = nullptr, *dO = nullptr, *dX = nullptr, *dY = nullptr, *dZ = nullptr;
+    int rc = GSR_OK;
+    auto cleanup = [&]() { dev_free(dP); dev_free(dA); dev_free(dCd); dev_free(dS); dev_free(dO); dev_free(dX); dev_free(dY); dev_free(dZ); };
+    if ((rc = dev_alloc(&dP, (size_t)n * 3)) || (rc = dev_alloc(&dA, (size_t)n)) || (rc = dev_alloc(&dCd, (size_t)n * 3)) ||
+        (rc = dev_alloc(&dS, (size_t)n * 3)) || (rc = dev_alloc(&dO, (size_t)n * 4))) { cleanup(); return rc; }
+    if (c->has_sh && ((rc = dev_alloc(&dX, (size_t)n * 16)) || (rc = dev_alloc(&dY, (size_t)n * 16)) || (rc = dev_alloc(&dZ, (size_t)n * 16)))) { cleanup(); return rc; }
+    hipError_t e = hipSuccess;
+    auto h2d = [&](void* d, const void* h, size_t bytes) { if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream); };
+    h2d(dP, P, (size_t)n * 12); h2d(dA, alpha, (size_t)n * 4); h2d(dCd, Cd, (size_t)n * 6);
+    h2d(dS, scale, (size_t)n * 6); h2d(dO, orient, (size_t)n * 8);
+    if (c->has_sh) { h2d(dX, shx, (size_t)n * 32); h2d(dY, shy, (size_t)n * 32); h2d(dZ, shz, (size_t)n * 32); }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_repack, dim3(div_up(n, 256)), dim3(256), 0, c->stream, n, c->up_filled, c->cap,
+                           c->has_sh ? 1 : 0, dP, dCd, dA, dS, dO, dX, dY, dZ, c->geoA, c->geoB, c->col);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_upload_append: %s", hipGetErrorString(e));
+    c->up_filled += n;
+    return GSR_OK;
+}
+
+extern "C" int gsr_upload_end(gsr_context* c)
+{
+    if (!c || !c->uploading) return set_err(GSR_E_INVALID, "gsr_upload_end: no upload in progress");
+    c->uploading = false;
+    if (c->up_filled != c->up_total)
+        return set_err(GSR_E_INVALID, "gsr_upload_end: %u of %u announced splats were appended", c->up_filled, c->up_total);
+    c->n = c->up_total;
+    c->geo_gen++;
+    c->sort_valid = false;
+    c->st.n_splats = c->n;
+    return GSR_OK;
+}
+
+extern "C" int gsr_upload(gsr_context* c, int64_t n, const float* P, const uint16_t* Cd, const float* alpha,
+                          const uint16_t* scale, const uint16_t* orient, const uint16_t* shx, const uint16_t* shy,
+                          const uint16_t* shz, const float origin[3])
+{
+    const int has_sh = (shx && shy && shz) ? 1 : 0;
+    int rc = gsr_upload_begin(c, n, has_sh, origin);
+    if (rc) return rc;
+    rc = gsr_upload_append(c, n, P, Cd, alpha, scale, orient, shx, shy, shz);
+    if (rc) { c->uploading = false; return rc; }
+    return gsr_upload_end(c);
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU shard helpers
+extern "C" int gsr_set_row_shard(gsr_context* c, int index, int count)
+{
+    if (!c) return set_err(GSR_E_INVALID, "gsr_set_row_shard: ctx is NULL");
+    if (count < 1 || index < 0 || index >= count) return set_err(GSR_E_INVALID, "gsr_set_row_shard: bad shard %d/%d", index, count);
+    c->shard_index = index;
+    c->shard_count = count;
+    return GSR_OK;
+}
+
+extern "C" int gsr_band_rows(int height, int index, int count)
+{
+    (void)index;  // every shard uses the same (padded) band height so that gathers are uniform
+    if (height <= 0 || count < 1) return 0;
+    const int tiles_y = (height + GSR_TILE - 1) / GSR_TILE;
+    return ((tiles_y + count - 1) / count) * GSR_TILE;
+}
+
+extern "C" int gsr_stitch_bands(gsr_context* c, const float* gathered, int count, int width, int height, float* out)
+{
+    if (!c || !gathered || !out || count < 1 || width <= 0 || height <= 0)
+        return set_err(GSR_E_INVALID, "gsr_stitch_bands: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npx = (size_t)width * height;
+    hipLaunchKernelGGL(k_stitch_bands, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const float4*>(gathered), count, gsr_band_rows(height, 0, count), width, height,
+                       reinterpret_cast<float4*>(out));
+    HIP_TRY(hipGetLastError());
+    return GSR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// scan + sort drivers
+static int ensure_u32(uint32_t** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return GSR_OK;
+    dev_free(*p);
+    *cap = 0;
+    size_t want = need + need / 4 + 1024;
+    int rc = dev_alloc(p, want);
+    if (rc) return rc;
+    *cap = want;
+    return GSR_OK;
+}
+
+// out may equal in.  total (device pointer) may be NULL.
+static int exclusive_scan(gsr_context* c, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* d_total)
+{
+    if (n == 0) {
+        if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, 4, c->stream));
+        return GSR_OK;
+    }
+    const uint32_t m = div_up(n, SC_TILE);
+    int rc = ensure_u32(&c->partial, &c->partial_cap, m);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scan_reduce, dim3(m), dim3(SC_THREADS), 0, c->stream, in, n, c->partial);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SC_THREADS), 0, c->stream, c->partial, m, d_total);
+    hipLaunchKernelGGL(k_scan_down, dim3(m), dim3(SC_THREADS), 0, c->stream, in, n, c->partial, out);
+    HIP_TRY(hipGetLastError());
+    return GSR_OK;
+}
+
+// stable LSD sort on key bits [0, bits); ping-pongs (kA,vA) <-> (kB,vB) and
+// leaves the result in (kA,vA) by swapping the pointers.
+static int radix_sort(gsr_context* c, uint32_t*& kA, uint32_t*& vA, uint32_t*& kB, uint32_t*& vB, uint32_t n, int bits)
+{
+    if (n == 0 || bits <= 0) return GSR_OK;
+    const uint32_t nblk = div_up(n, RS_TILE);
+    int rc = ensure_u32(&c->hist, &c->hist_cap, (size_t)256 * nblk + 8);
+    if (rc) return rc;
+    const int passes = (bits + 7) / 8;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * 8;
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kA, n, shift, c->hist, nblk);
+        rc = exclusive_scan(c, c->hist, c->hist, 256u * nblk, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kA, vA, kB, vB, n, shift,
+                           c->hist, nblk);
+        uint32_t* t = kA; kA = kB; kB = t;
+        t = vA; vA = vB; vB = t;
+    }
+    HIP_TRY(hipGetLastError());
+    return GSR_OK;
+}
+
+// ---------------------------------------------------------------------------
+static inline float M4h(const float* m, int r, int c) { return m[c * 4 + r]; }
+
+static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f)
+{
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 4; ++k) {
+            f->ov[r * 4 + k] = M4h(cam->obj_view, r, k);
+            f->vw[r * 4 + k] = M4h(cam->view, r, k);
+        }
+    for (int r = 0; r < 4; ++r)
+        for (int k = 0; k < 4; ++k) f->pr[r * 4 + k] = M4h(cam->proj, r, k);
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 3; ++k) {
+            f->ob[r * 3 + k] = M4h(cam->object, r, k);
+            f->io[r * 3 + k] = M4h(cam->inv_object, r, k);
+        }
+    for (int k = 0; k < 3; ++k) { f->cam[k] = cam->cam_pos[k]; f->origin[k] = c->origin[k]; }
+    // CalcCovariance2D's per-frame constants, float32, in the contract's order
+    // (/root/reference/gsplat_plugin/shaders/GSplatShaderCoreLib.h:44-53)
+    volatile float p00 = M4h(cam->proj, 0, 0), p11 = M4h(cam->proj, 1, 1);
+    volatile float aspect = p00 / p11;
+    volatile float tanFovX = 1.0f / p00;
+    volatile float p11a = p11 * aspect;
+    volatile float tanFovY = 1.0f / p11a;
+    f->limx = 1.3f * tanFovX;
+    f->limy = 1.3f * tanFovY;
+    f->W = (float)cam->width;
+    f->H = (float)cam->height;
+    volatile float wp = f->W * p00;
+    f->focal = wp * 0.5f;
+    f->width = cam->width;
+    f->height = cam->height;
+    f->sh_order = (c->has_sh && cam->sh_order > 0) ? (cam->sh_order > 3 ? 3 : cam->sh_order) : 0;
+    f->tiles_x = (cam->width + GSR_TILE - 1) / GSR_TILE;
+    f->tiles_y = (cam->height + GSR_TILE - 1) / GSR_TILE;
+    f->shard_index = c->shard_index;
+    f->shard_count = c->shard_count;
+    f->local_tiles_y = (f->tiles_y > c->shard_index) ? (f->tiles_y - c->shard_index + c->shard_count - 1) / c->shard_count : 0;
+}
+
+static void harvest_slot(gsr_context* c, int slot)
+{
+    if (!c->ev_pending[slot]) return;
+    c->ev_pending[slot] = false;
+    hipEvent_t* e = c->ev[slot];
+    if (hipEventSynchronize(e[6]) != hipSuccess) return;
+    float ms[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 6; ++k)
+        if (hipEventElapsedTime(&ms[k], e[k], e[k + 1]) != hipSuccess) ms[k] = 0.0f;
+    c->st.ms_preprocess = ms[0];
+    c->st.ms_depth_sort = ms[1];
+    c->st.ms_emit = ms[2];
+    c->st.ms_tile_sort = ms[3] + ms[4];
+    c->st.ms_blend = ms[5];
+    float tot = 0.0f;
+    (void)hipEventElapsedTime(&tot, e[0], e[6]);
+    c->st.ms_total = tot;
+    c->st.blend_ms_total += ms[5];
+    c->st.blend_launches += 1;
+    c->st.frame_ms_total += tot;
+}
+
+extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out, int out_is_device)
+{
+    if (!c || !cam || !rgba_out) return set_err(GSR_E_INVALID, "gsr_render: NULL argument");
+    if (c->uploading) return set_err(GSR_E_INVALID, "gsr_render: upload in progress");
+    if (cam->width <= 0 || cam->height <= 0 || cam->width > GSR_MAX_DIM || cam->height > GSR_MAX_DIM)
+        return set_err(GSR_E_INVALID, "gsr_render: bad framebuffer size %dx%d (max %d)", cam->width, cam->height, GSR_MAX_DIM);
+    if (c->geo_gen == 0) return set_err(GSR_E_NO_GEOMETRY, "gsr_render: nothing uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+
+    GsrFrame f;
+    build_frame(c, cam, &f);
+    const uint32_t n = c->n;
+    const int local_tiles = f.tiles_x * f.local_tiles_y;
+    const int band_rows = (c->shard_count > 1) ? gsr_band_rows(cam->height, c->shard_index, c->shard_count) : cam->height;
+    const size_t out_px = (size_t)band_rows * cam->width;
+
+    const int slot = (int)(c->frame_no % GSR_EVENT_SLOTS);
+    const bool timing = c->opt_timing != 0;
+    if (timing) harvest_slot(c, slot);
+    hipEvent_t* ev = c->ev[slot];
+#define MARK(k) do { if (timing) HIP_TRY(hipEventRecord(ev[k], s)); } while (0)
+
+    // per-tile range arrays
+    if ((size_t)local_tiles + 1 > c->tile_cap) {
+        dev_free(c->tstart); dev_free(c->tend);
+        c->tile_cap = 0;
+        int rc;
+        if ((rc = dev_alloc(&c->tstart, (size_t)local_tiles + 1)) || (rc = dev_alloc(&c->tend, (size_t)local_tiles + 1))) return rc;
+        c->tile_cap = (size_t)local_tiles + 1;
+    }
+    float* target = rgba_out;
+    if (!out_is_device) {
+        if (out_px * 4 > c->fb_cap) {
+            dev_free(c->fb);
+            c->fb_cap = 0;
+            int rc = dev_alloc(&c->fb, out_px * 4);
+            if (rc) return rc;
+            c->fb_cap = out_px * 4;
+        }
+        target = c->fb;
+    }
+
+    MARK(0);
+    HIP_TRY(hipMemsetAsync(c->counters, 0, 2 * sizeof(unsigned long long), s));  // [2] is a running total
+    const bool cache_hit = c->opt_sort_cache && c->sort_valid && c->sort_gen == c->geo_gen &&
+                           c->sort_cam[0] == cam->cam_pos[0] && c->sort_cam[1] == cam->cam_pos[1] &&
+                           c->sort_cam[2] == cam->cam_pos[2];
+    uint32_t D = 0;
+    if (n > 0) {
+        // on a cache hit K1 must not overwrite the sorted (keyA, idxA): send its key/idx output to the B buffers
+        hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, 256)), dim3(256), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
+                           c->rec, cache_hit ? c->keyB : c->keyA, cache_hit ? c->idxB : c->idxA, c->rect, c->counters);
+        HIP_TRY(hipGetLastError());
+    }
+    MARK(1);
+    if (n > 0 && !cache_hit) {
+        int rc = radix_sort(c, c->keyA, c->idxA, c->keyB, c->idxB, n, 32);
+        if (rc) return rc;
+        c->sort_valid = true;
+        c->sort_gen = c->geo_gen;
+        for (int k = 0; k < 3; ++k) c->sort_cam[k] = cam->cam_pos[k];
+    }
+    MARK(2);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_tile_counts, dim3(div_up(n, 256)), dim3(256), 0, s, c->idxA, c->rect, n, c->shard_index,
+                           c->shard_count, c->cnt);
+        int rc = exclusive_scan(c, c->cnt, c->poff, n, c->d_total);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->h_total, c->d_total, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        D = *c->h_total;
+        if ((unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
+            return set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: %u tile-splat pairs exceed the limit", D);
+        if (D > c->pair_cap) {
+            dev_free(c->pkA); dev_free(c->pkB); dev_free(c->pvA); dev_free(c->pvB);
+            c->pair_cap = 0;
+            const size_t want = (size_t)D + D / 4 + 4096;
+            if ((rc = dev_alloc(&c->pkA, want)) || (rc = dev_alloc(&c->pkB, want)) || (rc = dev_alloc(&c->pvA, want)) ||
+                (rc = dev_alloc(&c->pvB, want))) return rc;
+            c->pair_cap = want;
+        }
+        if (D > 0) {
+            hipLaunchKernelGGL(k_emit_pairs, dim3(div_up(n, 256)), dim3(256), 0, s, c->idxA, c->rect, c->poff, n,
+                               c->shard_index, c->shard_count, f.tiles_x, c->pkA, c->pvA);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    MARK(3);
+    if (D > 0) {
+        int bits = 1;
+        while ((1 << bits) < local_tiles) ++bits;
+        int rc = radix_sort(c, c->pkA, c->pvA, c->pkB, c->pvB, D, bits);
+        if (rc) return rc;
+    }
+    MARK(4);
+    HIP_TRY(hipMemsetAsync(c->tstart, 0, ((size_t)local_tiles + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(c->tend, 0, ((size_t)local_tiles + 1) * 4, s));
+    if (D > 0) {
+        hipLaunchKernelGGL(k_tile_ranges, dim3(div_up(D, 256)), dim3(256), 0, s, c->pkA, D, c->tstart, c->tend);
+        HIP_TRY(hipGetLastError());
+    }
+    MARK(5);
+    if (local_tiles > 0) {
+        GsrBlendArgs a;
+        a.width = cam->width; a.height = cam->height; a.tiles_x = f.tiles_x; a.local_tiles = local_tiles;
+        a.shard_index = c->shard_index; a.shard_count = c->shard_count; a.band_rows = band_rows;
+        a.swizzle = c->opt_swizzle; a.swz_chunk = (local_tiles + 7) / 8;
+        const unsigned grid = a.swizzle ? (unsigned)(a.swz_chunk * 8) : (unsigned)local_tiles;
+        hipLaunchKernelGGL(k_blend, dim3(grid), dim3(256), 0, s, a, c->pvA, c->tstart, c->tend, c->rec,
+                           reinterpret_cast<float4*>(target), c->counters);
+        HIP_TRY(hipGetLastError());
+    }
+    MARK(6);
+#undef MARK
+    if (timing) c->ev_pending[slot] = true;
+    c->sorted_pvals = c->pvA;
+    c->last_tiles_x = f.tiles_x;
+    c->last_local_ty = f.local_tiles_y;
+    c->last_pairs = D;
+    c->st.pairs_total = D;
+    c->st.tiles_x = f.tiles_x;
+    c->st.tiles_y = f.local_tiles_y;
+    c->st.frames += 1;
+    c->frame_no += 1;
+    // counters of this frame travel with the stream; they are read in gsr_get_stats
+    HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    if (!out_is_device) {
+        HIP_TRY(hipMemcpyAsync(rgba_out, c->fb, out_px * 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return GSR_OK;
+}
+
+extern "C" int gsr_synchronize(gsr_context* c)
+{
+    if (!c) return set_err(GSR_E_INVALID, "gsr_synchronize: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSR_OK;
+}
+
+extern "C" int gsr_get_stats(gsr_context* c, gsr_stats* out)
+{
+    if (!c || !out) return set_err(GSR_E_INVALID, "gsr_get_stats: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // harvest in submission order so that "last frame" fields end up describing the newest frame
+    for (int k = 0; k < GSR_EVENT_SLOTS; ++k) harvest_slot(c, (int)((c->frame_no + k) % GSR_EVENT_SLOTS));
+    if (c->frame_no > 0) {
+        c->st.n_visible = (int64_t)c->h_counters[0];
+        c->st.pairs_consumed = (int64_t)c->h_counters[1];
+        c->st.blend_pairs_consumed_total = (int64_t)c->h_counters[2];
+    }
+    *out = c->st;
+    return GSR_OK;
+}
+
+extern "C" int gsr_stats_reset(gsr_context* c)
+{
+    if (!c) return set_err(GSR_E_INVALID, "gsr_stats_reset: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < GSR_EVENT_SLOTS; ++k) harvest_slot(c, k);
+    HIP_TRY(hipMemsetAsync(c->counters, 0, 4 * sizeof(unsigned long long), c->stream));
+    const int64_t ns = c->st.n_splats;
+    c->st = gsr_stats{};
+    c->st.n_splats = ns;
+    c->st.record_bytes = (int32_t)sizeof(GsrRecord);
+    c->st.pair_bytes = 4;
+    return GSR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// debug / test access
+extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int64_t n)
+{
+    if (!c || !out || n < 0 || (uint64_t)n > c->n) return set_err(GSR_E_INVALID, "gsr_debug_read_records: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    GsrRecord* hr = new (std::nothrow) GsrRecord[n ? n : 1];
+    uint32_t* hk = new (std::nothrow) uint32_t[n ? n : 1];
+    uint32_t* hrect = new (std::nothrow) uint32_t[n ? n : 1];
+    uint32_t* hidx = new (std::nothrow) uint32_t[n ? n : 1];
+    int rc = GSR_OK;
+    if (!hr || !hk || !hrect || !hidx) rc = set_err(GSR_E_OOM, "gsr_debug_read_records: host allocation failed");
+    hipError_t e = hipSuccess;
+    if (!rc && n) {
+        e = hipMemcpy(hr, c->rec, (size_t)n * sizeof(GsrRecord), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(hrect, c->rect, (size_t)n * 4, hipMemcpyDeviceToHost);
+        // keys live in sorted order after the depth sort: un-permute through idxA
+        if (e == hipSuccess) e = hipMemcpy(hk, c->keyA, (size_t)n * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(hidx, c->idxA, (size_t)n * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = set_err(GSR_E_HIP, "gsr_debug_read_records: %s", hipGetErrorString(e));
+    }
+    if (!rc) {
+        for (int64_t i = 0; i < n; ++i) {
+            gsr_debug_record& o = out[i];
+            std::memset(&o, 0, sizeof(o));
+            const uint32_t rc_ = hrect[i];
+            const int x0 = rc_ & 255, y0 = (rc_ >> 8) & 255, x1 = (rc_ >> 16) & 255, y1 = rc_ >> 24;
+            o.visible = (x1 >= x0 && y1 >= y0) ? 1 : 0;
+            if (o.visible) {
+                const GsrRecord& r = hr[i];
+                o.cx = r.cx; o.cy = r.cy; o.ex = r.ex; o.ey = r.ey; o.is1 = r.is1; o.is2 = r.is2;
+                o.hx = r.hx; o.hy = r.hy; o.r = r.r; o.g = r.g; o.b = r.b; o.opacity = r.opacity;
+            }
+        }
+        for (int64_t r = 0; r < n; ++r)
+            if (hidx[r] < (uint64_t)n) std::memcpy(&out[hidx[r]].key, &hk[r], 4);
+    }
+    delete[] hr; delete[] hk; delete[] hrect; delete[] hidx;
+    return rc;
+}
+
+extern "C" int gsr_debug_read_depth_order(gsr_context* c, int32_t* perm, int64_t n)
+{
+    if (!c || !perm || n < 0 || (uint64_t)n > c->n) return set_err(GSR_E_INVALID, "gsr_debug_read_depth_order: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n) HIP_TRY(hipMemcpy(perm, c->idxA, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return GSR_OK;
+}
+
+extern "C" int gsr_debug_read_tile_lists(gsr_context* c, int32_t* tile_start, int32_t* tile_end, int64_t n_tiles,
+                                         int32_t* pair_splat, int64_t n_pairs)
+{
+    if (!c || !tile_start || !tile_end) return set_err(GSR_E_INVALID, "gsr_debug_read_tile_lists: bad argument");
+    const int64_t lt = (int64_t)c->last_tiles_x * c->last_local_ty;
+    if (n_tiles != lt || n_pairs != (int64_t)c->last_pairs || (n_pairs > 0 && !pair_splat))
+        return set_err(GSR_E_INVALID, "gsr_debug_read_tile_lists: expected %lld tiles / %u pairs", (long long)lt, c->last_pairs);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (lt) {
+        HIP_TRY(hipMemcpy(tile_start, c->tstart, (size_t)lt * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tile_end, c->tend, (size_t)lt * 4, hipMemcpyDeviceToHost));
+    }
+    if (n_pairs) HIP_TRY(hipMemcpy(pair_splat, c->sorted_pvals, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+    return GSR_OK;
+}
+
+extern "C" int gsr_debug_sort_pairs(gsr_context* c, uint32_t* keys, uint32_t* vals, int64_t n64, int key_bits)
+{
+    if (!c || n64 < 0 || n64 > 0x7fffffffll || key_bits < 1 || key_bits > 32 || (n64 > 0 && (!keys || !vals)))
+        return set_err(GSR_E_INVALID, "gsr_debug_sort_pairs: bad argument");
+    if (n64 == 0) return GSR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n = (uint32_t)n64;
+    uint32_t *kA = nullptr, *kB = nullptr, *vA = nullptr, *vB = nullptr;
+    int rc;
+    if ((rc = dev_alloc(&kA, n)) || (rc = dev_alloc(&kB, n)) || (rc = dev_alloc(&vA, n)) || (rc = dev_alloc(&vB, n))) {
+        dev_free(kA); dev_free(kB); dev_free(vA); dev_free(vB);
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(kA, keys, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(vA, vals, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        rc = radix_sort(c, kA, vA, kB, vB, n, key_bits);
+        if (!rc) {
+            e = hipMemcpyAsync(keys, kA, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(vals, vA, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+    }
+    dev_free(kA); dev_free(kB); dev_free(vA); dev_free(vB);
+    if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_debug_sort_pairs: %s", hipGetErrorString(e));
+    return rc;
+}

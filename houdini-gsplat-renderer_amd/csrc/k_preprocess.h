@@ -1,0 +1,279 @@
+// k_preprocess.h -- K0 (repack at upload) and K1 (per-splat vertex stage).
+//
+// K1 replaces the reference's main vertex shader
+// (/root/reference/gsplat_plugin/shaders/GSplatShaderSource.h:190-288 with the
+// helpers in shaders/GSplatShaderCoreLib.h:10-93,103-179) -- evaluated ONCE per
+// splat instead of once per quad corner -- and the CPU distance loop of
+// argsortByDistance (src/GSplatRenderer.C:194-204).  Roofline: HBM streaming
+// (128 B read + 60 B written per splat at SH order 3; ~250 flop).
+#pragma once
+#include "gsr_device.h"
+
+// ---------------------------------------------------------------------------
+// K0: raw registerUpdate()-layout arrays (already in device memory) -> SoA of
+// 16-byte vectors.  Runs once per geometry change, not per frame.
+__global__ void __launch_bounds__(256)
+k_repack(uint32_t n, uint32_t dst0, uint32_t cap, int has_sh,
+         const float* __restrict__ P, const uint16_t* __restrict__ Cd, const float* __restrict__ alpha,
+         const uint16_t* __restrict__ scale, const uint16_t* __restrict__ orient,
+         const uint16_t* __restrict__ shx, const uint16_t* __restrict__ shy, const uint16_t* __restrict__ shz,
+         float4* __restrict__ geoA, uint4* __restrict__ geoB, uint4* __restrict__ col)
+{
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t o = dst0 + i;
+    geoA[o] = make_float4(P[3 * (size_t)i], P[3 * (size_t)i + 1], P[3 * (size_t)i + 2], alpha[i]);
+    auto pk = [](uint16_t lo, uint16_t hi) { return (uint32_t)lo | ((uint32_t)hi << 16); };
+    const uint16_t* s = scale + 3 * (size_t)i;
+    const uint16_t* q = orient + 4 * (size_t)i;
+    geoB[o] = make_uint4(pk(s[0], s[1]), pk(s[2], q[0]), pk(q[1], q[2]), pk(q[3], 0));
+    uint16_t h[48];
+    h[0] = Cd[3 * (size_t)i]; h[1] = Cd[3 * (size_t)i + 1]; h[2] = Cd[3 * (size_t)i + 2];
+    if (has_sh) {
+#pragma unroll
+        for (int j = 0; j < 15; ++j) {  // coefficient j at (j/4, j%4) of the row-major 4x4 == flat index j
+            h[3 * (j + 1) + 0] = shx[16 * (size_t)i + j];
+            h[3 * (j + 1) + 1] = shy[16 * (size_t)i + j];
+            h[3 * (j + 1) + 2] = shz[16 * (size_t)i + j];
+        }
+    } else {
+#pragma unroll
+        for (int k = 3; k < 48; ++k) h[k] = 0;
+    }
+    const int nchunk = has_sh ? 6 : 1;
+    for (int c = 0; c < nchunk; ++c)
+        col[(size_t)c * cap + o] = make_uint4(pk(h[8 * c], h[8 * c + 1]), pk(h[8 * c + 2], h[8 * c + 3]),
+                                              pk(h[8 * c + 4], h[8 * c + 5]), pk(h[8 * c + 6], h[8 * c + 7]));
+}
+
+// ---------------------------------------------------------------------------
+// SH evaluation for one channel; expressions are written and associated exactly
+// as in the oracle (and in shaders/GSplatShaderCoreLib.h:146-175).
+__device__ __forceinline__ float gsr_shade_sh(float base, const float* sh, float x, float y, float z, int order)
+{
+    const float SH_C1 = 0.4886025f;
+    const float SH_C2_0 = 1.0925484f, SH_C2_1 = -1.0925484f, SH_C2_2 = 0.3153916f, SH_C2_3 = -1.0925484f,
+                SH_C2_4 = 0.5462742f;
+    const float SH_C3_0 = -0.5900436f, SH_C3_1 = 2.8906114f, SH_C3_2 = -0.4570458f, SH_C3_3 = 0.3731763f,
+                SH_C3_4 = -0.4570458f, SH_C3_5 = 1.4453057f, SH_C3_6 = -0.5900436f;
+    float res = base;
+    if (order >= 1) {
+        res += SH_C1 * (-sh[0] * y + sh[1] * z - sh[2] * x);
+        if (order >= 2) {
+            float xx = x * x, yy = y * y, zz = z * z;
+            float xy = x * y, yz = y * z, xz = x * z;
+            res += (SH_C2_0 * xy) * sh[3] + (SH_C2_1 * yz) * sh[4] + (SH_C2_2 * (2.0f * zz - xx - yy)) * sh[5] +
+                   (SH_C2_3 * xz) * sh[6] + (SH_C2_4 * (xx - yy)) * sh[7];
+            if (order >= 3) {
+                res += (SH_C3_0 * y * (3.0f * xx - yy)) * sh[8] + (SH_C3_1 * xy * z) * sh[9] +
+                       (SH_C3_2 * y * (4.0f * zz - xx - yy)) * sh[10] +
+                       (SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * sh[11] +
+                       (SH_C3_4 * x * (4.0f * zz - xx - yy)) * sh[12] + (SH_C3_5 * z * (xx - yy)) * sh[13] +
+                       (SH_C3_6 * x * (xx - 3.0f * yy)) * sh[14];
+            }
+        }
+    }
+    return __builtin_fmaxf(res, 0.0f);
+}
+
+__device__ __forceinline__ float aff4(const float* m, float x, float y, float z)
+{   // m[0]*x + m[1]*y + m[2]*z + m[3] as the contract's fma chain
+    return gsr_fma(m[0], x, gsr_fma(m[1], y, gsr_fma(m[2], z, m[3])));
+}
+__device__ __forceinline__ float lin3(const float* m, float x, float y, float z)
+{
+    return gsr_fma(m[0], x, gsr_fma(m[1], y, m[2] * z));
+}
+
+// K1: one thread per splat.
+//   in : geoA, geoB, col (SoA, coalesced 16 B/lane)
+//   out: rec[i] (48 B), key[i] (f32 distance^2 bits), idx[i] = i, rect[i] (packed tile rect or EMPTY)
+__global__ void __launch_bounds__(256)
+k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
+             const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col,
+             GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint32_t* __restrict__ idx,
+             uint32_t* __restrict__ rect, unsigned long long* __restrict__ counters)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool vis = false;
+    if (i < n) {
+        const float4 a = geoA[i];
+        const float px = a.x, py = a.y, pz = a.z, opacity = a.w;
+
+        // sort key: un-offset P vs camera (src/GSplatRenderer.C:197-201)
+        {
+            float dx = px - f.cam[0], dy = py - f.cam[1], dz = pz - f.cam[2];
+            float k = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
+            key[i] = __builtin_bit_cast(uint32_t, k);
+            idx[i] = i;
+        }
+        uint32_t out_rect = GSR_RECT_EMPTY;
+
+        // fl32(P - origin) + origin  (src/GSplatRenderer.C:459-461, shader :201-202)
+        const float x = (px - f.origin[0]) + f.origin[0];
+        const float y = (py - f.origin[1]) + f.origin[1];
+        const float z = (pz - f.origin[2]) + f.origin[2];
+
+        const float tvx = aff4(&f.ov[0], x, y, z);
+        const float tvy = aff4(&f.ov[4], x, y, z);
+        const float tvz = aff4(&f.ov[8], x, y, z);
+        const float ftvy = -tvy;  // flipYMatrix (:204-207)
+        const float clx = aff4(&f.pr[0], tvx, ftvy, tvz);
+        const float cly = aff4(&f.pr[4], tvx, ftvy, tvz);
+        const float clz = aff4(&f.pr[8], tvx, ftvy, tvz);
+        const float clw = aff4(&f.pr[12], tvx, ftvy, tvz);
+
+        // w<=0 (:209-214); near/far clip of a constant-z quad; alpha = e*opacity <= opacity
+        // can never reach 1/255 when opacity < 1/255 (e <= 1), so those splats draw nothing.
+        const bool keep = (clw > 0.0f) && !(clz < -clw || clz > clw) && (opacity >= (1.0f / 255.0f));
+        if (keep) {
+            const float ndcx = clx / clw;
+            const float ndcy = (-cly) / clw;
+            const float cx = gsr_fma(ndcx, 0.5f, 0.5f) * f.W;
+            const float cy = gsr_fma(ndcy, 0.5f, 0.5f) * f.H;
+
+            const uint4 b = geoB[i];
+            const float sx = gsr_h2f(b.x & 0xffffu), sy = gsr_h2f(b.x >> 16), sz = gsr_h2f(b.y & 0xffffu);
+            const float qi = gsr_h2f(b.y >> 16), qj = gsr_h2f(b.z & 0xffffu), qk = gsr_h2f(b.z >> 16);
+            const float qr = gsr_h2f(b.w & 0xffffu);
+
+            float R[3][3];
+            R[0][0] = 1.0f - 2.0f * gsr_fma(qj, qj, qk * qk);
+            R[0][1] = 2.0f * gsr_fma(qi, qj, -(qr * qk));
+            R[0][2] = 2.0f * gsr_fma(qi, qk, qr * qj);
+            R[1][0] = 2.0f * gsr_fma(qi, qj, qr * qk);
+            R[1][1] = 1.0f - 2.0f * gsr_fma(qi, qi, qk * qk);
+            R[1][2] = 2.0f * gsr_fma(qj, qk, -(qr * qi));
+            R[2][0] = 2.0f * gsr_fma(qi, qk, -(qr * qj));
+            R[2][1] = 2.0f * gsr_fma(qj, qk, qr * qi);
+            R[2][2] = 1.0f - 2.0f * gsr_fma(qi, qi, qj * qj);
+            const float sc[3] = {sx, sy, sz};
+            float M0[3][3], Mm[3][3], S[3][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) M0[p][q] = sc[p] * R[q][p];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    Mm[p][q] = gsr_fma(M0[p][2], f.ob[q * 3 + 2], gsr_fma(M0[p][1], f.ob[q * 3 + 1], M0[p][0] * f.ob[q * 3 + 0]));
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = p; q < 3; ++q) {
+                    float v = gsr_fma(Mm[2][p], Mm[2][q], gsr_fma(Mm[1][p], Mm[1][q], Mm[0][p] * Mm[0][q]));
+                    S[p][q] = v;
+                    S[q][p] = v;
+                }
+
+            float tx = aff4(&f.vw[0], x, y, z);
+            float ty = aff4(&f.vw[4], x, y, z);
+            const float tz = aff4(&f.vw[8], x, y, z);
+            {
+                float rx = tx / tz, ry = ty / tz;
+                rx = __builtin_fminf(__builtin_fmaxf(rx, -f.limx), f.limx);
+                ry = __builtin_fminf(__builtin_fmaxf(ry, -f.limy), f.limy);
+                tx = rx * tz;
+                ty = ry * tz;
+            }
+            const float j00 = f.focal / tz;
+            const float tz2 = tz * tz;
+            const float j02 = -(f.focal * tx) / tz2;
+            const float j12 = -(f.focal * ty) / tz2;
+            float A0[3], A1[3], u0[3], u1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                A0[c] = gsr_fma(j00, f.vw[0 * 4 + c], j02 * f.vw[2 * 4 + c]);
+                A1[c] = gsr_fma(j00, f.vw[1 * 4 + c], j12 * f.vw[2 * 4 + c]);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                u0[k] = gsr_fma(S[k][2], A0[2], gsr_fma(S[k][1], A0[1], S[k][0] * A0[0]));
+                u1[k] = gsr_fma(S[k][2], A1[2], gsr_fma(S[k][1], A1[1], S[k][0] * A1[0]));
+            }
+            const float cov00 = gsr_fma(A0[2], u0[2], gsr_fma(A0[1], u0[1], A0[0] * u0[0]));
+            const float cov01 = gsr_fma(A0[2], u1[2], gsr_fma(A0[1], u1[1], A0[0] * u1[0]));
+            const float cov11 = gsr_fma(A1[2], u1[2], gsr_fma(A1[1], u1[1], A1[0] * u1[0]));
+            const float ca = cov00 + 0.3f, cb = cov01, cc = cov11 + 0.3f;
+
+            const float mid = 0.5f * (ca + cc);
+            const float hd = (ca - cc) * 0.5f;
+            const float radius = __builtin_sqrtf(gsr_fma(hd, hd, cb * cb));
+            const float lambda1 = mid + radius;
+            const float lambda2 = __builtin_fmaxf(mid - radius, 0.1f);
+            const float dvx = cb, dvy = lambda1 - ca;
+            const float dlen = __builtin_sqrtf(gsr_fma(dvx, dvx, dvy * dvy));
+            float ex = 1.0f, ey = 0.0f;
+            if (dlen > 0.0f) {
+                ex = dvx / dlen;
+                ey = dvy / dlen;
+            }
+            const float s1 = __builtin_fminf(__builtin_sqrtf(2.0f * lambda1), 4096.0f);
+            const float s2 = __builtin_fminf(__builtin_sqrtf(2.0f * lambda2), 4096.0f);
+            const float hx = gsr_fma(2.0f * gsr_fma(s1, __builtin_fabsf(ex), s2 * __builtin_fabsf(ey)), 1.0001f, 0.01f);
+            const float hy = gsr_fma(2.0f * gsr_fma(s1, __builtin_fabsf(ey), s2 * __builtin_fabsf(ex)), 1.0001f, 0.01f);
+
+            // pixel range of the conservative bbox -> tile rect
+            const float xlo = cx - hx - 0.5f, xhi = cx + hx - 0.5f;
+            const float ylo = cy - hy - 0.5f, yhi = cy + hy - 0.5f;
+            const float wm1 = (float)(f.width - 1), hm1 = (float)(f.height - 1);
+            if (xhi >= 0.0f && xlo <= wm1 && yhi >= 0.0f && ylo <= hm1) {
+                const int i0 = (int)__builtin_ceilf(__builtin_fmaxf(xlo, 0.0f));
+                const int i1 = (int)__builtin_floorf(__builtin_fminf(xhi, wm1));
+                const int j0 = (int)__builtin_ceilf(__builtin_fmaxf(ylo, 0.0f));
+                const int j1 = (int)__builtin_floorf(__builtin_fminf(yhi, hm1));
+                if (i1 >= i0 && j1 >= j0) {
+                    out_rect = gsr_pack_rect(i0 >> 4, j0 >> 4, i1 >> 4, j1 >> 4);
+                    vis = gsr_rect_tiles(out_rect, f.shard_index, f.shard_count) > 0;
+                }
+            }
+
+            if (out_rect != GSR_RECT_EMPTY) {
+                // colour: Cd, optionally + SH (:224, :244-274)
+                const uint4 c0 = col[i];
+                float cr = gsr_h2f(c0.x & 0xffffu), cg = gsr_h2f(c0.x >> 16), cbl = gsr_h2f(c0.y & 0xffffu);
+                if (f.sh_order > 0) {
+                    uint32_t w[24];
+                    w[0] = c0.x; w[1] = c0.y; w[2] = c0.z; w[3] = c0.w;
+                    const int nchunk = f.sh_order == 1 ? 2 : (f.sh_order == 2 ? 4 : 6);
+#pragma unroll
+                    for (int c = 1; c < 6; ++c) {
+                        uint4 v = make_uint4(0, 0, 0, 0);
+                        if (c < nchunk) v = col[(size_t)c * cap + i];
+                        w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
+                    }
+                    float shr[15], shg[15], shb[15];
+#pragma unroll
+                    for (int j = 0; j < 15; ++j) {
+                        const int h0 = 3 * (j + 1);
+                        shr[j] = gsr_h2f((w[(h0) >> 1] >> (((h0) & 1) * 16)) & 0xffffu);
+                        shg[j] = gsr_h2f((w[(h0 + 1) >> 1] >> (((h0 + 1) & 1) * 16)) & 0xffffu);
+                        shb[j] = gsr_h2f((w[(h0 + 2) >> 1] >> (((h0 + 2) & 1) * 16)) & 0xffffu);
+                    }
+                    const float wx = x - f.cam[0], wy = y - f.cam[1], wz = z - f.cam[2];
+                    const float ox = lin3(&f.io[0], wx, wy, wz);
+                    const float oy = lin3(&f.io[3], wx, wy, wz);
+                    const float oz = lin3(&f.io[6], wx, wy, wz);
+                    const float len = __builtin_sqrtf(gsr_fma(oz, oz, gsr_fma(oy, oy, ox * ox)));
+                    const float dx = ox / len, dy = oy / len, dz = oz / len;
+                    cr = gsr_shade_sh(cr, shr, dx, dy, dz, f.sh_order);
+                    cg = gsr_shade_sh(cg, shg, dx, dy, dz, f.sh_order);
+                    cbl = gsr_shade_sh(cbl, shb, dx, dy, dz, f.sh_order);
+                }
+                GsrRecord o;
+                o.cx = cx; o.cy = cy; o.ex = ex; o.ey = ey;
+                o.is1 = 1.0f / s1; o.is2 = 1.0f / s2; o.hx = hx; o.hy = hy;
+                o.r = cr; o.g = cg; o.b = cbl; o.opacity = opacity;
+                float4* dst = reinterpret_cast<float4*>(rec + i);
+                dst[0] = make_float4(o.cx, o.cy, o.ex, o.ey);
+                dst[1] = make_float4(o.is1, o.is2, o.hx, o.hy);
+                dst[2] = make_float4(o.r, o.g, o.b, o.opacity);
+            }
+        }
+        rect[i] = out_rect;
+    }
+    // visible-splat counter: one atomic per wave
+    const unsigned long long m = __ballot(vis);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&counters[0], (unsigned long long)__builtin_popcountll(m));
+}

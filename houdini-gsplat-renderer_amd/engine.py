@@ -1,0 +1,425 @@
+"""ctypes binding of libgsplat_hip.so: the C ABI (include/gsplat_hip.h) and the flat wrappers
+of the GSplatRenderer host shim (include/GSplatRenderer.h).
+
+There is NO CPU fallback: if the library is missing or no GPU is visible, every
+render path raises ``GsrError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_LIB = None
+
+
+class GsrError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"gsplat_hip error {code}: {msg}")
+        self.code = code
+
+
+class gsr_camera(C.Structure):
+    _fields_ = [("obj_view", C.c_float * 16), ("object", C.c_float * 16), ("inv_object", C.c_float * 16),
+                ("view", C.c_float * 16), ("proj", C.c_float * 16), ("cam_pos", C.c_float * 3),
+                ("width", C.c_int32), ("height", C.c_int32), ("sh_order", C.c_int32)]
+
+
+class gsr_stats(C.Structure):
+    _fields_ = [("n_splats", C.c_int64), ("n_visible", C.c_int64), ("pairs_total", C.c_int64),
+                ("pairs_consumed", C.c_int64), ("tiles_x", C.c_int32), ("tiles_y", C.c_int32),
+                ("record_bytes", C.c_int32), ("pair_bytes", C.c_int32),
+                ("ms_preprocess", C.c_float), ("ms_depth_sort", C.c_float), ("ms_emit", C.c_float),
+                ("ms_tile_sort", C.c_float), ("ms_blend", C.c_float), ("ms_total", C.c_float),
+                ("blend_ms_total", C.c_double), ("blend_launches", C.c_int64),
+                ("blend_pairs_consumed_total", C.c_int64), ("frame_ms_total", C.c_double), ("frames", C.c_int64)]
+
+    def as_dict(self) -> dict:
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class gsr_debug_record(C.Structure):
+    _fields_ = [(n, C.c_float) for n in
+                ("cx", "cy", "ex", "ey", "is1", "is2", "hx", "hy", "r", "g", "b", "opacity", "key")] + \
+               [("visible", C.c_int32)]
+
+
+DEBUG_RECORD_DTYPE = np.dtype([(n, np.float32) for n in
+                               ("cx", "cy", "ex", "ey", "is1", "is2", "hx", "hy", "r", "g", "b", "opacity", "key")]
+                              + [("visible", np.int32)])
+
+
+class GSplatRenderContext(C.Structure):
+    _fields_ = [("obj_view", C.c_float * 16), ("object", C.c_float * 16), ("inv_object", C.c_float * 16),
+                ("view", C.c_float * 16), ("proj", C.c_float * 16), ("width", C.c_int32), ("height", C.c_int32),
+                ("target", C.c_void_p), ("target_is_device", C.c_int32)]
+
+
+OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE = 1, 2, 3
+
+# every symbol include/gsplat_hip.h and include/GSplatRenderer.h declare
+C_ABI_SYMBOLS = [
+    "gsr_device_count", "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_version", "gsr_set_stream",
+    "gsr_upload_begin", "gsr_upload_append", "gsr_upload_end", "gsr_upload", "gsr_set_row_shard", "gsr_band_rows",
+    "gsr_stitch_bands", "gsr_render", "gsr_synchronize", "gsr_get_stats", "gsr_stats_reset", "gsr_set_option",
+    "gsr_debug_read_records", "gsr_debug_read_depth_order", "gsr_debug_read_tile_lists", "gsr_debug_sort_pairs",
+    "gsplat_renderer_create", "gsplat_renderer_get_instance", "gsplat_renderer_destroy",
+    "gsplat_renderer_register_update", "gsplat_renderer_include_in_render_pass",
+    "gsplat_renderer_flush_entries_for_matching_detail", "gsplat_renderer_generate_render_geometry",
+    "gsplat_renderer_render", "gsplat_renderer_post_render", "gsplat_renderer_set_rendering_enabled",
+    "gsplat_renderer_set_explicit_camera_pos", "gsplat_renderer_set_spherical_harmonics_order",
+    "gsplat_renderer_query", "gsplat_renderer_get_origin", "gsplat_renderer_get_last_camera_pos",
+    "gsplat_renderer_engine", "gsplat_closest_sqrt_power_of_2", "gsplat_quantize_half",
+    "gsplat_pack_sh_from_vec3", "gsplat_pack_sh_from_frest", "gsplat_pack_sh_from_array",
+]
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree libgsplat_hip.so (never builds implicitly on a GPU box: the .so travels)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise GsrError(-100, f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950) first")
+    L = C.CDLL(path)
+    vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_float)
+    L.gsr_device_count.restype = i32
+    L.gsr_last_error.restype = C.c_char_p
+    L.gsr_version.restype = C.c_char_p
+    L.gsr_create.argtypes = [i32, C.POINTER(vp)]
+    L.gsr_destroy.argtypes = [vp]
+    L.gsr_destroy.restype = None
+    L.gsr_set_stream.argtypes = [vp, vp]
+    L.gsr_upload_begin.argtypes = [vp, i64, i32, f32p]
+    L.gsr_upload_append.argtypes = [vp, i64] + [vp] * 8
+    L.gsr_upload_end.argtypes = [vp]
+    L.gsr_upload.argtypes = [vp, i64] + [vp] * 8 + [f32p]
+    L.gsr_set_row_shard.argtypes = [vp, i32, i32]
+    L.gsr_band_rows.argtypes = [i32, i32, i32]
+    L.gsr_stitch_bands.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.gsr_render.argtypes = [vp, C.POINTER(gsr_camera), vp, i32]
+    L.gsr_synchronize.argtypes = [vp]
+    L.gsr_get_stats.argtypes = [vp, C.POINTER(gsr_stats)]
+    L.gsr_stats_reset.argtypes = [vp]
+    L.gsr_set_option.argtypes = [vp, i32, i32]
+    L.gsr_debug_read_records.argtypes = [vp, vp, i64]
+    L.gsr_debug_read_depth_order.argtypes = [vp, vp, i64]
+    L.gsr_debug_read_tile_lists.argtypes = [vp, vp, vp, i64, vp, i64]
+    L.gsr_debug_sort_pairs.argtypes = [vp, vp, vp, i64, i32]
+    # host shim wrappers
+    L.gsplat_renderer_create.restype = vp
+    L.gsplat_renderer_create.argtypes = [i32]
+    L.gsplat_renderer_get_instance.restype = vp
+    L.gsplat_renderer_destroy.argtypes = [vp]
+    L.gsplat_renderer_destroy.restype = None
+    L.gsplat_renderer_register_update.argtypes = [vp, C.c_uint64, C.POINTER(C.c_int64), i64, i64, f32p] + [vp] * 8 + \
+                                                 [i64, C.c_char_p, i32]
+    L.gsplat_renderer_include_in_render_pass.argtypes = [vp, C.c_char_p]
+    L.gsplat_renderer_include_in_render_pass.restype = None
+    L.gsplat_renderer_flush_entries_for_matching_detail.argtypes = [vp, C.c_char_p]
+    L.gsplat_renderer_flush_entries_for_matching_detail.restype = None
+    L.gsplat_renderer_generate_render_geometry.argtypes = [vp, C.POINTER(GSplatRenderContext)]
+    L.gsplat_renderer_generate_render_geometry.restype = None
+    L.gsplat_renderer_render.argtypes = [vp, C.POINTER(GSplatRenderContext), i32]
+    L.gsplat_renderer_render.restype = None
+    L.gsplat_renderer_post_render.argtypes = [vp]
+    L.gsplat_renderer_post_render.restype = None
+    L.gsplat_renderer_set_rendering_enabled.argtypes = [vp, i32]
+    L.gsplat_renderer_set_rendering_enabled.restype = None
+    L.gsplat_renderer_set_explicit_camera_pos.argtypes = [vp, f32p]
+    L.gsplat_renderer_set_explicit_camera_pos.restype = None
+    L.gsplat_renderer_set_spherical_harmonics_order.argtypes = [vp, i32]
+    L.gsplat_renderer_set_spherical_harmonics_order.restype = None
+    L.gsplat_renderer_query.argtypes = [vp, i32, C.c_char_p]
+    L.gsplat_renderer_query.restype = i64
+    L.gsplat_renderer_get_origin.argtypes = [vp, f32p]
+    L.gsplat_renderer_get_origin.restype = None
+    L.gsplat_renderer_get_last_camera_pos.argtypes = [vp, f32p]
+    L.gsplat_renderer_get_last_camera_pos.restype = None
+    L.gsplat_renderer_engine.argtypes = [vp]
+    L.gsplat_renderer_engine.restype = vp
+    L.gsplat_closest_sqrt_power_of_2.argtypes = [i32]
+    L.gsplat_closest_sqrt_power_of_2.restype = C.c_uint
+    L.gsplat_quantize_half.argtypes = [vp, vp, i64]
+    L.gsplat_quantize_half.restype = None
+    L.gsplat_pack_sh_from_vec3.argtypes = [C.POINTER(vp), i64, vp, vp, vp]
+    L.gsplat_pack_sh_from_vec3.restype = None
+    L.gsplat_pack_sh_from_frest.argtypes = [C.POINTER(vp), i64, vp, vp, vp]
+    L.gsplat_pack_sh_from_frest.restype = None
+    L.gsplat_pack_sh_from_array.argtypes = [vp, i64, i32, vp, vp, vp]
+    L.gsplat_pack_sh_from_array.restype = None
+    _LIB = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise GsrError(rc, load_library().gsr_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def camera_struct(cam) -> gsr_camera:
+    s = gsr_camera()
+    for name in ("obj_view", "object", "inv_object", "view", "proj"):
+        getattr(s, name)[:] = np.asarray(getattr(cam, name), dtype=np.float32).reshape(16).tolist()
+    s.cam_pos[:] = np.asarray(cam.cam_pos, dtype=np.float32).tolist()
+    s.width, s.height, s.sh_order = int(cam.width), int(cam.height), int(cam.sh_order)
+    return s
+
+
+class _Arrays:
+    """contiguous, correctly typed views of a Splats-like object (kept alive during the call)"""
+
+    def __init__(self, s):
+        self.P = np.ascontiguousarray(s.P, dtype=np.float32).reshape(-1, 3)
+        n = self.n = self.P.shape[0]
+        self.Cd = np.ascontiguousarray(s.Cd, dtype=np.uint16).reshape(n, 3)
+        self.alpha = np.ascontiguousarray(s.alpha, dtype=np.float32).reshape(n)
+        self.scale = np.ascontiguousarray(s.scale, dtype=np.uint16).reshape(n, 3)
+        self.orient = np.ascontiguousarray(s.orient, dtype=np.uint16).reshape(n, 4)
+        sh = getattr(s, "shx", None) is not None
+        self.shx = np.ascontiguousarray(s.shx, dtype=np.uint16).reshape(n, 16) if sh else None
+        self.shy = np.ascontiguousarray(s.shy, dtype=np.uint16).reshape(n, 16) if sh else None
+        self.shz = np.ascontiguousarray(s.shz, dtype=np.uint16).reshape(n, 16) if sh else None
+
+    def ptrs(self):
+        return [_ptr(a) for a in (self.P, self.Cd, self.alpha, self.scale, self.orient, self.shx, self.shy, self.shz)]
+
+
+class Engine:
+    """One libgsplat_hip context = one GPU.  Thin, 1:1 over the gsr_* C ABI."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        h = C.c_void_p()
+        _check(self.L.gsr_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = device
+        self.shard = (0, 1)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gsr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- staging
+    def upload(self, splats, origin=(0.0, 0.0, 0.0)):
+        a = _Arrays(splats)
+        _check(self.L.gsr_upload(self.h, a.n, *a.ptrs(), _f3(origin)))
+        return a.n
+
+    def upload_parts(self, parts, origin=(0.0, 0.0, 0.0)):
+        arrs = [_Arrays(p) for p in parts]
+        has_sh = bool(arrs) and all(a.shx is not None for a in arrs)
+        _check(self.L.gsr_upload_begin(self.h, sum(a.n for a in arrs), int(has_sh), _f3(origin)))
+        for a in arrs:
+            p = a.ptrs()
+            if not has_sh:
+                p[5:] = [None, None, None]
+            _check(self.L.gsr_upload_append(self.h, a.n, *p))
+        _check(self.L.gsr_upload_end(self.h))
+
+    # ---- configuration
+    def set_stream(self, hip_stream: int | None):
+        _check(self.L.gsr_set_stream(self.h, C.c_void_p(hip_stream or 0)))
+
+    def set_option(self, option: int, value: int):
+        _check(self.L.gsr_set_option(self.h, option, value))
+
+    def set_row_shard(self, index: int, count: int):
+        _check(self.L.gsr_set_row_shard(self.h, index, count))
+        self.shard = (index, count)
+
+    def band_rows(self, height: int) -> int:
+        return height if self.shard[1] == 1 else int(self.L.gsr_band_rows(height, self.shard[0], self.shard[1]))
+
+    # ---- per frame
+    def render(self, cam) -> np.ndarray:
+        """synchronous render to a host array [rows, W, 4] float32 (row 0 = bottom)"""
+        rows = self.band_rows(cam.height)
+        out = np.empty((rows, cam.width, 4), dtype=np.float32)
+        cs = camera_struct(cam)
+        _check(self.L.gsr_render(self.h, C.byref(cs), out.ctypes.data, 0))
+        return out
+
+    def render_to_device(self, cam, device_ptr: int):
+        cs = camera_struct(cam)
+        _check(self.L.gsr_render(self.h, C.byref(cs), C.c_void_p(device_ptr), 1))
+
+    def render_struct_to_device(self, cam_struct: gsr_camera, device_ptr: int):
+        _check(self.L.gsr_render(self.h, C.byref(cam_struct), C.c_void_p(device_ptr), 1))
+
+    def stitch_bands(self, gathered_ptr: int, count: int, width: int, height: int, out_ptr: int):
+        _check(self.L.gsr_stitch_bands(self.h, C.c_void_p(gathered_ptr), count, width, height, C.c_void_p(out_ptr)))
+
+    def synchronize(self):
+        _check(self.L.gsr_synchronize(self.h))
+
+    def stats(self) -> dict:
+        st = gsr_stats()
+        _check(self.L.gsr_get_stats(self.h, C.byref(st)))
+        return st.as_dict()
+
+    def stats_reset(self):
+        _check(self.L.gsr_stats_reset(self.h))
+
+    # ---- debug access
+    def debug_records(self, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=DEBUG_RECORD_DTYPE)
+        _check(self.L.gsr_debug_read_records(self.h, out.ctypes.data, n))
+        return out
+
+    def debug_depth_order(self, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=np.int32)
+        _check(self.L.gsr_debug_read_depth_order(self.h, out.ctypes.data, n))
+        return out
+
+    def debug_tile_lists(self):
+        st = self.stats()
+        nt = st["tiles_x"] * st["tiles_y"]
+        npairs = st["pairs_total"]
+        ts = np.zeros(nt, np.int32)
+        te = np.zeros(nt, np.int32)
+        pv = np.zeros(max(npairs, 1), np.int32)
+        _check(self.L.gsr_debug_read_tile_lists(self.h, ts.ctypes.data, te.ctypes.data, nt, pv.ctypes.data, npairs))
+        return ts, te, pv[:npairs]
+
+    def debug_sort_pairs(self, keys: np.ndarray, vals: np.ndarray, key_bits: int = 32):
+        k = np.ascontiguousarray(keys, dtype=np.uint32).copy()
+        v = np.ascontiguousarray(vals, dtype=np.uint32).copy()
+        _check(self.L.gsr_debug_sort_pairs(self.h, k.ctypes.data, v.ctypes.data, k.shape[0], key_bits))
+        return k, v
+
+
+class GSplatRenderer:
+    """Python face of the C++ GSplatRenderer host shim -- the reference's nine verbs
+    (include/GSplatRenderer.h:34-56 of the reference).  ``device=-1`` gives a dry
+    instance (registry/staging logic only, no GPU)."""
+
+    Q_REGISTRY_SIZE, Q_ACTIVE_STAGED, Q_SPLAT_COUNT, Q_CAN_RENDER, Q_STAGING_COUNT, Q_RENDER_COUNT, Q_SH_PRESENT, \
+        Q_LAST_STATUS, Q_ENTRY_AGE, Q_ENTRY_AGE_SINCE_ACTIVE = range(10)
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        self.h = self.L.gsplat_renderer_create(int(device))
+        if not self.h:
+            raise GsrError(-3, self.L.gsr_last_error().decode("utf-8", "replace") or "gsplat_renderer_create failed")
+        self._keep = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gsplat_renderer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def registerUpdate(self, gdp: int, gversion, gVtxOffset: int, splats, splatOrigin=None) -> str:
+        a = _Arrays(splats)
+        origin = splats.barycenter() if splatOrigin is None else splatOrigin
+        ver = (C.c_int64 * 4)(*[int(x) for x in gversion])
+        buf = C.create_string_buffer(256)
+        p = a.ptrs()
+        n = self.L.gsplat_renderer_register_update(self.h, int(gdp), ver, int(gVtxOffset), a.n, _f3(origin), *p,
+                                                   a.n if a.shx is not None else 0, buf, 256)
+        if n < 0:
+            raise GsrError(n, "registerUpdate failed")
+        rid = buf.value.decode()
+        self._keep[rid] = a  # the shim BORROWS the arrays, as the reference does
+        return rid
+
+    def includeInRenderPass(self, rid: str):
+        self.L.gsplat_renderer_include_in_render_pass(self.h, rid.encode())
+
+    def flushEntriesForMatchingDetail(self, rid: str):
+        self.L.gsplat_renderer_flush_entries_for_matching_detail(self.h, rid.encode())
+
+    @staticmethod
+    def context(cam, target=None, target_is_device=False) -> GSplatRenderContext:
+        r = GSplatRenderContext()
+        for name in ("obj_view", "object", "inv_object", "view", "proj"):
+            getattr(r, name)[:] = np.asarray(getattr(cam, name), dtype=np.float32).reshape(16).tolist()
+        r.width, r.height = int(cam.width), int(cam.height)
+        r.target = target
+        r.target_is_device = int(bool(target_is_device))
+        return r
+
+    def generateRenderGeometry(self, r: GSplatRenderContext):
+        self.L.gsplat_renderer_generate_render_geometry(self.h, C.byref(r))
+
+    def render(self, r: GSplatRenderContext, isObjectLevel: bool = False):
+        self.L.gsplat_renderer_render(self.h, C.byref(r), int(isObjectLevel))
+
+    def postRender(self):
+        self.L.gsplat_renderer_post_render(self.h)
+
+    def setRenderingEnabled(self, enabled: bool):
+        self.L.gsplat_renderer_set_rendering_enabled(self.h, int(enabled))
+
+    def setExplicitCameraPos(self, pos):
+        self.L.gsplat_renderer_set_explicit_camera_pos(self.h, _f3(pos))
+
+    def setSphericalHarmonicsOrder(self, order: int):
+        self.L.gsplat_renderer_set_spherical_harmonics_order(self.h, int(order))
+
+    def query(self, what: int, rid: str | None = None) -> int:
+        return int(self.L.gsplat_renderer_query(self.h, what, rid.encode() if rid else None))
+
+    def origin(self) -> np.ndarray:
+        o = (C.c_float * 3)()
+        self.L.gsplat_renderer_get_origin(self.h, o)
+        return np.array(list(o), dtype=np.float32)
+
+    def lastCameraPos(self) -> np.ndarray:
+        o = (C.c_float * 3)()
+        self.L.gsplat_renderer_get_last_camera_pos(self.h, o)
+        return np.array(list(o), dtype=np.float32)
+
+    def frame(self, cam, rids, height=None) -> np.ndarray:
+        """one redraw exactly as the reference drives it: N x GR_PrimGsplat::render marks entries
+        active, then the scene hook runs generate -> render -> postRender (src/DM_GSplatHook.C:30-39)"""
+        for rid in rids:
+            self.includeInRenderPass(rid)
+        out = np.zeros((cam.height, cam.width, 4), dtype=np.float32)
+        r = self.context(cam, out.ctypes.data, False)
+        self.generateRenderGeometry(r)
+        self.render(r, False)
+        self.postRender()
+        return out
+
+
+def quantize_half(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty(a.shape, dtype=np.uint16)
+    load_library().gsplat_quantize_half(a.ctypes.data, out.ctypes.data, a.size)
+    return out

@@ -1,0 +1,108 @@
+"""Synthetic splat clouds for BASELINE.json's configs (distributions frozen per SURVEY 8d).
+
+Arrays use the reference's registerUpdate() layout (include/GSplatRenderer.h:34-47 of the
+reference): P f32 [n,3]; Cd/scale f16 bits [n,3]; orient f16 bits [n,4] (x,y,z,w); alpha f32 [n];
+shx/shy/shz f16 bits [n,16] (coefficient j at flat index j) or None.  Quantisation is IEEE
+round-to-nearest-even, which is what HDK's fpreal16 does (src/GR_GSplat.C:315-318).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+C0 = 0.2820948
+
+
+@dataclass
+class Splats:
+    P: np.ndarray
+    Cd: np.ndarray
+    alpha: np.ndarray
+    scale: np.ndarray
+    orient: np.ndarray
+    shx: np.ndarray | None = None
+    shy: np.ndarray | None = None
+    shz: np.ndarray | None = None
+
+    @property
+    def n(self) -> int:
+        return int(self.P.shape[0])
+
+    @property
+    def has_sh(self) -> bool:
+        return self.shx is not None
+
+    def barycenter(self) -> np.ndarray:
+        """GEO_PrimGsplat::baryCenter: float32 mean of the points (src/GEO_GSplat.C:338-351)."""
+        if self.n == 0:
+            return np.zeros(3, dtype=np.float32)
+        return self.P.astype(np.float64).mean(axis=0).astype(np.float32)
+
+    def subset(self, sl) -> "Splats":
+        g = lambda a: None if a is None else np.ascontiguousarray(a[sl])
+        return Splats(g(self.P), g(self.Cd), g(self.alpha), g(self.scale), g(self.orient), g(self.shx), g(self.shy), g(self.shz))
+
+
+def f16bits(a: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32).astype(np.float16).view(np.uint16)
+
+
+def make_scene(n: int, seed: int, sh: bool = True, isotropic: bool = False, radius: float = 1.0,
+               log_scale_range=(-5.5, -3.5), chunk: int = 1 << 20) -> Splats:
+    """uniform-in-ball positions; scale = exp(U(lo,hi)); orient = normalised N(0,1)^4;
+    opacity = sigmoid(N(0,2)); Cd = clip(0.5 + C0*N(0,1), 0, 1); f_rest ~ N(0, 0.1)."""
+    rng = np.random.default_rng(seed)
+    P = np.empty((n, 3), np.float32)
+    Cd = np.empty((n, 3), np.uint16)
+    alpha = np.empty(n, np.float32)
+    scale = np.empty((n, 3), np.uint16)
+    orient = np.empty((n, 4), np.uint16)
+    shx = shy = shz = None
+    if sh:
+        shx = np.zeros((n, 16), np.uint16)
+        shy = np.zeros((n, 16), np.uint16)
+        shz = np.zeros((n, 16), np.uint16)
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        d = rng.standard_normal((m, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        r = radius * rng.random(m) ** (1.0 / 3.0)
+        P[lo:lo + m] = (d * r[:, None]).astype(np.float32)
+        if isotropic:
+            s = np.exp(rng.uniform(log_scale_range[0], log_scale_range[1], (m, 1))).repeat(3, axis=1)
+        else:
+            s = np.exp(rng.uniform(log_scale_range[0], log_scale_range[1], (m, 3)))
+        scale[lo:lo + m] = f16bits(s)
+        q = rng.standard_normal((m, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        orient[lo:lo + m] = f16bits(q)
+        alpha[lo:lo + m] = (1.0 / (1.0 + np.exp(-rng.normal(0.0, 2.0, m)))).astype(np.float32)
+        Cd[lo:lo + m] = f16bits(np.clip(0.5 + C0 * rng.standard_normal((m, 3)), 0.0, 1.0))
+        if sh:
+            fr = rng.normal(0.0, 0.1, (m, 45))  # f_rest_0..44, channel-major (INRIA layout)
+            shx[lo:lo + m, :15] = f16bits(fr[:, 0:15])
+            shy[lo:lo + m, :15] = f16bits(fr[:, 15:30])
+            shz[lo:lo + m, :15] = f16bits(fr[:, 30:45])
+    return Splats(P, Cd, alpha, scale, orient, shx, shy, shz)
+
+
+# BASELINE.json configs -> (n, seed, sh, isotropic, radius, width, height, sh_order)
+CONFIGS = {
+    "C1": dict(n=10_000, seed=1001, sh=False, isotropic=True, radius=1.0, width=512, height=512, sh_order=0),
+    "C2": dict(n=100_000, seed=1002, sh=True, isotropic=False, radius=1.0, width=1280, height=720, sh_order=3),
+    "C3": dict(n=1_000_000, seed=1003, sh=True, isotropic=False, radius=1.0, width=1920, height=1080, sh_order=3),
+    "C4": dict(n=6_000_000, seed=1004, sh=True, isotropic=False, radius=2.0, width=1920, height=1080, sh_order=3),
+    "C5": dict(n=6_000_000, seed=1005, sh=True, isotropic=False, radius=2.0, width=3840, height=2160, sh_order=3),
+}
+
+
+def make_config(name: str, n_override: int | None = None) -> tuple[Splats, dict]:
+    cfg = dict(CONFIGS[name])
+    if n_override is not None:
+        cfg["n"] = int(n_override)
+    s = make_scene(cfg["n"], cfg["seed"], sh=cfg["sh"], isotropic=cfg["isotropic"], radius=cfg["radius"])
+    if name == "C3":
+        # the example scene overwrites Cd with 0.5 grey before the SOP
+        s.Cd[:] = f16bits(np.full((1, 3), 0.5))
+    return s, cfg

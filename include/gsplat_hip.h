@@ -1,0 +1,161 @@
+/*
+ * gsplat_hip.h -- C ABI of libgsplat_hip.so, the MI355X (gfx950) Gaussian-splat
+ * rasterizer that replaces the device half (and the per-camera-move CPU sort)
+ * of the reference's GSplatRenderer.  No HDK, GL or torch types cross this
+ * boundary: plain pointers, sizes and PODs only.  Every function returns 0 on
+ * success or a negative GSR_E_* code and never throws; gsr_last_error() gives
+ * the text.  A context is bound to one GPU and is NOT thread-safe (the
+ * reference runs everything on Houdini's single draw thread).
+ *
+ * Reference interfaces replaced (paths relative to /root/reference/gsplat_plugin):
+ *   gsr_upload*        <- GSplatRenderer::generateRenderGeometry  src/GSplatRenderer.C:420-532
+ *                         (TBB pack into 1 RGBA32F + 2 RGB16F textures, setTexture x3)
+ *   gsr_render         <- GSplatRenderer::render                  src/GSplatRenderer.C:534-658
+ *                         = argsortByDistance :176-216 (CPU, TBB) + index-texture upload :586-592
+ *                         + GL state/uniforms :605-645 + drawInstanced :647, which runs
+ *                         shaders/GSplatShaderSource.h:190-288 (VS), :304-312 (FS)
+ *                         and the fixed-function blend :613-621
+ *   gsr_camera         <- the uniform block of the main program   shaders/GSplatShaderSource.h:119-133,153-159
+ */
+#ifndef GSPLAT_HIP_H
+#define GSPLAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_OK                0
+#define GSR_E_INVALID        -1   /* bad argument */
+#define GSR_E_HIP            -2   /* a HIP runtime call failed */
+#define GSR_E_NO_DEVICE      -3   /* no gfx950 device / device ordinal out of range */
+#define GSR_E_NO_GEOMETRY    -4   /* render before any upload */
+#define GSR_E_TOO_MANY_PAIRS -5   /* (tile, splat) pair count exceeds GSR_MAX_PAIRS */
+#define GSR_E_OOM            -6
+
+#define GSR_TILE              16          /* tile edge in pixels */
+#define GSR_MAX_DIM           4096        /* max framebuffer width/height */
+#define GSR_MAX_PAIRS         0x7fffff00ll
+
+typedef struct gsr_context gsr_context;
+
+/* Per-frame uniforms.  Field names = the GLSL uniforms of the reference's main
+ * program.  Matrices: 16 floats, GL column-major (m[c*4+r]); this is the byte
+ * layout of Houdini's UT_Matrix4F::data(), so HDK glue passes them through. */
+typedef struct gsr_camera {
+    float obj_view[16];    /* glH_ObjViewMatrix    */
+    float object[16];      /* glH_ObjectMatrix     */
+    float inv_object[16];  /* glH_InvObjectMatrix  */
+    float view[16];        /* glH_ViewMatrix       */
+    float proj[16];        /* glH_ProjectMatrix    */
+    float cam_pos[3];      /* WorldSpaceCameraPos: sort reference point and SH eye
+                              (src/GSplatRenderer.C:551-563) */
+    int32_t width;         /* glH_ScreenSize.x  (<= GSR_MAX_DIM) */
+    int32_t height;        /* glH_ScreenSize.y  (<= GSR_MAX_DIM) */
+    int32_t sh_order;      /* GSplatShOrder 0..3; forced to 0 when no SH was uploaded
+                              (doSH gate, src/GSplatRenderer.C:623,628) */
+} gsr_camera;
+
+/* Counters and timings of the most recent gsr_render plus running totals
+ * (totals feed bench.py's roofline: blend_ms_total / blend_launches). */
+typedef struct gsr_stats {
+    int64_t n_splats;          /* uploaded */
+    int64_t n_visible;         /* survived w/z culling and have >=1 tile */
+    int64_t pairs_total;       /* D: (tile, splat) pairs emitted */
+    int64_t pairs_consumed;    /* D_eff: pairs fetched by the blend kernel before early-out */
+    int32_t tiles_x, tiles_y;  /* tile grid of this context's shard */
+    int32_t record_bytes;      /* bytes of one projected record as read by the blend kernel */
+    int32_t pair_bytes;        /* bytes of one sorted pair payload as read by the blend kernel */
+    float ms_preprocess, ms_depth_sort, ms_emit, ms_tile_sort, ms_blend, ms_total; /* last frame, HIP events */
+    double blend_ms_total;     /* sum over all frames since gsr_stats_reset */
+    int64_t blend_launches;
+    int64_t blend_pairs_consumed_total;
+    double frame_ms_total;
+    int64_t frames;
+} gsr_stats;
+
+/* ---- lifetime ----------------------------------------------------------- */
+int  gsr_device_count(void);                              /* 0 if no GPU is visible */
+int  gsr_create(int device, gsr_context** out);           /* owns a HIP stream on `device` */
+void gsr_destroy(gsr_context* ctx);
+const char* gsr_last_error(void);                         /* thread-local, never NULL */
+const char* gsr_version(void);
+
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of
+ * the context's own; NULL restores the context stream. */
+int  gsr_set_stream(gsr_context* ctx, void* hip_stream);
+
+/* ---- geometry staging (active set changed) ------------------------------ */
+/* Arrays are HOST pointers in the reference's registerUpdate() layout
+ * (include/GSplatRenderer.h:34-47): P float[3n]; Cd half[3n]; alpha float[n];
+ * scale half[3n]; orient half[4n] (x,y,z,w); shx/shy/shz half[16n] (row-major
+ * 4x4 per splat, coefficient j at (j/4, j%4)) or all three NULL.  halves are raw
+ * binary16 bits.  Data is copied; the caller may free on return.
+ * begin/append/end lets the shim concatenate several registry entries without a
+ * host-side merge (src/GSplatRenderer.C:420-513). origin = GSplatOrigin. */
+int  gsr_upload_begin(gsr_context* ctx, int64_t total_splats, int has_sh, const float origin[3]);
+int  gsr_upload_append(gsr_context* ctx, int64_t n,
+                       const float* P, const uint16_t* Cd, const float* alpha,
+                       const uint16_t* scale, const uint16_t* orient,
+                       const uint16_t* shx, const uint16_t* shy, const uint16_t* shz);
+int  gsr_upload_end(gsr_context* ctx);
+/* begin + append + end for a single entry */
+int  gsr_upload(gsr_context* ctx, int64_t n,
+                const float* P, const uint16_t* Cd, const float* alpha,
+                const uint16_t* scale, const uint16_t* orient,
+                const uint16_t* shx, const uint16_t* shy, const uint16_t* shz,
+                const float origin[3]);
+
+/* ---- multi-GPU: tile-row shard ------------------------------------------ */
+/* This context renders only tile rows r with r % count == index (interleaved
+ * for load balance).  Its output is the compact band image: the owned tile rows
+ * stacked bottom-up, gsr_band_rows() pixel rows of `width` RGBA-f32 pixels. */
+int  gsr_set_row_shard(gsr_context* ctx, int index, int count);
+int  gsr_band_rows(int height, int index, int count);      /* pixel rows in that band image */
+/* Root side: bands[count] gathered back to back (each padded to
+ * gsr_band_rows(height, 0, count) rows) -> full image.  Device pointers. */
+int  gsr_stitch_bands(gsr_context* ctx, const float* gathered, int count,
+                      int width, int height, float* rgba_out);
+
+/* ---- per frame ---------------------------------------------------------- */
+/* Renders the uploaded splats.  rgba_out: float[rows*width*4], premultiplied
+ * RGBA, row 0 = BOTTOM row (GL window coordinates), cleared to 0 -- what the
+ * reference's blend leaves in an initially transparent float target.  rows =
+ * height, or gsr_band_rows() when sharded.  out_is_device: 0 = host pointer
+ * (synchronous), 1 = device pointer (asynchronous on the context stream after
+ * the internal pair-count readback). */
+int  gsr_render(gsr_context* ctx, const gsr_camera* cam, float* rgba_out, int out_is_device);
+
+int  gsr_synchronize(gsr_context* ctx);
+int  gsr_get_stats(gsr_context* ctx, gsr_stats* out);     /* synchronizes the stream */
+int  gsr_stats_reset(gsr_context* ctx);
+
+/* ---- knobs (performance only; never change pixels) ---------------------- */
+#define GSR_OPT_XCD_SWIZZLE     1   /* 0/1: XCD-aware tile -> workgroup mapping in the blend kernel */
+#define GSR_OPT_STAGE_TIMING    2   /* 0/1: record per-stage HIP events (default 1) */
+#define GSR_OPT_SORT_CACHE      3   /* 0/1: skip the depth sort when cam_pos and geometry are unchanged
+                                       (argsortByDistance's caching, src/GSplatRenderer.C:179-186) */
+int  gsr_set_option(gsr_context* ctx, int option, int value);
+
+/* ---- debug / test access (device -> host copies of intermediates) -------- */
+/* One projected record as tests read it back (not the packed device layout). */
+typedef struct gsr_debug_record {
+    float cx, cy, ex, ey, is1, is2, hx, hy, r, g, b, opacity;
+    float key;
+    int32_t visible;   /* 0 = culled */
+} gsr_debug_record;
+int  gsr_debug_read_records(gsr_context* ctx, gsr_debug_record* out, int64_t n);
+int  gsr_debug_read_depth_order(gsr_context* ctx, int32_t* perm, int64_t n);
+/* per-tile [start,end) into the sorted pair list + the list itself (splat indices) */
+int  gsr_debug_read_tile_lists(gsr_context* ctx, int32_t* tile_start, int32_t* tile_end, int64_t n_tiles,
+                               int32_t* pair_splat, int64_t n_pairs);
+
+/* Stand-alone device radix sort of (key,value) u32 pairs on bits [0, key_bits):
+ * the sort the pipeline uses, exposed for parity tests (host pointers). */
+int  gsr_debug_sort_pairs(gsr_context* ctx, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,558 @@
+/*
+ * gsplat_oracle.c -- CPU ORACLE (test infrastructure; see gsplat_oracle.h).
+ *
+ * Plain C restatement of the reference's per-frame render path.  Every block
+ * cites the reference lines it follows (paths relative to
+ * /root/reference/gsplat_plugin).  Build: see oracle/Makefile
+ * (-O2 -ffp-contract=off -mfma: only explicit fmaf() fuses).
+ */
+#include "gsplat_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define M4(m, r, c) ((m)[(c) * 4 + (r)])
+
+/* ------------------------------------------------------------------------- */
+/* binary16 <-> binary32.  The reference quantises Cd/scale/orient/SH through
+ * HDK fpreal16 constructors (src/GR_GSplat.C:315-318,345-367), i.e. IEEE
+ * round-to-nearest-even with overflow to infinity.                          */
+
+float gso_half_to_float(uint16_t h)
+{
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu;
+    uint32_t man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else { /* subnormal half -> normal float */
+            int e = -1;
+            do { man <<= 1; ++e; } while (!(man & 0x400u));
+            man &= 0x3ffu;
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+uint16_t gso_float_to_half(float f)
+{
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) /* inf / nan */
+        return (uint16_t)(sign | 0x7c00u | ((ax > 0x7f800000u) ? 0x200u : 0u));
+    if (ax >= 0x477ff000u) /* >= 65520 rounds to inf */
+        return (uint16_t)(sign | 0x7c00u);
+    if (ax < 0x33000001u) /* <= 2^-25 rounds to zero (tie at 2^-25 -> even = 0) */
+        return (uint16_t)sign;
+    int e = (int)(ax >> 23) - 127;
+    uint32_t man = (ax & 0x7fffffu) | 0x800000u; /* 24-bit significand */
+    int shift;                                   /* bits to drop */
+    uint32_t hexp;
+    if (e < -14) { /* subnormal half */
+        shift = 13 + (-14 - e);
+        hexp = 0;
+    } else {
+        shift = 13;
+        hexp = (uint32_t)(e + 15);
+    }
+    uint32_t kept = man >> shift;
+    uint32_t rem = man & ((1u << shift) - 1u);
+    uint32_t half_ulp = 1u << (shift - 1);
+    if (rem > half_ulp || (rem == half_ulp && (kept & 1u)))
+        ++kept;
+    uint32_t out;
+    if (hexp == 0)
+        out = kept; /* may carry into exponent 1: correct */
+    else
+        out = ((hexp - 1) << 10) + kept; /* kept has the implicit bit at 0x400 */
+    return (uint16_t)(sign | out);
+}
+
+/* ------------------------------------------------------------------------- */
+/* The contract's exp().  GLSL exp() (shaders/GSplatShaderSource.h:307) has
+ * no bit-level definition; the contract fixes one so that every threshold
+ * decision (alpha < 1/255) is reproducible.  Classic range reduction
+ * x = k*ln2 + r, |r| <= ln2/2, degree-5 polynomial for (exp(r)-1-r)/r^2
+ * (coefficients: the widely published single-precision minimax set),
+ * ~1 ulp.  Valid for -80 <= x <= 0 (the path only needs [-8, 0]).          */
+float gso_expf(float x)
+{
+    float kf = rintf(x * 1.44269504088896341f);
+    float r = fmaf(kf, -0.693359375f, x);
+    r = fmaf(kf, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = fmaf(p, r2, r) + 1.0f;
+    /* y * 2^k by exponent-field add; y in [0.70, 1.42], k in [-116, 0] */
+    int32_t k = (int32_t)kf;
+    uint32_t bits;
+    memcpy(&bits, &y, 4);
+    bits += (uint32_t)k << 23;
+    memcpy(&y, &bits, 4);
+    return y;
+}
+
+/* src/GSplatRenderer.C:155-163 (texture side length); kept as a KAT target */
+unsigned gso_closest_sqrt_power_of_2(int n)
+{
+    if (n <= 1) return 2;
+    float s = sqrtf((float)n);
+    unsigned p = (unsigned)ceilf(log2f(s));
+    return 1u << p;
+}
+
+/* ------------------------------------------------------------------------- */
+/* affine 4x3 row: m(r,0)*x + m(r,1)*y + m(r,2)*z + m(r,3) as an fmaf chain   */
+static inline float aff(const float* m, int r, float x, float y, float z)
+{
+    return fmaf(M4(m, r, 0), x, fmaf(M4(m, r, 1), y, fmaf(M4(m, r, 2), z, M4(m, r, 3))));
+}
+/* linear 3x3 row */
+static inline float lin(const float* m, int r, float x, float y, float z)
+{
+    return fmaf(M4(m, r, 0), x, fmaf(M4(m, r, 1), y, M4(m, r, 2) * z));
+}
+
+/* SH constants: shaders/GSplatShaderCoreLib.h:103-115 */
+static const float SH_C1 = 0.4886025f;
+static const float SH_C2_0 = 1.0925484f, SH_C2_1 = -1.0925484f, SH_C2_2 = 0.3153916f,
+                   SH_C2_3 = -1.0925484f, SH_C2_4 = 0.5462742f;
+static const float SH_C3_0 = -0.5900436f, SH_C3_1 = 2.8906114f, SH_C3_2 = -0.4570458f,
+                   SH_C3_3 = 0.3731763f, SH_C3_4 = -0.4570458f, SH_C3_5 = 1.4453057f,
+                   SH_C3_6 = -0.5900436f;
+
+/* ShadeSH for one colour channel (shaders/GSplatShaderCoreLib.h:117-179).
+ * sh[j] = coefficient sh(j+1) of this channel.  Expressions are evaluated
+ * left to right exactly as written there, without fusing.                   */
+static float shade_sh_channel(float base, const float* sh, float x, float y, float z, int order)
+{
+    float res = base;
+    if (order >= 1) {
+        res += SH_C1 * (-sh[0] * y + sh[1] * z - sh[2] * x);
+        if (order >= 2) {
+            float xx = x * x, yy = y * y, zz = z * z;
+            float xy = x * y, yz = y * z, xz = x * z;
+            res += (SH_C2_0 * xy) * sh[3] + (SH_C2_1 * yz) * sh[4] +
+                   (SH_C2_2 * (2.0f * zz - xx - yy)) * sh[5] + (SH_C2_3 * xz) * sh[6] +
+                   (SH_C2_4 * (xx - yy)) * sh[7];
+            if (order >= 3) {
+                res += (SH_C3_0 * y * (3.0f * xx - yy)) * sh[8] + (SH_C3_1 * xy * z) * sh[9] +
+                       (SH_C3_2 * y * (4.0f * zz - xx - yy)) * sh[10] +
+                       (SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * sh[11] +
+                       (SH_C3_4 * x * (4.0f * zz - xx - yy)) * sh[12] +
+                       (SH_C3_5 * z * (xx - yy)) * sh[13] + (SH_C3_6 * x * (xx - 3.0f * yy)) * sh[14];
+            }
+        }
+    }
+    return fmaxf(res, 0.0f); /* max(res, vec3(0)) :178 */
+}
+
+/* Vertex stage for one splat.  Mirrors main() of the main vertex shader
+ * (shaders/GSplatShaderSource.h:190-288) evaluated once per splat instead of
+ * once per quad corner; the corner placement (:276-282) becomes the analytic
+ * quad {c + qx*s1*e + qy*s2*e_perp, |qx|,|qy| <= 2} in GL window coordinates. */
+static void project_splat(const gso_splats* s, const gso_frame* f, int64_t i, gso_record* o)
+{
+    memset(o, 0, sizeof(*o));
+    const float W = (float)f->width, H = (float)f->height;
+
+    const float px = s->P[3 * i + 0], py = s->P[3 * i + 1], pz = s->P[3 * i + 2];
+
+    /* sort key: squared distance of the UN-offset point to the camera
+     * (src/GSplatRenderer.C:197-201, mySplatPoints :454) */
+    {
+        float dx = px - f->cam_pos[0], dy = py - f->cam_pos[1], dz = pz - f->cam_pos[2];
+        o->key = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    }
+
+    /* texel 0 holds fl32(P - origin) (src/GSplatRenderer.C:459-461); the
+     * shader adds the origin back (shader :201-202) */
+    const float x = (px - f->origin[0]) + f->origin[0];
+    const float y = (py - f->origin[1]) + f->origin[1];
+    const float z = (pz - f->origin[2]) + f->origin[2];
+
+    /* centerViewPos / centerClipPos with the flip-Y sandwich (:204-207) */
+    const float tvx = aff(f->obj_view, 0, x, y, z);
+    const float tvy = aff(f->obj_view, 1, x, y, z);
+    const float tvz = aff(f->obj_view, 2, x, y, z);
+    const float ftvy = -tvy;
+    const float clx = aff(f->proj, 0, tvx, ftvy, tvz);
+    const float cly = aff(f->proj, 1, tvx, ftvy, tvz);
+    const float clz = aff(f->proj, 2, tvx, ftvy, tvz);
+    const float clw = aff(f->proj, 3, tvx, ftvy, tvz);
+
+    if (!(clw > 0.0f)) return; /* :209-214 behind camera */
+    /* all four corners share the centre's z,w (:277-279): GL near/far clip
+     * drops the whole quad iff z is outside [-w, w] */
+    if (clz < -clw || clz > clw) return;
+
+    /* out_vertex.y = -out_vertex.y (:281) undoes the flip for the centre */
+    const float ndcx = clx / clw;
+    const float ndcy = (-cly) / clw;
+    o->cx = fmaf(ndcx, 0.5f, 0.5f) * W;
+    o->cy = fmaf(ndcy, 0.5f, 0.5f) * H;
+
+    /* attributes (:217-222); fp16 values are exact in fp32 */
+    const float sx = gso_half_to_float(s->scale[3 * i + 0]);
+    const float sy = gso_half_to_float(s->scale[3 * i + 1]);
+    const float sz = gso_half_to_float(s->scale[3 * i + 2]);
+    /* orient.wxyz -> rot (:230): rot.x = w (real), rot.yzw = xyz */
+    const float qi = gso_half_to_float(s->orient[4 * i + 0]);
+    const float qj = gso_half_to_float(s->orient[4 * i + 1]);
+    const float qk = gso_half_to_float(s->orient[4 * i + 2]);
+    const float qr = gso_half_to_float(s->orient[4 * i + 3]);
+
+    /* CalcMatrixFromRotationScale (CoreLib :10-27): ms*mr with mr's COLUMNS
+     * being the rows of the standard rotation matrix R(q); no normalisation */
+    float R[3][3];
+    R[0][0] = 1.0f - 2.0f * fmaf(qj, qj, qk * qk);
+    R[0][1] = 2.0f * fmaf(qi, qj, -(qr * qk));
+    R[0][2] = 2.0f * fmaf(qi, qk, qr * qj);
+    R[1][0] = 2.0f * fmaf(qi, qj, qr * qk);
+    R[1][1] = 1.0f - 2.0f * fmaf(qi, qi, qk * qk);
+    R[1][2] = 2.0f * fmaf(qj, qk, -(qr * qi));
+    R[2][0] = 2.0f * fmaf(qi, qk, -(qr * qj));
+    R[2][1] = 2.0f * fmaf(qj, qk, qr * qi);
+    R[2][2] = 1.0f - 2.0f * fmaf(qi, qi, qj * qj);
+    /* M = diag(s) * R^T ; then * transpose(mat3(glH_ObjectMatrix)) (:231) */
+    const float sc[3] = {sx, sy, sz};
+    float M0[3][3], Mm[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) M0[a][b] = sc[a] * R[b][a];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            Mm[a][b] = fmaf(M0[a][2], M4(f->object, b, 2),
+                            fmaf(M0[a][1], M4(f->object, b, 1), M0[a][0] * M4(f->object, b, 0)));
+    /* CalcCovariance3D (CoreLib :29-35): sigma = transpose(M) * M */
+    float S[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = a; b < 3; ++b) {
+            float v = fmaf(Mm[2][a], Mm[2][b], fmaf(Mm[1][a], Mm[1][b], Mm[0][a] * Mm[0][b]));
+            S[a][b] = v;
+            S[b][a] = v;
+        }
+
+    /* CalcCovariance2D (CoreLib :38-76).  Note the VIEW matrix (no object
+     * matrix) is used here (shader :240). */
+    float tx = aff(f->view, 0, x, y, z);
+    float ty = aff(f->view, 1, x, y, z);
+    const float tz = aff(f->view, 2, x, y, z);
+    {
+        const float p00 = M4(f->proj, 0, 0), p11 = M4(f->proj, 1, 1);
+        const float aspect = p00 / p11;
+        const float tanFovX = 1.0f / p00;
+        const float tanFovY = 1.0f / (p11 * aspect); /* == tanFovX up to rounding */
+        const float limX = 1.3f * tanFovX, limY = 1.3f * tanFovY;
+        float rx = tx / tz, ry = ty / tz;
+        rx = fminf(fmaxf(rx, -limX), limX);
+        ry = fminf(fmaxf(ry, -limY), limY);
+        tx = rx * tz;
+        ty = ry * tz;
+    }
+    const float focal = (W * M4(f->proj, 0, 0)) * 0.5f;
+    const float j00 = focal / tz;
+    const float tz2 = tz * tz;
+    const float j02 = -(focal * tx) / tz2;
+    const float j12 = -(focal * ty) / tz2;
+    /* rows of A = J * mat3(view) (2x3); cov = A * sigma * A^T */
+    float A0[3], A1[3];
+    for (int c = 0; c < 3; ++c) {
+        A0[c] = fmaf(j00, M4(f->view, 0, c), j02 * M4(f->view, 2, c));
+        A1[c] = fmaf(j00, M4(f->view, 1, c), j12 * M4(f->view, 2, c));
+    }
+    float u0[3], u1[3];
+    for (int k = 0; k < 3; ++k) {
+        u0[k] = fmaf(S[k][2], A0[2], fmaf(S[k][1], A0[1], S[k][0] * A0[0]));
+        u1[k] = fmaf(S[k][2], A1[2], fmaf(S[k][1], A1[1], S[k][0] * A1[0]));
+    }
+    const float cov00 = fmaf(A0[2], u0[2], fmaf(A0[1], u0[1], A0[0] * u0[0]));
+    const float cov01 = fmaf(A0[2], u1[2], fmaf(A0[1], u1[1], A0[0] * u1[0]));
+    const float cov11 = fmaf(A1[2], u1[2], fmaf(A1[1], u1[1], A1[0] * u1[0]));
+    const float ca = cov00 + 0.3f; /* low-pass :72-74 */
+    const float cb = cov01;
+    const float cc = cov11 + 0.3f;
+
+    /* DecomposeCovariance (CoreLib :79-93) */
+    const float mid = 0.5f * (ca + cc);
+    const float hd = (ca - cc) * 0.5f;
+    const float radius = sqrtf(fmaf(hd, hd, cb * cb));
+    const float lambda1 = mid + radius;
+    const float lambda2 = fmaxf(mid - radius, 0.1f);
+    const float dvx = cb, dvy = lambda1 - ca;
+    const float dlen = sqrtf(fmaf(dvx, dvx, dvy * dvy));
+    float ex, ey;
+    if (dlen > 0.0f) {
+        ex = dvx / dlen;
+        ey = dvy / dlen;
+    } else { /* normalize(vec2(0)) is undefined in GLSL: choose the
+                mathematically right eigenvector of a diagonal matrix with a>=c */
+        ex = 1.0f;
+        ey = 0.0f;
+    }
+    /* The shader negates diagVec.y (:89) and later out_vertex.y (:281); the
+     * two flips cancel in GL window coordinates, leaving axes s1*e, s2*e_perp. */
+    const float s1 = fminf(sqrtf(2.0f * lambda1), 4096.0f);
+    const float s2 = fminf(sqrtf(2.0f * lambda2), 4096.0f);
+    o->ex = ex;
+    o->ey = ey;
+    o->is1 = 1.0f / s1;
+    o->is2 = 1.0f / s2;
+    /* conservative bbox of the +-2 quad (padding covers rounding in q) */
+    o->hx = fmaf(2.0f * fmaf(s1, fabsf(ex), s2 * fabsf(ey)), 1.0001f, 0.01f);
+    o->hy = fmaf(2.0f * fmaf(s1, fabsf(ey), s2 * fabsf(ex)), 1.0001f, 0.01f);
+
+    /* colour (:224, :244-274) */
+    float cr = gso_half_to_float(s->Cd[3 * i + 0]);
+    float cg = gso_half_to_float(s->Cd[3 * i + 1]);
+    float cbl = gso_half_to_float(s->Cd[3 * i + 2]);
+    if (f->sh_order > 0 && s->shx) {
+        float shr[15], shg[15], shb[15];
+        for (int j = 0; j < 15; ++j) { /* coefficient j at (j/4, j%4) of the 4x4 (GR_GSplat.C:345-353) */
+            shr[j] = gso_half_to_float(s->shx[16 * i + j]);
+            shg[j] = gso_half_to_float(s->shy[16 * i + j]);
+            shb[j] = gso_half_to_float(s->shz[16 * i + j]);
+        }
+        const float wx = x - f->cam_pos[0], wy = y - f->cam_pos[1], wz = z - f->cam_pos[2];
+        const float ox = lin(f->inv_object, 0, wx, wy, wz);
+        const float oy = lin(f->inv_object, 1, wx, wy, wz);
+        const float oz = lin(f->inv_object, 2, wx, wy, wz);
+        const float len = sqrtf(fmaf(oz, oz, fmaf(oy, oy, ox * ox)));
+        const float dx = ox / len, dy = oy / len, dz = oz / len;
+        cr = shade_sh_channel(cr, shr, dx, dy, dz, f->sh_order);
+        cg = shade_sh_channel(cg, shg, dx, dy, dz, f->sh_order);
+        cbl = shade_sh_channel(cbl, shb, dx, dy, dz, f->sh_order);
+    }
+    o->r = cr;
+    o->g = cg;
+    o->b = cbl;
+    o->opacity = s->alpha[i];
+    o->visible = 1;
+}
+
+int gso_preprocess(const gso_splats* s, const gso_frame* f, gso_record* rec)
+{
+    if (!s || !f || !rec) return -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < s->n; ++i) project_splat(s, f, i, &rec[i]);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* stable LSD radix argsort on the IEEE bits of non-negative float keys.
+ * The reference uses an unstable tbb::parallel_sort (src/GSplatRenderer.C:206)
+ * whose tie order is unspecified; the contract fixes (key, index).          */
+static int argsort_keys(const float* keys, int64_t n, int32_t* perm)
+{
+    uint32_t* k0 = (uint32_t*)malloc((size_t)n * 4 + 4);
+    uint32_t* k1 = (uint32_t*)malloc((size_t)n * 4 + 4);
+    int32_t* p1 = (int32_t*)malloc((size_t)n * 4 + 4);
+    if (!k0 || !k1 || !p1) { free(k0); free(k1); free(p1); return -2; }
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t b;
+        memcpy(&b, &keys[i], 4);
+        /* keys are sums of squares: >= +0 or NaN; map to an order-preserving
+         * uint (general form, handles -0 too) */
+        b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+        k0[i] = b;
+        perm[i] = (int32_t)i;
+    }
+    uint32_t* ks = k0; uint32_t* kd = k1;
+    int32_t* ps = perm; int32_t* pd = p1;
+    for (int pass = 0; pass < 4; ++pass) {
+        int64_t cnt[257];
+        memset(cnt, 0, sizeof(cnt));
+        const int sh = pass * 8;
+        for (int64_t i = 0; i < n; ++i) ++cnt[((ks[i] >> sh) & 255u) + 1];
+        for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t dst = cnt[(ks[i] >> sh) & 255u]++;
+            kd[dst] = ks[i];
+            pd[dst] = ps[i];
+        }
+        uint32_t* tk = ks; ks = kd; kd = tk;
+        int32_t* tp = ps; ps = pd; pd = tp;
+    }
+    /* 4 passes: result is back in (k0, perm) */
+    free(k0); free(k1); free(p1);
+    return 0;
+}
+
+int gso_argsort(const gso_record* rec, int64_t n, int32_t* perm)
+{
+    float* keys = (float*)malloc((size_t)n * 4 + 4);
+    if (!keys) return -2;
+    for (int64_t i = 0; i < n; ++i) keys[i] = rec[i].key;
+    int rc = argsort_keys(keys, n, perm);
+    free(keys);
+    return rc;
+}
+
+int gso_host_sort_only(const float* P, int64_t n, const float cam_pos[3], int32_t* perm)
+{
+    float* keys = (float*)malloc((size_t)n * 4 + 4);
+    if (!keys) return -2;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        float dx = P[3 * i] - cam_pos[0], dy = P[3 * i + 1] - cam_pos[1], dz = P[3 * i + 2] - cam_pos[2];
+        keys[i] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    }
+    int rc = argsort_keys(keys, n, perm);
+    free(keys);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Fragment shader + blend for one splat over pixel rows [row_lo, row_hi].
+ * FS: shaders/GSplatShaderSource.h:304-312.  Blend: src factor
+ * ONE_MINUS_DST_ALPHA, dst factor ONE, equation ADD, for colour and alpha
+ * (src/GSplatRenderer.C:613-621).                                           */
+static void splat_rows(const gso_record* o, int width, int height, int row_lo, int row_hi, float* rgba)
+{
+    (void)height;
+    const float xlo = o->cx - o->hx - 0.5f, xhi = o->cx + o->hx - 0.5f;
+    const float ylo = o->cy - o->hy - 0.5f, yhi = o->cy + o->hy - 0.5f;
+    if (!(xhi >= 0.0f && xlo <= (float)(width - 1))) return;
+    if (!(yhi >= (float)row_lo && ylo <= (float)row_hi)) return;
+    const int i0 = (int)ceilf(fmaxf(xlo, 0.0f));
+    const int i1 = (int)floorf(fminf(xhi, (float)(width - 1)));
+    const int j0 = (int)ceilf(fmaxf(ylo, (float)row_lo));
+    const int j1 = (int)floorf(fminf(yhi, (float)row_hi));
+    const float inv255 = 1.0f / 255.0f;
+    for (int j = j0; j <= j1; ++j) {
+        const float dy = ((float)j + 0.5f) - o->cy;
+        float* row = rgba + (size_t)j * (size_t)width * 4;
+        for (int i = i0; i <= i1; ++i) {
+            const float dx = ((float)i + 0.5f) - o->cx;
+            /* fsIn.pos: the quad-local coordinate in [-2,2]^2 */
+            const float u = fmaf(dx, o->ex, dy * o->ey);
+            const float v = fmaf(dy, o->ex, -(dx * o->ey));
+            const float qx = u * o->is1;
+            const float qy = v * o->is2;
+            if (!(fabsf(qx) <= 2.0f && fabsf(qy) <= 2.0f)) continue; /* outside the quad */
+            const float power = -fmaf(qx, qx, qy * qy);
+            float alpha = gso_expf(power) * o->opacity;
+            alpha = fminf(fmaxf(alpha, 0.0f), 1.0f);
+            if (alpha < inv255) continue; /* discard */
+            float* px = row + (size_t)i * 4;
+            const float t = 1.0f - px[3];
+            px[0] = fmaf(t, o->r * alpha, px[0]);
+            px[1] = fmaf(t, o->g * alpha, px[1]);
+            px[2] = fmaf(t, o->b * alpha, px[2]);
+            px[3] = fmaf(t, alpha, px[3]);
+        }
+    }
+}
+
+int gso_blend_serial(const gso_record* rec, const int32_t* perm, int64_t n, int width, int height, float* rgba)
+{
+    if (!rec || !perm || !rgba || width <= 0 || height <= 0) return -1;
+    memset(rgba, 0, (size_t)width * (size_t)height * 16);
+    for (int64_t r = 0; r < n; ++r) { /* instance order = sorted order, nearest first */
+        const gso_record* o = &rec[perm[r]];
+        if (!o->visible) continue;
+        splat_rows(o, width, height, 0, height - 1, rgba);
+    }
+    return 0;
+}
+
+#define GSO_STRIP 8 /* rows per strip for the parallel renderer */
+
+int gso_blend_parallel(const gso_record* rec, const int32_t* perm, int64_t n, int width, int height,
+                       float* rgba, int threads)
+{
+    if (!rec || !perm || !rgba || width <= 0 || height <= 0) return -1;
+    memset(rgba, 0, (size_t)width * (size_t)height * 16);
+    const int nstrips = (height + GSO_STRIP - 1) / GSO_STRIP;
+    /* bin splat ranks to strips, in rank order (two passes) */
+    int64_t* start = (int64_t*)calloc((size_t)nstrips + 1, sizeof(int64_t));
+    if (!start) return -2;
+    int32_t* slo = (int32_t*)malloc((size_t)n * 4 + 4);
+    int32_t* shi = (int32_t*)malloc((size_t)n * 4 + 4);
+    if (!slo || !shi) { free(start); free(slo); free(shi); return -2; }
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r) {
+        const gso_record* o = &rec[perm[r]];
+        slo[r] = 1; shi[r] = 0;
+        if (!o->visible) continue;
+        const float ylo = o->cy - o->hy - 0.5f, yhi = o->cy + o->hy - 0.5f;
+        const float xlo = o->cx - o->hx - 0.5f, xhi = o->cx + o->hx - 0.5f;
+        if (!(yhi >= 0.0f && ylo <= (float)(height - 1))) continue;
+        if (!(xhi >= 0.0f && xlo <= (float)(width - 1))) continue;
+        const int j0 = (int)ceilf(fmaxf(ylo, 0.0f));
+        const int j1 = (int)floorf(fminf(yhi, (float)(height - 1)));
+        if (j1 < j0) continue;
+        slo[r] = j0 / GSO_STRIP;
+        shi[r] = j1 / GSO_STRIP;
+    }
+    for (int64_t r = 0; r < n; ++r)
+        for (int s = slo[r]; s <= shi[r]; ++s) ++start[s + 1];
+    for (int s = 0; s < nstrips; ++s) start[s + 1] += start[s];
+    int32_t* list = (int32_t*)malloc((size_t)start[nstrips] * 4 + 4);
+    int64_t* cur = (int64_t*)malloc(((size_t)nstrips + 1) * sizeof(int64_t));
+    if (!list || !cur) { free(start); free(slo); free(shi); free(list); free(cur); return -2; }
+    memcpy(cur, start, ((size_t)nstrips + 1) * sizeof(int64_t));
+    for (int64_t r = 0; r < n; ++r)
+        for (int s = slo[r]; s <= shi[r]; ++s) list[cur[s]++] = perm[r];
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int s = 0; s < nstrips; ++s) {
+        const int row_lo = s * GSO_STRIP;
+        const int row_hi = (row_lo + GSO_STRIP - 1 < height - 1) ? row_lo + GSO_STRIP - 1 : height - 1;
+        for (int64_t k = start[s]; k < start[s + 1]; ++k)
+            splat_rows(&rec[list[k]], width, height, row_lo, row_hi, rgba);
+    }
+    free(start); free(slo); free(shi); free(list); free(cur);
+    return 0;
+}
+
+int gso_render(const gso_splats* s, const gso_frame* f, float* rgba, int threads)
+{
+    if (!s || !f || !rgba) return -1;
+    gso_record* rec = (gso_record*)malloc((size_t)(s->n + 1) * sizeof(gso_record));
+    int32_t* perm = (int32_t*)malloc((size_t)(s->n + 1) * 4);
+    if (!rec || !perm) { free(rec); free(perm); return -2; }
+    int rc = gso_preprocess(s, f, rec);
+    if (!rc) rc = gso_argsort(rec, s->n, perm);
+    if (!rc) {
+        if (threads > 1)
+            rc = gso_blend_parallel(rec, perm, s->n, f->width, f->height, rgba, threads);
+        else
+            rc = gso_blend_serial(rec, perm, s->n, f->width, f->height, rgba);
+    }
+    free(rec);
+    free(perm);
+    return rc;
+}
+
+int gso_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -81,6 +81,7 @@ struct gsr_context {
     size_t pair_cap = 0;
     uint32_t* sorted_pvals = nullptr;  // which of pvA/pvB holds the tile-sorted list of the last frame
     int32_t *tstart = nullptr, *tend = nullptr;
+    uint32_t* tile_loaded = nullptr;
     size_t tile_cap = 0;
     float* fb = nullptr;
     size_t fb_cap = 0;
@@ -189,7 +190,7 @@ extern "C" void gsr_destroy(gsr_context* c)
     free_geometry(c);
     dev_free(c->hist); dev_free(c->partial);
     dev_free(c->pkA); dev_free(c->pkB); dev_free(c->pvA); dev_free(c->pvB);
-    dev_free(c->tstart); dev_free(c->tend); dev_free(c->fb);
+    dev_free(c->tstart); dev_free(c->tend); dev_free(c->tile_loaded); dev_free(c->fb);
     dev_free(c->counters); dev_free(c->d_total);
     if (c->h_total) (void)hipHostFree(c->h_total);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -492,10 +493,11 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
 
     // per-tile range arrays
     if ((size_t)local_tiles + 1 > c->tile_cap) {
-        dev_free(c->tstart); dev_free(c->tend);
+        dev_free(c->tstart); dev_free(c->tend); dev_free(c->tile_loaded);
         c->tile_cap = 0;
         int rc;
-        if ((rc = dev_alloc(&c->tstart, (size_t)local_tiles + 1)) || (rc = dev_alloc(&c->tend, (size_t)local_tiles + 1))) return rc;
+        if ((rc = dev_alloc(&c->tstart, (size_t)local_tiles + 1)) || (rc = dev_alloc(&c->tend, (size_t)local_tiles + 1)) ||
+            (rc = dev_alloc(&c->tile_loaded, (size_t)local_tiles + 1))) return rc;
         c->tile_cap = (size_t)local_tiles + 1;
     }
     float* target = rgba_out;
@@ -511,15 +513,14 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
     }
 
     MARK(0);
-    HIP_TRY(hipMemsetAsync(c->counters, 0, 2 * sizeof(unsigned long long), s));  // [2] is a running total
-    const bool cache_hit = c->opt_sort_cache && c->sort_valid && c->sort_gen == c->geo_gen &&
+        const bool cache_hit = c->opt_sort_cache && c->sort_valid && c->sort_gen == c->geo_gen &&
                            c->sort_cam[0] == cam->cam_pos[0] && c->sort_cam[1] == cam->cam_pos[1] &&
                            c->sort_cam[2] == cam->cam_pos[2];
     uint32_t D = 0;
     if (n > 0) {
         // on a cache hit K1 must not overwrite the sorted (keyA, idxA): send its key/idx output to the B buffers
         hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, 256)), dim3(256), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
-                           c->rec, cache_hit ? c->keyB : c->keyA, cache_hit ? c->idxB : c->idxA, c->rect, c->counters);
+                           c->rec, cache_hit ? c->keyB : c->keyA, cache_hit ? c->idxB : c->idxA, c->rect);
         HIP_TRY(hipGetLastError());
     }
     MARK(1);
@@ -577,10 +578,14 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
         a.swizzle = c->opt_swizzle; a.swz_chunk = (local_tiles + 7) / 8;
         const unsigned grid = a.swizzle ? (unsigned)(a.swz_chunk * 8) : (unsigned)local_tiles;
         hipLaunchKernelGGL(k_blend, dim3(grid), dim3(256), 0, s, a, c->pvA, c->tstart, c->tend, c->rec,
-                           reinterpret_cast<float4*>(target), c->counters);
+                           reinterpret_cast<float4*>(target), c->tile_loaded);
         HIP_TRY(hipGetLastError());
     }
     MARK(6);
+    if (local_tiles > 0) {
+        hipLaunchKernelGGL(k_sum_loaded, dim3(1), dim3(256), 0, s, c->tile_loaded, local_tiles, c->counters);
+        HIP_TRY(hipGetLastError());
+    }
 #undef MARK
     if (timing) c->ev_pending[slot] = true;
     c->sorted_pvals = c->pvA;
@@ -617,6 +622,13 @@ extern "C" int gsr_get_stats(gsr_context* c, gsr_stats* out)
     // harvest in submission order so that "last frame" fields end up describing the newest frame
     for (int k = 0; k < GSR_EVENT_SLOTS; ++k) harvest_slot(c, (int)((c->frame_no + k) % GSR_EVENT_SLOTS));
     if (c->frame_no > 0) {
+        // statistics-only pass over the rects of the last frame
+        HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream));
+        if (c->n > 0)
+            hipLaunchKernelGGL(k_count_visible, dim3(256), dim3(256), 0, c->stream, c->rect, c->n, c->shard_index,
+                               c->shard_count, c->counters);
+        HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
         c->st.n_visible = (int64_t)c->h_counters[0];
         c->st.pairs_consumed = (int64_t)c->h_counters[1];
         c->st.blend_pairs_consumed_total = (int64_t)c->h_counters[2];

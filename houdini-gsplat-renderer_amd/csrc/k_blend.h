@@ -46,7 +46,7 @@ __device__ __forceinline__ int gsr_tile_of_block(const GsrBlendArgs& a)
 __global__ void __launch_bounds__(256)
 k_blend(GsrBlendArgs a, const uint32_t* __restrict__ pvals, const int32_t* __restrict__ tstart,
         const int32_t* __restrict__ tend, const GsrRecord* __restrict__ recs, float4* __restrict__ out,
-        unsigned long long* __restrict__ counters)
+        uint32_t* __restrict__ tile_loaded)
 {
     __shared__ float4 s0[2][BL_CHUNK];   // cx, cy, ex, ey
     __shared__ float4 s1[2][BL_CHUNK];   // is1, is2, (unused hx, hy)
@@ -145,8 +145,26 @@ k_blend(GsrBlendArgs a, const uint32_t* __restrict__ pvals, const int32_t* __res
         const int brow = lty * GSR_TILE_PX + (wave >> 1) * 8 + (lane >> 3);
         out[(size_t)brow * a.width + px] = make_float4(C0, C1, C2, A);
     }
-    if (tid == 0 && loaded > 0) {
-        atomicAdd(&counters[1], (unsigned long long)loaded);  // this frame
-        atomicAdd(&counters[2], (unsigned long long)loaded);  // running total (bench roofline)
+    if (tid == 0) tile_loaded[tile] = (uint32_t)loaded;  // pairs fetched by this tile (D_eff bookkeeping)
+}
+
+// D_eff bookkeeping: one workgroup sums the per-tile fetch counts into counters[1] (this
+// frame) and counters[2] (running total for bench.py's roofline) -- two atomics per frame
+// instead of two per tile.
+__global__ void __launch_bounds__(256)
+k_sum_loaded(const uint32_t* __restrict__ tile_loaded, int n_tiles, unsigned long long* __restrict__ counters)
+{
+    __shared__ unsigned long long s_sum;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    unsigned long long local = 0;
+    for (int i = threadIdx.x; i < n_tiles; i += 256) local += tile_loaded[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) local += __shfl_down(local, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_sum, local);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counters[1] = s_sum;
+        atomicAdd(&counters[2], s_sum);
     }
 }

@@ -92,10 +92,9 @@ __global__ void __launch_bounds__(256)
 k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col,
              GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint32_t* __restrict__ idx,
-             uint32_t* __restrict__ rect, unsigned long long* __restrict__ counters)
+             uint32_t* __restrict__ rect)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    bool vis = false;
     if (i < n) {
         const float4 a = geoA[i];
         const float px = a.x, py = a.y, pz = a.z, opacity = a.w;
@@ -225,7 +224,6 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
                 const int j1 = (int)__builtin_floorf(__builtin_fminf(yhi, hm1));
                 if (i1 >= i0 && j1 >= j0) {
                     out_rect = gsr_pack_rect(i0 >> 4, j0 >> 4, i1 >> 4, j1 >> 4);
-                    vis = gsr_rect_tiles(out_rect, f.shard_index, f.shard_count) > 0;
                 }
             }
 
@@ -273,7 +271,25 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
         }
         rect[i] = out_rect;
     }
-    // visible-splat counter: one atomic per wave
-    const unsigned long long m = __ballot(vis);
-    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&counters[0], (unsigned long long)__builtin_popcountll(m));
+}
+
+// statistics only (gsr_get_stats): splats with at least one owned tile.  Same-address
+// atomics serialise at ~12 ns each on MI355X, so this is kept out of the frame path.
+__global__ void __launch_bounds__(256)
+k_count_visible(const uint32_t* __restrict__ rect, uint32_t n, int shard_index, int shard_count,
+                unsigned long long* __restrict__ counters)
+{
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t local = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+        local += gsr_rect_tiles(rect[i], shard_index, shard_count) > 0 ? 1u : 0u;
+    const unsigned long long m = __ballot(local != 0);  // keeps the wave converged before the reduction
+    (void)m;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) local += __shfl_down(local, d, 64);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&s_cnt, local);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)s_cnt);
 }

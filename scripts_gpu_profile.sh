@@ -1,0 +1,19 @@
+#!/bin/bash
+# Usage (on the GPU box, from the repo root): bash scripts_gpu_profile.sh <tag> [bench args...]
+# Runs bench.py un-profiled, then under rocprofv3 --kernel-trace --stats, and leaves the
+# summaries in gpurun_out/prof_<tag>/ (copy what should be judged into profiles/).
+set -u
+TAG=${1:-r1}; shift || true
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python bench.py "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
+tail -c 3000 "$OUT/bench.json"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$TAG -o trace -- python "$REPO/bench.py" --no-cpu-baseline "$@" > "$OUT/bench_profiled.json" 2> "$OUT/rocprof.err"
+cd "$REPO"
+find /tmp/rp_$TAG -name '*kernel_stats*' -exec cp {} "$OUT/kernel_stats.csv" \;
+find /tmp/rp_$TAG -name '*domain_stats*' -exec cp {} "$OUT/domain_stats.csv" \;
+ls -la /tmp/rp_$TAG/* | head
+head -30 "$OUT/kernel_stats.csv"

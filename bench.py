@@ -163,17 +163,20 @@ def main():
     # blend-kernel roofline, measured with HIP events on the kernel's own stream
     launches = max(1, st["blend_launches"])
     blend_ms = st["blend_ms_total"] / launches
-    d_eff = st["blend_pairs_consumed_total"] / launches
+    d_eff = st["blend_pairs_consumed_total"] / launches       # records gathered per launch
+    scanned = st["blend_entries_scanned_total"] / launches     # list entries (idx + rect) read per launch
     rec_b, pair_b = st["record_bytes"], st["pair_bytes"]
     own_px = sum(min(16, H - r * 16) for r in range(rank, (H + 15) // 16, world)) * W
-    bytes_blend = (rec_b + pair_b) * d_eff + 16.0 * own_px
+    # algorithmic bytes of k_blend: 8 B per list entry scanned + 48 B per record gathered + one RGBA-f32 store per pixel
+    bytes_blend = pair_b * scanned + rec_b * d_eff + 16.0 * own_px
     achieved = bytes_blend / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
     roofline = {
         "bound": "hbm", "kernel": "k_blend", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
         "avg_launch_ms": blend_ms, "algorithmic_bytes_per_launch": bytes_blend,
-        "pairs_consumed_per_launch": d_eff, "pairs_total_last_frame": st["pairs_total"],
-        "bytes_per_pair": rec_b + pair_b,
+        "records_gathered_per_launch": d_eff, "entries_scanned_per_launch": scanned,
+        "pairs_sorted_last_frame": st["pairs_total"], "record_bytes": rec_b, "entry_bytes": pair_b,
+        "super_tile": st["super_tile"],
         "note": "k_blend is VALU/LDS-bound at 16x16 tiles (DESIGN.md); HBM fraction reported as the metric asks",
     }
     stages = {k: st[k] for k in ("ms_preprocess", "ms_depth_sort", "ms_emit", "ms_tile_sort", "ms_blend", "ms_total")}

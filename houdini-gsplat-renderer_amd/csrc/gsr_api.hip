@@ -4,12 +4,12 @@
 // Pipeline per gsr_render (all on one HIP stream):
 //   K1 k_preprocess        N splats -> record/key/rect                     (HBM)
 //   depth sort             4 x {hist, scan, scatter} on (key, idx)         (HBM)
-//   K2 k_tile_counts+scan  pairs per depth rank -> offsets, D              (HBM)
+//   K2 k_super_counts+scan super-tile pairs per depth rank -> offsets, D   (HBM)
 //      [D read back: 4-byte D2H + stream sync -- sizes the pair buffers]
-//   K3 k_emit_pairs        D (tile, splat) pairs in depth order            (HBM)
-//   tile sort              ceil(log2(tiles)/8) stable radix passes         (HBM)
-//   K5 k_tile_ranges
-//   K6 k_blend             per-tile front-to-back compositing       (VALU/LDS)
+//   K3 k_emit_pairs        D (super-tile, splat) pairs in depth order      (HBM)
+//   bin sort               ONE stable 8-bit radix pass on the super-tile id (HBM)
+//   K5 k_super_ranges      list boundaries + per-entry tile rect
+//   K6 k_blend             per-tile list filtering + front-to-back compositing (VALU/LDS)
 // Reference counterpart: GSplatRenderer::render + the GLSL program it drives
 // (/root/reference/gsplat_plugin/src/GSplatRenderer.C:534-658).
 #include <hip/hip_runtime.h>
@@ -18,7 +18,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <new>
+#include <vector>
 
 #include "../../include/gsplat_hip.h"
 #include "gsr_device.h"
@@ -79,20 +81,22 @@ struct gsr_context {
     // pairs
     uint32_t *pkA = nullptr, *pkB = nullptr, *pvA = nullptr, *pvB = nullptr;
     size_t pair_cap = 0;
-    uint32_t* sorted_pvals = nullptr;  // which of pvA/pvB holds the tile-sorted list of the last frame
-    int32_t *tstart = nullptr, *tend = nullptr;
-    uint32_t* tile_loaded = nullptr;
-    size_t tile_cap = 0;
+    uint32_t* srect = nullptr;         // rect of every entry of the sorted super-tile lists
+    int32_t *sstart = nullptr, *send = nullptr;  // [256 + 1] super-tile ranges
+    uint2* tile_work = nullptr;        // per tile: entries scanned, records gathered
+    int32_t* tile_map = nullptr;       // blockIdx -> tile (XCD-aware order), -1 = idle block
+    size_t tile_cap = 0, map_cap = 0;
+    int map_w = 0, map_h = 0, map_si = -1, map_sc = 0, map_shift = -1, map_grid = 0;
     float* fb = nullptr;
     size_t fb_cap = 0;
     // small device/host mailboxes
-    unsigned long long* counters = nullptr;  // [0] visible, [1] pairs consumed
+    unsigned long long* counters = nullptr;  // [0] visible [1] records gathered [2] running [3] entries scanned [4] running
     uint32_t* d_total = nullptr;
     uint32_t* h_total = nullptr;             // pinned
     unsigned long long* h_counters = nullptr;  // pinned [2]
 
     int shard_index = 0, shard_count = 1;
-    int opt_swizzle = 1, opt_timing = 1, opt_sort_cache = 1;
+    int opt_swizzle = 1, opt_timing = 1, opt_sort_cache = 1, opt_super = 0;
 
     // depth-sort cache (argsortByDistance semantics)
     bool sort_valid = false;
@@ -100,7 +104,7 @@ struct gsr_context {
     uint64_t sort_gen = 0;
 
     // last frame description
-    int last_tiles_x = 0, last_local_ty = 0;
+    int last_tiles_x = 0, last_local_ty = 0, last_supers = 0;
     uint32_t last_pairs = 0;
 
     // stats
@@ -154,11 +158,11 @@ extern "C" int gsr_create(int device, gsr_context** out)
     if (e != hipSuccess) { delete c; return set_err(GSR_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
     bool ok = true;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&c->counters), 4 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&c->counters), 8 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&c->d_total), sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_total), sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), 4 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipMemset(c->counters, 0, 4 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), 8 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMemset(c->counters, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
     if (ok) {
         c->ev_ok = true;
         for (int s = 0; s < GSR_EVENT_SLOTS && ok; ++s)
@@ -169,7 +173,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
         return set_err(GSR_E_HIP, "gsr_create: allocating context mailboxes/events failed");
     }
     c->st.record_bytes = (int32_t)sizeof(GsrRecord);
-    c->st.pair_bytes = 4;
+    c->st.pair_bytes = 8;
     *out = c;
     return GSR_OK;
 }
@@ -190,7 +194,8 @@ extern "C" void gsr_destroy(gsr_context* c)
     free_geometry(c);
     dev_free(c->hist); dev_free(c->partial);
     dev_free(c->pkA); dev_free(c->pkB); dev_free(c->pvA); dev_free(c->pvB);
-    dev_free(c->tstart); dev_free(c->tend); dev_free(c->tile_loaded); dev_free(c->fb);
+    dev_free(c->srect); dev_free(c->sstart); dev_free(c->send); dev_free(c->tile_work); dev_free(c->tile_map);
+    dev_free(c->fb);
     dev_free(c->counters); dev_free(c->d_total);
     if (c->h_total) (void)hipHostFree(c->h_total);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -218,6 +223,11 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
     case GSR_OPT_XCD_SWIZZLE: c->opt_swizzle = value ? 1 : 0; break;
     case GSR_OPT_STAGE_TIMING: c->opt_timing = value ? 1 : 0; break;
     case GSR_OPT_SORT_CACHE: c->opt_sort_cache = value ? 1 : 0; c->sort_valid = false; break;
+    case GSR_OPT_SUPER_TILE:
+        if (value != 0 && (value < 1 || value > 16 || (value & (value - 1))))
+            return set_err(GSR_E_INVALID, "gsr_set_option: super-tile edge must be 0 (auto) or 1,2,4,8,16");
+        c->opt_super = value;
+        break;
     default: return set_err(GSR_E_INVALID, "gsr_set_option: unknown option %d", option);
     }
     return GSR_OK;
@@ -444,6 +454,57 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
     f->shard_index = c->shard_index;
     f->shard_count = c->shard_count;
     f->local_tiles_y = (f->tiles_y > c->shard_index) ? (f->tiles_y - c->shard_index + c->shard_count - 1) / c->shard_count : 0;
+    // super-tile edge: smallest power of two that leaves <= 256 super-tiles (ONE 8-bit radix pass)
+    int shift = 0;
+    if (c->opt_super > 0) {
+        while ((1 << shift) < c->opt_super) ++shift;
+    } else {
+        while ((((f->tiles_x - 1) >> shift) + 1) * (((f->tiles_y - 1) >> shift) + 1) > 256) ++shift;
+    }
+    f->super_shift = shift;
+    f->super = 1 << shift;
+    f->stiles_x = ((f->tiles_x - 1) >> shift) + 1;
+    f->stiles_y = ((f->tiles_y - 1) >> shift) + 1;
+}
+
+// blockIdx -> tile table for the blend kernel.  Workgroup b lands on XCD b % 8; XCD x is
+// handed the super-tiles x, x+8, x+16, ... (round robin for load balance), each with all of
+// its owned tiles, so the 64 tiles that walk one list and gather the same records share an L2.
+static int build_tile_map(gsr_context* c, const GsrFrame& f)
+{
+    if (c->map_w == f.width && c->map_h == f.height && c->map_si == c->shard_index && c->map_sc == c->shard_count &&
+        c->map_shift == f.super_shift && c->tile_map)
+        return GSR_OK;
+    const int n_super = f.stiles_x * f.stiles_y;
+    std::vector<std::vector<int32_t>> per_xcd(8);
+    for (int st = 0; st < n_super; ++st) {
+        std::vector<int32_t>& v = per_xcd[st & 7];
+        const int sx = st % f.stiles_x, sy = st / f.stiles_x;
+        for (int gty = sy << f.super_shift; gty < ((sy + 1) << f.super_shift) && gty < f.tiles_y; ++gty) {
+            if (gty % c->shard_count != c->shard_index) continue;
+            const int lty = gty / c->shard_count;
+            for (int tx = sx << f.super_shift; tx < ((sx + 1) << f.super_shift) && tx < f.tiles_x; ++tx)
+                v.push_back(lty * f.tiles_x + tx);
+        }
+    }
+    size_t chunk = 0;
+    for (auto& v : per_xcd) chunk = std::max(chunk, v.size());
+    std::vector<int32_t> map(chunk * 8 + 8, -1);
+    for (int x = 0; x < 8; ++x)
+        for (size_t k = 0; k < per_xcd[x].size(); ++k) map[k * 8 + x] = per_xcd[x][k];
+    if (map.size() > c->map_cap) {
+        dev_free(c->tile_map);
+        c->map_cap = 0;
+        int rc = dev_alloc(&c->tile_map, map.size());
+        if (rc) return rc;
+        c->map_cap = map.size();
+    }
+    HIP_TRY(hipMemcpyAsync(c->tile_map, map.data(), map.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `map` is a stack-owned buffer
+    c->map_grid = (int)(chunk * 8);
+    c->map_w = f.width; c->map_h = f.height; c->map_si = c->shard_index; c->map_sc = c->shard_count;
+    c->map_shift = f.super_shift;
+    return GSR_OK;
 }
 
 static void harvest_slot(gsr_context* c, int slot)
@@ -491,14 +552,19 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
     hipEvent_t* ev = c->ev[slot];
 #define MARK(k) do { if (timing) HIP_TRY(hipEventRecord(ev[k], s)); } while (0)
 
-    // per-tile range arrays
-    if ((size_t)local_tiles + 1 > c->tile_cap) {
-        dev_free(c->tstart); dev_free(c->tend); dev_free(c->tile_loaded);
+    // per-tile bookkeeping + super-tile ranges
+    const int n_super = f.stiles_x * f.stiles_y;
+    if ((size_t)local_tiles + 1 > c->tile_cap || !c->sstart) {
+        dev_free(c->tile_work); dev_free(c->sstart); dev_free(c->send);
         c->tile_cap = 0;
         int rc;
-        if ((rc = dev_alloc(&c->tstart, (size_t)local_tiles + 1)) || (rc = dev_alloc(&c->tend, (size_t)local_tiles + 1)) ||
-            (rc = dev_alloc(&c->tile_loaded, (size_t)local_tiles + 1))) return rc;
+        if ((rc = dev_alloc(&c->tile_work, (size_t)local_tiles + 1)) || (rc = dev_alloc(&c->sstart, (size_t)65536 + 1)) ||
+            (rc = dev_alloc(&c->send, (size_t)65536 + 1))) return rc;
         c->tile_cap = (size_t)local_tiles + 1;
+    }
+    if (c->opt_swizzle) {
+        int rc = build_tile_map(c, f);
+        if (rc) return rc;
     }
     float* target = rgba_out;
     if (!out_is_device) {
@@ -513,7 +579,7 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
     }
 
     MARK(0);
-        const bool cache_hit = c->opt_sort_cache && c->sort_valid && c->sort_gen == c->geo_gen &&
+    const bool cache_hit = c->opt_sort_cache && c->sort_valid && c->sort_gen == c->geo_gen &&
                            c->sort_cam[0] == cam->cam_pos[0] && c->sort_cam[1] == cam->cam_pos[1] &&
                            c->sort_cam[2] == cam->cam_pos[2];
     uint32_t D = 0;
@@ -533,41 +599,42 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
     }
     MARK(2);
     if (n > 0) {
-        hipLaunchKernelGGL(k_tile_counts, dim3(div_up(n, 256)), dim3(256), 0, s, c->idxA, c->rect, n, c->shard_index,
-                           c->shard_count, c->cnt);
+        hipLaunchKernelGGL(k_super_counts, dim3(div_up(n, 256)), dim3(256), 0, s, c->idxA, c->rect, n, f.super_shift,
+                           c->shard_index, c->shard_count, c->cnt);
         int rc = exclusive_scan(c, c->cnt, c->poff, n, c->d_total);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(c->h_total, c->d_total, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         D = *c->h_total;
         if ((unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
-            return set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: %u tile-splat pairs exceed the limit", D);
+            return set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: %u super-tile pairs exceed the limit", D);
         if (D > c->pair_cap) {
-            dev_free(c->pkA); dev_free(c->pkB); dev_free(c->pvA); dev_free(c->pvB);
+            dev_free(c->pkA); dev_free(c->pkB); dev_free(c->pvA); dev_free(c->pvB); dev_free(c->srect);
             c->pair_cap = 0;
             const size_t want = (size_t)D + D / 4 + 4096;
             if ((rc = dev_alloc(&c->pkA, want)) || (rc = dev_alloc(&c->pkB, want)) || (rc = dev_alloc(&c->pvA, want)) ||
-                (rc = dev_alloc(&c->pvB, want))) return rc;
+                (rc = dev_alloc(&c->pvB, want)) || (rc = dev_alloc(&c->srect, want))) return rc;
             c->pair_cap = want;
         }
         if (D > 0) {
             hipLaunchKernelGGL(k_emit_pairs, dim3(div_up(n, 256)), dim3(256), 0, s, c->idxA, c->rect, c->poff, n,
-                               c->shard_index, c->shard_count, f.tiles_x, c->pkA, c->pvA);
+                               f.super_shift, c->shard_index, c->shard_count, f.stiles_x, c->pkA, c->pvA);
             HIP_TRY(hipGetLastError());
         }
     }
     MARK(3);
     if (D > 0) {
         int bits = 1;
-        while ((1 << bits) < local_tiles) ++bits;
+        while ((1 << bits) < n_super) ++bits;
         int rc = radix_sort(c, c->pkA, c->pvA, c->pkB, c->pvB, D, bits);
         if (rc) return rc;
     }
     MARK(4);
-    HIP_TRY(hipMemsetAsync(c->tstart, 0, ((size_t)local_tiles + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(c->tend, 0, ((size_t)local_tiles + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(c->sstart, 0, ((size_t)n_super + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(c->send, 0, ((size_t)n_super + 1) * 4, s));
     if (D > 0) {
-        hipLaunchKernelGGL(k_tile_ranges, dim3(div_up(D, 256)), dim3(256), 0, s, c->pkA, D, c->tstart, c->tend);
+        hipLaunchKernelGGL(k_super_ranges, dim3(div_up(D, 256)), dim3(256), 0, s, c->pkA, c->pvA, D, c->rect, c->sstart,
+                           c->send, c->srect);
         HIP_TRY(hipGetLastError());
     }
     MARK(5);
@@ -575,30 +642,33 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
         GsrBlendArgs a;
         a.width = cam->width; a.height = cam->height; a.tiles_x = f.tiles_x; a.local_tiles = local_tiles;
         a.shard_index = c->shard_index; a.shard_count = c->shard_count; a.band_rows = band_rows;
-        a.swizzle = c->opt_swizzle; a.swz_chunk = (local_tiles + 7) / 8;
-        const unsigned grid = a.swizzle ? (unsigned)(a.swz_chunk * 8) : (unsigned)local_tiles;
-        hipLaunchKernelGGL(k_blend, dim3(grid), dim3(256), 0, s, a, c->pvA, c->tstart, c->tend, c->rec,
-                           reinterpret_cast<float4*>(target), c->tile_loaded);
+        a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = c->opt_swizzle ? 1 : 0;
+        const unsigned grid = a.use_map ? (unsigned)c->map_grid : (unsigned)local_tiles;
+        hipLaunchKernelGGL(k_blend, dim3(grid), dim3(256), 0, s, a, c->tile_map, c->pvA, c->srect, c->sstart, c->send,
+                           c->rec, reinterpret_cast<float4*>(target), c->tile_work);
         HIP_TRY(hipGetLastError());
     }
     MARK(6);
     if (local_tiles > 0) {
-        hipLaunchKernelGGL(k_sum_loaded, dim3(1), dim3(256), 0, s, c->tile_loaded, local_tiles, c->counters);
+        hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(256), 0, s, c->tile_work, local_tiles, c->counters);
         HIP_TRY(hipGetLastError());
     }
 #undef MARK
     if (timing) c->ev_pending[slot] = true;
-    c->sorted_pvals = c->pvA;
+    c->last_supers = n_super;
     c->last_tiles_x = f.tiles_x;
     c->last_local_ty = f.local_tiles_y;
     c->last_pairs = D;
     c->st.pairs_total = D;
     c->st.tiles_x = f.tiles_x;
     c->st.tiles_y = f.local_tiles_y;
+    c->st.super_tile = f.super;
+    c->st.stiles_x = f.stiles_x;
+    c->st.stiles_y = f.stiles_y;
     c->st.frames += 1;
     c->frame_no += 1;
     // counters of this frame travel with the stream; they are read in gsr_get_stats
-    HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     if (!out_is_device) {
         HIP_TRY(hipMemcpyAsync(rgba_out, c->fb, out_px * 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -632,6 +702,8 @@ extern "C" int gsr_get_stats(gsr_context* c, gsr_stats* out)
         c->st.n_visible = (int64_t)c->h_counters[0];
         c->st.pairs_consumed = (int64_t)c->h_counters[1];
         c->st.blend_pairs_consumed_total = (int64_t)c->h_counters[2];
+        c->st.entries_scanned = (int64_t)c->h_counters[3];
+        c->st.blend_entries_scanned_total = (int64_t)c->h_counters[4];
     }
     *out = c->st;
     return GSR_OK;
@@ -643,12 +715,12 @@ extern "C" int gsr_stats_reset(gsr_context* c)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int k = 0; k < GSR_EVENT_SLOTS; ++k) harvest_slot(c, k);
-    HIP_TRY(hipMemsetAsync(c->counters, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), c->stream));
     const int64_t ns = c->st.n_splats;
     c->st = gsr_stats{};
     c->st.n_splats = ns;
     c->st.record_bytes = (int32_t)sizeof(GsrRecord);
-    c->st.pair_bytes = 4;
+    c->st.pair_bytes = 8;
     return GSR_OK;
 }
 
@@ -703,20 +775,19 @@ extern "C" int gsr_debug_read_depth_order(gsr_context* c, int32_t* perm, int64_t
     return GSR_OK;
 }
 
-extern "C" int gsr_debug_read_tile_lists(gsr_context* c, int32_t* tile_start, int32_t* tile_end, int64_t n_tiles,
+extern "C" int gsr_debug_read_tile_lists(gsr_context* c, int32_t* list_start, int32_t* list_end, int64_t n_lists,
                                          int32_t* pair_splat, int64_t n_pairs)
 {
-    if (!c || !tile_start || !tile_end) return set_err(GSR_E_INVALID, "gsr_debug_read_tile_lists: bad argument");
-    const int64_t lt = (int64_t)c->last_tiles_x * c->last_local_ty;
-    if (n_tiles != lt || n_pairs != (int64_t)c->last_pairs || (n_pairs > 0 && !pair_splat))
-        return set_err(GSR_E_INVALID, "gsr_debug_read_tile_lists: expected %lld tiles / %u pairs", (long long)lt, c->last_pairs);
+    if (!c || !list_start || !list_end) return set_err(GSR_E_INVALID, "gsr_debug_read_tile_lists: bad argument");
+    if (n_lists != (int64_t)c->last_supers || n_pairs != (int64_t)c->last_pairs || (n_pairs > 0 && !pair_splat))
+        return set_err(GSR_E_INVALID, "gsr_debug_read_tile_lists: expected %d lists / %u pairs", c->last_supers, c->last_pairs);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (lt) {
-        HIP_TRY(hipMemcpy(tile_start, c->tstart, (size_t)lt * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(tile_end, c->tend, (size_t)lt * 4, hipMemcpyDeviceToHost));
+    if (n_lists) {
+        HIP_TRY(hipMemcpy(list_start, c->sstart, (size_t)n_lists * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(list_end, c->send, (size_t)n_lists * 4, hipMemcpyDeviceToHost));
     }
-    if (n_pairs) HIP_TRY(hipMemcpy(pair_splat, c->sorted_pvals, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+    if (n_pairs) HIP_TRY(hipMemcpy(pair_splat, c->pvA, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
     return GSR_OK;
 }
 

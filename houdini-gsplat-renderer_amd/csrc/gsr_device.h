@@ -48,6 +48,9 @@ struct GsrFrame {
     int32_t tiles_y;   // ceil(height/16) (whole image)
     int32_t shard_index, shard_count;  // tile row r is ours iff r % count == index
     int32_t local_tiles_y;             // rows owned by this shard
+    int32_t super;                     // super-tile edge in tiles (power of two)
+    int32_t super_shift;               // log2(super)
+    int32_t stiles_x, stiles_y;        // super-tile grid over the whole image
 };
 
 // ---- scalar helpers ---------------------------------------------------------
@@ -100,4 +103,20 @@ __device__ __forceinline__ int gsr_rect_tiles(uint32_t rect, int index, int coun
     int x0 = rect & 255, y0 = (rect >> 8) & 255, x1 = (rect >> 16) & 255, y1 = rect >> 24;
     if (x1 < x0 || y1 < y0) return 0;
     return (x1 - x0 + 1) * gsr_owned_rows(y0, y1, index, count);
+}
+
+// number of SUPER-tiles (2^shift x 2^shift tiles) the rect reaches through at least one owned tile row
+__device__ __forceinline__ int gsr_rect_supers(uint32_t rect, int shift, int index, int count)
+{
+    const int x0 = rect & 255, y0 = (rect >> 8) & 255, x1 = (rect >> 16) & 255, y1 = rect >> 24;
+    if (x1 < x0 || y1 < y0) return 0;
+    const int w = (x1 >> shift) - (x0 >> shift) + 1;
+    const int sy0 = y0 >> shift, sy1 = y1 >> shift;
+    if (count == 1) return w * (sy1 - sy0 + 1);
+    int rows = 0;
+    for (int sy = sy0; sy <= sy1; ++sy) {
+        const int lo = max(y0, sy << shift), hi = min(y1, ((sy + 1) << shift) - 1);
+        rows += gsr_owned_rows(lo, hi, index, count) > 0 ? 1 : 0;
+    }
+    return w * rows;
 }

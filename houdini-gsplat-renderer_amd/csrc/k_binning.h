@@ -1,84 +1,70 @@
-// k_binning.h -- splat -> tile duplication in depth order, and per-tile ranges.
+// k_binning.h -- coarse binning: splat -> SUPER-tile pairs in depth order, and
+// per-super-tile ranges.
 //
-// The GL rasteriser did this implicitly for the reference (one instanced quad
-// per splat, /root/reference/gsplat_plugin/src/GSplatRenderer.C:647); a tiled
-// compute rasterizer has to materialise (tile, splat) pairs.  Pairs are emitted
-// in DEPTH-RANK order, so a stable sort on the tile id alone yields per-tile
-// front-to-back lists.  Roofline: HBM (8 B written per pair; 12 B read per splat).
+// The GL rasteriser did all binning implicitly for the reference (one instanced
+// quad per splat, /root/reference/gsplat_plugin/src/GSplatRenderer.C:647).  Here
+// only a COARSE (super-tile = SxS tiles, <= 256 of them) list is materialised:
+// pairs are emitted in depth-rank order, ONE stable 8-bit radix pass on the
+// super-tile id turns them into front-to-back lists, and the blend kernel
+// filters each list down to its own 16x16 tile on the fly (wave ballots), so it
+// stops reading the moment the tile is opaque.  Materialising per-tile lists
+// instead cost 75 M pairs x 2 radix passes on the 6 M-splat scene, 93 % of which
+// were never consumed (profiles/r1_baseline_v1).
+// Roofline: HBM (12 B written per pair; 12 B read per splat).
 #pragma once
 #include "gsr_device.h"
 
-// cnt[r] = number of owned tiles of the splat at depth rank r
+// cnt[r] = number of owned super-tiles of the splat at depth rank r
 __global__ void __launch_bounds__(256)
-k_tile_counts(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rect, uint32_t n,
-              int shard_index, int shard_count, uint32_t* __restrict__ cnt)
+k_super_counts(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rect, uint32_t n, int shift,
+               int shard_index, int shard_count, uint32_t* __restrict__ cnt)
 {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= n) return;
-    cnt[r] = (uint32_t)gsr_rect_tiles(rect[perm[r]], shard_index, shard_count);
+    cnt[r] = (uint32_t)gsr_rect_supers(rect[perm[r]], shift, shard_index, shard_count);
 }
 
-// one lane per depth rank; small rects are written by their lane, rects with
-// more than 32 tiles are written cooperatively by the whole wave (giant splats:
-// the axis cap is 4096 px)
+// one lane per depth rank writes its (super-tile, splat) pairs at poff[r]
 __global__ void __launch_bounds__(256)
 k_emit_pairs(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rect,
-             const uint32_t* __restrict__ poff, uint32_t n, int shard_index, int shard_count, int tiles_x,
-             uint32_t* __restrict__ pkeys, uint32_t* __restrict__ pvals)
+             const uint32_t* __restrict__ poff, uint32_t n, int shift, int shard_index, int shard_count,
+             int stiles_x, uint32_t* __restrict__ pkeys, uint32_t* __restrict__ pvals)
 {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    uint32_t idx = 0, rc = GSR_RECT_EMPTY, o = 0;
-    int cnt = 0;
-    if (r < n) {
-        idx = perm[r];
-        rc = rect[idx];
-        cnt = gsr_rect_tiles(rc, shard_index, shard_count);
-        o = poff[r];
-    }
-    const bool big = cnt > 32;
-    if (cnt > 0 && !big) {
-        const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = (rc >> 16) & 255, y1 = rc >> 24;
-        int ty = y0 + ((shard_index - y0 % shard_count) + shard_count) % shard_count;
-        for (; ty <= y1; ty += shard_count) {
-            const uint32_t rowkey = (uint32_t)(ty / shard_count) * (uint32_t)tiles_x;
-            for (int tx = x0; tx <= x1; ++tx) {
-                pkeys[o] = rowkey + (uint32_t)tx;
-                pvals[o] = idx;
-                ++o;
-            }
+    if (r >= n) return;
+    const uint32_t idx = perm[r];
+    const uint32_t rc = rect[idx];
+    const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = (rc >> 16) & 255, y1 = rc >> 24;
+    if (x1 < x0 || y1 < y0) return;
+    uint32_t o = poff[r];
+    const int sx0 = x0 >> shift, sx1 = x1 >> shift;
+    for (int sy = y0 >> shift; sy <= (y1 >> shift); ++sy) {
+        if (shard_count > 1) {
+            const int lo = max(y0, sy << shift), hi = min(y1, ((sy + 1) << shift) - 1);
+            if (gsr_owned_rows(lo, hi, shard_index, shard_count) == 0) continue;
         }
-    }
-    unsigned long long m = __ballot(big);
-    while (m) {
-        const int src = __builtin_ctzll(m);
-        m &= m - 1;
-        const uint32_t rc_s = __shfl(rc, src, 64);
-        const uint32_t o_s = __shfl(o, src, 64);
-        const uint32_t idx_s = __shfl(idx, src, 64);
-        const int x0 = rc_s & 255, y0 = (rc_s >> 8) & 255, x1 = (rc_s >> 16) & 255, y1 = rc_s >> 24;
-        const int w = x1 - x0 + 1;
-        const int first = y0 + ((shard_index - y0 % shard_count) + shard_count) % shard_count;
-        const int rows = (first > y1) ? 0 : (y1 - first) / shard_count + 1;
-        const int total = w * rows;
-        for (int t = lane; t < total; t += 64) {
-            const int ry = t / w, tx = x0 + t % w;
-            const int ty = first + ry * shard_count;
-            pkeys[o_s + t] = (uint32_t)(ty / shard_count) * (uint32_t)tiles_x + (uint32_t)tx;
-            pvals[o_s + t] = idx_s;
+        const uint32_t rowkey = (uint32_t)sy * (uint32_t)stiles_x;
+        for (int sx = sx0; sx <= sx1; ++sx) {
+            pkeys[o] = rowkey + (uint32_t)sx;
+            pvals[o] = idx;
+            ++o;
         }
     }
 }
 
-// boundaries of equal-key runs in the tile-sorted pair list
+// boundaries of equal-key runs in the sorted pair list, plus the rect of every
+// listed splat (so that the blend kernel's tile filter is a coalesced read)
 __global__ void __launch_bounds__(256)
-k_tile_ranges(const uint32_t* __restrict__ keys, uint32_t n, int32_t* __restrict__ tstart, int32_t* __restrict__ tend)
+k_super_ranges(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
+               const uint32_t* __restrict__ rect, int32_t* __restrict__ sstart, int32_t* __restrict__ send,
+               uint32_t* __restrict__ srect)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint32_t k = keys[i];
-    if (i == 0 || keys[i - 1] != k) tstart[k] = (int32_t)i;
-    if (i == n - 1 || keys[i + 1] != k) tend[k] = (int32_t)(i + 1);
+    if (i == 0 || keys[i - 1] != k) sstart[k] = (int32_t)i;
+    if (i == n - 1 || keys[i + 1] != k) send[k] = (int32_t)(i + 1);
+    srect[i] = rect[vals[i]];
 }
 
 // root side of the multi-GPU path: de-interleave gathered band images.

@@ -1,4 +1,4 @@
-// k_blend.h -- K6: per-tile front-to-back compositing.
+// k_blend.h -- K6: per-tile front-to-back compositing with in-kernel tile filtering.
 //
 // Replaces the reference's fragment shader
 // (/root/reference/gsplat_plugin/shaders/GSplatShaderSource.h:304-312) and the
@@ -9,14 +9,18 @@
 // Geometry: one 256-thread workgroup per 16x16 tile; wave w owns the 8x8
 // quadrant (w&1, w>>1), lane l the pixel (l&7, l>>3) of it -- a wave64 is
 // exactly one 8x8 pixel block, so all culling is wave-uniform.
-// Data flow: the tile's sorted pair list is consumed in chunks of 256; each
-// thread gathers one 48-B record (3 x dwordx4) into registers one chunk ahead,
-// drops it into a double-buffered LDS stage together with a 4-bit
-// quadrant-overlap mask, and every wave turns those masks into a 64-bit ballot
-// so that it only ever touches records whose bbox reaches its quadrant.
-// Early-out: a wave stops when all its pixels have 1-A < 2^-14 (error bound
-// 2^-14 * max colour, well inside the 1e-3 budget); the workgroup stops
-// fetching when all four waves have stopped.
+// Data flow: the tile walks the depth-ordered list of its SUPER-tile in chunks
+// of 256 entries (idx + packed tile rect, coalesced).  A thread whose entry's
+// rect contains this tile gathers the 48-B record (3 x dwordx4) one chunk
+// ahead, drops it into a double-buffered LDS stage with a 4-bit
+// quadrant-overlap mask (0 for entries that miss the tile), and every wave
+// turns those masks into 64-bit ballots so that it only ever touches records
+// whose bbox reaches its quadrant.
+// Early-out: a PIXEL stops accumulating once 1-A < 2^-14 (dropped contribution
+// <= 2^-14 * max colour, inside the 1e-3 budget; being per pixel it does not
+// depend on chunking, so sharded and unsharded frames are bit-identical); a wave
+// stops when all its pixels have, and the workgroup stops reading its list when
+// all four waves have.
 #pragma once
 #include "gsr_device.h"
 
@@ -29,91 +33,103 @@ struct GsrBlendArgs {
     int32_t local_tiles;        // tiles_x * local_tiles_y
     int32_t shard_index, shard_count;
     int32_t band_rows;          // pixel rows of the output (band) image
-    int32_t swizzle;            // XCD-aware tile mapping
-    int32_t swz_chunk;          // tiles per XCD when swizzled
+    int32_t super_shift;        // log2(super-tile edge in tiles)
+    int32_t stiles_x;
+    int32_t use_map;            // blockIdx -> tile through tile_map (XCD-aware order)
 };
 
-// blockIdx -> tile.  Workgroup b runs on XCD b%8 (observed dispatch order,
-// MI355X guide): give each XCD a contiguous run of tiles so that neighbouring
-// tiles -- which gather the same records -- share one L2.
-__device__ __forceinline__ int gsr_tile_of_block(const GsrBlendArgs& a)
-{
-    const int b = blockIdx.x;
-    if (!a.swizzle) return b;
-    return (b & 7) * a.swz_chunk + (b >> 3);
-}
-
 __global__ void __launch_bounds__(256)
-k_blend(GsrBlendArgs a, const uint32_t* __restrict__ pvals, const int32_t* __restrict__ tstart,
-        const int32_t* __restrict__ tend, const GsrRecord* __restrict__ recs, float4* __restrict__ out,
-        uint32_t* __restrict__ tile_loaded)
+k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint32_t* __restrict__ svals,
+        const uint32_t* __restrict__ srects, const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
+        const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint2* __restrict__ tile_work)
 {
     __shared__ float4 s0[2][BL_CHUNK];   // cx, cy, ex, ey
-    __shared__ float4 s1[2][BL_CHUNK];   // is1, is2, (unused hx, hy)
+    __shared__ float4 s1[2][BL_CHUNK];   // is1, is2, (hx, hy unused after the mask)
     __shared__ float4 s2[2][BL_CHUNK];   // r, g, b, opacity
     __shared__ uint32_t smask[2][BL_CHUNK];
     __shared__ uint32_t sdone[2][4];
+    __shared__ uint32_t sfetched;
 
-    const int tile = gsr_tile_of_block(a);
-    if (tile >= a.local_tiles) return;
+    // Workgroup b runs on XCD b%8 (observed dispatch order, MI355X guide): tile_map hands each
+    // XCD whole super-tiles, whose 64 tiles read the same list and gather the same records.
+    const int tile = a.use_map ? tile_map[blockIdx.x] : (int)blockIdx.x;
+    if (tile < 0 || tile >= a.local_tiles) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % a.tiles_x, lty = tile / a.tiles_x;
     const int gty = lty * a.shard_count + a.shard_index;
-    const int qx = tx * GSR_TILE_PX + (wave & 1) * 8, qy = gty * GSR_TILE_PX + (wave >> 1) * 8;
-    const int px = qx + (lane & 7), py = qy + (lane >> 3);
+    const int px = tx * GSR_TILE_PX + (wave & 1) * 8 + (lane & 7);
+    const int py = gty * GSR_TILE_PX + (wave >> 1) * 8 + (lane >> 3);
     const bool pix_ok = (px < a.width) && (py < a.height);
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     // tile bounds in pixel-centre coordinates, for the quadrant masks
     const float tcx0 = (float)(tx * GSR_TILE_PX) + 0.5f, tcy0 = (float)(gty * GSR_TILE_PX) + 0.5f;
+    if (tid == 0) sfetched = 0;
+
+    const int st = (gty >> a.super_shift) * a.stiles_x + (tx >> a.super_shift);
+    const int s = sstart[st];
+    const int n = send[st] - s;
 
     float C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, A = 0.0f;
-    const int s = tstart[tile];
-    const int n = tend[tile] - s;
     bool wave_done = false;
-    int loaded = 0;
+    int chunks_read = 0;
+    uint32_t my_fetched = 0;
 
+    // list entries two chunks ahead, records one chunk ahead
+    auto tile_in = [&](uint32_t rc) {
+        const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = (rc >> 16) & 255, y1 = rc >> 24;
+        return tx >= x0 && tx <= x1 && gty >= y0 && gty <= y1;
+    };
+    uint32_t e_idx = 0, n_idx = 0;   // entry of the chunk being gathered next / the one after
+    bool e_hit = false, n_hit = false;
+    if (tid < n) { e_idx = svals[s + tid]; e_hit = tile_in(srects[s + tid]); }
+    if (BL_CHUNK + tid < n) { n_idx = svals[s + BL_CHUNK + tid]; n_hit = tile_in(srects[s + BL_CHUNK + tid]); }
+    chunks_read = 2;
     float4 r0, r1, r2;
-    bool have = tid < n;
+    bool have = e_hit;
     if (have) {
-        const float4* p = reinterpret_cast<const float4*>(recs + pvals[s + tid]);
+        const float4* p = reinterpret_cast<const float4*>(recs + e_idx);
         r0 = p[0]; r1 = p[1]; r2 = p[2];
+        ++my_fetched;
     }
-    loaded = n < BL_CHUNK ? n : BL_CHUNK;
 
     for (int c = 0; c * BL_CHUNK < n; ++c) {
         const int buf = c & 1;
+        uint32_t m = 0;
         if (have) {
             s0[buf][tid] = r0; s1[buf][tid] = r1; s2[buf][tid] = r2;
             // which 8x8 quadrants can the splat's bbox touch?
             const float bx0 = r0.x - r1.z, bx1 = r0.x + r1.z, by0 = r0.y - r1.w, by1 = r0.y + r1.w;
             const bool xl = bx0 <= tcx0 + 7.0f, xr = bx1 >= tcx0 + 8.0f;
             const bool yb = by0 <= tcy0 + 7.0f, yt = by1 >= tcy0 + 8.0f;
-            smask[buf][tid] = (uint32_t)(xl && yb) | ((uint32_t)(xr && yb) << 1) | ((uint32_t)(xl && yt) << 2) |
-                              ((uint32_t)(xr && yt) << 3);
+            m = (uint32_t)(xl && yb) | ((uint32_t)(xr && yb) << 1) | ((uint32_t)(xl && yt) << 2) |
+                ((uint32_t)(xr && yt) << 3);
         }
+        smask[buf][tid] = m;
         if (lane == 0) sdone[buf][wave] = wave_done ? 1u : 0u;
         __syncthreads();
         const bool block_done = (sdone[buf][0] & sdone[buf][1] & sdone[buf][2] & sdone[buf][3]) != 0u;
         if (block_done) break;
         const int cn = (n - c * BL_CHUNK < BL_CHUNK) ? (n - c * BL_CHUNK) : BL_CHUNK;
 
-        // prefetch the next chunk while this one is composited
-        const int nxt = (c + 1) * BL_CHUNK + tid;
-        have = nxt < n;
+        // software pipeline: gather chunk c+1's records, fetch chunk c+2's list entries
+        have = n_hit;
         if (have) {
-            const float4* p = reinterpret_cast<const float4*>(recs + pvals[s + nxt]);
+            const float4* p = reinterpret_cast<const float4*>(recs + n_idx);
             r0 = p[0]; r1 = p[1]; r2 = p[2];
+            ++my_fetched;
         }
-        if ((c + 1) * BL_CHUNK < n) {
-            const int more = n - (c + 1) * BL_CHUNK;
-            loaded += more < BL_CHUNK ? more : BL_CHUNK;
+        {
+            ++chunks_read;
+            const int nn = (c + 2) * BL_CHUNK + tid;
+            n_hit = false;
+            if (nn < n) { n_idx = svals[s + nn]; n_hit = tile_in(srects[s + nn]); }
         }
 
         if (!wave_done) {
             for (int g = 0; g * 64 < cn; ++g) {
                 const int j0 = g * 64;
-                const bool mine = (j0 + lane < cn) && ((smask[buf][j0 + lane] >> wave) & 1u);
-                unsigned long long acc = __ballot(mine);
+                unsigned long long acc = __ballot((smask[buf][j0 + lane] >> wave) & 1u);
+                if (acc == 0ull) continue;
                 while (acc) {
                     const int j = j0 + __builtin_ctzll(acc);
                     acc &= acc - 1;
@@ -129,8 +145,8 @@ k_blend(GsrBlendArgs a, const uint32_t* __restrict__ pvals, const int32_t* __res
                     // outside the quad power can be very negative: keep the exp argument in range
                     float alpha = gsr_expf(__builtin_fmaxf(power, -80.0f)) * g2.w;
                     alpha = __builtin_fminf(__builtin_fmaxf(alpha, 0.0f), 1.0f);
-                    if (inside && alpha >= (1.0f / 255.0f)) {
-                        const float t = 1.0f - A;
+                    const float t = 1.0f - A;
+                    if (inside && alpha >= (1.0f / 255.0f) && t >= GSR_T_MIN) {
                         C0 = gsr_fma(t, g2.x * alpha, C0);
                         C1 = gsr_fma(t, g2.y * alpha, C1);
                         C2 = gsr_fma(t, g2.z * alpha, C2);
@@ -145,26 +161,38 @@ k_blend(GsrBlendArgs a, const uint32_t* __restrict__ pvals, const int32_t* __res
         const int brow = lty * GSR_TILE_PX + (wave >> 1) * 8 + (lane >> 3);
         out[(size_t)brow * a.width + px] = make_float4(C0, C1, C2, A);
     }
-    if (tid == 0) tile_loaded[tile] = (uint32_t)loaded;  // pairs fetched by this tile (D_eff bookkeeping)
+    // bookkeeping for the roofline: list entries scanned and records gathered by this tile
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) my_fetched += __shfl_down(my_fetched, d, 64);
+    __syncthreads();  // orders the sfetched = 0 store when the list was empty
+    if (lane == 0) atomicAdd(&sfetched, my_fetched);
+    __syncthreads();
+    if (tid == 0) {
+        const int scanned = (chunks_read * BL_CHUNK < n) ? chunks_read * BL_CHUNK : n;
+        tile_work[tile] = make_uint2((uint32_t)scanned, sfetched);
+    }
 }
 
-// D_eff bookkeeping: one workgroup sums the per-tile fetch counts into counters[1] (this
-// frame) and counters[2] (running total for bench.py's roofline) -- two atomics per frame
-// instead of two per tile.
+// One workgroup sums the per-tile bookkeeping into counters[1] (records gathered, this
+// frame), counters[2] (records, running total), counters[3] (entries scanned, this frame),
+// counters[4] (entries, running total) -- a handful of atomics per frame instead of per tile
+// (same-address atomics serialise at ~12 ns each on MI355X).
 __global__ void __launch_bounds__(256)
-k_sum_loaded(const uint32_t* __restrict__ tile_loaded, int n_tiles, unsigned long long* __restrict__ counters)
+k_sum_work(const uint2* __restrict__ tile_work, int n_tiles, unsigned long long* __restrict__ counters)
 {
-    __shared__ unsigned long long s_sum;
-    if (threadIdx.x == 0) s_sum = 0;
+    __shared__ unsigned long long s_sum[2];
+    if (threadIdx.x < 2) s_sum[threadIdx.x] = 0;
     __syncthreads();
-    unsigned long long local = 0;
-    for (int i = threadIdx.x; i < n_tiles; i += 256) local += tile_loaded[i];
+    unsigned long long sc = 0, fe = 0;
+    for (int i = threadIdx.x; i < n_tiles; i += 256) { const uint2 w = tile_work[i]; sc += w.x; fe += w.y; }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) local += __shfl_down(local, d, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&s_sum, local);
+    for (int d = 32; d > 0; d >>= 1) { sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); }
     __syncthreads();
     if (threadIdx.x == 0) {
-        counters[1] = s_sum;
-        atomicAdd(&counters[2], s_sum);
+        counters[1] = s_sum[1];
+        atomicAdd(&counters[2], s_sum[1]);
+        counters[3] = s_sum[0];
+        atomicAdd(&counters[4], s_sum[0]);
     }
 }

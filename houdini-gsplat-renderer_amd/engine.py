@@ -35,7 +35,9 @@ class gsr_stats(C.Structure):
                 ("ms_preprocess", C.c_float), ("ms_depth_sort", C.c_float), ("ms_emit", C.c_float),
                 ("ms_tile_sort", C.c_float), ("ms_blend", C.c_float), ("ms_total", C.c_float),
                 ("blend_ms_total", C.c_double), ("blend_launches", C.c_int64),
-                ("blend_pairs_consumed_total", C.c_int64), ("frame_ms_total", C.c_double), ("frames", C.c_int64)]
+                ("blend_pairs_consumed_total", C.c_int64), ("frame_ms_total", C.c_double), ("frames", C.c_int64),
+                ("entries_scanned", C.c_int64), ("blend_entries_scanned_total", C.c_int64),
+                ("super_tile", C.c_int32), ("stiles_x", C.c_int32), ("stiles_y", C.c_int32), ("reserved_", C.c_int32)]
 
     def as_dict(self) -> dict:
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -58,7 +60,7 @@ class GSplatRenderContext(C.Structure):
                 ("target", C.c_void_p), ("target_is_device", C.c_int32)]
 
 
-OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE = 1, 2, 3
+OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE, OPT_SUPER_TILE = 1, 2, 3, 4
 
 # every symbol include/gsplat_hip.h and include/GSplatRenderer.h declare
 C_ABI_SYMBOLS = [
@@ -302,8 +304,9 @@ class Engine:
         return out
 
     def debug_tile_lists(self):
+        """per-SUPER-tile [start, end) + the depth-ordered splat list of the last frame"""
         st = self.stats()
-        nt = st["tiles_x"] * st["tiles_y"]
+        nt = st["stiles_x"] * st["stiles_y"]
         npairs = st["pairs_total"]
         ts = np.zeros(nt, np.int32)
         te = np.zeros(nt, np.int32)

@@ -62,17 +62,22 @@ typedef struct gsr_camera {
 typedef struct gsr_stats {
     int64_t n_splats;          /* uploaded */
     int64_t n_visible;         /* survived w/z culling and have >=1 tile */
-    int64_t pairs_total;       /* D: (tile, splat) pairs emitted */
-    int64_t pairs_consumed;    /* D_eff: pairs fetched by the blend kernel before early-out */
+    int64_t pairs_total;       /* D: (super-tile, splat) pairs emitted and sorted */
+    int64_t pairs_consumed;    /* records gathered by the blend kernel before early-out */
     int32_t tiles_x, tiles_y;  /* tile grid of this context's shard */
-    int32_t record_bytes;      /* bytes of one projected record as read by the blend kernel */
-    int32_t pair_bytes;        /* bytes of one sorted pair payload as read by the blend kernel */
+    int32_t record_bytes;      /* bytes of one projected record as gathered by the blend kernel (48) */
+    int32_t pair_bytes;        /* bytes of one list entry as scanned by the blend kernel (idx + rect = 8) */
     float ms_preprocess, ms_depth_sort, ms_emit, ms_tile_sort, ms_blend, ms_total; /* last frame, HIP events */
     double blend_ms_total;     /* sum over all frames since gsr_stats_reset */
     int64_t blend_launches;
     int64_t blend_pairs_consumed_total;
     double frame_ms_total;
     int64_t frames;
+    int64_t entries_scanned;               /* list entries (idx+rect) read by the blend kernel, last frame */
+    int64_t blend_entries_scanned_total;   /* ... running total */
+    int32_t super_tile;                    /* super-tile edge in tiles */
+    int32_t stiles_x, stiles_y;            /* super-tile grid (whole image) */
+    int32_t reserved_;
 } gsr_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -136,6 +141,8 @@ int  gsr_stats_reset(gsr_context* ctx);
 #define GSR_OPT_STAGE_TIMING    2   /* 0/1: record per-stage HIP events (default 1) */
 #define GSR_OPT_SORT_CACHE      3   /* 0/1: skip the depth sort when cam_pos and geometry are unchanged
                                        (argsortByDistance's caching, src/GSplatRenderer.C:179-186) */
+#define GSR_OPT_SUPER_TILE      4   /* super-tile edge in tiles: 0 = auto (smallest power of two giving
+                                       <= 256 super-tiles), or 1,2,4,8,16 */
 int  gsr_set_option(gsr_context* ctx, int option, int value);
 
 /* ---- debug / test access (device -> host copies of intermediates) -------- */
@@ -147,8 +154,9 @@ typedef struct gsr_debug_record {
 } gsr_debug_record;
 int  gsr_debug_read_records(gsr_context* ctx, gsr_debug_record* out, int64_t n);
 int  gsr_debug_read_depth_order(gsr_context* ctx, int32_t* perm, int64_t n);
-/* per-tile [start,end) into the sorted pair list + the list itself (splat indices) */
-int  gsr_debug_read_tile_lists(gsr_context* ctx, int32_t* tile_start, int32_t* tile_end, int64_t n_tiles,
+/* per-SUPER-tile [start,end) into the sorted pair list + the list itself (splat indices);
+ * n_lists = stiles_x*stiles_y, n_pairs = pairs_total of the last frame */
+int  gsr_debug_read_tile_lists(gsr_context* ctx, int32_t* list_start, int32_t* list_end, int64_t n_lists,
                                int32_t* pair_splat, int64_t n_pairs);
 
 /* Stand-alone device radix sort of (key,value) u32 pairs on bits [0, key_bits):

@@ -81,30 +81,36 @@ def test_radix_sort_pairs(engine, n, bits):
     assert np.array_equal(v, vals[order])
 
 
-def test_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine):
+def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine):
     splats = pkg.scenes.make_scene(30000, seed=21, sh=False)
     cam = pkg.camera.make_camera(400, 300, sh_order=0, frame=0)
     engine.upload(splats)
     engine.render(cam)
-    ts, te, pv = engine.debug_tile_lists()
+    ls, le, pv = engine.debug_tile_lists()
+    st = engine.stats()
+    S, sx = st["super_tile"], st["stiles_x"]
+    assert ls.shape[0] == st["stiles_x"] * st["stiles_y"] and st["pairs_total"] == pv.shape[0]
     rec = oracle.preprocess(splats, cam)
     perm = oracle.argsort(rec)
     rank = np.empty(splats.n, np.int64)
     rank[perm] = np.arange(splats.n)
-    tiles_x = (cam.width + 15) // 16
-    st = engine.stats()
-    assert st["pairs_total"] == pv.shape[0]
+    # expected membership: splats whose (device-identical) pixel bbox reaches the super-tile
+    dev = engine.debug_records(splats.n)
+    vis = np.flatnonzero(dev["visible"] == 1)
     seen = 0
-    for t in range(ts.shape[0]):
-        lst = pv[ts[t]:te[t]]
+    for t in range(ls.shape[0]):
+        lst = pv[ls[t]:le[t]]
         seen += lst.shape[0]
         if lst.shape[0] > 1:
-            assert (np.diff(rank[lst]) > 0).all(), f"tile {t} not in depth order"
-        # every splat listed must overlap the tile's pixel range (conservative bbox)
-        tx, ty = t % tiles_x, t // tiles_x
-        r = rec[lst]
-        assert (r["cx"] + r["hx"] >= tx * 16 + 0.5 - 1e-3).all() and (r["cx"] - r["hx"] <= tx * 16 + 15.5 + 1e-3).all()
-        assert (r["cy"] + r["hy"] >= ty * 16 + 0.5 - 1e-3).all() and (r["cy"] - r["hy"] <= ty * 16 + 15.5 + 1e-3).all()
+            assert (np.diff(rank[lst]) > 0).all(), f"super-tile {t} not in depth order"
+        x0, y0 = (t % sx) * S * 16, (t // sx) * S * 16
+        x1, y1 = x0 + S * 16 - 1, y0 + S * 16 - 1
+        r = rec[vis]
+        i0 = np.ceil(np.maximum(r["cx"] - r["hx"] - 0.5, 0)); i1 = np.floor(np.minimum(r["cx"] + r["hx"] - 0.5, cam.width - 1))
+        j0 = np.ceil(np.maximum(r["cy"] - r["hy"] - 0.5, 0)); j1 = np.floor(np.minimum(r["cy"] + r["hy"] - 0.5, cam.height - 1))
+        tx0, tx1, ty0, ty1 = i0 // 16, i1 // 16, j0 // 16, j1 // 16
+        hit = (tx1 >= x0 // 16) & (tx0 <= x1 // 16) & (ty1 >= y0 // 16) & (ty0 <= y1 // 16)
+        assert set(lst.tolist()) == set(vis[hit].tolist()), f"super-tile {t}: membership differs"
     assert seen == pv.shape[0]
 
 

@@ -122,22 +122,15 @@ def main():
         eng.set_row_shard(rank, world)
     eng.upload(splats)  # once: geometry stays resident in HBM
 
-    band_rows = eng.band_rows(H)
-    band = torch.zeros((band_rows, W, 4), dtype=torch.float32, device="cuda")
-    gathered = final = None
-    if world > 1 and rank == 0:
-        gathered = torch.zeros((world, band_rows, W, 4), dtype=torch.float32, device="cuda")
-        final = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    fg = pkg.multigpu.FrameGatherer(dist, rank, world, W, H, "cuda", engine=eng)
+    assert fg.rows == eng.band_rows(H)
     cams = [pkg.engine.camera_struct(pkg.camera.make_camera(W, H, sh_order=order, frame=i))
             for i in range(args.warmup + args.steps)]
 
     def step(i):
-        eng.render_struct_to_device(cams[i], band.data_ptr())
-        if world > 1:
-            # ONE collective per frame: band images -> rank 0 over xGMI (RCCL gather)
-            dist.gather(band, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
-            if rank == 0:
-                eng.stitch_bands(gathered.data_ptr(), world, W, H, final.data_ptr())
+        eng.render_struct_to_device(cams[i], fg.band.data_ptr())
+        # N>1: ONE collective per frame -- band images -> rank 0 over xGMI (RCCL gather) -- then stitch
+        fg.gather_and_stitch()
 
     for i in range(args.warmup):
         step(i)

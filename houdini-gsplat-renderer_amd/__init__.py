@@ -12,7 +12,7 @@ Layout:
   scenes.py   synthetic splat clouds of BASELINE.json's configs
   multigpu.py tile-row sharding across ranks + RCCL gather + stitch
 """
-from . import build, camera, scenes  # noqa: F401  (no GPU needed)
+from . import build, camera, multigpu, scenes  # noqa: F401  (no GPU needed)
 from .engine import Engine, GSplatRenderer, GsrError, lib_path, load_library  # noqa: F401
 
-__all__ = ["build", "camera", "scenes", "Engine", "GSplatRenderer", "GsrError", "lib_path", "load_library"]
+__all__ = ["build", "camera", "multigpu", "scenes", "Engine", "GSplatRenderer", "GsrError", "lib_path", "load_library"]

@@ -1,0 +1,437 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures that PIN the oracle: run the reference's OWN GLSL program
+(read from /root/reference at run time, never copied into this repo) on a software GLES 3.0
+rasteriser (SwiftShader, bundled in the `kaleido` wheel of the build container), with the
+reference's texture layouts, blend state and instanced draw reproduced by hand, and store
+inputs + the image it produced under tests/golden/*.npz.
+
+Run in the BUILD CONTAINER only:   python tests/golden/make_goldens.py
+(The GPU box has neither /root/reference nor needs it: tests only read the .npz files.)
+
+What is reproduced from the reference's host side (paths relative to
+/root/reference/gsplat_plugin):
+  * texture layouts and sizes        src/GSplatRenderer.C:106-139 (closestSqrtPowerOf2 :155-163),
+                                      pack loop :448-505 (4 RGBA32F texels / splat; 8 RGB16F texels / splat x2)
+  * sorted-index texture (INT32)     src/GSplatRenderer.C:583-593
+  * GL state                          :605-621  blend(ONE_MINUS_DST_ALPHA, ONE) colour+alpha, ADD; depth write off
+  * uniforms                          :625-645
+  * draw                              :647      6 vertices x N instances, triangles (0,1,2) (3,4,5)
+The shader text is taken verbatim from shaders/GSplatShaderCoreLib.h and
+shaders/GSplatShaderSource.h and made GLSL-ES-3.00 legal by the purely syntactic edits in
+ES3_EDITS below (int literals in float context -> float literals; interface blocks -> plain
+varyings; version/precision header).  No arithmetic is changed.  Every edit asserts that its
+pattern is present, so a different reference revision fails loudly instead of silently.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+REF = "/root/reference/gsplat_plugin/shaders"
+SWS = "/usr/local/lib/python3.10/dist-packages/kaleido/executable/bin/swiftshader"
+
+# ----------------------------------------------------------------------------- shader text
+def _raw_literal(text: str, name: str) -> str:
+    m = re.search(r"const char\* const " + re.escape(name) + r'\s*=\s*R"glsl\((.*?)\)glsl";', text, re.S)
+    assert m, f"raw string {name} not found in the reference"
+    return m.group(1)
+
+
+# (pattern, replacement, expected count) -- syntactic only
+ES3_EDITS_CORE = [
+    ("scale.x, 0, 0,", "scale.x, 0.0, 0.0,", 1),
+    ("0, scale.y, 0,", "0.0, scale.y, 0.0,", 1),
+    ("0, 0, scale.z", "0.0, 0.0, scale.z", 1),
+    ("vec4(worldPos, 1)", "vec4(worldPos, 1.0)", 1),
+    ("matrixP[0][0] / 2;", "matrixP[0][0] / 2.0;", 1),
+    ("focal / viewPos.z, 0, -(focal * viewPos.x)", "focal / viewPos.z, 0.0, -(focal * viewPos.x)", 1),
+    ("0, focal / viewPos.z, -(focal * viewPos.y)", "0.0, focal / viewPos.z, -(focal * viewPos.y)", 1),
+    ("            0, 0, 0\n", "            0.0, 0.0, 0.0\n", 1),
+]
+ES3_EDITS_SH = [
+    ("(2 * zz - xx - yy)", "(2.0 * zz - xx - yy)", 1),
+    ("(3 * xx - yy)", "(3.0 * xx - yy)", 1),
+    ("(4 * zz - xx - yy)", "(4.0 * zz - xx - yy)", 2),
+    ("(2 * zz - 3 * xx - 3 * yy)", "(2.0 * zz - 3.0 * xx - 3.0 * yy)", 1),
+    ("(xx - 3 * yy)", "(xx - 3.0 * yy)", 1),
+    ("vec3(0,0,0)", "vec3(0.0,0.0,0.0)", 1),
+]
+ES3_EDITS_VS = [
+    (re.compile(r"out parms\s*\{\s*vec4\s+pos;\s*vec3\s+color;\s*float\s+opacity;\s*\}\s*vsOut;"),
+     "out vec4 v_pos; out vec3 v_color; out float v_opacity;", 1),
+    ("vsOut.pos", "v_pos", None), ("vsOut.color", "v_color", None), ("vsOut.opacity", "v_opacity", None),
+    ("vec2 quadPos = vec2(0,0);", "vec2 quadPos = vec2(0.0,0.0);", 1),
+    ("quadPos = vec2(1,0);", "quadPos = vec2(1.0,0.0);", 1),
+    ("quadPos = vec2(0,1);", "quadPos = vec2(0.0,1.0);", 1),
+    ("quadPos = vec2(1,1);", "quadPos = vec2(1.0,1.0);", 1),
+    ("quadPos = (quadPos * 2) - 1;", "quadPos = (quadPos * 2.0) - 1.0;", 1),
+    ("quadPos *= 2;", "quadPos *= 2.0;", 1),
+    ("mat4(1,0,0,0,0,-1,0,0,0,0,1,0,0,0,0,1)", "mat4(1.0,0.0,0.0,0.0,0.0,-1.0,0.0,0.0,0.0,0.0,1.0,0.0,0.0,0.0,0.0,1.0)", 1),
+    ("vec4(centerViewPos, 1)", "vec4(centerViewPos, 1.0)", 1),
+    ("centerClipPos.w <= 0)", "centerClipPos.w <= 0.0)", 1),
+    ("gl_Position = vec4(0,0,0,0);", "gl_Position = vec4(0.0,0.0,0.0,0.0);", 1),
+    ("vec4(quadPos, 0, 1)", "vec4(quadPos, 0.0, 1.0)", 1),
+    ("* 2 / glH_ScreenSize", "* 2.0 / glH_ScreenSize", 1),
+]
+ES3_EDITS_FS = [
+    (re.compile(r"in parms\s*\{\s*vec4\s+pos;\s*vec3\s+color;\s*float\s+opacity;\s*\}\s*fsIn;"),
+     "in vec4 v_pos; in vec3 v_color; in float v_opacity;", 1),
+    ("fsIn.pos", "v_pos", None), ("fsIn.color", "v_color", None), ("fsIn.opacity", "v_opacity", None),
+]
+ES3_HEADER = ("#version 300 es\nprecision highp float;\nprecision highp int;\n"
+              "precision highp sampler2D;\nprecision highp isampler2D;\n")
+
+
+def _apply(text: str, edits) -> str:
+    for pat, rep, cnt in edits:
+        if isinstance(pat, str):
+            n = text.count(pat)
+            assert n > 0 and (cnt is None or n == cnt), f"edit pattern {pat!r}: found {n}, expected {cnt}"
+            text = text.replace(pat, rep)
+        else:
+            text, n = pat.subn(rep, text)
+            assert n == cnt, f"edit pattern {pat.pattern!r}: found {n}, expected {cnt}"
+    return text
+
+
+def reference_shaders() -> tuple[str, str]:
+    core_h = open(os.path.join(REF, "GSplatShaderCoreLib.h")).read()
+    src_h = open(os.path.join(REF, "GSplatShaderSource.h")).read()
+    core = _apply(_raw_literal(core_h, "GSplatCoreLib"), ES3_EDITS_CORE)
+    sh = _apply(_raw_literal(core_h, "GSplatSphericalHarmonicsLib"), ES3_EDITS_SH)
+    vs = _apply(_raw_literal(src_h, "_GSplatMainVertexShader"), ES3_EDITS_VS)
+    fs = _apply(_raw_literal(src_h, "_GSplatMainFragmentShader"), ES3_EDITS_FS)
+    # same assembly order as getFullShaderSrc("330", {core, sh, vs}) / {fs}  (GSplatShaderSource.h:9-15,291,315)
+    return ES3_HEADER + core + sh + vs, ES3_HEADER + fs
+
+
+# ----------------------------------------------------------------------------- EGL / GLES3
+GL_VERTEX_SHADER, GL_FRAGMENT_SHADER, GL_COMPILE_STATUS, GL_LINK_STATUS = 0x8B31, 0x8B30, 0x8B81, 0x8B82
+GL_TEXTURE_2D, GL_RGBA32F, GL_RGB16F, GL_R32I = 0x0DE1, 0x8814, 0x881B, 0x8235
+GL_RGBA, GL_RGB, GL_RED_INTEGER, GL_FLOAT, GL_HALF_FLOAT, GL_INT = 0x1908, 0x1907, 0x8D94, 0x1406, 0x140B, 0x1404
+GL_TEXTURE_MIN_FILTER, GL_TEXTURE_MAG_FILTER, GL_NEAREST = 0x2801, 0x2800, 0x2600
+GL_TEXTURE_WRAP_S, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE = 0x2802, 0x2803, 0x812F
+GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_FRAMEBUFFER_COMPLETE = 0x8D40, 0x8CE0, 0x8CD5
+GL_BLEND, GL_ONE_MINUS_DST_ALPHA, GL_ONE, GL_FUNC_ADD = 0x0BE2, 0x0305, 1, 0x8006
+GL_TRIANGLES, GL_COLOR_BUFFER_BIT, GL_TEXTURE0 = 4, 0x4000, 0x84C0
+GL_UNPACK_ALIGNMENT, GL_PACK_ALIGNMENT, GL_DEPTH_TEST, GL_CULL_FACE = 0x0CF5, 0x0D05, 0x0B71, 0x0B44
+
+
+class GLES:
+    def __init__(self):
+        self.gl = C.CDLL(os.path.join(SWS, "libGLESv2.so"), mode=C.RTLD_GLOBAL)
+        self.egl = C.CDLL(os.path.join(SWS, "libEGL.so"), mode=C.RTLD_GLOBAL)
+        egl = self.egl
+        egl.eglGetDisplay.restype = C.c_void_p
+        egl.eglGetDisplay.argtypes = [C.c_void_p]
+        egl.eglCreatePbufferSurface.restype = C.c_void_p
+        egl.eglCreateContext.restype = C.c_void_p
+        dpy = egl.eglGetDisplay(None)
+        assert dpy, "eglGetDisplay failed"
+        major, minor = C.c_int(), C.c_int()
+        assert egl.eglInitialize(C.c_void_p(dpy), C.byref(major), C.byref(minor))
+        cfg_attr = (C.c_int * 13)(0x3033, 0x0001, 0x3040, 0x0040, 0x3024, 8, 0x3023, 8, 0x3022, 8, 0x3021, 8, 0x3038)
+        cfg, ncfg = C.c_void_p(), C.c_int()
+        assert egl.eglChooseConfig(C.c_void_p(dpy), cfg_attr, C.byref(cfg), 1, C.byref(ncfg)) and ncfg.value >= 1
+        surf = egl.eglCreatePbufferSurface(C.c_void_p(dpy), cfg, (C.c_int * 5)(0x3057, 16, 0x3056, 16, 0x3038))
+        assert surf
+        assert egl.eglBindAPI(0x30A0)
+        ctx = egl.eglCreateContext(C.c_void_p(dpy), cfg, None, (C.c_int * 3)(0x3098, 3, 0x3038))
+        assert ctx, "no GLES3 context"
+        assert egl.eglMakeCurrent(C.c_void_p(dpy), C.c_void_p(surf), C.c_void_p(surf), C.c_void_p(ctx))
+        self.gl.glGetString.restype = C.c_char_p
+        self.version = self.gl.glGetString(0x1F02).decode()
+        self.renderer = self.gl.glGetString(0x1F01).decode()
+        self.gl.glGetUniformLocation.argtypes = [C.c_uint, C.c_char_p]
+        self.gl.glUniform2f.argtypes = [C.c_int, C.c_float, C.c_float]
+        self.gl.glUniform3f.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float]
+        self.gl.glClearColor.argtypes = [C.c_float] * 4
+
+    def check(self, where=""):
+        e = self.gl.glGetError()
+        assert e == 0, f"GL error {hex(e)} {where}"
+
+    def shader(self, kind, text):
+        gl = self.gl
+        s = gl.glCreateShader(kind)
+        src = C.c_char_p(text.encode())
+        gl.glShaderSource(s, 1, C.byref(src), None)
+        gl.glCompileShader(s)
+        ok = C.c_int()
+        gl.glGetShaderiv(s, GL_COMPILE_STATUS, C.byref(ok))
+        if not ok.value:
+            log = C.create_string_buffer(8192)
+            gl.glGetShaderInfoLog(s, 8192, None, log)
+            raise RuntimeError("shader compile failed:\n" + log.value.decode())
+        return s
+
+    def program(self, vs_text, fs_text, tf_varyings=None):
+        gl = self.gl
+        p = gl.glCreateProgram()
+        gl.glAttachShader(p, self.shader(GL_VERTEX_SHADER, vs_text))
+        gl.glAttachShader(p, self.shader(GL_FRAGMENT_SHADER, fs_text))
+        if tf_varyings:
+            arr = (C.c_char_p * len(tf_varyings))(*[v.encode() for v in tf_varyings])
+            gl.glTransformFeedbackVaryings(p, len(tf_varyings), arr, 0x8C8C)  # GL_INTERLEAVED_ATTRIBS
+        gl.glLinkProgram(p)
+        ok = C.c_int()
+        gl.glGetProgramiv(p, GL_LINK_STATUS, C.byref(ok))
+        if not ok.value:
+            log = C.create_string_buffer(8192)
+            gl.glGetProgramInfoLog(p, 8192, None, log)
+            raise RuntimeError("program link failed:\n" + log.value.decode())
+        return p
+
+    def texture(self, unit, internal, w, h, fmt, typ, data: np.ndarray):
+        gl = self.gl
+        t = C.c_uint()
+        gl.glGenTextures(1, C.byref(t))
+        gl.glActiveTexture(GL_TEXTURE0 + unit)
+        gl.glBindTexture(GL_TEXTURE_2D, t)
+        gl.glPixelStorei(GL_UNPACK_ALIGNMENT, 1)
+        data = np.ascontiguousarray(data)
+        gl.glTexImage2D(GL_TEXTURE_2D, 0, internal, w, h, 0, fmt, typ, C.c_void_p(data.ctypes.data))
+        for pn, v in ((GL_TEXTURE_MIN_FILTER, GL_NEAREST), (GL_TEXTURE_MAG_FILTER, GL_NEAREST),
+                      (GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE), (GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE)):
+            gl.glTexParameteri(GL_TEXTURE_2D, pn, v)
+        self.check("texture")
+        return t
+
+
+def closest_sqrt_pow2(n: int) -> int:  # src/GSplatRenderer.C:155-163
+    if n <= 1:
+        return 2
+    return int(2 ** int(np.ceil(np.log2(np.float32(np.sqrt(np.float32(n)))))))
+
+
+def h2f(bits: np.ndarray) -> np.ndarray:
+    return bits.view(np.float16).astype(np.float32)
+
+
+def render_reference_glsl(es: GLES, splats, cam, origin, perm, ss: int = 1):
+    """One frame of the reference's main program on SwiftShader.
+
+    ss (odd): the viewport/FBO is ss x larger than glH_ScreenSize while the uniform keeps the
+    nominal size, and only the hi-res pixels whose centres coincide with nominal pixel centres
+    (ss*i + ss//2) are kept.  Every shader input is unchanged, so each kept sample is exactly the
+    fragment a nominal-resolution rasteriser would shade -- but SwiftShader's 4-bit sub-pixel
+    vertex snapping (1/16 px) shrinks to 1/(16*ss) nominal px, i.e. ss=15 emulates the 8-bit
+    sub-pixel precision of hardware rasterisers.
+    Returns (image float32 [H,W,4] row 0 = bottom, vertex-stage capture float32 [n,6,12]:
+    gl_Position xyzw, v_pos xyzw, v_color rgb, v_opacity -- in INSTANCE (sorted) order)."""
+    assert ss % 2 == 1
+    gl = es.gl
+    n = splats.n
+    # (the reference skips the index upload when N is exactly 4^k -- SURVEY Q2; this harness always uploads)
+    vs, fs = reference_shaders()
+    prog = es.program(vs, fs, tf_varyings=["gl_Position", "v_pos", "v_color", "v_opacity"])
+    gl.glUseProgram(prog)
+    origin = np.asarray(origin, np.float32)
+
+    # ---- textures exactly as generateRenderGeometry packs them (:448-505)
+    dim_a = closest_sqrt_pow2(n * 4)
+    a = np.zeros((dim_a * dim_a, 4), np.float32)
+    a[0:4 * n:4, :3] = splats.P - origin          # fl32(P - origin), pad 0
+    a[1:4 * n:4, :3] = h2f(splats.Cd)
+    a[1:4 * n:4, 3] = splats.alpha
+    a[2:4 * n:4, :3] = h2f(splats.scale)
+    a[3:4 * n:4, :] = h2f(splats.orient)
+    es.texture(1, GL_RGBA32F, dim_a, dim_a, GL_RGBA, GL_FLOAT, a)
+    order = cam.sh_order if splats.has_sh else 0
+    dim_sh = 0
+    if splats.has_sh:
+        dim_sh = closest_sqrt_pow2(n * 8)
+        t1 = np.zeros((dim_sh * dim_sh, 3), np.uint16)
+        t2 = np.zeros((dim_sh * dim_sh, 3), np.uint16)
+        sh = np.stack([splats.shx[:, :15], splats.shy[:, :15], splats.shz[:, :15]], axis=2)  # [n,15,3]
+        for j in range(8):
+            t1[j:8 * n:8] = sh[:, j]
+        for j in range(8, 15):
+            t2[j - 8:8 * n:8] = sh[:, j]
+        es.texture(2, GL_RGB16F, dim_sh, dim_sh, GL_RGB, GL_HALF_FLOAT, t1)
+        es.texture(3, GL_RGB16F, dim_sh, dim_sh, GL_RGB, GL_HALF_FLOAT, t2)
+    dim_i = closest_sqrt_pow2(n)
+    idx = np.zeros(dim_i * dim_i, np.int32)
+    idx[:n] = perm
+    es.texture(0, GL_R32I, dim_i, dim_i, GL_RED_INTEGER, GL_INT, idx)
+
+    # ---- uniforms (:625-645 + Houdini built-ins consumed by the shader)
+    def loc(name):
+        return gl.glGetUniformLocation(prog, name.encode())
+
+    def u1i(name, v):
+        if loc(name) >= 0:
+            gl.glUniform1i(loc(name), int(v))
+
+    def umat(name, m):
+        if loc(name) >= 0:
+            arr = np.ascontiguousarray(m, np.float32)
+            gl.glUniformMatrix4fv(loc(name), 1, 0, C.c_void_p(arr.ctypes.data))
+
+    u1i("GSplatCount", n)
+    u1i("GSplatVertexCount", 6)
+    gl.glUniform3f(loc("GSplatOrigin"), float(origin[0]), float(origin[1]), float(origin[2]))
+    u1i("GSplatShOrder", order)
+    u1i("GSplatZOrderTexDim", dim_i)
+    u1i("GSplatZOrderIntegerTexSampler", 0)
+    u1i("GSplatPosColorAlphaScaleOrientTexDim", dim_a)
+    u1i("GSplatPosColorAlphaScaleOrientTexSampler", 1)
+    if order > 0:
+        gl.glUniform3f(loc("WorldSpaceCameraPos"), *[float(x) for x in cam.cam_pos])
+        u1i("GSplatShDeg1And2TexDim", dim_sh)
+        u1i("GSplatShDeg1And2TexSampler", 2)
+        if order > 2:
+            u1i("GSplatShDeg3TexDim", dim_sh)
+            u1i("GSplatShDeg3TexSampler", 3)
+    umat("glH_ObjViewMatrix", cam.obj_view)
+    umat("glH_ObjectMatrix", cam.object)
+    umat("glH_InvObjectMatrix", cam.inv_object)
+    umat("glH_ViewMatrix", cam.view)
+    umat("glH_ProjectMatrix", cam.proj)
+    gl.glUniform2f(loc("glH_ScreenSize"), float(cam.width), float(cam.height))
+    es.check("uniforms")
+
+    # ---- float render target cleared to transparent black
+    fb_tex = C.c_uint()
+    gl.glGenTextures(1, C.byref(fb_tex))
+    gl.glActiveTexture(GL_TEXTURE0 + 7)
+    gl.glBindTexture(GL_TEXTURE_2D, fb_tex)
+    gl.glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA32F, cam.width * ss, cam.height * ss, 0, GL_RGBA, GL_FLOAT, None)
+    fbo = C.c_uint()
+    gl.glGenFramebuffers(1, C.byref(fbo))
+    gl.glBindFramebuffer(GL_FRAMEBUFFER, fbo)
+    gl.glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, fb_tex, 0)
+    assert gl.glCheckFramebufferStatus(GL_FRAMEBUFFER) == GL_FRAMEBUFFER_COMPLETE, "RGBA32F FBO incomplete"
+    gl.glViewport(0, 0, cam.width * ss, cam.height * ss)
+    gl.glClearColor(0.0, 0.0, 0.0, 0.0)
+    gl.glClear(GL_COLOR_BUFFER_BIT)
+
+    # ---- GL state (:605-621): no depth attachment (nothing opaque in front), no culling
+    gl.glDisable(GL_DEPTH_TEST)
+    gl.glDisable(GL_CULL_FACE)
+    gl.glEnable(GL_BLEND)
+    gl.glBlendFuncSeparate(GL_ONE_MINUS_DST_ALPHA, GL_ONE, GL_ONE_MINUS_DST_ALPHA, GL_ONE)
+    gl.glBlendEquation(GL_FUNC_ADD)
+    vao = C.c_uint()
+    gl.glGenVertexArrays(1, C.byref(vao))
+    gl.glBindVertexArray(vao)
+    # vertex-stage capture (transform feedback), 12 floats per vertex
+    tfb = C.c_uint()
+    gl.glGenBuffers(1, C.byref(tfb))
+    GL_TFB = 0x8C8E
+    gl.glBindBuffer(GL_TFB, tfb)
+    nbytes = n * 6 * 12 * 4
+    gl.glBufferData(GL_TFB, C.c_ssize_t(nbytes), None, 0x88E9)  # GL_DYNAMIC_READ
+    gl.glBindBufferBase(GL_TFB, 0, tfb)
+    gl.glBeginTransformFeedback(GL_TRIANGLES)
+    gl.glDrawArraysInstanced(GL_TRIANGLES, 0, 6, n)  # drawInstanced(..., splatCount) :647
+    gl.glEndTransformFeedback()
+    gl.glFinish()
+    es.check("draw")
+    gl.glMapBufferRange.restype = C.c_void_p
+    gl.glMapBufferRange.argtypes = [C.c_uint, C.c_ssize_t, C.c_ssize_t, C.c_uint]
+    ptr = gl.glMapBufferRange(GL_TFB, 0, nbytes, 0x0001)  # GL_MAP_READ_BIT
+    assert ptr, "transform feedback buffer map failed"
+    vs_out = np.frombuffer((C.c_float * (n * 72)).from_address(ptr), dtype=np.float32).reshape(n, 6, 12).copy()
+    gl.glUnmapBuffer(GL_TFB)
+    hi = np.zeros((cam.height * ss, cam.width * ss, 4), np.float32)
+    gl.glPixelStorei(GL_PACK_ALIGNMENT, 1)
+    gl.glReadPixels(0, 0, cam.width * ss, cam.height * ss, GL_RGBA, GL_FLOAT, C.c_void_p(hi.ctypes.data))
+    es.check("readpixels")
+    gl.glBindFramebuffer(GL_FRAMEBUFFER, 0)
+    out = np.ascontiguousarray(hi[ss // 2::ss, ss // 2::ss])
+    assert out.shape == (cam.height, cam.width, 4)
+    return out, vs_out
+
+
+# ----------------------------------------------------------------------------- cases
+def cases(pkg):
+    sc, cm = pkg.scenes, pkg.camera
+    out = []
+    # G1: one isolated splat near the view centre, order 0 (KAT: centre alpha = opacity * exp(-|q|^2))
+    # (5 points, 4 of them far behind the camera: with a single point the reference's 2x2 attribute
+    #  texture is too narrow for its own iuv+ivec2(2,0) fetches)
+    s = sc.make_scene(5, seed=3, sh=False)
+    cam1 = cm.make_camera(64, 64, sh_order=0, frame=0)
+    s.P[:] = np.float32(cam1.cam_pos) * np.float32(3.0)
+    s.P[2] = np.float32([0.03, -0.02, 0.1])
+    s.scale[2] = sc.f16bits(np.float32([0.05, 0.02, 0.03]))
+    s.alpha[:] = 0.8
+    out.append(("g1_single", s, cam1, (0, 0, 0), 15))
+    # G2: small SH3 cloud
+    out.append(("g2_sh3_200", sc.make_scene(200, seed=12, sh=True, log_scale_range=(-4.0, -2.5)),
+                cm.make_camera(128, 96, sh_order=3, frame=0), (0, 0, 0), 15))
+    # G3: 2000 splats SH3, orbit frame 2
+    out.append(("g3_sh3_2000", sc.make_scene(2000, seed=13, sh=True, log_scale_range=(-4.5, -3.0)),
+                cm.make_camera(256, 192, sh_order=3, frame=2), (0, 0, 0), 9))
+    # G4: camera INSIDE the cloud (w<=0 and near-plane culls), SH order 1, non-zero GSplatOrigin
+    s = sc.make_scene(1500, seed=14, sh=True, log_scale_range=(-4.5, -3.0))
+    out.append(("g4_inside_sh1", s, cm.make_camera(200, 150, sh_order=1, frame=5, distance=0.4, near=0.05),
+                tuple(float(x) for x in s.barycenter()), 9))
+    # G5: SH order 2, opaque-ish splats (occlusion / blend order)
+    s = sc.make_scene(1200, seed=15, sh=True, log_scale_range=(-3.5, -2.5))
+    s.alpha[:] = np.clip(s.alpha * 1.6, 0, 1)
+    out.append(("g5_sh2_opaque", s, cm.make_camera(160, 160, sh_order=2, frame=9), (0, 0, 0), 15))
+    # G6: object matrix != identity (rotation+non-uniform scale) -- exercises O and O^-1 paths
+    ang = 0.6
+    obj = np.array([[np.cos(ang) * 1.2, -np.sin(ang), 0, 0.1], [np.sin(ang) * 1.2, np.cos(ang), 0, -0.05],
+                    [0, 0, 0.8, 0.02], [0, 0, 0, 1]], dtype=np.float64)
+    out.append(("g6_object_xform", sc.make_scene(800, seed=16, sh=True, log_scale_range=(-4.0, -2.8)),
+                cm.make_camera(160, 120, sh_order=3, frame=1, object_matrix=obj), (0, 0, 0), 15))
+    # C1: BASELINE config 0 -- 10k isotropic splats, SH degree 0, 512x512
+    s, cfg = sc.make_config("C1")
+    out.append(("c1_10k_iso", s, cm.make_camera(cfg["width"], cfg["height"], sh_order=0, frame=0), (0, 0, 0), 5))
+    return out
+
+
+def main():
+    pkg = ge.load_package()
+    oracle = ge.load_oracle()
+    es = GLES()
+    print("GL:", es.version, "|", es.renderer)
+    summary = []
+    for name, splats, cam, origin, ss in cases(pkg):
+        rec = oracle.preprocess(splats, cam, origin)
+        perm = oracle.argsort(rec)  # (distance^2, index) ascending = the order the reference's argsort would upload
+        img_gl, vs_sorted = render_reference_glsl(es, splats, cam, origin, perm, ss)
+        img_nominal, _ = render_reference_glsl(es, splats, cam, origin, perm, 1)
+        vs_out = np.empty_like(vs_sorted)
+        vs_out[perm] = vs_sorted            # back to splat order
+        img_or = oracle.render(splats, cam, origin)
+        e1 = np.abs(img_nominal - img_or)
+        print("   nominal-resolution raster (4-bit sub-pixel): max", float(e1.max()), "mean", float(e1.mean()),
+              "frac<=1e-3", float((e1.max(axis=2) <= 1e-3).mean()))
+        err = np.abs(img_gl - img_or)
+        frac_ok = float((err.max(axis=2) <= 1e-3).mean())
+        stats = dict(name=name, n=splats.n, size=(cam.width, cam.height), ss=ss, max_err=float(err.max()),
+                     mean_err=float(err.mean()),
+                     frac_pixels_within_1e3=frac_ok, p999=float(np.quantile(err, 0.999)),
+                     covered=float((img_or[..., 3] > 0).mean()))
+        print(stats)
+        summary.append(stats)
+        arrays = dict(P=splats.P, Cd=splats.Cd, alpha=splats.alpha, scale=splats.scale, orient=splats.orient,
+                      origin=np.asarray(origin, np.float32), image_reference_glsl=img_gl,
+                      image_reference_glsl_nominal=img_nominal.astype(np.float16), supersample=np.int32(ss),
+                      vs_out=vs_out,
+                      oracle_sha256=np.frombuffer(hashlib.sha256(img_or.tobytes()).digest(), dtype=np.uint8),
+                      cam_obj_view=cam.obj_view, cam_object=cam.object, cam_inv_object=cam.inv_object,
+                      cam_view=cam.view, cam_proj=cam.proj, cam_pos=cam.cam_pos,
+                      cam_whs=np.int32([cam.width, cam.height, cam.sh_order]))
+        if splats.has_sh:
+            arrays.update(shx=splats.shx, shy=splats.shy, shz=splats.shz)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    return summary
+
+
+if __name__ == "__main__":
+    main()

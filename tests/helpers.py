@@ -1,0 +1,47 @@
+"""shared helpers for the test-suite (loading golden fixtures)"""
+import glob
+import os
+import types
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    d = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    s = types.SimpleNamespace(P=d["P"], Cd=d["Cd"], alpha=d["alpha"], scale=d["scale"], orient=d["orient"],
+                              shx=d["shx"] if "shx" in d else None, shy=d["shy"] if "shy" in d else None,
+                              shz=d["shz"] if "shz" in d else None)
+    s.n = s.P.shape[0]
+    w, h, order = [int(x) for x in d["cam_whs"]]
+    c = types.SimpleNamespace(obj_view=d["cam_obj_view"], object=d["cam_object"], inv_object=d["cam_inv_object"],
+                              view=d["cam_view"], proj=d["cam_proj"], cam_pos=d["cam_pos"], width=w, height=h,
+                              sh_order=order)
+    return d, s, c
+
+
+# Acceptance of an image against the reference-GLSL golden (SwiftShader, supersampled so that its
+# vertex snapping matches 8-bit sub-pixel hardware).  A rasteriser decides coverage of pixels that
+# sit exactly on a quad edge by its own fixed-point rules, so a small set of edge pixels differs by
+# up to opacity*exp(-4) ~ 0.018 no matter what; everything else must be inside
+# the north-star tolerance of 1e-3 per channel.
+GOLDEN_TOL = 1e-3
+GOLDEN_MIN_FRAC = 0.998      # >= 99.8 % of pixels within 1e-3 on every channel
+GOLDEN_MAX_OUTLIER = 0.02    # edge-flip bound: exp(-4) * opacity * T
+GOLDEN_MEAN = 1e-4
+
+
+def check_against_golden(img, golden_img):
+    err = np.abs(img.astype(np.float64) - golden_img.astype(np.float64))
+    frac = float((err.max(axis=2) <= GOLDEN_TOL).mean())
+    assert frac >= GOLDEN_MIN_FRAC, f"only {frac:.5f} of pixels within {GOLDEN_TOL}"
+    assert err.max() <= GOLDEN_MAX_OUTLIER, f"outlier {err.max()} exceeds the edge-flip bound"
+    assert err.mean() <= GOLDEN_MEAN, f"mean abs error {err.mean()}"
+    signed = float((img.astype(np.float64) - golden_img).mean())
+    assert abs(signed) <= 2e-5, f"biased by {signed}"
+    return frac, float(err.max()), float(err.mean())

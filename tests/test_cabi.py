@@ -1,0 +1,96 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol the
+headers declare; without a GPU the product fails loudly (there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    if "extern \"C\" {" in text and header == "GSplatRenderer.h":
+        text = text[text.index("extern \"C\" {"):]          # the flat wrappers only (class members are C++)
+    return sorted(set(re.findall(r"\b(gsr_[a-z0-9_]+|gsplat_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.load_library()
+    declared = set(_declared("gsplat_hip.h")) | set(_declared("GSplatRenderer.h"))
+    assert len(declared) >= 40
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+    assert declared == set(pkg.engine.C_ABI_SYMBOLS), declared ^ set(pkg.engine.C_ABI_SYMBOLS)
+    assert L.gsr_version().decode().startswith("gsplat_hip")
+
+
+def test_structs_match_the_header(pkg):
+    e = pkg.engine
+    assert C.sizeof(e.gsr_camera) == 5 * 64 + 12 + 12
+    assert C.sizeof(e.gsr_debug_record) == 56
+    # gsr_stats layout: parse field order from the header
+    text = open(os.path.join(ROOT, "include", "gsplat_hip.h")).read()
+    body = text[text.index("typedef struct gsr_stats {") + len("typedef struct gsr_stats {"):text.index("} gsr_stats;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        m = re.match(r"(int64_t|int32_t|float|double)\s+(.*)", decl)
+        if m:
+            names += [x.strip() for x in m.group(2).split(",")]
+    assert names == [n for n, _ in e.gsr_stats._fields_]
+
+
+def test_fails_loudly_without_a_gpu(pkg):
+    L = pkg.load_library()
+    if L.gsr_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(pkg.GsrError) as ei:
+        pkg.Engine(0)
+    assert ei.value.code == -3 and "no HIP device" in str(ei.value)
+    with pytest.raises(pkg.GsrError):
+        pkg.GSplatRenderer(0)
+
+
+def test_argument_validation_needs_no_gpu(pkg):
+    L = pkg.load_library()
+    assert L.gsr_render(None, None, None, 0) == -1
+    assert b"NULL" in L.gsr_last_error()
+    assert L.gsr_band_rows(1080, 0, 1) == 68 * 16
+    assert L.gsr_band_rows(1080, 3, 8) == 9 * 16
+    assert L.gsr_band_rows(0, 0, 1) == 0
+    assert L.gsr_set_row_shard(None, 0, 1) == -1
+
+
+def test_ingest_helpers_match_numpy(pkg):
+    """fp32 -> fp16 RNE and the three SH encodings of GR_PrimGsplat::update (src/GR_GSplat.C:302-372)"""
+    L = pkg.load_library()
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.normal(0, 1, 4000), rng.normal(0, 1e-6, 500), rng.normal(0, 4e4, 500),
+                        [0, -0.0, 65504, 65520, 1e7, 2.98e-8, 6e-8]]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(pkg.engine.quantize_half(x), x.astype(np.float16).view(np.uint16))
+    n = 37
+    fr = rng.normal(0, 0.1, (45, n)).astype(np.float32)           # f_rest_0..44, channel-major
+    out = [np.full((n, 16), 0xFFFF, np.uint16) for _ in range(3)]
+    ptrs = (C.c_void_p * 45)(*[fr[k].ctypes.data for k in range(45)])
+    L.gsplat_pack_sh_from_frest(ptrs, n, *[o.ctypes.data for o in out])
+    for ch in range(3):
+        assert np.array_equal(out[ch][:, :15], fr[15 * ch:15 * ch + 15].T.astype(np.float16).view(np.uint16))
+        assert (out[ch][:, 15] == 0).all()
+    sh = rng.normal(0, 0.1, (15, n, 3)).astype(np.float32)        # sh1..sh15 vec3 attributes
+    out2 = [np.full((n, 16), 0xFFFF, np.uint16) for _ in range(3)]
+    ptrs = (C.c_void_p * 15)(*[sh[k].ctypes.data for k in range(15)])
+    L.gsplat_pack_sh_from_vec3(ptrs, n, *[o.ctypes.data for o in out2])
+    for ch in range(3):
+        assert np.array_equal(out2[ch][:, :15], sh[:, :, ch].T.astype(np.float16).view(np.uint16))
+    arr = np.ascontiguousarray(sh.transpose(1, 0, 2))             # sh_coefficients array attribute [n][15][3]
+    out3 = [np.full((n, 16), 0xFFFF, np.uint16) for _ in range(3)]
+    L.gsplat_pack_sh_from_array(arr.ctypes.data, n, 15, *[o.ctypes.data for o in out3])
+    for ch in range(3):
+        assert np.array_equal(out3[ch], out2[ch])

@@ -1,0 +1,156 @@
+"""CPU tests: the oracle against the golden vectors that pin it.
+
+The goldens are outputs of the REFERENCE'S OWN GLSL program executed on a software GLES3
+rasteriser in the build container (tests/golden/make_goldens.py); the reference ships no tests
+of its own.  Two layers are pinned:
+  * vertex stage  -- captured with transform feedback, compared per splat at float precision
+  * fragment stage + blend -- rendered images, compared per pixel (tolerance: helpers.py)
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from helpers import check_against_golden, golden_names, load_golden
+
+NAMES = golden_names()
+
+
+def test_goldens_are_present():
+    assert len(NAMES) >= 7
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_image_matches_reference_glsl(oracle, name):
+    d, s, c = load_golden(name)
+    img = oracle.render(s, c, d["origin"])
+    check_against_golden(img, d["image_reference_glsl"])
+    # regression pin of the oracle itself (deterministic IEEE arithmetic)
+    assert hashlib.sha256(img.tobytes()).digest() == d["oracle_sha256"].tobytes()
+    # the strip-parallel renderer is the same function, bit for bit
+    assert np.array_equal(img, oracle.render(s, c, d["origin"], threads=4))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_vertex_stage_matches_reference_glsl(oracle, name):
+    d, s, c = load_golden(name)
+    vs = d["vs_out"]                      # [n, 6 vertices, (gl_Position xyzw, v_pos xyzw, v_color rgb, v_opacity)]
+    rec = oracle.preprocess(s, c, d["origin"])
+    pos, w = vs[:, :, 0:4], vs[:, :, 3]
+    # culling: the shader zeroes gl_Position for w<=0 (GSplatShaderSource.h:209-214); GL clips z outside [-w,w]
+    gl_visible = (w[:, 0] > 0) & (pos[:, 0, 2] >= -w[:, 0]) & (pos[:, 0, 2] <= w[:, 0])
+    assert np.array_equal(gl_visible, rec["visible"] == 1)
+    m = gl_visible
+    if not m.any():
+        return
+    # corner map (GSplatShaderSource.h:168-188)
+    expect = np.float32([[2, -2], [2, 2], [-2, -2], [-2, 2], [-2, -2], [2, 2]])
+    assert np.array_equal(vs[m][:, :, 4:6], np.broadcast_to(expect, (m.sum(), 6, 2)))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        win = np.stack([(pos[:, :, 0] / w * 0.5 + 0.5) * c.width, (pos[:, :, 1] / w * 0.5 + 0.5) * c.height], axis=2)
+    ctr = (win[:, 1] + win[:, 2]) / 2                      # corners (+2,+2) and (-2,-2)
+    a1 = (win[:, 0] - win[:, 2]) / 4                       # (+2,-2) - (-2,-2) = 4 * axis1
+    a2 = (win[:, 1] - win[:, 0]) / 4                       # (+2,+2) - (+2,-2) = 4 * axis2
+    s1, s2 = np.linalg.norm(a1, axis=1), np.linalg.norm(a2, axis=1)
+    px_tol = 2e-5 * max(c.width, c.height) + 4e-6 * np.abs(ctr[m]).max()
+    assert np.abs(ctr[m, 0] - rec["cx"][m]).max() <= max(px_tol, 2e-3)
+    assert np.abs(ctr[m, 1] - rec["cy"][m]).max() <= max(px_tol, 2e-3)
+    assert (np.abs(s1[m] * rec["is1"][m] - 1) <= 3e-5).all()
+    assert (np.abs(s2[m] * rec["is2"][m] - 1) <= 3e-5).all()
+    # axis directions where they are well defined (anisotropic in screen space)
+    an = m & (s1 > 1.05 * s2)
+    if an.any():
+        e = a1[an] / s1[an, None]
+        assert (np.abs(e[:, 0] * rec["ex"][an] + e[:, 1] * rec["ey"][an] - 1) <= 2e-6).all()   # same sign too
+        ep = a2[an] / s2[an, None]
+        assert (np.abs(ep[:, 0] * -rec["ey"][an] + ep[:, 1] * rec["ex"][an] - 1) <= 2e-6).all()
+    col, op = vs[:, 0, 8:11], vs[:, 0, 11]
+    for k, f in enumerate(("r", "g", "b")):
+        assert np.abs(col[m, k] - rec[f][m]).max() <= 1e-6
+    assert np.array_equal(op[m], rec["opacity"][m])
+
+
+def test_known_answers_from_the_source(oracle):
+    # closestSqrtPowerOf2 (src/GSplatRenderer.C:155-163), values read off the source
+    for n, want in ((0, 2), (1, 2), (10_000, 128), (40_000, 256), (1_000_000, 1024), (6_000_000, 4096),
+                    (24_000_000, 8192)):
+        assert oracle.closest_sqrt_power_of_2(n) == want
+    # binary16 conversions are IEEE round-to-nearest-even (what HDK fpreal16 does)
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.normal(0, 1, 5000), rng.normal(0, 1e-6, 2000), rng.normal(0, 3e4, 2000),
+                         [0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e9, 2.98e-8, 2.9802322e-08, 6e-8, 6.1035156e-05]])
+    xs = xs.astype(np.float32)
+    with np.errstate(over="ignore"):
+        want = xs.astype(np.float16).view(np.uint16)
+    got = np.array([oracle.float_to_half(float(x)) for x in xs], dtype=np.uint16)
+    assert np.array_equal(got, want)
+    allh = np.arange(0, 0x7c00, 7, dtype=np.uint16)
+    back = np.array([oracle.half_to_float(int(h)) for h in allh], dtype=np.float32)
+    assert np.array_equal(back, allh.view(np.float16).astype(np.float32))
+    # the contract's exp(): <= 3 ulp over the range the fragment stage uses, exp(0) == 1, monotone
+    x = np.linspace(-8.0, 0.0, 20001).astype(np.float32)
+    y = np.array([oracle.expf(float(v)) for v in x], dtype=np.float64)
+    assert np.abs(y / np.exp(x.astype(np.float64)) - 1).max() < 4e-7
+    assert oracle.expf(0.0) == 1.0 and (np.diff(y) >= 0).all() and y.max() <= 1.0
+
+
+def test_single_splat_centre_alpha(oracle, pkg):
+    """an isolated splat: alpha at a pixel = clamp(opacity * exp(-|q|^2)) (GSplatShaderSource.h:304-312)"""
+    d, s, c = load_golden("g1_single")
+    rec = oracle.preprocess(s, c, d["origin"])
+    i = int(np.flatnonzero(rec["visible"])[0])
+    r = rec[i]
+    img = oracle.render(s, c, d["origin"])
+    ys, xs = np.nonzero(img[..., 3] > 0)
+    assert len(ys) > 4
+    for y, x in zip(ys, xs):
+        dx, dy = x + 0.5 - float(r["cx"]), y + 0.5 - float(r["cy"])
+        qx = (dx * float(r["ex"]) + dy * float(r["ey"])) * float(r["is1"])
+        qy = (dy * float(r["ex"]) - dx * float(r["ey"])) * float(r["is2"])
+        assert abs(qx) <= 2 + 1e-5 and abs(qy) <= 2 + 1e-5          # square +-2 support in the eigenbasis
+        a = min(max(float(r["opacity"]) * np.exp(-(qx * qx + qy * qy)), 0.0), 1.0)
+        assert a >= 1 / 255 - 1e-6                                     # 1/255 discard
+        assert abs(img[y, x, 3] - a) < 2e-6
+        assert np.allclose(img[y, x, :3], a * np.array([r["r"], r["g"], r["b"]]), atol=2e-6)  # premultiplied
+
+
+def test_opaque_front_splat_hides_everything_behind(oracle, pkg):
+    """blend src=1-dst.a, dst=1 (src/GSplatRenderer.C:613-621): once A == 1 nothing is added"""
+    cam = pkg.camera.make_camera(96, 96, sh_order=0)
+    s = pkg.scenes.make_scene(400, seed=8, sh=False, log_scale_range=(-3.5, -3.0))
+    view_dir = -cam.cam_pos / np.linalg.norm(cam.cam_pos)
+    # one big fully opaque splat in front of the cloud
+    s.P[0] = cam.cam_pos + view_dir * np.float32(2.0)
+    s.scale[0] = pkg.scenes.f16bits(np.float32([0.2, 0.2, 0.2]))
+    s.alpha[0] = 100.0   # clamp(exp(-|q|^2) * opacity, 0, 1) == 1 over most of the quad
+    s.Cd[0] = pkg.scenes.f16bits(np.float32([1.0, 0.0, 0.0]))
+    img = oracle.render(s, cam)
+    front = oracle.render(s.subset(slice(0, 1)), cam)
+    sat = front[..., 3] >= 1.0
+    assert sat.sum() > 20
+    assert np.array_equal(img[sat], front[sat])
+
+
+def test_behind_camera_contributes_nothing(oracle, pkg):
+    cam = pkg.camera.make_camera(64, 64, sh_order=0)
+    s = pkg.scenes.make_scene(500, seed=9, sh=False)
+    s.P[:] += np.float32(20.0) * cam.cam_pos / np.linalg.norm(cam.cam_pos)   # all behind the eye (w <= 0)
+    assert (oracle.preprocess(s, cam)["visible"] == 0).all()
+    assert np.count_nonzero(oracle.render(s, cam)) == 0
+
+
+def test_argsort_is_by_distance_then_index(oracle, pkg):
+    s = pkg.scenes.make_scene(5000, seed=4, sh=False)
+    s.P[100:150] = s.P[200:250]
+    cam = pkg.camera.make_camera(64, 64, sh_order=0, frame=3)
+    perm = oracle.host_sort_only(s.P, cam.cam_pos)
+    d = s.P.astype(np.float32) - cam.cam_pos.astype(np.float32)
+    key = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(np.float32)
+    k = key[perm].astype(np.float64)
+    # sorted up to 1 ulp (the contract's key uses fused multiply-adds), ties by index
+    assert (np.diff(k) >= -2e-6 * k[1:]).all()
+    rec = oracle.preprocess(s, cam)
+    kk = rec["key"][perm]
+    assert (np.diff(kk) >= 0).all()
+    same = np.flatnonzero(np.diff(kk) == 0)
+    assert len(same) >= 40 and (perm[same] < perm[same + 1]).all()

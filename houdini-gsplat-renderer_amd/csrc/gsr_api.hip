@@ -71,7 +71,8 @@ struct gsr_context {
 
     // per-splat frame buffers
     GsrRecord* rec = nullptr;
-    uint32_t *keyA = nullptr, *keyB = nullptr, *idxA = nullptr, *idxB = nullptr;
+    uint32_t *keyA = nullptr, *keyB = nullptr;
+    uint2 *valA = nullptr, *valB = nullptr;      // depth-sort payload: (splat index, packed tile rect)
     uint32_t *rect = nullptr, *cnt = nullptr, *poff = nullptr;
     // scan / sort scratch
     uint32_t* hist = nullptr;
@@ -79,9 +80,9 @@ struct gsr_context {
     uint32_t* partial = nullptr;
     size_t partial_cap = 0;
     // pairs
-    uint32_t *pkA = nullptr, *pkB = nullptr, *pvA = nullptr, *pvB = nullptr;
+    uint32_t *pkA = nullptr, *pkB = nullptr;
+    uint2 *pvA = nullptr, *pvB = nullptr;        // pair payload: (splat index, packed tile rect)
     size_t pair_cap = 0;
-    uint32_t* srect = nullptr;         // rect of every entry of the sorted super-tile lists
     int32_t *sstart = nullptr, *send = nullptr;  // [256 + 1] super-tile ranges
     uint2* tile_work = nullptr;        // per tile: entries scanned, records gathered
     int32_t* tile_map = nullptr;       // blockIdx -> tile (XCD-aware order), -1 = idle block
@@ -96,7 +97,7 @@ struct gsr_context {
     unsigned long long* h_counters = nullptr;  // pinned [2]
 
     int shard_index = 0, shard_count = 1;
-    int opt_swizzle = 1, opt_timing = 1, opt_sort_cache = 1, opt_super = 0;
+    int opt_swizzle = 1, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0;
 
     // depth-sort cache (argsortByDistance semantics)
     bool sort_valid = false;
@@ -181,7 +182,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
 static void free_geometry(gsr_context* c)
 {
     dev_free(c->geoA); dev_free(c->geoB); dev_free(c->col);
-    dev_free(c->rec); dev_free(c->keyA); dev_free(c->keyB); dev_free(c->idxA); dev_free(c->idxB);
+    dev_free(c->rec); dev_free(c->keyA); dev_free(c->keyB); dev_free(c->valA); dev_free(c->valB);
     dev_free(c->rect); dev_free(c->cnt); dev_free(c->poff);
     c->cap = 0; c->n = 0;
 }
@@ -194,7 +195,7 @@ extern "C" void gsr_destroy(gsr_context* c)
     free_geometry(c);
     dev_free(c->hist); dev_free(c->partial);
     dev_free(c->pkA); dev_free(c->pkB); dev_free(c->pvA); dev_free(c->pvB);
-    dev_free(c->srect); dev_free(c->sstart); dev_free(c->send); dev_free(c->tile_work); dev_free(c->tile_map);
+    dev_free(c->sstart); dev_free(c->send); dev_free(c->tile_work); dev_free(c->tile_map);
     dev_free(c->fb);
     dev_free(c->counters); dev_free(c->d_total);
     if (c->h_total) (void)hipHostFree(c->h_total);
@@ -223,6 +224,7 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
     case GSR_OPT_XCD_SWIZZLE: c->opt_swizzle = value ? 1 : 0; break;
     case GSR_OPT_STAGE_TIMING: c->opt_timing = value ? 1 : 0; break;
     case GSR_OPT_SORT_CACHE: c->opt_sort_cache = value ? 1 : 0; c->sort_valid = false; break;
+    case GSR_OPT_DEBUG_FLAGS: c->opt_flags = value; break;
     case GSR_OPT_SUPER_TILE:
         if (value != 0 && (value < 1 || value > 16 || (value & (value - 1))))
             return set_err(GSR_E_INVALID, "gsr_set_option: super-tile edge must be 0 (auto) or 1,2,4,8,16");
@@ -249,7 +251,7 @@ extern "C" int gsr_upload_begin(gsr_context* c, int64_t total, int has_sh, const
         int rc;
         if ((rc = dev_alloc(&c->geoA, cap)) || (rc = dev_alloc(&c->geoB, cap)) || (rc = dev_alloc(&c->col, cap * chunks)) ||
             (rc = dev_alloc(&c->rec, cap)) || (rc = dev_alloc(&c->keyA, cap)) || (rc = dev_alloc(&c->keyB, cap)) ||
-            (rc = dev_alloc(&c->idxA, cap)) || (rc = dev_alloc(&c->idxB, cap)) || (rc = dev_alloc(&c->rect, cap)) ||
+            (rc = dev_alloc(&c->valA, cap)) || (rc = dev_alloc(&c->valB, cap)) || (rc = dev_alloc(&c->rect, cap)) ||
             (rc = dev_alloc(&c->cnt, cap + 8)) || (rc = dev_alloc(&c->poff, cap + 8))) {
             free_geometry(c);
             return rc;
@@ -394,7 +396,8 @@ static int exclusive_scan(gsr_context* c, const uint32_t* in, uint32_t* out, uin
 
 // stable LSD sort on key bits [0, bits); ping-pongs (kA,vA) <-> (kB,vB) and
 // leaves the result in (kA,vA) by swapping the pointers.
-static int radix_sort(gsr_context* c, uint32_t*& kA, uint32_t*& vA, uint32_t*& kB, uint32_t*& vB, uint32_t n, int bits)
+template <typename V>
+static int radix_sort(gsr_context* c, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& vB, uint32_t n, int bits)
 {
     if (n == 0 || bits <= 0) return GSR_OK;
     const uint32_t nblk = div_up(n, RS_TILE);
@@ -406,10 +409,10 @@ static int radix_sort(gsr_context* c, uint32_t*& kA, uint32_t*& vA, uint32_t*& k
         hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kA, n, shift, c->hist, nblk);
         rc = exclusive_scan(c, c->hist, c->hist, 256u * nblk, nullptr);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kA, vA, kB, vB, n, shift,
-                           c->hist, nblk);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V>), dim3(nblk), dim3(RS_THREADS), 0, c->stream, kA, vA, kB,
+                           vB, n, shift, c->hist, nblk);
         uint32_t* t = kA; kA = kB; kB = t;
-        t = vA; vA = vB; vB = t;
+        V* tv = vA; vA = vB; vB = tv;
     }
     HIP_TRY(hipGetLastError());
     return GSR_OK;
@@ -462,6 +465,7 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
         while ((((f->tiles_x - 1) >> shift) + 1) * (((f->tiles_y - 1) >> shift) + 1) > 256) ++shift;
     }
     f->super_shift = shift;
+    f->flags = c->opt_flags;
     f->super = 1 << shift;
     f->stiles_x = ((f->tiles_x - 1) >> shift) + 1;
     f->stiles_y = ((f->tiles_y - 1) >> shift) + 1;
@@ -584,14 +588,16 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
                            c->sort_cam[2] == cam->cam_pos[2];
     uint32_t D = 0;
     if (n > 0) {
-        // on a cache hit K1 must not overwrite the sorted (keyA, idxA): send its key/idx output to the B buffers
+        // on a cache hit K1 must not touch the sorted (keyA, valA); the rects inside valA are refreshed instead
         hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, 256)), dim3(256), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
-                           c->rec, cache_hit ? c->keyB : c->keyA, cache_hit ? c->idxB : c->idxA, c->rect);
+                           c->rec, cache_hit ? (uint32_t*)nullptr : c->keyA, cache_hit ? (uint2*)nullptr : c->valA, c->rect);
+        if (cache_hit)
+            hipLaunchKernelGGL(k_refresh_rects, dim3(div_up(n, 256)), dim3(256), 0, s, c->valA, n, c->rect);
         HIP_TRY(hipGetLastError());
     }
     MARK(1);
     if (n > 0 && !cache_hit) {
-        int rc = radix_sort(c, c->keyA, c->idxA, c->keyB, c->idxB, n, 32);
+        int rc = radix_sort(c, c->keyA, c->valA, c->keyB, c->valB, n, 32);
         if (rc) return rc;
         c->sort_valid = true;
         c->sort_gen = c->geo_gen;
@@ -599,7 +605,7 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
     }
     MARK(2);
     if (n > 0) {
-        hipLaunchKernelGGL(k_super_counts, dim3(div_up(n, 256)), dim3(256), 0, s, c->idxA, c->rect, n, f.super_shift,
+        hipLaunchKernelGGL(k_super_counts, dim3(div_up(n, 256)), dim3(256), 0, s, c->valA, n, f.super_shift,
                            c->shard_index, c->shard_count, c->cnt);
         int rc = exclusive_scan(c, c->cnt, c->poff, n, c->d_total);
         if (rc) return rc;
@@ -609,16 +615,16 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
         if ((unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
             return set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: %u super-tile pairs exceed the limit", D);
         if (D > c->pair_cap) {
-            dev_free(c->pkA); dev_free(c->pkB); dev_free(c->pvA); dev_free(c->pvB); dev_free(c->srect);
+            dev_free(c->pkA); dev_free(c->pkB); dev_free(c->pvA); dev_free(c->pvB);
             c->pair_cap = 0;
             const size_t want = (size_t)D + D / 4 + 4096;
             if ((rc = dev_alloc(&c->pkA, want)) || (rc = dev_alloc(&c->pkB, want)) || (rc = dev_alloc(&c->pvA, want)) ||
-                (rc = dev_alloc(&c->pvB, want)) || (rc = dev_alloc(&c->srect, want))) return rc;
+                (rc = dev_alloc(&c->pvB, want))) return rc;
             c->pair_cap = want;
         }
         if (D > 0) {
-            hipLaunchKernelGGL(k_emit_pairs, dim3(div_up(n, 256)), dim3(256), 0, s, c->idxA, c->rect, c->poff, n,
-                               f.super_shift, c->shard_index, c->shard_count, f.stiles_x, c->pkA, c->pvA);
+            hipLaunchKernelGGL(k_emit_pairs, dim3(div_up(n, 256)), dim3(256), 0, s, c->valA, c->poff, n, f.super_shift,
+                               c->shard_index, c->shard_count, f.stiles_x, c->pkA, c->pvA);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -633,8 +639,7 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
     HIP_TRY(hipMemsetAsync(c->sstart, 0, ((size_t)n_super + 1) * 4, s));
     HIP_TRY(hipMemsetAsync(c->send, 0, ((size_t)n_super + 1) * 4, s));
     if (D > 0) {
-        hipLaunchKernelGGL(k_super_ranges, dim3(div_up(D, 256)), dim3(256), 0, s, c->pkA, c->pvA, D, c->rect, c->sstart,
-                           c->send, c->srect);
+        hipLaunchKernelGGL(k_super_ranges, dim3(div_up(D, 256)), dim3(256), 0, s, c->pkA, D, c->sstart, c->send);
         HIP_TRY(hipGetLastError());
     }
     MARK(5);
@@ -642,9 +647,9 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
         GsrBlendArgs a;
         a.width = cam->width; a.height = cam->height; a.tiles_x = f.tiles_x; a.local_tiles = local_tiles;
         a.shard_index = c->shard_index; a.shard_count = c->shard_count; a.band_rows = band_rows;
-        a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = c->opt_swizzle ? 1 : 0;
+        a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = c->opt_swizzle ? 1 : 0; a.flags = c->opt_flags;
         const unsigned grid = a.use_map ? (unsigned)c->map_grid : (unsigned)local_tiles;
-        hipLaunchKernelGGL(k_blend, dim3(grid), dim3(256), 0, s, a, c->tile_map, c->pvA, c->srect, c->sstart, c->send,
+        hipLaunchKernelGGL(k_blend, dim3(grid), dim3(256), 0, s, a, c->tile_map, c->pvA, c->sstart, c->send,
                            c->rec, reinterpret_cast<float4*>(target), c->tile_work);
         HIP_TRY(hipGetLastError());
     }
@@ -741,9 +746,9 @@ extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int
     if (!rc && n) {
         e = hipMemcpy(hr, c->rec, (size_t)n * sizeof(GsrRecord), hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemcpy(hrect, c->rect, (size_t)n * 4, hipMemcpyDeviceToHost);
-        // keys live in sorted order after the depth sort: un-permute through idxA
+        // keys live in sorted order after the depth sort: un-permute through the payload's index
         if (e == hipSuccess) e = hipMemcpy(hk, c->keyA, (size_t)n * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(hidx, c->idxA, (size_t)n * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy2D(hidx, 4, c->valA, 8, 4, (size_t)n, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = set_err(GSR_E_HIP, "gsr_debug_read_records: %s", hipGetErrorString(e));
     }
     if (!rc) {
@@ -771,7 +776,7 @@ extern "C" int gsr_debug_read_depth_order(gsr_context* c, int32_t* perm, int64_t
     if (!c || !perm || n < 0 || (uint64_t)n > c->n) return set_err(GSR_E_INVALID, "gsr_debug_read_depth_order: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (n) HIP_TRY(hipMemcpy(perm, c->idxA, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (n) HIP_TRY(hipMemcpy2D(perm, 4, c->valA, 8, 4, (size_t)n, hipMemcpyDeviceToHost));
     return GSR_OK;
 }
 
@@ -787,7 +792,7 @@ extern "C" int gsr_debug_read_tile_lists(gsr_context* c, int32_t* list_start, in
         HIP_TRY(hipMemcpy(list_start, c->sstart, (size_t)n_lists * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(list_end, c->send, (size_t)n_lists * 4, hipMemcpyDeviceToHost));
     }
-    if (n_pairs) HIP_TRY(hipMemcpy(pair_splat, c->pvA, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+    if (n_pairs) HIP_TRY(hipMemcpy2D(pair_splat, 4, c->pvA, 8, 4, (size_t)n_pairs, hipMemcpyDeviceToHost));
     return GSR_OK;
 }
 

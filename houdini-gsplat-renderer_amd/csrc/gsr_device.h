@@ -51,7 +51,10 @@ struct GsrFrame {
     int32_t super;                     // super-tile edge in tiles (power of two)
     int32_t super_shift;               // log2(super)
     int32_t stiles_x, stiles_y;        // super-tile grid over the whole image
+    int32_t flags;                     // GSR_FLAG_* (A/B switches; never change pixels)
 };
+#define GSR_FLAG_NO_ALPHA_RADIUS 1   // bbox from the full +-2 quad instead of the alpha>=1/255 support
+#define GSR_FLAG_NO_SAT          2   // quadrant masks from the bbox only
 
 // ---- scalar helpers ---------------------------------------------------------
 __device__ __forceinline__ float gsr_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -80,6 +83,48 @@ __device__ __forceinline__ float gsr_expf(float x)
     int32_t k = (int32_t)kf;
     uint32_t bits = __builtin_bit_cast(uint32_t, y) + ((uint32_t)k << 23);
     return __builtin_bit_cast(float, bits);
+}
+
+// two-wide float: the blend kernel evaluates two records per lane per iteration so that the
+// compiler can emit packed-FP32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 -- the
+// only way to reach gfx950's 157 TFLOP/s vector peak); each component is still an IEEE fma.
+typedef float gsr_v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ gsr_v2f gsr_fma2(gsr_v2f a, gsr_v2f b, gsr_v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// gsr_expf on two lanes of a pair: the same operation sequence per component
+__device__ __forceinline__ gsr_v2f gsr_expf2(gsr_v2f x)
+{
+    const gsr_v2f t = x * 1.44269504088896341f;
+    gsr_v2f kf;
+    kf.x = __builtin_rintf(t.x);
+    kf.y = __builtin_rintf(t.y);
+    gsr_v2f r = gsr_fma2(kf, (gsr_v2f)(-0.693359375f), x);
+    r = gsr_fma2(kf, (gsr_v2f)(2.12194440e-4f), r);
+    gsr_v2f p = (gsr_v2f)(1.9875691500e-4f);
+    p = gsr_fma2(p, r, (gsr_v2f)(1.3981999507e-3f));
+    p = gsr_fma2(p, r, (gsr_v2f)(8.3334519073e-3f));
+    p = gsr_fma2(p, r, (gsr_v2f)(4.1665795894e-2f));
+    p = gsr_fma2(p, r, (gsr_v2f)(1.6666665459e-1f));
+    p = gsr_fma2(p, r, (gsr_v2f)(5.0000001201e-1f));
+    const gsr_v2f r2 = r * r;
+    const gsr_v2f y = gsr_fma2(p, r2, r) + 1.0f;
+    // NB: __builtin_bit_cast applied directly to a vector ELEMENT (y.y) reads element 0 with this
+    // compiler (ROCm 7.2 clang) -- go through scalar temporaries.
+    const float y0 = y.x, y1 = y.y, k0 = kf.x, k1 = kf.y;
+    gsr_v2f o;
+    o.x = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, y0) + ((uint32_t)(int32_t)k0 << 23));
+    o.y = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, y1) + ((uint32_t)(int32_t)k1 << 23));
+    return o;
+}
+
+// Largest |q| at which alpha = exp(-|q|^2)*opacity can still reach 1/255 (capped at the quad's
+// half width 2).  Conservative: fast log (abs error < 1e-5 here) plus margins, so it only ever
+// removes pixels the fragment test would discard anyway.  Not part of the parity contract.
+__device__ __forceinline__ float gsr_support_radius(float opacity)
+{
+    const float L = __logf(255.0f * opacity);
+    return __builtin_fminf(2.0f, __builtin_sqrtf(__builtin_fmaxf(L, 0.0f) + 1.0e-4f) + 1.0e-3f);
 }
 
 // rect packing: tile coords < 256 (GSR_MAX_DIM 4096 / 16)

@@ -10,30 +10,42 @@
 // stops reading the moment the tile is opaque.  Materialising per-tile lists
 // instead cost 75 M pairs x 2 radix passes on the 6 M-splat scene, 93 % of which
 // were never consumed (profiles/r1_baseline_v1).
-// Roofline: HBM (12 B written per pair; 12 B read per splat).
+// Roofline: HBM (12 B written per pair; 12 B read per splat, all coalesced).
 #pragma once
 #include "gsr_device.h"
 
+// The depth sort carries a uint2 payload (splat index, packed tile rect), so everything
+// below reads its inputs coalesced in depth-rank order -- no gathers.
+
 // cnt[r] = number of owned super-tiles of the splat at depth rank r
 __global__ void __launch_bounds__(256)
-k_super_counts(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rect, uint32_t n, int shift,
-               int shard_index, int shard_count, uint32_t* __restrict__ cnt)
+k_super_counts(const uint2* __restrict__ sorted, uint32_t n, int shift, int shard_index, int shard_count,
+               uint32_t* __restrict__ cnt)
 {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= n) return;
-    cnt[r] = (uint32_t)gsr_rect_supers(rect[perm[r]], shift, shard_index, shard_count);
+    cnt[r] = (uint32_t)gsr_rect_supers(sorted[r].y, shift, shard_index, shard_count);
 }
 
-// one lane per depth rank writes its (super-tile, splat) pairs at poff[r]
+// depth-sort cache hit with a new view matrix: the order is still valid, the rects are not
 __global__ void __launch_bounds__(256)
-k_emit_pairs(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rect,
-             const uint32_t* __restrict__ poff, uint32_t n, int shift, int shard_index, int shard_count,
-             int stiles_x, uint32_t* __restrict__ pkeys, uint32_t* __restrict__ pvals)
+k_refresh_rects(uint2* __restrict__ sorted, uint32_t n, const uint32_t* __restrict__ rect)
 {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= n) return;
-    const uint32_t idx = perm[r];
-    const uint32_t rc = rect[idx];
+    sorted[r].y = rect[sorted[r].x];
+}
+
+// one lane per depth rank writes its (super-tile id ; splat index, rect) pairs at poff[r]
+__global__ void __launch_bounds__(256)
+k_emit_pairs(const uint2* __restrict__ sorted, const uint32_t* __restrict__ poff, uint32_t n, int shift,
+             int shard_index, int shard_count, int stiles_x, uint32_t* __restrict__ pkeys,
+             uint2* __restrict__ pvals)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n) return;
+    const uint2 v = sorted[r];
+    const uint32_t rc = v.y;
     const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = (rc >> 16) & 255, y1 = rc >> 24;
     if (x1 < x0 || y1 < y0) return;
     uint32_t o = poff[r];
@@ -46,25 +58,22 @@ k_emit_pairs(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rec
         const uint32_t rowkey = (uint32_t)sy * (uint32_t)stiles_x;
         for (int sx = sx0; sx <= sx1; ++sx) {
             pkeys[o] = rowkey + (uint32_t)sx;
-            pvals[o] = idx;
+            pvals[o] = v;
             ++o;
         }
     }
 }
 
-// boundaries of equal-key runs in the sorted pair list, plus the rect of every
-// listed splat (so that the blend kernel's tile filter is a coalesced read)
+// boundaries of equal-key runs in the sorted pair list
 __global__ void __launch_bounds__(256)
-k_super_ranges(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
-               const uint32_t* __restrict__ rect, int32_t* __restrict__ sstart, int32_t* __restrict__ send,
-               uint32_t* __restrict__ srect)
+k_super_ranges(const uint32_t* __restrict__ keys, uint32_t n, int32_t* __restrict__ sstart,
+               int32_t* __restrict__ send)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint32_t k = keys[i];
     if (i == 0 || keys[i - 1] != k) sstart[k] = (int32_t)i;
     if (i == n - 1 || keys[i + 1] != k) send[k] = (int32_t)(i + 1);
-    srect[i] = rect[vals[i]];
 }
 
 // root side of the multi-GPU path: de-interleave gathered band images.

@@ -36,11 +36,12 @@ struct GsrBlendArgs {
     int32_t super_shift;        // log2(super-tile edge in tiles)
     int32_t stiles_x;
     int32_t use_map;            // blockIdx -> tile through tile_map (XCD-aware order)
+    int32_t flags;              // GSR_FLAG_*
 };
 
 __global__ void __launch_bounds__(256)
-k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint32_t* __restrict__ svals,
-        const uint32_t* __restrict__ srects, const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
+k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __restrict__ svals,
+        const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
         const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint2* __restrict__ tile_work)
 {
     __shared__ float4 s0[2][BL_CHUNK];   // cx, cy, ex, ey
@@ -81,8 +82,8 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint32_t* __
     };
     uint32_t e_idx = 0, n_idx = 0;   // entry of the chunk being gathered next / the one after
     bool e_hit = false, n_hit = false;
-    if (tid < n) { e_idx = svals[s + tid]; e_hit = tile_in(srects[s + tid]); }
-    if (BL_CHUNK + tid < n) { n_idx = svals[s + BL_CHUNK + tid]; n_hit = tile_in(srects[s + BL_CHUNK + tid]); }
+    if (tid < n) { const uint2 e = svals[s + tid]; e_idx = e.x; e_hit = tile_in(e.y); }
+    if (BL_CHUNK + tid < n) { const uint2 e = svals[s + BL_CHUNK + tid]; n_idx = e.x; n_hit = tile_in(e.y); }
     chunks_read = 2;
     float4 r0, r1, r2;
     bool have = e_hit;
@@ -97,12 +98,24 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint32_t* __
         uint32_t m = 0;
         if (have) {
             s0[buf][tid] = r0; s1[buf][tid] = r1; s2[buf][tid] = r2;
-            // which 8x8 quadrants can the splat's bbox touch?
+            // Which 8x8 quadrants can the splat touch?  Separating-axis test of the oriented quad
+            // (shrunk to the radius where alpha can still reach 1/255) against each quadrant's box of
+            // pixel centres: the box axes (= bbox test) and the quad's own two axes.  Conservative.
+            const float rq = ((a.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius(r2.w)) + 1.0e-3f;
             const float bx0 = r0.x - r1.z, bx1 = r0.x + r1.z, by0 = r0.y - r1.w, by1 = r0.y + r1.w;
             const bool xl = bx0 <= tcx0 + 7.0f, xr = bx1 >= tcx0 + 8.0f;
             const bool yb = by0 <= tcy0 + 7.0f, yt = by1 >= tcy0 + 8.0f;
-            m = (uint32_t)(xl && yb) | ((uint32_t)(xr && yb) << 1) | ((uint32_t)(xl && yt) << 2) |
-                ((uint32_t)(xr && yt) << 3);
+            const float ext = 3.5f * (__builtin_fabsf(r0.z) + __builtin_fabsf(r0.w));  // box radius along e (and e_perp)
+            const float lim1 = rq + ext * r1.x, lim2 = rq + ext * r1.y;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const float ddx = (tcx0 + 3.5f + 8.0f * (float)(qd & 1)) - r0.x;
+                const float ddy = (tcy0 + 3.5f + 8.0f * (float)(qd >> 1)) - r0.y;
+                const float pu = __builtin_fabsf(ddx * r0.z + ddy * r0.w) * r1.x;
+                const float pv = __builtin_fabsf(ddy * r0.z - ddx * r0.w) * r1.y;
+                const bool box = ((qd & 1) ? xr : xl) && ((qd >> 1) ? yt : yb);
+                if (box && (((a.flags & GSR_FLAG_NO_SAT) != 0) || (pu <= lim1 && pv <= lim2))) m |= 1u << qd;
+            }
         }
         smask[buf][tid] = m;
         if (lane == 0) sdone[buf][wave] = wave_done ? 1u : 0u;
@@ -122,7 +135,7 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint32_t* __
             ++chunks_read;
             const int nn = (c + 2) * BL_CHUNK + tid;
             n_hit = false;
-            if (nn < n) { n_idx = svals[s + nn]; n_hit = tile_in(srects[s + nn]); }
+            if (nn < n) { const uint2 e = svals[s + nn]; n_idx = e.x; n_hit = tile_in(e.y); }
         }
 
         if (!wave_done) {
@@ -131,26 +144,42 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint32_t* __
                 unsigned long long acc = __ballot((smask[buf][j0 + lane] >> wave) & 1u);
                 if (acc == 0ull) continue;
                 while (acc) {
-                    const int j = j0 + __builtin_ctzll(acc);
+                    // two records per iteration (packed FP32); an odd tail evaluates its record twice
+                    const int ja = j0 + __builtin_ctzll(acc);
                     acc &= acc - 1;
-                    const float4 g0 = s0[buf][j];
-                    const float4 g1 = s1[buf][j];
-                    const float4 g2 = s2[buf][j];
-                    const float dx = fx - g0.x, dy = fy - g0.y;
-                    const float u = gsr_fma(dx, g0.z, dy * g0.w);
-                    const float v = gsr_fma(dy, g0.z, -(dx * g0.w));
-                    const float q0 = u * g1.x, q1 = v * g1.y;
-                    const bool inside = (__builtin_fabsf(q0) <= 2.0f) && (__builtin_fabsf(q1) <= 2.0f);
-                    const float power = -gsr_fma(q0, q0, q1 * q1);
-                    // outside the quad power can be very negative: keep the exp argument in range
-                    float alpha = gsr_expf(__builtin_fmaxf(power, -80.0f)) * g2.w;
-                    alpha = __builtin_fminf(__builtin_fmaxf(alpha, 0.0f), 1.0f);
-                    const float t = 1.0f - A;
-                    if (inside && alpha >= (1.0f / 255.0f) && t >= GSR_T_MIN) {
-                        C0 = gsr_fma(t, g2.x * alpha, C0);
-                        C1 = gsr_fma(t, g2.y * alpha, C1);
-                        C2 = gsr_fma(t, g2.z * alpha, C2);
-                        A = gsr_fma(t, alpha, A);
+                    const bool two = acc != 0ull;
+                    const int jb = two ? j0 + __builtin_ctzll(acc) : ja;
+                    acc &= acc - 1;   // no-op when acc == 0
+                    const float4 a0 = s0[buf][ja], a1 = s1[buf][ja], a2 = s2[buf][ja];
+                    const float4 b0 = s0[buf][jb], b1 = s1[buf][jb], b2 = s2[buf][jb];
+                    const gsr_v2f dx = (gsr_v2f)(fx) - (gsr_v2f){a0.x, b0.x};
+                    const gsr_v2f dy = (gsr_v2f)(fy) - (gsr_v2f){a0.y, b0.y};
+                    const gsr_v2f ex = {a0.z, b0.z}, ey = {a0.w, b0.w};
+                    const gsr_v2f u = gsr_fma2(dx, ex, dy * ey);
+                    const gsr_v2f v = gsr_fma2(dy, ex, -(dx * ey));
+                    const gsr_v2f q0 = u * (gsr_v2f){a1.x, b1.x};
+                    const gsr_v2f q1 = v * (gsr_v2f){a1.y, b1.y};
+                    const gsr_v2f power = -gsr_fma2(q0, q0, q1 * q1);
+                    // (lanes outside the quad may feed exp a large negative argument: their result is unused)
+                    gsr_v2f alpha = gsr_expf2(power) * (gsr_v2f){a2.w, b2.w};
+                    alpha = __builtin_elementwise_min(alpha, (gsr_v2f)(1.0f));   // opacity >= 1/255 > 0: no lower clamp needed
+                    const bool ina = (__builtin_fabsf(q0.x) <= 2.0f) && (__builtin_fabsf(q1.x) <= 2.0f) &&
+                                     (alpha.x >= (1.0f / 255.0f));
+                    const bool inb = two && (__builtin_fabsf(q0.y) <= 2.0f) && (__builtin_fabsf(q1.y) <= 2.0f) &&
+                                     (alpha.y >= (1.0f / 255.0f));
+                    float t = 1.0f - A;
+                    if (ina && t >= GSR_T_MIN) {
+                        C0 = gsr_fma(t, a2.x * alpha.x, C0);
+                        C1 = gsr_fma(t, a2.y * alpha.x, C1);
+                        C2 = gsr_fma(t, a2.z * alpha.x, C2);
+                        A = gsr_fma(t, alpha.x, A);
+                    }
+                    t = 1.0f - A;
+                    if (inb && t >= GSR_T_MIN) {
+                        C0 = gsr_fma(t, b2.x * alpha.y, C0);
+                        C1 = gsr_fma(t, b2.y * alpha.y, C1);
+                        C2 = gsr_fma(t, b2.z * alpha.y, C2);
+                        A = gsr_fma(t, alpha.y, A);
                     }
                 }
                 if (__all(!pix_ok || (1.0f - A) < GSR_T_MIN)) { wave_done = true; break; }

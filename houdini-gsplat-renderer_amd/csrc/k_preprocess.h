@@ -87,11 +87,11 @@ __device__ __forceinline__ float lin3(const float* m, float x, float y, float z)
 
 // K1: one thread per splat.
 //   in : geoA, geoB, col (SoA, coalesced 16 B/lane)
-//   out: rec[i] (48 B), key[i] (f32 distance^2 bits), idx[i] = i, rect[i] (packed tile rect or EMPTY)
+//   out: rec[i] (48 B), key[i] (f32 distance^2 bits), val[i] = (i, rect), rect[i] (packed tile rect or EMPTY)
 __global__ void __launch_bounds__(256)
 k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col,
-             GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint32_t* __restrict__ idx,
+             GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint2* __restrict__ val,
              uint32_t* __restrict__ rect)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -103,8 +103,7 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
         {
             float dx = px - f.cam[0], dy = py - f.cam[1], dz = pz - f.cam[2];
             float k = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
-            key[i] = __builtin_bit_cast(uint32_t, k);
-            idx[i] = i;
+            if (key) key[i] = __builtin_bit_cast(uint32_t, k);   // NULL on a depth-sort cache hit
         }
         uint32_t out_rect = GSR_RECT_EMPTY;
 
@@ -210,8 +209,10 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
             }
             const float s1 = __builtin_fminf(__builtin_sqrtf(2.0f * lambda1), 4096.0f);
             const float s2 = __builtin_fminf(__builtin_sqrtf(2.0f * lambda2), 4096.0f);
-            const float hx = gsr_fma(2.0f * gsr_fma(s1, __builtin_fabsf(ex), s2 * __builtin_fabsf(ey)), 1.0001f, 0.01f);
-            const float hy = gsr_fma(2.0f * gsr_fma(s1, __builtin_fabsf(ey), s2 * __builtin_fabsf(ex)), 1.0001f, 0.01f);
+            // conservative bbox of the part of the quad where alpha can reach 1/255 (|q| <= rq <= 2)
+            const float rq = (f.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius(opacity);
+            const float hx = gsr_fma(rq * gsr_fma(s1, __builtin_fabsf(ex), s2 * __builtin_fabsf(ey)), 1.0001f, 0.01f);
+            const float hy = gsr_fma(rq * gsr_fma(s1, __builtin_fabsf(ey), s2 * __builtin_fabsf(ex)), 1.0001f, 0.01f);
 
             // pixel range of the conservative bbox -> tile rect
             const float xlo = cx - hx - 0.5f, xhi = cx + hx - 0.5f;
@@ -270,6 +271,7 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
             }
         }
         rect[i] = out_rect;
+        if (val) val[i] = make_uint2(i, out_rect);   // sort payload: splat index + tile rect
     }
 }
 

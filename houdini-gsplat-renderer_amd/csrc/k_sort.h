@@ -15,9 +15,11 @@
 #include "gsr_device.h"
 
 #define RS_THREADS 256
+#ifndef RS_ITEMS
 #define RS_ITEMS 16
-#define RS_TILE (RS_THREADS * RS_ITEMS)  // 4096 items per workgroup
-#define RS_WAVE_ITEMS (RS_TILE / 4)      // 1024 items per wave
+#endif
+#define RS_TILE (RS_THREADS * RS_ITEMS)  // items per workgroup
+#define RS_WAVE_ITEMS (RS_TILE / 4)      // items per wave
 
 // ---------------------------------------------------------------------------
 // exclusive scan, three kernels (reduce / scan partials / downsweep)
@@ -159,11 +161,13 @@ k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t*
 }
 
 // radix pass, kernel 2 (after the scan of hist): stable scatter.
-// Item order inside a workgroup: wave w owns items [w*1024, (w+1)*1024) of the
+// Item order inside a workgroup: wave w owns items [w*RS_WAVE_ITEMS, (w+1)*RS_WAVE_ITEMS) of the
 // tile, round k covers 64 consecutive items -> (wave, round, lane) is input order.
+// V = payload type: uint32_t (4 B) or uint2 (8 B: splat index + packed tile rect).
+template <typename V>
 __global__ void __launch_bounds__(RS_THREADS)
-k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in,
+                uint32_t* __restrict__ keys_out, V* __restrict__ vals_out, uint32_t n, int shift,
                 const uint32_t* __restrict__ offs, uint32_t nblk)
 {
     __shared__ uint32_t wc[4][256];     // per-wave digit counters -> per-wave bases
@@ -171,7 +175,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
     __shared__ uint32_t gadj[256];      // global offset of the digit run minus dbase
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t skeys[RS_TILE];
-    __shared__ uint32_t svals[RS_TILE];
+    __shared__ V svals[RS_TILE];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t tile_base = blockIdx.x * RS_TILE;
@@ -180,13 +184,15 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
     for (int w = 0; w < 4; ++w) wc[w][threadIdx.x] = 0;
     __syncthreads();
 
-    uint32_t k_[RS_ITEMS], v_[RS_ITEMS], meta[RS_ITEMS];  // meta = digit | rank_in_wave_digit << 8
+    uint32_t k_[RS_ITEMS], meta[RS_ITEMS];  // meta = digit | rank_in_wave_digit << 8
+    V v_[RS_ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;
         const bool valid = li < nvalid;
-        uint32_t key = 0xffffffffu, val = 0;
+        uint32_t key = 0xffffffffu;
+        V val{};
         if (valid) { key = keys_in[tile_base + li]; val = vals_in[tile_base + li]; }
         // invalid tail items take digit 255: being last in input order they rank
         // after every valid item and are simply not written out

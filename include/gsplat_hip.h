@@ -143,6 +143,8 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        (argsortByDistance's caching, src/GSplatRenderer.C:179-186) */
 #define GSR_OPT_SUPER_TILE      4   /* super-tile edge in tiles: 0 = auto (smallest power of two giving
                                        <= 256 super-tiles), or 1,2,4,8,16 */
+#define GSR_OPT_DEBUG_FLAGS     5   /* A/B switches for profiling: 1 = no alpha-support shrink of the bboxes,
+                                       2 = bbox-only quadrant masks (no separating-axis test) */
 int  gsr_set_option(gsr_context* ctx, int option, int value);
 
 /* ---- debug / test access (device -> host copies of intermediates) -------- */

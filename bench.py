@@ -44,6 +44,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the cpu_baseline leg")
     ap.add_argument("--no-swizzle", action="store_true", help="disable the XCD-aware tile mapping (A/B)")
+    ap.add_argument("--super-tile", type=int, default=0, help="super-tile edge in tiles (0 = auto) (A/B)")
+    ap.add_argument("--flags", type=int, default=0, help="GSR_OPT_DEBUG_FLAGS (A/B)")
+    ap.add_argument("--verify", action="store_true",
+                    help="N>1: also render the last frame unsharded on rank 0 and require the stitched frame to be bit-identical")
     return ap.parse_args()
 
 
@@ -100,29 +104,41 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; GSR_BENCH_BACKEND=gloo + fewer GPUs than ranks is a functional test mode only
+    # (lets the sharded path run end-to-end on a 1-GPU box), never a performance configuration
+    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but only {ndev} GPUs")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     pkg = ge.load_package()
     splats, cfg = pkg.scenes.make_config(args.config, args.splats)
     W, H, order = cfg["width"], cfg["height"], cfg["sh_order"]
 
-    eng = pkg.Engine(local_rank)
+    eng = pkg.Engine(dev_index)
     # one explicit (non-null) HIP stream carries the kernels, the RCCL gather and the stitch in order
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
     eng.set_option(pkg.engine.OPT_XCD_SWIZZLE, 0 if args.no_swizzle else 1)
+    eng.set_option(pkg.engine.OPT_SUPER_TILE, args.super_tile)
+    eng.set_option(pkg.engine.OPT_DEBUG_FLAGS, args.flags)
     if world > 1:
         eng.set_row_shard(rank, world)
     eng.upload(splats)  # once: geometry stays resident in HBM
 
-    fg = pkg.multigpu.FrameGatherer(dist, rank, world, W, H, "cuda", engine=eng)
+    fg = pkg.multigpu.FrameGatherer(dist, rank, world, W, H, "cuda", engine=eng, via_host=(backend != "nccl"))
     assert fg.rows == eng.band_rows(H)
     cams = [pkg.engine.camera_struct(pkg.camera.make_camera(W, H, sh_order=order, frame=i))
             for i in range(args.warmup + args.steps)]
@@ -152,6 +168,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    verified = None
+    if args.verify and world > 1:
+        last = cams[args.warmup + args.steps - 1]
+        stitched = fg.gather_and_stitch()                      # bands of the last step are still in place
+        if rank == 0:
+            eng.set_row_shard(0, 1)
+            ref = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+            eng.render_struct_to_device(last, ref.data_ptr())
+            torch.cuda.synchronize()
+            verified = bool(torch.equal(stitched, ref)) and bool(ref[..., 3].max() > 0)
+            eng.set_row_shard(rank, world)
+            if not verified:
+                raise SystemExit("sharded frame differs from the unsharded frame")
     st = eng.stats()
     # blend-kernel roofline, measured with HIP events on the kernel's own stream
     launches = max(1, st["blend_launches"])
@@ -197,6 +226,8 @@ def main():
             "stages_ms_last_frame": stages,
             "n_visible": st["n_visible"],
         }
+        if verified is not None:
+            line["sharded_frame_bit_identical"] = verified
         if world == 1 and not args.no_cpu_baseline:
             oracle = ge.load_oracle()
             cam0 = pkg.camera.make_camera(W, H, sh_order=order, frame=0)

@@ -79,6 +79,11 @@ struct gsr_context {
     size_t hist_cap = 0;
     uint32_t* partial = nullptr;
     size_t partial_cap = 0;
+    uint32_t* totals = nullptr;        // [512] per-digit totals of the current radix pass
+    // bounding box of the uploaded positions (bounds the sort keys of a frame)
+    bool bbox_ok = false;
+    double bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
+    uint32_t key_min = 0;              // of the frame whose order is cached
     // pairs
     uint32_t *pkA = nullptr, *pkB = nullptr;
     uint2 *pvA = nullptr, *pvB = nullptr;        // pair payload: (splat index, packed tile rect)
@@ -161,6 +166,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
     bool ok = true;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&c->counters), 8 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&c->d_total), sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&c->totals), 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_total), sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), 8 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMemset(c->counters, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
@@ -197,7 +203,7 @@ extern "C" void gsr_destroy(gsr_context* c)
     dev_free(c->pkA); dev_free(c->pkB); dev_free(c->pvA); dev_free(c->pvB);
     dev_free(c->sstart); dev_free(c->send); dev_free(c->tile_work); dev_free(c->tile_map);
     dev_free(c->fb);
-    dev_free(c->counters); dev_free(c->d_total);
+    dev_free(c->counters); dev_free(c->d_total); dev_free(c->totals);
     if (c->h_total) (void)hipHostFree(c->h_total);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->ev_ok)
@@ -313,6 +319,31 @@ extern "C" int gsr_upload_end(gsr_context* c)
     if (c->up_filled != c->up_total)
         return set_err(GSR_E_INVALID, "gsr_upload_end: %u of %u announced splats were appended", c->up_filled, c->up_total);
     c->n = c->up_total;
+    // bounding box of the positions: bounds distance^2 to any camera, i.e. the sort-key range per frame
+    c->bbox_ok = false;
+    if (c->n > 0) {
+        HIP_TRY(hipSetDevice(c->device));
+        const int grid = 512;
+        float* d_part = nullptr;
+        int rc = dev_alloc(&d_part, (size_t)grid * 6);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_bbox_partials, dim3(grid), dim3(256), 0, c->stream, c->geoA, c->n, d_part);
+        std::vector<float> hp((size_t)grid * 6);
+        hipError_t e = hipMemcpyAsync(hp.data(), d_part, hp.size() * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        dev_free(d_part);
+        if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_upload_end: %s", hipGetErrorString(e));
+        bool ok = true;
+        for (int k = 0; k < 3; ++k) { c->bb_lo[k] = 3.0e38; c->bb_hi[k] = -3.0e38; }
+        for (int b = 0; b < grid; ++b)
+            for (int k = 0; k < 3; ++k) {
+                const float lo = hp[(size_t)b * 6 + k], hi = hp[(size_t)b * 6 + 3 + k];
+                ok = ok && std::isfinite(lo) && std::isfinite(hi);
+                c->bb_lo[k] = std::min(c->bb_lo[k], (double)lo);
+                c->bb_hi[k] = std::max(c->bb_hi[k], (double)hi);
+            }
+        c->bbox_ok = ok;
+    }
     c->geo_gen++;
     c->sort_valid = false;
     c->st.n_splats = c->n;
@@ -396,25 +427,38 @@ static int exclusive_scan(gsr_context* c, const uint32_t* in, uint32_t* out, uin
 
 // stable LSD sort on key bits [0, bits); ping-pongs (kA,vA) <-> (kB,vB) and
 // leaves the result in (kA,vA) by swapping the pointers.
+template <typename V, int DBITS>
+static int radix_pass(gsr_context* c, uint32_t* kA, V* vA, uint32_t* kB, V* vB, uint32_t n, int shift, uint32_t nblk)
+{
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS>), dim3(nblk), dim3(RS_THREADS), 0, c->stream, kA, n, shift,
+                       c->hist, nblk);
+    hipLaunchKernelGGL(k_scan_rows, dim3(1u << DBITS), dim3(SC_THREADS), 0, c->stream, c->hist, nblk, c->totals);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS>), dim3(nblk), dim3(RS_THREADS), 0, c->stream, kA, vA,
+                       kB, vB, n, shift, c->hist, c->totals, nblk);
+    HIP_TRY(hipGetLastError());
+    return GSR_OK;
+}
+
+// stable LSD sort on key bits [0, bits); ping-pongs (kA,vA) <-> (kB,vB) and leaves the result
+// in (kA,vA) by swapping the pointers.  9-bit digits are used when they save a pass.
 template <typename V>
-static int radix_sort(gsr_context* c, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& vB, uint32_t n, int bits)
+static int radix_sort(gsr_context* c, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& vB, uint32_t n, int bits,
+                      bool allow9 = true)
 {
     if (n == 0 || bits <= 0) return GSR_OK;
     const uint32_t nblk = div_up(n, RS_TILE);
-    int rc = ensure_u32(&c->hist, &c->hist_cap, (size_t)256 * nblk + 8);
+    int rc = ensure_u32(&c->hist, &c->hist_cap, (size_t)512 * nblk + 8);
     if (rc) return rc;
-    const int passes = (bits + 7) / 8;
+    const int p8 = (bits + 7) / 8, p9 = (bits + 8) / 9;
+    const bool use9 = allow9 && p9 < p8;
+    const int passes = use9 ? p9 : p8, width = use9 ? 9 : 8;
     for (int p = 0; p < passes; ++p) {
-        const int shift = p * 8;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kA, n, shift, c->hist, nblk);
-        rc = exclusive_scan(c, c->hist, c->hist, 256u * nblk, nullptr);
+        rc = use9 ? radix_pass<V, 9>(c, kA, vA, kB, vB, n, p * width, nblk)
+                  : radix_pass<V, 8>(c, kA, vA, kB, vB, n, p * width, nblk);
         if (rc) return rc;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V>), dim3(nblk), dim3(RS_THREADS), 0, c->stream, kA, vA, kB,
-                           vB, n, shift, c->hist, nblk);
         uint32_t* t = kA; kA = kB; kB = t;
         V* tv = vA; vA = vB; vB = tv;
     }
-    HIP_TRY(hipGetLastError());
     return GSR_OK;
 }
 
@@ -457,7 +501,8 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
     f->shard_index = c->shard_index;
     f->shard_count = c->shard_count;
     f->local_tiles_y = (f->tiles_y > c->shard_index) ? (f->tiles_y - c->shard_index + c->shard_count - 1) / c->shard_count : 0;
-    // super-tile edge: smallest power of two that leaves <= 256 super-tiles (ONE 8-bit radix pass)
+    // super-tile edge: smallest power of two that leaves <= 256 super-tiles (measured best at 1080p: S=8;
+    // an explicit smaller S with <= 512 super-tiles still sorts in ONE pass thanks to 9-bit digits)
     int shift = 0;
     if (c->opt_super > 0) {
         while ((1 << shift) < c->opt_super) ++shift;
@@ -466,6 +511,27 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
     }
     f->super_shift = shift;
     f->flags = c->opt_flags;
+    // sort-key range of this frame: distance^2 from cam_pos to the cloud's bounding box, as float bits
+    f->key_min = 0u;
+    f->key_max = 0xffffffffu;
+    if (c->bbox_ok && !(c->opt_flags & GSR_FLAG_FULL_KEYS)) {
+        double dmin2 = 0.0, dmax2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double p = cam->cam_pos[k];
+            const double near_ = p < c->bb_lo[k] ? c->bb_lo[k] - p : (p > c->bb_hi[k] ? p - c->bb_hi[k] : 0.0);
+            const double far_ = std::max(std::fabs(p - c->bb_lo[k]), std::fabs(p - c->bb_hi[k]));
+            dmin2 += near_ * near_;
+            dmax2 += far_ * far_;
+        }
+        const float lo = (float)(dmin2 * (1.0 - 1e-5)), hi = (float)(dmax2 * (1.0 + 1e-5)) ;
+        if (std::isfinite(lo) && std::isfinite(hi) && lo >= 0.0f && hi >= lo) {
+            uint32_t blo, bhi;
+            std::memcpy(&blo, &lo, 4);
+            std::memcpy(&bhi, &hi, 4);
+            f->key_min = blo > 2 ? blo - 2 : 0;
+            f->key_max = bhi + 2;
+        }
+    }
     f->super = 1 << shift;
     f->stiles_x = ((f->tiles_x - 1) >> shift) + 1;
     f->stiles_y = ((f->tiles_y - 1) >> shift) + 1;
@@ -597,7 +663,10 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
     }
     MARK(1);
     if (n > 0 && !cache_hit) {
-        int rc = radix_sort(c, c->keyA, c->valA, c->keyB, c->valB, n, 32);
+        int key_bits = 1;
+        while (key_bits < 32 && ((f.key_max - f.key_min) >> key_bits) != 0u) ++key_bits;
+        int rc = radix_sort(c, c->keyA, c->valA, c->keyB, c->valB, n, key_bits, !(c->opt_flags & GSR_FLAG_FULL_KEYS));
+        c->key_min = f.key_min;
         if (rc) return rc;
         c->sort_valid = true;
         c->sort_gen = c->geo_gen;
@@ -765,7 +834,10 @@ extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int
             }
         }
         for (int64_t r = 0; r < n; ++r)
-            if (hidx[r] < (uint64_t)n) std::memcpy(&out[hidx[r]].key, &hk[r], 4);
+            if (hidx[r] < (uint64_t)n) {
+                const uint32_t kb = hk[r] + c->key_min;   // keys are stored relative to the frame's key_min
+                std::memcpy(&out[hidx[r]].key, &kb, 4);
+            }
     }
     delete[] hr; delete[] hk; delete[] hrect; delete[] hidx;
     return rc;
@@ -796,6 +868,16 @@ extern "C" int gsr_debug_read_tile_lists(gsr_context* c, int32_t* list_start, in
     return GSR_OK;
 }
 
+extern "C" int gsr_debug_read_tile_work(gsr_context* c, uint32_t* scanned_fetched, int64_t n_tiles)
+{
+    if (!c || !scanned_fetched || n_tiles != (int64_t)c->last_tiles_x * c->last_local_ty)
+        return set_err(GSR_E_INVALID, "gsr_debug_read_tile_work: expected %d tiles", c ? c->last_tiles_x * c->last_local_ty : 0);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n_tiles) HIP_TRY(hipMemcpy(scanned_fetched, c->tile_work, (size_t)n_tiles * 8, hipMemcpyDeviceToHost));
+    return GSR_OK;
+}
+
 extern "C" int gsr_debug_sort_pairs(gsr_context* c, uint32_t* keys, uint32_t* vals, int64_t n64, int key_bits)
 {
     if (!c || n64 < 0 || n64 > 0x7fffffffll || key_bits < 1 || key_bits > 32 || (n64 > 0 && (!keys || !vals)))
@@ -812,7 +894,7 @@ extern "C" int gsr_debug_sort_pairs(gsr_context* c, uint32_t* keys, uint32_t* va
     hipError_t e = hipMemcpyAsync(kA, keys, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(vA, vals, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        rc = radix_sort(c, kA, vA, kB, vB, n, key_bits);
+        rc = radix_sort(c, kA, vA, kB, vB, n, key_bits, true);
         if (!rc) {
             e = hipMemcpyAsync(keys, kA, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(vals, vA, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);

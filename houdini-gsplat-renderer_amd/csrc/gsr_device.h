@@ -52,9 +52,11 @@ struct GsrFrame {
     int32_t super_shift;               // log2(super)
     int32_t stiles_x, stiles_y;        // super-tile grid over the whole image
     int32_t flags;                     // GSR_FLAG_* (A/B switches; never change pixels)
+    uint32_t key_min, key_max;         // sort keys are stored as clamp(bits, key_min, key_max) - key_min
 };
 #define GSR_FLAG_NO_ALPHA_RADIUS 1   // bbox from the full +-2 quad instead of the alpha>=1/255 support
 #define GSR_FLAG_NO_SAT          2   // quadrant masks from the bbox only
+#define GSR_FLAG_FULL_KEYS       4   // sort all 32 key bits (no key-range reduction, 8-bit digits)
 
 // ---- scalar helpers ---------------------------------------------------------
 __device__ __forceinline__ float gsr_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }

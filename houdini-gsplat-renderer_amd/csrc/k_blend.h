@@ -167,20 +167,20 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
                                      (alpha.x >= (1.0f / 255.0f));
                     const bool inb = two && (__builtin_fabsf(q0.y) <= 2.0f) && (__builtin_fabsf(q1.y) <= 2.0f) &&
                                      (alpha.y >= (1.0f / 255.0f));
+                    // branch-free under-blend: a rejected fragment blends alpha = 0, which leaves C and A
+                    // bit-identical (fma(t, +-0, C) == C), and costs no exec-mask juggling on the scalar unit
                     float t = 1.0f - A;
-                    if (ina && t >= GSR_T_MIN) {
-                        C0 = gsr_fma(t, a2.x * alpha.x, C0);
-                        C1 = gsr_fma(t, a2.y * alpha.x, C1);
-                        C2 = gsr_fma(t, a2.z * alpha.x, C2);
-                        A = gsr_fma(t, alpha.x, A);
-                    }
+                    const float aa = (ina && t >= GSR_T_MIN) ? alpha.x : 0.0f;
+                    C0 = gsr_fma(t, a2.x * aa, C0);
+                    C1 = gsr_fma(t, a2.y * aa, C1);
+                    C2 = gsr_fma(t, a2.z * aa, C2);
+                    A = gsr_fma(t, aa, A);
                     t = 1.0f - A;
-                    if (inb && t >= GSR_T_MIN) {
-                        C0 = gsr_fma(t, b2.x * alpha.y, C0);
-                        C1 = gsr_fma(t, b2.y * alpha.y, C1);
-                        C2 = gsr_fma(t, b2.z * alpha.y, C2);
-                        A = gsr_fma(t, alpha.y, A);
-                    }
+                    const float ab = (inb && t >= GSR_T_MIN) ? alpha.y : 0.0f;
+                    C0 = gsr_fma(t, b2.x * ab, C0);
+                    C1 = gsr_fma(t, b2.y * ab, C1);
+                    C2 = gsr_fma(t, b2.z * ab, C2);
+                    A = gsr_fma(t, ab, A);
                 }
                 if (__all(!pix_ok || (1.0f - A) < GSR_T_MIN)) { wave_done = true; break; }
             }

@@ -103,7 +103,13 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
         {
             float dx = px - f.cam[0], dy = py - f.cam[1], dz = pz - f.cam[2];
             float k = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
-            if (key) key[i] = __builtin_bit_cast(uint32_t, k);   // NULL on a depth-sort cache hit
+            if (key) {   // NULL on a depth-sort cache hit
+                // distance^2 >= 0: its IEEE bits are monotone.  The host bounds them for this frame from the
+                // cloud's bounding box (key_min/key_max), so the sort only has to cover key_max-key_min.
+                uint32_t kb = __builtin_bit_cast(uint32_t, k);
+                kb = kb < f.key_min ? f.key_min : (kb > f.key_max ? f.key_max : kb);
+                key[i] = kb - f.key_min;
+            }
         }
         uint32_t out_rect = GSR_RECT_EMPTY;
 
@@ -272,6 +278,42 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
         }
         rect[i] = out_rect;
         if (val) val[i] = make_uint2(i, out_rect);   // sort payload: splat index + tile rect
+    }
+}
+
+// upload time: per-workgroup partial bounding boxes of the positions (finished on the host)
+__global__ void __launch_bounds__(256)
+k_bbox_partials(const float4* __restrict__ geoA, uint32_t n, float* __restrict__ partial /*[grid][6]*/)
+{
+    __shared__ float s[4][6];
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    bool finite = true;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float4 a = geoA[i];
+        const float p[3] = {a.x, a.y, a.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            finite = finite && (__builtin_fabsf(p[k]) < 3.0e38f);   // false for inf and NaN
+            lo[k] = __builtin_fminf(lo[k], p[k]);
+            hi[k] = __builtin_fmaxf(hi[k], p[k]);
+        }
+    }
+    if (!finite) { lo[0] = -__builtin_inff(); hi[0] = __builtin_inff(); }   // poison: host falls back to full keys
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            lo[k] = __builtin_fminf(lo[k], __shfl_down(lo[k], d, 64));
+            hi[k] = __builtin_fmaxf(hi[k], __shfl_down(hi[k], d, 64));
+        }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; ++k) { s[wave][k] = lo[k]; s[wave][3 + k] = hi[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? __builtin_fminf(v, s[w][threadIdx.x]) : __builtin_fmaxf(v, s[w][threadIdx.x]);
+        partial[blockIdx.x * 6 + threadIdx.x] = v;
     }
 }
 

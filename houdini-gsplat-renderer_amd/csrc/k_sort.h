@@ -7,10 +7,11 @@
 // Stability is what turns "sort by distance, then by tile" into per-tile
 // front-to-back lists, and what makes ties deterministic (lower index first).
 //
-// Roofline: HBM streaming.  Per pass and item: 4 B (hist) + 8 B (scatter read)
-// + 8 B (scatter write) = 20 B.  Ranking uses wave64 ballots (8 per digit
-// match), per-wave LDS digit counters, and an LDS reorder so that global writes
-// leave each workgroup as contiguous per-digit runs.
+// Roofline: HBM streaming.  Per pass and item with an 8-byte payload: 4 B (hist)
+// + 12 B (scatter read) + 12 B (scatter write) = 28 B.  Digits are 8 or 9 bits
+// wide (9-bit digits sort a <=27-bit key range in 3 passes).  Ranking uses
+// wave64 ballots (one per digit bit), per-wave LDS digit counters, and an LDS
+// reorder so that global writes leave each workgroup as contiguous per-digit runs.
 #pragma once
 #include "gsr_device.h"
 
@@ -129,14 +130,21 @@ k_scan_down(const uint32_t* in, uint32_t n, const uint32_t* __restrict__ partial
 }
 
 // ---------------------------------------------------------------------------
-// radix pass, kernel 1: per-workgroup digit histogram -> hist[digit * nblk + blk]
+// One LSD radix pass on a DBITS-wide digit (8 or 9 bits; BINS = 2^DBITS):
+//   k_radix_hist<DBITS>      per-workgroup digit histogram -> hist[digit * nblk + blk]
+//   k_scan_rows              one workgroup per digit: exclusive scan of its row (over workgroups),
+//                            row total -> totals[digit]
+//   k_radix_scatter<V,DBITS> digit bases = exclusive scan of totals (recomputed per workgroup in
+//                            LDS), stable ranking, LDS reorder, coalesced runs out
+template <int DBITS>
 __global__ void __launch_bounds__(RS_THREADS)
 k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ hist, uint32_t nblk)
 {
-    __shared__ uint32_t h[4][256];
+    constexpr int BINS = 1 << DBITS;
+    constexpr uint32_t MASK = BINS - 1;
+    __shared__ uint32_t h[4][BINS];
     const int wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) h[w][threadIdx.x] = 0;
+    for (int b = threadIdx.x; b < 4 * BINS; b += RS_THREADS) (&h[0][0])[b] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * RS_TILE;
     if (base + RS_TILE <= n) {
@@ -144,35 +152,61 @@ k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t*
 #pragma unroll
         for (int k = 0; k < RS_ITEMS / 4; ++k) {
             uint4 v = p[k * RS_THREADS + threadIdx.x];
-            atomicAdd(&h[wave][(v.x >> shift) & 255u], 1u);
-            atomicAdd(&h[wave][(v.y >> shift) & 255u], 1u);
-            atomicAdd(&h[wave][(v.z >> shift) & 255u], 1u);
-            atomicAdd(&h[wave][(v.w >> shift) & 255u], 1u);
+            atomicAdd(&h[wave][(v.x >> shift) & MASK], 1u);
+            atomicAdd(&h[wave][(v.y >> shift) & MASK], 1u);
+            atomicAdd(&h[wave][(v.z >> shift) & MASK], 1u);
+            atomicAdd(&h[wave][(v.w >> shift) & MASK], 1u);
         }
     } else {
         for (int k = 0; k < RS_ITEMS; ++k) {
             uint32_t i = base + k * RS_THREADS + threadIdx.x;
-            if (i < n) atomicAdd(&h[wave][(keys[i] >> shift) & 255u], 1u);
+            if (i < n) atomicAdd(&h[wave][(keys[i] >> shift) & MASK], 1u);
         }
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblk + blockIdx.x] =
-        h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+    for (int b = threadIdx.x; b < BINS; b += RS_THREADS)
+        hist[(size_t)b * nblk + blockIdx.x] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
 }
 
-// radix pass, kernel 2 (after the scan of hist): stable scatter.
+// grid = BINS workgroups; workgroup d scans row d of hist in place (exclusive), total -> totals[d]
+__global__ void __launch_bounds__(SC_THREADS)
+k_scan_rows(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t s_wave[4];
+    uint32_t* row = hist + (size_t)blockIdx.x * nblk;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblk; base += SC_THREADS * 4) {
+        const uint32_t i0 = base + threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < nblk) ? row[i0 + k] : 0u;
+        uint32_t tot;
+        uint32_t ex = carry + block_excl_scan_256(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < nblk) row[i0 + k] = ex;
+            ex += v[k];
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+// V = payload type: uint32_t (4 B) or uint2 (8 B: splat index + packed tile rect).
 // Item order inside a workgroup: wave w owns items [w*RS_WAVE_ITEMS, (w+1)*RS_WAVE_ITEMS) of the
 // tile, round k covers 64 consecutive items -> (wave, round, lane) is input order.
-// V = payload type: uint32_t (4 B) or uint2 (8 B: splat index + packed tile rect).
-template <typename V>
+template <typename V, int DBITS>
 __global__ void __launch_bounds__(RS_THREADS)
 k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in,
                 uint32_t* __restrict__ keys_out, V* __restrict__ vals_out, uint32_t n, int shift,
-                const uint32_t* __restrict__ offs, uint32_t nblk)
+                const uint32_t* __restrict__ offs, const uint32_t* __restrict__ totals, uint32_t nblk)
 {
-    __shared__ uint32_t wc[4][256];     // per-wave digit counters -> per-wave bases
-    __shared__ uint32_t dbase[256];     // first local sorted position of each digit
-    __shared__ uint32_t gadj[256];      // global offset of the digit run minus dbase
+    constexpr int BINS = 1 << DBITS;
+    constexpr uint32_t MASK = BINS - 1;
+    constexpr int PER = BINS / RS_THREADS;   // digits per thread in the bookkeeping step (1 or 2)
+    __shared__ uint32_t wc[4][BINS];    // per-wave digit counters -> per-wave bases
+    __shared__ uint32_t dbase[BINS];    // first local sorted position of each digit
+    __shared__ uint32_t gadj[BINS];     // global position of the digit run minus dbase
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t skeys[RS_TILE];
     __shared__ V svals[RS_TILE];
@@ -180,11 +214,20 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t tile_base = blockIdx.x * RS_TILE;
     const uint32_t nvalid = (n - tile_base < RS_TILE) ? (n - tile_base) : RS_TILE;
+    for (int b = threadIdx.x; b < 4 * BINS; b += RS_THREADS) (&wc[0][0])[b] = 0;
+    // digit bases: exclusive scan of the per-digit totals (thread t owns digits t*PER .. t*PER+PER-1)
+    {
+        uint32_t tv[PER], tsum = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) wc[w][threadIdx.x] = 0;
+        for (int k = 0; k < PER; ++k) { tv[k] = totals[threadIdx.x * PER + k]; tsum += tv[k]; }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan_256(tsum, s_wave, &tot);   // (contains the __syncthreads for wc too)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { gadj[threadIdx.x * PER + k] = ex; ex += tv[k]; }
+    }
     __syncthreads();
 
-    uint32_t k_[RS_ITEMS], meta[RS_ITEMS];  // meta = digit | rank_in_wave_digit << 8
+    uint32_t k_[RS_ITEMS], meta[RS_ITEMS];  // meta = digit | rank_in_wave_digit << DBITS
     V v_[RS_ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
@@ -194,12 +237,12 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
         uint32_t key = 0xffffffffu;
         V val{};
         if (valid) { key = keys_in[tile_base + li]; val = vals_in[tile_base + li]; }
-        // invalid tail items take digit 255: being last in input order they rank
+        // invalid tail items take the last digit: being last in input order they rank
         // after every valid item and are simply not written out
-        const uint32_t d = valid ? ((key >> shift) & 255u) : 255u;
+        const uint32_t d = valid ? ((key >> shift) & MASK) : MASK;
         unsigned long long m = ~0ull;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < DBITS; ++b) {
             const bool bit = (d >> b) & 1u;
             const unsigned long long bal = __ballot(bit);
             m &= bit ? bal : ~bal;
@@ -214,24 +257,35 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
         const int leader = __builtin_ctzll(m);
         prev = __shfl(prev, leader, 64);
         k_[r] = key; v_[r] = val;
-        meta[r] = d | ((prev + rank) << 8);
+        meta[r] = d | ((prev + rank) << DBITS);
     }
     __syncthreads();
-    {   // thread t = digit t: wave bases, digit totals, digit bases
-        const uint32_t c0 = wc[0][threadIdx.x], c1 = wc[1][threadIdx.x], c2 = wc[2][threadIdx.x],
-                       c3 = wc[3][threadIdx.x];
+    {   // thread t owns digits t*PER..: wave bases, digit totals in this tile, local digit bases
+        uint32_t tot_d[PER], tsum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int d = threadIdx.x * PER + k;
+            const uint32_t c0 = wc[0][d], c1 = wc[1][d], c2 = wc[2][d], c3 = wc[3][d];
+            wc[0][d] = 0; wc[1][d] = c0; wc[2][d] = c0 + c1; wc[3][d] = c0 + c1 + c2;
+            tot_d[k] = c0 + c1 + c2 + c3;
+            tsum += tot_d[k];
+        }
         uint32_t tot;
-        const uint32_t ex = block_excl_scan_256(c0 + c1 + c2 + c3, s_wave, &tot);
-        wc[0][threadIdx.x] = 0; wc[1][threadIdx.x] = c0; wc[2][threadIdx.x] = c0 + c1;
-        wc[3][threadIdx.x] = c0 + c1 + c2;
-        dbase[threadIdx.x] = ex;
-        gadj[threadIdx.x] = offs[(size_t)threadIdx.x * nblk + blockIdx.x] - ex;
+        uint32_t ex = block_excl_scan_256(tsum, s_wave, &tot);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int d = threadIdx.x * PER + k;
+            dbase[d] = ex;
+            // global position of this tile's run of digit d = digit base + rank of the tile inside the digit
+            gadj[d] = gadj[d] + offs[(size_t)d * nblk + blockIdx.x] - ex;
+            ex += tot_d[k];
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
-        const uint32_t d = meta[r] & 255u;
-        const uint32_t lp = dbase[d] + wc[wave][d] + (meta[r] >> 8);
+        const uint32_t d = meta[r] & MASK;
+        const uint32_t lp = dbase[d] + wc[wave][d] + (meta[r] >> DBITS);
         skeys[lp] = k_[r];
         svals[lp] = v_[r];
     }
@@ -241,7 +295,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
         const uint32_t j = r * RS_THREADS + threadIdx.x;
         if (j < nvalid) {
             const uint32_t key = skeys[j];
-            const uint32_t pos = gadj[(key >> shift) & 255u] + j;
+            const uint32_t pos = gadj[(key >> shift) & MASK] + j;
             keys_out[pos] = key;
             vals_out[pos] = svals[j];
         }

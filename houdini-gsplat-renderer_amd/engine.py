@@ -68,6 +68,7 @@ C_ABI_SYMBOLS = [
     "gsr_upload_begin", "gsr_upload_append", "gsr_upload_end", "gsr_upload", "gsr_set_row_shard", "gsr_band_rows",
     "gsr_stitch_bands", "gsr_render", "gsr_synchronize", "gsr_get_stats", "gsr_stats_reset", "gsr_set_option",
     "gsr_debug_read_records", "gsr_debug_read_depth_order", "gsr_debug_read_tile_lists", "gsr_debug_sort_pairs",
+    "gsr_debug_read_tile_work",
     "gsplat_renderer_create", "gsplat_renderer_get_instance", "gsplat_renderer_destroy",
     "gsplat_renderer_register_update", "gsplat_renderer_include_in_render_pass",
     "gsplat_renderer_flush_entries_for_matching_detail", "gsplat_renderer_generate_render_geometry",
@@ -116,6 +117,7 @@ def load_library() -> C.CDLL:
     L.gsr_debug_read_depth_order.argtypes = [vp, vp, i64]
     L.gsr_debug_read_tile_lists.argtypes = [vp, vp, vp, i64, vp, i64]
     L.gsr_debug_sort_pairs.argtypes = [vp, vp, vp, i64, i32]
+    L.gsr_debug_read_tile_work.argtypes = [vp, vp, i64]
     # host shim wrappers
     L.gsplat_renderer_create.restype = vp
     L.gsplat_renderer_create.argtypes = [i32]
@@ -313,6 +315,14 @@ class Engine:
         pv = np.zeros(max(npairs, 1), np.int32)
         _check(self.L.gsr_debug_read_tile_lists(self.h, ts.ctypes.data, te.ctypes.data, nt, pv.ctypes.data, npairs))
         return ts, te, pv[:npairs]
+
+    def debug_tile_work(self) -> np.ndarray:
+        """[tiles_y, tiles_x, 2] uint32: list entries scanned / records gathered per tile (last frame)"""
+        st = self.stats()
+        nt = st["tiles_x"] * st["tiles_y"]
+        out = np.zeros((nt, 2), np.uint32)
+        _check(self.L.gsr_debug_read_tile_work(self.h, out.ctypes.data, nt))
+        return out.reshape(st["tiles_y"], st["tiles_x"], 2)
 
     def debug_sort_pairs(self, keys: np.ndarray, vals: np.ndarray, key_bits: int = 32):
         k = np.ascontiguousarray(keys, dtype=np.uint32).copy()

@@ -51,9 +51,11 @@ class FrameGatherer:
     """Gathers band tensors to rank 0 and stitches the frame.  `dist` is torch.distributed
     (already initialised: backend nccl == RCCL on ROCm, or gloo on CPU) or None for 1 rank."""
 
-    def __init__(self, dist, rank: int, world: int, width: int, height: int, device, engine=None):
+    def __init__(self, dist, rank: int, world: int, width: int, height: int, device, engine=None,
+                 via_host: bool = False):
         import torch
 
+        self.via_host = via_host    # functional-test mode: collective on host copies (backend without GPU support)
         self.dist, self.rank, self.world = dist, rank, world
         self.width, self.height = width, height
         self.engine = engine
@@ -68,7 +70,15 @@ class FrameGatherer:
         """returns the full frame tensor on rank 0 (None elsewhere); 1 rank: the band itself"""
         if self.world == 1:
             return self.band
-        self.dist.gather(self.band, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0)
+        if self.via_host and self.band.is_cuda:
+            import torch
+            hb = self.band.cpu()
+            hg = [torch.empty_like(hb) for _ in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(hb, hg, dst=0)
+            if self.rank == 0:
+                self.gathered.copy_(torch.stack(hg))
+        else:
+            self.dist.gather(self.band, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0)
         if self.rank != 0:
             return None
         if self.band.is_cuda:

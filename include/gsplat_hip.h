@@ -161,6 +161,9 @@ int  gsr_debug_read_depth_order(gsr_context* ctx, int32_t* perm, int64_t n);
 int  gsr_debug_read_tile_lists(gsr_context* ctx, int32_t* list_start, int32_t* list_end, int64_t n_lists,
                                int32_t* pair_splat, int64_t n_pairs);
 
+/* per tile of the last frame: {list entries scanned, records gathered} by the blend kernel (uint32 pairs) */
+int  gsr_debug_read_tile_work(gsr_context* ctx, uint32_t* scanned_fetched, int64_t n_tiles);
+
 /* Stand-alone device radix sort of (key,value) u32 pairs on bits [0, key_bits):
  * the sort the pipeline uses, exposed for parity tests (host pointers). */
 int  gsr_debug_sort_pairs(gsr_context* ctx, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits);

@@ -9,13 +9,15 @@
 // Geometry: one 256-thread workgroup per 16x16 tile; wave w owns the 8x8
 // quadrant (w&1, w>>1), lane l the pixel (l&7, l>>3) of it -- a wave64 is
 // exactly one 8x8 pixel block, so all culling is wave-uniform.
-// Data flow: the tile walks the depth-ordered list of its SUPER-tile in chunks
-// of 256 entries (idx + packed tile rect, coalesced).  A thread whose entry's
-// rect contains this tile gathers the 48-B record (3 x dwordx4) one chunk
-// ahead, drops it into a double-buffered LDS stage with a 4-bit
-// quadrant-overlap mask (0 for entries that miss the tile), and every wave
-// turns those masks into 64-bit ballots so that it only ever touches records
-// whose bbox reaches its quadrant.
+// Data flow (scan -> compact -> composite): the tile walks the depth-ordered list of its
+// SUPER-tile 1024 entries at a time (idx + packed tile rect, 8 B each, coalesced, prefetched one
+// step ahead); entries whose rect contains this tile are COMPACTED, in list order, into an LDS hit
+// queue (wave ballots + a 16-entry cross-wave prefix).  Compositing then runs in rounds of 256
+// hits: each thread gathers one 48-B record (3 x dwordx4), computes a 4-bit
+// quadrant-overlap mask (separating-axis test) and stages both in LDS; every wave turns the masks
+// into 64-bit ballots so that it only touches records that reach its quadrant, and evaluates them
+// two at a time with packed FP32 math.  Scanning is 4 entries/thread/step and SAT/staging run on
+// fully populated waves, so sparse lists cost little.
 // Early-out: a PIXEL stops accumulating once 1-A < 2^-14 (dropped contribution
 // <= 2^-14 * max colour, inside the 1e-3 budget; being per pixel it does not
 // depend on chunking, so sharded and unsharded frames are bit-identical); a wave
@@ -24,7 +26,15 @@
 #pragma once
 #include "gsr_device.h"
 
-#define BL_CHUNK 256
+#ifndef BL_ROUND
+#define BL_ROUND 256          // records composited per round (at most one per thread)
+#endif
+#ifndef BL_LOOKAHEAD
+#define BL_LOOKAHEAD 0        // 1 = gather the next round's records while the current one is composited
+                              // (measured no faster on MI355X, and it fetches a wasted round per tile)
+#endif
+#define BL_SCAN_K 4           // list entries scanned per thread per scan step
+#define BL_QCAP 2048          // hit-queue ring capacity (>= 2*BL_ROUND + BL_SCAN_K*256)
 #define GSR_T_MIN 6.103515625e-05f  // 2^-14
 
 struct GsrBlendArgs {
@@ -44,10 +54,12 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
         const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
         const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint2* __restrict__ tile_work)
 {
-    __shared__ float4 s0[2][BL_CHUNK];   // cx, cy, ex, ey
-    __shared__ float4 s1[2][BL_CHUNK];   // is1, is2, (hx, hy unused after the mask)
-    __shared__ float4 s2[2][BL_CHUNK];   // r, g, b, opacity
-    __shared__ uint32_t smask[2][BL_CHUNK];
+    __shared__ float4 s0[BL_ROUND];   // cx, cy, ex, ey
+    __shared__ float4 s1[BL_ROUND];   // is1, is2, (hx, hy unused after the mask)
+    __shared__ float4 s2[BL_ROUND];   // r, g, b, opacity
+    __shared__ uint32_t smask[BL_ROUND];
+    __shared__ uint32_t q[BL_QCAP];   // hit queue: splat indices in list (= depth) order
+    __shared__ uint32_t scnt[2][BL_SCAN_K][4];
     __shared__ uint32_t sdone[2][4];
     __shared__ uint32_t sfetched;
 
@@ -72,32 +84,86 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
 
     float C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, A = 0.0f;
     bool wave_done = false;
-    int chunks_read = 0;
     uint32_t my_fetched = 0;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    // list entries two chunks ahead, records one chunk ahead
     auto tile_in = [&](uint32_t rc) {
         const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = (rc >> 16) & 255, y1 = rc >> 24;
         return tx >= x0 && tx <= x1 && gty >= y0 && gty <= y1;
     };
-    uint32_t e_idx = 0, n_idx = 0;   // entry of the chunk being gathered next / the one after
-    bool e_hit = false, n_hit = false;
-    if (tid < n) { const uint2 e = svals[s + tid]; e_idx = e.x; e_hit = tile_in(e.y); }
-    if (BL_CHUNK + tid < n) { const uint2 e = svals[s + BL_CHUNK + tid]; n_idx = e.x; n_hit = tile_in(e.y); }
-    chunks_read = 2;
-    float4 r0, r1, r2;
-    bool have = e_hit;
-    if (have) {
-        const float4* p = reinterpret_cast<const float4*>(recs + e_idx);
-        r0 = p[0]; r1 = p[1]; r2 = p[2];
-        ++my_fetched;
-    }
 
-    for (int c = 0; c * BL_CHUNK < n; ++c) {
-        const int buf = c & 1;
+    // ---- scan state (identical in every thread)
+    int scan_pos = 0;                 // next list entry to scan
+    uint32_t q_head = 0, q_tail = 0;  // monotonic; slot = counter & (BL_QCAP-1)
+    int spar = 0;
+    uint2 pre[BL_SCAN_K];             // entries of the next scan step, prefetched
+#pragma unroll
+    for (int k = 0; k < BL_SCAN_K; ++k) {
+        const int i = k * 256 + tid;
+        pre[k] = (i < n) ? svals[s + i] : make_uint2(0u, GSR_RECT_EMPTY);
+    }
+    // ---- round state
+    float4 r0, r1, r2;                // record of the upcoming round held by this thread
+    bool have = false;
+    int pending = 0;                  // records of the upcoming round already gathered into registers
+    int round = 0;
+
+    for (;;) {
+        // (1) SCAN until two rounds' worth of hits are queued, or the list ends
+        bool scanned_any = false;
+        while ((int)(q_tail - q_head) < (1 + BL_LOOKAHEAD) * BL_ROUND && scan_pos < n) {
+            uint32_t rank[BL_SCAN_K];
+            bool hit[BL_SCAN_K];
+#pragma unroll
+            for (int k = 0; k < BL_SCAN_K; ++k) {
+                hit[k] = tile_in(pre[k].y);          // padding entries carry an empty rect
+                const unsigned long long bal = __ballot(hit[k]);
+                rank[k] = (uint32_t)__builtin_popcountll(bal & lt_mask);
+                if (lane == 0) scnt[spar][k][wave] = (uint32_t)__builtin_popcountll(bal);
+            }
+            __syncthreads();
+            uint32_t tot = 0, mybase[BL_SCAN_K];
+#pragma unroll
+            for (int k = 0; k < BL_SCAN_K; ++k)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if (w == wave) mybase[k] = tot;
+                    tot += scnt[spar][k][w];
+                }
+#pragma unroll
+            for (int k = 0; k < BL_SCAN_K; ++k)
+                if (hit[k]) q[(q_tail + mybase[k] + rank[k]) & (BL_QCAP - 1)] = pre[k].x;
+            q_tail += tot;
+            scan_pos += BL_SCAN_K * 256;
+            spar ^= 1;
+            scanned_any = true;
+#pragma unroll
+            for (int k = 0; k < BL_SCAN_K; ++k) {   // prefetch the next step's entries
+                const int i = scan_pos + k * 256 + tid;
+                pre[k] = (i < n) ? svals[s + i] : make_uint2(0u, GSR_RECT_EMPTY);
+            }
+        }
+        if (scanned_any) __syncthreads();            // queue writes visible to every wave
+
+        // (2) records of this round: normally gathered one round ahead; otherwise (first round, or the
+        //     queue had run dry) gather them now
+        const int avail = (int)(q_tail - q_head);
+        if (pending == 0) {
+            pending = avail < BL_ROUND ? avail : BL_ROUND;
+            have = tid < pending;
+            if (have) {
+                const float4* p = reinterpret_cast<const float4*>(recs + q[(q_head + tid) & (BL_QCAP - 1)]);
+                r0 = p[0]; r1 = p[1]; r2 = p[2];
+                ++my_fetched;
+            }
+        }
+        const int take = pending;
+        if (take == 0) break;                         // list exhausted and queue empty
+
+        // (3) stage this round
         uint32_t m = 0;
         if (have) {
-            s0[buf][tid] = r0; s1[buf][tid] = r1; s2[buf][tid] = r2;
+            s0[tid] = r0; s1[tid] = r1; s2[tid] = r2;
             // Which 8x8 quadrants can the splat touch?  Separating-axis test of the oriented quad
             // (shrunk to the radius where alpha can still reach 1/255) against each quadrant's box of
             // pixel centres: the box axes (= bbox test) and the quad's own two axes.  Conservative.
@@ -117,41 +183,41 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
                 if (box && (((a.flags & GSR_FLAG_NO_SAT) != 0) || (pu <= lim1 && pv <= lim2))) m |= 1u << qd;
             }
         }
-        smask[buf][tid] = m;
-        if (lane == 0) sdone[buf][wave] = wave_done ? 1u : 0u;
+        smask[tid] = m;
+        const int rpar = round & 1;
+        if (lane == 0) sdone[rpar][wave] = wave_done ? 1u : 0u;
         __syncthreads();
-        const bool block_done = (sdone[buf][0] & sdone[buf][1] & sdone[buf][2] & sdone[buf][3]) != 0u;
+        const bool block_done = (sdone[rpar][0] & sdone[rpar][1] & sdone[rpar][2] & sdone[rpar][3]) != 0u;
         if (block_done) break;
-        const int cn = (n - c * BL_CHUNK < BL_CHUNK) ? (n - c * BL_CHUNK) : BL_CHUNK;
 
-        // software pipeline: gather chunk c+1's records, fetch chunk c+2's list entries
-        have = n_hit;
+        // (4) gather the NEXT round's records while this one is composited
+        q_head += (uint32_t)take;
+        pending = BL_LOOKAHEAD ? (int)(q_tail - q_head) : 0;
+        if (pending > BL_ROUND) pending = BL_ROUND;
+        have = tid < pending;
         if (have) {
-            const float4* p = reinterpret_cast<const float4*>(recs + n_idx);
+            const float4* p = reinterpret_cast<const float4*>(recs + q[(q_head + tid) & (BL_QCAP - 1)]);
             r0 = p[0]; r1 = p[1]; r2 = p[2];
             ++my_fetched;
         }
-        {
-            ++chunks_read;
-            const int nn = (c + 2) * BL_CHUNK + tid;
-            n_hit = false;
-            if (nn < n) { const uint2 e = svals[s + nn]; n_idx = e.x; n_hit = tile_in(e.y); }
-        }
 
+        // (5) composite
         if (!wave_done) {
-            for (int g = 0; g * 64 < cn; ++g) {
+            for (int g = 0; g * 64 < take; ++g) {
                 const int j0 = g * 64;
-                unsigned long long acc = __ballot((smask[buf][j0 + lane] >> wave) & 1u);
+                unsigned long long acc = __ballot((smask[j0 + lane] >> wave) & 1u);
                 if (acc == 0ull) continue;
                 while (acc) {
-                    // two records per iteration (packed FP32); an odd tail evaluates its record twice
+                    // two records per iteration (packed FP32); an odd tail evaluates its record twice.
+                    // (Measured: prefetching the next pair's LDS reads, or four records per iteration, are
+                    //  both SLOWER -- the loop is VALU-issue bound, extra registers only cost occupancy.)
                     const int ja = j0 + __builtin_ctzll(acc);
                     acc &= acc - 1;
                     const bool two = acc != 0ull;
                     const int jb = two ? j0 + __builtin_ctzll(acc) : ja;
                     acc &= acc - 1;   // no-op when acc == 0
-                    const float4 a0 = s0[buf][ja], a1 = s1[buf][ja], a2 = s2[buf][ja];
-                    const float4 b0 = s0[buf][jb], b1 = s1[buf][jb], b2 = s2[buf][jb];
+                    const float4 a0 = s0[ja], a1 = s1[ja], a2 = s2[ja];
+                    const float4 b0 = s0[jb], b1 = s1[jb], b2 = s2[jb];
                     const gsr_v2f dx = (gsr_v2f)(fx) - (gsr_v2f){a0.x, b0.x};
                     const gsr_v2f dy = (gsr_v2f)(fy) - (gsr_v2f){a0.y, b0.y};
                     const gsr_v2f ex = {a0.z, b0.z}, ey = {a0.w, b0.w};
@@ -185,6 +251,8 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
                 if (__all(!pix_ok || (1.0f - A) < GSR_T_MIN)) { wave_done = true; break; }
             }
         }
+        ++round;
+        __syncthreads();   // staging area (and consumed queue slots) may be overwritten from here on
     }
     if (pix_ok) {
         const int brow = lty * GSR_TILE_PX + (wave >> 1) * 8 + (lane >> 3);
@@ -197,8 +265,9 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
     if (lane == 0) atomicAdd(&sfetched, my_fetched);
     __syncthreads();
     if (tid == 0) {
-        const int scanned = (chunks_read * BL_CHUNK < n) ? chunks_read * BL_CHUNK : n;
-        tile_work[tile] = make_uint2((uint32_t)scanned, sfetched);
+        // entries actually read: everything up to scan_pos plus the prefetched step
+        const int rd = scan_pos + BL_SCAN_K * 256;
+        tile_work[tile] = make_uint2((uint32_t)(rd < n ? rd : n), sfetched);
     }
 }
 

@@ -192,9 +192,18 @@ def main():
     # algorithmic bytes of k_blend: 8 B per list entry scanned + 48 B per record gathered + one RGBA-f32 store per pixel
     bytes_blend = pair_b * scanned + rec_b * d_eff + 16.0 * own_px
     achieved = bytes_blend / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
+    # HBM traffic of k_blend per launch from the PMC pass of this same command (scripts_gpu_pmc.sh ->
+    # profiles/pmc_traffic.json; 2*FETCH_SIZE + WRITE_SIZE as the MI355X guide prescribes); null if absent
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath) and world == 1 and args.config == "C4" and args.splats is None:
+        try:
+            traffic = float(json.load(open(tpath))["k_blend"]["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
     roofline = {
         "bound": "hbm", "kernel": "k_blend", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
         "avg_launch_ms": blend_ms, "algorithmic_bytes_per_launch": bytes_blend,
         "records_gathered_per_launch": d_eff, "entries_scanned_per_launch": scanned,
         "pairs_sorted_last_frame": st["pairs_total"], "record_bytes": rec_b, "entry_bytes": pair_b,

@@ -23,3 +23,16 @@ for k in sorted(acc, key=lambda k: -acc[k].get("SQ_WAVE_CYCLES", [0, 1])[0]):
         if c in acc[k]:
             s, n = acc[k][c]
             print(f"   {c:28s} {s / n:18.1f}   (dispatches {n})")
+
+# HBM traffic per kernel launch, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950:
+# FETCH_SIZE (KiB) under-reports wide coalesced reads by exactly 2x, WRITE_SIZE (KiB) is taken as is.
+import json
+traffic = {}
+for k in acc:
+    if "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+        f = acc[k]["FETCH_SIZE"][0] / acc[k]["FETCH_SIZE"][1]
+        w = acc[k]["WRITE_SIZE"][0] / acc[k]["WRITE_SIZE"][1]
+        traffic[k] = {"fetch_KiB_reported": f, "write_KiB_reported": w,
+                      "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
+                      "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB->bytes); calibrated on k_preprocess whose reads are a pure stream"}
+json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)

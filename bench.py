@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--no-swizzle", action="store_true", help="disable the XCD-aware tile mapping (A/B)")
     ap.add_argument("--super-tile", type=int, default=0, help="super-tile edge in tiles (0 = auto) (A/B)")
     ap.add_argument("--flags", type=int, default=0, help="GSR_OPT_DEBUG_FLAGS (A/B)")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="1 = strictly serial frames; 2 (default) = frame f+1's front end overlaps frame f's blend")
     ap.add_argument("--verify", action="store_true",
                     help="N>1: also render the last frame unsharded on rank 0 and require the stitched frame to be bit-identical")
     return ap.parse_args()
@@ -134,6 +136,7 @@ def main():
     eng.set_option(pkg.engine.OPT_XCD_SWIZZLE, 0 if args.no_swizzle else 1)
     eng.set_option(pkg.engine.OPT_SUPER_TILE, args.super_tile)
     eng.set_option(pkg.engine.OPT_DEBUG_FLAGS, args.flags)
+    eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, args.frames_in_flight)
     if world > 1:
         eng.set_row_shard(rank, world)
     eng.upload(splats)  # once: geometry stays resident in HBM
@@ -230,7 +233,7 @@ def main():
             "config": {"workload": f"{args.config}: {splats.n} synthetic splats (SH deg {order}, seed {cfg['seed']}), "
                                    f"{W}x{H}, orbiting camera (re-sort every frame)",
                        "parallelism": f"tile-row shard x{world}" if world > 1 else "single GPU",
-                       "n_splats": splats.n, "width": W, "height": H},
+                       "n_splats": splats.n, "width": W, "height": H, "frames_in_flight": args.frames_in_flight},
             "roofline": roofline,
             "stages_ms_last_frame": stages,
             "n_visible": st["n_visible"],

@@ -30,7 +30,7 @@
 #include "k_sort.h"
 
 #define GSR_VERSION_STR "gsplat_hip 0.1.0 (gfx950)"
-#define GSR_EVENT_SLOTS 4
+#define GSR_MAX_SLOTS 2
 #define GSR_STAGE_EVENTS 7
 
 static thread_local char g_err[512] = "";
@@ -52,23 +52,13 @@ static int set_err(int code, const char* fmt, ...)
                            hipGetErrorString(e_), __FILE__, __LINE__);                             \
     } while (0)
 
-struct gsr_context {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
+// Everything one frame in flight owns: its HIP stream, the per-frame HBM arrays, the small
+// mailboxes and the stage events.  Two slots alternate, so that frame f+1's memory-bound front end
+// (k_preprocess, depth sort, binning) overlaps frame f's VALU-bound k_blend on the GPU.
+struct FrameSlot {
     hipStream_t stream = nullptr;
-
-    // geometry (SoA of 16-byte vectors)
-    uint32_t n = 0, cap = 0;
-    bool has_sh = false;
-    float origin[3] = {0, 0, 0};
-    uint64_t geo_gen = 0;
-    float4* geoA = nullptr;
-    uint4* geoB = nullptr;
-    uint4* col = nullptr;
-    int col_chunks = 0;
-    bool uploading = false;
-    uint32_t up_total = 0, up_filled = 0;
-
+    hipEvent_t ev_done = nullptr;      // end of the frame on `stream`
+    hipEvent_t ev_user = nullptr;      // caller's stream position at gsr_render entry
     // per-splat frame buffers
     GsrRecord* rec = nullptr;
     uint32_t *keyA = nullptr, *keyB = nullptr;
@@ -80,44 +70,66 @@ struct gsr_context {
     uint32_t* partial = nullptr;
     size_t partial_cap = 0;
     uint32_t* totals = nullptr;        // [512] per-digit totals of the current radix pass
-    // bounding box of the uploaded positions (bounds the sort keys of a frame)
-    bool bbox_ok = false;
-    double bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
-    uint32_t key_min = 0;              // of the frame whose order is cached
     // pairs
     uint32_t *pkA = nullptr, *pkB = nullptr;
     uint2 *pvA = nullptr, *pvB = nullptr;        // pair payload: (splat index, packed tile rect)
     size_t pair_cap = 0;
-    int32_t *sstart = nullptr, *send = nullptr;  // [256 + 1] super-tile ranges
+    int32_t *sstart = nullptr, *send = nullptr;  // super-tile ranges
     uint2* tile_work = nullptr;        // per tile: entries scanned, records gathered
-    int32_t* tile_map = nullptr;       // blockIdx -> tile (XCD-aware order), -1 = idle block
-    size_t tile_cap = 0, map_cap = 0;
-    int map_w = 0, map_h = 0, map_si = -1, map_sc = 0, map_shift = -1, map_grid = 0;
-    float* fb = nullptr;
+    size_t tile_cap = 0;
+    float* fb = nullptr;               // staging for host-pointer output
     size_t fb_cap = 0;
     // small device/host mailboxes
     unsigned long long* counters = nullptr;  // [0] visible [1] records gathered [2] running [3] entries scanned [4] running
     uint32_t* d_total = nullptr;
     uint32_t* h_total = nullptr;             // pinned
-    unsigned long long* h_counters = nullptr;  // pinned [2]
-
-    int shard_index = 0, shard_count = 1;
-    int opt_swizzle = 1, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0;
-
+    unsigned long long* h_counters = nullptr;  // pinned
     // depth-sort cache (argsortByDistance semantics)
     bool sort_valid = false;
     float sort_cam[3] = {0, 0, 0};
     uint64_t sort_gen = 0;
-
-    // last frame description
+    uint32_t key_min = 0;              // of the frame whose order is cached
+    // last frame rendered in this slot
     int last_tiles_x = 0, last_local_ty = 0, last_supers = 0;
     uint32_t last_pairs = 0;
-
-    // stats
-    gsr_stats st{};
-    hipEvent_t ev[GSR_EVENT_SLOTS][GSR_STAGE_EVENTS];
-    bool ev_pending[GSR_EVENT_SLOTS] = {false, false, false, false};
+    int super_tile = 0, stiles_x = 0, stiles_y = 0;
+    uint64_t frame_id = 0;             // 1-based id of that frame, 0 = never used
+    hipEvent_t ev[GSR_STAGE_EVENTS];
+    bool ev_pending = false;
     bool ev_ok = false;
+};
+
+struct gsr_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;      // the PUBLIC stream: results are ordered on it
+
+    // geometry (SoA of 16-byte vectors), shared read-only by the frame slots
+    uint32_t n = 0, cap = 0;
+    bool has_sh = false;
+    float origin[3] = {0, 0, 0};
+    uint64_t geo_gen = 0;
+    float4* geoA = nullptr;
+    uint4* geoB = nullptr;
+    uint4* col = nullptr;
+    int col_chunks = 0;
+    bool uploading = false;
+    uint32_t up_total = 0, up_filled = 0;
+    // bounding box of the uploaded positions (bounds the sort keys of a frame)
+    bool bbox_ok = false;
+    double bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
+
+    FrameSlot slot[GSR_MAX_SLOTS];
+    int nslots = GSR_MAX_SLOTS;        // frames in flight (GSR_OPT_FRAMES_IN_FLIGHT)
+
+    int32_t* tile_map = nullptr;       // blockIdx -> tile (XCD-aware order), -1 = idle block
+    size_t map_cap = 0;
+    int map_w = 0, map_h = 0, map_si = -1, map_sc = 0, map_shift = -1, map_grid = 0;
+
+    int shard_index = 0, shard_count = 1;
+    int opt_swizzle = 1, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0;
+
+    gsr_stats st{};
     uint64_t frame_no = 0;
 };
 
@@ -149,6 +161,57 @@ extern "C" int gsr_device_count(void)
 extern "C" const char* gsr_last_error(void) { return g_err; }
 extern "C" const char* gsr_version(void) { return GSR_VERSION_STR; }
 
+static int sync_all(gsr_context* c)
+{
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k)
+        if (c->slot[k].stream) HIP_TRY(hipStreamSynchronize(c->slot[k].stream));
+    if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSR_OK;
+}
+
+static bool slot_init(FrameSlot& sl)
+{
+    bool ok = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&sl.ev_user, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.counters), 8 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_total), sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.totals), 512 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), 8 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMemset(sl.counters, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
+    if (ok) {
+        for (int k = 0; k < GSR_STAGE_EVENTS; ++k) sl.ev[k] = nullptr;
+        sl.ev_ok = true;
+        for (int k = 0; k < GSR_STAGE_EVENTS && ok; ++k) ok = hipEventCreate(&sl.ev[k]) == hipSuccess;
+    }
+    return ok;
+}
+
+static void slot_free_splat_arrays(FrameSlot& sl)
+{
+    dev_free(sl.rec); dev_free(sl.keyA); dev_free(sl.keyB); dev_free(sl.valA); dev_free(sl.valB);
+    dev_free(sl.rect); dev_free(sl.cnt); dev_free(sl.poff);
+    sl.sort_valid = false;
+}
+
+static void slot_destroy(FrameSlot& sl)
+{
+    slot_free_splat_arrays(sl);
+    dev_free(sl.hist); dev_free(sl.partial); dev_free(sl.totals);
+    dev_free(sl.pkA); dev_free(sl.pkB); dev_free(sl.pvA); dev_free(sl.pvB);
+    dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.fb);
+    dev_free(sl.counters); dev_free(sl.d_total);
+    if (sl.h_total) (void)hipHostFree(sl.h_total);
+    if (sl.h_counters) (void)hipHostFree(sl.h_counters);
+    if (sl.ev_ok)
+        for (int k = 0; k < GSR_STAGE_EVENTS; ++k)
+            if (sl.ev[k]) (void)hipEventDestroy(sl.ev[k]);
+    if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    if (sl.ev_user) (void)hipEventDestroy(sl.ev_user);
+    if (sl.stream) (void)hipStreamDestroy(sl.stream);
+}
+
 extern "C" int gsr_create(int device, gsr_context** out)
 {
     if (!out) return set_err(GSR_E_INVALID, "gsr_create: out is NULL");
@@ -164,20 +227,10 @@ extern "C" int gsr_create(int device, gsr_context** out)
     if (e != hipSuccess) { delete c; return set_err(GSR_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
     bool ok = true;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&c->counters), 8 * sizeof(unsigned long long)) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&c->d_total), sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&c->totals), 512 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_total), sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), 8 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipMemset(c->counters, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
-    if (ok) {
-        c->ev_ok = true;
-        for (int s = 0; s < GSR_EVENT_SLOTS && ok; ++s)
-            for (int k = 0; k < GSR_STAGE_EVENTS && ok; ++k) ok = hipEventCreate(&c->ev[s][k]) == hipSuccess;
-    }
+    for (int k = 0; k < GSR_MAX_SLOTS && ok; ++k) ok = slot_init(c->slot[k]);
     if (!ok) {
         gsr_destroy(c);
-        return set_err(GSR_E_HIP, "gsr_create: allocating context mailboxes/events failed");
+        return set_err(GSR_E_HIP, "gsr_create: allocating frame slots (streams/events/mailboxes) failed");
     }
     c->st.record_bytes = (int32_t)sizeof(GsrRecord);
     c->st.pair_bytes = 8;
@@ -188,8 +241,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
 static void free_geometry(gsr_context* c)
 {
     dev_free(c->geoA); dev_free(c->geoB); dev_free(c->col);
-    dev_free(c->rec); dev_free(c->keyA); dev_free(c->keyB); dev_free(c->valA); dev_free(c->valB);
-    dev_free(c->rect); dev_free(c->cnt); dev_free(c->poff);
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k) slot_free_splat_arrays(c->slot[k]);
     c->cap = 0; c->n = 0;
 }
 
@@ -197,19 +249,10 @@ extern "C" void gsr_destroy(gsr_context* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     free_geometry(c);
-    dev_free(c->hist); dev_free(c->partial);
-    dev_free(c->pkA); dev_free(c->pkB); dev_free(c->pvA); dev_free(c->pvB);
-    dev_free(c->sstart); dev_free(c->send); dev_free(c->tile_work); dev_free(c->tile_map);
-    dev_free(c->fb);
-    dev_free(c->counters); dev_free(c->d_total); dev_free(c->totals);
-    if (c->h_total) (void)hipHostFree(c->h_total);
-    if (c->h_counters) (void)hipHostFree(c->h_counters);
-    if (c->ev_ok)
-        for (int s = 0; s < GSR_EVENT_SLOTS; ++s)
-            for (int k = 0; k < GSR_STAGE_EVENTS; ++k)
-                if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k) slot_destroy(c->slot[k]);
+    dev_free(c->tile_map);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -218,7 +261,8 @@ extern "C" int gsr_set_stream(gsr_context* c, void* s)
 {
     if (!c) return set_err(GSR_E_INVALID, "gsr_set_stream: ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = sync_all(c);
+    if (rc) return rc;
     c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
     return GSR_OK;
 }
@@ -229,13 +273,25 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
     switch (option) {
     case GSR_OPT_XCD_SWIZZLE: c->opt_swizzle = value ? 1 : 0; break;
     case GSR_OPT_STAGE_TIMING: c->opt_timing = value ? 1 : 0; break;
-    case GSR_OPT_SORT_CACHE: c->opt_sort_cache = value ? 1 : 0; c->sort_valid = false; break;
+    case GSR_OPT_SORT_CACHE:
+        c->opt_sort_cache = value ? 1 : 0;
+        for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
+        break;
     case GSR_OPT_DEBUG_FLAGS: c->opt_flags = value; break;
     case GSR_OPT_SUPER_TILE:
         if (value != 0 && (value < 1 || value > 16 || (value & (value - 1))))
             return set_err(GSR_E_INVALID, "gsr_set_option: super-tile edge must be 0 (auto) or 1,2,4,8,16");
         c->opt_super = value;
         break;
+    case GSR_OPT_FRAMES_IN_FLIGHT: {
+        if (value < 1 || value > GSR_MAX_SLOTS)
+            return set_err(GSR_E_INVALID, "gsr_set_option: frames in flight must be 1..%d", GSR_MAX_SLOTS);
+        HIP_TRY(hipSetDevice(c->device));
+        int rc = sync_all(c);
+        if (rc) return rc;
+        c->nslots = value;
+        break;
+    }
     default: return set_err(GSR_E_INVALID, "gsr_set_option: unknown option %d", option);
     }
     return GSR_OK;
@@ -248,19 +304,25 @@ extern "C" int gsr_upload_begin(gsr_context* c, int64_t total, int has_sh, const
     if (!c) return set_err(GSR_E_INVALID, "gsr_upload_begin: ctx is NULL");
     if (total < 0 || total > 0x7fffffffll) return set_err(GSR_E_INVALID, "gsr_upload_begin: bad splat count %lld", (long long)total);
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = sync_all(c);
+    if (rc) return rc;
     const uint32_t n = (uint32_t)total;
     const int chunks = has_sh ? 6 : 1;
     if (n > c->cap || chunks != c->col_chunks) {
         free_geometry(c);
         const size_t cap = n ? n : 1;
-        int rc;
-        if ((rc = dev_alloc(&c->geoA, cap)) || (rc = dev_alloc(&c->geoB, cap)) || (rc = dev_alloc(&c->col, cap * chunks)) ||
-            (rc = dev_alloc(&c->rec, cap)) || (rc = dev_alloc(&c->keyA, cap)) || (rc = dev_alloc(&c->keyB, cap)) ||
-            (rc = dev_alloc(&c->valA, cap)) || (rc = dev_alloc(&c->valB, cap)) || (rc = dev_alloc(&c->rect, cap)) ||
-            (rc = dev_alloc(&c->cnt, cap + 8)) || (rc = dev_alloc(&c->poff, cap + 8))) {
+        if ((rc = dev_alloc(&c->geoA, cap)) || (rc = dev_alloc(&c->geoB, cap)) || (rc = dev_alloc(&c->col, cap * chunks))) {
             free_geometry(c);
             return rc;
+        }
+        for (int k = 0; k < GSR_MAX_SLOTS; ++k) {
+            FrameSlot& sl = c->slot[k];
+            if ((rc = dev_alloc(&sl.rec, cap)) || (rc = dev_alloc(&sl.keyA, cap)) || (rc = dev_alloc(&sl.keyB, cap)) ||
+                (rc = dev_alloc(&sl.valA, cap)) || (rc = dev_alloc(&sl.valB, cap)) || (rc = dev_alloc(&sl.rect, cap)) ||
+                (rc = dev_alloc(&sl.cnt, cap + 8)) || (rc = dev_alloc(&sl.poff, cap + 8))) {
+                free_geometry(c);
+                return rc;
+            }
         }
         c->cap = (uint32_t)cap;
         c->col_chunks = chunks;
@@ -271,7 +333,7 @@ extern "C" int gsr_upload_begin(gsr_context* c, int64_t total, int has_sh, const
     c->up_filled = 0;
     c->uploading = true;
     for (int k = 0; k < 3; ++k) c->origin[k] = origin ? origin[k] : 0.0f;
-    c->sort_valid = false;
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
     return GSR_OK;
 }
 
@@ -287,6 +349,7 @@ extern "C" int gsr_upload_append(gsr_context* c, int64_t n64, const float* P, co
     if (c->has_sh && (!shx || !shy || !shz)) return set_err(GSR_E_INVALID, "gsr_upload_append: SH announced but arrays are NULL");
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t n = (uint32_t)n64;
+    hipStream_t us = c->slot[0].stream;
     // raw staging buffers (freed before return: upload is not the per-frame path)
     float *dP = nullptr, *dA = nullptr;
     uint16_t *dCd = nullptr, *dS = nullptr, *dO = nullptr, *dX = nullptr, *dY = nullptr, *dZ = nullptr;
@@ -296,16 +359,16 @@ extern "C" int gsr_upload_append(gsr_context* c, int64_t n64, const float* P, co
         (rc = dev_alloc(&dS, (size_t)n * 3)) || (rc = dev_alloc(&dO, (size_t)n * 4))) { cleanup(); return rc; }
     if (c->has_sh && ((rc = dev_alloc(&dX, (size_t)n * 16)) || (rc = dev_alloc(&dY, (size_t)n * 16)) || (rc = dev_alloc(&dZ, (size_t)n * 16)))) { cleanup(); return rc; }
     hipError_t e = hipSuccess;
-    auto h2d = [&](void* d, const void* h, size_t bytes) { if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream); };
+    auto h2d = [&](void* d, const void* h, size_t bytes) { if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, us); };
     h2d(dP, P, (size_t)n * 12); h2d(dA, alpha, (size_t)n * 4); h2d(dCd, Cd, (size_t)n * 6);
     h2d(dS, scale, (size_t)n * 6); h2d(dO, orient, (size_t)n * 8);
     if (c->has_sh) { h2d(dX, shx, (size_t)n * 32); h2d(dY, shy, (size_t)n * 32); h2d(dZ, shz, (size_t)n * 32); }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_repack, dim3(div_up(n, 256)), dim3(256), 0, c->stream, n, c->up_filled, c->cap,
+        hipLaunchKernelGGL(k_repack, dim3(div_up(n, 256)), dim3(256), 0, us, n, c->up_filled, c->cap,
                            c->has_sh ? 1 : 0, dP, dCd, dA, dS, dO, dX, dY, dZ, c->geoA, c->geoB, c->col);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(us);
     cleanup();
     if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_upload_append: %s", hipGetErrorString(e));
     c->up_filled += n;
@@ -323,14 +386,15 @@ extern "C" int gsr_upload_end(gsr_context* c)
     c->bbox_ok = false;
     if (c->n > 0) {
         HIP_TRY(hipSetDevice(c->device));
+        hipStream_t us = c->slot[0].stream;
         const int grid = 512;
         float* d_part = nullptr;
         int rc = dev_alloc(&d_part, (size_t)grid * 6);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_bbox_partials, dim3(grid), dim3(256), 0, c->stream, c->geoA, c->n, d_part);
+        hipLaunchKernelGGL(k_bbox_partials, dim3(grid), dim3(256), 0, us, c->geoA, c->n, d_part);
         std::vector<float> hp((size_t)grid * 6);
-        hipError_t e = hipMemcpyAsync(hp.data(), d_part, hp.size() * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipError_t e = hipMemcpyAsync(hp.data(), d_part, hp.size() * 4, hipMemcpyDeviceToHost, us);
+        if (e == hipSuccess) e = hipStreamSynchronize(us);
         dev_free(d_part);
         if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_upload_end: %s", hipGetErrorString(e));
         bool ok = true;
@@ -345,7 +409,7 @@ extern "C" int gsr_upload_end(gsr_context* c)
         c->bbox_ok = ok;
     }
     c->geo_gen++;
-    c->sort_valid = false;
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
     c->st.n_splats = c->n;
     return GSR_OK;
 }
@@ -395,7 +459,7 @@ extern "C" int gsr_stitch_bands(gsr_context* c, const float* gathered, int count
 }
 
 // ---------------------------------------------------------------------------
-// scan + sort drivers
+// scan + sort drivers (all on the slot's stream)
 static int ensure_u32(uint32_t** p, size_t* cap, size_t need)
 {
     if (need <= *cap) return GSR_OK;
@@ -409,32 +473,30 @@ static int ensure_u32(uint32_t** p, size_t* cap, size_t need)
 }
 
 // out may equal in.  total (device pointer) may be NULL.
-static int exclusive_scan(gsr_context* c, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* d_total)
+static int exclusive_scan(FrameSlot& sl, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* d_total)
 {
     if (n == 0) {
-        if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, 4, c->stream));
+        if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, 4, sl.stream));
         return GSR_OK;
     }
     const uint32_t m = div_up(n, SC_TILE);
-    int rc = ensure_u32(&c->partial, &c->partial_cap, m);
+    int rc = ensure_u32(&sl.partial, &sl.partial_cap, m);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(m), dim3(SC_THREADS), 0, c->stream, in, n, c->partial);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SC_THREADS), 0, c->stream, c->partial, m, d_total);
-    hipLaunchKernelGGL(k_scan_down, dim3(m), dim3(SC_THREADS), 0, c->stream, in, n, c->partial, out);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(m), dim3(SC_THREADS), 0, sl.stream, in, n, sl.partial);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SC_THREADS), 0, sl.stream, sl.partial, m, d_total);
+    hipLaunchKernelGGL(k_scan_down, dim3(m), dim3(SC_THREADS), 0, sl.stream, in, n, sl.partial, out);
     HIP_TRY(hipGetLastError());
     return GSR_OK;
 }
 
-// stable LSD sort on key bits [0, bits); ping-pongs (kA,vA) <-> (kB,vB) and
-// leaves the result in (kA,vA) by swapping the pointers.
 template <typename V, int DBITS>
-static int radix_pass(gsr_context* c, uint32_t* kA, V* vA, uint32_t* kB, V* vB, uint32_t n, int shift, uint32_t nblk)
+static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, uint32_t n, int shift, uint32_t nblk)
 {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS>), dim3(nblk), dim3(RS_THREADS), 0, c->stream, kA, n, shift,
-                       c->hist, nblk);
-    hipLaunchKernelGGL(k_scan_rows, dim3(1u << DBITS), dim3(SC_THREADS), 0, c->stream, c->hist, nblk, c->totals);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS>), dim3(nblk), dim3(RS_THREADS), 0, c->stream, kA, vA,
-                       kB, vB, n, shift, c->hist, c->totals, nblk);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, n, shift,
+                       sl.hist, nblk);
+    hipLaunchKernelGGL(k_scan_rows, dim3(1u << DBITS), dim3(SC_THREADS), 0, sl.stream, sl.hist, nblk, sl.totals);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, vA,
+                       kB, vB, n, shift, sl.hist, sl.totals, nblk);
     HIP_TRY(hipGetLastError());
     return GSR_OK;
 }
@@ -442,19 +504,19 @@ static int radix_pass(gsr_context* c, uint32_t* kA, V* vA, uint32_t* kB, V* vB, 
 // stable LSD sort on key bits [0, bits); ping-pongs (kA,vA) <-> (kB,vB) and leaves the result
 // in (kA,vA) by swapping the pointers.  9-bit digits are used when they save a pass.
 template <typename V>
-static int radix_sort(gsr_context* c, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& vB, uint32_t n, int bits,
+static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& vB, uint32_t n, int bits,
                       bool allow9 = true)
 {
     if (n == 0 || bits <= 0) return GSR_OK;
     const uint32_t nblk = div_up(n, RS_TILE);
-    int rc = ensure_u32(&c->hist, &c->hist_cap, (size_t)512 * nblk + 8);
+    int rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)512 * nblk + 8);
     if (rc) return rc;
     const int p8 = (bits + 7) / 8, p9 = (bits + 8) / 9;
     const bool use9 = allow9 && p9 < p8;
     const int passes = use9 ? p9 : p8, width = use9 ? 9 : 8;
     for (int p = 0; p < passes; ++p) {
-        rc = use9 ? radix_pass<V, 9>(c, kA, vA, kB, vB, n, p * width, nblk)
-                  : radix_pass<V, 8>(c, kA, vA, kB, vB, n, p * width, nblk);
+        rc = use9 ? radix_pass<V, 9>(sl, kA, vA, kB, vB, n, p * width, nblk)
+                  : radix_pass<V, 8>(sl, kA, vA, kB, vB, n, p * width, nblk);
         if (rc) return rc;
         uint32_t* t = kA; kA = kB; kB = t;
         V* tv = vA; vA = vB; vB = tv;
@@ -523,7 +585,7 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
             dmin2 += near_ * near_;
             dmax2 += far_ * far_;
         }
-        const float lo = (float)(dmin2 * (1.0 - 1e-5)), hi = (float)(dmax2 * (1.0 + 1e-5)) ;
+        const float lo = (float)(dmin2 * (1.0 - 1e-5)), hi = (float)(dmax2 * (1.0 + 1e-5));
         if (std::isfinite(lo) && std::isfinite(hi) && lo >= 0.0f && hi >= lo) {
             uint32_t blo, bhi;
             std::memcpy(&blo, &lo, 4);
@@ -545,6 +607,8 @@ static int build_tile_map(gsr_context* c, const GsrFrame& f)
     if (c->map_w == f.width && c->map_h == f.height && c->map_si == c->shard_index && c->map_sc == c->shard_count &&
         c->map_shift == f.super_shift && c->tile_map)
         return GSR_OK;
+    int rc = sync_all(c);   // a frame in flight may still be reading the old table
+    if (rc) return rc;
     const int n_super = f.stiles_x * f.stiles_y;
     std::vector<std::vector<int32_t>> per_xcd(8);
     for (int st = 0; st < n_super; ++st) {
@@ -565,23 +629,22 @@ static int build_tile_map(gsr_context* c, const GsrFrame& f)
     if (map.size() > c->map_cap) {
         dev_free(c->tile_map);
         c->map_cap = 0;
-        int rc = dev_alloc(&c->tile_map, map.size());
+        rc = dev_alloc(&c->tile_map, map.size());
         if (rc) return rc;
         c->map_cap = map.size();
     }
-    HIP_TRY(hipMemcpyAsync(c->tile_map, map.data(), map.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // `map` is a stack-owned buffer
+    HIP_TRY(hipMemcpy(c->tile_map, map.data(), map.size() * 4, hipMemcpyHostToDevice));
     c->map_grid = (int)(chunk * 8);
     c->map_w = f.width; c->map_h = f.height; c->map_si = c->shard_index; c->map_sc = c->shard_count;
     c->map_shift = f.super_shift;
     return GSR_OK;
 }
 
-static void harvest_slot(gsr_context* c, int slot)
+static void harvest_slot(gsr_context* c, FrameSlot& sl)
 {
-    if (!c->ev_pending[slot]) return;
-    c->ev_pending[slot] = false;
-    hipEvent_t* e = c->ev[slot];
+    if (!sl.ev_pending) return;
+    sl.ev_pending = false;
+    hipEvent_t* e = sl.ev;
     if (hipEventSynchronize(e[6]) != hipSuccess) return;
     float ms[6] = {0, 0, 0, 0, 0, 0};
     for (int k = 0; k < 6; ++k)
@@ -607,7 +670,12 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
         return set_err(GSR_E_INVALID, "gsr_render: bad framebuffer size %dx%d (max %d)", cam->width, cam->height, GSR_MAX_DIM);
     if (c->geo_gen == 0) return set_err(GSR_E_NO_GEOMETRY, "gsr_render: nothing uploaded");
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
+
+    // Frames alternate between the slots.  Everything up to the blend kernel touches only the slot's
+    // private arrays (plus the read-only geometry), so it may run while the previous frame -- and
+    // whatever the caller queued on the public stream -- is still executing.
+    FrameSlot& sl = c->slot[c->frame_no % (uint64_t)c->nslots];
+    hipStream_t s = sl.stream;
 
     GsrFrame f;
     build_frame(c, cam, &f);
@@ -615,22 +683,26 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
     const int local_tiles = f.tiles_x * f.local_tiles_y;
     const int band_rows = (c->shard_count > 1) ? gsr_band_rows(cam->height, c->shard_index, c->shard_count) : cam->height;
     const size_t out_px = (size_t)band_rows * cam->width;
+    const int n_super = f.stiles_x * f.stiles_y;
 
-    const int slot = (int)(c->frame_no % GSR_EVENT_SLOTS);
     const bool timing = c->opt_timing != 0;
-    if (timing) harvest_slot(c, slot);
-    hipEvent_t* ev = c->ev[slot];
+    if (timing) harvest_slot(c, sl);
+    hipEvent_t* ev = sl.ev;
 #define MARK(k) do { if (timing) HIP_TRY(hipEventRecord(ev[k], s)); } while (0)
 
+    // the caller's stream position now: the blend kernel (the only writer of caller-visible memory)
+    // waits for it, so an output buffer that earlier work on the public stream still reads is safe
+    HIP_TRY(hipEventRecord(sl.ev_user, c->stream));
+
     // per-tile bookkeeping + super-tile ranges
-    const int n_super = f.stiles_x * f.stiles_y;
-    if ((size_t)local_tiles + 1 > c->tile_cap || !c->sstart) {
-        dev_free(c->tile_work); dev_free(c->sstart); dev_free(c->send);
-        c->tile_cap = 0;
+    if ((size_t)local_tiles + 1 > sl.tile_cap || !sl.sstart) {
+        HIP_TRY(hipStreamSynchronize(s));
+        dev_free(sl.tile_work); dev_free(sl.sstart); dev_free(sl.send);
+        sl.tile_cap = 0;
         int rc;
-        if ((rc = dev_alloc(&c->tile_work, (size_t)local_tiles + 1)) || (rc = dev_alloc(&c->sstart, (size_t)65536 + 1)) ||
-            (rc = dev_alloc(&c->send, (size_t)65536 + 1))) return rc;
-        c->tile_cap = (size_t)local_tiles + 1;
+        if ((rc = dev_alloc(&sl.tile_work, (size_t)local_tiles + 1)) || (rc = dev_alloc(&sl.sstart, (size_t)65536 + 1)) ||
+            (rc = dev_alloc(&sl.send, (size_t)65536 + 1))) return rc;
+        sl.tile_cap = (size_t)local_tiles + 1;
     }
     if (c->opt_swizzle) {
         int rc = build_tile_map(c, f);
@@ -638,62 +710,63 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
     }
     float* target = rgba_out;
     if (!out_is_device) {
-        if (out_px * 4 > c->fb_cap) {
-            dev_free(c->fb);
-            c->fb_cap = 0;
-            int rc = dev_alloc(&c->fb, out_px * 4);
+        if (out_px * 4 > sl.fb_cap) {
+            HIP_TRY(hipStreamSynchronize(s));
+            dev_free(sl.fb);
+            sl.fb_cap = 0;
+            int rc = dev_alloc(&sl.fb, out_px * 4);
             if (rc) return rc;
-            c->fb_cap = out_px * 4;
+            sl.fb_cap = out_px * 4;
         }
-        target = c->fb;
+        target = sl.fb;
     }
 
     MARK(0);
-    const bool cache_hit = c->opt_sort_cache && c->sort_valid && c->sort_gen == c->geo_gen &&
-                           c->sort_cam[0] == cam->cam_pos[0] && c->sort_cam[1] == cam->cam_pos[1] &&
-                           c->sort_cam[2] == cam->cam_pos[2];
+    const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_gen == c->geo_gen &&
+                           sl.sort_cam[0] == cam->cam_pos[0] && sl.sort_cam[1] == cam->cam_pos[1] &&
+                           sl.sort_cam[2] == cam->cam_pos[2];
     uint32_t D = 0;
     if (n > 0) {
         // on a cache hit K1 must not touch the sorted (keyA, valA); the rects inside valA are refreshed instead
         hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, 256)), dim3(256), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
-                           c->rec, cache_hit ? (uint32_t*)nullptr : c->keyA, cache_hit ? (uint2*)nullptr : c->valA, c->rect);
+                           sl.rec, cache_hit ? (uint32_t*)nullptr : sl.keyA, cache_hit ? (uint2*)nullptr : sl.valA, sl.rect);
         if (cache_hit)
-            hipLaunchKernelGGL(k_refresh_rects, dim3(div_up(n, 256)), dim3(256), 0, s, c->valA, n, c->rect);
+            hipLaunchKernelGGL(k_refresh_rects, dim3(div_up(n, 256)), dim3(256), 0, s, sl.valA, n, sl.rect);
         HIP_TRY(hipGetLastError());
     }
     MARK(1);
     if (n > 0 && !cache_hit) {
         int key_bits = 1;
         while (key_bits < 32 && ((f.key_max - f.key_min) >> key_bits) != 0u) ++key_bits;
-        int rc = radix_sort(c, c->keyA, c->valA, c->keyB, c->valB, n, key_bits, !(c->opt_flags & GSR_FLAG_FULL_KEYS));
-        c->key_min = f.key_min;
+        int rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n, key_bits, !(c->opt_flags & GSR_FLAG_FULL_KEYS));
         if (rc) return rc;
-        c->sort_valid = true;
-        c->sort_gen = c->geo_gen;
-        for (int k = 0; k < 3; ++k) c->sort_cam[k] = cam->cam_pos[k];
+        sl.key_min = f.key_min;
+        sl.sort_valid = true;
+        sl.sort_gen = c->geo_gen;
+        for (int k = 0; k < 3; ++k) sl.sort_cam[k] = cam->cam_pos[k];
     }
     MARK(2);
     if (n > 0) {
-        hipLaunchKernelGGL(k_super_counts, dim3(div_up(n, 256)), dim3(256), 0, s, c->valA, n, f.super_shift,
-                           c->shard_index, c->shard_count, c->cnt);
-        int rc = exclusive_scan(c, c->cnt, c->poff, n, c->d_total);
+        hipLaunchKernelGGL(k_super_counts, dim3(div_up(n, 256)), dim3(256), 0, s, sl.valA, n, f.super_shift,
+                           c->shard_index, c->shard_count, sl.cnt);
+        int rc = exclusive_scan(sl, sl.cnt, sl.poff, n, sl.d_total);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(c->h_total, c->d_total, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        D = *c->h_total;
+        HIP_TRY(hipMemcpyAsync(sl.h_total, sl.d_total, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));   // waits for THIS frame's front end only; the other slot keeps running
+        D = *sl.h_total;
         if ((unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
             return set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: %u super-tile pairs exceed the limit", D);
-        if (D > c->pair_cap) {
-            dev_free(c->pkA); dev_free(c->pkB); dev_free(c->pvA); dev_free(c->pvB);
-            c->pair_cap = 0;
+        if (D > sl.pair_cap) {
+            dev_free(sl.pkA); dev_free(sl.pkB); dev_free(sl.pvA); dev_free(sl.pvB);
+            sl.pair_cap = 0;
             const size_t want = (size_t)D + D / 4 + 4096;
-            if ((rc = dev_alloc(&c->pkA, want)) || (rc = dev_alloc(&c->pkB, want)) || (rc = dev_alloc(&c->pvA, want)) ||
-                (rc = dev_alloc(&c->pvB, want))) return rc;
-            c->pair_cap = want;
+            if ((rc = dev_alloc(&sl.pkA, want)) || (rc = dev_alloc(&sl.pkB, want)) || (rc = dev_alloc(&sl.pvA, want)) ||
+                (rc = dev_alloc(&sl.pvB, want))) return rc;
+            sl.pair_cap = want;
         }
         if (D > 0) {
-            hipLaunchKernelGGL(k_emit_pairs, dim3(div_up(n, 256)), dim3(256), 0, s, c->valA, c->poff, n, f.super_shift,
-                               c->shard_index, c->shard_count, f.stiles_x, c->pkA, c->pvA);
+            hipLaunchKernelGGL(k_emit_pairs, dim3(div_up(n, 256)), dim3(256), 0, s, sl.valA, sl.poff, n, f.super_shift,
+                               c->shard_index, c->shard_count, f.stiles_x, sl.pkA, sl.pvA);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -701,52 +774,52 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
     if (D > 0) {
         int bits = 1;
         while ((1 << bits) < n_super) ++bits;
-        int rc = radix_sort(c, c->pkA, c->pvA, c->pkB, c->pvB, D, bits);
+        int rc = radix_sort(sl, sl.pkA, sl.pvA, sl.pkB, sl.pvB, D, bits);
         if (rc) return rc;
     }
     MARK(4);
-    HIP_TRY(hipMemsetAsync(c->sstart, 0, ((size_t)n_super + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(c->send, 0, ((size_t)n_super + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(sl.sstart, 0, ((size_t)n_super + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(sl.send, 0, ((size_t)n_super + 1) * 4, s));
     if (D > 0) {
-        hipLaunchKernelGGL(k_super_ranges, dim3(div_up(D, 256)), dim3(256), 0, s, c->pkA, D, c->sstart, c->send);
+        hipLaunchKernelGGL(k_super_ranges, dim3(div_up(D, 256)), dim3(256), 0, s, sl.pkA, D, sl.sstart, sl.send);
         HIP_TRY(hipGetLastError());
     }
     MARK(5);
     if (local_tiles > 0) {
+        HIP_TRY(hipStreamWaitEvent(s, sl.ev_user, 0));
         GsrBlendArgs a;
         a.width = cam->width; a.height = cam->height; a.tiles_x = f.tiles_x; a.local_tiles = local_tiles;
         a.shard_index = c->shard_index; a.shard_count = c->shard_count; a.band_rows = band_rows;
         a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = c->opt_swizzle ? 1 : 0; a.flags = c->opt_flags;
         const unsigned grid = a.use_map ? (unsigned)c->map_grid : (unsigned)local_tiles;
-        hipLaunchKernelGGL(k_blend, dim3(grid), dim3(256), 0, s, a, c->tile_map, c->pvA, c->sstart, c->send,
-                           c->rec, reinterpret_cast<float4*>(target), c->tile_work);
+        hipLaunchKernelGGL(k_blend, dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart, sl.send,
+                           sl.rec, reinterpret_cast<float4*>(target), sl.tile_work);
         HIP_TRY(hipGetLastError());
     }
     MARK(6);
     if (local_tiles > 0) {
-        hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(256), 0, s, c->tile_work, local_tiles, c->counters);
+        hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(256), 0, s, sl.tile_work, local_tiles, sl.counters);
         HIP_TRY(hipGetLastError());
     }
 #undef MARK
-    if (timing) c->ev_pending[slot] = true;
-    c->last_supers = n_super;
-    c->last_tiles_x = f.tiles_x;
-    c->last_local_ty = f.local_tiles_y;
-    c->last_pairs = D;
-    c->st.pairs_total = D;
-    c->st.tiles_x = f.tiles_x;
-    c->st.tiles_y = f.local_tiles_y;
-    c->st.super_tile = f.super;
-    c->st.stiles_x = f.stiles_x;
-    c->st.stiles_y = f.stiles_y;
+    if (timing) sl.ev_pending = true;
+    sl.last_supers = n_super;
+    sl.last_tiles_x = f.tiles_x;
+    sl.last_local_ty = f.local_tiles_y;
+    sl.last_pairs = D;
+    sl.super_tile = f.super; sl.stiles_x = f.stiles_x; sl.stiles_y = f.stiles_y;
     c->st.frames += 1;
     c->frame_no += 1;
+    sl.frame_id = c->frame_no;
     // counters of this frame travel with the stream; they are read in gsr_get_stats
-    HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(sl.h_counters, sl.counters, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     if (!out_is_device) {
-        HIP_TRY(hipMemcpyAsync(rgba_out, c->fb, out_px * 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(rgba_out, sl.fb, out_px * 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
+    // results are ordered on the public stream: anything the caller queues there next sees this frame
+    HIP_TRY(hipEventRecord(sl.ev_done, s));
+    HIP_TRY(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
     return GSR_OK;
 }
 
@@ -754,30 +827,56 @@ extern "C" int gsr_synchronize(gsr_context* c)
 {
     if (!c) return set_err(GSR_E_INVALID, "gsr_synchronize: ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return GSR_OK;
+    return sync_all(c);
+}
+
+// the slot that rendered the most recent frame (NULL before the first frame)
+static FrameSlot* latest_slot(gsr_context* c)
+{
+    FrameSlot* best = nullptr;
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k)
+        if (c->slot[k].frame_id && (!best || c->slot[k].frame_id > best->frame_id)) best = &c->slot[k];
+    return best;
 }
 
 extern "C" int gsr_get_stats(gsr_context* c, gsr_stats* out)
 {
     if (!c || !out) return set_err(GSR_E_INVALID, "gsr_get_stats: NULL argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = sync_all(c);
+    if (rc) return rc;
     // harvest in submission order so that "last frame" fields end up describing the newest frame
-    for (int k = 0; k < GSR_EVENT_SLOTS; ++k) harvest_slot(c, (int)((c->frame_no + k) % GSR_EVENT_SLOTS));
-    if (c->frame_no > 0) {
+    FrameSlot* last = latest_slot(c);
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k)
+        if (&c->slot[k] != last) harvest_slot(c, c->slot[k]);
+    if (last) {
+        harvest_slot(c, *last);
+        FrameSlot& sl = *last;
         // statistics-only pass over the rects of the last frame
-        HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemsetAsync(sl.counters, 0, sizeof(unsigned long long), sl.stream));
         if (c->n > 0)
-            hipLaunchKernelGGL(k_count_visible, dim3(256), dim3(256), 0, c->stream, c->rect, c->n, c->shard_index,
-                               c->shard_count, c->counters);
-        HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->st.n_visible = (int64_t)c->h_counters[0];
-        c->st.pairs_consumed = (int64_t)c->h_counters[1];
-        c->st.blend_pairs_consumed_total = (int64_t)c->h_counters[2];
-        c->st.entries_scanned = (int64_t)c->h_counters[3];
-        c->st.blend_entries_scanned_total = (int64_t)c->h_counters[4];
+            hipLaunchKernelGGL(k_count_visible, dim3(256), dim3(256), 0, sl.stream, sl.rect, c->n, c->shard_index,
+                               c->shard_count, sl.counters);
+        HIP_TRY(hipMemcpyAsync(sl.h_counters, sl.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, sl.stream));
+        HIP_TRY(hipStreamSynchronize(sl.stream));
+        c->st.n_visible = (int64_t)sl.h_counters[0];
+        c->st.pairs_consumed = (int64_t)sl.h_counters[1];
+        c->st.entries_scanned = (int64_t)sl.h_counters[3];
+        c->st.pairs_total = sl.last_pairs;
+        c->st.tiles_x = sl.last_tiles_x;
+        c->st.tiles_y = sl.last_local_ty;
+        c->st.super_tile = sl.super_tile;
+        c->st.stiles_x = sl.stiles_x;
+        c->st.stiles_y = sl.stiles_y;
+        // running totals live per slot
+        int64_t rec_tot = 0, ent_tot = 0;
+        for (int k = 0; k < GSR_MAX_SLOTS; ++k) {
+            if (!c->slot[k].frame_id) continue;
+            rec_tot += (int64_t)c->slot[k].h_counters[2];
+            ent_tot += (int64_t)c->slot[k].h_counters[4];
+        }
+        c->st.blend_pairs_consumed_total = rec_tot;
+        c->st.blend_entries_scanned_total = ent_tot;
     }
     *out = c->st;
     return GSR_OK;
@@ -787,9 +886,13 @@ extern "C" int gsr_stats_reset(gsr_context* c)
 {
     if (!c) return set_err(GSR_E_INVALID, "gsr_stats_reset: ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < GSR_EVENT_SLOTS; ++k) harvest_slot(c, k);
-    HIP_TRY(hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k) {
+        harvest_slot(c, c->slot[k]);
+        HIP_TRY(hipMemset(c->slot[k].counters, 0, 8 * sizeof(unsigned long long)));
+        for (int j = 0; j < 8; ++j) c->slot[k].h_counters[j] = 0;
+    }
     const int64_t ns = c->st.n_splats;
     c->st = gsr_stats{};
     c->st.n_splats = ns;
@@ -799,12 +902,15 @@ extern "C" int gsr_stats_reset(gsr_context* c)
 }
 
 // ---------------------------------------------------------------------------
-// debug / test access
+// debug / test access: intermediates of the most recent frame
 extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int64_t n)
 {
     if (!c || !out || n < 0 || (uint64_t)n > c->n) return set_err(GSR_E_INVALID, "gsr_debug_read_records: bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    int src = sync_all(c);
+    if (src) return src;
+    FrameSlot* sl = latest_slot(c);
+    if (!sl) return set_err(GSR_E_INVALID, "gsr_debug_read_records: no frame rendered yet");
     GsrRecord* hr = new (std::nothrow) GsrRecord[n ? n : 1];
     uint32_t* hk = new (std::nothrow) uint32_t[n ? n : 1];
     uint32_t* hrect = new (std::nothrow) uint32_t[n ? n : 1];
@@ -813,11 +919,11 @@ extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int
     if (!hr || !hk || !hrect || !hidx) rc = set_err(GSR_E_OOM, "gsr_debug_read_records: host allocation failed");
     hipError_t e = hipSuccess;
     if (!rc && n) {
-        e = hipMemcpy(hr, c->rec, (size_t)n * sizeof(GsrRecord), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(hrect, c->rect, (size_t)n * 4, hipMemcpyDeviceToHost);
+        e = hipMemcpy(hr, sl->rec, (size_t)n * sizeof(GsrRecord), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(hrect, sl->rect, (size_t)n * 4, hipMemcpyDeviceToHost);
         // keys live in sorted order after the depth sort: un-permute through the payload's index
-        if (e == hipSuccess) e = hipMemcpy(hk, c->keyA, (size_t)n * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy2D(hidx, 4, c->valA, 8, 4, (size_t)n, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(hk, sl->keyA, (size_t)n * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy2D(hidx, 4, sl->valA, 8, 4, (size_t)n, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = set_err(GSR_E_HIP, "gsr_debug_read_records: %s", hipGetErrorString(e));
     }
     if (!rc) {
@@ -835,7 +941,7 @@ extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int
         }
         for (int64_t r = 0; r < n; ++r)
             if (hidx[r] < (uint64_t)n) {
-                const uint32_t kb = hk[r] + c->key_min;   // keys are stored relative to the frame's key_min
+                const uint32_t kb = hk[r] + sl->key_min;   // keys are stored relative to the frame's key_min
                 std::memcpy(&out[hidx[r]].key, &kb, 4);
             }
     }
@@ -847,8 +953,11 @@ extern "C" int gsr_debug_read_depth_order(gsr_context* c, int32_t* perm, int64_t
 {
     if (!c || !perm || n < 0 || (uint64_t)n > c->n) return set_err(GSR_E_INVALID, "gsr_debug_read_depth_order: bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (n) HIP_TRY(hipMemcpy2D(perm, 4, c->valA, 8, 4, (size_t)n, hipMemcpyDeviceToHost));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    FrameSlot* sl = latest_slot(c);
+    if (!sl) return set_err(GSR_E_INVALID, "gsr_debug_read_depth_order: no frame rendered yet");
+    if (n) HIP_TRY(hipMemcpy2D(perm, 4, sl->valA, 8, 4, (size_t)n, hipMemcpyDeviceToHost));
     return GSR_OK;
 }
 
@@ -856,25 +965,31 @@ extern "C" int gsr_debug_read_tile_lists(gsr_context* c, int32_t* list_start, in
                                          int32_t* pair_splat, int64_t n_pairs)
 {
     if (!c || !list_start || !list_end) return set_err(GSR_E_INVALID, "gsr_debug_read_tile_lists: bad argument");
-    if (n_lists != (int64_t)c->last_supers || n_pairs != (int64_t)c->last_pairs || (n_pairs > 0 && !pair_splat))
-        return set_err(GSR_E_INVALID, "gsr_debug_read_tile_lists: expected %d lists / %u pairs", c->last_supers, c->last_pairs);
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    FrameSlot* sl = latest_slot(c);
+    if (!sl) return set_err(GSR_E_INVALID, "gsr_debug_read_tile_lists: no frame rendered yet");
+    if (n_lists != (int64_t)sl->last_supers || n_pairs != (int64_t)sl->last_pairs || (n_pairs > 0 && !pair_splat))
+        return set_err(GSR_E_INVALID, "gsr_debug_read_tile_lists: expected %d lists / %u pairs", sl->last_supers, sl->last_pairs);
     if (n_lists) {
-        HIP_TRY(hipMemcpy(list_start, c->sstart, (size_t)n_lists * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(list_end, c->send, (size_t)n_lists * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(list_start, sl->sstart, (size_t)n_lists * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(list_end, sl->send, (size_t)n_lists * 4, hipMemcpyDeviceToHost));
     }
-    if (n_pairs) HIP_TRY(hipMemcpy2D(pair_splat, 4, c->pvA, 8, 4, (size_t)n_pairs, hipMemcpyDeviceToHost));
+    if (n_pairs) HIP_TRY(hipMemcpy2D(pair_splat, 4, sl->pvA, 8, 4, (size_t)n_pairs, hipMemcpyDeviceToHost));
     return GSR_OK;
 }
 
 extern "C" int gsr_debug_read_tile_work(gsr_context* c, uint32_t* scanned_fetched, int64_t n_tiles)
 {
-    if (!c || !scanned_fetched || n_tiles != (int64_t)c->last_tiles_x * c->last_local_ty)
-        return set_err(GSR_E_INVALID, "gsr_debug_read_tile_work: expected %d tiles", c ? c->last_tiles_x * c->last_local_ty : 0);
+    if (!c || !scanned_fetched) return set_err(GSR_E_INVALID, "gsr_debug_read_tile_work: bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (n_tiles) HIP_TRY(hipMemcpy(scanned_fetched, c->tile_work, (size_t)n_tiles * 8, hipMemcpyDeviceToHost));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    FrameSlot* sl = latest_slot(c);
+    if (!sl || n_tiles != (int64_t)sl->last_tiles_x * sl->last_local_ty)
+        return set_err(GSR_E_INVALID, "gsr_debug_read_tile_work: expected %d tiles", sl ? sl->last_tiles_x * sl->last_local_ty : 0);
+    if (n_tiles) HIP_TRY(hipMemcpy(scanned_fetched, sl->tile_work, (size_t)n_tiles * 8, hipMemcpyDeviceToHost));
     return GSR_OK;
 }
 
@@ -884,21 +999,23 @@ extern "C" int gsr_debug_sort_pairs(gsr_context* c, uint32_t* keys, uint32_t* va
         return set_err(GSR_E_INVALID, "gsr_debug_sort_pairs: bad argument");
     if (n64 == 0) return GSR_OK;
     HIP_TRY(hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    FrameSlot& sl = c->slot[0];
     const uint32_t n = (uint32_t)n64;
     uint32_t *kA = nullptr, *kB = nullptr, *vA = nullptr, *vB = nullptr;
-    int rc;
     if ((rc = dev_alloc(&kA, n)) || (rc = dev_alloc(&kB, n)) || (rc = dev_alloc(&vA, n)) || (rc = dev_alloc(&vB, n))) {
         dev_free(kA); dev_free(kB); dev_free(vA); dev_free(vB);
         return rc;
     }
-    hipError_t e = hipMemcpyAsync(kA, keys, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(vA, vals, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    hipError_t e = hipMemcpyAsync(kA, keys, (size_t)n * 4, hipMemcpyHostToDevice, sl.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(vA, vals, (size_t)n * 4, hipMemcpyHostToDevice, sl.stream);
     if (e == hipSuccess) {
-        rc = radix_sort(c, kA, vA, kB, vB, n, key_bits, true);
+        rc = radix_sort(sl, kA, vA, kB, vB, n, key_bits, true);
         if (!rc) {
-            e = hipMemcpyAsync(keys, kA, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(vals, vA, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            e = hipMemcpyAsync(keys, kA, (size_t)n * 4, hipMemcpyDeviceToHost, sl.stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(vals, vA, (size_t)n * 4, hipMemcpyDeviceToHost, sl.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(sl.stream);
         }
     }
     dev_free(kA); dev_free(kB); dev_free(vA); dev_free(vB);

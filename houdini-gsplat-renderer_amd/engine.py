@@ -60,7 +60,7 @@ class GSplatRenderContext(C.Structure):
                 ("target", C.c_void_p), ("target_is_device", C.c_int32)]
 
 
-OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE, OPT_SUPER_TILE, OPT_DEBUG_FLAGS = 1, 2, 3, 4, 5
+OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE, OPT_SUPER_TILE, OPT_DEBUG_FLAGS, OPT_FRAMES_IN_FLIGHT = 1, 2, 3, 4, 5, 6
 
 # every symbol include/gsplat_hip.h and include/GSplatRenderer.h declare
 C_ABI_SYMBOLS = [

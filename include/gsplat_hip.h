@@ -87,8 +87,10 @@ void gsr_destroy(gsr_context* ctx);
 const char* gsr_last_error(void);                         /* thread-local, never NULL */
 const char* gsr_version(void);
 
-/* Launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of
- * the context's own; NULL restores the context stream. */
+/* The context's PUBLIC stream: gsr_render orders its result on it (work queued there afterwards sees
+ * the finished frame; the frame's output write waits for work queued there before).  Internally the
+ * kernels run on per-frame-slot streams.  Pass a caller-owned hipStream_t (e.g. torch's current
+ * stream); NULL restores the context's own stream. */
 int  gsr_set_stream(gsr_context* ctx, void* hip_stream);
 
 /* ---- geometry staging (active set changed) ------------------------------ */
@@ -143,6 +145,9 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        (argsortByDistance's caching, src/GSplatRenderer.C:179-186) */
 #define GSR_OPT_SUPER_TILE      4   /* super-tile edge in tiles: 0 = auto (smallest power of two giving
                                        <= 256 super-tiles), or 1,2,4,8,16 */
+#define GSR_OPT_FRAMES_IN_FLIGHT 6  /* 1 or 2 (default 2): with 2, frame f+1's memory-bound front end
+                                       (preprocess, sorts, binning) overlaps frame f's blend kernel on the GPU.
+                                       Per-frame results and their order on the context stream are unchanged. */
 #define GSR_OPT_DEBUG_FLAGS     5   /* A/B switches for profiling: 1 = no alpha-support shrink of the bboxes,
                                        2 = bbox-only quadrant masks (no separating-axis test) */
 int  gsr_set_option(gsr_context* ctx, int option, int value);

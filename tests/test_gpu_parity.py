@@ -244,10 +244,37 @@ def test_options_do_not_change_pixels(pkg, engine):
     cam = pkg.camera.make_camera(640, 400, sh_order=3, frame=3)
     engine.upload(splats)
     base = engine.render(cam)
-    for opt, vals in ((pkg.engine.OPT_XCD_SWIZZLE, (0, 1)), (pkg.engine.OPT_SUPER_TILE, (1, 2, 4, 8, 16, 0))):
+    for opt, vals in ((pkg.engine.OPT_XCD_SWIZZLE, (0, 1)), (pkg.engine.OPT_SUPER_TILE, (1, 2, 4, 8, 16, 0)),
+                      (pkg.engine.OPT_DEBUG_FLAGS, (1, 2, 4, 7, 0)), (pkg.engine.OPT_FRAMES_IN_FLIGHT, (1, 2))):
         for v in vals:
             engine.set_option(opt, v)
             assert np.array_equal(engine.render(cam), base), f"option {opt}={v} changed the image"
+
+
+def test_frames_in_flight_keep_every_frame_intact(pkg, oracle, engine):
+    """two frames in flight: back-to-back asynchronous frames with different cameras into different
+    device buffers must each equal the synchronous render of the same camera"""
+    import ctypes as C
+    L = pkg.load_library()
+    splats = pkg.scenes.make_scene(200000, seed=71, sh=True)
+    engine.upload(splats)
+    w, h = 640, 360
+    cams = [pkg.camera.make_camera(w, h, sh_order=3, frame=i) for i in range(6)]
+    want = [engine.render(c) for c in cams]
+    hip = C.CDLL("libamdhip64.so")
+    bufs = []
+    for _ in cams:
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(w * h * 16)) == 0
+        bufs.append(p)
+    for c, p in zip(cams, bufs):
+        engine.render_to_device(c, p.value)            # no synchronisation between frames
+    engine.synchronize()
+    for k, p in enumerate(bufs):
+        got = np.empty((h, w, 4), np.float32)
+        assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), p, C.c_size_t(w * h * 16), 2) == 0
+        assert np.array_equal(got, want[k]), f"frame {k} differs"
+        hip.hipFree(p)
 
 
 def test_baseline_config_c4_full_size_properties(pkg, oracle, engine):

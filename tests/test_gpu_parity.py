@@ -299,3 +299,57 @@ def test_baseline_config_c4_full_size_properties(pkg, oracle, engine):
     assert np.array_equal(out, full)
     ref = oracle.render(splats, cam, threads=oracle.max_threads())
     _check_image(full, ref)
+
+
+def test_adversarial_inputs(pkg, oracle, engine):
+    """NaN/inf positions, zero / huge scales, negative and >1 opacities, degenerate quaternions"""
+    rng = np.random.default_rng(5)
+    s = pkg.scenes.make_scene(4000, seed=81, sh=True)
+    s.P[10] = np.nan
+    s.P[11, 0] = np.inf
+    s.P[12] = -np.inf
+    s.scale[20:40] = 0                                            # zero scale: only the 0.3 low-pass is left
+    s.scale[40:46] = pkg.scenes.f16bits(np.full((6, 3), 3.0e4))   # far beyond the 4096-px axis cap
+    s.scale[46:50] = pkg.scenes.f16bits(np.full((4, 3), np.inf))
+    s.alpha[60:70] = -0.5
+    s.alpha[70:80] = 37.0                                         # clamp(alpha, 0, 1)
+    s.alpha[80:85] = np.nan
+    s.alpha[85:90] = 1.0 / 255.0                                  # exactly at the discard threshold
+    s.orient[90:100] = 0                                          # q = 0: R = I (no normalisation in the reference)
+    s.orient[100:110] = pkg.scenes.f16bits(rng.normal(0, 30, (10, 4)))   # far from unit length
+    s.shx[110:120] = 0x7C00                                       # +inf SH coefficients
+    for frame, size in ((0, (320, 200)), (3, (257, 129))):
+        cam = pkg.camera.make_camera(size[0], size[1], sh_order=3, frame=frame)
+        engine.upload(s)
+        img = engine.render(cam)
+        ref = oracle.render(s, cam)
+        ok = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(img), ok)              # non-finite colours propagate identically
+        err = np.abs(img[ok] - ref[ok])
+        assert err.max() <= TOL, err.max()
+
+
+def test_maximum_size_through_the_shim(pkg, oracle):
+    """2^23-1 splats is the reference's per-frame budget (include/GSplatRenderer.h:26): two entries that
+    together exceed it are truncated while packing (src/GSplatRenderer.C:336-376,436-446)"""
+    R = pkg.GSplatRenderer(0)
+    a = pkg.scenes.make_scene(5_000_000, seed=91, sh=False, radius=2.0)
+    b = pkg.scenes.make_scene(4_000_000, seed=92, sh=False, radius=2.0)
+    cam = pkg.camera.make_camera(480, 270, sh_order=0, frame=2)
+    ida = R.registerUpdate(0x10, (1, 0, 0, 0), 0, a)
+    idb = R.registerUpdate(0x20, (1, 0, 0, 0), 0, b)
+    img = R.frame(cam, [ida, idb])
+    cap = (1 << 23) - 1
+    assert R.query(R.Q_SPLAT_COUNT) == cap
+    first, second = (a, b) if ida < idb else (b, a)
+    keep = cap - first.n
+    cat = pkg.scenes.Splats(*[np.concatenate([getattr(first, f), getattr(second, f)[:keep]]) for f in
+                              ("P", "Cd", "alpha", "scale", "orient")])
+    origin = (a.barycenter() + b.barycenter()) / np.float32(2)
+    # the shim derives the camera position itself (inverse of the view matrix in double, as the reference
+    # does, src/GSplatRenderer.C:556-562); with 8.4 M splats the sort has many near-ties, so the oracle
+    # must be given exactly that position rather than numpy's last-ulp-different inverse
+    cam.cam_pos = R.lastCameraPos()
+    ref = oracle.render(cat, cam, origin=origin, threads=oracle.max_threads())
+    _check_image(img, ref)
+    R.close()

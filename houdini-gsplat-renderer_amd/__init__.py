@@ -11,8 +11,9 @@ Layout:
   camera.py   the reference scene's viewport camera as GL-layout matrices
   scenes.py   synthetic splat clouds of BASELINE.json's configs
   multigpu.py tile-row sharding across ranks + RCCL gather + stitch
+  ply.py      INRIA 3DGS .ply ingest with the example scene's activations
 """
-from . import build, camera, multigpu, scenes  # noqa: F401  (no GPU needed)
+from . import build, camera, multigpu, ply, scenes  # noqa: F401  (no GPU needed)
 from .engine import Engine, GSplatRenderer, GsrError, lib_path, load_library  # noqa: F401
 
-__all__ = ["build", "camera", "multigpu", "scenes", "Engine", "GSplatRenderer", "GsrError", "lib_path", "load_library"]
+__all__ = ["build", "camera", "multigpu", "ply", "scenes", "Engine", "GSplatRenderer", "GsrError", "lib_path", "load_library"]

@@ -64,6 +64,9 @@ struct FrameSlot {
     uint32_t *keyA = nullptr, *keyB = nullptr;
     uint2 *valA = nullptr, *valB = nullptr;      // depth-sort payload: (splat index, packed tile rect)
     uint32_t *rect = nullptr, *cnt = nullptr, *poff = nullptr;
+    float* zwin = nullptr;             // per-splat window depth (depth-tested frames)
+    float* depth_stage = nullptr;      // device copy of a host depth buffer
+    size_t depth_cap = 0;
     // scan / sort scratch
     uint32_t* hist = nullptr;
     size_t hist_cap = 0;
@@ -191,7 +194,7 @@ static bool slot_init(FrameSlot& sl)
 static void slot_free_splat_arrays(FrameSlot& sl)
 {
     dev_free(sl.rec); dev_free(sl.keyA); dev_free(sl.keyB); dev_free(sl.valA); dev_free(sl.valB);
-    dev_free(sl.rect); dev_free(sl.cnt); dev_free(sl.poff);
+    dev_free(sl.rect); dev_free(sl.cnt); dev_free(sl.poff); dev_free(sl.zwin);
     sl.sort_valid = false;
 }
 
@@ -200,7 +203,7 @@ static void slot_destroy(FrameSlot& sl)
     slot_free_splat_arrays(sl);
     dev_free(sl.hist); dev_free(sl.partial); dev_free(sl.totals);
     dev_free(sl.pkA); dev_free(sl.pkB); dev_free(sl.pvA); dev_free(sl.pvB);
-    dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.fb);
+    dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.fb); dev_free(sl.depth_stage);
     dev_free(sl.counters); dev_free(sl.d_total);
     if (sl.h_total) (void)hipHostFree(sl.h_total);
     if (sl.h_counters) (void)hipHostFree(sl.h_counters);
@@ -319,7 +322,7 @@ extern "C" int gsr_upload_begin(gsr_context* c, int64_t total, int has_sh, const
             FrameSlot& sl = c->slot[k];
             if ((rc = dev_alloc(&sl.rec, cap)) || (rc = dev_alloc(&sl.keyA, cap)) || (rc = dev_alloc(&sl.keyB, cap)) ||
                 (rc = dev_alloc(&sl.valA, cap)) || (rc = dev_alloc(&sl.valB, cap)) || (rc = dev_alloc(&sl.rect, cap)) ||
-                (rc = dev_alloc(&sl.cnt, cap + 8)) || (rc = dev_alloc(&sl.poff, cap + 8))) {
+                (rc = dev_alloc(&sl.cnt, cap + 8)) || (rc = dev_alloc(&sl.poff, cap + 8)) || (rc = dev_alloc(&sl.zwin, cap))) {
                 free_geometry(c);
                 return rc;
             }
@@ -664,6 +667,12 @@ static void harvest_slot(gsr_context* c, FrameSlot& sl)
 
 extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out, int out_is_device)
 {
+    return gsr_render_depth(c, cam, nullptr, 0, rgba_out, out_is_device);
+}
+
+extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const float* depth, int depth_is_device,
+                                float* rgba_out, int out_is_device)
+{
     if (!c || !cam || !rgba_out) return set_err(GSR_E_INVALID, "gsr_render: NULL argument");
     if (c->uploading) return set_err(GSR_E_INVALID, "gsr_render: upload in progress");
     if (cam->width <= 0 || cam->height <= 0 || cam->width > GSR_MAX_DIM || cam->height > GSR_MAX_DIM)
@@ -708,6 +717,20 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
         int rc = build_tile_map(c, f);
         if (rc) return rc;
     }
+    const float* d_depth = depth;
+    if (depth && !depth_is_device) {
+        const size_t npx = (size_t)cam->width * cam->height;
+        if (npx > sl.depth_cap) {
+            HIP_TRY(hipStreamSynchronize(s));
+            dev_free(sl.depth_stage);
+            sl.depth_cap = 0;
+            int rc = dev_alloc(&sl.depth_stage, npx);
+            if (rc) return rc;
+            sl.depth_cap = npx;
+        }
+        HIP_TRY(hipMemcpyAsync(sl.depth_stage, depth, npx * 4, hipMemcpyHostToDevice, s));
+        d_depth = sl.depth_stage;
+    }
     float* target = rgba_out;
     if (!out_is_device) {
         if (out_px * 4 > sl.fb_cap) {
@@ -729,7 +752,8 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
     if (n > 0) {
         // on a cache hit K1 must not touch the sorted (keyA, valA); the rects inside valA are refreshed instead
         hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, 256)), dim3(256), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
-                           sl.rec, cache_hit ? (uint32_t*)nullptr : sl.keyA, cache_hit ? (uint2*)nullptr : sl.valA, sl.rect);
+                           sl.rec, cache_hit ? (uint32_t*)nullptr : sl.keyA, cache_hit ? (uint2*)nullptr : sl.valA, sl.rect,
+                           d_depth ? sl.zwin : (float*)nullptr);
         if (cache_hit)
             hipLaunchKernelGGL(k_refresh_rects, dim3(div_up(n, 256)), dim3(256), 0, s, sl.valA, n, sl.rect);
         HIP_TRY(hipGetLastError());
@@ -793,7 +817,7 @@ extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out
         a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = c->opt_swizzle ? 1 : 0; a.flags = c->opt_flags;
         const unsigned grid = a.use_map ? (unsigned)c->map_grid : (unsigned)local_tiles;
         hipLaunchKernelGGL(k_blend, dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart, sl.send,
-                           sl.rec, reinterpret_cast<float4*>(target), sl.tile_work);
+                           sl.rec, reinterpret_cast<float4*>(target), sl.tile_work, sl.zwin, d_depth);
         HIP_TRY(hipGetLastError());
     }
     MARK(6);

@@ -52,7 +52,8 @@ struct GsrBlendArgs {
 __global__ void __launch_bounds__(256)
 k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __restrict__ svals,
         const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
-        const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint2* __restrict__ tile_work)
+        const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint2* __restrict__ tile_work,
+        const float* __restrict__ zwin, const float* __restrict__ depth)
 {
     __shared__ float4 s0[BL_ROUND];   // cx, cy, ex, ey
     __shared__ float4 s1[BL_ROUND];   // is1, is2, (hx, hy unused after the mask)
@@ -77,6 +78,9 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
     // tile bounds in pixel-centre coordinates, for the quadrant masks
     const float tcx0 = (float)(tx * GSR_TILE_PX) + 0.5f, tcy0 = (float)(gty * GSR_TILE_PX) + 0.5f;
     if (tid == 0) sfetched = 0;
+    // depth test against what the opaque pass left (depth writes stay off): a fragment survives iff its quad's
+    // window depth <= depth[pixel] (src/GSplatRenderer.C:595-610).  No depth buffer = +inf.
+    const float dpx = (depth && pix_ok) ? depth[(size_t)py * a.width + px] : __builtin_inff();
 
     const int st = (gty >> a.super_shift) * a.stiles_x + (tx >> a.super_shift);
     const int s = sstart[st];
@@ -104,6 +108,7 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
     }
     // ---- round state
     float4 r0, r1, r2;                // record of the upcoming round held by this thread
+    float rz = 0.0f;                  // ... and its window depth (depth-tested frames only)
     bool have = false;
     int pending = 0;                  // records of the upcoming round already gathered into registers
     int round = 0;
@@ -152,8 +157,10 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
             pending = avail < BL_ROUND ? avail : BL_ROUND;
             have = tid < pending;
             if (have) {
-                const float4* p = reinterpret_cast<const float4*>(recs + q[(q_head + tid) & (BL_QCAP - 1)]);
+                const uint32_t ridx = q[(q_head + tid) & (BL_QCAP - 1)];
+                const float4* p = reinterpret_cast<const float4*>(recs + ridx);
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
+                rz = depth ? zwin[ridx] : 0.0f;
                 ++my_fetched;
             }
         }
@@ -163,7 +170,7 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
         // (3) stage this round
         uint32_t m = 0;
         if (have) {
-            s0[tid] = r0; s1[tid] = r1; s2[tid] = r2;
+            s0[tid] = r0; s1[tid] = make_float4(r1.x, r1.y, rz, 0.0f); s2[tid] = r2;   // (hx, hy are only needed for the mask below)
             // Which 8x8 quadrants can the splat touch?  Separating-axis test of the oriented quad
             // (shrunk to the radius where alpha can still reach 1/255) against each quadrant's box of
             // pixel centres: the box axes (= bbox test) and the quad's own two axes.  Conservative.
@@ -196,8 +203,10 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
         if (pending > BL_ROUND) pending = BL_ROUND;
         have = tid < pending;
         if (have) {
-            const float4* p = reinterpret_cast<const float4*>(recs + q[(q_head + tid) & (BL_QCAP - 1)]);
+            const uint32_t ridx = q[(q_head + tid) & (BL_QCAP - 1)];
+            const float4* p = reinterpret_cast<const float4*>(recs + ridx);
             r0 = p[0]; r1 = p[1]; r2 = p[2];
+            rz = depth ? zwin[ridx] : 0.0f;
             ++my_fetched;
         }
 
@@ -230,9 +239,9 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
                     gsr_v2f alpha = gsr_expf2(power) * (gsr_v2f){a2.w, b2.w};
                     alpha = __builtin_elementwise_min(alpha, (gsr_v2f)(1.0f));   // opacity >= 1/255 > 0: no lower clamp needed
                     const bool ina = (__builtin_fabsf(q0.x) <= 2.0f) && (__builtin_fabsf(q1.x) <= 2.0f) &&
-                                     (alpha.x >= (1.0f / 255.0f));
+                                     (alpha.x >= (1.0f / 255.0f)) && (a1.z <= dpx);
                     const bool inb = two && (__builtin_fabsf(q0.y) <= 2.0f) && (__builtin_fabsf(q1.y) <= 2.0f) &&
-                                     (alpha.y >= (1.0f / 255.0f));
+                                     (alpha.y >= (1.0f / 255.0f)) && (b1.z <= dpx);
                     // branch-free under-blend: a rejected fragment blends alpha = 0, which leaves C and A
                     // bit-identical (fma(t, +-0, C) == C), and costs no exec-mask juggling on the scalar unit
                     float t = 1.0f - A;

@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256)
 k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col,
              GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint2* __restrict__ val,
-             uint32_t* __restrict__ rect)
+             uint32_t* __restrict__ rect, float* __restrict__ zwin /* NULL unless the frame is depth-tested */)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) {
@@ -135,6 +135,8 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
             const float ndcy = (-cly) / clw;
             const float cx = gsr_fma(ndcx, 0.5f, 0.5f) * f.W;
             const float cy = gsr_fma(ndcy, 0.5f, 0.5f) * f.H;
+            // every corner carries the centre's z and w: one window depth per quad (depth range 0..1)
+            if (zwin) zwin[i] = gsr_fma(clz / clw, 0.5f, 0.5f);
 
             const uint4 b = geoB[i];
             const float sx = gsr_h2f(b.x & 0xffffu), sy = gsr_h2f(b.x >> 16), sz = gsr_h2f(b.y & 0xffffu);

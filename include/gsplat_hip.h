@@ -134,6 +134,14 @@ int  gsr_stitch_bands(gsr_context* ctx, const float* gathered, int count,
  * the internal pair-count readback). */
 int  gsr_render(gsr_context* ctx, const gsr_camera* cam, float* rgba_out, int out_is_device);
 
+/* Same frame, depth-tested against what is already in the viewport: the reference draws
+ * after Houdini's opaque pass with the depth test on and depth writes off (src/GSplatRenderer.C:595-610).
+ * depth: float[height*width] window-space depth (0..1, row 0 = bottom) of the FULL image (also when
+ * sharded), host or device pointer; NULL = no test.  A fragment survives iff the splat's window depth
+ * (one value per quad, ndc.z*0.5+0.5) <= depth[pixel]. */
+int  gsr_render_depth(gsr_context* ctx, const gsr_camera* cam, const float* depth, int depth_is_device,
+                      float* rgba_out, int out_is_device);
+
 int  gsr_synchronize(gsr_context* ctx);
 int  gsr_get_stats(gsr_context* ctx, gsr_stats* out);     /* synchronizes the stream */
 int  gsr_stats_reset(gsr_context* ctx);

@@ -211,6 +211,8 @@ static void project_splat(const gso_splats* s, const gso_frame* f, int64_t i, gs
     const float ndcy = (-cly) / clw;
     o->cx = fmaf(ndcx, 0.5f, 0.5f) * W;
     o->cy = fmaf(ndcy, 0.5f, 0.5f) * H;
+    /* every corner carries the centre's z and w: one window depth per quad (default depth range 0..1) */
+    o->zwin = fmaf(clz / clw, 0.5f, 0.5f);
 
     /* attributes (:217-222); fp16 values are exact in fp32 */
     const float sx = gso_half_to_float(s->scale[3 * i + 0]);
@@ -426,7 +428,16 @@ int gso_host_sort_only(const float* P, int64_t n, const float cam_pos[3], int32_
  * FS: shaders/GSplatShaderSource.h:304-312.  Blend: src factor
  * ONE_MINUS_DST_ALPHA, dst factor ONE, equation ADD, for colour and alpha
  * (src/GSplatRenderer.C:613-621).                                           */
+static void splat_rows_depth(const gso_record* o, int width, int height, int row_lo, int row_hi,
+                             const float* depth, float* rgba);
+
 static void splat_rows(const gso_record* o, int width, int height, int row_lo, int row_hi, float* rgba)
+{
+    splat_rows_depth(o, width, height, row_lo, row_hi, (const float*)0, rgba);
+}
+
+static void splat_rows_depth(const gso_record* o, int width, int height, int row_lo, int row_hi,
+                             const float* depth, float* rgba)
 {
     (void)height;
     const float xlo = o->cx - o->hx - 0.5f, xhi = o->cx + o->hx - 0.5f;
@@ -453,6 +464,8 @@ static void splat_rows(const gso_record* o, int width, int height, int row_lo, i
             float alpha = gso_expf(power) * o->opacity;
             alpha = fminf(fmaxf(alpha, 0.0f), 1.0f);
             if (alpha < inv255) continue; /* discard */
+            /* depth test against the opaque pass (depth writes are off): GL_LEQUAL */
+            if (depth && !(o->zwin <= depth[(size_t)j * (size_t)width + (size_t)i])) continue;
             float* px = row + (size_t)i * 4;
             const float t = 1.0f - px[3];
             px[0] = fmaf(t, o->r * alpha, px[0]);
@@ -473,6 +486,33 @@ int gso_blend_serial(const gso_record* rec, const int32_t* perm, int64_t n, int 
         splat_rows(o, width, height, 0, height - 1, rgba);
     }
     return 0;
+}
+
+int gso_blend_serial_depth(const gso_record* rec, const int32_t* perm, int64_t n, int width, int height,
+                           const float* depth, float* rgba)
+{
+    if (!rec || !perm || !rgba || width <= 0 || height <= 0) return -1;
+    memset(rgba, 0, (size_t)width * (size_t)height * 16);
+    for (int64_t r = 0; r < n; ++r) {
+        const gso_record* o = &rec[perm[r]];
+        if (!o->visible) continue;
+        splat_rows_depth(o, width, height, 0, height - 1, depth, rgba);
+    }
+    return 0;
+}
+
+int gso_render_depth(const gso_splats* s, const gso_frame* f, const float* depth, float* rgba)
+{
+    if (!s || !f || !rgba) return -1;
+    gso_record* rec = (gso_record*)malloc((size_t)(s->n + 1) * sizeof(gso_record));
+    int32_t* perm = (int32_t*)malloc((size_t)(s->n + 1) * 4);
+    if (!rec || !perm) { free(rec); free(perm); return -2; }
+    int rc = gso_preprocess(s, f, rec);
+    if (!rc) rc = gso_argsort(rec, s->n, perm);
+    if (!rc) rc = gso_blend_serial_depth(rec, perm, s->n, f->width, f->height, depth, rgba);
+    free(rec);
+    free(perm);
+    return rc;
 }
 
 #define GSO_STRIP 8 /* rows per strip for the parallel renderer */

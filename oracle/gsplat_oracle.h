@@ -66,6 +66,7 @@ typedef struct gso_record {
     float r, g, b;      /* colour after SH                                            */
     float opacity;
     float key;          /* squared distance to cam_pos (sort key)                     */
+    float zwin;         /* window-space depth of the whole quad: ndc.z*0.5+0.5        */
     int32_t visible;    /* 0 if culled (w<=0, z outside [-w,w])                        */
 } gso_record;
 
@@ -111,6 +112,14 @@ int gso_blend_serial(const gso_record* rec, const int32_t* perm, int64_t n,
 /* same pixels, bit-identical, strip-parallel with OpenMP (CPU baseline). */
 int gso_blend_parallel(const gso_record* rec, const int32_t* perm, int64_t n,
                        int width, int height, float* rgba, int threads);
+
+/* Depth-tested variant: the reference draws after the opaque pass with the depth test
+ * on and depth writes off (src/GSplatRenderer.C:595-610).  depth = float[height*width] window depth
+ * (0..1, row 0 = bottom) of what is already in the framebuffer, or NULL for no test; a splat
+ * fragment survives iff its quad's depth <= depth[pixel] (GL_LEQUAL). */
+int gso_blend_serial_depth(const gso_record* rec, const int32_t* perm, int64_t n,
+                           int width, int height, const float* depth, float* rgba);
+int gso_render_depth(const gso_splats* s, const gso_frame* f, const float* depth, float* rgba);
 
 /* whole frame: preprocess + argsort + blend.  threads<=1 -> serial blend. */
 int gso_render(const gso_splats* s, const gso_frame* f, float* rgba, int threads);

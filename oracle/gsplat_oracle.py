@@ -37,12 +37,12 @@ class gso_frame(C.Structure):
 
 class gso_record(C.Structure):
     _fields_ = [(n, C.c_float) for n in
-                ("cx", "cy", "ex", "ey", "is1", "is2", "hx", "hy", "r", "g", "b", "opacity", "key")] + \
+                ("cx", "cy", "ex", "ey", "is1", "is2", "hx", "hy", "r", "g", "b", "opacity", "key", "zwin")] + \
                [("visible", C.c_int32)]
 
 
 RECORD_DTYPE = np.dtype([(n, np.float32) for n in
-                         ("cx", "cy", "ex", "ey", "is1", "is2", "hx", "hy", "r", "g", "b", "opacity", "key")]
+                         ("cx", "cy", "ex", "ey", "is1", "is2", "hx", "hy", "r", "g", "b", "opacity", "key", "zwin")]
                         + [("visible", np.int32)])
 
 
@@ -88,6 +88,7 @@ def lib() -> C.CDLL:
         L.gso_blend_serial.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         L.gso_blend_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.gso_render.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p, C.c_int]
+        L.gso_render_depth.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p, C.c_void_p]
         L.gso_host_sort_only.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p]
         L.gso_max_threads.restype = C.c_int
         _lib = L
@@ -179,6 +180,17 @@ def render(splats, cam, origin=(0, 0, 0), threads=1) -> np.ndarray:
     f = make_frame(cam, origin)
     out = np.zeros((f.height, f.width, 4), dtype=np.float32)
     rc = lib().gso_render(C.byref(pk.struct), C.byref(f), out.ctypes.data, threads)
+    assert rc == 0
+    return out
+
+
+def render_depth(splats, cam, depth, origin=(0, 0, 0)) -> np.ndarray:
+    """depth: float32 [H, W] window depth of the opaque pass (row 0 = bottom) or None"""
+    pk = _SplatPack(splats)
+    f = make_frame(cam, origin)
+    out = np.zeros((f.height, f.width, 4), dtype=np.float32)
+    d = None if depth is None else np.ascontiguousarray(depth, dtype=np.float32).reshape(f.height, f.width)
+    rc = lib().gso_render_depth(C.byref(pk.struct), C.byref(f), None if d is None else d.ctypes.data, out.ctypes.data)
     assert rc == 0
     return out
 

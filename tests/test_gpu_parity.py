@@ -353,3 +353,35 @@ def test_maximum_size_through_the_shim(pkg, oracle):
     ref = oracle.render(cat, cam, origin=origin, threads=oracle.max_threads())
     _check_image(img, ref)
     R.close()
+
+
+def test_depth_tested_compositing(pkg, oracle, engine):
+    """splats behind what the opaque pass left in the depth buffer are rejected
+    (depth test on, depth writes off -- src/GSplatRenderer.C:595-610)"""
+    splats = pkg.scenes.make_scene(60000, seed=95, sh=True)
+    cam = pkg.camera.make_camera(480, 300, sh_order=3, frame=4)
+    rec = oracle.preprocess(splats, cam)
+    zmid = float(np.median(rec["zwin"][rec["visible"] == 1]))
+    yy, xx = np.mgrid[0:cam.height, 0:cam.width]
+    depth = np.full((cam.height, cam.width), 1.0, np.float32)
+    depth[(xx // 40 + yy // 40) % 2 == 0] = zmid            # checkerboard "wall" through the middle of the cloud
+    depth[:20] = 0.0                                         # a strip that hides everything
+    engine.upload(splats)
+    img = engine.render_depth(cam, depth)
+    ref = oracle.render_depth(splats, cam, depth)
+    _check_image(img, ref)
+    assert np.count_nonzero(img[:20]) == 0
+    free = engine.render(cam)
+    assert np.array_equal(engine.render_depth(cam, np.ones_like(depth)), free)     # depth = far plane: nothing rejected
+    assert not np.array_equal(img, free)
+    # sharded, with the full-size depth image
+    out = np.zeros_like(img)
+    tiles_y = (cam.height + 15) // 16
+    for idx in range(2):
+        engine.set_row_shard(idx, 2)
+        band = engine.render_depth(cam, depth)
+        for lrow, trow in enumerate(range(idx, tiles_y, 2)):
+            y0, y1 = trow * 16, min(trow * 16 + 16, cam.height)
+            out[y0:y1] = band[lrow * 16: lrow * 16 + (y1 - y0)]
+    engine.set_row_shard(0, 1)
+    assert np.array_equal(out, img)

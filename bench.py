@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--flags", type=int, default=0, help="GSR_OPT_DEBUG_FLAGS (A/B)")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="1 = strictly serial frames; 2 (default) = frame f+1's front end overlaps frame f's blend")
+    ap.add_argument("--emulate-shard", type=int, default=0,
+                    help="single-GPU diagnostic: render only tile-row shard 0 of N (per-rank cost of an N-GPU run, no gather)")
     ap.add_argument("--verify", action="store_true",
                     help="N>1: also render the last frame unsharded on rank 0 and require the stitched frame to be bit-identical")
     return ap.parse_args()
@@ -139,10 +141,15 @@ def main():
     eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, args.frames_in_flight)
     if world > 1:
         eng.set_row_shard(rank, world)
+    elif args.emulate_shard > 1:
+        eng.set_row_shard(0, args.emulate_shard)
     eng.upload(splats)  # once: geometry stays resident in HBM
 
     fg = pkg.multigpu.FrameGatherer(dist, rank, world, W, H, "cuda", engine=eng, via_host=(backend != "nccl"))
-    assert fg.rows == eng.band_rows(H)
+    if args.emulate_shard > 1:
+        import torch as _t
+        fg.band = _t.zeros((eng.band_rows(H), W, 4), dtype=_t.float32, device="cuda")
+    assert fg.band.shape[0] == eng.band_rows(H)
     cams = [pkg.engine.camera_struct(pkg.camera.make_camera(W, H, sh_order=order, frame=i))
             for i in range(args.warmup + args.steps)]
 

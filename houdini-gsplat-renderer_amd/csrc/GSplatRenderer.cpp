@@ -300,7 +300,7 @@ void GSplatRenderer::render(GSplatRenderContext& r, bool isObjectLevel)
     cam.sh_order = doSH ? myShOrder : 0;
     // the engine re-sorts only when cam_pos or the geometry changed: argsortByDistance's
     // caching with threshold 0 (:165-186)
-    myLastStatus = gsr_render(myEngine, &cam, r.target, r.target_is_device);
+    myLastStatus = gsr_render_depth(myEngine, &cam, r.depth, r.depth_is_device, r.target, r.target_is_device);
     if (myLastStatus != GSR_OK) {
         logLine("ERROR", "render failed: %s", gsr_last_error());
         return;

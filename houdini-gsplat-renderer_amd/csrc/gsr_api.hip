@@ -2,8 +2,9 @@
 // per-frame kernel pipeline and the C ABI declared in include/gsplat_hip.h.
 //
 // Pipeline per gsr_render (all on one HIP stream):
-//   K1 k_preprocess        N splats -> record/key/rect                     (HBM)
-//   depth sort             4 x {hist, scan, scatter} on (key, idx)         (HBM)
+//   K1 k_preprocess        N splats -> record, key, (idx, rect)            (HBM)
+//   depth sort             3 x {hist, row scan, scatter}; the FIRST pass drops culled splats,
+//                          so everything downstream runs on the visible ones (count in HBM)
 //   K2 k_super_counts+scan super-tile pairs per depth rank -> offsets, D   (HBM)
 //      [D read back: 4-byte D2H + stream sync -- sizes the pair buffers]
 //   K3 k_emit_pairs        D (super-tile, splat) pairs in depth order      (HBM)
@@ -63,7 +64,8 @@ struct FrameSlot {
     GsrRecord* rec = nullptr;
     uint32_t *keyA = nullptr, *keyB = nullptr;
     uint2 *valA = nullptr, *valB = nullptr;      // depth-sort payload: (splat index, packed tile rect)
-    uint32_t *rect = nullptr, *cnt = nullptr, *poff = nullptr;
+    uint32_t *cnt = nullptr, *poff = nullptr;
+    uint32_t* d_n = nullptr;           // splats that survived culling = items after the first sort pass
     float* zwin = nullptr;             // per-splat window depth (depth-tested frames)
     float* depth_stage = nullptr;      // device copy of a host depth buffer
     size_t depth_cap = 0;
@@ -88,9 +90,14 @@ struct FrameSlot {
     uint32_t* h_total = nullptr;             // pinned
     unsigned long long* h_counters = nullptr;  // pinned
     // depth-sort cache (argsortByDistance semantics)
+    // The cached order covers exactly the splats visible to the camera that sorted, so it is reused
+    // only for an identical frame description (the reference re-sorts on any camera translation,
+    // src/GSplatRenderer.C:165-186; a static viewport redraw is the case that matters)
     bool sort_valid = false;
-    float sort_cam[3] = {0, 0, 0};
+    gsr_camera sort_camera{};
+    int sort_shard_index = 0, sort_shard_count = 1, sort_flags = 0;
     uint64_t sort_gen = 0;
+    uint32_t h_n = 0;                  // host copy of *d_n of the last frame (after synchronisation)
     uint32_t key_min = 0;              // of the frame whose order is cached
     // last frame rendered in this slot
     int last_tiles_x = 0, last_local_ty = 0, last_supers = 0;
@@ -179,6 +186,8 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipEventCreateWithFlags(&sl.ev_user, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.counters), 8 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_total), sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_n), sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(sl.d_n, 0, sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.totals), 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), 8 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
@@ -194,7 +203,7 @@ static bool slot_init(FrameSlot& sl)
 static void slot_free_splat_arrays(FrameSlot& sl)
 {
     dev_free(sl.rec); dev_free(sl.keyA); dev_free(sl.keyB); dev_free(sl.valA); dev_free(sl.valB);
-    dev_free(sl.rect); dev_free(sl.cnt); dev_free(sl.poff); dev_free(sl.zwin);
+    dev_free(sl.cnt); dev_free(sl.poff); dev_free(sl.zwin);
     sl.sort_valid = false;
 }
 
@@ -204,7 +213,7 @@ static void slot_destroy(FrameSlot& sl)
     dev_free(sl.hist); dev_free(sl.partial); dev_free(sl.totals);
     dev_free(sl.pkA); dev_free(sl.pkB); dev_free(sl.pvA); dev_free(sl.pvB);
     dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.fb); dev_free(sl.depth_stage);
-    dev_free(sl.counters); dev_free(sl.d_total);
+    dev_free(sl.counters); dev_free(sl.d_total); dev_free(sl.d_n);
     if (sl.h_total) (void)hipHostFree(sl.h_total);
     if (sl.h_counters) (void)hipHostFree(sl.h_counters);
     if (sl.ev_ok)
@@ -321,7 +330,7 @@ extern "C" int gsr_upload_begin(gsr_context* c, int64_t total, int has_sh, const
         for (int k = 0; k < GSR_MAX_SLOTS; ++k) {
             FrameSlot& sl = c->slot[k];
             if ((rc = dev_alloc(&sl.rec, cap)) || (rc = dev_alloc(&sl.keyA, cap)) || (rc = dev_alloc(&sl.keyB, cap)) ||
-                (rc = dev_alloc(&sl.valA, cap)) || (rc = dev_alloc(&sl.valB, cap)) || (rc = dev_alloc(&sl.rect, cap)) ||
+                (rc = dev_alloc(&sl.valA, cap)) || (rc = dev_alloc(&sl.valB, cap)) ||
                 (rc = dev_alloc(&sl.cnt, cap + 8)) || (rc = dev_alloc(&sl.poff, cap + 8)) || (rc = dev_alloc(&sl.zwin, cap))) {
                 free_geometry(c);
                 return rc;
@@ -492,25 +501,32 @@ static int exclusive_scan(FrameSlot& sl, const uint32_t* in, uint32_t* out, uint
     return GSR_OK;
 }
 
-template <typename V, int DBITS>
-static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, uint32_t n, int shift, uint32_t nblk)
+template <typename V, int DBITS, bool SKIP>
+static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, uint32_t n, const uint32_t* n_dev,
+                      int shift, uint32_t nblk)
 {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, n, shift,
-                       sl.hist, nblk);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS, SKIP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, n,
+                       n_dev, shift, sl.hist, nblk);
     hipLaunchKernelGGL(k_scan_rows, dim3(1u << DBITS), dim3(SC_THREADS), 0, sl.stream, sl.hist, nblk, sl.totals);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, vA,
-                       kB, vB, n, shift, sl.hist, sl.totals, nblk);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS, SKIP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA,
+                       vA, kB, vB, n, n_dev, shift, sl.hist, sl.totals, nblk);
     HIP_TRY(hipGetLastError());
     return GSR_OK;
 }
 
 // stable LSD sort on key bits [0, bits); ping-pongs (kA,vA) <-> (kB,vB) and leaves the result
 // in (kA,vA) by swapping the pointers.  9-bit digits are used when they save a pass.
+// compact_to != NULL: the first pass drops items whose key is 0xffffffff and the surviving count is
+// written to *compact_to (device); the remaining passes and the caller's later kernels read it there.
 template <typename V>
 static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& vB, uint32_t n, int bits,
-                      bool allow9 = true)
+                      bool allow9 = true, uint32_t* compact_to = nullptr)
 {
-    if (n == 0 || bits <= 0) return GSR_OK;
+    if (n == 0) {
+        if (compact_to) HIP_TRY(hipMemsetAsync(compact_to, 0, 4, sl.stream));
+        return GSR_OK;
+    }
+    if (bits <= 0) bits = 1;
     const uint32_t nblk = div_up(n, RS_TILE);
     int rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)512 * nblk + 8);
     if (rc) return rc;
@@ -518,9 +534,19 @@ static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& v
     const bool use9 = allow9 && p9 < p8;
     const int passes = use9 ? p9 : p8, width = use9 ? 9 : 8;
     for (int p = 0; p < passes; ++p) {
-        rc = use9 ? radix_pass<V, 9>(sl, kA, vA, kB, vB, n, p * width, nblk)
-                  : radix_pass<V, 8>(sl, kA, vA, kB, vB, n, p * width, nblk);
+        const bool skip = compact_to && p == 0;
+        const uint32_t* n_dev = (compact_to && p > 0) ? compact_to : nullptr;
+        if (use9)
+            rc = skip ? radix_pass<V, 9, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk)
+                      : radix_pass<V, 9, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk);
+        else
+            rc = skip ? radix_pass<V, 8, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk)
+                      : radix_pass<V, 8, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk);
         if (rc) return rc;
+        if (skip) {
+            hipLaunchKernelGGL(k_sum_totals, dim3(1), dim3(SC_THREADS), 0, sl.stream, sl.totals, 1 << width, compact_to);
+            HIP_TRY(hipGetLastError());
+        }
         uint32_t* t = kA; kA = kB; kB = t;
         V* tv = vA; vA = vB; vB = tv;
     }
@@ -746,32 +772,33 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
 
     MARK(0);
     const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_gen == c->geo_gen &&
-                           sl.sort_cam[0] == cam->cam_pos[0] && sl.sort_cam[1] == cam->cam_pos[1] &&
-                           sl.sort_cam[2] == cam->cam_pos[2];
+                           sl.sort_shard_index == c->shard_index && sl.sort_shard_count == c->shard_count &&
+                           sl.sort_flags == c->opt_flags && std::memcmp(&sl.sort_camera, cam, sizeof(gsr_camera)) == 0;
     uint32_t D = 0;
     if (n > 0) {
-        // on a cache hit K1 must not touch the sorted (keyA, valA); the rects inside valA are refreshed instead
+        // on a cache hit (identical frame description) the sorted (keyA, valA) are kept and K1's key/payload
+        // output goes to the scratch buffers
         hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, 256)), dim3(256), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
-                           sl.rec, cache_hit ? (uint32_t*)nullptr : sl.keyA, cache_hit ? (uint2*)nullptr : sl.valA, sl.rect,
+                           sl.rec, cache_hit ? sl.keyB : sl.keyA, cache_hit ? sl.valB : sl.valA,
                            d_depth ? sl.zwin : (float*)nullptr);
-        if (cache_hit)
-            hipLaunchKernelGGL(k_refresh_rects, dim3(div_up(n, 256)), dim3(256), 0, s, sl.valA, n, sl.rect);
         HIP_TRY(hipGetLastError());
     }
     MARK(1);
-    if (n > 0 && !cache_hit) {
+    if (!cache_hit) {
         int key_bits = 1;
         while (key_bits < 32 && ((f.key_max - f.key_min) >> key_bits) != 0u) ++key_bits;
-        int rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n, key_bits, !(c->opt_flags & GSR_FLAG_FULL_KEYS));
+        int rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n, key_bits, !(c->opt_flags & GSR_FLAG_FULL_KEYS),
+                            sl.d_n);
         if (rc) return rc;
         sl.key_min = f.key_min;
         sl.sort_valid = true;
         sl.sort_gen = c->geo_gen;
-        for (int k = 0; k < 3; ++k) sl.sort_cam[k] = cam->cam_pos[k];
+        sl.sort_camera = *cam;
+        sl.sort_shard_index = c->shard_index; sl.sort_shard_count = c->shard_count; sl.sort_flags = c->opt_flags;
     }
     MARK(2);
     if (n > 0) {
-        hipLaunchKernelGGL(k_super_counts, dim3(div_up(n, 256)), dim3(256), 0, s, sl.valA, n, f.super_shift,
+        hipLaunchKernelGGL(k_super_counts, dim3(div_up(n, 256)), dim3(256), 0, s, sl.valA, n, sl.d_n, f.super_shift,
                            c->shard_index, c->shard_count, sl.cnt);
         int rc = exclusive_scan(sl, sl.cnt, sl.poff, n, sl.d_total);
         if (rc) return rc;
@@ -789,8 +816,8 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
             sl.pair_cap = want;
         }
         if (D > 0) {
-            hipLaunchKernelGGL(k_emit_pairs, dim3(div_up(n, 256)), dim3(256), 0, s, sl.valA, sl.poff, n, f.super_shift,
-                               c->shard_index, c->shard_count, f.stiles_x, sl.pkA, sl.pvA);
+            hipLaunchKernelGGL(k_emit_pairs, dim3(div_up(n, 256)), dim3(256), 0, s, sl.valA, sl.poff, sl.d_n,
+                               f.super_shift, c->shard_index, c->shard_count, f.stiles_x, sl.pkA, sl.pvA);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -837,6 +864,8 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
     sl.frame_id = c->frame_no;
     // counters of this frame travel with the stream; they are read in gsr_get_stats
     HIP_TRY(hipMemcpyAsync(sl.h_counters, sl.counters, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    sl.h_counters[6] = 0;
+    HIP_TRY(hipMemcpyAsync(&sl.h_counters[6], sl.d_n, 4, hipMemcpyDeviceToHost, s));   // visible splats of this frame
     if (!out_is_device) {
         HIP_TRY(hipMemcpyAsync(rgba_out, sl.fb, out_px * 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -876,14 +905,7 @@ extern "C" int gsr_get_stats(gsr_context* c, gsr_stats* out)
     if (last) {
         harvest_slot(c, *last);
         FrameSlot& sl = *last;
-        // statistics-only pass over the rects of the last frame
-        HIP_TRY(hipMemsetAsync(sl.counters, 0, sizeof(unsigned long long), sl.stream));
-        if (c->n > 0)
-            hipLaunchKernelGGL(k_count_visible, dim3(256), dim3(256), 0, sl.stream, sl.rect, c->n, c->shard_index,
-                               c->shard_count, sl.counters);
-        HIP_TRY(hipMemcpyAsync(sl.h_counters, sl.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, sl.stream));
-        HIP_TRY(hipStreamSynchronize(sl.stream));
-        c->st.n_visible = (int64_t)sl.h_counters[0];
+        c->st.n_visible = (int64_t)(sl.h_counters[6] & 0xffffffffull);
         c->st.pairs_consumed = (int64_t)sl.h_counters[1];
         c->st.entries_scanned = (int64_t)sl.h_counters[3];
         c->st.pairs_total = sl.last_pairs;
@@ -927,6 +949,9 @@ extern "C" int gsr_stats_reset(gsr_context* c)
 
 // ---------------------------------------------------------------------------
 // debug / test access: intermediates of the most recent frame
+// number of entries of the depth-sorted list of the last frame (= visible splats of that frame)
+static uint32_t sorted_count(FrameSlot* sl) { return (uint32_t)(sl->h_counters[6] & 0xffffffffull); }
+
 extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int64_t n)
 {
     if (!c || !out || n < 0 || (uint64_t)n > c->n) return set_err(GSR_E_INVALID, "gsr_debug_read_records: bad argument");
@@ -935,53 +960,50 @@ extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int
     if (src) return src;
     FrameSlot* sl = latest_slot(c);
     if (!sl) return set_err(GSR_E_INVALID, "gsr_debug_read_records: no frame rendered yet");
+    const uint32_t ns = sorted_count(sl);
     GsrRecord* hr = new (std::nothrow) GsrRecord[n ? n : 1];
-    uint32_t* hk = new (std::nothrow) uint32_t[n ? n : 1];
-    uint32_t* hrect = new (std::nothrow) uint32_t[n ? n : 1];
-    uint32_t* hidx = new (std::nothrow) uint32_t[n ? n : 1];
+    uint32_t* hk = new (std::nothrow) uint32_t[ns ? ns : 1];
+    uint2* hv = new (std::nothrow) uint2[ns ? ns : 1];
     int rc = GSR_OK;
-    if (!hr || !hk || !hrect || !hidx) rc = set_err(GSR_E_OOM, "gsr_debug_read_records: host allocation failed");
+    if (!hr || !hk || !hv) rc = set_err(GSR_E_OOM, "gsr_debug_read_records: host allocation failed");
     hipError_t e = hipSuccess;
     if (!rc && n) {
         e = hipMemcpy(hr, sl->rec, (size_t)n * sizeof(GsrRecord), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(hrect, sl->rect, (size_t)n * 4, hipMemcpyDeviceToHost);
-        // keys live in sorted order after the depth sort: un-permute through the payload's index
-        if (e == hipSuccess) e = hipMemcpy(hk, sl->keyA, (size_t)n * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy2D(hidx, 4, sl->valA, 8, 4, (size_t)n, hipMemcpyDeviceToHost);
+        // keys and rects live in depth order and only for the visible splats: un-permute through the payload
+        if (e == hipSuccess && ns) e = hipMemcpy(hk, sl->keyA, (size_t)ns * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && ns) e = hipMemcpy(hv, sl->valA, (size_t)ns * 8, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = set_err(GSR_E_HIP, "gsr_debug_read_records: %s", hipGetErrorString(e));
     }
     if (!rc) {
-        for (int64_t i = 0; i < n; ++i) {
+        for (int64_t i = 0; i < n; ++i) std::memset(&out[i], 0, sizeof(out[i]));
+        for (uint32_t r = 0; r < ns; ++r) {
+            const uint32_t i = hv[r].x;
+            if ((int64_t)i >= n) continue;
             gsr_debug_record& o = out[i];
-            std::memset(&o, 0, sizeof(o));
-            const uint32_t rc_ = hrect[i];
-            const int x0 = rc_ & 255, y0 = (rc_ >> 8) & 255, x1 = (rc_ >> 16) & 255, y1 = rc_ >> 24;
-            o.visible = (x1 >= x0 && y1 >= y0) ? 1 : 0;
-            if (o.visible) {
-                const GsrRecord& r = hr[i];
-                o.cx = r.cx; o.cy = r.cy; o.ex = r.ex; o.ey = r.ey; o.is1 = r.is1; o.is2 = r.is2;
-                o.hx = r.hx; o.hy = r.hy; o.r = r.r; o.g = r.g; o.b = r.b; o.opacity = r.opacity;
-            }
+            const GsrRecord& q = hr[i];
+            o.visible = 1;
+            o.cx = q.cx; o.cy = q.cy; o.ex = q.ex; o.ey = q.ey; o.is1 = q.is1; o.is2 = q.is2;
+            o.hx = q.hx; o.hy = q.hy; o.r = q.r; o.g = q.g; o.b = q.b; o.opacity = q.opacity;
+            const uint32_t kb = hk[r] + sl->key_min;   // keys are stored relative to the frame's key_min
+            std::memcpy(&o.key, &kb, 4);
         }
-        for (int64_t r = 0; r < n; ++r)
-            if (hidx[r] < (uint64_t)n) {
-                const uint32_t kb = hk[r] + sl->key_min;   // keys are stored relative to the frame's key_min
-                std::memcpy(&out[hidx[r]].key, &kb, 4);
-            }
     }
-    delete[] hr; delete[] hk; delete[] hrect; delete[] hidx;
+    delete[] hr; delete[] hk; delete[] hv;
     return rc;
 }
 
-extern "C" int gsr_debug_read_depth_order(gsr_context* c, int32_t* perm, int64_t n)
+extern "C" int gsr_debug_read_depth_order(gsr_context* c, int32_t* perm, int64_t cap, int64_t* n_sorted)
 {
-    if (!c || !perm || n < 0 || (uint64_t)n > c->n) return set_err(GSR_E_INVALID, "gsr_debug_read_depth_order: bad argument");
+    if (!c || !perm || !n_sorted || cap < 0) return set_err(GSR_E_INVALID, "gsr_debug_read_depth_order: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
     FrameSlot* sl = latest_slot(c);
     if (!sl) return set_err(GSR_E_INVALID, "gsr_debug_read_depth_order: no frame rendered yet");
-    if (n) HIP_TRY(hipMemcpy2D(perm, 4, sl->valA, 8, 4, (size_t)n, hipMemcpyDeviceToHost));
+    const uint32_t ns = sorted_count(sl);
+    *n_sorted = ns;
+    const int64_t m = (int64_t)ns < cap ? (int64_t)ns : cap;
+    if (m) HIP_TRY(hipMemcpy2D(perm, 4, sl->valA, 8, 4, (size_t)m, hipMemcpyDeviceToHost));
     return GSR_OK;
 }
 
@@ -1035,7 +1057,7 @@ extern "C" int gsr_debug_sort_pairs(gsr_context* c, uint32_t* keys, uint32_t* va
     hipError_t e = hipMemcpyAsync(kA, keys, (size_t)n * 4, hipMemcpyHostToDevice, sl.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(vA, vals, (size_t)n * 4, hipMemcpyHostToDevice, sl.stream);
     if (e == hipSuccess) {
-        rc = radix_sort(sl, kA, vA, kB, vB, n, key_bits, true);
+        rc = radix_sort(sl, kA, vA, kB, vB, n, key_bits, true, (uint32_t*)nullptr);
         if (!rc) {
             e = hipMemcpyAsync(keys, kA, (size_t)n * 4, hipMemcpyDeviceToHost, sl.stream);
             if (e == hipSuccess) e = hipMemcpyAsync(vals, vA, (size_t)n * 4, hipMemcpyDeviceToHost, sl.stream);

@@ -19,31 +19,23 @@
 
 // cnt[r] = number of owned super-tiles of the splat at depth rank r
 __global__ void __launch_bounds__(256)
-k_super_counts(const uint2* __restrict__ sorted, uint32_t n, int shift, int shard_index, int shard_count,
-               uint32_t* __restrict__ cnt)
+k_super_counts(const uint2* __restrict__ sorted, uint32_t n_max, const uint32_t* __restrict__ n_dev, int shift,
+               int shard_index, int shard_count, uint32_t* __restrict__ cnt)
 {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= n) return;
-    cnt[r] = (uint32_t)gsr_rect_supers(sorted[r].y, shift, shard_index, shard_count);
-}
-
-// depth-sort cache hit with a new view matrix: the order is still valid, the rects are not
-__global__ void __launch_bounds__(256)
-k_refresh_rects(uint2* __restrict__ sorted, uint32_t n, const uint32_t* __restrict__ rect)
-{
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= n) return;
-    sorted[r].y = rect[sorted[r].x];
+    if (r >= n_max) return;
+    // n_dev = number of splats that survived the compacting first sort pass; the scan runs over n_max
+    cnt[r] = (r < *n_dev) ? (uint32_t)gsr_rect_supers(sorted[r].y, shift, shard_index, shard_count) : 0u;
 }
 
 // one lane per depth rank writes its (super-tile id ; splat index, rect) pairs at poff[r]
 __global__ void __launch_bounds__(256)
-k_emit_pairs(const uint2* __restrict__ sorted, const uint32_t* __restrict__ poff, uint32_t n, int shift,
-             int shard_index, int shard_count, int stiles_x, uint32_t* __restrict__ pkeys,
+k_emit_pairs(const uint2* __restrict__ sorted, const uint32_t* __restrict__ poff, const uint32_t* __restrict__ n_dev,
+             int shift, int shard_index, int shard_count, int stiles_x, uint32_t* __restrict__ pkeys,
              uint2* __restrict__ pvals)
 {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= n) return;
+    if (r >= *n_dev) return;
     const uint2 v = sorted[r];
     const uint32_t rc = v.y;
     const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = (rc >> 16) & 255, y1 = rc >> 24;

@@ -9,6 +9,10 @@
 #pragma once
 #include "gsr_device.h"
 
+#ifndef GSR_PRELOAD_COLOR
+#define GSR_PRELOAD_COLOR 0   // 1 = fetch the colour chunks before the visibility test (measured slower: K1 is HBM-bound)
+#endif
+
 // ---------------------------------------------------------------------------
 // K0: raw registerUpdate()-layout arrays (already in device memory) -> SoA of
 // 16-byte vectors.  Runs once per geometry change, not per frame.
@@ -92,24 +96,38 @@ __global__ void __launch_bounds__(256)
 k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col,
              GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint2* __restrict__ val,
-             uint32_t* __restrict__ rect, float* __restrict__ zwin /* NULL unless the frame is depth-tested */)
+             float* __restrict__ zwin /* NULL unless the frame is depth-tested */)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) {
+        // geoA and geoB are fetched together; the colour chunks only once the splat is known to be needed
+        // (GSR_PRELOAD_COLOR=1 fetches them up front too -- one round trip instead of two, but the kernel is
+        // HBM-bound and the bytes wasted on culled splats make it slower: 0.293 vs 0.280 ms on C4).
         const float4 a = geoA[i];
+        const uint4 b = geoB[i];
+#if GSR_PRELOAD_COLOR
+        uint4 cchunk[6];
+        {
+            const int nchunk_pre = f.sh_order == 0 ? 1 : (f.sh_order == 1 ? 2 : (f.sh_order == 2 ? 4 : 6));
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                cchunk[c] = make_uint4(0, 0, 0, 0);
+                if (c < nchunk_pre) cchunk[c] = col[(size_t)c * cap + i];
+            }
+        }
+#endif
         const float px = a.x, py = a.y, pz = a.z, opacity = a.w;
 
-        // sort key: un-offset P vs camera (src/GSplatRenderer.C:197-201)
+        // sort key: un-offset P vs camera (src/GSplatRenderer.C:197-201).  distance^2 >= 0: its IEEE bits
+        // are monotone.  The host bounds them for this frame from the cloud's bounding box
+        // (key_min/key_max), so the sort only has to cover key_max - key_min.
+        uint32_t kb;
         {
             float dx = px - f.cam[0], dy = py - f.cam[1], dz = pz - f.cam[2];
             float k = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
-            if (key) {   // NULL on a depth-sort cache hit
-                // distance^2 >= 0: its IEEE bits are monotone.  The host bounds them for this frame from the
-                // cloud's bounding box (key_min/key_max), so the sort only has to cover key_max-key_min.
-                uint32_t kb = __builtin_bit_cast(uint32_t, k);
-                kb = kb < f.key_min ? f.key_min : (kb > f.key_max ? f.key_max : kb);
-                key[i] = kb - f.key_min;
-            }
+            kb = __builtin_bit_cast(uint32_t, k);
+            kb = kb < f.key_min ? f.key_min : (kb > f.key_max ? f.key_max : kb);
+            kb -= f.key_min;
         }
         uint32_t out_rect = GSR_RECT_EMPTY;
 
@@ -138,7 +156,6 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
             // every corner carries the centre's z and w: one window depth per quad (depth range 0..1)
             if (zwin) zwin[i] = gsr_fma(clz / clw, 0.5f, 0.5f);
 
-            const uint4 b = geoB[i];
             const float sx = gsr_h2f(b.x & 0xffffu), sy = gsr_h2f(b.x >> 16), sz = gsr_h2f(b.y & 0xffffu);
             const float qi = gsr_h2f(b.y >> 16), qj = gsr_h2f(b.z & 0xffffu), qk = gsr_h2f(b.z >> 16);
             const float qr = gsr_h2f(b.w & 0xffffu);
@@ -236,9 +253,17 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
                 }
             }
 
+            // a splat none of whose tiles belong to this context's row shard is dropped here: it costs no
+            // colour fetch, no record and (sentinel key below) no sorting
+            if (out_rect != GSR_RECT_EMPTY && gsr_rect_tiles(out_rect, f.shard_index, f.shard_count) == 0)
+                out_rect = GSR_RECT_EMPTY;
             if (out_rect != GSR_RECT_EMPTY) {
                 // colour: Cd, optionally + SH (:224, :244-274)
+#if GSR_PRELOAD_COLOR
+                const uint4 c0 = cchunk[0];
+#else
                 const uint4 c0 = col[i];
+#endif
                 float cr = gsr_h2f(c0.x & 0xffffu), cg = gsr_h2f(c0.x >> 16), cbl = gsr_h2f(c0.y & 0xffffu);
                 if (f.sh_order > 0) {
                     uint32_t w[24];
@@ -246,8 +271,12 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
                     const int nchunk = f.sh_order == 1 ? 2 : (f.sh_order == 2 ? 4 : 6);
 #pragma unroll
                     for (int c = 1; c < 6; ++c) {
+#if GSR_PRELOAD_COLOR
+                        const uint4 v = cchunk[c];
+#else
                         uint4 v = make_uint4(0, 0, 0, 0);
                         if (c < nchunk) v = col[(size_t)c * cap + i];
+#endif
                         w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
                     }
                     float shr[15], shg[15], shb[15];
@@ -278,8 +307,10 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
                 dst[2] = make_float4(o.r, o.g, o.b, o.opacity);
             }
         }
-        rect[i] = out_rect;
-        if (val) val[i] = make_uint2(i, out_rect);   // sort payload: splat index + tile rect
+        // key 0xffffffff (never a real key: keys are distance^2 bits minus key_min) marks a splat the first
+        // radix pass drops, so everything after it runs on the visible splats only
+        key[i] = (out_rect != GSR_RECT_EMPTY) ? kb : 0xffffffffu;
+        val[i] = make_uint2(i, out_rect);   // sort payload: splat index + tile rect
     }
 }
 
@@ -317,25 +348,4 @@ k_bbox_partials(const float4* __restrict__ geoA, uint32_t n, float* __restrict__
         for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? __builtin_fminf(v, s[w][threadIdx.x]) : __builtin_fmaxf(v, s[w][threadIdx.x]);
         partial[blockIdx.x * 6 + threadIdx.x] = v;
     }
-}
-
-// statistics only (gsr_get_stats): splats with at least one owned tile.  Same-address
-// atomics serialise at ~12 ns each on MI355X, so this is kept out of the frame path.
-__global__ void __launch_bounds__(256)
-k_count_visible(const uint32_t* __restrict__ rect, uint32_t n, int shard_index, int shard_count,
-                unsigned long long* __restrict__ counters)
-{
-    __shared__ uint32_t s_cnt;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    uint32_t local = 0;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
-        local += gsr_rect_tiles(rect[i], shard_index, shard_count) > 0 ? 1u : 0u;
-    const unsigned long long m = __ballot(local != 0);  // keeps the wave converged before the reduction
-    (void)m;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) local += __shfl_down(local, d, 64);
-    if ((threadIdx.x & 63u) == 0) atomicAdd(&s_cnt, local);
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)s_cnt);
 }

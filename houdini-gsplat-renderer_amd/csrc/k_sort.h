@@ -136,9 +136,13 @@ k_scan_down(const uint32_t* in, uint32_t n, const uint32_t* __restrict__ partial
 //                            row total -> totals[digit]
 //   k_radix_scatter<V,DBITS> digit bases = exclusive scan of totals (recomputed per workgroup in
 //                            LDS), stable ranking, LDS reorder, coalesced runs out
-template <int DBITS>
+// n_dev != NULL: the item count lives in device memory (it is the output of a compacting first
+// pass); the grid is sized for the host-side upper bound and surplus workgroups just publish zeros.
+// SKIP: items whose key is the sentinel 0xffffffff do not exist (compacting first pass).
+template <int DBITS, bool SKIP>
 __global__ void __launch_bounds__(RS_THREADS)
-k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ hist, uint32_t nblk)
+k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n_host, const uint32_t* __restrict__ n_dev, int shift,
+             uint32_t* __restrict__ hist, uint32_t nblk)
 {
     constexpr int BINS = 1 << DBITS;
     constexpr uint32_t MASK = BINS - 1;
@@ -146,21 +150,25 @@ k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t*
     const int wave = threadIdx.x >> 6;
     for (int b = threadIdx.x; b < 4 * BINS; b += RS_THREADS) (&h[0][0])[b] = 0;
     __syncthreads();
+    const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t base = blockIdx.x * RS_TILE;
     if (base + RS_TILE <= n) {
         const uint4* p = reinterpret_cast<const uint4*>(keys + base);
 #pragma unroll
         for (int k = 0; k < RS_ITEMS / 4; ++k) {
             uint4 v = p[k * RS_THREADS + threadIdx.x];
-            atomicAdd(&h[wave][(v.x >> shift) & MASK], 1u);
-            atomicAdd(&h[wave][(v.y >> shift) & MASK], 1u);
-            atomicAdd(&h[wave][(v.z >> shift) & MASK], 1u);
-            atomicAdd(&h[wave][(v.w >> shift) & MASK], 1u);
+            if (!SKIP || v.x != 0xffffffffu) atomicAdd(&h[wave][(v.x >> shift) & MASK], 1u);
+            if (!SKIP || v.y != 0xffffffffu) atomicAdd(&h[wave][(v.y >> shift) & MASK], 1u);
+            if (!SKIP || v.z != 0xffffffffu) atomicAdd(&h[wave][(v.z >> shift) & MASK], 1u);
+            if (!SKIP || v.w != 0xffffffffu) atomicAdd(&h[wave][(v.w >> shift) & MASK], 1u);
         }
     } else {
         for (int k = 0; k < RS_ITEMS; ++k) {
             uint32_t i = base + k * RS_THREADS + threadIdx.x;
-            if (i < n) atomicAdd(&h[wave][(keys[i] >> shift) & MASK], 1u);
+            if (i < n) {
+                const uint32_t key = keys[i];
+                if (!SKIP || key != 0xffffffffu) atomicAdd(&h[wave][(key >> shift) & MASK], 1u);
+            }
         }
     }
     __syncthreads();
@@ -192,13 +200,26 @@ k_scan_rows(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ t
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// number of items that survived a compacting pass = sum of the per-digit totals
+__global__ void __launch_bounds__(SC_THREADS)
+k_sum_totals(const uint32_t* __restrict__ totals, int bins, uint32_t* __restrict__ n_out)
+{
+    __shared__ uint32_t s_wave[4];
+    uint32_t v = 0;
+    for (int b = threadIdx.x; b < bins; b += SC_THREADS) v += totals[b];
+    uint32_t tot;
+    (void)block_excl_scan_256(v, s_wave, &tot);
+    if (threadIdx.x == 0) *n_out = tot;
+}
+
 // V = payload type: uint32_t (4 B) or uint2 (8 B: splat index + packed tile rect).
 // Item order inside a workgroup: wave w owns items [w*RS_WAVE_ITEMS, (w+1)*RS_WAVE_ITEMS) of the
 // tile, round k covers 64 consecutive items -> (wave, round, lane) is input order.
-template <typename V, int DBITS>
+template <typename V, int DBITS, bool SKIP>
 __global__ void __launch_bounds__(RS_THREADS)
 k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in,
-                uint32_t* __restrict__ keys_out, V* __restrict__ vals_out, uint32_t n, int shift,
+                uint32_t* __restrict__ keys_out, V* __restrict__ vals_out, uint32_t n_host,
+                const uint32_t* __restrict__ n_dev, int shift,
                 const uint32_t* __restrict__ offs, const uint32_t* __restrict__ totals, uint32_t nblk)
 {
     constexpr int BINS = 1 << DBITS;
@@ -212,7 +233,9 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
     __shared__ V svals[RS_TILE];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t tile_base = blockIdx.x * RS_TILE;
+    if (tile_base >= n) return;   // surplus workgroup of an upper-bound grid
     const uint32_t nvalid = (n - tile_base < RS_TILE) ? (n - tile_base) : RS_TILE;
     for (int b = threadIdx.x; b < 4 * BINS; b += RS_THREADS) (&wc[0][0])[b] = 0;
     // digit bases: exclusive scan of the per-digit totals (thread t owns digits t*PER .. t*PER+PER-1)
@@ -227,20 +250,21 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
     }
     __syncthreads();
 
-    uint32_t k_[RS_ITEMS], meta[RS_ITEMS];  // meta = digit | rank_in_wave_digit << DBITS
+    uint32_t k_[RS_ITEMS], meta[RS_ITEMS];  // meta = digit | rank_in_wave_digit << DBITS, 0xffffffff = no item
+    __shared__ uint32_t s_tile_items;
     V v_[RS_ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;
-        const bool valid = li < nvalid;
+        bool valid = li < nvalid;
         uint32_t key = 0xffffffffu;
         V val{};
         if (valid) { key = keys_in[tile_base + li]; val = vals_in[tile_base + li]; }
-        // invalid tail items take the last digit: being last in input order they rank
-        // after every valid item and are simply not written out
-        const uint32_t d = valid ? ((key >> shift) & MASK) : MASK;
-        unsigned long long m = ~0ull;
+        if (SKIP) valid = valid && key != 0xffffffffu;   // compacting pass: sentinel items do not exist
+        // items that do not exist neither rank nor count nor get written
+        const uint32_t d = (key >> shift) & MASK;
+        unsigned long long m = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < DBITS; ++b) {
             const bool bit = (d >> b) & 1u;
@@ -250,14 +274,14 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
         const uint32_t rank = (uint32_t)__builtin_popcountll(m & lt_mask);
         const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
         uint32_t prev = 0;
-        if (rank == 0) {  // lowest lane of each digit group owns the counter update
+        if (valid && rank == 0) {  // lowest lane of each digit group owns the counter update
             prev = wc[wave][d];
             wc[wave][d] = prev + cnt;
         }
-        const int leader = __builtin_ctzll(m);
+        const int leader = m ? __builtin_ctzll(m) : 0;
         prev = __shfl(prev, leader, 64);
         k_[r] = key; v_[r] = val;
-        meta[r] = d | ((prev + rank) << DBITS);
+        meta[r] = valid ? (d | ((prev + rank) << DBITS)) : 0xffffffffu;
     }
     __syncthreads();
     {   // thread t owns digits t*PER..: wave bases, digit totals in this tile, local digit bases
@@ -272,6 +296,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
         }
         uint32_t tot;
         uint32_t ex = block_excl_scan_256(tsum, s_wave, &tot);
+        if (threadIdx.x == 0) s_tile_items = tot;   // items of this tile that exist
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int d = threadIdx.x * PER + k;
@@ -284,16 +309,18 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
+        if (meta[r] == 0xffffffffu) continue;
         const uint32_t d = meta[r] & MASK;
         const uint32_t lp = dbase[d] + wc[wave][d] + (meta[r] >> DBITS);
         skeys[lp] = k_[r];
         svals[lp] = v_[r];
     }
     __syncthreads();
+    const uint32_t tile_items = s_tile_items;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const uint32_t j = r * RS_THREADS + threadIdx.x;
-        if (j < nvalid) {
+        if (j < tile_items) {
             const uint32_t key = skeys[j];
             const uint32_t pos = gadj[(key >> shift) & MASK] + j;
             keys_out[pos] = key;

@@ -57,7 +57,8 @@ DEBUG_RECORD_DTYPE = np.dtype([(n, np.float32) for n in
 class GSplatRenderContext(C.Structure):
     _fields_ = [("obj_view", C.c_float * 16), ("object", C.c_float * 16), ("inv_object", C.c_float * 16),
                 ("view", C.c_float * 16), ("proj", C.c_float * 16), ("width", C.c_int32), ("height", C.c_int32),
-                ("target", C.c_void_p), ("target_is_device", C.c_int32)]
+                ("target", C.c_void_p), ("target_is_device", C.c_int32),
+                ("depth", C.c_void_p), ("depth_is_device", C.c_int32)]
 
 
 OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE, OPT_SUPER_TILE, OPT_DEBUG_FLAGS, OPT_FRAMES_IN_FLIGHT = 1, 2, 3, 4, 5, 6
@@ -115,7 +116,7 @@ def load_library() -> C.CDLL:
     L.gsr_stats_reset.argtypes = [vp]
     L.gsr_set_option.argtypes = [vp, i32, i32]
     L.gsr_debug_read_records.argtypes = [vp, vp, i64]
-    L.gsr_debug_read_depth_order.argtypes = [vp, vp, i64]
+    L.gsr_debug_read_depth_order.argtypes = [vp, vp, i64, C.POINTER(C.c_int64)]
     L.gsr_debug_read_tile_lists.argtypes = [vp, vp, vp, i64, vp, i64]
     L.gsr_debug_sort_pairs.argtypes = [vp, vp, vp, i64, i32]
     L.gsr_debug_read_tile_work.argtypes = [vp, vp, i64]
@@ -311,9 +312,11 @@ class Engine:
         return out
 
     def debug_depth_order(self, n: int) -> np.ndarray:
+        """indices of the splats that survived culling, nearest first"""
         out = np.zeros(n, dtype=np.int32)
-        _check(self.L.gsr_debug_read_depth_order(self.h, out.ctypes.data, n))
-        return out
+        cnt = C.c_int64()
+        _check(self.L.gsr_debug_read_depth_order(self.h, out.ctypes.data, n, C.byref(cnt)))
+        return out[:cnt.value]
 
     def debug_tile_lists(self):
         """per-SUPER-tile [start, end) + the depth-ordered splat list of the last frame"""

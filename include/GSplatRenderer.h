@@ -49,6 +49,9 @@ typedef struct GSplatRenderContext {
     int32_t width, height;/* glH_ScreenSize      */
     float* target;        /* RGBA-f32 premultiplied, row 0 = bottom; height*width*4 floats */
     int32_t target_is_device;
+    const float* depth;   /* optional: window depth (0..1, row 0 = bottom) left by the opaque pass; the splats are
+                             depth-tested against it with depth writes off (src/GSplatRenderer.C:595-610); NULL = none */
+    int32_t depth_is_device;
 } GSplatRenderContext;
 
 #ifdef __cplusplus

@@ -149,8 +149,10 @@ int  gsr_stats_reset(gsr_context* ctx);
 /* ---- knobs (performance only; never change pixels) ---------------------- */
 #define GSR_OPT_XCD_SWIZZLE     1   /* 0/1: XCD-aware tile -> workgroup mapping in the blend kernel */
 #define GSR_OPT_STAGE_TIMING    2   /* 0/1: record per-stage HIP events (default 1) */
-#define GSR_OPT_SORT_CACHE      3   /* 0/1: skip the depth sort when cam_pos and geometry are unchanged
-                                       (argsortByDistance's caching, src/GSplatRenderer.C:179-186) */
+#define GSR_OPT_SORT_CACHE      3   /* 0/1: skip the depth sort when the frame description (camera, shard, geometry) is
+                                       unchanged -- argsortByDistance's caching (src/GSplatRenderer.C:179-186) for the case
+                                       that matters, a static viewport redraw; the sorted list holds only the splats visible
+                                       to the camera that sorted, so a pure rotation re-sorts */
 #define GSR_OPT_SUPER_TILE      4   /* super-tile edge in tiles: 0 = auto (smallest power of two giving
                                        <= 256 super-tiles), or 1,2,4,8,16 */
 #define GSR_OPT_FRAMES_IN_FLIGHT 6  /* 1 or 2 (default 2): with 2, frame f+1's memory-bound front end
@@ -168,7 +170,9 @@ typedef struct gsr_debug_record {
     int32_t visible;   /* 0 = culled */
 } gsr_debug_record;
 int  gsr_debug_read_records(gsr_context* ctx, gsr_debug_record* out, int64_t n);
-int  gsr_debug_read_depth_order(gsr_context* ctx, int32_t* perm, int64_t n);
+/* depth order (nearest first) of the splats that survived culling in the last frame; writes min(cap, count)
+ * indices and the count */
+int  gsr_debug_read_depth_order(gsr_context* ctx, int32_t* perm, int64_t cap, int64_t* n_sorted);
 /* per-SUPER-tile [start,end) into the sorted pair list + the list itself (splat indices);
  * n_lists = stiles_x*stiles_y, n_pairs = pairs_total of the last frame */
 int  gsr_debug_read_tile_lists(gsr_context* ctx, int32_t* list_start, int32_t* list_end, int64_t n_lists,

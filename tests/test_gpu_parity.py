@@ -47,10 +47,10 @@ def test_records_bit_exact(pkg, oracle, engine):
     engine.render(cam)
     dev = engine.debug_records(splats.n)
     ref = oracle.preprocess(splats, cam, origin=(0.25, -0.5, 0.125))
-    # keys: every splat, bit exact
-    assert np.array_equal(dev["key"].view(np.uint32), ref["key"].view(np.uint32))
     vis = dev["visible"] == 1
     assert vis.sum() > 1000
+    # sort keys of every splat that survived culling, bit exact (culled splats are dropped before the sort)
+    assert np.array_equal(dev["key"][vis].view(np.uint32), ref["key"][vis].view(np.uint32))
     assert (ref["visible"][vis] == 1).all()        # device culls a superset of what the oracle culls
     for f in REC_FIELDS:
         a, b = dev[f][vis].view(np.uint32), ref[f][vis].view(np.uint32)
@@ -66,9 +66,13 @@ def test_depth_order_matches_oracle(pkg, oracle, engine):
     cam = pkg.camera.make_camera(256, 256, sh_order=0, frame=9)
     engine.upload(splats)
     engine.render(cam)
-    dev = engine.debug_depth_order(splats.n)
-    ref = oracle.host_sort_only(splats.P, cam.cam_pos)
-    assert np.array_equal(dev, ref)
+    dev = engine.debug_depth_order(splats.n)          # the splats that survived culling, nearest first
+    ref = oracle.host_sort_only(splats.P, cam.cam_pos)  # all splats, (distance^2, index) ascending
+    assert dev.shape[0] > 0.9 * splats.n
+    keep = np.zeros(splats.n, bool)
+    keep[dev] = True
+    assert np.array_equal(dev, ref[keep[ref]])
+    assert keep[1000:1100].sum() > 80 and keep[2000:2100].sum() > 80   # the exact ties are in play
 
 
 @pytest.mark.parametrize("n,bits", [(0, 32), (1, 32), (63, 8), (4096, 32), (4097, 13), (250001, 32), (1 << 20, 16)])

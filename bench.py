@@ -202,7 +202,7 @@ def main():
     # algorithmic bytes of k_blend: 8 B per list entry scanned + 48 B per record gathered + one RGBA-f32 store per pixel
     bytes_blend = pair_b * scanned + rec_b * d_eff + 16.0 * own_px
     achieved = bytes_blend / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
-    # HBM traffic of k_blend per launch from the PMC pass of this same command (scripts_gpu_pmc.sh ->
+    # HBM traffic of k_blend per launch from the PMC pass of this same command (tools/gpu_pmc.sh ->
     # profiles/pmc_traffic.json; 2*FETCH_SIZE + WRITE_SIZE as the MI355X guide prescribes); null if absent
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (GPU box, repo root): bash scripts_gpu_pmc.sh <tag> [bench args...]
+# Usage (GPU box, repo root): bash tools/gpu_pmc.sh <tag> [bench args...]
 # PMC counters per kernel, one rocprofv3 pass per counter group (never combined with tracing
 # domains other than --kernel-trace).  Summaries -> gpurun_out/pmc_<tag>/summary.txt
 set -u
@@ -24,6 +24,6 @@ for GROUP in \
   if [ -n "$f" ]; then cp "$f" "$OUT/pass$i.csv"; else echo "pass $i produced no counter csv" ; tail -5 "$OUT/pass$i.log"; fi
 done
 cd "$REPO"
-python scripts_pmc_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
+python tools/pmc_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
 rm -f "$OUT"/pass*.csv    # raw per-dispatch dumps are large; the summary is what is kept

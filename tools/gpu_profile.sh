@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (on the GPU box, from the repo root): bash scripts_gpu_profile.sh <tag> [bench args...]
+# Usage (on the GPU box, from the repo root): bash tools/gpu_profile.sh <tag> [bench args...]
 # Runs bench.py un-profiled, then under rocprofv3 --kernel-trace --stats, and leaves the
 # summaries in gpurun_out/prof_<tag>/ (copy what should be judged into profiles/).
 set -u

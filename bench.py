@@ -220,6 +220,14 @@ def main():
         "super_tile": st["super_tile"],
         "note": "k_blend is VALU/LDS-bound at 16x16 tiles (DESIGN.md); HBM fraction reported as the metric asks",
     }
+    # the bound that actually binds k_blend: FP32 vector issue.  One pixel evaluation of one record is 47 FLOP
+    # (fma = 2: 2 sub, rotate 6, scale 2, power 3, contract-exp 20, opacity+clamp 2, under-blend 12), counted
+    # per 64-lane wave evaluation by the kernel itself (lanes outside the quad execute the same instructions)
+    wave_evals = st["blend_wave_evals_total"] / launches
+    valu_tflops = wave_evals * 64 * 47.0 / (blend_ms * 1e-3) / 1e12 if blend_ms > 0 else 0.0
+    roofline["valu"] = {"bound": "fp32 vector", "achieved": valu_tflops, "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": valu_tflops / 157.3, "wave_record_evals_per_launch": wave_evals,
+                        "flop_per_pixel_eval": 47}
     stages = {k: st[k] for k in ("ms_preprocess", "ms_depth_sort", "ms_emit", "ms_tile_sort", "ms_blend", "ms_total")}
 
     if rank == 0:

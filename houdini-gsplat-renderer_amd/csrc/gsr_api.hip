@@ -80,7 +80,7 @@ struct FrameSlot {
     uint2 *pvA = nullptr, *pvB = nullptr;        // pair payload: (splat index, packed tile rect)
     size_t pair_cap = 0;
     int32_t *sstart = nullptr, *send = nullptr;  // super-tile ranges
-    uint2* tile_work = nullptr;        // per tile: entries scanned, records gathered
+    uint4* tile_work = nullptr;        // per tile: entries scanned, records gathered, wave-record evaluations
     size_t tile_cap = 0;
     float* fb = nullptr;               // staging for host-pointer output
     size_t fb_cap = 0;
@@ -863,7 +863,7 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
     c->frame_no += 1;
     sl.frame_id = c->frame_no;
     // counters of this frame travel with the stream; they are read in gsr_get_stats
-    HIP_TRY(hipMemcpyAsync(sl.h_counters, sl.counters, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(sl.h_counters, sl.counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     sl.h_counters[6] = 0;
     HIP_TRY(hipMemcpyAsync(&sl.h_counters[6], sl.d_n, 4, hipMemcpyDeviceToHost, s));   // visible splats of this frame
     if (!out_is_device) {
@@ -915,14 +915,16 @@ extern "C" int gsr_get_stats(gsr_context* c, gsr_stats* out)
         c->st.stiles_x = sl.stiles_x;
         c->st.stiles_y = sl.stiles_y;
         // running totals live per slot
-        int64_t rec_tot = 0, ent_tot = 0;
+        int64_t rec_tot = 0, ent_tot = 0, ev_tot = 0;
         for (int k = 0; k < GSR_MAX_SLOTS; ++k) {
             if (!c->slot[k].frame_id) continue;
             rec_tot += (int64_t)c->slot[k].h_counters[2];
             ent_tot += (int64_t)c->slot[k].h_counters[4];
+            ev_tot += (int64_t)c->slot[k].h_counters[5];
         }
         c->st.blend_pairs_consumed_total = rec_tot;
         c->st.blend_entries_scanned_total = ent_tot;
+        c->st.blend_wave_evals_total = ev_tot;
     }
     *out = c->st;
     return GSR_OK;
@@ -1035,7 +1037,7 @@ extern "C" int gsr_debug_read_tile_work(gsr_context* c, uint32_t* scanned_fetche
     FrameSlot* sl = latest_slot(c);
     if (!sl || n_tiles != (int64_t)sl->last_tiles_x * sl->last_local_ty)
         return set_err(GSR_E_INVALID, "gsr_debug_read_tile_work: expected %d tiles", sl ? sl->last_tiles_x * sl->last_local_ty : 0);
-    if (n_tiles) HIP_TRY(hipMemcpy(scanned_fetched, sl->tile_work, (size_t)n_tiles * 8, hipMemcpyDeviceToHost));
+    if (n_tiles) HIP_TRY(hipMemcpy2D(scanned_fetched, 8, sl->tile_work, 16, 8, (size_t)n_tiles, hipMemcpyDeviceToHost));
     return GSR_OK;
 }
 

@@ -52,7 +52,7 @@ struct GsrBlendArgs {
 __global__ void __launch_bounds__(256)
 k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __restrict__ svals,
         const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
-        const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint2* __restrict__ tile_work,
+        const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint4* __restrict__ tile_work,
         const float* __restrict__ zwin, const float* __restrict__ depth)
 {
     __shared__ float4 s0[BL_ROUND];   // cx, cy, ex, ey
@@ -62,7 +62,7 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
     __shared__ uint32_t q[BL_QCAP];   // hit queue: splat indices in list (= depth) order
     __shared__ uint32_t scnt[2][BL_SCAN_K][4];
     __shared__ uint32_t sdone[2][4];
-    __shared__ uint32_t sfetched;
+    __shared__ uint32_t sfetched, sevals;
 
     // Workgroup b runs on XCD b%8 (observed dispatch order, MI355X guide): tile_map hands each
     // XCD whole super-tiles, whose 64 tiles read the same list and gather the same records.
@@ -77,7 +77,8 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     // tile bounds in pixel-centre coordinates, for the quadrant masks
     const float tcx0 = (float)(tx * GSR_TILE_PX) + 0.5f, tcy0 = (float)(gty * GSR_TILE_PX) + 0.5f;
-    if (tid == 0) sfetched = 0;
+    if (tid == 0) { sfetched = 0; sevals = 0; }
+    uint32_t my_evals = 0;            // (wave-uniform) records this wave evaluated for its 64 pixels
     // depth test against what the opaque pass left (depth writes stay off): a fragment survives iff its quad's
     // window depth <= depth[pixel] (src/GSplatRenderer.C:595-610).  No depth buffer = +inf.
     const float dpx = (depth && pix_ok) ? depth[(size_t)py * a.width + px] : __builtin_inff();
@@ -225,6 +226,7 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
                     const bool two = acc != 0ull;
                     const int jb = two ? j0 + __builtin_ctzll(acc) : ja;
                     acc &= acc - 1;   // no-op when acc == 0
+                    my_evals += two ? 2u : 1u;
                     const float4 a0 = s0[ja], a1 = s1[ja], a2 = s2[ja];
                     const float4 b0 = s0[jb], b1 = s1[jb], b2 = s2[jb];
                     const gsr_v2f dx = (gsr_v2f)(fx) - (gsr_v2f){a0.x, b0.x};
@@ -271,35 +273,36 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) my_fetched += __shfl_down(my_fetched, d, 64);
     __syncthreads();  // orders the sfetched = 0 store when the list was empty
-    if (lane == 0) atomicAdd(&sfetched, my_fetched);
+    if (lane == 0) { atomicAdd(&sfetched, my_fetched); atomicAdd(&sevals, my_evals); }
     __syncthreads();
     if (tid == 0) {
         // entries actually read: everything up to scan_pos plus the prefetched step
         const int rd = scan_pos + BL_SCAN_K * 256;
-        tile_work[tile] = make_uint2((uint32_t)(rd < n ? rd : n), sfetched);
+        tile_work[tile] = make_uint4((uint32_t)(rd < n ? rd : n), sfetched, sevals, 0u);
     }
 }
 
-// One workgroup sums the per-tile bookkeeping into counters[1] (records gathered, this
-// frame), counters[2] (records, running total), counters[3] (entries scanned, this frame),
-// counters[4] (entries, running total) -- a handful of atomics per frame instead of per tile
-// (same-address atomics serialise at ~12 ns each on MI355X).
+// One workgroup sums the per-tile bookkeeping into counters[1] (records gathered, this frame),
+// [2] (records, running total), [3] (entries scanned, this frame), [4] (entries, running total),
+// [5] (wave-record evaluations, running total) -- a handful of atomics per frame instead of per
+// tile (same-address atomics serialise at ~12 ns each on MI355X).
 __global__ void __launch_bounds__(256)
-k_sum_work(const uint2* __restrict__ tile_work, int n_tiles, unsigned long long* __restrict__ counters)
+k_sum_work(const uint4* __restrict__ tile_work, int n_tiles, unsigned long long* __restrict__ counters)
 {
-    __shared__ unsigned long long s_sum[2];
-    if (threadIdx.x < 2) s_sum[threadIdx.x] = 0;
+    __shared__ unsigned long long s_sum[3];
+    if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
     __syncthreads();
-    unsigned long long sc = 0, fe = 0;
-    for (int i = threadIdx.x; i < n_tiles; i += 256) { const uint2 w = tile_work[i]; sc += w.x; fe += w.y; }
+    unsigned long long sc = 0, fe = 0, ev = 0;
+    for (int i = threadIdx.x; i < n_tiles; i += 256) { const uint4 w = tile_work[i]; sc += w.x; fe += w.y; ev += w.z; }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); }
+    for (int d = 32; d > 0; d >>= 1) { sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); atomicAdd(&s_sum[2], ev); }
     __syncthreads();
     if (threadIdx.x == 0) {
         counters[1] = s_sum[1];
         atomicAdd(&counters[2], s_sum[1]);
         counters[3] = s_sum[0];
         atomicAdd(&counters[4], s_sum[0]);
+        atomicAdd(&counters[5], s_sum[2]);
     }
 }

@@ -78,6 +78,7 @@ typedef struct gsr_stats {
     int32_t super_tile;                    /* super-tile edge in tiles */
     int32_t stiles_x, stiles_y;            /* super-tile grid (whole image) */
     int32_t reserved_;
+    int64_t blend_wave_evals_total;        /* (wave, record) evaluations by the blend kernel = 64 pixel evaluations each, running total */
 } gsr_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */

@@ -29,6 +29,7 @@
 #include "k_blend.h"
 #include "k_preprocess.h"
 #include "k_sort.h"
+#include "k_wire.h"
 
 #define GSR_VERSION_STR "gsplat_hip 0.1.0 (gfx950)"
 #define GSR_MAX_SLOTS 2
@@ -873,6 +874,41 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
     // results are ordered on the public stream: anything the caller queues there next sees this frame
     HIP_TRY(hipEventRecord(sl.ev_done, s));
     HIP_TRY(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
+    return GSR_OK;
+}
+
+// Wireframe overlay: synchronous, not on the per-frame beauty path.
+extern "C" int gsr_render_wire(gsr_context* c, const gsr_camera* cam, float* rgba_out, int out_is_device)
+{
+    if (!c || !cam || !rgba_out) return set_err(GSR_E_INVALID, "gsr_render_wire: NULL argument");
+    if (c->uploading) return set_err(GSR_E_INVALID, "gsr_render_wire: upload in progress");
+    if (cam->width <= 0 || cam->height <= 0 || cam->width > GSR_MAX_DIM || cam->height > GSR_MAX_DIM)
+        return set_err(GSR_E_INVALID, "gsr_render_wire: bad framebuffer size %dx%d", cam->width, cam->height);
+    if (c->geo_gen == 0) return set_err(GSR_E_NO_GEOMETRY, "gsr_render_wire: nothing uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    hipStream_t s = c->slot[0].stream;
+    GsrFrame f;
+    build_frame(c, cam, &f);
+    const size_t npix = (size_t)cam->width * cam->height;
+    unsigned long long* zbuf = nullptr;
+    float* dout = nullptr;
+    if ((rc = dev_alloc(&zbuf, npix))) return rc;
+    if (!out_is_device && (rc = dev_alloc(&dout, npix * 4))) { dev_free(zbuf); return rc; }
+    float* target = out_is_device ? rgba_out : dout;
+    hipError_t e = hipMemsetAsync(zbuf, 0xff, npix * 8, s);
+    if (e == hipSuccess && c->n > 0)
+        hipLaunchKernelGGL(k_wire_splats, dim3(div_up(c->n, 256)), dim3(256), 0, s, c->n, f, c->geoA, c->geoB, zbuf);
+    if (e == hipSuccess)
+        hipLaunchKernelGGL(k_wire_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, zbuf, npix, c->col,
+                           reinterpret_cast<float4*>(target));
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess && !out_is_device) e = hipMemcpyAsync(rgba_out, dout, npix * 16, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    dev_free(zbuf);
+    dev_free(dout);
+    if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_render_wire: %s", hipGetErrorString(e));
     return GSR_OK;
 }
 

@@ -89,6 +89,90 @@ __device__ __forceinline__ float lin3(const float* m, float x, float y, float z)
     return gsr_fma(m[0], x, gsr_fma(m[1], y, m[2] * z));
 }
 
+// Covariance chain shared by the beauty path (K1) and the wireframe overlay: Sigma = M^T M with
+// M = diag(scale) R(q)^T Obj^T, EWA projection with the view matrix (+0.3 low-pass), eigen-decomposition
+// -> unit major axis e and the two axis lengths (shaders/GSplatShaderCoreLib.h:10-93).  obm = mat3 of the
+// object matrix (rows), or the identity for the wire program, which never applies it.
+__device__ __forceinline__ void gsr_covariance_axes(const GsrFrame& f, const float* obm, float x, float y, float z,
+                                                    float sx, float sy, float sz, float qi, float qj, float qk,
+                                                    float qr, float& ex, float& ey, float& s1, float& s2)
+{
+    float R[3][3];
+    R[0][0] = 1.0f - 2.0f * gsr_fma(qj, qj, qk * qk);
+    R[0][1] = 2.0f * gsr_fma(qi, qj, -(qr * qk));
+    R[0][2] = 2.0f * gsr_fma(qi, qk, qr * qj);
+    R[1][0] = 2.0f * gsr_fma(qi, qj, qr * qk);
+    R[1][1] = 1.0f - 2.0f * gsr_fma(qi, qi, qk * qk);
+    R[1][2] = 2.0f * gsr_fma(qj, qk, -(qr * qi));
+    R[2][0] = 2.0f * gsr_fma(qi, qk, -(qr * qj));
+    R[2][1] = 2.0f * gsr_fma(qj, qk, qr * qi);
+    R[2][2] = 1.0f - 2.0f * gsr_fma(qi, qi, qj * qj);
+    const float sc[3] = {sx, sy, sz};
+    float M0[3][3], Mm[3][3], S[3][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) M0[p][q] = sc[p] * R[q][p];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            Mm[p][q] = gsr_fma(M0[p][2], obm[q * 3 + 2], gsr_fma(M0[p][1], obm[q * 3 + 1], M0[p][0] * obm[q * 3 + 0]));
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = p; q < 3; ++q) {
+            float v = gsr_fma(Mm[2][p], Mm[2][q], gsr_fma(Mm[1][p], Mm[1][q], Mm[0][p] * Mm[0][q]));
+            S[p][q] = v;
+            S[q][p] = v;
+        }
+
+    float tx = aff4(&f.vw[0], x, y, z);
+    float ty = aff4(&f.vw[4], x, y, z);
+    const float tz = aff4(&f.vw[8], x, y, z);
+    {
+        float rx = tx / tz, ry = ty / tz;
+        rx = __builtin_fminf(__builtin_fmaxf(rx, -f.limx), f.limx);
+        ry = __builtin_fminf(__builtin_fmaxf(ry, -f.limy), f.limy);
+        tx = rx * tz;
+        ty = ry * tz;
+    }
+    const float j00 = f.focal / tz;
+    const float tz2 = tz * tz;
+    const float j02 = -(f.focal * tx) / tz2;
+    const float j12 = -(f.focal * ty) / tz2;
+    float A0[3], A1[3], u0[3], u1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        A0[c] = gsr_fma(j00, f.vw[0 * 4 + c], j02 * f.vw[2 * 4 + c]);
+        A1[c] = gsr_fma(j00, f.vw[1 * 4 + c], j12 * f.vw[2 * 4 + c]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        u0[k] = gsr_fma(S[k][2], A0[2], gsr_fma(S[k][1], A0[1], S[k][0] * A0[0]));
+        u1[k] = gsr_fma(S[k][2], A1[2], gsr_fma(S[k][1], A1[1], S[k][0] * A1[0]));
+    }
+    const float cov00 = gsr_fma(A0[2], u0[2], gsr_fma(A0[1], u0[1], A0[0] * u0[0]));
+    const float cov01 = gsr_fma(A0[2], u1[2], gsr_fma(A0[1], u1[1], A0[0] * u1[0]));
+    const float cov11 = gsr_fma(A1[2], u1[2], gsr_fma(A1[1], u1[1], A1[0] * u1[0]));
+    const float ca = cov00 + 0.3f, cb = cov01, cc = cov11 + 0.3f;
+
+    const float mid = 0.5f * (ca + cc);
+    const float hd = (ca - cc) * 0.5f;
+    const float radius = __builtin_sqrtf(gsr_fma(hd, hd, cb * cb));
+    const float lambda1 = mid + radius;
+    const float lambda2 = __builtin_fmaxf(mid - radius, 0.1f);
+    const float dvx = cb, dvy = lambda1 - ca;
+    const float dlen = __builtin_sqrtf(gsr_fma(dvx, dvx, dvy * dvy));
+    ex = 1.0f; ey = 0.0f;
+    if (dlen > 0.0f) {
+        ex = dvx / dlen;
+        ey = dvy / dlen;
+    }
+    s1 = __builtin_fminf(__builtin_sqrtf(2.0f * lambda1), 4096.0f);
+    s2 = __builtin_fminf(__builtin_sqrtf(2.0f * lambda2), 4096.0f);
+}
+
 // K1: one thread per splat.
 //   in : geoA, geoB, col (SoA, coalesced 16 B/lane)
 //   out: rec[i] (48 B), key[i] (f32 distance^2 bits), val[i] = (i, rect), rect[i] (packed tile rect or EMPTY)
@@ -160,80 +244,8 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
             const float qi = gsr_h2f(b.y >> 16), qj = gsr_h2f(b.z & 0xffffu), qk = gsr_h2f(b.z >> 16);
             const float qr = gsr_h2f(b.w & 0xffffu);
 
-            float R[3][3];
-            R[0][0] = 1.0f - 2.0f * gsr_fma(qj, qj, qk * qk);
-            R[0][1] = 2.0f * gsr_fma(qi, qj, -(qr * qk));
-            R[0][2] = 2.0f * gsr_fma(qi, qk, qr * qj);
-            R[1][0] = 2.0f * gsr_fma(qi, qj, qr * qk);
-            R[1][1] = 1.0f - 2.0f * gsr_fma(qi, qi, qk * qk);
-            R[1][2] = 2.0f * gsr_fma(qj, qk, -(qr * qi));
-            R[2][0] = 2.0f * gsr_fma(qi, qk, -(qr * qj));
-            R[2][1] = 2.0f * gsr_fma(qj, qk, qr * qi);
-            R[2][2] = 1.0f - 2.0f * gsr_fma(qi, qi, qj * qj);
-            const float sc[3] = {sx, sy, sz};
-            float M0[3][3], Mm[3][3], S[3][3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) M0[p][q] = sc[p] * R[q][p];
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    Mm[p][q] = gsr_fma(M0[p][2], f.ob[q * 3 + 2], gsr_fma(M0[p][1], f.ob[q * 3 + 1], M0[p][0] * f.ob[q * 3 + 0]));
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int q = p; q < 3; ++q) {
-                    float v = gsr_fma(Mm[2][p], Mm[2][q], gsr_fma(Mm[1][p], Mm[1][q], Mm[0][p] * Mm[0][q]));
-                    S[p][q] = v;
-                    S[q][p] = v;
-                }
-
-            float tx = aff4(&f.vw[0], x, y, z);
-            float ty = aff4(&f.vw[4], x, y, z);
-            const float tz = aff4(&f.vw[8], x, y, z);
-            {
-                float rx = tx / tz, ry = ty / tz;
-                rx = __builtin_fminf(__builtin_fmaxf(rx, -f.limx), f.limx);
-                ry = __builtin_fminf(__builtin_fmaxf(ry, -f.limy), f.limy);
-                tx = rx * tz;
-                ty = ry * tz;
-            }
-            const float j00 = f.focal / tz;
-            const float tz2 = tz * tz;
-            const float j02 = -(f.focal * tx) / tz2;
-            const float j12 = -(f.focal * ty) / tz2;
-            float A0[3], A1[3], u0[3], u1[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                A0[c] = gsr_fma(j00, f.vw[0 * 4 + c], j02 * f.vw[2 * 4 + c]);
-                A1[c] = gsr_fma(j00, f.vw[1 * 4 + c], j12 * f.vw[2 * 4 + c]);
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                u0[k] = gsr_fma(S[k][2], A0[2], gsr_fma(S[k][1], A0[1], S[k][0] * A0[0]));
-                u1[k] = gsr_fma(S[k][2], A1[2], gsr_fma(S[k][1], A1[1], S[k][0] * A1[0]));
-            }
-            const float cov00 = gsr_fma(A0[2], u0[2], gsr_fma(A0[1], u0[1], A0[0] * u0[0]));
-            const float cov01 = gsr_fma(A0[2], u1[2], gsr_fma(A0[1], u1[1], A0[0] * u1[0]));
-            const float cov11 = gsr_fma(A1[2], u1[2], gsr_fma(A1[1], u1[1], A1[0] * u1[0]));
-            const float ca = cov00 + 0.3f, cb = cov01, cc = cov11 + 0.3f;
-
-            const float mid = 0.5f * (ca + cc);
-            const float hd = (ca - cc) * 0.5f;
-            const float radius = __builtin_sqrtf(gsr_fma(hd, hd, cb * cb));
-            const float lambda1 = mid + radius;
-            const float lambda2 = __builtin_fmaxf(mid - radius, 0.1f);
-            const float dvx = cb, dvy = lambda1 - ca;
-            const float dlen = __builtin_sqrtf(gsr_fma(dvx, dvx, dvy * dvy));
-            float ex = 1.0f, ey = 0.0f;
-            if (dlen > 0.0f) {
-                ex = dvx / dlen;
-                ey = dvy / dlen;
-            }
-            const float s1 = __builtin_fminf(__builtin_sqrtf(2.0f * lambda1), 4096.0f);
-            const float s2 = __builtin_fminf(__builtin_sqrtf(2.0f * lambda2), 4096.0f);
+            float ex, ey, s1, s2;
+            gsr_covariance_axes(f, f.ob, x, y, z, sx, sy, sz, qi, qj, qk, qr, ex, ey, s1, s2);
             // conservative bbox of the part of the quad where alpha can reach 1/255 (|q| <= rq <= 2)
             const float rq = (f.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius(opacity);
             const float hx = gsr_fma(rq * gsr_fma(s1, __builtin_fabsf(ex), s2 * __builtin_fabsf(ey)), 1.0001f, 0.01f);

@@ -68,7 +68,7 @@ OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE, OPT_SUPER_TILE, OPT_DEBUG_FLA
 C_ABI_SYMBOLS = [
     "gsr_device_count", "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_version", "gsr_set_stream",
     "gsr_upload_begin", "gsr_upload_append", "gsr_upload_end", "gsr_upload", "gsr_set_row_shard", "gsr_band_rows",
-    "gsr_stitch_bands", "gsr_render", "gsr_render_depth", "gsr_synchronize", "gsr_get_stats", "gsr_stats_reset", "gsr_set_option",
+    "gsr_stitch_bands", "gsr_render", "gsr_render_depth", "gsr_render_wire", "gsr_synchronize", "gsr_get_stats", "gsr_stats_reset", "gsr_set_option",
     "gsr_debug_read_records", "gsr_debug_read_depth_order", "gsr_debug_read_tile_lists", "gsr_debug_sort_pairs",
     "gsr_debug_read_tile_work",
     "gsplat_renderer_create", "gsplat_renderer_get_instance", "gsplat_renderer_destroy",
@@ -112,6 +112,7 @@ def load_library() -> C.CDLL:
     L.gsr_stitch_bands.argtypes = [vp, vp, i32, i32, i32, vp]
     L.gsr_render.argtypes = [vp, C.POINTER(gsr_camera), vp, i32]
     L.gsr_render_depth.argtypes = [vp, C.POINTER(gsr_camera), vp, i32, vp, i32]
+    L.gsr_render_wire.argtypes = [vp, C.POINTER(gsr_camera), vp, i32]
     L.gsr_synchronize.argtypes = [vp]
     L.gsr_get_stats.argtypes = [vp, C.POINTER(gsr_stats)]
     L.gsr_stats_reset.argtypes = [vp]
@@ -283,6 +284,13 @@ class Engine:
         d = np.ascontiguousarray(depth, dtype=np.float32).reshape(cam.height, cam.width)
         cs = camera_struct(cam)
         _check(self.L.gsr_render_depth(self.h, C.byref(cs), d.ctypes.data, 0, out.ctypes.data, 0))
+        return out
+
+    def render_wire(self, cam) -> np.ndarray:
+        """wireframe overlay (outlines of the +-2 quads, colour Cd), float32 [H, W, 4]"""
+        out = np.empty((cam.height, cam.width, 4), dtype=np.float32)
+        cs = camera_struct(cam)
+        _check(self.L.gsr_render_wire(self.h, C.byref(cs), out.ctypes.data, 0))
         return out
 
     def render_to_device(self, cam, device_ptr: int):

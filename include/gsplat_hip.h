@@ -143,6 +143,12 @@ int  gsr_render(gsr_context* ctx, const gsr_camera* cam, float* rgba_out, int ou
 int  gsr_render_depth(gsr_context* ctx, const gsr_camera* cam, const float* depth, int depth_is_device,
                       float* rgba_out, int out_is_device);
 
+/* Wireframe overlay (the reference's wire program, shaders/GSplatShaderSource.h:22-110 drawn in
+ * src/GR_GSplat.C:477-483): the outline of every splat's +-2 quad in colour Cd, alpha 1, nearest line wins,
+ * background 0.  Whole image (ignores the row shard), synchronous.  Like the reference's wire program it uses
+ * P without the GSplatOrigin round trip and no object matrix in the covariance. */
+int  gsr_render_wire(gsr_context* ctx, const gsr_camera* cam, float* rgba_out, int out_is_device);
+
 int  gsr_synchronize(gsr_context* ctx);
 int  gsr_get_stats(gsr_context* ctx, gsr_stats* out);     /* synchronizes the stream */
 int  gsr_stats_reset(gsr_context* ctx);

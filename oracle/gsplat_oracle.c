@@ -167,63 +167,13 @@ static float shade_sh_channel(float base, const float* sh, float x, float y, flo
     return fmaxf(res, 0.0f); /* max(res, vec3(0)) :178 */
 }
 
-/* Vertex stage for one splat.  Mirrors main() of the main vertex shader
- * (shaders/GSplatShaderSource.h:190-288) evaluated once per splat instead of
- * once per quad corner; the corner placement (:276-282) becomes the analytic
- * quad {c + qx*s1*e + qy*s2*e_perp, |qx|,|qy| <= 2} in GL window coordinates. */
-static void project_splat(const gso_splats* s, const gso_frame* f, int64_t i, gso_record* o)
+/* Covariance chain shared by the beauty path and the wireframe overlay.  use_object = 0 for the wire
+ * program, which never multiplies by transpose(mat3(glH_ObjectMatrix)) (shaders/GSplatShaderSource.h:75-77). */
+#define OB(r, c) (use_object ? M4(f->object, (r), (c)) : ((r) == (c) ? 1.0f : 0.0f))
+static void covariance_axes(const gso_frame* f, int use_object, float x, float y, float z, float sx, float sy, float sz,
+                            float qi, float qj, float qk, float qr, float* pex, float* pey, float* ps1, float* ps2)
 {
-    memset(o, 0, sizeof(*o));
-    const float W = (float)f->width, H = (float)f->height;
-
-    const float px = s->P[3 * i + 0], py = s->P[3 * i + 1], pz = s->P[3 * i + 2];
-
-    /* sort key: squared distance of the UN-offset point to the camera
-     * (src/GSplatRenderer.C:197-201, mySplatPoints :454) */
-    {
-        float dx = px - f->cam_pos[0], dy = py - f->cam_pos[1], dz = pz - f->cam_pos[2];
-        o->key = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-    }
-
-    /* texel 0 holds fl32(P - origin) (src/GSplatRenderer.C:459-461); the
-     * shader adds the origin back (shader :201-202) */
-    const float x = (px - f->origin[0]) + f->origin[0];
-    const float y = (py - f->origin[1]) + f->origin[1];
-    const float z = (pz - f->origin[2]) + f->origin[2];
-
-    /* centerViewPos / centerClipPos with the flip-Y sandwich (:204-207) */
-    const float tvx = aff(f->obj_view, 0, x, y, z);
-    const float tvy = aff(f->obj_view, 1, x, y, z);
-    const float tvz = aff(f->obj_view, 2, x, y, z);
-    const float ftvy = -tvy;
-    const float clx = aff(f->proj, 0, tvx, ftvy, tvz);
-    const float cly = aff(f->proj, 1, tvx, ftvy, tvz);
-    const float clz = aff(f->proj, 2, tvx, ftvy, tvz);
-    const float clw = aff(f->proj, 3, tvx, ftvy, tvz);
-
-    if (!(clw > 0.0f)) return; /* :209-214 behind camera */
-    /* all four corners share the centre's z,w (:277-279): GL near/far clip
-     * drops the whole quad iff z is outside [-w, w] (SURVEY 8a12) */
-    if (clz < -clw || clz > clw) return;
-
-    /* out_vertex.y = -out_vertex.y (:281) undoes the flip for the centre */
-    const float ndcx = clx / clw;
-    const float ndcy = (-cly) / clw;
-    o->cx = fmaf(ndcx, 0.5f, 0.5f) * W;
-    o->cy = fmaf(ndcy, 0.5f, 0.5f) * H;
-    /* every corner carries the centre's z and w: one window depth per quad (default depth range 0..1) */
-    o->zwin = fmaf(clz / clw, 0.5f, 0.5f);
-
-    /* attributes (:217-222); fp16 values are exact in fp32 */
-    const float sx = gso_half_to_float(s->scale[3 * i + 0]);
-    const float sy = gso_half_to_float(s->scale[3 * i + 1]);
-    const float sz = gso_half_to_float(s->scale[3 * i + 2]);
-    /* orient.wxyz -> rot (:230): rot.x = w (real), rot.yzw = xyz */
-    const float qi = gso_half_to_float(s->orient[4 * i + 0]);
-    const float qj = gso_half_to_float(s->orient[4 * i + 1]);
-    const float qk = gso_half_to_float(s->orient[4 * i + 2]);
-    const float qr = gso_half_to_float(s->orient[4 * i + 3]);
-
+    const float W = (float)f->width;
     /* CalcMatrixFromRotationScale (CoreLib :10-27): ms*mr with mr's COLUMNS
      * being the rows of the standard rotation matrix R(q); no normalisation */
     float R[3][3];
@@ -243,8 +193,8 @@ static void project_splat(const gso_splats* s, const gso_frame* f, int64_t i, gs
         for (int b = 0; b < 3; ++b) M0[a][b] = sc[a] * R[b][a];
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b)
-            Mm[a][b] = fmaf(M0[a][2], M4(f->object, b, 2),
-                            fmaf(M0[a][1], M4(f->object, b, 1), M0[a][0] * M4(f->object, b, 0)));
+            Mm[a][b] = fmaf(M0[a][2], OB(b, 2),
+                            fmaf(M0[a][1], OB(b, 1), M0[a][0] * OB(b, 0)));
     /* CalcCovariance3D (CoreLib :29-35): sigma = transpose(M) * M */
     float S[3][3];
     for (int a = 0; a < 3; ++a)
@@ -302,19 +252,80 @@ static void project_splat(const gso_splats* s, const gso_frame* f, int64_t i, gs
     const float lambda2 = fmaxf(mid - radius, 0.1f);
     const float dvx = cb, dvy = lambda1 - ca;
     const float dlen = sqrtf(fmaf(dvx, dvx, dvy * dvy));
-    float ex, ey;
     if (dlen > 0.0f) {
-        ex = dvx / dlen;
-        ey = dvy / dlen;
+        *pex = dvx / dlen;
+        *pey = dvy / dlen;
     } else { /* normalize(vec2(0)) is undefined in GLSL: choose the
                 mathematically right eigenvector of a diagonal matrix with a>=c */
-        ex = 1.0f;
-        ey = 0.0f;
+        *pex = 1.0f;
+        *pey = 0.0f;
     }
     /* The shader negates diagVec.y (:89) and later out_vertex.y (:281); the
      * two flips cancel in GL window coordinates, leaving axes s1*e, s2*e_perp. */
-    const float s1 = fminf(sqrtf(2.0f * lambda1), 4096.0f);
-    const float s2 = fminf(sqrtf(2.0f * lambda2), 4096.0f);
+    *ps1 = fminf(sqrtf(2.0f * lambda1), 4096.0f);
+    *ps2 = fminf(sqrtf(2.0f * lambda2), 4096.0f);
+}
+#undef OB
+
+/* Vertex stage for one splat.  Mirrors main() of the main vertex shader
+ * (shaders/GSplatShaderSource.h:190-288) evaluated once per splat instead of
+ * once per quad corner; the corner placement (:276-282) becomes the analytic
+ * quad {c + qx*s1*e + qy*s2*e_perp, |qx|,|qy| <= 2} in GL window coordinates. */
+static void project_splat(const gso_splats* s, const gso_frame* f, int64_t i, gso_record* o)
+{
+    memset(o, 0, sizeof(*o));
+    const float W = (float)f->width, H = (float)f->height;
+
+    const float px = s->P[3 * i + 0], py = s->P[3 * i + 1], pz = s->P[3 * i + 2];
+
+    /* sort key: squared distance of the UN-offset point to the camera
+     * (src/GSplatRenderer.C:197-201, mySplatPoints :454) */
+    {
+        float dx = px - f->cam_pos[0], dy = py - f->cam_pos[1], dz = pz - f->cam_pos[2];
+        o->key = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    }
+
+    /* texel 0 holds fl32(P - origin) (src/GSplatRenderer.C:459-461); the
+     * shader adds the origin back (shader :201-202) */
+    const float x = (px - f->origin[0]) + f->origin[0];
+    const float y = (py - f->origin[1]) + f->origin[1];
+    const float z = (pz - f->origin[2]) + f->origin[2];
+
+    /* centerViewPos / centerClipPos with the flip-Y sandwich (:204-207) */
+    const float tvx = aff(f->obj_view, 0, x, y, z);
+    const float tvy = aff(f->obj_view, 1, x, y, z);
+    const float tvz = aff(f->obj_view, 2, x, y, z);
+    const float ftvy = -tvy;
+    const float clx = aff(f->proj, 0, tvx, ftvy, tvz);
+    const float cly = aff(f->proj, 1, tvx, ftvy, tvz);
+    const float clz = aff(f->proj, 2, tvx, ftvy, tvz);
+    const float clw = aff(f->proj, 3, tvx, ftvy, tvz);
+
+    if (!(clw > 0.0f)) return; /* :209-214 behind camera */
+    /* all four corners share the centre's z,w (:277-279): GL near/far clip
+     * drops the whole quad iff z is outside [-w, w] (SURVEY 8a12) */
+    if (clz < -clw || clz > clw) return;
+
+    /* out_vertex.y = -out_vertex.y (:281) undoes the flip for the centre */
+    const float ndcx = clx / clw;
+    const float ndcy = (-cly) / clw;
+    o->cx = fmaf(ndcx, 0.5f, 0.5f) * W;
+    o->cy = fmaf(ndcy, 0.5f, 0.5f) * H;
+    /* every corner carries the centre's z and w: one window depth per quad (default depth range 0..1) */
+    o->zwin = fmaf(clz / clw, 0.5f, 0.5f);
+
+    /* attributes (:217-222); fp16 values are exact in fp32 */
+    const float sx = gso_half_to_float(s->scale[3 * i + 0]);
+    const float sy = gso_half_to_float(s->scale[3 * i + 1]);
+    const float sz = gso_half_to_float(s->scale[3 * i + 2]);
+    /* orient.wxyz -> rot (:230): rot.x = w (real), rot.yzw = xyz */
+    const float qi = gso_half_to_float(s->orient[4 * i + 0]);
+    const float qj = gso_half_to_float(s->orient[4 * i + 1]);
+    const float qk = gso_half_to_float(s->orient[4 * i + 2]);
+    const float qr = gso_half_to_float(s->orient[4 * i + 3]);
+
+    float ex, ey, s1, s2;
+    covariance_axes(f, 1, x, y, z, sx, sy, sz, qi, qj, qk, qr, &ex, &ey, &s1, &s2);
     o->ex = ex;
     o->ey = ey;
     o->is1 = 1.0f / s1;
@@ -586,6 +597,86 @@ int gso_render(const gso_splats* s, const gso_frame* f, float* rgba, int threads
     free(rec);
     free(perm);
     return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Wireframe overlay: shaders/GSplatShaderSource.h:22-110, geometry src/GR_GSplat.C:374-421.
+ * Line rule = the contract's stand-in for GL's diamond-exit rule (see k_wire.h / DESIGN.md).          */
+static void wire_edge(float x0, float y0, float x1, float y1, int width, int height, uint64_t frag, uint64_t* zbuf)
+{
+    const float dx = x1 - x0, dy = y1 - y0;
+    if (!(fabsf(dx) < 3.0e38f) || !(fabsf(dy) < 3.0e38f)) return;
+    const int xmajor = fabsf(dx) >= fabsf(dy);
+    const float m0 = xmajor ? x0 : y0, m1 = xmajor ? x1 : y1, n0 = xmajor ? y0 : x0;
+    const float dm = xmajor ? dx : dy, dn = xmajor ? dy : dx;
+    if (dm == 0.0f) return;
+    const float lo = fminf(m0, m1), hi = fmaxf(m0, m1);
+    const int mmax = (xmajor ? width : height) - 1, nmax = (xmajor ? height : width) - 1;
+    const float flo = ceilf(lo - 0.5f), fhi = ceilf(hi - 0.5f) - 1.0f;
+    if (!(fhi >= 0.0f && flo <= (float)mmax)) return;
+    const int i0 = (int)fmaxf(flo, 0.0f), i1 = (int)fminf(fhi, (float)mmax);
+    for (int i = i0; i <= i1; ++i) {
+        const float t = (((float)i + 0.5f) - m0) / dm;
+        const float nv = floorf(fmaf(t, dn, n0));
+        if (!(nv >= 0.0f && nv <= (float)nmax)) continue;
+        const int j = (int)nv;
+        const size_t pix = xmajor ? ((size_t)j * (size_t)width + (size_t)i) : ((size_t)i * (size_t)width + (size_t)j);
+        if (frag < zbuf[pix]) zbuf[pix] = frag;
+    }
+}
+
+int gso_render_wire(const gso_splats* s, const gso_frame* f, float* rgba)
+{
+    if (!s || !f || !rgba) return -1;
+    const int width = f->width, height = f->height;
+    const size_t npix = (size_t)width * (size_t)height;
+    uint64_t* zbuf = (uint64_t*)malloc(npix * 8 + 8);
+    if (!zbuf) return -2;
+    memset(zbuf, 0xff, npix * 8);
+    const float W = (float)width, H = (float)height;
+    for (int64_t i = 0; i < s->n; ++i) {
+        const float x = s->P[3 * i], y = s->P[3 * i + 1], z = s->P[3 * i + 2]; /* no origin offset here */
+        const float tvx = aff(f->obj_view, 0, x, y, z), tvy = aff(f->obj_view, 1, x, y, z), tvz = aff(f->obj_view, 2, x, y, z);
+        const float ftvy = -tvy;
+        const float clx = aff(f->proj, 0, tvx, ftvy, tvz), cly = aff(f->proj, 1, tvx, ftvy, tvz);
+        const float clz = aff(f->proj, 2, tvx, ftvy, tvz), clw = aff(f->proj, 3, tvx, ftvy, tvz);
+        if (!(clw > 0.0f) || clz < -clw || clz > clw) continue;
+        const float cx = fmaf(clx / clw, 0.5f, 0.5f) * W;
+        const float cy = fmaf((-cly) / clw, 0.5f, 0.5f) * H;
+        const float zw = fmaf(clz / clw, 0.5f, 0.5f);
+        const float sx = gso_half_to_float(s->scale[3 * i]), sy = gso_half_to_float(s->scale[3 * i + 1]),
+                    sz = gso_half_to_float(s->scale[3 * i + 2]);
+        const float qi = gso_half_to_float(s->orient[4 * i]), qj = gso_half_to_float(s->orient[4 * i + 1]),
+                    qk = gso_half_to_float(s->orient[4 * i + 2]), qr = gso_half_to_float(s->orient[4 * i + 3]);
+        float ex, ey, s1, s2;
+        covariance_axes(f, 0, x, y, z, sx, sy, sz, qi, qj, qk, qr, &ex, &ey, &s1, &s2);
+        const float ax = (2.0f * s1) * ex, ay = (2.0f * s1) * ey;
+        const float bx = (2.0f * s2) * (-ey), by = (2.0f * s2) * ex;
+        const float c0x = (cx - ax) - bx, c0y = (cy - ay) - by;
+        const float c1x = (cx + ax) - bx, c1y = (cy + ay) - by;
+        const float c2x = (cx + ax) + bx, c2y = (cy + ay) + by;
+        const float c3x = (cx - ax) + bx, c3y = (cy - ay) + by;
+        uint32_t zb;
+        memcpy(&zb, &zw, 4);
+        const uint64_t frag = ((uint64_t)zb << 32) | (uint64_t)i;
+        wire_edge(c0x, c0y, c1x, c1y, width, height, frag, zbuf);
+        wire_edge(c1x, c1y, c2x, c2y, width, height, frag, zbuf);
+        wire_edge(c2x, c2y, c3x, c3y, width, height, frag, zbuf);
+        wire_edge(c3x, c3y, c0x, c0y, width, height, frag, zbuf);
+    }
+    for (size_t p = 0; p < npix; ++p) {
+        float* o = rgba + p * 4;
+        o[0] = o[1] = o[2] = o[3] = 0.0f;
+        if (zbuf[p] != 0xffffffffffffffffull) {
+            const int64_t i = (int64_t)(zbuf[p] & 0xffffffffull);
+            o[0] = gso_half_to_float(s->Cd[3 * i]);
+            o[1] = gso_half_to_float(s->Cd[3 * i + 1]);
+            o[2] = gso_half_to_float(s->Cd[3 * i + 2]);
+            o[3] = 1.0f;
+        }
+    }
+    free(zbuf);
+    return 0;
 }
 
 int gso_max_threads(void)

@@ -121,6 +121,9 @@ int gso_blend_serial_depth(const gso_record* rec, const int32_t* perm, int64_t n
                            int width, int height, const float* depth, float* rgba);
 int gso_render_depth(const gso_splats* s, const gso_frame* f, const float* depth, float* rgba);
 
+/* wireframe overlay: outlines of the +-2 quads, colour Cd, alpha 1, nearest line wins */
+int gso_render_wire(const gso_splats* s, const gso_frame* f, float* rgba);
+
 /* whole frame: preprocess + argsort + blend.  threads<=1 -> serial blend. */
 int gso_render(const gso_splats* s, const gso_frame* f, float* rgba, int threads);
 

@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
         L.gso_blend_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.gso_render.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p, C.c_int]
         L.gso_render_depth.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p, C.c_void_p]
+        L.gso_render_wire.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p]
         L.gso_host_sort_only.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p]
         L.gso_max_threads.restype = C.c_int
         _lib = L
@@ -191,6 +192,15 @@ def render_depth(splats, cam, depth, origin=(0, 0, 0)) -> np.ndarray:
     out = np.zeros((f.height, f.width, 4), dtype=np.float32)
     d = None if depth is None else np.ascontiguousarray(depth, dtype=np.float32).reshape(f.height, f.width)
     rc = lib().gso_render_depth(C.byref(pk.struct), C.byref(f), None if d is None else d.ctypes.data, out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def render_wire(splats, cam) -> np.ndarray:
+    pk = _SplatPack(splats)
+    f = make_frame(cam, (0, 0, 0))
+    out = np.zeros((f.height, f.width, 4), dtype=np.float32)
+    rc = lib().gso_render_wire(C.byref(pk.struct), C.byref(f), out.ctypes.data)
     assert rc == 0
     return out
 

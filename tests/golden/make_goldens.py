@@ -88,6 +88,23 @@ ES3_EDITS_FS = [
      "in vec4 v_pos; in vec3 v_color; in float v_opacity;", 1),
     ("fsIn.pos", "v_pos", None), ("fsIn.color", "v_color", None), ("fsIn.opacity", "v_opacity", None),
 ]
+ES3_EDITS_WIRE_VS = [
+    (re.compile(r"out parms\s*\{\s*vec3\s+color;\s*\}\s*vsOut;"), "out vec3 v_color;", 1),
+    ("vsOut.color", "v_color", None),
+    ("vec2 quadPos = vec2(0,0);", "vec2 quadPos = vec2(0.0,0.0);", 1),
+    ("quadPos = vec2(1,0);", "quadPos = vec2(1.0,0.0);", 1),
+    ("quadPos = vec2(1,1);", "quadPos = vec2(1.0,1.0);", 1),
+    ("quadPos = vec2(0,1);", "quadPos = vec2(0.0,1.0);", 1),
+    ("quadPos = (quadPos * 2) - 1;", "quadPos = (quadPos * 2.0) - 1.0;", 1),
+    ("quadPos *= 2;", "quadPos *= 2.0;", 1),
+    ("mat4(1,0,0,0,0,-1,0,0,0,0,1,0,0,0,0,1)", "mat4(1.0,0.0,0.0,0.0,0.0,-1.0,0.0,0.0,0.0,0.0,1.0,0.0,0.0,0.0,0.0,1.0)", 1),
+    ("vec4(centerWorldPos, 1)", "vec4(centerWorldPos, 1.0)", 2),   # one of the two sits in a comment
+    ("* 2 / glH_ScreenSize", "* 2.0 / glH_ScreenSize", 1),
+]
+ES3_EDITS_WIRE_FS = [
+    (re.compile(r"in parms\s*\{\s*vec3\s+color;\s*\}\s*fsIn;"), "in vec3 v_color;", 1),
+    ("fsIn.color", "v_color", None),
+]
 ES3_HEADER = ("#version 300 es\nprecision highp float;\nprecision highp int;\n"
               "precision highp sampler2D;\nprecision highp isampler2D;\n")
 
@@ -113,6 +130,15 @@ def reference_shaders() -> tuple[str, str]:
     fs = _apply(_raw_literal(src_h, "_GSplatMainFragmentShader"), ES3_EDITS_FS)
     # same assembly order as getFullShaderSrc("330", {core, sh, vs}) / {fs}  (GSplatShaderSource.h:9-15,291,315)
     return ES3_HEADER + core + sh + vs, ES3_HEADER + fs
+
+
+def reference_wire_shaders() -> tuple[str, str]:
+    core_h = open(os.path.join(REF, "GSplatShaderCoreLib.h")).read()
+    src_h = open(os.path.join(REF, "GSplatShaderSource.h")).read()
+    core = _apply(_raw_literal(core_h, "GSplatCoreLib"), ES3_EDITS_CORE)
+    vs = _apply(_raw_literal(src_h, "_GSplatWireVertexShader"), ES3_EDITS_WIRE_VS)
+    fs = _apply(_raw_literal(src_h, "_GSplatWireFragmentShader"), ES3_EDITS_WIRE_FS)
+    return ES3_HEADER + core + vs, ES3_HEADER + fs     # getFullShaderSrc("330", {GSplatCoreLib, wire VS}) :89
 
 
 # ----------------------------------------------------------------------------- EGL / GLES3
@@ -354,6 +380,79 @@ def render_reference_glsl(es: GLES, splats, cam, origin, perm, ss: int = 1):
     return out, vs_out
 
 
+def render_reference_wire(es: GLES, splats, cam) -> np.ndarray:
+    """the reference's WIRE program: 8-vertex line list per splat (src/GR_GSplat.C:374-421), depth test on"""
+    gl = es.gl
+    n = splats.n
+    vs, fs = reference_wire_shaders()
+    prog = es.program(vs, fs)
+    gl.glUseProgram(prog)
+    gl.glGetAttribLocation.argtypes = [C.c_uint, C.c_char_p]
+    vao = C.c_uint()
+    gl.glGenVertexArrays(1, C.byref(vao))
+    gl.glBindVertexArray(vao)
+    attrs = {"P": np.repeat(splats.P.astype(np.float32), 8, axis=0),
+             "Cd": np.repeat(h2f(splats.Cd), 8, axis=0),
+             "scale": np.repeat(h2f(splats.scale), 8, axis=0),
+             "orient": np.repeat(h2f(splats.orient), 8, axis=0)}
+    keep = []
+    for name, arr in attrs.items():
+        loc = gl.glGetAttribLocation(prog, name.encode())
+        if loc < 0:
+            continue
+        arr = np.ascontiguousarray(arr, np.float32)
+        keep.append(arr)
+        buf = C.c_uint()
+        gl.glGenBuffers(1, C.byref(buf))
+        gl.glBindBuffer(0x8892, buf)                                     # GL_ARRAY_BUFFER
+        gl.glBufferData(0x8892, C.c_ssize_t(arr.nbytes), C.c_void_p(arr.ctypes.data), 0x88E4)  # STATIC_DRAW
+        gl.glEnableVertexAttribArray(loc)
+        gl.glVertexAttribPointer(loc, arr.shape[1], GL_FLOAT, 0, 0, None)
+
+    def loc(name):
+        return gl.glGetUniformLocation(prog, name.encode())
+
+    for name, m in (("glH_ObjViewMatrix", cam.obj_view), ("glH_ViewMatrix", cam.view), ("glH_ProjectMatrix", cam.proj)):
+        if loc(name) >= 0:
+            arr = np.ascontiguousarray(m, np.float32)
+            gl.glUniformMatrix4fv(loc(name), 1, 0, C.c_void_p(arr.ctypes.data))
+    gl.glUniform2f(loc("glH_ScreenSize"), float(cam.width), float(cam.height))
+    fb_tex = C.c_uint()
+    gl.glGenTextures(1, C.byref(fb_tex))
+    gl.glActiveTexture(GL_TEXTURE0 + 7)
+    gl.glBindTexture(GL_TEXTURE_2D, fb_tex)
+    gl.glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA32F, cam.width, cam.height, 0, GL_RGBA, GL_FLOAT, None)
+    rb = C.c_uint()
+    gl.glGenRenderbuffers(1, C.byref(rb))
+    gl.glBindRenderbuffer(0x8D41, rb)
+    gl.glRenderbufferStorage(0x8D41, 0x8CAC, cam.width, cam.height)     # DEPTH_COMPONENT32F
+    fbo = C.c_uint()
+    gl.glGenFramebuffers(1, C.byref(fbo))
+    gl.glBindFramebuffer(GL_FRAMEBUFFER, fbo)
+    gl.glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, fb_tex, 0)
+    gl.glFramebufferRenderbuffer(GL_FRAMEBUFFER, 0x8D00, 0x8D41, rb)      # DEPTH_ATTACHMENT
+    assert gl.glCheckFramebufferStatus(GL_FRAMEBUFFER) == GL_FRAMEBUFFER_COMPLETE
+    gl.glViewport(0, 0, cam.width, cam.height)
+    gl.glClearColor(0.0, 0.0, 0.0, 0.0)
+    gl.glClearDepthf.argtypes = [C.c_float]
+    gl.glClearDepthf(1.0)
+    gl.glClear(GL_COLOR_BUFFER_BIT | 0x100)
+    gl.glDisable(GL_BLEND)
+    gl.glEnable(GL_DEPTH_TEST)
+    gl.glDepthFunc(0x0201)                                               # GL_LESS
+    gl.glDrawArrays(1, 0, 8 * n)                                         # GL_LINES
+    gl.glFinish()
+    es.check("wire draw")
+    out = np.zeros((cam.height, cam.width, 4), np.float32)
+    gl.glPixelStorei(GL_PACK_ALIGNMENT, 1)
+    gl.glReadPixels(0, 0, cam.width, cam.height, GL_RGBA, GL_FLOAT, C.c_void_p(out.ctypes.data))
+    es.check("wire readpixels")
+    gl.glBindFramebuffer(GL_FRAMEBUFFER, 0)
+    gl.glDisable(GL_DEPTH_TEST)
+    gl.glBindVertexArray(0)
+    return out
+
+
 # ----------------------------------------------------------------------------- cases
 def cases(pkg):
     sc, cm = pkg.scenes, pkg.camera
@@ -430,6 +529,28 @@ def main():
         if splats.has_sh:
             arrays.update(shx=splats.shx, shy=splats.shy, shz=splats.shz)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    # ---- wireframe overlay: the reference's wire program as a LOOSE golden -- GL's diamond-exit
+    #      line rule and the oracle's rule agree up to one pixel, not pixel for pixel
+    sc, cm = pkg.scenes, pkg.camera
+    ws = sc.make_scene(150, seed=17, sh=False, log_scale_range=(-3.6, -2.4))
+    wcam = cm.make_camera(200, 150, sh_order=0, frame=3)
+    wire_gl = render_reference_wire(es, ws, wcam)
+    wire_or = oracle.render_wire(ws, wcam)
+    g, o = wire_gl[..., 3] > 0, wire_or[..., 3] > 0
+
+    def dil(m):
+        out = m.copy()
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                out |= np.roll(np.roll(m, dy, 0), dx, 1)
+        return out
+    print("wire: GL px", int(g.sum()), "oracle px", int(o.sum()), "GL within 1px of oracle", float((g & dil(o)).sum() / g.sum()),
+          "oracle within 1px of GL", float((o & dil(g)).sum() / o.sum()), "identical px", float((g & o).sum() / g.sum()))
+    np.savez_compressed(os.path.join(HERE, "w1_wire.npz"), P=ws.P, Cd=ws.Cd, alpha=ws.alpha, scale=ws.scale,
+                        orient=ws.orient, origin=np.zeros(3, np.float32), wire_reference_glsl=wire_gl.astype(np.float16),
+                        cam_obj_view=wcam.obj_view, cam_object=wcam.object, cam_inv_object=wcam.inv_object,
+                        cam_view=wcam.view, cam_proj=wcam.proj, cam_pos=wcam.cam_pos,
+                        cam_whs=np.int32([wcam.width, wcam.height, wcam.sh_order]))
     return summary
 
 

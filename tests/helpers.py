@@ -9,7 +9,9 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """beauty-path fixtures (the wireframe fixture w1_wire is handled by its own tests)"""
+    return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+                  if not n.startswith("w"))
 
 
 def load_golden(name):
@@ -45,3 +47,24 @@ def check_against_golden(img, golden_img):
     signed = float((img.astype(np.float64) - golden_img).mean())
     assert abs(signed) <= 2e-5, f"biased by {signed}"
     return frac, float(err.max()), float(err.mean())
+
+
+def dilate1(m):
+    out = m.copy()
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            out |= np.roll(np.roll(m, dy, 0), dx, 1)
+    return out
+
+
+def check_wire_against_golden(img, golden_wire):
+    """GL rasterises lines with the diamond-exit rule, the contract with a centre-sampling rule: the two
+    agree to within one pixel everywhere and pixel-for-pixel on the vast majority"""
+    g, o = golden_wire[..., 3] > 0, img[..., 3] > 0
+    assert g.sum() > 1000
+    assert (g & dilate1(o)).sum() == g.sum() and (o & dilate1(g)).sum() == o.sum()
+    same = g & o
+    assert same.sum() >= 0.97 * g.sum()
+    # where both drew the same splat's line the colour (Cd, fp16-exact) is identical
+    eq = np.all(img[same] == golden_wire[same].astype(np.float32), axis=1)
+    assert eq.mean() >= 0.97

@@ -192,7 +192,7 @@ def test_renderer_shim_frame_protocol(pkg, oracle):
 
 # ---------------------------------------------------------------------------------------------
 # golden fixtures: the reference's own GLSL on a software rasteriser (tests/golden/make_goldens.py)
-from helpers import check_against_golden, golden_names, load_golden  # noqa: E402
+from helpers import check_against_golden, check_wire_against_golden, golden_names, load_golden  # noqa: E402
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -389,3 +389,18 @@ def test_depth_tested_compositing(pkg, oracle, engine):
             out[y0:y1] = band[lrow * 16: lrow * 16 + (y1 - y0)]
     engine.set_row_shard(0, 1)
     assert np.array_equal(out, img)
+
+
+def test_wireframe_overlay(pkg, oracle, engine):
+    """quad outlines, colour Cd, nearest line wins -- bit-identical to the oracle, and within the
+    line-rule slack of the reference's wire program on SwiftShader"""
+    d, s, c = load_golden("w1_wire")
+    engine.upload(s)
+    img = engine.render_wire(c)
+    assert np.array_equal(img, oracle.render_wire(s, c))
+    check_wire_against_golden(img, d["wire_reference_glsl"])
+    big = pkg.scenes.make_scene(200000, seed=97, sh=True)
+    big.scale[:20] = pkg.scenes.f16bits(np.full((20, 3), 50.0))      # axis cap: outlines far larger than the screen
+    cam = pkg.camera.make_camera(640, 400, sh_order=3, frame=6, distance=1.2)   # some splats behind the eye
+    engine.upload(big)
+    assert np.array_equal(engine.render_wire(cam), oracle.render_wire(big, cam))

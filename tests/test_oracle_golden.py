@@ -11,7 +11,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from helpers import check_against_golden, golden_names, load_golden
+from helpers import check_against_golden, check_wire_against_golden, golden_names, load_golden
 
 NAMES = golden_names()
 
@@ -154,3 +154,11 @@ def test_argsort_is_by_distance_then_index(oracle, pkg):
     assert (np.diff(kk) >= 0).all()
     same = np.flatnonzero(np.diff(kk) == 0)
     assert len(same) >= 40 and (perm[same] < perm[same + 1]).all()
+
+
+def test_oracle_wireframe_matches_reference_wire_program(oracle):
+    """the reference's wire program (shaders/GSplatShaderSource.h:22-110) on SwiftShader"""
+    d, s, c = load_golden("w1_wire")
+    img = oracle.render_wire(s, c)
+    check_wire_against_golden(img, d["wire_reference_glsl"])
+    assert set(np.unique(img[..., 3]).tolist()) <= {0.0, 1.0}

@@ -844,8 +844,12 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
         a.shard_index = c->shard_index; a.shard_count = c->shard_count; a.band_rows = band_rows;
         a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = c->opt_swizzle ? 1 : 0; a.flags = c->opt_flags;
         const unsigned grid = a.use_map ? (unsigned)c->map_grid : (unsigned)local_tiles;
-        hipLaunchKernelGGL(k_blend, dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart, sl.send,
-                           sl.rec, reinterpret_cast<float4*>(target), sl.tile_work, sl.zwin, d_depth);
+        if (d_depth)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<true>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
+                               sl.send, sl.rec, reinterpret_cast<float4*>(target), sl.tile_work, sl.zwin, d_depth);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
+                               sl.send, sl.rec, reinterpret_cast<float4*>(target), sl.tile_work, sl.zwin, d_depth);
         HIP_TRY(hipGetLastError());
     }
     MARK(6);

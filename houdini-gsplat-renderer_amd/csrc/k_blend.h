@@ -49,6 +49,8 @@ struct GsrBlendArgs {
     int32_t flags;              // GSR_FLAG_*
 };
 
+// HAS_DEPTH = false compiles the depth compare out of the inner loop (two v_cmp per iteration).
+template <bool HAS_DEPTH>
 __global__ void __launch_bounds__(256)
 k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __restrict__ svals,
         const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
@@ -81,7 +83,7 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
     uint32_t my_evals = 0;            // (wave-uniform) records this wave evaluated for its 64 pixels
     // depth test against what the opaque pass left (depth writes stay off): a fragment survives iff its quad's
     // window depth <= depth[pixel] (src/GSplatRenderer.C:595-610).  No depth buffer = +inf.
-    const float dpx = (depth && pix_ok) ? depth[(size_t)py * a.width + px] : __builtin_inff();
+    const float dpx = (HAS_DEPTH && pix_ok) ? depth[(size_t)py * a.width + px] : __builtin_inff();
 
     const int st = (gty >> a.super_shift) * a.stiles_x + (tx >> a.super_shift);
     const int s = sstart[st];
@@ -161,7 +163,7 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
                 const uint32_t ridx = q[(q_head + tid) & (BL_QCAP - 1)];
                 const float4* p = reinterpret_cast<const float4*>(recs + ridx);
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
-                rz = depth ? zwin[ridx] : 0.0f;
+                rz = HAS_DEPTH ? zwin[ridx] : 0.0f;
                 ++my_fetched;
             }
         }
@@ -207,7 +209,7 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
             const uint32_t ridx = q[(q_head + tid) & (BL_QCAP - 1)];
             const float4* p = reinterpret_cast<const float4*>(recs + ridx);
             r0 = p[0]; r1 = p[1]; r2 = p[2];
-            rz = depth ? zwin[ridx] : 0.0f;
+            rz = HAS_DEPTH ? zwin[ridx] : 0.0f;
             ++my_fetched;
         }
 
@@ -240,10 +242,11 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
                     // (lanes outside the quad may feed exp a large negative argument: their result is unused)
                     gsr_v2f alpha = gsr_expf2(power) * (gsr_v2f){a2.w, b2.w};
                     alpha = __builtin_elementwise_min(alpha, (gsr_v2f)(1.0f));   // opacity >= 1/255 > 0: no lower clamp needed
-                    const bool ina = (__builtin_fabsf(q0.x) <= 2.0f) && (__builtin_fabsf(q1.x) <= 2.0f) &&
-                                     (alpha.x >= (1.0f / 255.0f)) && (a1.z <= dpx);
-                    const bool inb = two && (__builtin_fabsf(q0.y) <= 2.0f) && (__builtin_fabsf(q1.y) <= 2.0f) &&
-                                     (alpha.y >= (1.0f / 255.0f)) && (b1.z <= dpx);
+                    // |q0| <= 2 && |q1| <= 2  <=>  max(|q0|, |q1|) <= 2: one v_max + one v_cmp instead of two v_cmp
+                    const bool ina = (__builtin_fmaxf(__builtin_fabsf(q0.x), __builtin_fabsf(q1.x)) <= 2.0f) &&
+                                     (alpha.x >= (1.0f / 255.0f)) && (!HAS_DEPTH || a1.z <= dpx);
+                    const bool inb = two && (__builtin_fmaxf(__builtin_fabsf(q0.y), __builtin_fabsf(q1.y)) <= 2.0f) &&
+                                     (alpha.y >= (1.0f / 255.0f)) && (!HAS_DEPTH || b1.z <= dpx);
                     // branch-free under-blend: a rejected fragment blends alpha = 0, which leaves C and A
                     // bit-identical (fma(t, +-0, C) == C), and costs no exec-mask juggling on the scalar unit
                     float t = 1.0f - A;

@@ -504,13 +504,13 @@ static int exclusive_scan(FrameSlot& sl, const uint32_t* in, uint32_t* out, uint
 
 template <typename V, int DBITS, bool SKIP>
 static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, uint32_t n, const uint32_t* n_dev,
-                      int shift, uint32_t nblk)
+                      int shift, uint32_t nblk, bool contig)
 {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS, SKIP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, n,
-                       n_dev, shift, sl.hist, nblk);
+                       n_dev, shift, sl.hist, nblk, contig);
     hipLaunchKernelGGL(k_scan_rows, dim3(1u << DBITS), dim3(SC_THREADS), 0, sl.stream, sl.hist, nblk, sl.totals);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS, SKIP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA,
-                       vA, kB, vB, n, n_dev, shift, sl.hist, sl.totals, nblk);
+                       vA, kB, vB, n, n_dev, shift, sl.hist, sl.totals, nblk, contig);
     HIP_TRY(hipGetLastError());
     return GSR_OK;
 }
@@ -521,7 +521,7 @@ static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, u
 // written to *compact_to (device); the remaining passes and the caller's later kernels read it there.
 template <typename V>
 static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& vB, uint32_t n, int bits,
-                      bool allow9 = true, uint32_t* compact_to = nullptr)
+                      bool allow9 = true, uint32_t* compact_to = nullptr, bool contig = false)
 {
     if (n == 0) {
         if (compact_to) HIP_TRY(hipMemsetAsync(compact_to, 0, 4, sl.stream));
@@ -538,11 +538,11 @@ static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& v
         const bool skip = compact_to && p == 0;
         const uint32_t* n_dev = (compact_to && p > 0) ? compact_to : nullptr;
         if (use9)
-            rc = skip ? radix_pass<V, 9, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk)
-                      : radix_pass<V, 9, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk);
+            rc = skip ? radix_pass<V, 9, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig)
+                      : radix_pass<V, 9, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig);
         else
-            rc = skip ? radix_pass<V, 8, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk)
-                      : radix_pass<V, 8, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk);
+            rc = skip ? radix_pass<V, 8, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig)
+                      : radix_pass<V, 8, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig);
         if (rc) return rc;
         if (skip) {
             hipLaunchKernelGGL(k_sum_totals, dim3(1), dim3(SC_THREADS), 0, sl.stream, sl.totals, 1 << width, compact_to);
@@ -779,7 +779,7 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
     if (n > 0) {
         // on a cache hit (identical frame description) the sorted (keyA, valA) are kept and K1's key/payload
         // output goes to the scratch buffers
-        hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, 256)), dim3(256), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
+        hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, GSR_K1_THREADS)), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, cache_hit ? sl.keyB : sl.keyA, cache_hit ? sl.valB : sl.valA,
                            d_depth ? sl.zwin : (float*)nullptr);
         HIP_TRY(hipGetLastError());
@@ -789,7 +789,7 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
         int key_bits = 1;
         while (key_bits < 32 && ((f.key_max - f.key_min) >> key_bits) != 0u) ++key_bits;
         int rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n, key_bits, !(c->opt_flags & GSR_FLAG_FULL_KEYS),
-                            sl.d_n);
+                            sl.d_n, RS_XCD_DEPTH != 0);
         if (rc) return rc;
         sl.key_min = f.key_min;
         sl.sort_valid = true;
@@ -826,7 +826,7 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
     if (D > 0) {
         int bits = 1;
         while ((1 << bits) < n_super) ++bits;
-        int rc = radix_sort(sl, sl.pkA, sl.pvA, sl.pkB, sl.pvB, D, bits);
+        int rc = radix_sort(sl, sl.pkA, sl.pvA, sl.pkB, sl.pvB, D, bits, true, (uint32_t*)nullptr, RS_XCD_BIN != 0);
         if (rc) return rc;
     }
     MARK(4);
@@ -1099,7 +1099,7 @@ extern "C" int gsr_debug_sort_pairs(gsr_context* c, uint32_t* keys, uint32_t* va
     hipError_t e = hipMemcpyAsync(kA, keys, (size_t)n * 4, hipMemcpyHostToDevice, sl.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(vA, vals, (size_t)n * 4, hipMemcpyHostToDevice, sl.stream);
     if (e == hipSuccess) {
-        rc = radix_sort(sl, kA, vA, kB, vB, n, key_bits, true, (uint32_t*)nullptr);
+        rc = radix_sort(sl, kA, vA, kB, vB, n, key_bits, true, (uint32_t*)nullptr, RS_XCD_DEPTH != 0);
         if (!rc) {
             e = hipMemcpyAsync(keys, kA, (size_t)n * 4, hipMemcpyDeviceToHost, sl.stream);
             if (e == hipSuccess) e = hipMemcpyAsync(vals, vA, (size_t)n * 4, hipMemcpyDeviceToHost, sl.stream);

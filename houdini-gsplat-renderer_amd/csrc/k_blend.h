@@ -12,12 +12,13 @@
 // Data flow (scan -> compact -> composite): the tile walks the depth-ordered list of its
 // SUPER-tile 1024 entries at a time (idx + packed tile rect, 8 B each, coalesced, prefetched one
 // step ahead); entries whose rect contains this tile are COMPACTED, in list order, into an LDS hit
-// queue (wave ballots + a 16-entry cross-wave prefix).  Compositing then runs in rounds of 256
-// hits: each thread gathers one 48-B record (3 x dwordx4), computes a 4-bit
-// quadrant-overlap mask (separating-axis test) and stages both in LDS; every wave turns the masks
-// into 64-bit ballots so that it only touches records that reach its quadrant, and evaluates them
-// two at a time with packed FP32 math.  Scanning is 4 entries/thread/step and SAT/staging run on
-// fully populated waves, so sparse lists cost little.
+// queue (wave ballots + a 16-entry cross-wave prefix).  Compositing then runs in rounds of BL_ROUND
+// hits: each thread gathers one 48-B record (3 x dwordx4), computes a 4-bit quadrant-overlap mask
+// (separating-axis test) and appends the record, still in depth order, to the LDS list of every
+// quadrant it reaches (ballot ranks + a cross-wave prefix); each wave then walks only its own
+// list, two records per iteration in packed FP32, the pair pre-interleaved in LDS so the operands
+// arrive as register pairs.  Scanning is 4 entries/thread/step and SAT/staging run on fully
+// populated waves, so sparse lists cost little.
 // Early-out: a PIXEL stops accumulating once 1-A < 2^-14 (dropped contribution
 // <= 2^-14 * max colour, inside the 1e-3 budget; being per pixel it does not
 // depend on chunking, so sharded and unsharded frames are bit-identical); a wave
@@ -27,14 +28,15 @@
 #include "gsr_device.h"
 
 #ifndef BL_ROUND
-#define BL_ROUND 256          // records composited per round (at most one per thread)
+#define BL_ROUND 64           // records composited per round.  The kernel wants waves per SIMD: measured on C4
+                              // 256 -> 0.40 ms (57 KB LDS, 2 workgroups/CU), 128 -> 0.295, 64 -> 0.278, 32 -> 0.30 (barriers)
 #endif
-#ifndef BL_LOOKAHEAD
-#define BL_LOOKAHEAD 0        // 1 = gather the next round's records while the current one is composited
-                              // (measured no faster on MI355X, and it fetches a wasted round per tile)
+#ifndef BL_WAVES_PER_EU
+#define BL_WAVES_PER_EU 6     // 80 VGPRs (8 dwords of spill) instead of 94: 0.278 -> 0.270 ms
 #endif
 #define BL_SCAN_K 4           // list entries scanned per thread per scan step
-#define BL_QCAP 2048          // hit-queue ring capacity (>= 2*BL_ROUND + BL_SCAN_K*256)
+#define BL_QCAP 2048          // hit-queue ring capacity (>= BL_ROUND + 2 * BL_SCAN_K * 256)
+#define BL_PAIR_F4 6          // float4s per staged record PAIR (96 B)
 #define GSR_T_MIN 6.103515625e-05f  // 2^-14
 
 struct GsrBlendArgs {
@@ -49,20 +51,29 @@ struct GsrBlendArgs {
     int32_t flags;              // GSR_FLAG_*
 };
 
+// Staging layout: one list PER QUADRANT (= per wave), holding the round's records that reach that
+// quadrant, in depth order, two records interleaved per 96-byte block so that every ds_read_b128
+// lands as two ready-made operand pairs of the packed-FP32 instructions (no v_mov shuffling):
+//   f4 0: a.cx b.cx a.cy b.cy     f4 3: a.opacity b.opacity a.zwin b.zwin
+//   f4 1: a.ex b.ex a.ey b.ey     f4 4: a.r a.g a.b 1
+//   f4 2: a.1/s1 b.1/s1 a.1/s2 b.1/s2     f4 5: b.r b.g b.b 1
 // HAS_DEPTH = false compiles the depth compare out of the inner loop (two v_cmp per iteration).
+#if BL_WAVES_PER_EU > 0
+#define BL_OCC __attribute__((amdgpu_waves_per_eu(BL_WAVES_PER_EU)))
+#else
+#define BL_OCC
+#endif
 template <bool HAS_DEPTH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) BL_OCC
 k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __restrict__ svals,
         const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
         const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint4* __restrict__ tile_work,
         const float* __restrict__ zwin, const float* __restrict__ depth)
 {
-    __shared__ float4 s0[BL_ROUND];   // cx, cy, ex, ey
-    __shared__ float4 s1[BL_ROUND];   // is1, is2, (hx, hy unused after the mask)
-    __shared__ float4 s2[BL_ROUND];   // r, g, b, opacity
-    __shared__ uint32_t smask[BL_ROUND];
+    __shared__ float4 slist[4][(BL_ROUND / 2) * BL_PAIR_F4];
     __shared__ uint32_t q[BL_QCAP];   // hit queue: splat indices in list (= depth) order
     __shared__ uint32_t scnt[2][BL_SCAN_K][4];
+    __shared__ unsigned long long swcnt[2][4];   // per gathering wave: 4 x 16-bit counts of records reaching quadrant 0..3
     __shared__ uint32_t sdone[2][4];
     __shared__ uint32_t sfetched, sevals;
 
@@ -76,7 +87,7 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
     const int px = tx * GSR_TILE_PX + (wave & 1) * 8 + (lane & 7);
     const int py = gty * GSR_TILE_PX + (wave >> 1) * 8 + (lane >> 3);
     const bool pix_ok = (px < a.width) && (py < a.height);
-    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    const gsr_v2f fx = (gsr_v2f)((float)px + 0.5f), fy = (gsr_v2f)((float)py + 0.5f);
     // tile bounds in pixel-centre coordinates, for the quadrant masks
     const float tcx0 = (float)(tx * GSR_TILE_PX) + 0.5f, tcy0 = (float)(gty * GSR_TILE_PX) + 0.5f;
     if (tid == 0) { sfetched = 0; sevals = 0; }
@@ -89,7 +100,7 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
     const int s = sstart[st];
     const int n = send[st] - s;
 
-    float C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, A = 0.0f;
+    gsr_v2f C01 = {0.0f, 0.0f}, CA = {0.0f, 0.0f};   // {C0, C1}, {C2, A}: the accumulators as two register pairs
     bool wave_done = false;
     uint32_t my_fetched = 0;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -109,17 +120,12 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
         const int i = k * 256 + tid;
         pre[k] = (i < n) ? svals[s + i] : make_uint2(0u, GSR_RECT_EMPTY);
     }
-    // ---- round state
-    float4 r0, r1, r2;                // record of the upcoming round held by this thread
-    float rz = 0.0f;                  // ... and its window depth (depth-tested frames only)
-    bool have = false;
-    int pending = 0;                  // records of the upcoming round already gathered into registers
     int round = 0;
 
     for (;;) {
-        // (1) SCAN until two rounds' worth of hits are queued, or the list ends
+        // (1) SCAN until a round's worth of hits is queued, or the list ends
         bool scanned_any = false;
-        while ((int)(q_tail - q_head) < (1 + BL_LOOKAHEAD) * BL_ROUND && scan_pos < n) {
+        while ((int)(q_tail - q_head) < BL_ROUND && scan_pos < n) {
             uint32_t rank[BL_SCAN_K];
             bool hit[BL_SCAN_K];
 #pragma unroll
@@ -153,27 +159,20 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
         }
         if (scanned_any) __syncthreads();            // queue writes visible to every wave
 
-        // (2) records of this round: normally gathered one round ahead; otherwise (first round, or the
-        //     queue had run dry) gather them now
+        // (2) gather this round's records: thread t takes the t-th queued hit
         const int avail = (int)(q_tail - q_head);
-        if (pending == 0) {
-            pending = avail < BL_ROUND ? avail : BL_ROUND;
-            have = tid < pending;
-            if (have) {
-                const uint32_t ridx = q[(q_head + tid) & (BL_QCAP - 1)];
-                const float4* p = reinterpret_cast<const float4*>(recs + ridx);
-                r0 = p[0]; r1 = p[1]; r2 = p[2];
-                rz = HAS_DEPTH ? zwin[ridx] : 0.0f;
-                ++my_fetched;
-            }
-        }
-        const int take = pending;
+        const int take = avail < BL_ROUND ? avail : BL_ROUND;
         if (take == 0) break;                         // list exhausted and queue empty
-
-        // (3) stage this round
+        const bool have = tid < take;
+        float4 r0, r1, r2;
+        float rz = 0.0f;
         uint32_t m = 0;
         if (have) {
-            s0[tid] = r0; s1[tid] = make_float4(r1.x, r1.y, rz, 0.0f); s2[tid] = r2;   // (hx, hy are only needed for the mask below)
+            const uint32_t ridx = q[(q_head + tid) & (BL_QCAP - 1)];
+            const float4* p = reinterpret_cast<const float4*>(recs + ridx);
+            r0 = p[0]; r1 = p[1]; r2 = p[2];
+            rz = HAS_DEPTH ? zwin[ridx] : 0.0f;
+            ++my_fetched;
             // Which 8x8 quadrants can the splat touch?  Separating-axis test of the oriented quad
             // (shrunk to the radius where alpha can still reach 1/255) against each quadrant's box of
             // pixel centres: the box axes (= bbox test) and the quad's own two axes.  Conservative.
@@ -193,84 +192,103 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
                 if (box && (((a.flags & GSR_FLAG_NO_SAT) != 0) || (pu <= lim1 && pv <= lim2))) m |= 1u << qd;
             }
         }
-        smask[tid] = m;
+        // (3) per-quadrant list positions: rank inside this gathering wave now, wave bases after the barrier
+        uint32_t rnk[4];
+        unsigned long long wcnt = 0;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const unsigned long long bal = __ballot((m >> qd) & 1u);
+            rnk[qd] = (uint32_t)__builtin_popcountll(bal & lt_mask);
+            wcnt |= (unsigned long long)__builtin_popcountll(bal) << (16 * qd);
+        }
         const int rpar = round & 1;
-        if (lane == 0) sdone[rpar][wave] = wave_done ? 1u : 0u;
+        if (lane == 0) { swcnt[rpar][wave] = wcnt; sdone[rpar][wave] = wave_done ? 1u : 0u; }
         __syncthreads();
         const bool block_done = (sdone[rpar][0] & sdone[rpar][1] & sdone[rpar][2] & sdone[rpar][3]) != 0u;
         if (block_done) break;
-
-        // (4) gather the NEXT round's records while this one is composited
-        q_head += (uint32_t)take;
-        pending = BL_LOOKAHEAD ? (int)(q_tail - q_head) : 0;
-        if (pending > BL_ROUND) pending = BL_ROUND;
-        have = tid < pending;
-        if (have) {
-            const uint32_t ridx = q[(q_head + tid) & (BL_QCAP - 1)];
-            const float4* p = reinterpret_cast<const float4*>(recs + ridx);
-            r0 = p[0]; r1 = p[1]; r2 = p[2];
-            rz = HAS_DEPTH ? zwin[ridx] : 0.0f;
-            ++my_fetched;
+        unsigned long long base = 0, total = 0;   // 4 x 16-bit fields (a field is at most BL_ROUND)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const unsigned long long c = swcnt[rpar][g];
+            if (g < wave) base += c;
+            total += c;
         }
-
-        // (5) composite
-        if (!wave_done) {
-            for (int g = 0; g * 64 < take; ++g) {
-                const int j0 = g * 64;
-                unsigned long long acc = __ballot((smask[j0 + lane] >> wave) & 1u);
-                if (acc == 0ull) continue;
-                while (acc) {
-                    // two records per iteration (packed FP32); an odd tail evaluates its record twice.
-                    // (Measured: prefetching the next pair's LDS reads, or four records per iteration, are
-                    //  both SLOWER -- the loop is VALU-issue bound, extra registers only cost occupancy.)
-                    const int ja = j0 + __builtin_ctzll(acc);
-                    acc &= acc - 1;
-                    const bool two = acc != 0ull;
-                    const int jb = two ? j0 + __builtin_ctzll(acc) : ja;
-                    acc &= acc - 1;   // no-op when acc == 0
-                    my_evals += two ? 2u : 1u;
-                    const float4 a0 = s0[ja], a1 = s1[ja], a2 = s2[ja];
-                    const float4 b0 = s0[jb], b1 = s1[jb], b2 = s2[jb];
-                    const gsr_v2f dx = (gsr_v2f)(fx) - (gsr_v2f){a0.x, b0.x};
-                    const gsr_v2f dy = (gsr_v2f)(fy) - (gsr_v2f){a0.y, b0.y};
-                    const gsr_v2f ex = {a0.z, b0.z}, ey = {a0.w, b0.w};
-                    const gsr_v2f u = gsr_fma2(dx, ex, dy * ey);
-                    const gsr_v2f v = gsr_fma2(dy, ex, -(dx * ey));
-                    const gsr_v2f q0 = u * (gsr_v2f){a1.x, b1.x};
-                    const gsr_v2f q1 = v * (gsr_v2f){a1.y, b1.y};
-                    const gsr_v2f power = -gsr_fma2(q0, q0, q1 * q1);
-                    // (lanes outside the quad may feed exp a large negative argument: their result is unused)
-                    gsr_v2f alpha = gsr_expf2(power) * (gsr_v2f){a2.w, b2.w};
-                    alpha = __builtin_elementwise_min(alpha, (gsr_v2f)(1.0f));   // opacity >= 1/255 > 0: no lower clamp needed
-                    // |q0| <= 2 && |q1| <= 2  <=>  max(|q0|, |q1|) <= 2: one v_max + one v_cmp instead of two v_cmp
-                    const bool ina = (__builtin_fmaxf(__builtin_fabsf(q0.x), __builtin_fabsf(q1.x)) <= 2.0f) &&
-                                     (alpha.x >= (1.0f / 255.0f)) && (!HAS_DEPTH || a1.z <= dpx);
-                    const bool inb = two && (__builtin_fmaxf(__builtin_fabsf(q0.y), __builtin_fabsf(q1.y)) <= 2.0f) &&
-                                     (alpha.y >= (1.0f / 255.0f)) && (!HAS_DEPTH || b1.z <= dpx);
-                    // branch-free under-blend: a rejected fragment blends alpha = 0, which leaves C and A
-                    // bit-identical (fma(t, +-0, C) == C), and costs no exec-mask juggling on the scalar unit
-                    float t = 1.0f - A;
-                    const float aa = (ina && t >= GSR_T_MIN) ? alpha.x : 0.0f;
-                    C0 = gsr_fma(t, a2.x * aa, C0);
-                    C1 = gsr_fma(t, a2.y * aa, C1);
-                    C2 = gsr_fma(t, a2.z * aa, C2);
-                    A = gsr_fma(t, aa, A);
-                    t = 1.0f - A;
-                    const float ab = (inb && t >= GSR_T_MIN) ? alpha.y : 0.0f;
-                    C0 = gsr_fma(t, b2.x * ab, C0);
-                    C1 = gsr_fma(t, b2.y * ab, C1);
-                    C2 = gsr_fma(t, b2.z * ab, C2);
-                    A = gsr_fma(t, ab, A);
-                }
-                if (__all(!pix_ok || (1.0f - A) < GSR_T_MIN)) { wave_done = true; break; }
+        if (m) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                if (!((m >> qd) & 1u)) continue;
+                const uint32_t pos = (uint32_t)((base >> (16 * qd)) & 0xffffu) + rnk[qd];
+                float* blk = reinterpret_cast<float*>(&slist[qd][(pos >> 1) * BL_PAIR_F4]);
+                const uint32_t h = pos & 1u;
+                blk[0 + h] = r0.x; blk[2 + h] = r0.y; blk[4 + h] = r0.z; blk[6 + h] = r0.w;
+                blk[8 + h] = r1.x; blk[10 + h] = r1.y; blk[12 + h] = r2.w; blk[14 + h] = rz;
+                reinterpret_cast<float4*>(blk)[4 + h] = make_float4(r2.x, r2.y, r2.z, 1.0f);
             }
         }
+        if (tid < 4) {   // odd list: pad with a record that cannot contribute (opacity 0 -> alpha 0 < 1/255)
+            const uint32_t cnt = (uint32_t)((total >> (16 * tid)) & 0xffffu);
+            if (cnt & 1u) {
+                float* blk = reinterpret_cast<float*>(&slist[tid][(cnt >> 1) * BL_PAIR_F4]);
+                blk[1] = 0.0f; blk[3] = 0.0f; blk[5] = 1.0f; blk[7] = 0.0f;
+                blk[9] = 0.0f; blk[11] = 0.0f; blk[13] = 0.0f; blk[15] = 0.0f;
+                reinterpret_cast<float4*>(blk)[5] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            }
+        }
+        q_head += (uint32_t)take;
+        __syncthreads();
+
+        // (4) composite: wave w walks ITS list, two records per iteration in packed FP32
+        if (!wave_done) {
+            // (wave-uniform by construction; readfirstlane tells the compiler, so the loop runs on the scalar unit)
+            const int cnt = __builtin_amdgcn_readfirstlane((int)((total >> (16 * wave)) & 0xffffu));
+            const int npairs = (cnt + 1) >> 1;
+            const float4* L = slist[wave];
+            int p = 0;
+            while (p < npairs) {
+                const int pend = (p + 32 < npairs) ? p + 32 : npairs;
+                for (; p < pend; ++p) {
+                    const float4 v0 = L[p * BL_PAIR_F4 + 0], v1 = L[p * BL_PAIR_F4 + 1], v2 = L[p * BL_PAIR_F4 + 2];
+                    const float4 v3 = L[p * BL_PAIR_F4 + 3], v4 = L[p * BL_PAIR_F4 + 4], v5 = L[p * BL_PAIR_F4 + 5];
+                    const gsr_v2f dx = fx - (gsr_v2f){v0.x, v0.y};
+                    const gsr_v2f dy = fy - (gsr_v2f){v0.z, v0.w};
+                    const gsr_v2f ex = {v1.x, v1.y}, ey = {v1.z, v1.w};
+                    const gsr_v2f u = gsr_fma2(dx, ex, dy * ey);
+                    const gsr_v2f v = gsr_fma2(dy, ex, -(dx * ey));
+                    const gsr_v2f q0 = u * (gsr_v2f){v2.x, v2.y};
+                    const gsr_v2f q1 = v * (gsr_v2f){v2.z, v2.w};
+                    const gsr_v2f power = -gsr_fma2(q0, q0, q1 * q1);
+                    // (lanes outside the quad may feed exp a large negative argument: their result is unused)
+                    gsr_v2f alpha = gsr_expf2(power) * (gsr_v2f){v3.x, v3.y};
+                    alpha = __builtin_elementwise_min(alpha, (gsr_v2f)(1.0f));   // opacity >= 0: no lower clamp needed
+                    // |q0| <= 2 && |q1| <= 2  <=>  max(|q0|, |q1|) <= 2: one v_max + one v_cmp instead of two v_cmp
+                    const bool ina = (__builtin_fmaxf(__builtin_fabsf(q0.x), __builtin_fabsf(q1.x)) <= 2.0f) &&
+                                     (alpha.x >= (1.0f / 255.0f)) && (!HAS_DEPTH || v3.z <= dpx);
+                    const bool inb = (__builtin_fmaxf(__builtin_fabsf(q0.y), __builtin_fabsf(q1.y)) <= 2.0f) &&
+                                     (alpha.y >= (1.0f / 255.0f)) && (!HAS_DEPTH || v3.w <= dpx);
+                    // branch-free under-blend: a rejected fragment blends alpha = 0, which leaves C and A
+                    // bit-identical (fma(t, +-0, C) == C), and costs no exec-mask juggling on the scalar unit.
+                    // {C0,C1} and {C2,A} update as pairs: the staged colour is (r,g,b,1), and
+                    // fma(t, 1*aa, A) == fma(t, aa, A) exactly.
+                    float t = 1.0f - CA.y;
+                    const float aa = (ina && t >= GSR_T_MIN) ? alpha.x : 0.0f;
+                    C01 = gsr_fma2((gsr_v2f)(t), (gsr_v2f){v4.x, v4.y} * (gsr_v2f)(aa), C01);
+                    CA = gsr_fma2((gsr_v2f)(t), (gsr_v2f){v4.z, v4.w} * (gsr_v2f)(aa), CA);
+                    t = 1.0f - CA.y;
+                    const float ab = (inb && t >= GSR_T_MIN) ? alpha.y : 0.0f;
+                    C01 = gsr_fma2((gsr_v2f)(t), (gsr_v2f){v5.x, v5.y} * (gsr_v2f)(ab), C01);
+                    CA = gsr_fma2((gsr_v2f)(t), (gsr_v2f){v5.z, v5.w} * (gsr_v2f)(ab), CA);
+                }
+                if (__all(!pix_ok || (1.0f - CA.y) < GSR_T_MIN)) { wave_done = true; break; }
+            }
+            const int evald = 2 * p;
+            my_evals += (uint32_t)(evald < cnt ? evald : cnt);
+        }
         ++round;
-        __syncthreads();   // staging area (and consumed queue slots) may be overwritten from here on
+        __syncthreads();   // the lists (and consumed queue slots) may be overwritten from here on
     }
     if (pix_ok) {
         const int brow = lty * GSR_TILE_PX + (wave >> 1) * 8 + (lane >> 3);
-        out[(size_t)brow * a.width + px] = make_float4(C0, C1, C2, A);
+        out[(size_t)brow * a.width + px] = make_float4(C01.x, C01.y, CA.x, CA.y);
     }
     // bookkeeping for the roofline: list entries scanned and records gathered by this tile
 #pragma unroll

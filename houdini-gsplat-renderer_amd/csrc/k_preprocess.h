@@ -9,6 +9,9 @@
 #pragma once
 #include "gsr_device.h"
 
+#ifndef GSR_K1_THREADS
+#define GSR_K1_THREADS 256
+#endif
 #ifndef GSR_PRELOAD_COLOR
 #define GSR_PRELOAD_COLOR 0   // 1 = fetch the colour chunks before the visibility test (measured slower: K1 is HBM-bound)
 #endif
@@ -176,13 +179,13 @@ __device__ __forceinline__ void gsr_covariance_axes(const GsrFrame& f, const flo
 // K1: one thread per splat.
 //   in : geoA, geoB, col (SoA, coalesced 16 B/lane)
 //   out: rec[i] (48 B), key[i] (f32 distance^2 bits), val[i] = (i, rect), rect[i] (packed tile rect or EMPTY)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(GSR_K1_THREADS)
 k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col,
              GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint2* __restrict__ val,
              float* __restrict__ zwin /* NULL unless the frame is depth-tested */)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = blockIdx.x * (uint32_t)GSR_K1_THREADS + threadIdx.x;
     if (i < n) {
         // geoA and geoB are fetched together; the colour chunks only once the splat is known to be needed
         // (GSR_PRELOAD_COLOR=1 fetches them up front too -- one round trip instead of two, but the kernel is

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Usage (build container): bash tools/build_variants.sh name1:"-DFOO=1 -DBAR=2" name2:"" ...
+# Builds houdini-gsplat-renderer_amd/variants/libgsplat_hip_<name>.so for A/B runs (tools/gpu_ab.sh).
+set -e
+cd "$(dirname "$0")/.."
+P=houdini-gsplat-renderer_amd
+mkdir -p $P/variants
+for spec in "$@"; do
+  name=${spec%%:*}; defs=${spec#*:}
+  [ "$defs" = "$spec" ] && defs=""
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $defs \
+      -o $P/variants/libgsplat_hip_$name.so $P/csrc/gsr_api.hip $P/csrc/GSplatRenderer.cpp &
+done
+wait
+ls -la $P/variants/

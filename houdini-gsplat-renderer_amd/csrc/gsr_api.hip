@@ -65,7 +65,6 @@ struct FrameSlot {
     GsrRecord* rec = nullptr;
     uint32_t *keyA = nullptr, *keyB = nullptr;
     uint2 *valA = nullptr, *valB = nullptr;      // depth-sort payload: (splat index, packed tile rect)
-    uint32_t *cnt = nullptr, *poff = nullptr;
     uint32_t* d_n = nullptr;           // splats that survived culling = items after the first sort pass
     float* zwin = nullptr;             // per-splat window depth (depth-tested frames)
     float* depth_stage = nullptr;      // device copy of a host depth buffer
@@ -73,12 +72,9 @@ struct FrameSlot {
     // scan / sort scratch
     uint32_t* hist = nullptr;
     size_t hist_cap = 0;
-    uint32_t* partial = nullptr;
-    size_t partial_cap = 0;
     uint32_t* totals = nullptr;        // [512] per-digit totals of the current radix pass
     // pairs
-    uint32_t *pkA = nullptr, *pkB = nullptr;
-    uint2 *pvA = nullptr, *pvB = nullptr;        // pair payload: (splat index, packed tile rect)
+    uint2* pvA = nullptr;                        // super-tile lists: (splat index, packed tile rect) per entry
     size_t pair_cap = 0;
     int32_t *sstart = nullptr, *send = nullptr;  // super-tile ranges
     uint4* tile_work = nullptr;        // per tile: entries scanned, records gathered, wave-record evaluations
@@ -204,15 +200,15 @@ static bool slot_init(FrameSlot& sl)
 static void slot_free_splat_arrays(FrameSlot& sl)
 {
     dev_free(sl.rec); dev_free(sl.keyA); dev_free(sl.keyB); dev_free(sl.valA); dev_free(sl.valB);
-    dev_free(sl.cnt); dev_free(sl.poff); dev_free(sl.zwin);
+    dev_free(sl.zwin);
     sl.sort_valid = false;
 }
 
 static void slot_destroy(FrameSlot& sl)
 {
     slot_free_splat_arrays(sl);
-    dev_free(sl.hist); dev_free(sl.partial); dev_free(sl.totals);
-    dev_free(sl.pkA); dev_free(sl.pkB); dev_free(sl.pvA); dev_free(sl.pvB);
+    dev_free(sl.hist); dev_free(sl.totals);
+    dev_free(sl.pvA);
     dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.fb); dev_free(sl.depth_stage);
     dev_free(sl.counters); dev_free(sl.d_total); dev_free(sl.d_n);
     if (sl.h_total) (void)hipHostFree(sl.h_total);
@@ -332,7 +328,7 @@ extern "C" int gsr_upload_begin(gsr_context* c, int64_t total, int has_sh, const
             FrameSlot& sl = c->slot[k];
             if ((rc = dev_alloc(&sl.rec, cap)) || (rc = dev_alloc(&sl.keyA, cap)) || (rc = dev_alloc(&sl.keyB, cap)) ||
                 (rc = dev_alloc(&sl.valA, cap)) || (rc = dev_alloc(&sl.valB, cap)) ||
-                (rc = dev_alloc(&sl.cnt, cap + 8)) || (rc = dev_alloc(&sl.poff, cap + 8)) || (rc = dev_alloc(&sl.zwin, cap))) {
+                (rc = dev_alloc(&sl.zwin, cap))) {
                 free_geometry(c);
                 return rc;
             }
@@ -485,23 +481,6 @@ static int ensure_u32(uint32_t** p, size_t* cap, size_t need)
     return GSR_OK;
 }
 
-// out may equal in.  total (device pointer) may be NULL.
-static int exclusive_scan(FrameSlot& sl, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* d_total)
-{
-    if (n == 0) {
-        if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, 4, sl.stream));
-        return GSR_OK;
-    }
-    const uint32_t m = div_up(n, SC_TILE);
-    int rc = ensure_u32(&sl.partial, &sl.partial_cap, m);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(m), dim3(SC_THREADS), 0, sl.stream, in, n, sl.partial);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SC_THREADS), 0, sl.stream, sl.partial, m, d_total);
-    hipLaunchKernelGGL(k_scan_down, dim3(m), dim3(SC_THREADS), 0, sl.stream, in, n, sl.partial, out);
-    HIP_TRY(hipGetLastError());
-    return GSR_OK;
-}
-
 template <typename V, int DBITS, bool SKIP>
 static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, uint32_t n, const uint32_t* n_dev,
                       int shift, uint32_t nblk, bool contig)
@@ -593,14 +572,12 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
     f->shard_index = c->shard_index;
     f->shard_count = c->shard_count;
     f->local_tiles_y = (f->tiles_y > c->shard_index) ? (f->tiles_y - c->shard_index + c->shard_count - 1) / c->shard_count : 0;
-    // super-tile edge: smallest power of two that leaves <= 256 super-tiles (measured best at 1080p: S=8;
-    // an explicit smaller S with <= 512 super-tiles still sorts in ONE pass thanks to 9-bit digits)
+    // super-tile edge: smallest power of two that leaves <= 256 super-tiles (measured best at 1080p: S=8);
+    // an explicit request is a lower bound -- the counting sort (k_binning.h) keeps one LDS bin per super-tile
     int shift = 0;
-    if (c->opt_super > 0) {
+    if (c->opt_super > 0)
         while ((1 << shift) < c->opt_super) ++shift;
-    } else {
-        while ((((f->tiles_x - 1) >> shift) + 1) * (((f->tiles_y - 1) >> shift) + 1) > 256) ++shift;
-    }
+    while ((((f->tiles_x - 1) >> shift) + 1) * (((f->tiles_y - 1) >> shift) + 1) > 256) ++shift;
     f->super_shift = shift;
     f->flags = c->opt_flags;
     // sort-key range of this frame: distance^2 from cam_pos to the cloud's bounding box, as float bits
@@ -799,43 +776,41 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
     }
     MARK(2);
     if (n > 0) {
-        hipLaunchKernelGGL(k_super_counts, dim3(div_up(n, 256)), dim3(256), 0, s, sl.valA, n, sl.d_n, f.super_shift,
-                           c->shard_index, c->shard_count, sl.cnt);
-        int rc = exclusive_scan(sl, sl.cnt, sl.poff, n, sl.d_total);
+        // coarse binning as a counting sort (k_binning.h): count -> scan -> ranges -> [pair count to the host] -> place
+        const uint32_t nblk = div_up(n, BN_TILE);
+        int rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)BN_BINS * nblk + 8);
         if (rc) return rc;
+        hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift, c->shard_index,
+                           c->shard_count, f.stiles_x, sl.hist, nblk);
+        hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals);
+        hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, sl.totals, n_super, sl.sstart, sl.send, sl.d_total);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(sl.h_total, sl.d_total, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));   // waits for THIS frame's front end only; the other slot keeps running
         D = *sl.h_total;
         if ((unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
             return set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: %u super-tile pairs exceed the limit", D);
         if (D > sl.pair_cap) {
-            dev_free(sl.pkA); dev_free(sl.pkB); dev_free(sl.pvA); dev_free(sl.pvB);
+            dev_free(sl.pvA);
             sl.pair_cap = 0;
             const size_t want = (size_t)D + D / 4 + 4096;
-            if ((rc = dev_alloc(&sl.pkA, want)) || (rc = dev_alloc(&sl.pkB, want)) || (rc = dev_alloc(&sl.pvA, want)) ||
-                (rc = dev_alloc(&sl.pvB, want))) return rc;
+            if ((rc = dev_alloc(&sl.pvA, want))) return rc;
             sl.pair_cap = want;
         }
+        MARK(3);
         if (D > 0) {
-            hipLaunchKernelGGL(k_emit_pairs, dim3(div_up(n, 256)), dim3(256), 0, s, sl.valA, sl.poff, sl.d_n,
-                               f.super_shift, c->shard_index, c->shard_count, f.stiles_x, sl.pkA, sl.pvA);
+            const size_t lds = (size_t)4 * BN_ITEMS * n_super * 8 + (size_t)4 * n_super * 4;
+            hipLaunchKernelGGL(k_bin_place, dim3(nblk), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n, f.super_shift,
+                               c->shard_index, c->shard_count, f.stiles_x, n_super, sl.hist, sl.sstart, nblk,
+                               (uint32_t)sl.pair_cap, sl.pvA);
             HIP_TRY(hipGetLastError());
         }
-    }
-    MARK(3);
-    if (D > 0) {
-        int bits = 1;
-        while ((1 << bits) < n_super) ++bits;
-        int rc = radix_sort(sl, sl.pkA, sl.pvA, sl.pkB, sl.pvB, D, bits, true, (uint32_t*)nullptr, RS_XCD_BIN != 0);
-        if (rc) return rc;
+    } else {
+        HIP_TRY(hipMemsetAsync(sl.sstart, 0, ((size_t)n_super + 1) * 4, s));
+        HIP_TRY(hipMemsetAsync(sl.send, 0, ((size_t)n_super + 1) * 4, s));
+        MARK(3);
     }
     MARK(4);
-    HIP_TRY(hipMemsetAsync(sl.sstart, 0, ((size_t)n_super + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(sl.send, 0, ((size_t)n_super + 1) * 4, s));
-    if (D > 0) {
-        hipLaunchKernelGGL(k_super_ranges, dim3(div_up(D, 256)), dim3(256), 0, s, sl.pkA, D, sl.sstart, sl.send);
-        HIP_TRY(hipGetLastError());
-    }
     MARK(5);
     if (local_tiles > 0) {
         HIP_TRY(hipStreamWaitEvent(s, sl.ev_user, 0));

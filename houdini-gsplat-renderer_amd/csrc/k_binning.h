@@ -1,46 +1,43 @@
-// k_binning.h -- coarse binning: splat -> SUPER-tile pairs in depth order, and
-// per-super-tile ranges.
+// k_binning.h -- coarse binning: depth-ordered splats -> per-SUPER-tile front-to-back lists.
 //
 // The GL rasteriser did all binning implicitly for the reference (one instanced
 // quad per splat, /root/reference/gsplat_plugin/src/GSplatRenderer.C:647).  Here
-// only a COARSE (super-tile = SxS tiles, <= 256 of them) list is materialised:
-// pairs are emitted in depth-rank order, ONE stable 8-bit radix pass on the
-// super-tile id turns them into front-to-back lists, and the blend kernel
-// filters each list down to its own 16x16 tile on the fly (wave ballots), so it
-// stops reading the moment the tile is opaque.  Materialising per-tile lists
-// instead cost 75 M pairs x 2 radix passes on the 6 M-splat scene, 93 % of which
-// were never consumed (profiles/r1_baseline_v1).
-// Roofline: HBM (12 B written per pair; 12 B read per splat, all coalesced).
+// only a COARSE (super-tile = SxS tiles, <= 256 of them) list is materialised, and the
+// blend kernel filters each list down to its own 16x16 tile on the fly (wave ballots), so it
+// stops reading the moment the tile is opaque.  Materialising per-tile lists instead cost
+// 75 M pairs x 2 radix passes on the 6 M-splat scene, 93 % of which were never consumed
+// (profiles/r1_baseline_v1).
+//
+// The lists are built by a counting sort that never materialises (key, value) pairs:
+//   k_bin_count   per block of BN_TILE depth-ranked splats: how many of its (splat, super-tile)
+//                 pairs fall into each super-tile            -> hist[super][block]
+//   k_scan_rows   (k_sort.h) exclusive scan of every super-tile's row over the blocks
+//   k_bin_ranges  exclusive scan of the per-super-tile totals -> list ranges, pair count D
+//   k_bin_place   every block re-derives its pairs and writes (splat index, tile rect) straight
+//                 to its final list position, in depth order
+// versus emit pairs -> radix pass (histogram + scatter) -> find ranges: 8 B written per pair
+// instead of 12 B written + 16 B read + 12 B written, and 4 launches instead of 11.
+// Roofline: HBM / L2 write combining (8 B per pair, scattered over <= 256 open lists).
 #pragma once
 #include "gsr_device.h"
+#include "k_sort.h"
 
-// The depth sort carries a uint2 payload (splat index, packed tile rect), so everything
-// below reads its inputs coalesced in depth-rank order -- no gathers.
+#define BN_THREADS 256
+#ifndef BN_ITEMS
+#define BN_ITEMS 4                         // splats per thread (measured on C4: 2 -> 0.056 ms place + 0.058 count/scan, 4 -> 0.065 + 0.044, 8 -> 0.081 + 0.041)
+#endif
+#define BN_TILE (BN_THREADS * BN_ITEMS)    // splats per block
+#define BN_WAVE_ITEMS (BN_TILE / 4)        // wave w owns the w-th contiguous quarter of the block
+#define BN_BINS 256                        // super-tiles are at most 256 (GsrFrame.super is chosen that way)
 
-// cnt[r] = number of owned super-tiles of the splat at depth rank r
-__global__ void __launch_bounds__(256)
-k_super_counts(const uint2* __restrict__ sorted, uint32_t n_max, const uint32_t* __restrict__ n_dev, int shift,
-               int shard_index, int shard_count, uint32_t* __restrict__ cnt)
+#define BN_BIG 8                           // a splat covering more super-tiles than this is expanded by the whole wave
+
+// visit the owned super-tiles of a packed tile rect
+template <typename F>
+__device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, int shard_index, int shard_count, int stiles_x, F&& fn)
 {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= n_max) return;
-    // n_dev = number of splats that survived the compacting first sort pass; the scan runs over n_max
-    cnt[r] = (r < *n_dev) ? (uint32_t)gsr_rect_supers(sorted[r].y, shift, shard_index, shard_count) : 0u;
-}
-
-// one lane per depth rank writes its (super-tile id ; splat index, rect) pairs at poff[r]
-__global__ void __launch_bounds__(256)
-k_emit_pairs(const uint2* __restrict__ sorted, const uint32_t* __restrict__ poff, const uint32_t* __restrict__ n_dev,
-             int shift, int shard_index, int shard_count, int stiles_x, uint32_t* __restrict__ pkeys,
-             uint2* __restrict__ pvals)
-{
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= *n_dev) return;
-    const uint2 v = sorted[r];
-    const uint32_t rc = v.y;
     const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = (rc >> 16) & 255, y1 = rc >> 24;
     if (x1 < x0 || y1 < y0) return;
-    uint32_t o = poff[r];
     const int sx0 = x0 >> shift, sx1 = x1 >> shift;
     for (int sy = y0 >> shift; sy <= (y1 >> shift); ++sy) {
         if (shard_count > 1) {
@@ -48,24 +45,147 @@ k_emit_pairs(const uint2* __restrict__ sorted, const uint32_t* __restrict__ poff
             if (gsr_owned_rows(lo, hi, shard_index, shard_count) == 0) continue;
         }
         const uint32_t rowkey = (uint32_t)sy * (uint32_t)stiles_x;
-        for (int sx = sx0; sx <= sx1; ++sx) {
-            pkeys[o] = rowkey + (uint32_t)sx;
-            pvals[o] = v;
-            ++o;
+        for (int sx = sx0; sx <= sx1; ++sx) fn(rowkey + (uint32_t)sx);
+    }
+}
+
+// All (splat, super-tile) pairs of a GROUP of 64 depth-consecutive splats (lane = splat, v = its
+// (index, rect)): fn(owner_lane, owner_v, super_tile).  The nearest splats cover dozens of
+// super-tiles while the median covers one or two, and depth order puts all the big ones into the
+// same few groups -- so a lane walks its own rect only when it is small; the rect of a big splat
+// is spread over the 64 lanes (the caller's fn never assumes owner_lane == its own lane).
+template <typename F>
+__device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, int shard_index, int shard_count, int stiles_x, F&& fn)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t rc = v.y;
+    const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = rc >> 16 & 255, y1 = rc >> 24;
+    const bool some = x1 >= x0 && y1 >= y0;
+    const int area = some ? ((x1 >> shift) - (x0 >> shift) + 1) * ((y1 >> shift) - (y0 >> shift) + 1) : 0;
+    const bool big = area > BN_BIG;
+    if (!big) bn_for_each_super(rc, shift, shard_index, shard_count, stiles_x, [&](uint32_t d) { fn(lane, v, d); });
+    unsigned long long bigs = __ballot(big);
+    while (bigs) {
+        const int L = __builtin_ctzll(bigs);
+        bigs &= bigs - 1ull;
+        const uint2 vL = make_uint2((uint32_t)__shfl((int)v.x, L, 64), (uint32_t)__shfl((int)v.y, L, 64));
+        const uint32_t r = vL.y;
+        const int X0 = r & 255, Y0 = (r >> 8) & 255, X1 = (r >> 16) & 255, Y1 = r >> 24;
+        const int sx0 = X0 >> shift, sy0 = Y0 >> shift;
+        const int w = (X1 >> shift) - sx0 + 1, h = (Y1 >> shift) - sy0 + 1;
+        for (int t = lane; t < w * h; t += 64) {
+            const int ry = t / w, sy = sy0 + ry, sx = sx0 + (t - ry * w);
+            if (shard_count > 1) {
+                const int lo = max(Y0, sy << shift), hi = min(Y1, ((sy + 1) << shift) - 1);
+                if (gsr_owned_rows(lo, hi, shard_index, shard_count) == 0) continue;
+            }
+            fn(L, vL, (uint32_t)sy * (uint32_t)stiles_x + (uint32_t)sx);
         }
     }
 }
 
-// boundaries of equal-key runs in the sorted pair list
-__global__ void __launch_bounds__(256)
-k_super_ranges(const uint32_t* __restrict__ keys, uint32_t n, int32_t* __restrict__ sstart,
-               int32_t* __restrict__ send)
+// sorted = (splat index, packed tile rect) in depth-rank order; *n_dev of them exist (the grid is
+// sized for the host-side upper bound: surplus blocks publish zeros).  Blocks are handed to XCDs
+// in contiguous eighths (rs_tile_of_block), like the depth sort's.
+__global__ void __launch_bounds__(BN_THREADS)
+k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, int shard_index,
+            int shard_count, int stiles_x, uint32_t* __restrict__ hist, uint32_t nblk)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = keys[i];
-    if (i == 0 || keys[i - 1] != k) sstart[k] = (int32_t)i;
-    if (i == n - 1 || keys[i + 1] != k) send[k] = (int32_t)(i + 1);
+    __shared__ uint32_t h[4][BN_BINS];
+    const int wave = threadIdx.x >> 6;
+    for (int b = threadIdx.x; b < 4 * BN_BINS; b += BN_THREADS) (&h[0][0])[b] = 0;
+    __syncthreads();
+    const uint32_t n = *n_dev;
+    const uint32_t nb = (n + BN_TILE - 1) / BN_TILE;
+    const uint32_t tile = blockIdx.x < nb ? rs_tile_of_block(blockIdx.x, nb, true) : blockIdx.x;
+    if (blockIdx.x < nb) {
+        const uint32_t base = tile * BN_TILE;
+#pragma unroll 2
+        for (int k = 0; k < BN_ITEMS; ++k) {
+            const uint32_t i = base + k * BN_THREADS + threadIdx.x;   // (every wave sees 64 consecutive splats)
+            const uint2 v = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
+            bn_group_pairs(v, shift, shard_index, shard_count, stiles_x,
+                           [&](int, uint2, uint32_t d) { atomicAdd(&h[wave][d], 1u); });
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < BN_BINS; b += BN_THREADS)
+        hist[(size_t)b * nblk + tile] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
+}
+
+// one workgroup: list range of every super-tile = exclusive scan of the totals; *d_total = pair count
+__global__ void __launch_bounds__(BN_BINS)
+k_bin_ranges(const uint32_t* __restrict__ totals, int n_super, int32_t* __restrict__ sstart, int32_t* __restrict__ send,
+             uint32_t* __restrict__ d_total)
+{
+    __shared__ uint32_t s_wave[4];
+    const uint32_t v = ((int)threadIdx.x < n_super) ? totals[threadIdx.x] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan_256(v, s_wave, &tot);
+    if ((int)threadIdx.x < n_super) { sstart[threadIdx.x] = (int32_t)ex; send[threadIdx.x] = (int32_t)(ex + v); }
+    if (threadIdx.x == 0) *d_total = tot;
+}
+
+// Placement.  Inside a list the order must be the depth order of the splats, so the pairs of one
+// super-tile are ranked by splat position: across blocks by the scanned histogram, across the four
+// waves of a block by per-wave counts, and inside a wave through 64-bit LANE MASKS in LDS -- for
+// every group of 64 consecutive splats (lane = splat) and every super-tile, the set of lanes whose
+// splat covers it.  Every lane ORs its bit into the masks of the super-tiles it covers (A); the
+// counts of the masks give the wave bases (S); and a pair's list position is its wave base + the
+// population of the earlier groups' masks + the number of lower lanes in its own group's mask (B).
+// Nothing is mutated between A and B, so a wave pays a handful of dependent LDS round trips in
+// total instead of several per group.
+// Dynamic LDS: lmask[4 waves][BN_ITEMS groups][ns] (u64) followed by wbase[4][ns] (u32), ns = n_super.
+__global__ void __launch_bounds__(BN_THREADS)
+k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, int shard_index,
+            int shard_count, int stiles_x, int ns, const uint32_t* __restrict__ offs, const int32_t* __restrict__ sstart,
+            uint32_t nblk, uint32_t cap, uint2* __restrict__ out)
+{
+    extern __shared__ unsigned long long bn_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long* lmask = bn_lds + (size_t)wave * BN_ITEMS * ns;                       // [g][d] of this wave
+    uint32_t* wbase_all = reinterpret_cast<uint32_t*>(bn_lds + (size_t)4 * BN_ITEMS * ns);   // [wave][d]
+    uint32_t* wbase = wbase_all + wave * ns;
+    const uint32_t n = *n_dev;
+    const uint32_t nb = (n + BN_TILE - 1) / BN_TILE;
+    if (blockIdx.x >= nb) return;
+    const uint32_t tile = rs_tile_of_block(blockIdx.x, nb, true);
+    const uint32_t first = tile * BN_TILE + wave * BN_WAVE_ITEMS;
+    for (int b = lane; b < BN_ITEMS * ns; b += 64) lmask[b] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint2 v[BN_ITEMS];
+#pragma unroll
+    for (int g = 0; g < BN_ITEMS; ++g) {   // (A)
+        const uint32_t i = first + g * 64 + lane;
+        v[g] = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
+        bn_group_pairs(v[g], shift, shard_index, shard_count, stiles_x,
+                       [&](int L, uint2, uint32_t d) { atomicOr(&lmask[g * ns + d], 1ull << L); });
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int d = lane; d < ns; d += 64) {  // (S) this wave's pair count per super-tile
+        uint32_t c = 0;
+#pragma unroll
+        for (int g = 0; g < BN_ITEMS; ++g) c += (uint32_t)__builtin_popcountll(lmask[g * ns + d]);
+        wbase[d] = c;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < ns; d += BN_THREADS) {   // counts -> first list position of each wave
+        uint32_t p = (uint32_t)sstart[d] + offs[(size_t)d * nblk + tile];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const uint32_t c = wbase_all[w * ns + d]; wbase_all[w * ns + d] = p; p += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < BN_ITEMS; ++g) {   // (B)
+        bn_group_pairs(v[g], shift, shard_index, shard_count, stiles_x, [&](int L, uint2 vL, uint32_t d) {
+            uint32_t pos = wbase[d] + (uint32_t)__builtin_popcountll(lmask[g * ns + d] & ((1ull << L) - 1ull));
+#pragma unroll
+            for (int e = 0; e < g; ++e) pos += (uint32_t)__builtin_popcountll(lmask[e * ns + d]);
+            if (pos < cap) out[pos] = vL;
+        });
+    }
 }
 
 // root side of the multi-GPU path: de-interleave gathered band images.

@@ -1,4 +1,4 @@
-// k_sort.h -- device-wide exclusive scan and stable LSD radix sort (8-bit digits)
+// k_sort.h -- stable LSD radix sort (8- or 9-bit digits)
 // of (u32 key, u32 value) pairs.
 //
 // Replaces tbb::parallel_sort of the index array in argsortByDistance
@@ -41,10 +41,8 @@ __device__ __forceinline__ uint32_t rs_tile_of_block(uint32_t b, uint32_t nb, bo
 }
 
 // ---------------------------------------------------------------------------
-// exclusive scan, three kernels (reduce / scan partials / downsweep)
+// block-level scan helpers
 #define SC_THREADS 256
-#define SC_ITEMS 8
-#define SC_TILE (SC_THREADS * SC_ITEMS)  // 2048
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
@@ -75,76 +73,6 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_
     __syncthreads();
     *total = tot;
     return base + inc - v;
-}
-
-__global__ void __launch_bounds__(SC_THREADS)
-k_scan_reduce(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ partial)
-{
-    __shared__ uint32_t s_wave[4];
-    const uint32_t base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
-    uint32_t sum = 0;
-    if (base + SC_ITEMS <= n) {
-        const uint4* p = reinterpret_cast<const uint4*>(in + base);
-        uint4 a = p[0], b = p[1];
-        sum = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
-    } else {
-        for (int k = 0; k < SC_ITEMS; ++k)
-            if (base + k < n) sum += in[base + k];
-    }
-    uint32_t tot;
-    (void)block_excl_scan_256(sum, s_wave, &tot);
-    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
-}
-
-// single workgroup: in-place exclusive scan of partial[0..m), grand total -> *total
-__global__ void __launch_bounds__(SC_THREADS)
-k_scan_partials(uint32_t* __restrict__ partial, uint32_t m, uint32_t* __restrict__ total)
-{
-    __shared__ uint32_t s_wave[4];
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < m; base += SC_THREADS) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = (i < m) ? partial[i] : 0u;
-        uint32_t tot;
-        uint32_t ex = block_excl_scan_256(v, s_wave, &tot);
-        if (i < m) partial[i] = carry + ex;
-        carry += tot;
-    }
-    if (threadIdx.x == 0 && total) *total = carry;
-}
-
-__global__ void __launch_bounds__(SC_THREADS)
-k_scan_down(const uint32_t* in, uint32_t n, const uint32_t* __restrict__ partial,
-            uint32_t* out)  // in == out allowed (each thread reads its items before writing them)
-{
-    __shared__ uint32_t s_wave[4];
-    const uint32_t base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
-    uint32_t v[SC_ITEMS];
-    uint32_t sum = 0;
-    if (base + SC_ITEMS <= n) {
-        const uint4* p = reinterpret_cast<const uint4*>(in + base);
-        uint4 a = p[0], b = p[1];
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < SC_ITEMS; ++k) v[k] = (base + k < n) ? in[base + k] : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < SC_ITEMS; ++k) sum += v[k];
-    uint32_t tot;
-    uint32_t ex = block_excl_scan_256(sum, s_wave, &tot) + partial[blockIdx.x];
-    uint32_t o[SC_ITEMS];
-#pragma unroll
-    for (int k = 0; k < SC_ITEMS; ++k) { o[k] = ex; ex += v[k]; }
-    if (base + SC_ITEMS <= n) {
-        uint4* q = reinterpret_cast<uint4*>(out + base);
-        q[0] = make_uint4(o[0], o[1], o[2], o[3]);
-        q[1] = make_uint4(o[4], o[5], o[6], o[7]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < SC_ITEMS; ++k)
-            if (base + k < n) out[base + k] = o[k];
-    }
 }
 
 // ---------------------------------------------------------------------------

@@ -161,7 +161,8 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        that matters, a static viewport redraw; the sorted list holds only the splats visible
                                        to the camera that sorted, so a pure rotation re-sorts */
 #define GSR_OPT_SUPER_TILE      4   /* super-tile edge in tiles: 0 = auto (smallest power of two giving
-                                       <= 256 super-tiles), or 1,2,4,8,16 */
+                                       <= 256 super-tiles), or a lower bound 1,2,4,8,16 (raised as needed
+                                       to stay within 256 super-tiles) */
 #define GSR_OPT_FRAMES_IN_FLIGHT 6  /* 1 or 2 (default 2): with 2, frame f+1's memory-bound front end
                                        (preprocess, sorts, binning) overlaps frame f's blend kernel on the GPU.
                                        Per-frame results and their order on the context stream are unchanged. */

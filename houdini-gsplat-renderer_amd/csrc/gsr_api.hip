@@ -84,8 +84,10 @@ struct FrameSlot {
     // small device/host mailboxes
     unsigned long long* counters = nullptr;  // [0] visible [1] records gathered [2] running [3] entries scanned [4] running
     uint32_t* d_total = nullptr;
-    uint32_t* h_total = nullptr;             // pinned
-    unsigned long long* h_counters = nullptr;  // pinned
+    uint32_t* h_total = nullptr;             // pinned + mapped: k_bin_ranges writes the pair count here
+    uint32_t* h_total_dev = nullptr;         // its device-side address
+    unsigned long long* h_counters = nullptr;  // pinned + mapped: k_sum_work writes the frame's bookkeeping here
+    unsigned long long* h_counters_dev = nullptr;
     // depth-sort cache (argsortByDistance semantics)
     // The cached order covers exactly the splats visible to the camera that sorted, so it is reused
     // only for an identical frame description (the reference re-sorts on any camera translation,
@@ -103,6 +105,7 @@ struct FrameSlot {
     uint64_t frame_id = 0;             // 1-based id of that frame, 0 = never used
     hipEvent_t ev[GSR_STAGE_EVENTS];
     bool ev_pending = false;
+    bool ev_all = false;             // all seven stage events were recorded (timing level 2), not just the blend kernel's
     bool ev_ok = false;
 };
 
@@ -186,8 +189,11 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_n), sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.d_n, 0, sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.totals), 512 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), 8 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess;
+    ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_total_dev), sl.h_total, 0) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess;
+    ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_counters_dev), sl.h_counters, 0) == hipSuccess;
+    if (ok) for (int j = 0; j < 8; ++j) sl.h_counters[j] = 0;
     ok = ok && hipMemset(sl.counters, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
     if (ok) {
         for (int k = 0; k < GSR_STAGE_EVENTS; ++k) sl.ev[k] = nullptr;
@@ -281,7 +287,7 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
     if (!c) return set_err(GSR_E_INVALID, "gsr_set_option: ctx is NULL");
     switch (option) {
     case GSR_OPT_XCD_SWIZZLE: c->opt_swizzle = value ? 1 : 0; break;
-    case GSR_OPT_STAGE_TIMING: c->opt_timing = value ? 1 : 0; break;
+    case GSR_OPT_STAGE_TIMING: c->opt_timing = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_SORT_CACHE:
         c->opt_sort_cache = value ? 1 : 0;
         for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
@@ -654,6 +660,13 @@ static void harvest_slot(gsr_context* c, FrameSlot& sl)
     hipEvent_t* e = sl.ev;
     if (hipEventSynchronize(e[6]) != hipSuccess) return;
     float ms[6] = {0, 0, 0, 0, 0, 0};
+    if (!sl.ev_all) {   // only the blend kernel was bracketed
+        if (hipEventElapsedTime(&ms[5], e[5], e[6]) != hipSuccess) ms[5] = 0.0f;
+        c->st.ms_blend = ms[5];
+        c->st.blend_ms_total += ms[5];
+        c->st.blend_launches += 1;
+        return;
+    }
     for (int k = 0; k < 6; ++k)
         if (hipEventElapsedTime(&ms[k], e[k], e[k + 1]) != hipSuccess) ms[k] = 0.0f;
     c->st.ms_preprocess = ms[0];
@@ -701,7 +714,8 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
     const bool timing = c->opt_timing != 0;
     if (timing) harvest_slot(c, sl);
     hipEvent_t* ev = sl.ev;
-#define MARK(k) do { if (timing) HIP_TRY(hipEventRecord(ev[k], s)); } while (0)
+    const bool timing_all = c->opt_timing >= 2;   // level 1 brackets only the blend kernel (events 5 and 6)
+#define MARK(k) do { if (timing && (timing_all || (k) >= 5)) HIP_TRY(hipEventRecord(ev[k], s)); } while (0)
 
     // the caller's stream position now: the blend kernel (the only writer of caller-visible memory)
     // waits for it, so an output buffer that earlier work on the public stream still reads is safe
@@ -783,9 +797,8 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
         hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift, c->shard_index,
                            c->shard_count, f.stiles_x, sl.hist, nblk);
         hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals);
-        hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, sl.totals, n_super, sl.sstart, sl.send, sl.d_total);
+        hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, sl.totals, n_super, sl.sstart, sl.send, sl.h_total_dev);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(sl.h_total, sl.d_total, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));   // waits for THIS frame's front end only; the other slot keeps running
         D = *sl.h_total;
         if ((unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
@@ -828,12 +841,11 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
         HIP_TRY(hipGetLastError());
     }
     MARK(6);
-    if (local_tiles > 0) {
-        hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(256), 0, s, sl.tile_work, local_tiles, sl.counters);
-        HIP_TRY(hipGetLastError());
-    }
+    hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, local_tiles, sl.counters, sl.d_n,
+                       sl.h_counters_dev);
+    HIP_TRY(hipGetLastError());
 #undef MARK
-    if (timing) sl.ev_pending = true;
+    if (timing) { sl.ev_pending = true; sl.ev_all = timing_all; }
     sl.last_supers = n_super;
     sl.last_tiles_x = f.tiles_x;
     sl.last_local_ty = f.local_tiles_y;
@@ -842,10 +854,7 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
     c->st.frames += 1;
     c->frame_no += 1;
     sl.frame_id = c->frame_no;
-    // counters of this frame travel with the stream; they are read in gsr_get_stats
-    HIP_TRY(hipMemcpyAsync(sl.h_counters, sl.counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    sl.h_counters[6] = 0;
-    HIP_TRY(hipMemcpyAsync(&sl.h_counters[6], sl.d_n, 4, hipMemcpyDeviceToHost, s));   // visible splats of this frame
+    // (the frame's counters were written to the host mirror by k_sum_work; they are read in gsr_get_stats)
     if (!out_is_device) {
         HIP_TRY(hipMemcpyAsync(rgba_out, sl.fb, out_px * 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));

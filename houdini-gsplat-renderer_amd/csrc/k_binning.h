@@ -113,17 +113,17 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
         hist[(size_t)b * nblk + tile] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
 }
 
-// one workgroup: list range of every super-tile = exclusive scan of the totals; *d_total = pair count
+// one workgroup: list range of every super-tile = exclusive scan of the totals; *host_total = pair count
 __global__ void __launch_bounds__(BN_BINS)
 k_bin_ranges(const uint32_t* __restrict__ totals, int n_super, int32_t* __restrict__ sstart, int32_t* __restrict__ send,
-             uint32_t* __restrict__ d_total)
+             volatile uint32_t* __restrict__ host_total /* pinned, mapped */)
 {
     __shared__ uint32_t s_wave[4];
     const uint32_t v = ((int)threadIdx.x < n_super) ? totals[threadIdx.x] : 0u;
     uint32_t tot;
     const uint32_t ex = block_excl_scan_256(v, s_wave, &tot);
     if ((int)threadIdx.x < n_super) { sstart[threadIdx.x] = (int32_t)ex; send[threadIdx.x] = (int32_t)(ex + v); }
-    if (threadIdx.x == 0) *d_total = tot;
+    if (threadIdx.x == 0) { *host_total = tot; __threadfence_system(); }   // the host sizes the list buffer from it
 }
 
 // Placement.  Inside a list the order must be the depth order of the splats, so the pairs of one

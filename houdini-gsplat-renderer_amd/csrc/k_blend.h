@@ -306,15 +306,26 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
 // One workgroup sums the per-tile bookkeeping into counters[1] (records gathered, this frame),
 // [2] (records, running total), [3] (entries scanned, this frame), [4] (entries, running total),
 // [5] (wave-record evaluations, running total) -- a handful of atomics per frame instead of per
-// tile (same-address atomics serialise at ~12 ns each on MI355X).
-__global__ void __launch_bounds__(256)
-k_sum_work(const uint4* __restrict__ tile_work, int n_tiles, unsigned long long* __restrict__ counters)
+// tile (same-address atomics serialise at ~12 ns each on MI355X).  Last kernel of a frame.
+#define SW_THREADS 1024
+__global__ void __launch_bounds__(SW_THREADS)
+k_sum_work(const uint4* __restrict__ tile_work, int n_tiles, unsigned long long* __restrict__ counters,
+           const uint32_t* __restrict__ n_visible, volatile unsigned long long* __restrict__ host /* pinned, mapped: [7] */)
 {
     __shared__ unsigned long long s_sum[3];
     if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
     __syncthreads();
     unsigned long long sc = 0, fe = 0, ev = 0;
-    for (int i = threadIdx.x; i < n_tiles; i += 256) { const uint4 w = tile_work[i]; sc += w.x; fe += w.y; ev += w.z; }
+    for (int i0 = 0; i0 < n_tiles; i0 += 4 * SW_THREADS) {
+        uint4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {   // independent loads: one memory round trip per 4096 tiles
+            const int i = i0 + u * SW_THREADS + (int)threadIdx.x;
+            w[u] = i < n_tiles ? tile_work[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sc += w[u].x; fe += w[u].y; ev += w[u].z; }
+    }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); atomicAdd(&s_sum[2], ev); }
@@ -325,5 +336,12 @@ k_sum_work(const uint4* __restrict__ tile_work, int n_tiles, unsigned long long*
         counters[3] = s_sum[0];
         atomicAdd(&counters[4], s_sum[0]);
         atomicAdd(&counters[5], s_sum[2]);
+        // the frame's bookkeeping goes straight to the host mirror (read in gsr_get_stats after a stream sync):
+        // no copy-engine packets at the end of every frame
+        __threadfence();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) host[k] = counters[k];
+        host[6] = (unsigned long long)*n_visible;
+        __threadfence_system();
     }
 }

@@ -155,7 +155,8 @@ int  gsr_stats_reset(gsr_context* ctx);
 
 /* ---- knobs (performance only; never change pixels) ---------------------- */
 #define GSR_OPT_XCD_SWIZZLE     1   /* 0/1: XCD-aware tile -> workgroup mapping in the blend kernel */
-#define GSR_OPT_STAGE_TIMING    2   /* 0/1: record per-stage HIP events (default 1) */
+#define GSR_OPT_STAGE_TIMING    2   /* HIP events on the frame's stream: 0 = none, 1 = around the blend kernel only
+                                       (default; feeds gsr_stats.blend_ms_total), 2 = around every stage (ms_* fields) */
 #define GSR_OPT_SORT_CACHE      3   /* 0/1: skip the depth sort when the frame description (camera, shard, geometry) is
                                        unchanged -- argsortByDistance's caching (src/GSplatRenderer.C:179-186) for the case
                                        that matters, a static viewport redraw; the sorted list holds only the splats visible

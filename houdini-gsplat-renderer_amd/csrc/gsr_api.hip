@@ -5,12 +5,14 @@
 //   K1 k_preprocess        N splats -> record, key, (idx, rect)            (HBM)
 //   depth sort             3 x {hist, row scan, scatter}; the FIRST pass drops culled splats,
 //                          so everything downstream runs on the visible ones (count in HBM)
-//   K2 k_super_counts+scan super-tile pairs per depth rank -> offsets, D   (HBM)
-//      [D read back: 4-byte D2H + stream sync -- sizes the pair buffers]
-//   K3 k_emit_pairs        D (super-tile, splat) pairs in depth order      (HBM)
-//   bin sort               ONE stable 8-bit radix pass on the super-tile id (HBM)
-//   K5 k_super_ranges      list boundaries + per-entry tile rect
+//   binning (k_binning.h)  counting sort of the (splat, super-tile) pairs into per-super-tile, depth-ordered lists:
+//      k_bin_count         pairs per (block of depth-consecutive splats, super-tile)
+//      k_scan_rows         per super-tile: exclusive scan over the blocks
+//      k_bin_ranges        list ranges; pair count D -> mapped host memory
+//      [stream sync: the host sizes the list buffer from D]
+//      k_bin_place         every pair's (idx, rect) entry straight to its list position
 //   K6 k_blend             per-tile list filtering + front-to-back compositing (VALU/LDS)
+//   k_sum_work             per-tile bookkeeping -> counters -> mapped host memory
 // Reference counterpart: GSplatRenderer::render + the GLSL program it drives
 // (/root/reference/gsplat_plugin/src/GSplatRenderer.C:534-658).
 #include <hip/hip_runtime.h>

@@ -62,12 +62,14 @@ typedef struct gsr_camera {
 typedef struct gsr_stats {
     int64_t n_splats;          /* uploaded */
     int64_t n_visible;         /* survived w/z culling and have >=1 tile */
-    int64_t pairs_total;       /* D: (super-tile, splat) pairs emitted and sorted */
+    int64_t pairs_total;       /* D: (super-tile, splat) list entries of the frame */
     int64_t pairs_consumed;    /* records gathered by the blend kernel before early-out */
     int32_t tiles_x, tiles_y;  /* tile grid of this context's shard */
     int32_t record_bytes;      /* bytes of one projected record as gathered by the blend kernel (48) */
     int32_t pair_bytes;        /* bytes of one list entry as scanned by the blend kernel (idx + rect = 8) */
-    float ms_preprocess, ms_depth_sort, ms_emit, ms_tile_sort, ms_blend, ms_total; /* last frame, HIP events */
+    float ms_preprocess, ms_depth_sort, ms_emit, ms_tile_sort, ms_blend, ms_total; /* last frame, HIP events (timing
+                                  level 2; level 1 fills ms_blend only): ms_emit = binning count + scans + pair count
+                                  to the host, ms_tile_sort = binning placement */
     double blend_ms_total;     /* sum over all frames since gsr_stats_reset */
     int64_t blend_launches;
     int64_t blend_pairs_consumed_total;

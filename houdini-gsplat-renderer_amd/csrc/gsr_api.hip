@@ -63,6 +63,7 @@ struct FrameSlot {
     hipStream_t stream = nullptr;
     hipEvent_t ev_done = nullptr;      // end of the frame on `stream`
     hipEvent_t ev_user = nullptr;      // caller's stream position at gsr_render entry
+    hipEvent_t ev_pairs = nullptr;     // the frame's pair count has reached host memory
     // per-splat frame buffers
     GsrRecord* rec = nullptr;
     uint32_t *keyA = nullptr, *keyB = nullptr;
@@ -186,6 +187,7 @@ static bool slot_init(FrameSlot& sl)
     bool ok = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&sl.ev_user, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&sl.ev_pairs, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.counters), 8 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_total), sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_n), sizeof(uint32_t)) == hipSuccess;
@@ -226,6 +228,7 @@ static void slot_destroy(FrameSlot& sl)
             if (sl.ev[k]) (void)hipEventDestroy(sl.ev[k]);
     if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
     if (sl.ev_user) (void)hipEventDestroy(sl.ev_user);
+    if (sl.ev_pairs) (void)hipEventDestroy(sl.ev_pairs);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
 }
 
@@ -801,48 +804,70 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
         hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals);
         hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, sl.totals, n_super, sl.sstart, sl.send, sl.h_total_dev);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(s));   // waits for THIS frame's front end only; the other slot keeps running
-        D = *sl.h_total;
-        if ((unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
-            return set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: %u super-tile pairs exceed the limit", D);
-        if (D > sl.pair_cap) {
-            dev_free(sl.pvA);
-            sl.pair_cap = 0;
-            const size_t want = (size_t)D + D / 4 + 4096;
-            if ((rc = dev_alloc(&sl.pvA, want))) return rc;
-            sl.pair_cap = want;
-        }
+        HIP_TRY(hipEventRecord(sl.ev_pairs, s));
+    } else {
+        HIP_TRY(hipMemsetAsync(sl.sstart, 0, ((size_t)n_super + 1) * 4, s));
+        HIP_TRY(hipMemsetAsync(sl.send, 0, ((size_t)n_super + 1) * 4, s));
+    }
+    // back end = placement + compositing.  The host needs the pair count D only to make sure the list buffer is
+    // large enough, so when a buffer exists the back end is queued SPECULATIVELY right behind the count (both
+    // kernels clamp to the buffer's capacity) and the host reads D while the GPU is already placing: the stream
+    // never drains mid-frame.  Only if D turns out to exceed the capacity (first frame, or the pair count grew by
+    // more than the 25 % headroom) is the buffer regrown and the back end run again -- before anything is returned.
+    auto back_end = [&]() -> int {
         MARK(3);
-        if (D > 0) {
+        if (n > 0) {
+            const uint32_t nblk = div_up(n, BN_TILE);
             const size_t lds = (size_t)4 * BN_ITEMS * n_super * 8 + (size_t)4 * n_super * 4;
             hipLaunchKernelGGL(k_bin_place, dim3(nblk), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n, f.super_shift,
                                c->shard_index, c->shard_count, f.stiles_x, n_super, sl.hist, sl.sstart, nblk,
                                (uint32_t)sl.pair_cap, sl.pvA);
             HIP_TRY(hipGetLastError());
         }
-    } else {
-        HIP_TRY(hipMemsetAsync(sl.sstart, 0, ((size_t)n_super + 1) * 4, s));
-        HIP_TRY(hipMemsetAsync(sl.send, 0, ((size_t)n_super + 1) * 4, s));
-        MARK(3);
+        MARK(4);
+        MARK(5);
+        if (local_tiles > 0) {
+            HIP_TRY(hipStreamWaitEvent(s, sl.ev_user, 0));
+            GsrBlendArgs a;
+            a.width = cam->width; a.height = cam->height; a.tiles_x = f.tiles_x; a.local_tiles = local_tiles;
+            a.shard_index = c->shard_index; a.shard_count = c->shard_count; a.band_rows = band_rows;
+            a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = c->opt_swizzle ? 1 : 0; a.flags = c->opt_flags;
+            a.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
+            const unsigned grid = a.use_map ? (unsigned)c->map_grid : (unsigned)local_tiles;
+            if (d_depth)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<true>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
+                                   sl.send, sl.rec, reinterpret_cast<float4*>(target), sl.tile_work, sl.zwin, d_depth);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
+                                   sl.send, sl.rec, reinterpret_cast<float4*>(target), sl.tile_work, sl.zwin, d_depth);
+            HIP_TRY(hipGetLastError());
+        }
+        MARK(6);
+        return GSR_OK;
+    };
+    const bool speculative = n > 0 && sl.pair_cap > 0;
+    if (speculative || n == 0) {
+        int rc = back_end();
+        if (rc) return rc;
     }
-    MARK(4);
-    MARK(5);
-    if (local_tiles > 0) {
-        HIP_TRY(hipStreamWaitEvent(s, sl.ev_user, 0));
-        GsrBlendArgs a;
-        a.width = cam->width; a.height = cam->height; a.tiles_x = f.tiles_x; a.local_tiles = local_tiles;
-        a.shard_index = c->shard_index; a.shard_count = c->shard_count; a.band_rows = band_rows;
-        a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = c->opt_swizzle ? 1 : 0; a.flags = c->opt_flags;
-        const unsigned grid = a.use_map ? (unsigned)c->map_grid : (unsigned)local_tiles;
-        if (d_depth)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<true>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
-                               sl.send, sl.rec, reinterpret_cast<float4*>(target), sl.tile_work, sl.zwin, d_depth);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
-                               sl.send, sl.rec, reinterpret_cast<float4*>(target), sl.tile_work, sl.zwin, d_depth);
-        HIP_TRY(hipGetLastError());
+    if (n > 0) {
+        HIP_TRY(hipEventSynchronize(sl.ev_pairs));   // the pair count is in host memory; the GPU carries on
+        D = *sl.h_total;
+        if ((unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
+            return set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: %u super-tile pairs exceed the limit", D);
+        if (D > sl.pair_cap || !speculative) {
+            if (D > sl.pair_cap) {
+                dev_free(sl.pvA);   // (hipFree waits for the device: a speculative back end has finished by now)
+                sl.pair_cap = 0;
+                const size_t want = (size_t)D + D / 4 + 4096;
+                int rc = dev_alloc(&sl.pvA, want);
+                if (rc) return rc;
+                sl.pair_cap = want;
+            }
+            int rc = back_end();
+            if (rc) return rc;
+        }
     }
-    MARK(6);
     hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, local_tiles, sl.counters, sl.d_n,
                        sl.h_counters_dev);
     HIP_TRY(hipGetLastError());

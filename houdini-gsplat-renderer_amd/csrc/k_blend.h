@@ -49,6 +49,7 @@ struct GsrBlendArgs {
     int32_t stiles_x;
     int32_t use_map;            // blockIdx -> tile through tile_map (XCD-aware order)
     int32_t flags;              // GSR_FLAG_*
+    int32_t list_cap;           // entries the list buffer holds (a speculative launch may see ranges beyond it)
 };
 
 // Staging layout: one list PER QUADRANT (= per wave), holding the round's records that reach that
@@ -98,7 +99,8 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
 
     const int st = (gty >> a.super_shift) * a.stiles_x + (tx >> a.super_shift);
     const int s = sstart[st];
-    const int n = send[st] - s;
+    const int e_ = send[st] < a.list_cap ? send[st] : a.list_cap;
+    const int n = e_ > s ? e_ - s : 0;
 
     gsr_v2f C01 = {0.0f, 0.0f}, CA = {0.0f, 0.0f};   // {C0, C1}, {C2, A}: the accumulators as two register pairs
     bool wave_done = false;

@@ -404,3 +404,34 @@ def test_wireframe_overlay(pkg, oracle, engine):
     cam = pkg.camera.make_camera(640, 400, sh_order=3, frame=6, distance=1.2)   # some splats behind the eye
     engine.upload(big)
     assert np.array_equal(engine.render_wire(cam), oracle.render_wire(big, cam))
+
+
+def test_list_buffer_regrows_behind_a_speculative_back_end(pkg, oracle):
+    """The back end (placement + compositing) is queued before the host knows the frame's pair count,
+    clamped to the list buffer's capacity; when the count exceeds it the buffer is regrown and the back
+    end re-run before gsr_render returns.  A frame with few pairs followed by frames with many more
+    (two successively bigger scenes) must still be exact."""
+    eng = pkg.Engine(0)
+    try:
+        for fif in (1, 2):
+            eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, fif)
+            small = pkg.scenes.make_scene(500, seed=5, sh=False)
+            eng.upload(small)
+            eng.render(pkg.camera.make_camera(128, 96, sh_order=0, frame=0))
+            d0 = eng.stats()["pairs_total"]
+            big = pkg.scenes.make_scene(60000, seed=6, sh=True)
+            eng.upload(big)
+            cam = pkg.camera.make_camera(800, 600, sh_order=3, frame=2)
+            img = eng.render(cam)
+            d1 = eng.stats()["pairs_total"]
+            assert d1 > 4 * max(d0, 1)
+            _check_image(img, oracle.render(big, cam))
+            assert np.array_equal(img, eng.render(cam))      # now non-speculative growth is over: same pixels
+            huge = pkg.scenes.make_scene(300000, seed=7, sh=True)            # 5x the splats on 4.3x the pixels
+            eng.upload(huge)
+            cam2 = pkg.camera.make_camera(1920, 1080, sh_order=3, frame=2)
+            img2 = eng.render(cam2)
+            assert eng.stats()["pairs_total"] > 2 * d1
+            _check_image(img2, oracle.render(huge, cam2, threads=oracle.max_threads()))
+    finally:
+        eng.close()

@@ -266,6 +266,25 @@ def main():
                         "frac": valu_tflops / 157.3, "wave_record_evals_per_launch": wave_evals,
                         "flop_per_pixel_eval": 47}
     stages = {k: st[k] for k in ("ms_preprocess", "ms_depth_sort", "ms_emit", "ms_tile_sort", "ms_blend", "ms_total")}
+    # the memory-bound kernel next to it: k_preprocess (stage 0 of the frame is exactly this one kernel).  Algorithmic bytes
+    # per splat at SH order 3: visible 32 (geometry) + 96 (colour) read, 48 (record) + 12 (key, payload) written; culled or
+    # not owned 32 read + 12 written
+    roofline_k1 = None
+    if st["stage_frames"] > 0 and world == 1:
+        k1_ms = st["stage_ms_total"][0] / st["stage_frames"]
+        nvis = st["n_visible"]
+        col_b = {0: 16, 1: 32, 2: 64, 3: 96}[order if splats.shx is not None else 0]
+        k1_bytes = nvis * (32 + col_b + 48 + 12) + (splats.n - nvis) * (32 + 12)
+        k1_traffic = None
+        try:
+            tj = json.load(open(tpath))
+            k1_traffic = float(tj["k_preprocess"]["hbm_bytes_per_launch"]) if (args.config == "C4" and args.splats is None) else None
+        except Exception:
+            k1_traffic = None
+        k1_gbps = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        roofline_k1 = {"bound": "hbm", "kernel": "k_preprocess", "achieved": k1_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": k1_gbps / HBM_PEAK_GBPS, "traffic": k1_traffic, "avg_launch_ms": k1_ms,
+                       "algorithmic_bytes_per_launch": k1_bytes}
 
     if rank == 0:
         line = {
@@ -287,6 +306,7 @@ def main():
                        "parallelism": f"tile-row shard x{world}" if world > 1 else "single GPU",
                        "n_splats": splats.n, "width": W, "height": H, "frames_in_flight": args.frames_in_flight},
             "roofline": roofline,
+            "roofline_preprocess": roofline_k1,
             "stages_ms_last_frame": stages,
             "n_visible": st["n_visible"],
         }

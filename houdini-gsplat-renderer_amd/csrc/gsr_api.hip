@@ -685,6 +685,12 @@ static void harvest_slot(gsr_context* c, FrameSlot& sl)
     c->st.blend_ms_total += ms[5];
     c->st.blend_launches += 1;
     c->st.frame_ms_total += tot;
+    c->st.stage_ms_total[0] += ms[0];
+    c->st.stage_ms_total[1] += ms[1];
+    c->st.stage_ms_total[2] += ms[2];
+    c->st.stage_ms_total[3] += ms[3] + ms[4];
+    c->st.stage_ms_total[4] += ms[5];
+    c->st.stage_frames += 1;
 }
 
 extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out, int out_is_device)

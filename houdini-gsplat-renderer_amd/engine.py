@@ -38,10 +38,13 @@ class gsr_stats(C.Structure):
                 ("blend_pairs_consumed_total", C.c_int64), ("frame_ms_total", C.c_double), ("frames", C.c_int64),
                 ("entries_scanned", C.c_int64), ("blend_entries_scanned_total", C.c_int64),
                 ("super_tile", C.c_int32), ("stiles_x", C.c_int32), ("stiles_y", C.c_int32), ("reserved_", C.c_int32),
-                ("blend_wave_evals_total", C.c_int64)]
+                ("blend_wave_evals_total", C.c_int64), ("stage_ms_total", C.c_double * 5),
+                ("stage_frames", C.c_int64)]
 
     def as_dict(self) -> dict:
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["stage_ms_total"] = list(self.stage_ms_total)
+        return d
 
 
 class gsr_debug_record(C.Structure):

@@ -81,6 +81,9 @@ typedef struct gsr_stats {
     int32_t stiles_x, stiles_y;            /* super-tile grid (whole image) */
     int32_t reserved_;
     int64_t blend_wave_evals_total;        /* (wave, record) evaluations by the blend kernel = 64 pixel evaluations each, running total */
+    double stage_ms_total[5];              /* timing level 2: running totals of ms_preprocess, ms_depth_sort, ms_emit,
+                                              ms_tile_sort, ms_blend over stage_frames frames */
+    int64_t stage_frames;
 } gsr_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */

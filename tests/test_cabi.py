@@ -42,7 +42,7 @@ def test_structs_match_the_header(pkg):
         decl = decl.strip()
         m = re.match(r"(int64_t|int32_t|float|double)\s+(.*)", decl)
         if m:
-            names += [x.strip() for x in m.group(2).split(",")]
+            names += [re.sub(r"\[\d+\]", "", x.strip()) for x in m.group(2).split(",")]   # arrays: name only
     assert names == [n for n, _ in e.gsr_stats._fields_]
 
 

@@ -88,37 +88,61 @@ def test_radix_sort_pairs(engine, n, bits):
     assert np.array_equal(v, vals[order])
 
 
-def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine):
-    splats = pkg.scenes.make_scene(30000, seed=21, sh=False)
-    cam = pkg.camera.make_camera(400, 300, sh_order=0, frame=0)
+@pytest.mark.parametrize("n,w,h,frame,big,shard", [
+    (30000, 400, 300, 0, 0, (0, 1)),
+    (20000, 1280, 720, 1, 3000, (0, 1)),      # 240 super-tiles, thousands of splats covering dozens of them each
+    (20000, 4096, 4096, 2, 500, (0, 1)),      # the maximum: 256 super-tiles of 16x16 tiles
+    (25000, 640, 480, 3, 1500, (1, 3)),       # row shard: a super-tile lists a splat only through an OWNED tile row
+    (25000, 1920, 1080, 4, 1500, (5, 8)),
+])
+def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine, n, w, h, frame, big, shard):
+    """the counting-sort binning (k_bin_count / k_bin_place): every super-tile's list holds exactly the splats
+    whose tile rect reaches it (through an owned tile row), in depth order"""
+    splats = pkg.scenes.make_scene(n, seed=21 + frame, sh=False)
+    if big:
+        sc = pkg.scenes.f16bits(np.random.default_rng(frame).uniform(0.5, 4.0, size=(big, 3)))
+        splats.scale[:big] = sc
+    cam = pkg.camera.make_camera(w, h, sh_order=0, frame=frame)
     engine.upload(splats)
-    engine.render(cam)
-    ls, le, pv = engine.debug_tile_lists()
-    st = engine.stats()
+    engine.set_row_shard(*shard)
+    try:
+        engine.render(cam)
+        ls, le, pv = engine.debug_tile_lists()
+        st = engine.stats()
+        dev = engine.debug_records(splats.n)
+    finally:
+        engine.set_row_shard(0, 1)
     S, sx = st["super_tile"], st["stiles_x"]
-    assert ls.shape[0] == st["stiles_x"] * st["stiles_y"] and st["pairs_total"] == pv.shape[0]
+    assert ls.shape[0] == st["stiles_x"] * st["stiles_y"] <= 256 and st["pairs_total"] == pv.shape[0]
     rec = oracle.preprocess(splats, cam)
     perm = oracle.argsort(rec)
     rank = np.empty(splats.n, np.int64)
     rank[perm] = np.arange(splats.n)
-    # expected membership: splats whose (device-identical) pixel bbox reaches the super-tile
-    dev = engine.debug_records(splats.n)
+    # expected membership from the (device-identical) pixel bbox -> tile rect
     vis = np.flatnonzero(dev["visible"] == 1)
+    r = dev[vis]
+    i0 = np.ceil(np.maximum(r["cx"] - r["hx"] - 0.5, 0)); i1 = np.floor(np.minimum(r["cx"] + r["hx"] - 0.5, w - 1))
+    j0 = np.ceil(np.maximum(r["cy"] - r["hy"] - 0.5, 0)); j1 = np.floor(np.minimum(r["cy"] + r["hy"] - 0.5, h - 1))
+    ok = (i1 >= i0) & (j1 >= j0)
+    tx0, tx1, ty0, ty1 = (i0 // 16).astype(np.int64), (i1 // 16).astype(np.int64), (j0 // 16).astype(np.int64), (j1 // 16).astype(np.int64)
+    idx, cnt = shard
     seen = 0
+    multi = 0
     for t in range(ls.shape[0]):
         lst = pv[ls[t]:le[t]]
         seen += lst.shape[0]
         if lst.shape[0] > 1:
             assert (np.diff(rank[lst]) > 0).all(), f"super-tile {t} not in depth order"
-        x0, y0 = (t % sx) * S * 16, (t // sx) * S * 16
-        x1, y1 = x0 + S * 16 - 1, y0 + S * 16 - 1
-        r = dev[vis]
-        i0 = np.ceil(np.maximum(r["cx"] - r["hx"] - 0.5, 0)); i1 = np.floor(np.minimum(r["cx"] + r["hx"] - 0.5, cam.width - 1))
-        j0 = np.ceil(np.maximum(r["cy"] - r["hy"] - 0.5, 0)); j1 = np.floor(np.minimum(r["cy"] + r["hy"] - 0.5, cam.height - 1))
-        tx0, tx1, ty0, ty1 = i0 // 16, i1 // 16, j0 // 16, j1 // 16
-        hit = (tx1 >= x0 // 16) & (tx0 <= x1 // 16) & (ty1 >= y0 // 16) & (ty0 <= y1 // 16)
+        X0, Y0 = (t % sx) * S, (t // sx) * S
+        X1, Y1 = X0 + S - 1, Y0 + S - 1
+        lo, hi = np.maximum(ty0, Y0), np.minimum(ty1, Y1)          # tile rows of the rect inside this super-tile
+        first = lo + ((idx - lo % cnt) + cnt) % cnt                 # first owned row >= lo
+        hit = ok & (tx1 >= X0) & (tx0 <= X1) & (hi >= lo) & (first <= hi)
         assert set(lst.tolist()) == set(vis[hit].tolist()), f"super-tile {t}: membership differs"
     assert seen == pv.shape[0]
+    if big:
+        cover = ((tx1 // S - tx0 // S + 1) * (ty1 // S - ty0 // S + 1))[ok]
+        assert (cover > 8).sum() > 50       # the cooperative big-splat path was exercised
 
 
 def test_edge_cases(pkg, oracle, engine):
@@ -435,3 +459,29 @@ def test_list_buffer_regrows_behind_a_speculative_back_end(pkg, oracle):
             _check_image(img2, oracle.render(huge, cam2, threads=oracle.max_threads()))
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_frames_match_oracle(pkg, oracle, engine, seed):
+    """seeded random frame descriptions (size, SH order, camera, splat sizes, super-tile edge, frames in flight)"""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 40000))
+    w, h = int(rng.integers(17, 900)), int(rng.integers(17, 700))
+    sh = bool(rng.integers(0, 2))
+    order = int(rng.integers(0, 4))
+    splats = pkg.scenes.make_scene(n, seed=2000 + seed, sh=sh)
+    nbig = int(rng.integers(0, max(1, n // 10)))
+    if nbig:
+        splats.scale[:nbig] = pkg.scenes.f16bits(rng.uniform(0.3, 5.0, size=(nbig, 3)))
+    frame = int(rng.integers(0, 120))
+    cam = pkg.camera.make_camera(w, h, sh_order=order, frame=frame)
+    engine.set_option(pkg.engine.OPT_SUPER_TILE, int(rng.choice([0, 1, 2, 4, 8, 16])))
+    engine.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, int(rng.choice([1, 2])))
+    try:
+        engine.upload(splats)
+        img = engine.render(cam)
+    finally:
+        engine.set_option(pkg.engine.OPT_SUPER_TILE, 0)
+        engine.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, 2)
+    cam_o = pkg.camera.make_camera(w, h, sh_order=order if sh else 0, frame=frame)   # (no SH data: the doSH gate forces order 0)
+    _check_image(img, oracle.render(splats, cam_o, threads=oracle.max_threads()))

@@ -487,6 +487,9 @@ def cases(pkg):
                     [0, 0, 0.8, 0.02], [0, 0, 0, 1]], dtype=np.float64)
     out.append(("g6_object_xform", sc.make_scene(800, seed=16, sh=True, log_scale_range=(-4.0, -2.8)),
                 cm.make_camera(160, 120, sh_order=3, frame=1, object_matrix=obj), (0, 0, 0), 15))
+    # G7: a slice of BASELINE config 1 (anisotropic, SH degree 3, the C2 generator settings) at 640x360
+    s, cfg = sc.make_config("C2", 20000)
+    out.append(("g7_aniso_sh3_20k", s, cm.make_camera(640, 360, sh_order=3, frame=4), (0, 0, 0), 9))
     # C1: BASELINE config 0 -- 10k isotropic splats, SH degree 0, 512x512
     s, cfg = sc.make_config("C1")
     out.append(("c1_10k_iso", s, cm.make_camera(cfg["width"], cfg["height"], sh_order=0, frame=0), (0, 0, 0), 5))
@@ -499,7 +502,10 @@ def main():
     es = GLES()
     print("GL:", es.version, "|", es.renderer)
     summary = []
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]   # optional: regenerate just these cases
     for name, splats, cam, origin, ss in cases(pkg):
+        if only and name not in only:
+            continue
         rec = oracle.preprocess(splats, cam, origin)
         perm = oracle.argsort(rec)  # (distance^2, index) ascending = the order the reference's argsort would upload
         img_gl, vs_sorted = render_reference_glsl(es, splats, cam, origin, perm, ss)
@@ -529,6 +535,8 @@ def main():
         if splats.has_sh:
             arrays.update(shx=splats.shx, shy=splats.shy, shz=splats.shz)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    if only and "w1_wire" not in only:
+        return summary
     # ---- wireframe overlay: the reference's wire program as a LOOSE golden -- GL's diamond-exit
     #      line rule and the oracle's rule agree up to one pixel, not pixel for pixel
     sc, cm = pkg.scenes, pkg.camera

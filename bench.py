@@ -92,6 +92,15 @@ def cpu_baseline(oracle, splats, cam0, pkg, budget_s: float) -> dict:
             break
     t_med = float(np.median(times))
     fps_sample = 1.0 / t_med
+    # the reference's own per-camera-move HOST stage (squared distances + parallel comparison argsort of the indices,
+    # src/GSplatRenderer.C:188-208; oracle/host_stage_ref.cpp) on all splats: what the GPU depth sort replaces
+    hs = []
+    for k in range(4):
+        cam = pkg.camera.make_camera(cam0.width, cam0.height, sh_order=cam0.sh_order, frame=k)
+        t0 = time.perf_counter()
+        oracle.reference_host_stage(splats.P, cam.cam_pos, threads)
+        hs.append(time.perf_counter() - t0)
+    host_stage_ms = float(np.median(hs[1:])) * 1e3
     return {
         "value": fps_sample * (sample_n / n),
         "unit": "frames/sec",
@@ -102,6 +111,9 @@ def cpu_baseline(oracle, splats, cam0, pkg, budget_s: float) -> dict:
                    f"{len(times)} frames, median {t_med * 1e3:.1f} ms/frame; value = sample fps x {sample_n}/{n} "
                    f"(work is linear in splats)"),
         "sample_fps": fps_sample,
+        "reference_host_stage_ms": host_stage_ms,
+        "reference_host_stage": (f"argsortByDistance restated (distance^2 + __gnu_parallel::sort of int indices by indirect float "
+                                 f"compare, standing in for tbb::parallel_sort) on all {n} splats, {threads} threads: median of 3"),
     }
 
 

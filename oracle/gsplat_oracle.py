@@ -214,6 +214,28 @@ def host_sort_only(P, cam_pos) -> np.ndarray:
     return perm
 
 
+_host_lib = None
+
+
+def reference_host_stage(P, cam_pos, threads: int = 0) -> np.ndarray:
+    """The reference's per-camera-move CPU work (squared distances + parallel comparison argsort of the
+    indices, src/GSplatRenderer.C:188-208) -- oracle/host_stage_ref.cpp; used to TIME that stage on the
+    bench box.  Unstable like the reference's tbb::parallel_sort: ties come back in arbitrary order."""
+    global _host_lib
+    if _host_lib is None:
+        path = os.path.join(_HERE, "libgsplat_hoststage.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-C", _HERE, "libgsplat_hoststage.so"], check=True, stdout=subprocess.DEVNULL)
+        _host_lib = C.CDLL(path)
+        _host_lib.gso_reference_host_stage.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p, C.c_int]
+    P = _c(P, np.float32).reshape(-1, 3)
+    perm = np.zeros(P.shape[0], dtype=np.int32)
+    cp = (C.c_float * 3)(*np.asarray(cam_pos, dtype=np.float32).tolist())
+    rc = _host_lib.gso_reference_host_stage(P.ctypes.data, P.shape[0], cp, perm.ctypes.data, int(threads))
+    assert rc == 0
+    return perm
+
+
 def max_threads() -> int:
     return int(lib().gso_max_threads())
 

@@ -162,3 +162,16 @@ def test_oracle_wireframe_matches_reference_wire_program(oracle):
     img = oracle.render_wire(s, c)
     check_wire_against_golden(img, d["wire_reference_glsl"])
     assert set(np.unique(img[..., 3]).tolist()) <= {0.0, 1.0}
+
+
+def test_reference_host_stage_restatement(pkg, oracle):
+    """oracle/host_stage_ref.cpp (timed by bench.py as the reference's per-camera-move CPU work): a permutation
+    that orders the squared distances; agrees with the oracle's stable argsort wherever keys are distinct"""
+    s = pkg.scenes.make_scene(50000, seed=77, sh=False)
+    cam = pkg.camera.make_camera(320, 200, frame=3)
+    p = oracle.reference_host_stage(s.P, cam.cam_pos, 4)
+    assert sorted(p.tolist()) == list(range(s.n))
+    ref = oracle.host_sort_only(s.P, cam.cam_pos)
+    d = ((s.P.astype(np.float32) - cam.cam_pos.astype(np.float32)) ** 2).sum(1)
+    assert (np.diff(d[p]) >= -1e-6).all()
+    assert np.mean(p == ref) > 0.99       # ties, and 1-ulp differences between this distance and the contract's fma chain, swap neighbours

@@ -85,8 +85,8 @@ struct FrameSlot {
     float* fb = nullptr;               // staging for host-pointer output
     size_t fb_cap = 0;
     // small device/host mailboxes
-    unsigned long long* counters = nullptr;  // [0] visible [1] records gathered [2] running [3] entries scanned [4] running
-    uint32_t* d_total = nullptr;
+    unsigned long long* counters = nullptr;  // k_sum_work's layout: [1]/[2] records gathered (frame/running), [3]/[4] list entries
+                                             // scanned, [5] wave-record evaluations (running)
     uint32_t* h_total = nullptr;             // pinned + mapped: k_bin_ranges writes the pair count here
     uint32_t* h_total_dev = nullptr;         // its device-side address
     unsigned long long* h_counters = nullptr;  // pinned + mapped: k_sum_work writes the frame's bookkeeping here
@@ -99,7 +99,6 @@ struct FrameSlot {
     gsr_camera sort_camera{};
     int sort_shard_index = 0, sort_shard_count = 1, sort_flags = 0;
     uint64_t sort_gen = 0;
-    uint32_t h_n = 0;                  // host copy of *d_n of the last frame (after synchronisation)
     uint32_t key_min = 0;              // of the frame whose order is cached
     // last frame rendered in this slot
     int last_tiles_x = 0, last_local_ty = 0, last_supers = 0;
@@ -189,7 +188,6 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipEventCreateWithFlags(&sl.ev_user, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&sl.ev_pairs, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.counters), 8 * sizeof(unsigned long long)) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_total), sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_n), sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.d_n, 0, sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.totals), 512 * sizeof(uint32_t)) == hipSuccess;
@@ -220,7 +218,7 @@ static void slot_destroy(FrameSlot& sl)
     dev_free(sl.hist); dev_free(sl.totals);
     dev_free(sl.pvA);
     dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.fb); dev_free(sl.depth_stage);
-    dev_free(sl.counters); dev_free(sl.d_total); dev_free(sl.d_n);
+    dev_free(sl.counters); dev_free(sl.d_n);
     if (sl.h_total) (void)hipHostFree(sl.h_total);
     if (sl.h_counters) (void)hipHostFree(sl.h_counters);
     if (sl.ev_ok)

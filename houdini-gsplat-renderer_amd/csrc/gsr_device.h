@@ -94,13 +94,17 @@ typedef float gsr_v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ gsr_v2f gsr_fma2(gsr_v2f a, gsr_v2f b, gsr_v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-// gsr_expf on two lanes of a pair: the same operation sequence per component
+// gsr_expf on two lanes of a pair: the same values per component.  rint() and the float->int conversion are
+// half-rate, unpackable instructions on gfx950 (tools/ubench_valu.hip), so the rounding is done the classic
+// way: s = t + 1.5*2^23 rounds t to the nearest-even integer in s's low mantissa bits (|t| < 2^22; here
+// t in [-116, 0]), s - 1.5*2^23 is that integer as a float (== rintf(t)), and the integer itself is the low
+// bits of s -- shifting them into the exponent field discards the rest.  Bit-identical to gsr_expf.
 __device__ __forceinline__ gsr_v2f gsr_expf2(gsr_v2f x)
 {
     const gsr_v2f t = x * 1.44269504088896341f;
-    gsr_v2f kf;
-    kf.x = __builtin_rintf(t.x);
-    kf.y = __builtin_rintf(t.y);
+    const gsr_v2f magic = (gsr_v2f)(12582912.0f);
+    const gsr_v2f s = t + magic;
+    const gsr_v2f kf = s - magic;
     gsr_v2f r = gsr_fma2(kf, (gsr_v2f)(-0.693359375f), x);
     r = gsr_fma2(kf, (gsr_v2f)(2.12194440e-4f), r);
     gsr_v2f p = (gsr_v2f)(1.9875691500e-4f);
@@ -113,10 +117,10 @@ __device__ __forceinline__ gsr_v2f gsr_expf2(gsr_v2f x)
     const gsr_v2f y = gsr_fma2(p, r2, r) + 1.0f;
     // NB: __builtin_bit_cast applied directly to a vector ELEMENT (y.y) reads element 0 with this
     // compiler (ROCm 7.2 clang) -- go through scalar temporaries.
-    const float y0 = y.x, y1 = y.y, k0 = kf.x, k1 = kf.y;
+    const float y0 = y.x, y1 = y.y, s0 = s.x, s1 = s.y;
     gsr_v2f o;
-    o.x = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, y0) + ((uint32_t)(int32_t)k0 << 23));
-    o.y = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, y1) + ((uint32_t)(int32_t)k1 << 23));
+    o.x = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, y0) + (__builtin_bit_cast(uint32_t, s0) << 23));
+    o.y = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, y1) + (__builtin_bit_cast(uint32_t, s1) << 23));
     return o;
 }
 

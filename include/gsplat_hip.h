@@ -136,8 +136,9 @@ int  gsr_stitch_bands(gsr_context* ctx, const float* gathered, int count,
  * RGBA, row 0 = BOTTOM row (GL window coordinates), cleared to 0 -- what the
  * reference's blend leaves in an initially transparent float target.  rows =
  * height, or gsr_band_rows() when sharded.  out_is_device: 0 = host pointer
- * (synchronous), 1 = device pointer (asynchronous on the context stream after
- * the internal pair-count readback). */
+ * (synchronous), 1 = device pointer: asynchronous, ordered on the context's public stream
+ * (gsr_set_stream); the call itself only waits for the frame's 4-byte pair count, which the GPU
+ * delivers mid-frame while it keeps working. */
 int  gsr_render(gsr_context* ctx, const gsr_camera* cam, float* rgba_out, int out_is_device);
 
 /* Same frame, depth-tested against what is already in the viewport: the reference draws

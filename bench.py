@@ -275,10 +275,10 @@ def main():
     wave_evals = st["blend_wave_evals_total"] / launches
     valu_tflops = wave_evals * 64 * 47.0 / (blend_ms * 1e-3) / 1e12 if blend_ms > 0 else 0.0
     # ... and against the ISSUE RATES measured on this GPU (tools/ubench_valu.hip -> profiles/ubench_valu_mi355x.txt):
-    # one inner-loop iteration = two wave-record evaluations = 30 packed-FP32 instructions (2.02 ns each per SIMD)
-    # + 3 sub, 2 min (1.0 ns) + 2 max|.|, 6 cmp, 2 rndne, 2 cvt, 2 lshl_add (1.72 ns) + 2 cndmask (1.6 ns) = 93 ns
+    # one inner-loop iteration = two wave-record evaluations = 32 packed-FP32 instructions (2.02 ns each per SIMD)
+    # + 3 sub, 2 min (1.0 ns) + 2 max|.|, 6 cmp, 2 lshl_add (1.72 ns) + 2 cndmask (1.6 ns) = 90 ns
     n_simd = 256 * 4
-    iter_ns = 30 * 2.02 + 5 * 1.0 + 16 * 1.72 + 2 * 1.6
+    iter_ns = 32 * 2.02 + 5 * 1.0 + 10 * 1.72 + 2 * 1.6
     issue_ms = (wave_evals / 2.0) * iter_ns / n_simd * 1e-6
     roofline["valu"] = {"bound": "fp32 vector", "achieved": valu_tflops, "peak": 157.3, "unit": "TFLOP/s",
                         "frac": valu_tflops / 157.3, "wave_record_evals_per_launch": wave_evals,

@@ -94,3 +94,29 @@ def test_ingest_helpers_match_numpy(pkg):
     L.gsplat_pack_sh_from_array(arr.ctypes.data, n, 15, *[o.ctypes.data for o in out3])
     for ch in range(3):
         assert np.array_equal(out3[ch], out2[ch])
+
+
+def test_product_never_touches_the_oracle_or_the_reference():
+    """the oracle is test infrastructure: nothing under the product package (Python or C++/HIP) or include/ may
+    import, include, link or name it -- nor read /root/reference at run time"""
+    bad = []
+    for base in (os.path.join(ROOT, "houdini-gsplat-renderer_amd"), os.path.join(ROOT, "include")):
+        for dirpath, _, files in os.walk(base):
+            for fn in files:
+                if not fn.endswith((".py", ".h", ".hip", ".cpp")):
+                    continue
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                if not fn.endswith(".py"):   # comments may cite the oracle's function names; code may not use them
+                    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+                    text = re.sub(r"//[^\n]*", "", text)
+                for needle in ("gsplat_oracle", "libgsplat_oracle", "gso_", "oracle/", "load_oracle"):
+                    if needle in text:
+                        bad.append((fn, needle))
+                # the reference may be CITED in comments (file:line), never opened
+                for line in text.splitlines():
+                    if "/root/reference" in line and ("open(" in line or "fopen" in line or "ifstream" in line or "#include" in line):
+                        bad.append((fn, line.strip()))
+    assert not bad, bad
+    # bench.py uses the oracle only inside its cpu_baseline leg
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("load_oracle") == 1 and "def cpu_baseline" in bench

@@ -34,6 +34,18 @@ import __graft_entry__ as ge  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def kernel_source_sha() -> str:
+    """fingerprint of the kernel sources: ties profiles/pmc_traffic.json to the kernels it was collected with"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "houdini-gsplat-renderer_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".h", ".hip", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,46 +255,59 @@ def main():
     # blend-kernel roofline, measured with HIP events on the kernel's own stream
     launches = max(1, st["blend_launches"])
     blend_ms = st["blend_ms_total"] / launches
-    d_eff = st["blend_pairs_consumed_total"] / launches       # records gathered per launch
+    d_eff = st["blend_pairs_consumed_total"] / launches       # (tile, splat) pairs CONSUMED per launch = records gathered
     scanned = st["blend_entries_scanned_total"] / launches     # list entries (idx + rect) read per launch
     rec_b, pair_b = st["record_bytes"], st["pair_bytes"]
     own_px = sum(min(16, H - r * 16) for r in range(rank, (H + 15) // 16, world)) * W
-    # algorithmic bytes of k_blend: 8 B per list entry scanned + 48 B per record gathered + one RGBA-f32 store per pixel
-    bytes_blend = pair_b * scanned + rec_b * d_eff + 16.0 * own_px
+    # unit of work = one consumed (tile, splat) pair = its list entry (8 B) + its projected record (48 B; this
+    # build's true sizes), plus one RGBA-f32 store per pixel.  The entries a tile merely SCANS in its super-tile's list to
+    # find its own (the price of coarse lists) are NOT algorithmic bytes: they are reported beside it.
+    bytes_blend = (pair_b + rec_b) * d_eff + 16.0 * own_px
     achieved = bytes_blend / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
-    # HBM traffic of k_blend per launch from the PMC pass of this same command (tools/gpu_pmc.sh ->
-    # profiles/pmc_traffic.json; 2*FETCH_SIZE + WRITE_SIZE as the MI355X guide prescribes); null if absent
-    traffic = None
+    # HBM traffic of k_blend per launch: PMC counters cannot be read from inside this process, so the figure is REPLAYED from
+    # the rocprofv3 --pmc passes of this same command (tools/gpu_pmc.sh -> profiles/pmc_traffic.json; 2*FETCH_SIZE +
+    # WRITE_SIZE as the MI355X guide prescribes) -- and only when that file was produced by the kernels being run now
+    traffic, traffic_from = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    tj = None
     if os.path.exists(tpath) and world == 1 and args.config == "C4" and args.splats is None:
         try:
             tj = json.load(open(tpath))
-            traffic = float(next(v for k, v in tj.items() if "k_blend" in k)["hbm_bytes_per_launch"])
+            if tj.get("_kernel_source_sha") != kernel_source_sha():
+                tj = None       # stale: collected with other kernels
+            else:
+                traffic = float(next(v for k, v in tj.items() if "k_blend" in k)["hbm_bytes_per_launch"])
+                traffic_from = "profiles/pmc_traffic.json (" + str(tj.get("_collected", "rocprofv3 --pmc passes of this command")) + ")"
         except Exception:
-            traffic = None
+            traffic, tj = None, None
     roofline = {
         "bound": "hbm", "kernel": "k_blend", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_replayed_from": traffic_from,
         "avg_launch_ms": blend_ms, "algorithmic_bytes_per_launch": bytes_blend,
-        "records_gathered_per_launch": d_eff, "entries_scanned_per_launch": scanned,
+        "pairs_consumed_per_launch": d_eff, "bytes_per_consumed_pair": pair_b + rec_b,
+        "entries_scanned_per_launch": scanned, "list_scan_bytes": pair_b * scanned,
+        "scan_amplification": scanned / d_eff if d_eff > 0 else None,
         "pairs_sorted_last_frame": st["pairs_total"], "record_bytes": rec_b, "entry_bytes": pair_b,
         "super_tile": st["super_tile"],
-        "note": "k_blend is VALU/LDS-bound at 16x16 tiles (DESIGN.md); HBM fraction reported as the metric asks",
+        "note": "k_blend is FP32-vector-issue bound at this arithmetic intensity (DESIGN.md); the HBM fraction is reported "
+                "as the metric asks, on consumed pairs only (SURVEY 8d)",
     }
-    # the bound that actually binds k_blend: FP32 vector issue.  One pixel evaluation of one record is 47 FLOP
-    # (fma = 2: 2 sub, rotate 6, scale 2, power 3, contract-exp 20, opacity+clamp 2, under-blend 12), counted
+    # the bound that actually binds k_blend: FP32 vector issue.  One pixel evaluation of one record is 34 FLOP
+    # (fma = 2: affine forms 8, power 3, contract-exp2 13, opacity+clamp 2, under-blend 8), counted
     # per 64-lane wave evaluation by the kernel itself (lanes outside the quad execute the same instructions)
+    FLOP_PER_EVAL = 34.0
     wave_evals = st["blend_wave_evals_total"] / launches
-    valu_tflops = wave_evals * 64 * 47.0 / (blend_ms * 1e-3) / 1e12 if blend_ms > 0 else 0.0
-    # ... and against the ISSUE RATES measured on this GPU (tools/ubench_valu.hip -> profiles/ubench_valu_mi355x.txt):
-    # one inner-loop iteration = two wave-record evaluations = 32 packed-FP32 instructions (2.02 ns each per SIMD)
-    # + 3 sub, 2 min (1.0 ns) + 2 max|.|, 6 cmp, 2 lshl_add (1.72 ns) + 2 cndmask (1.6 ns) = 90 ns
+    valu_tflops = wave_evals * 64 * FLOP_PER_EVAL / (blend_ms * 1e-3) / 1e12 if blend_ms > 0 else 0.0
+    # ... and against the ISSUE RATES measured on this GPU (tools/ubench_valu.hip -> profiles/ubench_valu_mi355x.txt).
+    # One inner-loop iteration = two wave-record evaluations (ISA of k_blend<false>, tools/kernel_resources.py --isa):
+    # 5 v_pk_fma_f32 with three full operands (2.02 ns per SIMD), 7 with a broadcast operand (1.77), 4 v_pk_mul/add (1.76),
+    # 2 v_lshl_add (1.74), 2 v_max + 6 v_cmp (1.72), 2 v_cndmask (1.64), 9 full-rate mul/fmac/sub/add (1.0)
     n_simd = 256 * 4
-    iter_ns = 32 * 2.02 + 5 * 1.0 + 10 * 1.72 + 2 * 1.6
+    iter_ns = 5 * 2.02 + 7 * 1.77 + 4 * 1.76 + 2 * 1.74 + 8 * 1.72 + 2 * 1.64 + 9 * 1.0
     issue_ms = (wave_evals / 2.0) * iter_ns / n_simd * 1e-6
     roofline["valu"] = {"bound": "fp32 vector", "achieved": valu_tflops, "peak": 157.3, "unit": "TFLOP/s",
                         "frac": valu_tflops / 157.3, "wave_record_evals_per_launch": wave_evals,
-                        "flop_per_pixel_eval": 47,
+                        "flop_per_pixel_eval": FLOP_PER_EVAL, "inner_loop_iteration_ns": iter_ns,
                         "inner_loop_issue_bound_ms": issue_ms, "inner_loop_issue_frac": issue_ms / blend_ms if blend_ms > 0 else 0.0,
                         "note": "issue bound = inner-loop instruction mix x issue intervals measured with tools/ubench_valu.hip"}
     stages = {k: st[k] for k in ("ms_preprocess", "ms_depth_sort", "ms_emit", "ms_tile_sort", "ms_blend", "ms_total")}
@@ -297,8 +322,7 @@ def main():
         k1_bytes = nvis * (32 + col_b + 48 + 12) + (splats.n - nvis) * (32 + 12)
         k1_traffic = None
         try:
-            tj = json.load(open(tpath))
-            k1_traffic = float(tj["k_preprocess"]["hbm_bytes_per_launch"]) if (args.config == "C4" and args.splats is None) else None
+            k1_traffic = float(tj["k_preprocess"]["hbm_bytes_per_launch"]) if tj is not None else None
         except Exception:
             k1_traffic = None
         k1_gbps = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0

@@ -21,13 +21,19 @@
 //                     order 3 chunks 0-5)
 //
 // Projected record, rewritten every frame (48 B, 3 x float4, AoS so the blend
-// kernel's gather touches one or two lines per splat):
+// kernel's gather touches one or two lines per splat).  Contract v2: the quad-local coordinate of a
+// pixel is carried as two affine forms scaled by kappa = sqrt(log2 e),
+//     kappa*q0 = d . (a1x, a1y),   kappa*q1 = d . (b1x, b1y),   d = pixel centre - (cx, cy),
+// so that exp(-|q|^2) == 2^-(|kappa q|^2) needs no per-fragment 1/s multiply and an exact base-2
+// range reduction.
 struct __attribute__((aligned(16))) GsrRecord {
-    float cx, cy, ex, ey;        // centre (GL window coords), unit major axis
-    float is1, is2, hx, hy;      // 1/s1, 1/s2, conservative bbox half extents
+    float cx, cy, hx, hy;        // centre (GL window coords), conservative bbox half extents
+    float a1x, a1y, b1x, b1y;    // kappa * e / s1, kappa * e_perp / s2  (e = unit major axis, e_perp = (-ey, ex))
     float r, g, b, opacity;      // colour after SH, opacity
 };
 static_assert(sizeof(GsrRecord) == 48, "record layout");
+#define GSR_KAPPA 1.2011224087864498f   // sqrt(log2 e)
+#define GSR_QLIM  (2.0f * GSR_KAPPA)    // |q| <= 2 in kappa units
 
 // Frame constants, computed once per frame on the host in float32 (same
 // operation order as the oracle) and passed by value.
@@ -67,54 +73,45 @@ __device__ __forceinline__ float gsr_h2f(uint32_t bits16)
     return (float)h;  // v_cvt_f32_f16: exact
 }
 
-// The contract's exp() for x in [-80, 0]: identical operation sequence to the
-// oracle's gso_expf (range reduction by ln2 hi/lo, degree-5 polynomial, exponent add).
-__device__ __forceinline__ float gsr_expf(float x)
+// The contract's 2^x for x in [-2^22, 0]: identical operation sequence to the oracle's gso_exp2f
+// (round to the nearest-even integer with the 1.5*2^23 trick, EXACT remainder r = x - k, degree-5
+// polynomial for 2^r on [-0.5, 0.5], exponent add).  <= 2.8 ulp, exp2(0) == 1, never above 1.
+__device__ __forceinline__ float gsr_exp2n(float x)
 {
-    float kf = __builtin_rintf(x * 1.44269504088896341f);
-    float r = gsr_fma(kf, -0.693359375f, x);
-    r = gsr_fma(kf, 2.12194440e-4f, r);
-    float p = 1.9875691500e-4f;
-    p = gsr_fma(p, r, 1.3981999507e-3f);
-    p = gsr_fma(p, r, 8.3334519073e-3f);
-    p = gsr_fma(p, r, 4.1665795894e-2f);
-    p = gsr_fma(p, r, 1.6666665459e-1f);
-    p = gsr_fma(p, r, 5.0000001201e-1f);
-    float r2 = r * r;
-    float y = gsr_fma(p, r2, r) + 1.0f;
-    int32_t k = (int32_t)kf;
-    uint32_t bits = __builtin_bit_cast(uint32_t, y) + ((uint32_t)k << 23);
-    return __builtin_bit_cast(float, bits);
+    const float magic = 12582912.0f;
+    const float s = x + magic;
+    const float kf = s - magic;
+    const float r = x - kf;
+    float p = 1.3292919611558318e-3f;
+    p = gsr_fma(p, r, 9.671509265899658e-3f);
+    p = gsr_fma(p, r, 5.550636723637581e-2f);
+    p = gsr_fma(p, r, 2.4022242426872253e-1f);
+    p = gsr_fma(p, r, 6.931470632553101e-1f);
+    const float y = gsr_fma(p, r, 1.0f);
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, y) + (__builtin_bit_cast(uint32_t, s) << 23));
 }
 
 // two-wide float: the blend kernel evaluates two records per lane per iteration so that the
-// compiler can emit packed-FP32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 -- the
-// only way to reach gfx950's 157 TFLOP/s vector peak); each component is still an IEEE fma.
+// compiler can emit packed-FP32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32); each
+// component is still an IEEE fma.
 typedef float gsr_v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ gsr_v2f gsr_fma2(gsr_v2f a, gsr_v2f b, gsr_v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-// gsr_expf on two lanes of a pair: the same values per component.  rint() and the float->int conversion are
-// half-rate, unpackable instructions on gfx950 (tools/ubench_valu.hip), so the rounding is done the classic
-// way: s = t + 1.5*2^23 rounds t to the nearest-even integer in s's low mantissa bits (|t| < 2^22; here
-// t in [-116, 0]), s - 1.5*2^23 is that integer as a float (== rintf(t)), and the integer itself is the low
-// bits of s -- shifting them into the exponent field discards the rest.  Bit-identical to gsr_expf.
-__device__ __forceinline__ gsr_v2f gsr_expf2(gsr_v2f x)
+// gsr_exp2n on the two lanes of a pair: the same values per component (the integer k sits in the low mantissa
+// bits of s; shifting them into the exponent field discards the rest).
+__device__ __forceinline__ gsr_v2f gsr_exp2n2(gsr_v2f x)
 {
-    const gsr_v2f t = x * 1.44269504088896341f;
     const gsr_v2f magic = (gsr_v2f)(12582912.0f);
-    const gsr_v2f s = t + magic;
+    const gsr_v2f s = x + magic;
     const gsr_v2f kf = s - magic;
-    gsr_v2f r = gsr_fma2(kf, (gsr_v2f)(-0.693359375f), x);
-    r = gsr_fma2(kf, (gsr_v2f)(2.12194440e-4f), r);
-    gsr_v2f p = (gsr_v2f)(1.9875691500e-4f);
-    p = gsr_fma2(p, r, (gsr_v2f)(1.3981999507e-3f));
-    p = gsr_fma2(p, r, (gsr_v2f)(8.3334519073e-3f));
-    p = gsr_fma2(p, r, (gsr_v2f)(4.1665795894e-2f));
-    p = gsr_fma2(p, r, (gsr_v2f)(1.6666665459e-1f));
-    p = gsr_fma2(p, r, (gsr_v2f)(5.0000001201e-1f));
-    const gsr_v2f r2 = r * r;
-    const gsr_v2f y = gsr_fma2(p, r2, r) + 1.0f;
+    const gsr_v2f r = x - kf;
+    gsr_v2f p = (gsr_v2f)(1.3292919611558318e-3f);
+    p = gsr_fma2(p, r, (gsr_v2f)(9.671509265899658e-3f));
+    p = gsr_fma2(p, r, (gsr_v2f)(5.550636723637581e-2f));
+    p = gsr_fma2(p, r, (gsr_v2f)(2.4022242426872253e-1f));
+    p = gsr_fma2(p, r, (gsr_v2f)(6.931470632553101e-1f));
+    const gsr_v2f y = gsr_fma2(p, r, (gsr_v2f)(1.0f));
     // NB: __builtin_bit_cast applied directly to a vector ELEMENT (y.y) reads element 0 with this
     // compiler (ROCm 7.2 clang) -- go through scalar temporaries.
     const float y0 = y.x, y1 = y.y, s0 = s.x, s1 = s.y;

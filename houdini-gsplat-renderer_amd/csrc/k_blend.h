@@ -36,7 +36,7 @@
 #endif
 #define BL_SCAN_K 4           // list entries scanned per thread per scan step
 #define BL_QCAP 2048          // hit-queue ring capacity (>= BL_ROUND + 2 * BL_SCAN_K * 256)
-#define BL_PAIR_F4 6          // float4s per staged record PAIR (96 B)
+#define BL_PAIR_F4_MAX 6      // float4s per staged record PAIR: 5 (80 B), 6 with the depth test
 #define GSR_T_MIN 6.103515625e-05f  // 2^-14
 
 struct GsrBlendArgs {
@@ -53,12 +53,14 @@ struct GsrBlendArgs {
 };
 
 // Staging layout: one list PER QUADRANT (= per wave), holding the round's records that reach that
-// quadrant, in depth order, two records interleaved per 96-byte block so that every ds_read_b128
-// lands as two ready-made operand pairs of the packed-FP32 instructions (no v_mov shuffling):
-//   f4 0: a.cx b.cx a.cy b.cy     f4 3: a.opacity b.opacity a.zwin b.zwin
-//   f4 1: a.ex b.ex a.ey b.ey     f4 4: a.r a.g a.b 1
-//   f4 2: a.1/s1 b.1/s1 a.1/s2 b.1/s2     f4 5: b.r b.g b.b 1
-// HAS_DEPTH = false compiles the depth compare out of the inner loop (two v_cmp per iteration).
+// quadrant, in depth order, two records interleaved per block so that every ds_read_b128 lands as
+// ready-made operand pairs of the packed-FP32 instructions (no v_mov shuffling):
+//   f4 0: a.a1x b.a1x a.a1y b.a1y     f4 3: a.r a.g a.b a.opacity
+//   f4 1: a.b1x b.b1x a.b1y b.b1y     f4 4: b.r b.g b.b b.opacity
+//   f4 2: a.c0  b.c0  a.c1  b.c1      f4 5: a.zwin b.zwin - -          (HAS_DEPTH only)
+// c0/c1 = the two affine forms of the record at the TILE origin (contract v2): kq0 = lx*a1x + ly*a1y + c0 for the
+// pixel (lx, ly) of the tile -- computed once per (record, tile) by the gathering thread.
+// HAS_DEPTH = false compiles the depth compare and the sixth float4 out of the inner loop.
 #if BL_WAVES_PER_EU > 0
 #define BL_OCC __attribute__((amdgpu_waves_per_eu(BL_WAVES_PER_EU)))
 #else
@@ -71,12 +73,15 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
         const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint4* __restrict__ tile_work,
         const float* __restrict__ zwin, const float* __restrict__ depth)
 {
-    __shared__ float4 slist[4][(BL_ROUND / 2) * BL_PAIR_F4];
+    constexpr int PF4 = HAS_DEPTH ? 6 : 5;
+    __shared__ float4 slist[4][(BL_ROUND / 2) * PF4];
     __shared__ uint32_t q[BL_QCAP];   // hit queue: splat indices in list (= depth) order
     __shared__ uint32_t scnt[2][BL_SCAN_K][4];
     __shared__ unsigned long long swcnt[2][4];   // per gathering wave: 4 x 16-bit counts of records reaching quadrant 0..3
     __shared__ uint32_t sdone[2][4];
     __shared__ uint32_t sfetched, sevals;
+    __shared__ float4 spark[BL_ROUND];   // the gathered (r, g, b, opacity) waits here between gather and staging: LDS
+                                         // instead of three VGPRs the register allocator would spill to scratch
 
     // Workgroup b runs on XCD b%8 (observed dispatch order, MI355X guide): tile_map hands each
     // XCD whole super-tiles, whose 64 tiles read the same list and gather the same records.
@@ -88,7 +93,8 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
     const int px = tx * GSR_TILE_PX + (wave & 1) * 8 + (lane & 7);
     const int py = gty * GSR_TILE_PX + (wave >> 1) * 8 + (lane >> 3);
     const bool pix_ok = (px < a.width) && (py < a.height);
-    const gsr_v2f fx = (gsr_v2f)((float)px + 0.5f), fy = (gsr_v2f)((float)py + 0.5f);
+    // pixel index inside the tile (contract v2: fragment positions are relative to the tile origin)
+    const gsr_v2f lx = (gsr_v2f)((float)((wave & 1) * 8 + (lane & 7))), ly = (gsr_v2f)((float)((wave >> 1) * 8 + (lane >> 3)));
     // tile bounds in pixel-centre coordinates, for the quadrant masks
     const float tcx0 = (float)(tx * GSR_TILE_PX) + 0.5f, tcy0 = (float)(gty * GSR_TILE_PX) + 0.5f;
     if (tid == 0) { sfetched = 0; sevals = 0; }
@@ -102,7 +108,8 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
     const int e_ = send[st] < a.list_cap ? send[st] : a.list_cap;
     const int n = e_ > s ? e_ - s : 0;
 
-    gsr_v2f C01 = {0.0f, 0.0f}, CA = {0.0f, 0.0f};   // {C0, C1}, {C2, A}: the accumulators as two register pairs
+    gsr_v2f C01 = {0.0f, 0.0f};   // {C0, C1} as a register pair
+    float C2 = 0.0f, T = 1.0f;    // blue, transmittance 1 - A
     bool wave_done = false;
     uint32_t my_fetched = 0;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -167,32 +174,39 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
         if (take == 0) break;                         // list exhausted and queue empty
         const bool have = tid < take;
         float4 r0, r1, r2;
-        float rz = 0.0f;
+        float rz = 0.0f, c0 = 0.0f, c1 = 0.0f;
         uint32_t m = 0;
         if (have) {
             const uint32_t ridx = q[(q_head + tid) & (BL_QCAP - 1)];
             const float4* p = reinterpret_cast<const float4*>(recs + ridx);
             r0 = p[0]; r1 = p[1]; r2 = p[2];
+            spark[tid] = r2;
             rz = HAS_DEPTH ? zwin[ridx] : 0.0f;
             ++my_fetched;
             // Which 8x8 quadrants can the splat touch?  Separating-axis test of the oriented quad
             // (shrunk to the radius where alpha can still reach 1/255) against each quadrant's box of
             // pixel centres: the box axes (= bbox test) and the quad's own two axes.  Conservative.
-            const float rq = ((a.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius(r2.w)) + 1.0e-3f;
-            const float bx0 = r0.x - r1.z, bx1 = r0.x + r1.z, by0 = r0.y - r1.w, by1 = r0.y + r1.w;
+            // r0 = (cx, cy, hx, hy), r1 = (a1x, a1y, b1x, b1y) = kappa e/s1, kappa e_perp/s2, r2 = (r, g, b, opacity)
+            const float rqk = (((a.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius(r2.w)) + 1.0e-3f) * GSR_KAPPA;
+            const float bx0 = r0.x - r0.z, bx1 = r0.x + r0.z, by0 = r0.y - r0.w, by1 = r0.y + r0.w;
             const bool xl = bx0 <= tcx0 + 7.0f, xr = bx1 >= tcx0 + 8.0f;
             const bool yb = by0 <= tcy0 + 7.0f, yt = by1 >= tcy0 + 8.0f;
-            const float ext = 3.5f * (__builtin_fabsf(r0.z) + __builtin_fabsf(r0.w));  // box radius along e (and e_perp)
-            const float lim1 = rq + ext * r1.x, lim2 = rq + ext * r1.y;
+            // radius of a quadrant's box of pixel centres along each (scaled) quad axis
+            const float lim1 = rqk + 3.5f * (__builtin_fabsf(r1.x) + __builtin_fabsf(r1.y));
+            const float lim2 = rqk + 3.5f * (__builtin_fabsf(r1.z) + __builtin_fabsf(r1.w));
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const float ddx = (tcx0 + 3.5f + 8.0f * (float)(qd & 1)) - r0.x;
                 const float ddy = (tcy0 + 3.5f + 8.0f * (float)(qd >> 1)) - r0.y;
-                const float pu = __builtin_fabsf(ddx * r0.z + ddy * r0.w) * r1.x;
-                const float pv = __builtin_fabsf(ddy * r0.z - ddx * r0.w) * r1.y;
+                const float pu = __builtin_fabsf(ddx * r1.x + ddy * r1.y);
+                const float pv = __builtin_fabsf(ddx * r1.z + ddy * r1.w);
                 const bool box = ((qd & 1) ? xr : xl) && ((qd >> 1) ? yt : yb);
                 if (box && (((a.flags & GSR_FLAG_NO_SAT) != 0) || (pu <= lim1 && pv <= lim2))) m |= 1u << qd;
             }
+            // the record's two affine forms at the tile origin (contract v2, same operations as the oracle)
+            const float d0x = tcx0 - r0.x, d0y = tcy0 - r0.y;
+            c0 = gsr_fma(d0x, r1.x, d0y * r1.y);
+            c1 = gsr_fma(d0x, r1.z, d0y * r1.w);
         }
         // (3) per-quadrant list positions: rank inside this gathering wave now, wave bases after the barrier
         uint32_t rnk[4];
@@ -220,20 +234,26 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
             for (int qd = 0; qd < 4; ++qd) {
                 if (!((m >> qd) & 1u)) continue;
                 const uint32_t pos = (uint32_t)((base >> (16 * qd)) & 0xffffu) + rnk[qd];
-                float* blk = reinterpret_cast<float*>(&slist[qd][(pos >> 1) * BL_PAIR_F4]);
+                float* blk = reinterpret_cast<float*>(&slist[qd][(pos >> 1) * PF4]);
                 const uint32_t h = pos & 1u;
-                blk[0 + h] = r0.x; blk[2 + h] = r0.y; blk[4 + h] = r0.z; blk[6 + h] = r0.w;
-                blk[8 + h] = r1.x; blk[10 + h] = r1.y; blk[12 + h] = r2.w; blk[14 + h] = rz;
-                reinterpret_cast<float4*>(blk)[4 + h] = make_float4(r2.x, r2.y, r2.z, 1.0f);
+                blk[0 + h] = r1.x; blk[2 + h] = r1.y; blk[4 + h] = r1.z; blk[6 + h] = r1.w;
+                blk[8 + h] = c0; blk[10 + h] = c1;
+                reinterpret_cast<float4*>(blk)[3 + h] = spark[tid];
+                if (HAS_DEPTH) blk[20 + h] = rz;
             }
         }
         if (tid < 4) {   // odd list: pad with a record that cannot contribute (opacity 0 -> alpha 0 < 1/255)
             const uint32_t cnt = (uint32_t)((total >> (16 * tid)) & 0xffffu);
             if (cnt & 1u) {
-                float* blk = reinterpret_cast<float*>(&slist[tid][(cnt >> 1) * BL_PAIR_F4]);
-                blk[1] = 0.0f; blk[3] = 0.0f; blk[5] = 1.0f; blk[7] = 0.0f;
-                blk[9] = 0.0f; blk[11] = 0.0f; blk[13] = 0.0f; blk[15] = 0.0f;
-                reinterpret_cast<float4*>(blk)[5] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+                float* blk = reinterpret_cast<float*>(&slist[tid][(cnt >> 1) * PF4]);
+                blk[1] = 0.0f; blk[3] = 0.0f; blk[5] = 0.0f; blk[7] = 0.0f;
+                blk[9] = 0.0f; blk[11] = 0.0f;
+                // colour and opacity 0 (the axes may be stale garbage: a NaN there is rejected by the quad test).  The zero is
+                // made in place: hipcc would otherwise keep a float4 of zeros live across the whole loop -- and spill it.
+                float z;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+                blk[16] = z; blk[17] = z; blk[18] = z; blk[19] = z;
+                if (HAS_DEPTH) blk[21] = 0.0f;
             }
         }
         q_head += (uint32_t)take;
@@ -249,38 +269,39 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
             while (p < npairs) {
                 const int pend = (p + 32 < npairs) ? p + 32 : npairs;
                 for (; p < pend; ++p) {
-                    const float4 v0 = L[p * BL_PAIR_F4 + 0], v1 = L[p * BL_PAIR_F4 + 1], v2 = L[p * BL_PAIR_F4 + 2];
-                    const float4 v3 = L[p * BL_PAIR_F4 + 3], v4 = L[p * BL_PAIR_F4 + 4], v5 = L[p * BL_PAIR_F4 + 5];
-                    const gsr_v2f dx = fx - (gsr_v2f){v0.x, v0.y};
-                    const gsr_v2f dy = fy - (gsr_v2f){v0.z, v0.w};
-                    const gsr_v2f ex = {v1.x, v1.y}, ey = {v1.z, v1.w};
-                    const gsr_v2f u = gsr_fma2(dx, ex, dy * ey);
-                    const gsr_v2f v = gsr_fma2(dy, ex, -(dx * ey));
-                    const gsr_v2f q0 = u * (gsr_v2f){v2.x, v2.y};
-                    const gsr_v2f q1 = v * (gsr_v2f){v2.z, v2.w};
-                    const gsr_v2f power = -gsr_fma2(q0, q0, q1 * q1);
-                    // (lanes outside the quad may feed exp a large negative argument: their result is unused)
-                    gsr_v2f alpha = gsr_expf2(power) * (gsr_v2f){v3.x, v3.y};
-                    alpha = __builtin_elementwise_min(alpha, (gsr_v2f)(1.0f));   // opacity >= 0: no lower clamp needed
-                    // |q0| <= 2 && |q1| <= 2  <=>  max(|q0|, |q1|) <= 2: one v_max + one v_cmp instead of two v_cmp
-                    const bool ina = (__builtin_fmaxf(__builtin_fabsf(q0.x), __builtin_fabsf(q1.x)) <= 2.0f) &&
-                                     (alpha.x >= (1.0f / 255.0f)) && (!HAS_DEPTH || v3.z <= dpx);
-                    const bool inb = (__builtin_fmaxf(__builtin_fabsf(q0.y), __builtin_fabsf(q1.y)) <= 2.0f) &&
-                                     (alpha.y >= (1.0f / 255.0f)) && (!HAS_DEPTH || v3.w <= dpx);
-                    // branch-free under-blend: a rejected fragment blends alpha = 0, which leaves C and A
-                    // bit-identical (fma(t, +-0, C) == C), and costs no exec-mask juggling on the scalar unit.
-                    // {C0,C1} and {C2,A} update as pairs: the staged colour is (r,g,b,1), and
-                    // fma(t, 1*aa, A) == fma(t, aa, A) exactly.
-                    float t = 1.0f - CA.y;
-                    const float aa = (ina && t >= GSR_T_MIN) ? alpha.x : 0.0f;
-                    C01 = gsr_fma2((gsr_v2f)(t), (gsr_v2f){v4.x, v4.y} * (gsr_v2f)(aa), C01);
-                    CA = gsr_fma2((gsr_v2f)(t), (gsr_v2f){v4.z, v4.w} * (gsr_v2f)(aa), CA);
-                    t = 1.0f - CA.y;
-                    const float ab = (inb && t >= GSR_T_MIN) ? alpha.y : 0.0f;
-                    C01 = gsr_fma2((gsr_v2f)(t), (gsr_v2f){v5.x, v5.y} * (gsr_v2f)(ab), C01);
-                    CA = gsr_fma2((gsr_v2f)(t), (gsr_v2f){v5.z, v5.w} * (gsr_v2f)(ab), CA);
+                    const float4 v0 = L[p * PF4 + 0], v1 = L[p * PF4 + 1], v2 = L[p * PF4 + 2];
+                    const float4 v3 = L[p * PF4 + 3], v4 = L[p * PF4 + 4];
+                    // kappa * (quad-local coordinate) of this pixel for the two records
+                    const gsr_v2f q0 = gsr_fma2(lx, (gsr_v2f){v0.x, v0.y}, gsr_fma2(ly, (gsr_v2f){v0.z, v0.w}, (gsr_v2f){v2.x, v2.y}));
+                    const gsr_v2f q1 = gsr_fma2(lx, (gsr_v2f){v1.x, v1.y}, gsr_fma2(ly, (gsr_v2f){v1.z, v1.w}, (gsr_v2f){v2.z, v2.w}));
+                    const gsr_v2f pw = gsr_fma2(q0, q0, q1 * q1);
+                    // (lanes outside the quad may feed exp2 a large negative argument: their result is unused)
+                    const gsr_v2f e = gsr_exp2n2(-pw);
+                    // clamp(exp * opacity, 0, 1): folds into the multiply's clamp modifier
+                    const float ala = __builtin_fminf(__builtin_fmaxf(e.x * v3.w, 0.0f), 1.0f);
+                    const float alb = __builtin_fminf(__builtin_fmaxf(e.y * v4.w, 0.0f), 1.0f);
+                    bool ina = (__builtin_fmaxf(__builtin_fabsf(q0.x), __builtin_fabsf(q1.x)) <= GSR_QLIM) && (ala >= (1.0f / 255.0f));
+                    bool inb = (__builtin_fmaxf(__builtin_fabsf(q0.y), __builtin_fabsf(q1.y)) <= GSR_QLIM) && (alb >= (1.0f / 255.0f));
+                    if (HAS_DEPTH) {
+                        const float4 v5 = L[p * PF4 + 5];
+                        ina = ina && (v5.x <= dpx);
+                        inb = inb && (v5.y <= dpx);
+                    }
+                    // branch-free under-blend: a rejected fragment blends weight 0, which leaves C and T
+                    // bit-identical and costs no exec-mask juggling on the scalar unit.  w = (1-A)*alpha once;
+                    // {C0,C1} update as a register pair.
+                    // a PIXEL stops accumulating once T < 2^-14: per pixel, so the image is a pure function of the
+                    // depth-ordered records -- independent of rounds, quadrant masks, super-tiles and shards
+                    const float wa = T * ((ina && T >= GSR_T_MIN) ? ala : 0.0f);
+                    C01 = gsr_fma2((gsr_v2f)(wa), (gsr_v2f){v3.x, v3.y}, C01);
+                    C2 = gsr_fma(wa, v3.z, C2);
+                    T = T - wa;
+                    const float wb = T * ((inb && T >= GSR_T_MIN) ? alb : 0.0f);
+                    C01 = gsr_fma2((gsr_v2f)(wb), (gsr_v2f){v4.x, v4.y}, C01);
+                    C2 = gsr_fma(wb, v4.z, C2);
+                    T = T - wb;
                 }
-                if (__all(!pix_ok || (1.0f - CA.y) < GSR_T_MIN)) { wave_done = true; break; }
+                if (__all(!pix_ok || T < GSR_T_MIN)) { wave_done = true; break; }
             }
             const int evald = 2 * p;
             my_evals += (uint32_t)(evald < cnt ? evald : cnt);
@@ -289,8 +310,13 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
         __syncthreads();   // the lists (and consumed queue slots) may be overwritten from here on
     }
     if (pix_ok) {
-        const int brow = lty * GSR_TILE_PX + (wave >> 1) * 8 + (lane >> 3);
-        out[(size_t)brow * a.width + px] = make_float4(C01.x, C01.y, CA.x, CA.y);
+        // (pixel coordinates re-derived from an opaque copy of the thread id: keeping them live across the loop costs a spill)
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        const int w2 = t2 >> 6, l2 = t2 & 63;
+        const int brow = lty * GSR_TILE_PX + (w2 >> 1) * 8 + (l2 >> 3);
+        const int bcol = tx * GSR_TILE_PX + (w2 & 1) * 8 + (l2 & 7);
+        out[(size_t)brow * a.width + bcol] = make_float4(C01.x, C01.y, C2, 1.0f - T);
     }
     // bookkeeping for the roofline: list entries scanned and records gathered by this tile
 #pragma unroll

@@ -96,7 +96,9 @@ __device__ __forceinline__ float lin3(const float* m, float x, float y, float z)
 // M = diag(scale) R(q)^T Obj^T, EWA projection with the view matrix (+0.3 low-pass), eigen-decomposition
 // -> unit major axis e and the two axis lengths (shaders/GSplatShaderCoreLib.h:10-93).  obm = mat3 of the
 // object matrix (rows), or the identity for the wire program, which never applies it.
-__device__ __forceinline__ void gsr_covariance_axes(const GsrFrame& f, const float* obm, float x, float y, float z,
+// Returns false when the projected covariance is not finite (inf/NaN scale or orient halves, or overflow): such a splat
+// is dropped -- fminf(NaN, 4096) would otherwise turn it into a screen-filling 4096-px quad.
+__device__ __forceinline__ bool gsr_covariance_axes(const GsrFrame& f, const float* obm, float x, float y, float z,
                                                     float sx, float sy, float sz, float qi, float qj, float qk,
                                                     float qr, float& ex, float& ey, float& s1, float& s2)
 {
@@ -174,6 +176,7 @@ __device__ __forceinline__ void gsr_covariance_axes(const GsrFrame& f, const flo
     }
     s1 = __builtin_fminf(__builtin_sqrtf(2.0f * lambda1), 4096.0f);
     s2 = __builtin_fminf(__builtin_sqrtf(2.0f * lambda2), 4096.0f);
+    return __builtin_fabsf(lambda1) < 3.0e38f;   // false for inf and NaN
 }
 
 // K1: one thread per splat.
@@ -248,7 +251,7 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
             const float qr = gsr_h2f(b.w & 0xffffu);
 
             float ex, ey, s1, s2;
-            gsr_covariance_axes(f, f.ob, x, y, z, sx, sy, sz, qi, qj, qk, qr, ex, ey, s1, s2);
+            const bool finite = gsr_covariance_axes(f, f.ob, x, y, z, sx, sy, sz, qi, qj, qk, qr, ex, ey, s1, s2);
             // conservative bbox of the part of the quad where alpha can reach 1/255 (|q| <= rq <= 2)
             const float rq = (f.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius(opacity);
             const float hx = gsr_fma(rq * gsr_fma(s1, __builtin_fabsf(ex), s2 * __builtin_fabsf(ey)), 1.0001f, 0.01f);
@@ -258,7 +261,7 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
             const float xlo = cx - hx - 0.5f, xhi = cx + hx - 0.5f;
             const float ylo = cy - hy - 0.5f, yhi = cy + hy - 0.5f;
             const float wm1 = (float)(f.width - 1), hm1 = (float)(f.height - 1);
-            if (xhi >= 0.0f && xlo <= wm1 && yhi >= 0.0f && ylo <= hm1) {
+            if (finite && xhi >= 0.0f && xlo <= wm1 && yhi >= 0.0f && ylo <= hm1) {
                 const int i0 = (int)__builtin_ceilf(__builtin_fmaxf(xlo, 0.0f));
                 const int i1 = (int)__builtin_floorf(__builtin_fminf(xhi, wm1));
                 const int j0 = (int)__builtin_ceilf(__builtin_fmaxf(ylo, 0.0f));
@@ -312,14 +315,12 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
                     cg = gsr_shade_sh(cg, shg, dx, dy, dz, f.sh_order);
                     cbl = gsr_shade_sh(cbl, shb, dx, dy, dz, f.sh_order);
                 }
-                GsrRecord o;
-                o.cx = cx; o.cy = cy; o.ex = ex; o.ey = ey;
-                o.is1 = 1.0f / s1; o.is2 = 1.0f / s2; o.hx = hx; o.hy = hy;
-                o.r = cr; o.g = cg; o.b = cbl; o.opacity = opacity;
+                // contract v2: the quad-local coordinate as two affine forms scaled by kappa = sqrt(log2 e)
+                const float k1 = (1.0f / s1) * GSR_KAPPA, k2 = (1.0f / s2) * GSR_KAPPA;
                 float4* dst = reinterpret_cast<float4*>(rec + i);
-                dst[0] = make_float4(o.cx, o.cy, o.ex, o.ey);
-                dst[1] = make_float4(o.is1, o.is2, o.hx, o.hy);
-                dst[2] = make_float4(o.r, o.g, o.b, o.opacity);
+                dst[0] = make_float4(cx, cy, hx, hy);
+                dst[1] = make_float4(ex * k1, ey * k1, -(ey * k2), ex * k2);
+                dst[2] = make_float4(cr, cg, cbl, opacity);
             }
         }
         // key 0xffffffff (never a real key: keys are distance^2 bits minus key_min) marks a splat the first

@@ -60,7 +60,7 @@ k_wire_splats(uint32_t n, GsrFrame f, const float4* __restrict__ geoA, const uin
     const float qi = gsr_h2f(b.y >> 16), qj = gsr_h2f(b.z & 0xffffu), qk = gsr_h2f(b.z >> 16), qr = gsr_h2f(b.w & 0xffffu);
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     float ex, ey, s1, s2;
-    gsr_covariance_axes(f, ident, x, y, z, sx, sy, sz, qi, qj, qk, qr, ex, ey, s1, s2);
+    if (!gsr_covariance_axes(f, ident, x, y, z, sx, sy, sz, qi, qj, qk, qr, ex, ey, s1, s2)) return;   // non-finite covariance
     // corner(sx, sy) = c + sx*(2 s1 e) + sy*(2 s2 e_perp), e_perp = (-ey, ex)
     const float ax = (2.0f * s1) * ex, ay = (2.0f * s1) * ey;
     const float bx = (2.0f * s2) * (-ey), by = (2.0f * s2) * ex;

@@ -49,12 +49,12 @@ class gsr_stats(C.Structure):
 
 class gsr_debug_record(C.Structure):
     _fields_ = [(n, C.c_float) for n in
-                ("cx", "cy", "ex", "ey", "is1", "is2", "hx", "hy", "r", "g", "b", "opacity", "key")] + \
+                ("cx", "cy", "a1x", "a1y", "b1x", "b1y", "hx", "hy", "r", "g", "b", "opacity", "key")] + \
                [("visible", C.c_int32)]
 
 
 DEBUG_RECORD_DTYPE = np.dtype([(n, np.float32) for n in
-                               ("cx", "cy", "ex", "ey", "is1", "is2", "hx", "hy", "r", "g", "b", "opacity", "key")]
+                               ("cx", "cy", "a1x", "a1y", "b1x", "b1y", "hx", "hy", "r", "g", "b", "opacity", "key")]
                               + [("visible", np.int32)])
 
 

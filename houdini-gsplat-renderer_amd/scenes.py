@@ -106,3 +106,38 @@ def make_config(name: str, n_override: int | None = None) -> tuple[Splats, dict]
         # the example scene overwrites Cd with 0.5 grey before the SOP
         s.Cd[:] = f16bits(np.full((1, 3), 0.5))
     return s, cfg
+
+
+INRIA_PROPERTIES = ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{k}" for k in range(45)] + \
+                   ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+
+
+def make_inria_raw(n: int, seed: int, radius: float = 1.0, log_scale_range=(-5.5, -3.5)) -> np.ndarray:
+    """RAW (pre-activation) INRIA 3DGS attributes with the distributions of make_scene(): what the example scene's
+    `file1` node would import (the capture itself is not shipped) -- structured float32 array with
+    the PLY property names; ply.splats_from_inria() applies the scene's activations to it."""
+    rng = np.random.default_rng(seed)
+    v = np.zeros(n, dtype=[(nm, "<f4") for nm in INRIA_PROPERTIES])
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    p = d * (radius * rng.random(n) ** (1.0 / 3.0))[:, None]
+    v["x"], v["y"], v["z"] = p[:, 0], p[:, 1], p[:, 2]
+    for k in range(3):
+        v[f"f_dc_{k}"] = rng.standard_normal(n)
+        v[f"scale_{k}"] = rng.uniform(log_scale_range[0], log_scale_range[1], n)     # log scale (activation: exp)
+    fr = rng.normal(0.0, 0.1, (n, 45))
+    for k in range(45):
+        v[f"f_rest_{k}"] = fr[:, k]
+    v["opacity"] = rng.normal(0.0, 2.0, n)                                            # logit (activation: sigmoid)
+    q = rng.standard_normal((n, 4)) * rng.uniform(0.5, 2.0, (n, 1))                   # un-normalised (activation: normalize)
+    for k in range(4):
+        v[f"rot_{k}"] = q[:, k]
+    return v
+
+
+def write_inria_ply(path: str, v: np.ndarray) -> None:
+    hdr = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % v.shape[0]
+    hdr += "".join(f"property float {nm}\n" for nm in v.dtype.names) + "end_header\n"
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        f.write(v.tobytes())

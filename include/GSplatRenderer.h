@@ -25,7 +25,6 @@
 #ifdef __cplusplus
 #include <map>
 #include <memory>
-#include <set>
 #include <string>
 #include <vector>
 
@@ -66,6 +65,9 @@ public:
     /* device >= 0: bind a libgsplat_hip context on that GPU;
      * device <  0: "dry" instance -- registry/staging logic only, no GPU (tests). */
     explicit GSplatRenderer(int device);
+    /* several GPUs behind the same nine verbs, driven from the one draw thread (gsr_multi_*, gsplat_hip.h):
+     * tile rows are sharded over `devices`, the frame lands on devices[0].  transport: GSR_TRANSPORT_*. */
+    GSplatRenderer(const int* devices, int count, int transport);
     ~GSplatRenderer();
     GSplatRenderer(const GSplatRenderer&) = delete;
     GSplatRenderer& operator=(const GSplatRenderer&) = delete;
@@ -98,49 +100,65 @@ public:
     int64_t query(int what, const std::string& id = std::string()) const;
     void origin(float out[3]) const;
     void lastCameraPos(float out[3]) const;
-    gsr_context* engine() const { return myEngine; }
+    gsr_context* engine() const { return engine_; }
+    gsr_multi* multi() const { return multi_; }
 
     static unsigned int closestSqrtPowerOf2(int n); /* src/GSplatRenderer.C:155-163 */
 
 private:
-    struct GSplatRegisterEntry { /* include/GSplatRenderer.h:59-76 */
-        const void* gdp = nullptr;
-        GSplatCacheVersion gversion;
-        int64_t gvtx = 0;
-        int64_t splatCount = 0;
-        float splatOrigin[3] = {0, 0, 0};
-        bool active = false;
-        int age = -1;
-        int ageSinceLastActive = -1;
-        const float* splatPts = nullptr;
-        const uint16_t* splatColors = nullptr;
-        const float* splatAlphas = nullptr;
-        const uint16_t* splatScales = nullptr;
-        const uint16_t* splatOrients = nullptr;
-        const uint16_t* splatShxs = nullptr;
-        const uint16_t* splatShys = nullptr;
-        const uint16_t* splatShzs = nullptr;
-        int64_t shCount = 0;
+    /* one registered primitive (what registerUpdate() was told; arrays borrowed) */
+    struct Row {
+        const void* detail = nullptr;
+        GSplatCacheVersion version;
+        int64_t count = 0;
+        float origin[3] = {0, 0, 0};
+        const float* P = nullptr;
+        const uint16_t* Cd = nullptr;
+        const float* alpha = nullptr;
+        const uint16_t* scale = nullptr;
+        const uint16_t* orient = nullptr;
+        const uint16_t *shx = nullptr, *shy = nullptr, *shz = nullptr;
+        int64_t sh_count = 0;
+        bool shown = false;             /* includeInRenderPass() since the last postRender() */
+        int redraws = -1;               /* postRender() calls since registration, minus one */
+        int redraws_since_shown = -1;   /* -1 = never shown */
     };
-    bool isRenderStateRegistryCurrent() const;
+    /* what one redraw puts on the GPU */
+    struct Plan {
+        struct Part { std::string id; int64_t take; };
+        std::vector<Part> parts;        /* rows in packing order, with the number of splats taken from each */
+        int64_t total = 0;              /* splats in the pass (<= 2^23 - 1) */
+        int64_t wanted = 0;             /* splats the joined rows hold before truncation */
+        int64_t registered = 0;         /* splats in the whole table */
+        bool sh = false;
+        float origin[3] = {0, 0, 0};
+        bool sameAs(const Plan& o) const
+        {
+            if (parts.size() != o.parts.size() || total != o.total) return false;
+            for (size_t k = 0; k < parts.size(); ++k)
+                if (parts[k].id != o.parts[k].id || parts[k].take != o.parts[k].take) return false;
+            return true;
+        }
+    };
+    Plan planFrame() const;
+    bool upload(const Plan& p);
 
-    std::map<std::string, std::unique_ptr<GSplatRegisterEntry>> myRenderStateRegistry;
-    std::set<std::string> myActiveRegistries;
-    gsr_context* myEngine = nullptr;
-    bool myDry = false;
-    float mySplatOrigin[3] = {0, 0, 0};
-    int64_t myGSplatCount = 0;
-    bool myIsRenderEnabled = true;
-    bool myIsShDataPresent = false;
-    bool myCanRender = false;
-    bool myIsExplicitCameraPosSet = false;
-    float myExplicitCameraPos[3] = {0, 0, 0};
-    float myLastCameraPos[3] = {0, 0, 0};
-    int myShOrder = 3;
-    int64_t myStagingCount = 0, myRenderCount = 0;
-    int myLastStatus = 0;
-    bool myJustPrintedOBJLevelRenderingWarning = false;
-    bool myVersionLogged = false;
+    std::map<std::string, Row> table_;
+    Plan resident_;                     /* the plan whose splats are in HBM */
+    bool resident_ok_ = false;
+    gsr_context* engine_ = nullptr;     /* one GPU ... */
+    gsr_multi* multi_ = nullptr;        /* ... or several */
+    bool dry_ = false;
+    bool enabled_ = true;
+    bool can_render_ = false;
+    bool eye_override_ = false;
+    float eye_explicit_[3] = {0, 0, 0};
+    float eye_[3] = {0, 0, 0};
+    int sh_order_ = 3;
+    int64_t stagings_ = 0, frames_ = 0;
+    int status_ = 0;
+    bool obj_notice_given_ = false;
+    bool greeted_ = false;
 };
 
 extern "C" {
@@ -150,6 +168,7 @@ extern "C" {
 typedef struct gsplat_renderer gsplat_renderer;
 
 gsplat_renderer* gsplat_renderer_create(int device);       /* device < 0: dry instance; NULL on failure */
+gsplat_renderer* gsplat_renderer_create_multi(const int* devices, int count, int transport);   /* gsr_multi_create behind the verbs */
 gsplat_renderer* gsplat_renderer_get_instance(void);       /* the singleton (GPU 0) */
 void gsplat_renderer_destroy(gsplat_renderer* h);           /* not for the singleton */
 /* writes the registry id (NUL-terminated) into id_out; returns its length or <0 */
@@ -171,6 +190,7 @@ int64_t gsplat_renderer_query(gsplat_renderer* h, int what, const char* id_or_nu
 void gsplat_renderer_get_origin(gsplat_renderer* h, float out[3]);
 void gsplat_renderer_get_last_camera_pos(gsplat_renderer* h, float out[3]);
 gsr_context* gsplat_renderer_engine(gsplat_renderer* h);
+gsr_multi* gsplat_renderer_multi(gsplat_renderer* h);
 unsigned int gsplat_closest_sqrt_power_of_2(int n);
 
 /* ---- attribute ingest (what GR_PrimGsplat::update does before registerUpdate,

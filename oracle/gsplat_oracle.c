@@ -112,6 +112,32 @@ float gso_expf(float x)
     return y;
 }
 
+/* Contract v2: the fragment stage evaluates the gaussian as 2^(-|kappa q|^2) with kappa^2 = log2(e) folded into the
+ * quad axes (vertex stage), so exp() becomes a base-2 exponential whose range reduction is EXACT
+ * (r = x - rint(x)) -- 8 instead of 13 operations per fragment on the GPU.  x <= 0, |x| < 2^22:
+ * s = x + 1.5*2^23 rounds x to the nearest-even integer (kf = s - 1.5*2^23), r = x - kf in [-0.5, 0.5],
+ * 2^r by a degree-5 polynomial (minimax on that interval, <= 2.8 ulp overall, exp2(0) == 1, never above 1),
+ * scaled by 2^kf through the exponent field.                                                              */
+float gso_exp2f(float x)
+{
+    const float magic = 12582912.0f;
+    float s = x + magic;
+    float kf = s - magic;
+    float r = x - kf;
+    float p = 1.3292919611558318e-3f;
+    p = fmaf(p, r, 9.671509265899658e-3f);
+    p = fmaf(p, r, 5.550636723637581e-2f);
+    p = fmaf(p, r, 2.4022242426872253e-1f);
+    p = fmaf(p, r, 6.931470632553101e-1f);
+    float y = fmaf(p, r, 1.0f);
+    int32_t k = (int32_t)kf;
+    uint32_t bits;
+    memcpy(&bits, &y, 4);
+    bits += (uint32_t)k << 23;
+    memcpy(&y, &bits, 4);
+    return y;
+}
+
 /* src/GSplatRenderer.C:155-163 (texture side length); kept as a KAT target */
 unsigned gso_closest_sqrt_power_of_2(int n)
 {
@@ -170,7 +196,9 @@ static float shade_sh_channel(float base, const float* sh, float x, float y, flo
 /* Covariance chain shared by the beauty path and the wireframe overlay.  use_object = 0 for the wire
  * program, which never multiplies by transpose(mat3(glH_ObjectMatrix)) (shaders/GSplatShaderSource.h:75-77). */
 #define OB(r, c) (use_object ? M4(f->object, (r), (c)) : ((r) == (c) ? 1.0f : 0.0f))
-static void covariance_axes(const gso_frame* f, int use_object, float x, float y, float z, float sx, float sy, float sz,
+/* Returns 0 when the projected covariance is not finite (inf/NaN attribute halves, overflow): the contract drops such a
+ * splat (GLSL leaves min(NaN, 4096) undefined; it must not become a screen-filling quad).                         */
+static int covariance_axes(const gso_frame* f, int use_object, float x, float y, float z, float sx, float sy, float sz,
                             float qi, float qj, float qk, float qr, float* pex, float* pey, float* ps1, float* ps2)
 {
     const float W = (float)f->width;
@@ -264,6 +292,7 @@ static void covariance_axes(const gso_frame* f, int use_object, float x, float y
      * two flips cancel in GL window coordinates, leaving axes s1*e, s2*e_perp. */
     *ps1 = fminf(sqrtf(2.0f * lambda1), 4096.0f);
     *ps2 = fminf(sqrtf(2.0f * lambda2), 4096.0f);
+    return fabsf(lambda1) < 3.0e38f;
 }
 #undef OB
 
@@ -325,11 +354,21 @@ static void project_splat(const gso_splats* s, const gso_frame* f, int64_t i, gs
     const float qr = gso_half_to_float(s->orient[4 * i + 3]);
 
     float ex, ey, s1, s2;
-    covariance_axes(f, 1, x, y, z, sx, sy, sz, qi, qj, qk, qr, &ex, &ey, &s1, &s2);
+    if (!covariance_axes(f, 1, x, y, z, sx, sy, sz, qi, qj, qk, qr, &ex, &ey, &s1, &s2)) return;
     o->ex = ex;
     o->ey = ey;
     o->is1 = 1.0f / s1;
     o->is2 = 1.0f / s2;
+    /* contract v2: quad-local coordinate scaled by kappa = sqrt(log2 e), as two affine forms of the pixel position
+     * (the fragment shader's interpolated fsIn.pos, shaders/GSplatShaderSource.h:276-282,305-306, times kappa):
+     *   kq0 = d . (a1x, a1y),  kq1 = d . (b1x, b1y),  d = pixel centre - quad centre                         */
+    {
+        const float k1 = o->is1 * GSO_KAPPA, k2 = o->is2 * GSO_KAPPA;
+        o->a1x = ex * k1;
+        o->a1y = ey * k1;
+        o->b1x = -(ey * k2);
+        o->b1y = ex * k2;
+    }
     /* conservative bbox of the +-2 quad (padding covers rounding in q) */
     o->hx = fmaf(2.0f * fmaf(s1, fabsf(ex), s2 * fabsf(ey)), 1.0001f, 0.01f);
     o->hy = fmaf(2.0f * fmaf(s1, fabsf(ey), s2 * fabsf(ex)), 1.0001f, 0.01f);
@@ -439,6 +478,19 @@ int gso_host_sort_only(const float* P, int64_t n, const float cam_pos[3], int32_
  * FS: shaders/GSplatShaderSource.h:304-312.  Blend: src factor
  * ONE_MINUS_DST_ALPHA, dst factor ONE, equation ADD, for colour and alpha
  * (src/GSplatRenderer.C:613-621).                                           */
+/* While a frame is being composited the ALPHA channel of rgba holds the transmittance T = 1 - A (cleared to 1 by
+ * begin_frame); finish_frame turns it into A.  Carrying T saves the product one subtraction per fragment.        */
+static void begin_frame(float* rgba, int width, int height)
+{
+    const size_t n = (size_t)width * (size_t)height;
+    for (size_t p = 0; p < n; ++p) { rgba[4 * p] = rgba[4 * p + 1] = rgba[4 * p + 2] = 0.0f; rgba[4 * p + 3] = 1.0f; }
+}
+static void finish_frame(float* rgba, int width, int height)
+{
+    const size_t n = (size_t)width * (size_t)height;
+    for (size_t p = 0; p < n; ++p) rgba[4 * p + 3] = 1.0f - rgba[4 * p + 3];
+}
+
 static void splat_rows_depth(const gso_record* o, int width, int height, int row_lo, int row_hi,
                              const float* depth, float* rgba);
 
@@ -461,28 +513,37 @@ static void splat_rows_depth(const gso_record* o, int width, int height, int row
     const int j1 = (int)floorf(fminf(yhi, (float)row_hi));
     const float inv255 = 1.0f / 255.0f;
     for (int j = j0; j <= j1; ++j) {
-        const float dy = ((float)j + 0.5f) - o->cy;
         float* row = rgba + (size_t)j * (size_t)width * 4;
+        /* Contract v2: positions are taken relative to the pixel's 16x16 TILE origin (the product composites per
+         * tile; relative coordinates keep every product small, and the per-(splat, tile) constants c0/c1 are shared
+         * by the tile's 256 pixels):  kq = l . a + ((tile origin - centre) . a),  l = pixel index inside the tile */
+        const int tj = j & ~(GSO_TILE - 1);
+        const float d0y = ((float)tj + 0.5f) - o->cy;
+        const float ly = (float)(j - tj);
         for (int i = i0; i <= i1; ++i) {
-            const float dx = ((float)i + 0.5f) - o->cx;
-            /* fsIn.pos: the quad-local coordinate in [-2,2]^2 */
-            const float u = fmaf(dx, o->ex, dy * o->ey);
-            const float v = fmaf(dy, o->ex, -(dx * o->ey));
-            const float qx = u * o->is1;
-            const float qy = v * o->is2;
-            if (!(fabsf(qx) <= 2.0f && fabsf(qy) <= 2.0f)) continue; /* outside the quad */
-            const float power = -fmaf(qx, qx, qy * qy);
-            float alpha = gso_expf(power) * o->opacity;
+            const int ti = i & ~(GSO_TILE - 1);
+            const float d0x = ((float)ti + 0.5f) - o->cx;
+            const float lx = (float)(i - ti);
+            const float c0 = fmaf(d0x, o->a1x, d0y * o->a1y);
+            const float c1 = fmaf(d0x, o->b1x, d0y * o->b1y);
+            /* kappa * fsIn.pos: the quad-local coordinate, |q| <= 2 <=> |kq| <= 2 kappa */
+            const float q0 = fmaf(lx, o->a1x, fmaf(ly, o->a1y, c0));
+            const float q1 = fmaf(lx, o->b1x, fmaf(ly, o->b1y, c1));
+            if (!(fmaxf(fabsf(q0), fabsf(q1)) <= GSO_QLIM)) continue; /* outside the quad */
+            const float pw = fmaf(q0, q0, q1 * q1);                   /* = log2(e) * |q|^2 */
+            float alpha = gso_exp2f(-pw) * o->opacity;                /* exp(-|q|^2) * opacity (:306-307) */
             alpha = fminf(fmaxf(alpha, 0.0f), 1.0f);
             if (alpha < inv255) continue; /* discard */
             /* depth test against the opaque pass (depth writes are off): GL_LEQUAL */
             if (depth && !(o->zwin <= depth[(size_t)j * (size_t)width + (size_t)i])) continue;
             float* px = row + (size_t)i * 4;
-            const float t = 1.0f - px[3];
-            px[0] = fmaf(t, o->r * alpha, px[0]);
-            px[1] = fmaf(t, o->g * alpha, px[1]);
-            px[2] = fmaf(t, o->b * alpha, px[2]);
-            px[3] = fmaf(t, alpha, px[3]);
+            /* src = (rgb*alpha, alpha), factors (1 - dst.a, 1): C += (1-A)*alpha*rgb, A += (1-A)*alpha, with the
+             * weight w = T*alpha formed once and T = 1 - A carried instead of A */
+            const float w = px[3] * alpha;
+            px[0] = fmaf(w, o->r, px[0]);
+            px[1] = fmaf(w, o->g, px[1]);
+            px[2] = fmaf(w, o->b, px[2]);
+            px[3] = px[3] - w;
         }
     }
 }
@@ -490,12 +551,13 @@ static void splat_rows_depth(const gso_record* o, int width, int height, int row
 int gso_blend_serial(const gso_record* rec, const int32_t* perm, int64_t n, int width, int height, float* rgba)
 {
     if (!rec || !perm || !rgba || width <= 0 || height <= 0) return -1;
-    memset(rgba, 0, (size_t)width * (size_t)height * 16);
+    begin_frame(rgba, width, height);
     for (int64_t r = 0; r < n; ++r) { /* instance order = sorted order, nearest first */
         const gso_record* o = &rec[perm[r]];
         if (!o->visible) continue;
         splat_rows(o, width, height, 0, height - 1, rgba);
     }
+    finish_frame(rgba, width, height);
     return 0;
 }
 
@@ -503,12 +565,13 @@ int gso_blend_serial_depth(const gso_record* rec, const int32_t* perm, int64_t n
                            const float* depth, float* rgba)
 {
     if (!rec || !perm || !rgba || width <= 0 || height <= 0) return -1;
-    memset(rgba, 0, (size_t)width * (size_t)height * 16);
+    begin_frame(rgba, width, height);
     for (int64_t r = 0; r < n; ++r) {
         const gso_record* o = &rec[perm[r]];
         if (!o->visible) continue;
         splat_rows_depth(o, width, height, 0, height - 1, depth, rgba);
     }
+    finish_frame(rgba, width, height);
     return 0;
 }
 
@@ -532,7 +595,7 @@ int gso_blend_parallel(const gso_record* rec, const int32_t* perm, int64_t n, in
                        float* rgba, int threads)
 {
     if (!rec || !perm || !rgba || width <= 0 || height <= 0) return -1;
-    memset(rgba, 0, (size_t)width * (size_t)height * 16);
+    begin_frame(rgba, width, height);
     const int nstrips = (height + GSO_STRIP - 1) / GSO_STRIP;
     /* bin splat ranks to strips, in rank order (two passes) */
     int64_t* start = (int64_t*)calloc((size_t)nstrips + 1, sizeof(int64_t));
@@ -576,6 +639,7 @@ int gso_blend_parallel(const gso_record* rec, const int32_t* perm, int64_t n, in
         for (int64_t k = start[s]; k < start[s + 1]; ++k)
             splat_rows(&rec[list[k]], width, height, row_lo, row_hi, rgba);
     }
+    finish_frame(rgba, width, height);
     free(start); free(slo); free(shi); free(list); free(cur);
     return 0;
 }
@@ -649,7 +713,7 @@ int gso_render_wire(const gso_splats* s, const gso_frame* f, float* rgba)
         const float qi = gso_half_to_float(s->orient[4 * i]), qj = gso_half_to_float(s->orient[4 * i + 1]),
                     qk = gso_half_to_float(s->orient[4 * i + 2]), qr = gso_half_to_float(s->orient[4 * i + 3]);
         float ex, ey, s1, s2;
-        covariance_axes(f, 0, x, y, z, sx, sy, sz, qi, qj, qk, qr, &ex, &ey, &s1, &s2);
+        if (!covariance_axes(f, 0, x, y, z, sx, sy, sz, qi, qj, qk, qr, &ex, &ey, &s1, &s2)) continue;
         const float ax = (2.0f * s1) * ex, ay = (2.0f * s1) * ey;
         const float bx = (2.0f * s2) * (-ey), by = (2.0f * s2) * ex;
         const float c0x = (cx - ax) - bx, c0y = (cy - ay) - by;

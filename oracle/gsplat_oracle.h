@@ -36,6 +36,11 @@
 extern "C" {
 #endif
 
+#define GSO_TILE  16                 /* the product's tile edge (include/gsplat_hip.h GSR_TILE): fragment positions
+                                        are formed relative to the tile origin (contract v2)                     */
+#define GSO_KAPPA 1.2011224087864498f /* sqrt(log2 e): exp(-|q|^2) == 2^(-|kappa q|^2)                            */
+#define GSO_QLIM  (2.0f * GSO_KAPPA)  /* the quad |q| <= 2 in kappa units                                         */
+
 /* Per-frame uniforms, named after the GLSL uniforms they stand for
  * (shaders/GSplatShaderSource.h:119-133,153-159).  Matrices are 16 floats in
  * GL column-major order, m[c*4+r] = element (row r, column c) of the matrix
@@ -62,6 +67,8 @@ typedef struct gso_record {
     float cx, cy;       /* quad centre, GL window coords (y up, pixel centres at +0.5) */
     float ex, ey;       /* unit major axis e; minor axis is (-ey, ex)                  */
     float is1, is2;     /* 1/s1, 1/s2 with s = min(sqrt(2*lambda), 4096)              */
+    float a1x, a1y;     /* kappa * e / s1        (contract v2: kappa = sqrt(log2 e))  */
+    float b1x, b1y;     /* kappa * e_perp / s2                                        */
     float hx, hy;       /* conservative half extents of the quad's bbox (not parity-relevant) */
     float r, g, b;      /* colour after SH                                            */
     float opacity;
@@ -95,7 +102,8 @@ typedef struct gso_splats {
 /* scalar helpers (exposed for known-answer tests) */
 float    gso_half_to_float(uint16_t h);
 uint16_t gso_float_to_half(float f);              /* round-to-nearest-even */
-float    gso_expf(float x);                       /* the contract's exp, x in [-80, 0] */
+float    gso_expf(float x);                       /* contract v1 exp, x in [-80, 0] (kept as a known-answer target) */
+float    gso_exp2f(float x);                      /* the contract's 2^x, x in [-100, 0] */
 unsigned gso_closest_sqrt_power_of_2(int n);      /* src/GSplatRenderer.C:155-163 */
 
 /* vertex stage for all splats; rec[n] */

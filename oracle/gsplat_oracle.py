@@ -37,12 +37,12 @@ class gso_frame(C.Structure):
 
 class gso_record(C.Structure):
     _fields_ = [(n, C.c_float) for n in
-                ("cx", "cy", "ex", "ey", "is1", "is2", "hx", "hy", "r", "g", "b", "opacity", "key", "zwin")] + \
+                ("cx", "cy", "ex", "ey", "is1", "is2", "a1x", "a1y", "b1x", "b1y", "hx", "hy", "r", "g", "b", "opacity", "key", "zwin")] + \
                [("visible", C.c_int32)]
 
 
 RECORD_DTYPE = np.dtype([(n, np.float32) for n in
-                         ("cx", "cy", "ex", "ey", "is1", "is2", "hx", "hy", "r", "g", "b", "opacity", "key", "zwin")]
+                         ("cx", "cy", "ex", "ey", "is1", "is2", "a1x", "a1y", "b1x", "b1y", "hx", "hy", "r", "g", "b", "opacity", "key", "zwin")]
                         + [("visible", np.int32)])
 
 
@@ -81,6 +81,8 @@ def lib() -> C.CDLL:
         L.gso_float_to_half.argtypes = [C.c_float]
         L.gso_expf.restype = C.c_float
         L.gso_expf.argtypes = [C.c_float]
+        L.gso_exp2f.restype = C.c_float
+        L.gso_exp2f.argtypes = [C.c_float]
         L.gso_closest_sqrt_power_of_2.restype = C.c_uint
         L.gso_closest_sqrt_power_of_2.argtypes = [C.c_int]
         L.gso_preprocess.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p]
@@ -250,6 +252,10 @@ def float_to_half(f: float) -> int:
 
 def expf(x: float) -> float:
     return float(lib().gso_expf(float(x)))
+
+
+def exp2f(x: float) -> float:
+    return float(lib().gso_exp2f(float(x)))
 
 
 def closest_sqrt_power_of_2(n: int) -> int:

@@ -496,7 +496,25 @@ def cases(pkg):
     return out
 
 
+def refresh_oracle_sha():
+    """The arithmetic contract changed (oracle + kernels together): keep the reference-GLSL images and captures,
+    re-check the new oracle against them with the acceptance rule of tests/helpers.py, re-pin its checksum."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import helpers
+    oracle = ge.load_oracle()
+    for name in helpers.golden_names():
+        path = os.path.join(HERE, name + ".npz")
+        d, s, c = helpers.load_golden(name)
+        img = oracle.render(s, c, d["origin"])
+        print(name, helpers.check_against_golden(img, d["image_reference_glsl"]))
+        arrays = {k: d[k] for k in d.files}
+        arrays["oracle_sha256"] = np.frombuffer(hashlib.sha256(img.tobytes()).digest(), dtype=np.uint8)
+        np.savez_compressed(path, **arrays)
+
+
 def main():
+    if "--refresh-oracle-sha" in sys.argv:
+        return refresh_oracle_sha()
     pkg = ge.load_package()
     oracle = ge.load_oracle()
     es = GLES()

@@ -68,3 +68,36 @@ def check_wire_against_golden(img, golden_wire):
     # where both drew the same splat's line the colour (Cd, fp16-exact) is identical
     eq = np.all(img[same] == golden_wire[same].astype(np.float32), axis=1)
     assert eq.mean() >= 0.97
+
+
+class HipBuffers:
+    """raw device buffers for tests that hand DEVICE pointers to the C ABI (hipMalloc / hipMemcpy through ctypes)"""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.hip = C.CDLL("libamdhip64.so")
+        self.ptrs = []
+
+    def alloc(self, nbytes: int) -> int:
+        p = self.C.c_void_p()
+        assert self.hip.hipMalloc(self.C.byref(p), self.C.c_size_t(nbytes)) == 0
+        self.ptrs.append(p)
+        return p.value
+
+    def upload(self, arr: np.ndarray) -> int:
+        a = np.ascontiguousarray(arr)
+        p = self.alloc(a.nbytes)
+        assert self.hip.hipMemcpy(self.C.c_void_p(p), self.C.c_void_p(a.ctypes.data), self.C.c_size_t(a.nbytes), 1) == 0
+        return p
+
+    def download(self, ptr: int, shape, dtype=np.float32) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        assert self.hip.hipDeviceSynchronize() == 0
+        assert self.hip.hipMemcpy(self.C.c_void_p(out.ctypes.data), self.C.c_void_p(ptr), self.C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def free(self):
+        for p in self.ptrs:
+            self.hip.hipFree(p)
+        self.ptrs = []

@@ -35,4 +35,12 @@ for k in acc:
         traffic[k] = {"fetch_KiB_reported": f, "write_KiB_reported": w,
                       "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
                       "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB->bytes); calibrated on k_preprocess whose reads are a pure stream"}
+# stamp: which kernel sources produced these numbers (bench.py replays them only for the same sources)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    traffic["_kernel_source_sha"] = bench.kernel_source_sha()
+except Exception as e:  # noqa: BLE001
+    traffic["_kernel_source_sha"] = "unknown: " + str(e)
+traffic["_collected"] = "rocprofv3 --kernel-trace --pmc passes of `python bench.py --no-cpu-baseline` (tools/gpu_pmc.sh " + os.path.basename(out.rstrip("/")) + ")"
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)

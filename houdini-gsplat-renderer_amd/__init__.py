@@ -14,6 +14,6 @@ Layout:
   ply.py      INRIA 3DGS .ply ingest with the example scene's activations
 """
 from . import build, camera, multigpu, ply, scenes  # noqa: F401  (no GPU needed)
-from .engine import Engine, GSplatRenderer, GsrError, lib_path, load_library  # noqa: F401
+from .engine import Engine, GSplatPrim, GSplatRenderer, GsrError, MultiEngine, lib_path, load_library  # noqa: F401
 
-__all__ = ["build", "camera", "multigpu", "ply", "scenes", "Engine", "GSplatRenderer", "GsrError", "lib_path", "load_library"]
+__all__ = ["build", "camera", "multigpu", "ply", "scenes", "Engine", "GSplatPrim", "GSplatRenderer", "GsrError", "MultiEngine", "lib_path", "load_library"]

@@ -8,11 +8,11 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgsplat_hip.so")
-SOURCES = ["gsr_api.hip", "GSplatRenderer.cpp"]
+SOURCES = ["gsr_api.hip", "gsr_multi.cpp", "GSplatRenderer.cpp", "gsplat_ingest.cpp"]
 HEADERS = ["gsr_device.h", "k_preprocess.h", "k_sort.h", "k_binning.h", "k_blend.h", "k_wire.h"]
 # -ffp-contract=off: only explicit fmaf() fuses (the float32 op-order contract)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-result"]
+         "-Wall", "-Wno-unused-result", "-ldl"]
 
 
 def hipcc() -> str:
@@ -27,7 +27,7 @@ def is_stale() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    deps += [os.path.join(HERE, "..", "include", f) for f in ("gsplat_hip.h", "GSplatRenderer.h")]
+    deps += [os.path.join(HERE, "..", "include", f) for f in ("gsplat_hip.h", "GSplatRenderer.h", "GSplatPrim.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -56,6 +56,33 @@ static int set_err(int code, const char* fmt, ...)
                            hipGetErrorString(e_), __FILE__, __LINE__);                             \
     } while (0)
 
+// what identifies a depth order: the geometry generation, the shard (a rank sorts only the splats it owns) and the camera
+struct SortKey {
+    uint64_t gen = 0;
+    int shard_index = 0, shard_count = 1, flags = 0;
+    gsr_camera cam{};
+    bool same(const SortKey& o) const
+    {
+        return gen == o.gen && shard_index == o.shard_index && shard_count == o.shard_count && flags == o.flags &&
+               std::memcmp(&cam, &o.cam, sizeof(gsr_camera)) == 0;
+    }
+};
+
+// what a queued frame needs again when it is finished (or its back end re-queued)
+struct FrameJob {
+    bool open = false;
+    GsrFrame f{};
+    uint32_t n = 0;
+    int local_tiles = 0, band_rows = 0, n_super = 0;
+    size_t out_px = 0;
+    float* target = nullptr;       // device buffer the blend kernel writes
+    float* user_out = nullptr;     // the caller's pointer (host or device)
+    const float* d_depth = nullptr;
+    bool out_is_device = false, timing = false, timing_all = false, use_map = false;
+    bool speculative = false;      // the back end was queued before the pair count was known
+    bool deferred = false;         // ... and the frame handed over without waiting for it (GSR_OPT_DEFERRED_CHECK)
+};
+
 // Everything one frame in flight owns: its HIP stream, the per-frame HBM arrays, the small
 // mailboxes and the stage events.  Two slots alternate, so that frame f+1's memory-bound front end
 // (k_preprocess, depth sort, binning) overlaps frame f's VALU-bound k_blend on the GPU.
@@ -91,15 +118,11 @@ struct FrameSlot {
     uint32_t* h_total_dev = nullptr;         // its device-side address
     unsigned long long* h_counters = nullptr;  // pinned + mapped: k_sum_work writes the frame's bookkeeping here
     unsigned long long* h_counters_dev = nullptr;
-    // depth-sort cache (argsortByDistance semantics)
-    // The cached order covers exactly the splats visible to the camera that sorted, so it is reused
-    // only for an identical frame description (the reference re-sorts on any camera translation,
-    // src/GSplatRenderer.C:165-186; a static viewport redraw is the case that matters)
+    // depth-sort cache: the frame description whose order is in (keyA, valA)
     bool sort_valid = false;
-    gsr_camera sort_camera{};
-    int sort_shard_index = 0, sort_shard_count = 1, sort_flags = 0;
-    uint64_t sort_gen = 0;
+    SortKey sort_key{};
     uint32_t key_min = 0;              // of the frame whose order is cached
+    FrameJob job;                      // the frame queued in this slot (open until frame_finish)
     // last frame rendered in this slot
     int last_tiles_x = 0, last_local_ty = 0, last_supers = 0;
     uint32_t last_pairs = 0;
@@ -139,10 +162,11 @@ struct gsr_context {
     int map_w = 0, map_h = 0, map_si = -1, map_sc = 0, map_shift = -1, map_grid = 0;
 
     int shard_index = 0, shard_count = 1;
-    int opt_swizzle = 1, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0;
+    int opt_swizzle = 1, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0;
 
     gsr_stats st{};
     uint64_t frame_no = 0;
+    size_t pair_want = 0;              // largest list buffer any frame slot needed so far
 };
 
 template <typename T>
@@ -163,6 +187,10 @@ static void dev_free(T*& p)
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------
+// for the other translation units of the library (gsr_multi.cpp)
+__attribute__((visibility("hidden"))) int gsr_internal_set_error(int code, const char* text) { return set_err(code, "%s", text); }
+void gsr_internal_comm_release(gsr_context* c);
+
 extern "C" int gsr_device_count(void)
 {
     int n = 0;
@@ -173,8 +201,12 @@ extern "C" int gsr_device_count(void)
 extern "C" const char* gsr_last_error(void) { return g_err; }
 extern "C" const char* gsr_version(void) { return GSR_VERSION_STR; }
 
+static int finish_open_frames(gsr_context* c);
+
 static int sync_all(gsr_context* c)
 {
+    int frc = finish_open_frames(c);   // deferred frames: look at their pair counts now
+    if (frc) return frc;
     for (int k = 0; k < GSR_MAX_SLOTS; ++k)
         if (c->slot[k].stream) HIP_TRY(hipStreamSynchronize(c->slot[k].stream));
     if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -268,6 +300,7 @@ extern "C" void gsr_destroy(gsr_context* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
+    gsr_internal_comm_release(c);
     free_geometry(c);
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) slot_destroy(c->slot[k]);
     dev_free(c->tile_map);
@@ -296,6 +329,7 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
         for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
         break;
     case GSR_OPT_DEBUG_FLAGS: c->opt_flags = value; break;
+    case GSR_OPT_DEFERRED_CHECK: c->opt_deferred = value ? 1 : 0; break;
     case GSR_OPT_SUPER_TILE:
         if (value != 0 && (value < 1 || value > 16 || (value & (value - 1))))
             return set_err(GSR_E_INVALID, "gsr_set_option: super-tile edge must be 0 (auto) or 1,2,4,8,16");
@@ -432,6 +466,14 @@ extern "C" int gsr_upload_end(gsr_context* c)
     return GSR_OK;
 }
 
+extern "C" int gsr_upload_abort(gsr_context* c)
+{
+    if (!c) return set_err(GSR_E_INVALID, "gsr_upload_abort: ctx is NULL");
+    // an upload that failed half-way leaves no geometry behind: rendering needs a complete new upload
+    if (c->uploading) { c->uploading = false; c->n = 0; c->up_total = c->up_filled = 0; c->st.n_splats = 0; }
+    return GSR_OK;
+}
+
 extern "C" int gsr_upload(gsr_context* c, int64_t n, const float* P, const uint16_t* Cd, const float* alpha,
                           const uint16_t* scale, const uint16_t* orient, const uint16_t* shx, const uint16_t* shy,
                           const uint16_t* shz, const float origin[3])
@@ -440,8 +482,9 @@ extern "C" int gsr_upload(gsr_context* c, int64_t n, const float* P, const uint1
     int rc = gsr_upload_begin(c, n, has_sh, origin);
     if (rc) return rc;
     rc = gsr_upload_append(c, n, P, Cd, alpha, scale, orient, shx, shy, shz);
-    if (rc) { c->uploading = false; return rc; }
-    return gsr_upload_end(c);
+    if (!rc) rc = gsr_upload_end(c);
+    if (rc) (void)gsr_upload_abort(c);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------
@@ -691,13 +734,138 @@ static void harvest_slot(gsr_context* c, FrameSlot& sl)
     c->st.stage_frames += 1;
 }
 
-extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out, int out_is_device)
+// ---------------------------------------------------------------------------
+// A frame is QUEUED by frame_begin (everything, including a speculative back end) and COMPLETED by
+// frame_finish (the one host-side wait of a frame: its pair count).  gsr_render = begin + finish; the
+// multi-GPU driver begins on every GPU before it finishes on any, so the waits overlap; with
+// GSR_OPT_DEFERRED_CHECK a device-target frame returns right after begin and its count is looked at later.
+static inline int mark(FrameSlot& sl, int k)
 {
-    return gsr_render_depth(c, cam, nullptr, 0, rgba_out, out_is_device);
+    const FrameJob& j = sl.job;
+    if (j.timing && (j.timing_all || k >= 5)) HIP_TRY(hipEventRecord(sl.ev[k], sl.stream));
+    return GSR_OK;
 }
 
-extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const float* depth, int depth_is_device,
-                                float* rgba_out, int out_is_device)
+// back end = placement + compositing.  The host needs the pair count D only to make sure the list buffer is
+// large enough, so when a buffer exists the back end is queued SPECULATIVELY right behind the count (both
+// kernels clamp to the buffer's capacity) and the host reads D while the GPU is already placing: the stream
+// never drains mid-frame.  Only if D turns out to exceed the capacity (first frame, or the pair count grew by
+// more than the 25 % headroom) is the buffer regrown and the back end run again.
+static int queue_back_end(gsr_context* c, FrameSlot& sl)
+{
+    const FrameJob& j = sl.job;
+    const GsrFrame& f = j.f;
+    hipStream_t s = sl.stream;
+    int rc;
+    if ((rc = mark(sl, 3))) return rc;
+    if (j.n > 0) {
+        const uint32_t nblk = div_up(j.n, BN_TILE);
+        const size_t lds = (size_t)4 * BN_ITEMS * j.n_super * 8 + (size_t)4 * j.n_super * 4;
+        hipLaunchKernelGGL(k_bin_place, dim3(nblk), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n, f.super_shift,
+                           f.shard_index, f.shard_count, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk,
+                           (uint32_t)sl.pair_cap, sl.pvA);
+        HIP_TRY(hipGetLastError());
+    }
+    if ((rc = mark(sl, 4)) || (rc = mark(sl, 5))) return rc;
+    if (j.local_tiles > 0) {
+        HIP_TRY(hipStreamWaitEvent(s, sl.ev_user, 0));
+        GsrBlendArgs a;
+        a.width = f.width; a.height = f.height; a.tiles_x = f.tiles_x; a.local_tiles = j.local_tiles;
+        a.shard_index = f.shard_index; a.shard_count = f.shard_count; a.band_rows = j.band_rows;
+        a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
+        a.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
+        const unsigned grid = a.use_map ? (unsigned)c->map_grid : (unsigned)j.local_tiles;
+        if (j.d_depth)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<true>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
+                               sl.send, sl.rec, reinterpret_cast<float4*>(j.target), sl.tile_work, sl.zwin, j.d_depth);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
+                               sl.send, sl.rec, reinterpret_cast<float4*>(j.target), sl.tile_work, sl.zwin, j.d_depth);
+        HIP_TRY(hipGetLastError());
+    }
+    return mark(sl, 6);
+}
+
+// bookkeeping + hand-over: the frame's counters to the host mirror, host copy if asked, result ordered on the public stream
+static int queue_frame_end(gsr_context* c, FrameSlot& sl)
+{
+    const FrameJob& j = sl.job;
+    hipStream_t s = sl.stream;
+    hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, j.local_tiles, sl.counters, sl.d_n,
+                       sl.h_counters_dev);
+    HIP_TRY(hipGetLastError());
+    if (j.timing) { sl.ev_pending = true; sl.ev_all = j.timing_all; }
+    if (!j.out_is_device) {
+        HIP_TRY(hipMemcpyAsync(j.user_out, sl.fb, j.out_px * 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    // results are ordered on the public stream: anything the caller queues there next sees this frame
+    HIP_TRY(hipEventRecord(sl.ev_done, s));
+    HIP_TRY(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
+    return GSR_OK;
+}
+
+// a frame that failed half-way may have kernels queued that still write the caller's buffer: drain them first
+static int frame_abort(FrameSlot& sl, int rc)
+{
+    sl.job.open = false;
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    return rc;
+}
+
+static int frame_finish(gsr_context* c, FrameSlot& sl)
+{
+    if (!sl.job.open) return GSR_OK;
+    FrameJob& j = sl.job;
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t D = 0;
+    if (j.n > 0) {
+        hipError_t e = hipEventSynchronize(sl.ev_pairs);   // the pair count is in host memory; the GPU carries on
+        if (e != hipSuccess) return frame_abort(sl, set_err(GSR_E_HIP, "gsr_render: waiting for the pair count: %s", hipGetErrorString(e)));
+        D = *sl.h_total;
+        if (D == 0xffffffffu || (unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
+            return frame_abort(sl, set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: the frame's super-tile pairs exceed the limit of %lld", GSR_MAX_PAIRS));
+        const bool short_buffer = D > sl.pair_cap;
+        if (short_buffer) {
+            (void)hipStreamSynchronize(sl.stream);   // a speculative (clamped) back end may still be reading the old buffer
+            dev_free(sl.pvA);
+            sl.pair_cap = 0;
+            const size_t want = (size_t)D + D / 4 + 4096;
+            int rc = dev_alloc(&sl.pvA, want);
+            if (rc) return frame_abort(sl, rc);
+            sl.pair_cap = want;
+            c->pair_want = std::max(c->pair_want, want);   // the other frame slot grows before its next frame
+        }
+        if (j.deferred) {
+            // the frame was handed over before its pair count was known; if the lists were clamped it misses their tails
+            if (short_buffer) c->st.frames_truncated += 1;
+        } else if (short_buffer || !j.speculative) {
+            if (short_buffer && j.speculative) c->st.frames_requeued += 1;
+            int rc = queue_back_end(c, sl);
+            if (rc) return frame_abort(sl, rc);
+        }
+    }
+    sl.last_pairs = D;
+    if (!j.deferred) {
+        int rc = queue_frame_end(c, sl);
+        if (rc) return frame_abort(sl, rc);
+    }
+    j.open = false;
+    return GSR_OK;
+}
+
+static int finish_open_frames(gsr_context* c)
+{
+    int rc = GSR_OK;
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k) {
+        const int r = frame_finish(c, c->slot[k]);
+        if (r && !rc) rc = r;
+    }
+    return rc;
+}
+
+static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth, int depth_is_device,
+                       float* rgba_out, int out_is_device, FrameSlot** used)
 {
     if (!c || !cam || !rgba_out) return set_err(GSR_E_INVALID, "gsr_render: NULL argument");
     if (c->uploading) return set_err(GSR_E_INVALID, "gsr_render: upload in progress");
@@ -710,191 +878,165 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
     // private arrays (plus the read-only geometry), so it may run while the previous frame -- and
     // whatever the caller queued on the public stream -- is still executing.
     FrameSlot& sl = c->slot[c->frame_no % (uint64_t)c->nslots];
+    if (used) *used = &sl;
+    int rc = frame_finish(c, sl);   // a deferred frame of this slot: look at its pair count now
+    if (rc) return rc;
     hipStream_t s = sl.stream;
+    if (sl.pair_cap > 0 && sl.pair_cap < c->pair_want) {   // the other slot met a frame that outgrew this size
+        HIP_TRY(hipStreamSynchronize(s));
+        dev_free(sl.pvA);
+        sl.pair_cap = 0;
+        if ((rc = dev_alloc(&sl.pvA, c->pair_want))) return rc;
+        sl.pair_cap = c->pair_want;
+    }
 
-    GsrFrame f;
-    build_frame(c, cam, &f);
+    FrameJob& j = sl.job;
+    j = FrameJob();
+    build_frame(c, cam, &j.f);
+    const GsrFrame& f = j.f;
     const uint32_t n = c->n;
-    const int local_tiles = f.tiles_x * f.local_tiles_y;
-    const int band_rows = (c->shard_count > 1) ? gsr_band_rows(cam->height, c->shard_index, c->shard_count) : cam->height;
-    const size_t out_px = (size_t)band_rows * cam->width;
-    const int n_super = f.stiles_x * f.stiles_y;
-
-    const bool timing = c->opt_timing != 0;
-    if (timing) harvest_slot(c, sl);
-    hipEvent_t* ev = sl.ev;
-    const bool timing_all = c->opt_timing >= 2;   // level 1 brackets only the blend kernel (events 5 and 6)
-#define MARK(k) do { if (timing && (timing_all || (k) >= 5)) HIP_TRY(hipEventRecord(ev[k], s)); } while (0)
+    j.n = n;
+    j.local_tiles = f.tiles_x * f.local_tiles_y;
+    j.band_rows = (c->shard_count > 1) ? gsr_band_rows(cam->height, c->shard_index, c->shard_count) : cam->height;
+    j.out_px = (size_t)j.band_rows * cam->width;
+    j.n_super = f.stiles_x * f.stiles_y;
+    j.timing = c->opt_timing != 0;
+    j.timing_all = c->opt_timing >= 2;   // level 1 brackets only the blend kernel (events 5 and 6)
+    j.use_map = c->opt_swizzle != 0;
+    j.user_out = rgba_out;
+    j.out_is_device = out_is_device != 0;
+    j.deferred = c->opt_deferred && j.out_is_device;
+    if (j.timing) harvest_slot(c, sl);
 
     // the caller's stream position now: the blend kernel (the only writer of caller-visible memory)
     // waits for it, so an output buffer that earlier work on the public stream still reads is safe
     HIP_TRY(hipEventRecord(sl.ev_user, c->stream));
 
     // per-tile bookkeeping + super-tile ranges
-    if ((size_t)local_tiles + 1 > sl.tile_cap || !sl.sstart) {
+    if ((size_t)j.local_tiles + 1 > sl.tile_cap || !sl.sstart) {
         HIP_TRY(hipStreamSynchronize(s));
         dev_free(sl.tile_work); dev_free(sl.sstart); dev_free(sl.send);
         sl.tile_cap = 0;
-        int rc;
-        if ((rc = dev_alloc(&sl.tile_work, (size_t)local_tiles + 1)) || (rc = dev_alloc(&sl.sstart, (size_t)65536 + 1)) ||
+        if ((rc = dev_alloc(&sl.tile_work, (size_t)j.local_tiles + 1)) || (rc = dev_alloc(&sl.sstart, (size_t)65536 + 1)) ||
             (rc = dev_alloc(&sl.send, (size_t)65536 + 1))) return rc;
-        sl.tile_cap = (size_t)local_tiles + 1;
+        sl.tile_cap = (size_t)j.local_tiles + 1;
     }
-    if (c->opt_swizzle) {
-        int rc = build_tile_map(c, f);
-        if (rc) return rc;
-    }
-    const float* d_depth = depth;
+    if (j.use_map && (rc = build_tile_map(c, f))) return rc;
+    j.d_depth = depth;
     if (depth && !depth_is_device) {
         const size_t npx = (size_t)cam->width * cam->height;
         if (npx > sl.depth_cap) {
             HIP_TRY(hipStreamSynchronize(s));
             dev_free(sl.depth_stage);
             sl.depth_cap = 0;
-            int rc = dev_alloc(&sl.depth_stage, npx);
-            if (rc) return rc;
+            if ((rc = dev_alloc(&sl.depth_stage, npx))) return rc;
             sl.depth_cap = npx;
         }
         HIP_TRY(hipMemcpyAsync(sl.depth_stage, depth, npx * 4, hipMemcpyHostToDevice, s));
-        d_depth = sl.depth_stage;
+        j.d_depth = sl.depth_stage;
     }
-    float* target = rgba_out;
+    j.target = rgba_out;
     if (!out_is_device) {
-        if (out_px * 4 > sl.fb_cap) {
+        if (j.out_px * 4 > sl.fb_cap) {
             HIP_TRY(hipStreamSynchronize(s));
             dev_free(sl.fb);
             sl.fb_cap = 0;
-            int rc = dev_alloc(&sl.fb, out_px * 4);
-            if (rc) return rc;
-            sl.fb_cap = out_px * 4;
+            if ((rc = dev_alloc(&sl.fb, j.out_px * 4))) return rc;
+            sl.fb_cap = j.out_px * 4;
         }
-        target = sl.fb;
+        j.target = sl.fb;
     }
 
-    MARK(0);
-    const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_gen == c->geo_gen &&
-                           sl.sort_shard_index == c->shard_index && sl.sort_shard_count == c->shard_count &&
-                           sl.sort_flags == c->opt_flags && std::memcmp(&sl.sort_camera, cam, sizeof(gsr_camera)) == 0;
-    uint32_t D = 0;
+    j.open = true;   // from here on kernels are queued: every error path drains them (frame_abort)
+    if ((rc = mark(sl, 0))) return frame_abort(sl, rc);
+    // The depth order depends on the camera POSITION only (argsortByDistance re-sorts when the position moves,
+    // src/GSplatRenderer.C:165-186) -- but the sorted list holds just the splats visible to the frame that sorted, so
+    // it is reused as is only for an identical frame description (a static viewport redraw), per frame slot.
+    const SortKey key_now = {c->geo_gen, c->shard_index, c->shard_count, c->opt_flags, *cam};
+    const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now);
     if (n > 0) {
         // on a cache hit (identical frame description) the sorted (keyA, valA) are kept and K1's key/payload
         // output goes to the scratch buffers
         hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, GSR_K1_THREADS)), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, cache_hit ? sl.keyB : sl.keyA, cache_hit ? sl.valB : sl.valA,
-                           d_depth ? sl.zwin : (float*)nullptr);
-        HIP_TRY(hipGetLastError());
+                           j.d_depth ? sl.zwin : (float*)nullptr);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return frame_abort(sl, set_err(GSR_E_HIP, "k_preprocess: %s", hipGetErrorString(e)));
     }
-    MARK(1);
-    if (!cache_hit) {
+    if ((rc = mark(sl, 1))) return frame_abort(sl, rc);
+    if (cache_hit) {
+        c->st.sorts_skipped += 1;
+    } else {
         int key_bits = 1;
         while (key_bits < 32 && ((f.key_max - f.key_min) >> key_bits) != 0u) ++key_bits;
-        int rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n, key_bits, !(c->opt_flags & GSR_FLAG_FULL_KEYS),
-                            sl.d_n, RS_XCD_DEPTH != 0);
-        if (rc) return rc;
+        rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n, key_bits, !(c->opt_flags & GSR_FLAG_FULL_KEYS),
+                        sl.d_n, RS_XCD_DEPTH != 0);
+        if (rc) return frame_abort(sl, rc);
         sl.key_min = f.key_min;
         sl.sort_valid = true;
-        sl.sort_gen = c->geo_gen;
-        sl.sort_camera = *cam;
-        sl.sort_shard_index = c->shard_index; sl.sort_shard_count = c->shard_count; sl.sort_flags = c->opt_flags;
+        sl.sort_key = key_now;
     }
-    MARK(2);
+    if ((rc = mark(sl, 2))) return frame_abort(sl, rc);
+    hipError_t e = hipSuccess;
     if (n > 0) {
         // coarse binning as a counting sort (k_binning.h): count -> scan -> ranges -> [pair count to the host] -> place
         const uint32_t nblk = div_up(n, BN_TILE);
-        int rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)BN_BINS * nblk + 8);
-        if (rc) return rc;
+        rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)BN_BINS * nblk + 8);
+        if (rc) return frame_abort(sl, rc);
         hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift, c->shard_index,
                            c->shard_count, f.stiles_x, sl.hist, nblk);
         hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals);
-        hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, sl.totals, n_super, sl.sstart, sl.send, sl.h_total_dev);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(sl.ev_pairs, s));
+        hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, sl.totals, j.n_super, sl.sstart, sl.send, sl.h_total_dev,
+                           (unsigned long long)GSR_MAX_PAIRS);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(sl.ev_pairs, s);
     } else {
-        HIP_TRY(hipMemsetAsync(sl.sstart, 0, ((size_t)n_super + 1) * 4, s));
-        HIP_TRY(hipMemsetAsync(sl.send, 0, ((size_t)n_super + 1) * 4, s));
+        e = hipMemsetAsync(sl.sstart, 0, ((size_t)j.n_super + 1) * 4, s);
+        if (e == hipSuccess) e = hipMemsetAsync(sl.send, 0, ((size_t)j.n_super + 1) * 4, s);
     }
-    // back end = placement + compositing.  The host needs the pair count D only to make sure the list buffer is
-    // large enough, so when a buffer exists the back end is queued SPECULATIVELY right behind the count (both
-    // kernels clamp to the buffer's capacity) and the host reads D while the GPU is already placing: the stream
-    // never drains mid-frame.  Only if D turns out to exceed the capacity (first frame, or the pair count grew by
-    // more than the 25 % headroom) is the buffer regrown and the back end run again -- before anything is returned.
-    auto back_end = [&]() -> int {
-        MARK(3);
-        if (n > 0) {
-            const uint32_t nblk = div_up(n, BN_TILE);
-            const size_t lds = (size_t)4 * BN_ITEMS * n_super * 8 + (size_t)4 * n_super * 4;
-            hipLaunchKernelGGL(k_bin_place, dim3(nblk), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n, f.super_shift,
-                               c->shard_index, c->shard_count, f.stiles_x, n_super, sl.hist, sl.sstart, nblk,
-                               (uint32_t)sl.pair_cap, sl.pvA);
-            HIP_TRY(hipGetLastError());
-        }
-        MARK(4);
-        MARK(5);
-        if (local_tiles > 0) {
-            HIP_TRY(hipStreamWaitEvent(s, sl.ev_user, 0));
-            GsrBlendArgs a;
-            a.width = cam->width; a.height = cam->height; a.tiles_x = f.tiles_x; a.local_tiles = local_tiles;
-            a.shard_index = c->shard_index; a.shard_count = c->shard_count; a.band_rows = band_rows;
-            a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = c->opt_swizzle ? 1 : 0; a.flags = c->opt_flags;
-            a.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
-            const unsigned grid = a.use_map ? (unsigned)c->map_grid : (unsigned)local_tiles;
-            if (d_depth)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<true>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
-                                   sl.send, sl.rec, reinterpret_cast<float4*>(target), sl.tile_work, sl.zwin, d_depth);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
-                                   sl.send, sl.rec, reinterpret_cast<float4*>(target), sl.tile_work, sl.zwin, d_depth);
-            HIP_TRY(hipGetLastError());
-        }
-        MARK(6);
-        return GSR_OK;
-    };
-    const bool speculative = n > 0 && sl.pair_cap > 0;
-    if (speculative || n == 0) {
-        int rc = back_end();
-        if (rc) return rc;
+    if (e != hipSuccess) return frame_abort(sl, set_err(GSR_E_HIP, "gsr_render: binning: %s", hipGetErrorString(e)));
+    j.speculative = n > 0 && sl.pair_cap > 0;
+    if (j.speculative || n == 0) {
+        if ((rc = queue_back_end(c, sl))) return frame_abort(sl, rc);
+    } else {
+        j.deferred = false;   // no list buffer yet (first frame): the host has to size it before anything is composited
     }
-    if (n > 0) {
-        HIP_TRY(hipEventSynchronize(sl.ev_pairs));   // the pair count is in host memory; the GPU carries on
-        D = *sl.h_total;
-        if ((unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
-            return set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: %u super-tile pairs exceed the limit", D);
-        if (D > sl.pair_cap || !speculative) {
-            if (D > sl.pair_cap) {
-                dev_free(sl.pvA);   // (hipFree waits for the device: a speculative back end has finished by now)
-                sl.pair_cap = 0;
-                const size_t want = (size_t)D + D / 4 + 4096;
-                int rc = dev_alloc(&sl.pvA, want);
-                if (rc) return rc;
-                sl.pair_cap = want;
-            }
-            int rc = back_end();
-            if (rc) return rc;
-        }
-    }
-    hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, local_tiles, sl.counters, sl.d_n,
-                       sl.h_counters_dev);
-    HIP_TRY(hipGetLastError());
-#undef MARK
-    if (timing) { sl.ev_pending = true; sl.ev_all = timing_all; }
-    sl.last_supers = n_super;
+    if (j.deferred && (rc = queue_frame_end(c, sl))) return frame_abort(sl, rc);
+    sl.last_supers = j.n_super;
     sl.last_tiles_x = f.tiles_x;
     sl.last_local_ty = f.local_tiles_y;
-    sl.last_pairs = D;
     sl.super_tile = f.super; sl.stiles_x = f.stiles_x; sl.stiles_y = f.stiles_y;
     c->st.frames += 1;
     c->frame_no += 1;
     sl.frame_id = c->frame_no;
-    // (the frame's counters were written to the host mirror by k_sum_work; they are read in gsr_get_stats)
-    if (!out_is_device) {
-        HIP_TRY(hipMemcpyAsync(rgba_out, sl.fb, out_px * 16, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-    }
-    // results are ordered on the public stream: anything the caller queues there next sees this frame
-    HIP_TRY(hipEventRecord(sl.ev_done, s));
-    HIP_TRY(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
+    // (the frame's counters are written to the host mirror by k_sum_work; they are read in gsr_get_stats)
     return GSR_OK;
 }
+
+extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out, int out_is_device)
+{
+    return gsr_render_depth(c, cam, nullptr, 0, rgba_out, out_is_device);
+}
+
+extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const float* depth, int depth_is_device,
+                                float* rgba_out, int out_is_device)
+{
+    FrameSlot* sl = nullptr;
+    int rc = frame_begin(c, cam, depth, depth_is_device, rgba_out, out_is_device, &sl);
+    if (rc) return rc;
+    if (sl->job.deferred) return GSR_OK;   // GSR_OPT_DEFERRED_CHECK: the pair count is looked at by the next call that syncs
+    return frame_finish(c, *sl);
+}
+
+// split form for callers that drive several contexts from one thread (gsr_multi.cpp)
+__attribute__((visibility("hidden"))) int gsr_internal_frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth,
+                                                                    int depth_is_device, float* out_dev)
+{
+    return frame_begin(c, cam, depth, depth_is_device, out_dev, 1, nullptr);
+}
+__attribute__((visibility("hidden"))) int gsr_internal_frame_finish(gsr_context* c) { return c ? finish_open_frames(c) : GSR_OK; }
+__attribute__((visibility("hidden"))) void* gsr_internal_stream(gsr_context* c) { return c ? (void*)c->stream : nullptr; }
+__attribute__((visibility("hidden"))) int gsr_internal_device(gsr_context* c) { return c ? c->device : -1; }
 
 // Wireframe overlay: synchronous, not on the per-frame beauty path.
 extern "C" int gsr_render_wire(gsr_context* c, const gsr_camera* cam, float* rgba_out, int out_is_device)

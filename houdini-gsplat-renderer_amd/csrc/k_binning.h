@@ -113,17 +113,28 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
         hist[(size_t)b * nblk + tile] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
 }
 
-// one workgroup: list range of every super-tile = exclusive scan of the totals; *host_total = pair count
+// one workgroup: list range of every super-tile = exclusive scan of the totals; *host_total = pair count.
+// The count is formed in 64 bits as well: past max_pairs (list positions are int32) every range is left empty and
+// the host is told 0xffffffff -- it reports GSR_E_TOO_MANY_PAIRS instead of compositing wrapped positions.
 __global__ void __launch_bounds__(BN_BINS)
 k_bin_ranges(const uint32_t* __restrict__ totals, int n_super, int32_t* __restrict__ sstart, int32_t* __restrict__ send,
-             volatile uint32_t* __restrict__ host_total /* pinned, mapped */)
+             volatile uint32_t* __restrict__ host_total /* pinned, mapped */, unsigned long long max_pairs)
 {
     __shared__ uint32_t s_wave[4];
+    __shared__ unsigned long long s_sum[4];
     const uint32_t v = ((int)threadIdx.x < n_super) ? totals[threadIdx.x] : 0u;
+    unsigned long long w = v;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) w += __shfl_down(w, d, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = w;
     uint32_t tot;
-    const uint32_t ex = block_excl_scan_256(v, s_wave, &tot);
-    if ((int)threadIdx.x < n_super) { sstart[threadIdx.x] = (int32_t)ex; send[threadIdx.x] = (int32_t)(ex + v); }
-    if (threadIdx.x == 0) { *host_total = tot; __threadfence_system(); }   // the host sizes the list buffer from it
+    const uint32_t ex = block_excl_scan_256(v, s_wave, &tot);   // (its barriers publish s_sum too)
+    const bool too_many = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3] > max_pairs;
+    if ((int)threadIdx.x < n_super) {
+        sstart[threadIdx.x] = too_many ? 0 : (int32_t)ex;
+        send[threadIdx.x] = too_many ? 0 : (int32_t)(ex + v);
+    }
+    if (threadIdx.x == 0) { *host_total = too_many ? 0xffffffffu : tot; __threadfence_system(); }   // the host sizes the list buffer from it
 }
 
 // Placement.  Inside a list the order must be the depth order of the splats, so the pairs of one

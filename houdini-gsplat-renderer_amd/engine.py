@@ -39,7 +39,8 @@ class gsr_stats(C.Structure):
                 ("entries_scanned", C.c_int64), ("blend_entries_scanned_total", C.c_int64),
                 ("super_tile", C.c_int32), ("stiles_x", C.c_int32), ("stiles_y", C.c_int32), ("reserved_", C.c_int32),
                 ("blend_wave_evals_total", C.c_int64), ("stage_ms_total", C.c_double * 5),
-                ("stage_frames", C.c_int64)]
+                ("stage_frames", C.c_int64), ("sorts_skipped", C.c_int64), ("frames_requeued", C.c_int64),
+                ("frames_truncated", C.c_int64)]
 
     def as_dict(self) -> dict:
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -65,15 +66,32 @@ class GSplatRenderContext(C.Structure):
                 ("depth", C.c_void_p), ("depth_is_device", C.c_int32)]
 
 
-OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE, OPT_SUPER_TILE, OPT_DEBUG_FLAGS, OPT_FRAMES_IN_FLIGHT = 1, 2, 3, 4, 5, 6
+class gsplat_attrs(C.Structure):
+    _fields_ = [("count", C.c_int64), ("P", C.c_void_p), ("Cd", C.c_void_p), ("opacity", C.c_void_p), ("Alpha", C.c_void_p),
+                ("scale", C.c_void_p), ("orient", C.c_void_p), ("sh_coefficients", C.c_void_p),
+                ("sh_coefficients_len", C.c_int32), ("sh", C.POINTER(C.c_void_p)), ("f_rest", C.POINTER(C.c_void_p)),
+                ("sh_order", C.POINTER(C.c_int32)), ("explicit_camera_pos", C.POINTER(C.c_float))]
+
+
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_COPY = 0, 1, 2
+MISSING_CD, MISSING_OPACITY, MISSING_SCALE, MISSING_ORIENT, MISSING_SH, BAD_SH_ORDER = 1, 2, 4, 8, 16, 32
+OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE, OPT_SUPER_TILE, OPT_DEBUG_FLAGS, OPT_FRAMES_IN_FLIGHT, OPT_DEFERRED_CHECK = 1, 2, 3, 4, 5, 6, 7
 
 # every symbol include/gsplat_hip.h and include/GSplatRenderer.h declare
 C_ABI_SYMBOLS = [
     "gsr_device_count", "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_version", "gsr_set_stream",
-    "gsr_upload_begin", "gsr_upload_append", "gsr_upload_end", "gsr_upload", "gsr_set_row_shard", "gsr_band_rows",
+    "gsr_upload_begin", "gsr_upload_append", "gsr_upload_end", "gsr_upload_abort", "gsr_upload", "gsr_set_row_shard", "gsr_band_rows",
     "gsr_stitch_bands", "gsr_render", "gsr_render_depth", "gsr_render_wire", "gsr_synchronize", "gsr_get_stats", "gsr_stats_reset", "gsr_set_option",
     "gsr_debug_read_records", "gsr_debug_read_depth_order", "gsr_debug_read_tile_lists", "gsr_debug_sort_pairs",
     "gsr_debug_read_tile_work",
+    "gsr_multi_create", "gsr_multi_destroy", "gsr_multi_count", "gsr_multi_transport", "gsr_multi_context",
+    "gsr_multi_set_stream", "gsr_multi_set_option", "gsr_multi_upload_begin", "gsr_multi_upload_append",
+    "gsr_multi_upload_end", "gsr_multi_upload_abort", "gsr_multi_upload", "gsr_multi_render", "gsr_multi_render_depth",
+    "gsr_multi_synchronize", "gsr_multi_get_stats",
+    "gsr_comm_get_unique_id", "gsr_comm_init", "gsr_comm_destroy", "gsr_comm_render",
+    "gsplat_renderer_create_multi", "gsplat_renderer_multi",
+    "gsplat_prim_create", "gsplat_prim_destroy", "gsplat_prim_update", "gsplat_prim_render", "gsplat_prim_missing",
+    "gsplat_prim_sh_order", "gsplat_prim_has_sh", "gsplat_prim_array",
     "gsplat_renderer_create", "gsplat_renderer_get_instance", "gsplat_renderer_destroy",
     "gsplat_renderer_register_update", "gsplat_renderer_include_in_render_pass",
     "gsplat_renderer_flush_entries_for_matching_detail", "gsplat_renderer_generate_render_geometry",
@@ -109,6 +127,7 @@ def load_library() -> C.CDLL:
     L.gsr_upload_begin.argtypes = [vp, i64, i32, f32p]
     L.gsr_upload_append.argtypes = [vp, i64] + [vp] * 8
     L.gsr_upload_end.argtypes = [vp]
+    L.gsr_upload_abort.argtypes = [vp]
     L.gsr_upload.argtypes = [vp, i64] + [vp] * 8 + [f32p]
     L.gsr_set_row_shard.argtypes = [vp, i32, i32]
     L.gsr_band_rows.argtypes = [i32, i32, i32]
@@ -167,6 +186,47 @@ def load_library() -> C.CDLL:
     L.gsplat_pack_sh_from_frest.restype = None
     L.gsplat_pack_sh_from_array.argtypes = [vp, i64, i32, vp, vp, vp]
     L.gsplat_pack_sh_from_array.restype = None
+    # several GPUs
+    L.gsr_multi_create.argtypes = [C.POINTER(C.c_int), i32, i32, C.POINTER(vp)]
+    L.gsr_multi_destroy.argtypes = [vp]
+    L.gsr_multi_destroy.restype = None
+    L.gsr_multi_count.argtypes = [vp]
+    L.gsr_multi_transport.argtypes = [vp]
+    L.gsr_multi_context.argtypes = [vp, i32]
+    L.gsr_multi_context.restype = vp
+    L.gsr_multi_set_stream.argtypes = [vp, vp]
+    L.gsr_multi_set_option.argtypes = [vp, i32, i32]
+    L.gsr_multi_upload_begin.argtypes = [vp, i64, i32, f32p]
+    L.gsr_multi_upload_append.argtypes = [vp, i64] + [vp] * 8
+    L.gsr_multi_upload_end.argtypes = [vp]
+    L.gsr_multi_upload_abort.argtypes = [vp]
+    L.gsr_multi_upload.argtypes = [vp, i64] + [vp] * 8 + [f32p]
+    L.gsr_multi_render.argtypes = [vp, C.POINTER(gsr_camera), vp, i32]
+    L.gsr_multi_render_depth.argtypes = [vp, C.POINTER(gsr_camera), vp, i32, vp, i32]
+    L.gsr_multi_synchronize.argtypes = [vp]
+    L.gsr_multi_get_stats.argtypes = [vp, i32, C.POINTER(gsr_stats)]
+    L.gsr_comm_get_unique_id.argtypes = [vp]
+    L.gsr_comm_init.argtypes = [vp, vp, i32, i32]
+    L.gsr_comm_destroy.argtypes = [vp]
+    L.gsr_comm_render.argtypes = [vp, C.POINTER(gsr_camera), vp, i32, vp]
+    L.gsplat_renderer_create_multi.argtypes = [C.POINTER(C.c_int), i32, i32]
+    L.gsplat_renderer_create_multi.restype = vp
+    L.gsplat_renderer_multi.argtypes = [vp]
+    L.gsplat_renderer_multi.restype = vp
+    # the viewport primitive's part (N1 ingest)
+    L.gsplat_prim_create.argtypes = [vp]
+    L.gsplat_prim_create.restype = vp
+    L.gsplat_prim_destroy.argtypes = [vp]
+    L.gsplat_prim_destroy.restype = None
+    L.gsplat_prim_update.argtypes = [vp, C.c_uint64, C.POINTER(C.c_int64), i64, C.POINTER(gsplat_attrs), f32p, C.c_char_p, i32]
+    L.gsplat_prim_render.argtypes = [vp, i32]
+    L.gsplat_prim_render.restype = None
+    L.gsplat_prim_missing.argtypes = [vp]
+    L.gsplat_prim_missing.restype = C.c_uint
+    L.gsplat_prim_sh_order.argtypes = [vp]
+    L.gsplat_prim_has_sh.argtypes = [vp]
+    L.gsplat_prim_array.argtypes = [vp, i32]
+    L.gsplat_prim_array.restype = vp
     _LIB = L
     return L
 
@@ -364,9 +424,14 @@ class GSplatRenderer:
     Q_REGISTRY_SIZE, Q_ACTIVE_STAGED, Q_SPLAT_COUNT, Q_CAN_RENDER, Q_STAGING_COUNT, Q_RENDER_COUNT, Q_SH_PRESENT, \
         Q_LAST_STATUS, Q_ENTRY_AGE, Q_ENTRY_AGE_SINCE_ACTIVE = range(10)
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device=0, transport: int = TRANSPORT_AUTO):
+        """device: an int (one GPU; -1 = dry) or a sequence of device ordinals (tile rows sharded over them)"""
         self.L = load_library()
-        self.h = self.L.gsplat_renderer_create(int(device))
+        if isinstance(device, (list, tuple)):
+            arr = (C.c_int * len(device))(*[int(d) for d in device])
+            self.h = self.L.gsplat_renderer_create_multi(arr, len(device), int(transport))
+        else:
+            self.h = self.L.gsplat_renderer_create(int(device))
         if not self.h:
             raise GsrError(-3, self.L.gsr_last_error().decode("utf-8", "replace") or "gsplat_renderer_create failed")
         self._keep = {}
@@ -461,3 +526,145 @@ def quantize_half(a: np.ndarray) -> np.ndarray:
     out = np.empty(a.shape, dtype=np.uint16)
     load_library().gsplat_quantize_half(a.ctypes.data, out.ctypes.data, a.size)
     return out
+
+
+class MultiEngine:
+    """gsr_multi_*: several GPUs (or several contexts on one GPU, transport COPY) driven from this one thread."""
+
+    def __init__(self, devices, transport: int = TRANSPORT_AUTO):
+        self.L = load_library()
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        _check(self.L.gsr_multi_create(arr, len(devices), int(transport), C.byref(h)))
+        self.h = h
+        self.count = len(devices)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gsr_multi_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def transport(self) -> int:
+        return int(self.L.gsr_multi_transport(self.h))
+
+    def set_stream(self, hip_stream):
+        _check(self.L.gsr_multi_set_stream(self.h, C.c_void_p(hip_stream or 0)))
+
+    def set_option(self, option: int, value: int):
+        _check(self.L.gsr_multi_set_option(self.h, option, value))
+
+    def upload(self, splats, origin=(0.0, 0.0, 0.0)):
+        a = _Arrays(splats)
+        _check(self.L.gsr_multi_upload(self.h, a.n, *a.ptrs(), _f3(origin)))
+
+    def render(self, cam, depth=None) -> np.ndarray:
+        out = np.empty((cam.height, cam.width, 4), dtype=np.float32)
+        cs = camera_struct(cam)
+        if depth is None:
+            _check(self.L.gsr_multi_render(self.h, C.byref(cs), out.ctypes.data, 0))
+        else:
+            d = np.ascontiguousarray(depth, dtype=np.float32).reshape(cam.height, cam.width)
+            _check(self.L.gsr_multi_render_depth(self.h, C.byref(cs), d.ctypes.data, 0, out.ctypes.data, 0))
+        return out
+
+    def render_struct_to_device(self, cam_struct: gsr_camera, device_ptr: int, depth_ptr: int = 0):
+        _check(self.L.gsr_multi_render_depth(self.h, C.byref(cam_struct), C.c_void_p(depth_ptr or None), 1,
+                                             C.c_void_p(device_ptr), 1))
+
+    def synchronize(self):
+        _check(self.L.gsr_multi_synchronize(self.h))
+
+    def stats(self, rank: int = 0) -> dict:
+        st = gsr_stats()
+        _check(self.L.gsr_multi_get_stats(self.h, rank, C.byref(st)))
+        return st.as_dict()
+
+
+class GSplatPrim:
+    """Python face of the GSplatPrim mirror of GR_PrimGsplat (include/GSplatPrim.h): attribute ingest + the
+    per-redraw verbs.  attrs: dict of float32 arrays keyed by Houdini attribute names
+    (P, Cd, opacity, Alpha, scale, orient, sh_coefficients, sh1..sh15, f_rest_0..44) plus the detail attributes
+    gsplat__sh_order (int) and gsplat__explicit_camera_pos (3 floats)."""
+
+    def __init__(self, renderer: GSplatRenderer):
+        self.L = load_library()
+        self.R = renderer
+        self.h = self.L.gsplat_prim_create(renderer.h)
+        if not self.h:
+            raise GsrError(-1, "gsplat_prim_create failed")
+        self.id = ""
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gsplat_prim_destroy(self.h)
+            self.h = None
+
+    def update(self, detail: int, version, vtx_offset: int, attrs: dict, barycenter=None) -> str:
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        keep = {k: f32(v) for k, v in attrs.items() if not k.startswith("gsplat__")}
+        a = gsplat_attrs()
+        a.count = int(keep["P"].reshape(-1, 3).shape[0]) if "P" in keep else 0
+        for name in ("P", "Cd", "opacity", "Alpha", "scale", "orient"):
+            setattr(a, name, keep[name].ctypes.data if name in keep else None)
+        if "sh_coefficients" in keep:
+            a.sh_coefficients = keep["sh_coefficients"].ctypes.data
+            a.sh_coefficients_len = int(keep["sh_coefficients"].size // max(a.count, 1))
+        sh_ptrs = (C.c_void_p * 15)(*[keep[f"sh{k + 1}"].ctypes.data if f"sh{k + 1}" in keep else None for k in range(15)])
+        fr_ptrs = (C.c_void_p * 45)(*[keep[f"f_rest_{k}"].ctypes.data if f"f_rest_{k}" in keep else None for k in range(45)])
+        a.sh = sh_ptrs
+        a.f_rest = fr_ptrs
+        order = C.c_int32(int(attrs["gsplat__sh_order"])) if "gsplat__sh_order" in attrs else None
+        a.sh_order = C.pointer(order) if order is not None else None
+        eye = _f3(attrs["gsplat__explicit_camera_pos"]) if "gsplat__explicit_camera_pos" in attrs else None
+        a.explicit_camera_pos = eye
+        ver = (C.c_int64 * 4)(*[int(x) for x in version])
+        buf = C.create_string_buffer(256)
+        bc = _f3(barycenter) if barycenter is not None else None
+        n = self.L.gsplat_prim_update(self.h, int(detail), ver, int(vtx_offset), C.byref(a), bc, buf, 256)
+        if n < 0:
+            raise GsrError(n, "gsplat_prim_update failed")
+        self._keep = (keep, sh_ptrs, fr_ptrs, order, eye)
+        self.id = buf.value.decode()
+        return self.id
+
+    def render(self, beauty_mode: bool = True):
+        self.L.gsplat_prim_render(self.h, int(beauty_mode))
+
+    @property
+    def missing(self) -> int:
+        return int(self.L.gsplat_prim_missing(self.h))
+
+    @property
+    def sh_order(self) -> int:
+        return int(self.L.gsplat_prim_sh_order(self.h))
+
+    @property
+    def has_sh(self) -> bool:
+        return bool(self.L.gsplat_prim_has_sh(self.h))
+
+    def arrays(self, n: int):
+        """the quantised registerUpdate-layout arrays (copies) as a scenes.Splats-like namespace"""
+        import types
+        def grab(what, dtype, width):
+            p = self.L.gsplat_prim_array(self.h, what)
+            if not p:
+                return None
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n * width * np.dtype(dtype).itemsize,)) \
+                .view(dtype).reshape(n, width).copy()
+        return types.SimpleNamespace(P=grab(0, np.float32, 3), Cd=grab(1, np.uint16, 3), alpha=grab(2, np.float32, 1).reshape(n),
+                                     scale=grab(3, np.uint16, 3), orient=grab(4, np.uint16, 4), shx=grab(5, np.uint16, 16),
+                                     shy=grab(6, np.uint16, 16), shz=grab(7, np.uint16, 16), n=n)

@@ -192,6 +192,9 @@ void gsplat_renderer_get_last_camera_pos(gsplat_renderer* h, float out[3]);
 gsr_context* gsplat_renderer_engine(gsplat_renderer* h);
 gsr_multi* gsplat_renderer_multi(gsplat_renderer* h);
 unsigned int gsplat_closest_sqrt_power_of_2(int n);
+#ifdef __cplusplus
+GSplatRenderer* gsplat_renderer_impl(gsplat_renderer* h);   /* the C++ object behind a handle (C++ callers in the same library) */
+#endif
 
 /* ---- attribute ingest (what GR_PrimGsplat::update does before registerUpdate,
  *      src/GR_GSplat.C:302-372): fp32 -> fp16 RNE and the three SH encodings -- */

@@ -33,6 +33,7 @@ extern "C" {
 #define GSR_E_NO_GEOMETRY    -4   /* render before any upload */
 #define GSR_E_TOO_MANY_PAIRS -5   /* (tile, splat) pair count exceeds GSR_MAX_PAIRS */
 #define GSR_E_OOM            -6
+#define GSR_E_COMM           -7   /* RCCL could not be loaded, or a communicator call failed */
 
 #define GSR_TILE              16          /* tile edge in pixels */
 #define GSR_MAX_DIM           4096        /* max framebuffer width/height */
@@ -84,6 +85,10 @@ typedef struct gsr_stats {
     double stage_ms_total[5];              /* timing level 2: running totals of ms_preprocess, ms_depth_sort, ms_emit,
                                               ms_tile_sort, ms_blend over stage_frames frames */
     int64_t stage_frames;
+    int64_t sorts_skipped;                 /* frames that reused the cached depth order (GSR_OPT_SORT_CACHE) */
+    int64_t frames_requeued;               /* frames whose back end ran twice: the pair count outgrew the list buffer */
+    int64_t frames_truncated;              /* GSR_OPT_DEFERRED_CHECK only: frames handed over with clamped lists (must stay 0
+                                              for exact pixels; the buffer is regrown for the following frames) */
 } gsr_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -113,6 +118,8 @@ int  gsr_upload_append(gsr_context* ctx, int64_t n,
                        const uint16_t* scale, const uint16_t* orient,
                        const uint16_t* shx, const uint16_t* shy, const uint16_t* shz);
 int  gsr_upload_end(gsr_context* ctx);
+/* gives up an upload that failed between begin and end: the context holds no geometry afterwards */
+int  gsr_upload_abort(gsr_context* ctx);
 /* begin + append + end for a single entry */
 int  gsr_upload(gsr_context* ctx, int64_t n,
                 const float* P, const uint16_t* Cd, const float* alpha,
@@ -131,6 +138,50 @@ int  gsr_band_rows(int height, int index, int count);      /* pixel rows in that
 int  gsr_stitch_bands(gsr_context* ctx, const float* gathered, int count,
                       int width, int height, float* rgba_out);
 
+/* ---- several GPUs, one caller thread -------------------------------------- */
+/* The reference draws from Houdini's single draw thread (src/DM_GSplatHook.C:30-39); gsr_multi drives G contexts -- one
+ * per GPU, tile row r -> rank r % G, splats replicated -- from that one thread: a frame is queued on every GPU before
+ * the host waits for any, the band images are gathered to devices[0] by ONE collective (ncclRecv x (G-1) + ncclSend per
+ * peer in one group; RCCL over xGMI) and de-interleaved there.  The result is bit-identical to the 1-GPU frame. */
+typedef struct gsr_multi gsr_multi;
+#define GSR_TRANSPORT_AUTO   0   /* RCCL when the devices are distinct (and librccl loads), else COPY */
+#define GSR_TRANSPORT_RCCL   1   /* single-process communicator (ncclCommInitAll) */
+#define GSR_TRANSPORT_COPY   2   /* hipMemcpyPeerAsync / device-to-device copies ordered by events: several contexts on ONE
+                                    GPU (how the 1-GPU test box runs the whole path), or a fallback without RCCL */
+int  gsr_multi_create(const int* devices, int count, int transport, gsr_multi** out);   /* devices may repeat for COPY */
+void gsr_multi_destroy(gsr_multi* m);
+int  gsr_multi_count(gsr_multi* m);
+int  gsr_multi_transport(gsr_multi* m);                       /* the transport in use (GSR_TRANSPORT_RCCL / _COPY) */
+gsr_context* gsr_multi_context(gsr_multi* m, int rank);      /* rank's context (stats, debug access); do not destroy */
+int  gsr_multi_set_stream(gsr_multi* m, void* hip_stream);   /* the ROOT's public stream (device devices[0]) */
+int  gsr_multi_set_option(gsr_multi* m, int option, int value);
+int  gsr_multi_upload_begin(gsr_multi* m, int64_t total_splats, int has_sh, const float origin[3]);
+int  gsr_multi_upload_append(gsr_multi* m, int64_t n, const float* P, const uint16_t* Cd, const float* alpha,
+                             const uint16_t* scale, const uint16_t* orient,
+                             const uint16_t* shx, const uint16_t* shy, const uint16_t* shz);
+int  gsr_multi_upload_end(gsr_multi* m);
+int  gsr_multi_upload_abort(gsr_multi* m);
+int  gsr_multi_upload(gsr_multi* m, int64_t n, const float* P, const uint16_t* Cd, const float* alpha,
+                      const uint16_t* scale, const uint16_t* orient,
+                      const uint16_t* shx, const uint16_t* shy, const uint16_t* shz, const float origin[3]);
+/* full frame on devices[0] (device pointer there, asynchronous on the root's public stream) or in host memory */
+int  gsr_multi_render(gsr_multi* m, const gsr_camera* cam, float* rgba_out, int out_is_device);
+int  gsr_multi_render_depth(gsr_multi* m, const gsr_camera* cam, const float* depth, int depth_is_device,
+                            float* rgba_out, int out_is_device);
+int  gsr_multi_synchronize(gsr_multi* m);
+int  gsr_multi_get_stats(gsr_multi* m, int rank, gsr_stats* out);
+
+/* ---- one process per GPU (torchrun-style launches): the same gather ----------- */
+/* The launcher hands every rank the 128-byte id rank 0 obtained (any side channel); after gsr_comm_init a frame is one
+ * call per rank: the rank's band is rendered, sent (ncclSend) or received and stitched (root).  Asynchronous, ordered on
+ * the context's public stream; rgba_out_device is the FULL frame on the root and ignored elsewhere. */
+#define GSR_COMM_ID_BYTES 128
+int  gsr_comm_get_unique_id(void* id);
+int  gsr_comm_init(gsr_context* ctx, const void* id, int rank, int world);   /* collective; sets the row shard (rank, world) */
+int  gsr_comm_destroy(gsr_context* ctx);
+int  gsr_comm_render(gsr_context* ctx, const gsr_camera* cam, const float* depth, int depth_is_device,
+                     float* rgba_out_device);
+
 /* ---- per frame ---------------------------------------------------------- */
 /* Renders the uploaded splats.  rgba_out: float[rows*width*4], premultiplied
  * RGBA, row 0 = BOTTOM row (GL window coordinates), cleared to 0 -- what the
@@ -138,7 +189,7 @@ int  gsr_stitch_bands(gsr_context* ctx, const float* gathered, int count,
  * height, or gsr_band_rows() when sharded.  out_is_device: 0 = host pointer
  * (synchronous), 1 = device pointer: asynchronous, ordered on the context's public stream
  * (gsr_set_stream); the call itself only waits for the frame's 4-byte pair count, which the GPU
- * delivers mid-frame while it keeps working. */
+ * delivers mid-frame while it keeps working (GSR_OPT_DEFERRED_CHECK removes that wait too). */
 int  gsr_render(gsr_context* ctx, const gsr_camera* cam, float* rgba_out, int out_is_device);
 
 /* Same frame, depth-tested against what is already in the viewport: the reference draws
@@ -175,6 +226,12 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        Per-frame results and their order on the context stream are unchanged. */
 #define GSR_OPT_DEBUG_FLAGS     5   /* A/B switches for profiling: 1 = no alpha-support shrink of the bboxes,
                                        2 = bbox-only quadrant masks (no separating-axis test) */
+#define GSR_OPT_DEFERRED_CHECK   7   /* 0 (default) / 1: with a DEVICE target, gsr_render returns as soon as the frame is queued --
+                                       no host wait at all -- and the frame's pair count is looked at by the next call that
+                                       touches the context.  The back end always runs against the list buffer sized from
+                                       earlier frames (+25 % headroom); a frame whose pair count outgrows it is composited
+                                       from clamped lists and counted in gsr_stats.frames_truncated (the buffer is regrown
+                                       for the next frame).  The first frame after a buffer-less start is never deferred. */
 int  gsr_set_option(gsr_context* ctx, int option, int value);
 
 /* ---- debug / test access (device -> host copies of intermediates) -------- */

@@ -9,7 +9,9 @@ for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}
   [ "$defs" = "$spec" ] && defs=""
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $defs \
-      -o $P/variants/libgsplat_hip_$name.so $P/csrc/gsr_api.hip $P/csrc/GSplatRenderer.cpp &
+      -o $P/variants/libgsplat_hip_$name.so $P/csrc/gsr_api.hip $P/csrc/gsr_multi.cpp $P/csrc/GSplatRenderer.cpp $P/csrc/gsplat_ingest.cpp -ldl \
+      > /tmp/variant_$name.log 2>&1 &
 done
 wait
+grep -l "error" /tmp/variant_*.log 2>/dev/null | xargs -r tail -5
 ls -la $P/variants/

@@ -69,8 +69,13 @@ def parse_args():
                     help="after the timed region, time the same K steps again with two frames in flight and report "
                          "them as 'pipelined' (off by default so that a rocprofv3 run of the default command sees "
                          "only the serial frames the roofline is computed from)")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="which shard --emulate-shard renders")
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="single-GPU diagnostic: render only tile-row shard 0 of N (per-rank cost of an N-GPU run, no gather)")
+    ap.add_argument("--lazy", type=int, default=1, choices=(0, 1),
+                    help="GSR_OPT_LAZY_COLOUR: 1 (library default) = SH colours only for the splats a frame can composite; 0 = eager (A/B)")
+    ap.add_argument("--torch-gather", action="store_true",
+                    help="N>1: gather with torch.distributed (multigpu.FrameGatherer) instead of the in-library RCCL gather")
     ap.add_argument("--verify", action="store_true",
                     help="N>1: also render the last frame unsharded on rank 0 and require the stitched frame to be bit-identical")
     return ap.parse_args()
@@ -173,24 +178,58 @@ def main():
     eng.set_option(pkg.engine.OPT_DEBUG_FLAGS, args.flags)
     eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, args.frames_in_flight)
     eng.set_option(pkg.engine.OPT_STAGE_TIMING, args.stage_timing)
+    eng.set_option(pkg.engine.OPT_LAZY_COLOUR, args.lazy)
     if world > 1:
         eng.set_row_shard(rank, world)
     elif args.emulate_shard > 1:
-        eng.set_row_shard(0, args.emulate_shard)
+        eng.set_row_shard(args.emulate_rank % args.emulate_shard, args.emulate_shard)
     eng.upload(splats)  # once: geometry stays resident in HBM
 
-    fg = pkg.multigpu.FrameGatherer(dist, rank, world, W, H, "cuda", engine=eng, via_host=(backend != "nccl"))
-    if args.emulate_shard > 1:
-        import torch as _t
-        fg.band = _t.zeros((eng.band_rows(H), W, 4), dtype=_t.float32, device="cuda")
-    assert fg.band.shape[0] == eng.band_rows(H)
     cams = [pkg.engine.camera_struct(pkg.camera.make_camera(W, H, sh_order=order, frame=i))
             for i in range(args.warmup + args.steps)]
+    # N>1: the frame's ONE collective -- band images -> rank 0 over xGMI -- lives INSIDE the library (gsr_comm_render:
+    # render band -> ncclSend / ncclRecv x (N-1) in one group -> k_stitch_bands on the root).  torch.distributed only
+    # carries the 128-byte communicator id, the barriers and the max-over-ranks of the timing.  Every rank must be able
+    # to load RCCL for that; otherwise (and in the gloo functional-test mode) the torch gather of multigpu.py is used.
+    gather = "none (1 GPU)"
+    fg = None
+    final = None
+    if world > 1:
+        use_lib = backend == "nccl" and not args.torch_gather
+        if use_lib:
+            idbuf = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            ok = torch.ones(1, dtype=torch.int32, device="cuda")
+            if rank == 0:
+                try:
+                    idbuf.copy_(torch.frombuffer(bytearray(eng.comm_unique_id()), dtype=torch.uint8))
+                except Exception:
+                    ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            use_lib = bool(ok.item())
+            if use_lib:
+                dist.broadcast(idbuf, src=0)
+                eng.comm_init(bytes(idbuf.cpu().numpy().tobytes()), rank, world)     # collective (ncclCommInitRank)
+                final = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+                gather = "in-library RCCL: gsr_comm_render (ncclSend/ncclRecv group + k_stitch_bands)"
+        if not use_lib:
+            fg = pkg.multigpu.FrameGatherer(dist, rank, world, W, H, "cuda", engine=eng, via_host=(backend != "nccl"))
+            gather = "torch.distributed.gather + gsr_stitch_bands"
+    band = torch.zeros((eng.band_rows(H), W, 4), dtype=torch.float32, device="cuda") if fg is None else fg.band
+    assert band.shape[0] == eng.band_rows(H)
 
     def step(i):
-        eng.render_struct_to_device(cams[i], fg.band.data_ptr())
-        # N>1: ONE collective per frame -- band images -> rank 0 over xGMI (RCCL gather) -- then stitch
-        fg.gather_and_stitch()
+        if final is not None or (world > 1 and fg is None):
+            eng.comm_render(cams[i], final.data_ptr() if final is not None else 0)
+        else:
+            eng.render_struct_to_device(cams[i], band.data_ptr())
+            if fg is not None:
+                fg.gather_and_stitch()
+
+    def current_frame():
+        """rank 0: the full frame of the last step (device tensor)"""
+        if final is not None:
+            return final
+        return fg.gather_and_stitch() if fg is not None else band
 
     for i in range(args.warmup):
         step(i)
@@ -215,16 +254,19 @@ def main():
     verified = None
     if args.verify and world > 1:
         last = cams[args.warmup + args.steps - 1]
-        stitched = fg.gather_and_stitch()                      # bands of the last step are still in place
+        stitched = current_frame()                              # the last step's frame on rank 0
         if rank == 0:
-            eng.set_row_shard(0, 1)
+            ref_eng = pkg.Engine(dev_index)                     # an unsharded context beside the sharded one
+            ref_eng.set_stream(stream.cuda_stream)
+            ref_eng.upload(splats)
             ref = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-            eng.render_struct_to_device(last, ref.data_ptr())
+            ref_eng.render_struct_to_device(last, ref.data_ptr())
             torch.cuda.synchronize()
             verified = bool(torch.equal(stitched, ref)) and bool(ref[..., 3].max() > 0)
-            eng.set_row_shard(rank, world)
+            ref_eng.close()
             if not verified:
                 raise SystemExit("sharded frame differs from the unsharded frame")
+        dist.barrier()
     st = eng.stats()
     # extra leg (informational): the same K steps with two frames in flight
     pipelined = None
@@ -347,12 +389,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {splats.n} synthetic splats (SH deg {order}, seed {cfg['seed']}), "
                                    f"{W}x{H}, orbiting camera (re-sort every frame)",
-                       "parallelism": f"tile-row shard x{world}" if world > 1 else "single GPU",
+                       "parallelism": f"tile-row shard x{world}" if world > 1 else "single GPU", "gather": gather,
                        "n_splats": splats.n, "width": W, "height": H, "frames_in_flight": args.frames_in_flight},
             "roofline": roofline,
             "roofline_preprocess": roofline_k1,
             "stages_ms_last_frame": stages,
             "n_visible": st["n_visible"],
+            "lazy_colour": {"enabled": bool(args.lazy), "colours_evaluated_per_frame": st["lazy_colours_total"] / max(1, st["frames"]),
+                            "fallback_tiles_last_frame": st["lazy_redo_tiles"]},
         }
         if pipelined is not None:
             line["pipelined"] = pipelined

@@ -29,6 +29,7 @@
 #include "gsr_device.h"
 #include "k_binning.h"
 #include "k_blend.h"
+#include "k_colour.h"
 #include "k_preprocess.h"
 #include "k_sort.h"
 #include "k_wire.h"
@@ -81,6 +82,7 @@ struct FrameJob {
     bool out_is_device = false, timing = false, timing_all = false, use_map = false;
     bool speculative = false;      // the back end was queued before the pair count was known
     bool deferred = false;         // ... and the frame handed over without waiting for it (GSR_OPT_DEFERRED_CHECK)
+    bool lazy = false;             // K1 left the SH colours pending (k_colour.h)
 };
 
 // Everything one frame in flight owns: its HIP stream, the per-frame HBM arrays, the small
@@ -109,6 +111,10 @@ struct FrameSlot {
     int32_t *sstart = nullptr, *send = nullptr;  // super-tile ranges
     uint4* tile_work = nullptr;        // per tile: entries scanned, records gathered, wave-record evaluations
     size_t tile_cap = 0;
+    int32_t* redo = nullptr;           // lazy colour: tiles the plain blend kernel gave up (tile_cap entries)
+    unsigned long long* lazy_ctr = nullptr;   // [0] low word: redo count of the frame, [1]: colours evaluated (running)
+    uint32_t* colour_evals = nullptr;         // [256] colours evaluated per super-tile list (this frame; folded into lazy_ctr[1])
+    bool last_lazy = false;            // the last frame of this slot left colours pending
     float* fb = nullptr;               // staging for host-pointer output
     size_t fb_cap = 0;
     // small device/host mailboxes
@@ -146,8 +152,13 @@ struct gsr_context {
     uint64_t geo_gen = 0;
     float4* geoA = nullptr;
     uint4* geoB = nullptr;
-    uint4* col = nullptr;
+    uint4* col = nullptr;              // colour halves as SoA chunks (eager colour in K1)
+    uint4* colrow = nullptr;           // ... and as one contiguous row per splat (lazy colour gathers by index)
     int col_chunks = 0;
+    uint32_t* prefix = nullptr;        // lazy colour: per super-tile, list entries to colour next frame (k_sum_work writes it)
+    uint32_t* prefix_all = nullptr;    // 256 x 0xffffffff: colour every list completely (first frame, debug read-back)
+    uint32_t* prefix_none = nullptr;   // 256 x 0: colour nothing ahead of time (GSR_FLAG_LAZY_NO_PREFIX: every tile takes the fallback)
+    bool prefix_valid = false;
     bool uploading = false;
     uint32_t up_total = 0, up_filled = 0;
     // bounding box of the uploaded positions (bounds the sort keys of a frame)
@@ -162,11 +173,17 @@ struct gsr_context {
     int map_w = 0, map_h = 0, map_si = -1, map_sc = 0, map_shift = -1, map_grid = 0;
 
     int shard_index = 0, shard_count = 1;
-    int opt_swizzle = 1, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0;
+    int opt_swizzle = 1, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0, opt_lazy = 1;
 
     gsr_stats st{};
     uint64_t frame_no = 0;
     size_t pair_want = 0;              // largest list buffer any frame slot needed so far
+    int64_t lazy_base = 0;             // lazy_colours_total at the last gsr_stats_reset
+    unsigned long long* wire_zbuf = nullptr;   // wireframe overlay: (depth bits, splat index) per pixel ...
+    float* wire_out = nullptr;                 // ... and the image staged for a host target
+    size_t wire_cap = 0;                       // pixels both hold
+    char* stage = nullptr;                     // raw attribute arrays of an upload in progress
+    size_t stage_cap = 0;
 };
 
 template <typename T>
@@ -223,6 +240,10 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_n), sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.d_n, 0, sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.totals), 512 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.lazy_ctr), 2 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMemset(sl.lazy_ctr, 0, 2 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.colour_evals), 256 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(sl.colour_evals, 0, 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess;
     ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_total_dev), sl.h_total, 0) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess;
@@ -250,6 +271,7 @@ static void slot_destroy(FrameSlot& sl)
     dev_free(sl.hist); dev_free(sl.totals);
     dev_free(sl.pvA);
     dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.fb); dev_free(sl.depth_stage);
+    dev_free(sl.redo); dev_free(sl.lazy_ctr); dev_free(sl.colour_evals);
     dev_free(sl.counters); dev_free(sl.d_n);
     if (sl.h_total) (void)hipHostFree(sl.h_total);
     if (sl.h_counters) (void)hipHostFree(sl.h_counters);
@@ -282,6 +304,14 @@ extern "C" int gsr_create(int device, gsr_context** out)
         gsr_destroy(c);
         return set_err(GSR_E_HIP, "gsr_create: allocating frame slots (streams/events/mailboxes) failed");
     }
+    if (hipMalloc(reinterpret_cast<void**>(&c->prefix), 256 * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->prefix_all), 256 * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->prefix_none), 256 * 4) != hipSuccess ||
+        hipMemset(c->prefix, 0xff, 256 * 4) != hipSuccess || hipMemset(c->prefix_all, 0xff, 256 * 4) != hipSuccess ||
+        hipMemset(c->prefix_none, 0, 256 * 4) != hipSuccess) {
+        gsr_destroy(c);
+        return set_err(GSR_E_HIP, "gsr_create: allocating the colour-prefix tables failed");
+    }
     c->st.record_bytes = (int32_t)sizeof(GsrRecord);
     c->st.pair_bytes = 8;
     *out = c;
@@ -290,7 +320,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
 
 static void free_geometry(gsr_context* c)
 {
-    dev_free(c->geoA); dev_free(c->geoB); dev_free(c->col);
+    dev_free(c->geoA); dev_free(c->geoB); dev_free(c->col); dev_free(c->colrow);
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) slot_free_splat_arrays(c->slot[k]);
     c->cap = 0; c->n = 0;
 }
@@ -304,6 +334,8 @@ extern "C" void gsr_destroy(gsr_context* c)
     free_geometry(c);
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) slot_destroy(c->slot[k]);
     dev_free(c->tile_map);
+    dev_free(c->wire_zbuf); dev_free(c->wire_out); dev_free(c->stage);
+    dev_free(c->prefix); dev_free(c->prefix_all); dev_free(c->prefix_none);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -330,6 +362,7 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
         break;
     case GSR_OPT_DEBUG_FLAGS: c->opt_flags = value; break;
     case GSR_OPT_DEFERRED_CHECK: c->opt_deferred = value ? 1 : 0; break;
+    case GSR_OPT_LAZY_COLOUR: c->opt_lazy = value ? 1 : 0; break;
     case GSR_OPT_SUPER_TILE:
         if (value != 0 && (value < 1 || value > 16 || (value & (value - 1))))
             return set_err(GSR_E_INVALID, "gsr_set_option: super-tile edge must be 0 (auto) or 1,2,4,8,16");
@@ -363,7 +396,8 @@ extern "C" int gsr_upload_begin(gsr_context* c, int64_t total, int has_sh, const
     if (n > c->cap || chunks != c->col_chunks) {
         free_geometry(c);
         const size_t cap = n ? n : 1;
-        if ((rc = dev_alloc(&c->geoA, cap)) || (rc = dev_alloc(&c->geoB, cap)) || (rc = dev_alloc(&c->col, cap * chunks))) {
+        if ((rc = dev_alloc(&c->geoA, cap)) || (rc = dev_alloc(&c->geoB, cap)) || (rc = dev_alloc(&c->col, cap * chunks)) ||
+            (has_sh && (rc = dev_alloc(&c->colrow, cap * 8)))) {
             free_geometry(c);
             return rc;
         }
@@ -402,14 +436,33 @@ extern "C" int gsr_upload_append(gsr_context* c, int64_t n64, const float* P, co
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t n = (uint32_t)n64;
     hipStream_t us = c->slot[0].stream;
-    // raw staging buffers (freed before return: upload is not the per-frame path)
-    float *dP = nullptr, *dA = nullptr;
-    uint16_t *dCd = nullptr, *dS = nullptr, *dO = nullptr, *dX = nullptr, *dY = nullptr, *dZ = nullptr;
-    int rc = GSR_OK;
-    auto cleanup = [&]() { dev_free(dP); dev_free(dA); dev_free(dCd); dev_free(dS); dev_free(dO); dev_free(dX); dev_free(dY); dev_free(dZ); };
-    if ((rc = dev_alloc(&dP, (size_t)n * 3)) || (rc = dev_alloc(&dA, (size_t)n)) || (rc = dev_alloc(&dCd, (size_t)n * 3)) ||
-        (rc = dev_alloc(&dS, (size_t)n * 3)) || (rc = dev_alloc(&dO, (size_t)n * 4))) { cleanup(); return rc; }
-    if (c->has_sh && ((rc = dev_alloc(&dX, (size_t)n * 16)) || (rc = dev_alloc(&dY, (size_t)n * 16)) || (rc = dev_alloc(&dZ, (size_t)n * 16)))) { cleanup(); return rc; }
+    // raw staging arena: one device allocation shared by the appends of an upload (grown on demand, released by
+    // gsr_upload_end / _abort -- it is as large as the geometry itself)
+    const size_t al = 256;
+    auto pad = [&](size_t b) { return (b + al - 1) / al * al; };
+    const size_t bP = pad((size_t)n * 12), bA = pad((size_t)n * 4), bC = pad((size_t)n * 6), bS = pad((size_t)n * 6),
+                 bO = pad((size_t)n * 8), bH = c->has_sh ? pad((size_t)n * 32) : 0;
+    const size_t need = bP + bA + bC + bS + bO + 3 * bH;
+    if (need > c->stage_cap) {
+        HIP_TRY(hipStreamSynchronize(us));
+        dev_free(c->stage);
+        c->stage_cap = 0;
+        int rc = dev_alloc(&c->stage, need);
+        if (rc) return rc;
+        c->stage_cap = need;
+    }
+    char* base = c->stage;
+    float* dP = reinterpret_cast<float*>(base); base += bP;
+    float* dA = reinterpret_cast<float*>(base); base += bA;
+    uint16_t* dCd = reinterpret_cast<uint16_t*>(base); base += bC;
+    uint16_t* dS = reinterpret_cast<uint16_t*>(base); base += bS;
+    uint16_t* dO = reinterpret_cast<uint16_t*>(base); base += bO;
+    uint16_t *dX = nullptr, *dY = nullptr, *dZ = nullptr;
+    if (c->has_sh) {
+        dX = reinterpret_cast<uint16_t*>(base); base += bH;
+        dY = reinterpret_cast<uint16_t*>(base); base += bH;
+        dZ = reinterpret_cast<uint16_t*>(base);
+    }
     hipError_t e = hipSuccess;
     auto h2d = [&](void* d, const void* h, size_t bytes) { if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, us); };
     h2d(dP, P, (size_t)n * 12); h2d(dA, alpha, (size_t)n * 4); h2d(dCd, Cd, (size_t)n * 6);
@@ -417,11 +470,10 @@ extern "C" int gsr_upload_append(gsr_context* c, int64_t n64, const float* P, co
     if (c->has_sh) { h2d(dX, shx, (size_t)n * 32); h2d(dY, shy, (size_t)n * 32); h2d(dZ, shz, (size_t)n * 32); }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_repack, dim3(div_up(n, 256)), dim3(256), 0, us, n, c->up_filled, c->cap,
-                           c->has_sh ? 1 : 0, dP, dCd, dA, dS, dO, dX, dY, dZ, c->geoA, c->geoB, c->col);
+                           c->has_sh ? 1 : 0, dP, dCd, dA, dS, dO, dX, dY, dZ, c->geoA, c->geoB, c->col, c->colrow);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(us);
-    cleanup();
+    if (e == hipSuccess) e = hipStreamSynchronize(us);   // the caller's arrays may be freed on return
     if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_upload_append: %s", hipGetErrorString(e));
     c->up_filled += n;
     return GSR_OK;
@@ -431,6 +483,8 @@ extern "C" int gsr_upload_end(gsr_context* c)
 {
     if (!c || !c->uploading) return set_err(GSR_E_INVALID, "gsr_upload_end: no upload in progress");
     c->uploading = false;
+    dev_free(c->stage);
+    c->stage_cap = 0;
     if (c->up_filled != c->up_total)
         return set_err(GSR_E_INVALID, "gsr_upload_end: %u of %u announced splats were appended", c->up_filled, c->up_total);
     c->n = c->up_total;
@@ -462,6 +516,7 @@ extern "C" int gsr_upload_end(gsr_context* c)
     }
     c->geo_gen++;
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
+    c->prefix_valid = false;           // lazy colour: the first frame of a new cloud colours every list completely
     c->st.n_splats = c->n;
     return GSR_OK;
 }
@@ -471,6 +526,8 @@ extern "C" int gsr_upload_abort(gsr_context* c)
     if (!c) return set_err(GSR_E_INVALID, "gsr_upload_abort: ctx is NULL");
     // an upload that failed half-way leaves no geometry behind: rendering needs a complete new upload
     if (c->uploading) { c->uploading = false; c->n = 0; c->up_total = c->up_filled = 0; c->st.n_splats = 0; }
+    dev_free(c->stage);
+    c->stage_cap = 0;
     return GSR_OK;
 }
 
@@ -766,7 +823,16 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
                            (uint32_t)sl.pair_cap, sl.pvA);
         HIP_TRY(hipGetLastError());
     }
-    if ((rc = mark(sl, 4)) || (rc = mark(sl, 5))) return rc;
+    if ((rc = mark(sl, 4))) return rc;
+    if (j.lazy && j.n > 0) {
+        // colours for the front of every super-tile list: as deep as the previous frame's tiles scanned (+ headroom)
+        const bool predict = c->prefix_valid && !(f.flags & GSR_FLAG_LAZY_NO_PREFIX);
+        hipLaunchKernelGGL(k_colour_prefix, dim3((unsigned)(j.n_super * CL_BLOCKS_PER_LIST)), dim3(CL_THREADS), 0, s, f, sl.pvA,
+                           sl.sstart, sl.send, (f.flags & GSR_FLAG_LAZY_NO_PREFIX) ? c->prefix_none : (predict ? c->prefix : c->prefix_all),
+                           (int)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff), c->colrow, sl.rec, sl.colour_evals);
+        HIP_TRY(hipGetLastError());
+    }
+    if ((rc = mark(sl, 5))) return rc;
     if (j.local_tiles > 0) {
         HIP_TRY(hipStreamWaitEvent(s, sl.ev_user, 0));
         GsrBlendArgs a;
@@ -775,12 +841,25 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
         a.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
         const unsigned grid = a.use_map ? (unsigned)c->map_grid : (unsigned)j.local_tiles;
+        GsrLazyArgs lz;
+        lz.f = f; lz.colrow = c->colrow;
+        lz.redo = j.lazy ? sl.redo : nullptr;
+        lz.redo_count = reinterpret_cast<uint32_t*>(sl.lazy_ctr);
+        float4* tgt = reinterpret_cast<float4*>(j.target);
         if (j.d_depth)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<true>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
-                               sl.send, sl.rec, reinterpret_cast<float4*>(j.target), sl.tile_work, sl.zwin, j.d_depth);
+                               sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
-                               sl.send, sl.rec, reinterpret_cast<float4*>(j.target), sl.tile_work, sl.zwin, j.d_depth);
+                               sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
+        if (j.lazy) {   // the tiles that met a pending colour, with on-demand evaluation (normally none: the blocks exit at once)
+            if (j.d_depth)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<true>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
+                                   sl.pvA, sl.sstart, sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<false>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
+                                   sl.pvA, sl.sstart, sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
+        }
         HIP_TRY(hipGetLastError());
     }
     return mark(sl, 6);
@@ -791,9 +870,15 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
 {
     const FrameJob& j = sl.job;
     hipStream_t s = sl.stream;
-    hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, j.local_tiles, sl.counters, sl.d_n,
-                       sl.h_counters_dev);
+    GsrSumArgs g;
+    g.n_tiles = j.local_tiles; g.tiles_x = j.f.tiles_x; g.shard_index = j.f.shard_index; g.shard_count = j.f.shard_count;
+    g.super_shift = j.f.super_shift; g.stiles_x = j.f.stiles_x; g.n_super = j.n_super;
+    hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, g, sl.counters, sl.d_n, sl.h_counters_dev,
+                       j.lazy ? c->prefix : (uint32_t*)nullptr, j.lazy ? reinterpret_cast<const uint32_t*>(sl.lazy_ctr) : (const uint32_t*)nullptr,
+                       sl.colour_evals, sl.lazy_ctr + 1);
     HIP_TRY(hipGetLastError());
+    if (j.lazy) c->prefix_valid = true;
+    sl.last_lazy = j.lazy;
     if (j.timing) { sl.ev_pending = true; sl.ev_all = j.timing_all; }
     if (!j.out_is_device) {
         HIP_TRY(hipMemcpyAsync(j.user_out, sl.fb, j.out_px * 16, hipMemcpyDeviceToHost, s));
@@ -906,6 +991,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     j.user_out = rgba_out;
     j.out_is_device = out_is_device != 0;
     j.deferred = c->opt_deferred && j.out_is_device;
+    j.lazy = c->opt_lazy && f.sh_order > 0;   // order 0: the colour is Cd itself, nothing to defer
     if (j.timing) harvest_slot(c, sl);
 
     // the caller's stream position now: the blend kernel (the only writer of caller-visible memory)
@@ -915,10 +1001,10 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     // per-tile bookkeeping + super-tile ranges
     if ((size_t)j.local_tiles + 1 > sl.tile_cap || !sl.sstart) {
         HIP_TRY(hipStreamSynchronize(s));
-        dev_free(sl.tile_work); dev_free(sl.sstart); dev_free(sl.send);
+        dev_free(sl.tile_work); dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.redo);
         sl.tile_cap = 0;
         if ((rc = dev_alloc(&sl.tile_work, (size_t)j.local_tiles + 1)) || (rc = dev_alloc(&sl.sstart, (size_t)65536 + 1)) ||
-            (rc = dev_alloc(&sl.send, (size_t)65536 + 1))) return rc;
+            (rc = dev_alloc(&sl.send, (size_t)65536 + 1)) || (rc = dev_alloc(&sl.redo, (size_t)j.local_tiles + 1))) return rc;
         sl.tile_cap = (size_t)j.local_tiles + 1;
     }
     if (j.use_map && (rc = build_tile_map(c, f))) return rc;
@@ -959,7 +1045,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         // output goes to the scratch buffers
         hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, GSR_K1_THREADS)), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, cache_hit ? sl.keyB : sl.keyA, cache_hit ? sl.valB : sl.valA,
-                           j.d_depth ? sl.zwin : (float*)nullptr);
+                           j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return frame_abort(sl, set_err(GSR_E_HIP, "k_preprocess: %s", hipGetErrorString(e)));
     }
@@ -987,7 +1073,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
                            c->shard_count, f.stiles_x, sl.hist, nblk);
         hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals);
         hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, sl.totals, j.n_super, sl.sstart, sl.send, sl.h_total_dev,
-                           (unsigned long long)GSR_MAX_PAIRS);
+                           (unsigned long long)GSR_MAX_PAIRS, reinterpret_cast<uint32_t*>(sl.lazy_ctr));
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(sl.ev_pairs, s);
     } else {
@@ -1053,11 +1139,18 @@ extern "C" int gsr_render_wire(gsr_context* c, const gsr_camera* cam, float* rgb
     GsrFrame f;
     build_frame(c, cam, &f);
     const size_t npix = (size_t)cam->width * cam->height;
-    unsigned long long* zbuf = nullptr;
-    float* dout = nullptr;
-    if ((rc = dev_alloc(&zbuf, npix))) return rc;
-    if (!out_is_device && (rc = dev_alloc(&dout, npix * 4))) { dev_free(zbuf); return rc; }
-    float* target = out_is_device ? rgba_out : dout;
+    // the z-buffer (and the staging image for a host target) are kept between calls: an overlay redraw allocates nothing
+    if (npix > c->wire_cap) {
+        dev_free(c->wire_zbuf); dev_free(c->wire_out);
+        c->wire_cap = 0;
+        if ((rc = dev_alloc(&c->wire_zbuf, npix)) || (rc = dev_alloc(&c->wire_out, npix * 4))) {
+            dev_free(c->wire_zbuf); dev_free(c->wire_out);
+            return rc;
+        }
+        c->wire_cap = npix;
+    }
+    unsigned long long* zbuf = c->wire_zbuf;
+    float* target = out_is_device ? rgba_out : c->wire_out;
     hipError_t e = hipMemsetAsync(zbuf, 0xff, npix * 8, s);
     if (e == hipSuccess && c->n > 0)
         hipLaunchKernelGGL(k_wire_splats, dim3(div_up(c->n, 256)), dim3(256), 0, s, c->n, f, c->geoA, c->geoB, zbuf);
@@ -1065,10 +1158,8 @@ extern "C" int gsr_render_wire(gsr_context* c, const gsr_camera* cam, float* rgb
         hipLaunchKernelGGL(k_wire_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, zbuf, npix, c->col,
                            reinterpret_cast<float4*>(target));
     if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess && !out_is_device) e = hipMemcpyAsync(rgba_out, dout, npix * 16, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && !out_is_device) e = hipMemcpyAsync(rgba_out, c->wire_out, npix * 16, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    dev_free(zbuf);
-    dev_free(dout);
     if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_render_wire: %s", hipGetErrorString(e));
     return GSR_OK;
 }
@@ -1103,6 +1194,7 @@ extern "C" int gsr_get_stats(gsr_context* c, gsr_stats* out)
         harvest_slot(c, *last);
         FrameSlot& sl = *last;
         c->st.n_visible = (int64_t)(sl.h_counters[6] & 0xffffffffull);
+        c->st.lazy_redo_tiles = sl.last_lazy ? (int64_t)(sl.h_counters[7] & 0xffffffffull) : 0;
         c->st.pairs_consumed = (int64_t)sl.h_counters[1];
         c->st.entries_scanned = (int64_t)sl.h_counters[3];
         c->st.pairs_total = sl.last_pairs;
@@ -1122,6 +1214,12 @@ extern "C" int gsr_get_stats(gsr_context* c, gsr_stats* out)
         c->st.blend_pairs_consumed_total = rec_tot;
         c->st.blend_entries_scanned_total = ent_tot;
         c->st.blend_wave_evals_total = ev_tot;
+        {   // colours evaluated ahead of time (device-side running counters, one per slot)
+            unsigned long long tot = 0, v = 0;
+            for (int k = 0; k < GSR_MAX_SLOTS; ++k)
+                if (c->slot[k].lazy_ctr && hipMemcpy(&v, c->slot[k].lazy_ctr + 1, 8, hipMemcpyDeviceToHost) == hipSuccess) tot += v;
+            c->st.lazy_colours_total = (int64_t)tot - c->lazy_base;
+        }
     }
     *out = c->st;
     return GSR_OK;
@@ -1139,6 +1237,12 @@ extern "C" int gsr_stats_reset(gsr_context* c)
         for (int j = 0; j < 8; ++j) c->slot[k].h_counters[j] = 0;
     }
     const int64_t ns = c->st.n_splats;
+    {
+        unsigned long long tot = 0, v = 0;
+        for (int k = 0; k < GSR_MAX_SLOTS; ++k)
+            if (c->slot[k].lazy_ctr && hipMemcpy(&v, c->slot[k].lazy_ctr + 1, 8, hipMemcpyDeviceToHost) == hipSuccess) tot += v;
+        c->lazy_base = (int64_t)tot;
+    }
     c->st = gsr_stats{};
     c->st.n_splats = ns;
     c->st.record_bytes = (int32_t)sizeof(GsrRecord);
@@ -1159,6 +1263,14 @@ extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int
     if (src) return src;
     FrameSlot* sl = latest_slot(c);
     if (!sl) return set_err(GSR_E_INVALID, "gsr_debug_read_records: no frame rendered yet");
+    if (sl->last_lazy && sl->last_supers > 0 && c->n > 0) {
+        // lazy colour leaves most records pending: evaluate every list completely before reading them back
+        hipLaunchKernelGGL(k_colour_prefix, dim3((unsigned)(sl->last_supers * CL_BLOCKS_PER_LIST)), dim3(CL_THREADS), 0, sl->stream,
+                           sl->job.f, sl->pvA, sl->sstart, sl->send, c->prefix_all, (int)std::min<size_t>(sl->pair_cap, (size_t)0x7fffffff),
+                           c->colrow, sl->rec, sl->colour_evals);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(sl->stream));
+    }
     const uint32_t ns = sorted_count(sl);
     GsrRecord* hr = new (std::nothrow) GsrRecord[n ? n : 1];
     uint32_t* hk = new (std::nothrow) uint32_t[ns ? ns : 1];

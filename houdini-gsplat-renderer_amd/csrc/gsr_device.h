@@ -63,6 +63,7 @@ struct GsrFrame {
 #define GSR_FLAG_NO_ALPHA_RADIUS 1   // bbox from the full +-2 quad instead of the alpha>=1/255 support
 #define GSR_FLAG_NO_SAT          2   // quadrant masks from the bbox only
 #define GSR_FLAG_FULL_KEYS       4   // sort all 32 key bits (no key-range reduction, 8-bit digits)
+#define GSR_FLAG_LAZY_NO_PREFIX  8   // lazy colour: colour nothing ahead of time, so that every tile takes the on-demand fallback
 
 // ---- scalar helpers ---------------------------------------------------------
 __device__ __forceinline__ float gsr_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }

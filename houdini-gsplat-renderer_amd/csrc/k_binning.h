@@ -118,8 +118,10 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
 // the host is told 0xffffffff -- it reports GSR_E_TOO_MANY_PAIRS instead of compositing wrapped positions.
 __global__ void __launch_bounds__(BN_BINS)
 k_bin_ranges(const uint32_t* __restrict__ totals, int n_super, int32_t* __restrict__ sstart, int32_t* __restrict__ send,
-             volatile uint32_t* __restrict__ host_total /* pinned, mapped */, unsigned long long max_pairs)
+             volatile uint32_t* __restrict__ host_total /* pinned, mapped */, unsigned long long max_pairs,
+             uint32_t* __restrict__ redo_count /* the frame's list of tiles given up by the plain blend kernel starts empty */)
 {
+    if (threadIdx.x == 0) *redo_count = 0u;
     __shared__ uint32_t s_wave[4];
     __shared__ unsigned long long s_sum[4];
     const uint32_t v = ((int)threadIdx.x < n_super) ? totals[threadIdx.x] : 0u;

@@ -26,6 +26,7 @@
 // all four waves have.
 #pragma once
 #include "gsr_device.h"
+#include "k_preprocess.h"   // gsr_splat_colour_from_row (on-demand colour of the lazy path)
 
 #ifndef BL_ROUND
 #define BL_ROUND 64           // records composited per round.  The kernel wants waves per SIMD: measured on C4
@@ -66,12 +67,21 @@ struct GsrBlendArgs {
 #else
 #define BL_OCC
 #endif
-template <bool HAS_DEPTH>
-__global__ void __launch_bounds__(256) BL_OCC
-k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __restrict__ svals,
-        const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
-        const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint4* __restrict__ tile_work,
-        const float* __restrict__ zwin, const float* __restrict__ depth)
+// Lazy colour (k_colour.h): a record whose colour is still pending makes the plain kernel (LAZY = false) give the tile up
+// -- it is appended to `redo` -- and the LAZY = true instantiation, launched right behind, composites exactly those tiles
+// with the colour evaluated on demand in the gather.
+struct GsrLazyArgs {
+    GsrFrame f;
+    const uint4* colrow;       // 128-byte row per splat: position + colour halves
+    int32_t* redo;             // tiles given up by the plain kernel
+    uint32_t* redo_count;
+};
+template <bool HAS_DEPTH, bool LAZY>
+__device__ __forceinline__ void
+gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, const uint2* __restrict__ svals,
+               const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
+               const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint4* __restrict__ tile_work,
+               const float* __restrict__ zwin, const float* __restrict__ depth, const GsrLazyArgs& lz)
 {
     constexpr int PF4 = HAS_DEPTH ? 6 : 5;
     __shared__ float4 slist[4][(BL_ROUND / 2) * PF4];
@@ -79,13 +89,19 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
     __shared__ uint32_t scnt[2][BL_SCAN_K][4];
     __shared__ unsigned long long swcnt[2][4];   // per gathering wave: 4 x 16-bit counts of records reaching quadrant 0..3
     __shared__ uint32_t sdone[2][4];
-    __shared__ uint32_t sfetched, sevals;
+    __shared__ uint32_t sfetched, sevals, sredo;
     __shared__ float4 spark[BL_ROUND];   // the gathered (r, g, b, opacity) waits here between gather and staging: LDS
                                          // instead of three VGPRs the register allocator would spill to scratch
 
     // Workgroup b runs on XCD b%8 (observed dispatch order, MI355X guide): tile_map hands each
     // XCD whole super-tiles, whose 64 tiles read the same list and gather the same records.
-    const int tile = a.use_map ? tile_map[blockIdx.x] : (int)blockIdx.x;
+    int tile;
+    if (LAZY) {
+        if (blockIdx.x >= *lz.redo_count) return;
+        tile = lz.redo[blockIdx.x];
+    } else {
+        tile = a.use_map ? tile_map[blockIdx.x] : (int)blockIdx.x;
+    }
     if (tile < 0 || tile >= a.local_tiles) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % a.tiles_x, lty = tile / a.tiles_x;
@@ -97,7 +113,7 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
     const gsr_v2f lx = (gsr_v2f)((float)((wave & 1) * 8 + (lane & 7))), ly = (gsr_v2f)((float)((wave >> 1) * 8 + (lane >> 3)));
     // tile bounds in pixel-centre coordinates, for the quadrant masks
     const float tcx0 = (float)(tx * GSR_TILE_PX) + 0.5f, tcy0 = (float)(gty * GSR_TILE_PX) + 0.5f;
-    if (tid == 0) { sfetched = 0; sevals = 0; }
+    if (tid == 0) { sfetched = 0; sevals = 0; sredo = 0; }
     uint32_t my_evals = 0;            // (wave-uniform) records this wave evaluated for its 64 pixels
     // depth test against what the opaque pass left (depth writes stay off): a fragment survives iff its quad's
     // window depth <= depth[pixel] (src/GSplatRenderer.C:595-610).  No depth buffer = +inf.
@@ -130,6 +146,7 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
         pre[k] = (i < n) ? svals[s + i] : make_uint2(0u, GSR_RECT_EMPTY);
     }
     int round = 0;
+    bool saturated = false;           // left because every pixel is opaque, not because the list ended
 
     for (;;) {
         // (1) SCAN until a round's worth of hits is queued, or the list ends
@@ -180,6 +197,11 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
             const uint32_t ridx = q[(q_head + tid) & (BL_QCAP - 1)];
             const float4* p = reinterpret_cast<const float4*>(recs + ridx);
             r0 = p[0]; r1 = p[1]; r2 = p[2];
+            const uint32_t tag = __builtin_bit_cast(uint32_t, r2.x);
+            if (tag == GSR_COLOUR_PENDING) {
+                if (LAZY) gsr_splat_colour_from_row(lz.f, lz.colrow, ridx, r2.x, r2.y, r2.z);
+                else sredo = 1u;   // the colour pass did not reach this record: give the tile to the LAZY instantiation
+            }
             spark[tid] = r2;
             rz = HAS_DEPTH ? zwin[ridx] : 0.0f;
             ++my_fetched;
@@ -220,8 +242,12 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
         const int rpar = round & 1;
         if (lane == 0) { swcnt[rpar][wave] = wcnt; sdone[rpar][wave] = wave_done ? 1u : 0u; }
         __syncthreads();
+        if (!LAZY && sredo) {   // (uniform: read after the barrier that follows every gather)
+            if (tid == 0 && lz.redo) lz.redo[atomicAdd(lz.redo_count, 1u)] = tile;
+            return;
+        }
         const bool block_done = (sdone[rpar][0] & sdone[rpar][1] & sdone[rpar][2] & sdone[rpar][3]) != 0u;
-        if (block_done) break;
+        if (block_done) { saturated = true; break; }
         unsigned long long base = 0, total = 0;   // 4 x 16-bit fields (a field is at most BL_ROUND)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -327,8 +353,29 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
     if (tid == 0) {
         // entries actually read: everything up to scan_pos plus the prefetched step
         const int rd = scan_pos + BL_SCAN_K * 256;
-        tile_work[tile] = make_uint4((uint32_t)(rd < n ? rd : n), sfetched, sevals, 0u);
+        tile_work[tile] = make_uint4((uint32_t)(rd < n ? rd : n), sfetched, sevals, saturated ? 1u : 0u);
     }
+}
+
+// the two entry points: the plain kernel at 6 waves per SIMD; the fallback carries the SH evaluation and is left to the
+// register allocator (it runs for the few tiles the colour pass did not cover)
+template <bool HAS_DEPTH>
+__global__ void __launch_bounds__(256) BL_OCC
+k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __restrict__ svals,
+        const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
+        const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint4* __restrict__ tile_work,
+        const float* __restrict__ zwin, const float* __restrict__ depth, GsrLazyArgs lz)
+{
+    gsr_blend_tile<HAS_DEPTH, false>(a, tile_map, svals, sstart, send, recs, out, tile_work, zwin, depth, lz);
+}
+template <bool HAS_DEPTH>
+__global__ void __launch_bounds__(256)
+k_blend_lazy(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __restrict__ svals,
+             const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
+             const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint4* __restrict__ tile_work,
+             const float* __restrict__ zwin, const float* __restrict__ depth, GsrLazyArgs lz)
+{
+    gsr_blend_tile<HAS_DEPTH, true>(a, tile_map, svals, sstart, send, recs, out, tile_work, zwin, depth, lz);
 }
 
 // One workgroup sums the per-tile bookkeeping into counters[1] (records gathered, this frame),
@@ -336,28 +383,61 @@ k_blend(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* __res
 // [5] (wave-record evaluations, running total) -- a handful of atomics per frame instead of per
 // tile (same-address atomics serialise at ~12 ns each on MI355X).  Last kernel of a frame.
 #define SW_THREADS 1024
+struct GsrSumArgs {
+    int32_t n_tiles, tiles_x, shard_index, shard_count, super_shift, stiles_x, n_super;
+};
 __global__ void __launch_bounds__(SW_THREADS)
-k_sum_work(const uint4* __restrict__ tile_work, int n_tiles, unsigned long long* __restrict__ counters,
-           const uint32_t* __restrict__ n_visible, volatile unsigned long long* __restrict__ host /* pinned, mapped: [7] */)
+k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long* __restrict__ counters,
+           const uint32_t* __restrict__ n_visible, volatile unsigned long long* __restrict__ host /* pinned, mapped: [8] */,
+           uint32_t* __restrict__ prefix /* [256] lazy colour: list entries to colour per super-tile, next frame (or NULL) */,
+           const uint32_t* __restrict__ redo_count /* tiles the plain blend kernel gave up this frame (or NULL) */,
+           uint32_t* __restrict__ colour_evals /* [256] per-list counts of the colour pass, cleared here (or NULL) */,
+           unsigned long long* __restrict__ colour_total /* running total of the above */)
 {
     __shared__ unsigned long long s_sum[3];
+    __shared__ uint32_t s_max[256];
     if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+    if (threadIdx.x < 256) s_max[threadIdx.x] = 0;
     __syncthreads();
     unsigned long long sc = 0, fe = 0, ev = 0;
-    for (int i0 = 0; i0 < n_tiles; i0 += 4 * SW_THREADS) {
+    for (int i0 = 0; i0 < g.n_tiles; i0 += 4 * SW_THREADS) {
         uint4 w[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {   // independent loads: one memory round trip per 4096 tiles
             const int i = i0 + u * SW_THREADS + (int)threadIdx.x;
-            w[u] = i < n_tiles ? tile_work[i] : make_uint4(0u, 0u, 0u, 0u);
+            w[u] = i < g.n_tiles ? tile_work[i] : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { sc += w[u].x; fe += w[u].y; ev += w[u].z; }
+        for (int u = 0; u < 4; ++u) {
+            sc += w[u].x; fe += w[u].y; ev += w[u].z;
+            const int i = i0 + u * SW_THREADS + (int)threadIdx.x;
+            // deepest scan among the tiles of each super-tile that SATURATED: a tile that ran to the end of its list (the
+            // cloud's silhouette) would ask for the whole list; such tiles have few hits and take the on-demand fallback
+            if (prefix && i < g.n_tiles && w[u].w) {
+                const int tx = i % g.tiles_x, gty = (i / g.tiles_x) * g.shard_count + g.shard_index;
+                atomicMax(&s_max[(gty >> g.super_shift) * g.stiles_x + (tx >> g.super_shift)], w[u].x);
+            }
+        }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); atomicAdd(&s_sum[2], ev); }
     __syncthreads();
+    if (prefix && (int)threadIdx.x < g.n_super) {
+        const uint32_t m = s_max[threadIdx.x];
+#ifndef SW_HEADROOM_SHIFT
+#define SW_HEADROOM_SHIFT 2
+#endif
+#ifndef SW_HEADROOM_ADD
+#define SW_HEADROOM_ADD 1024u
+#endif
+        prefix[threadIdx.x] = m + (m >> SW_HEADROOM_SHIFT) + SW_HEADROOM_ADD;   // headroom for the next frame's camera move
+    }
+    if (colour_evals && threadIdx.x < 256) {
+        const uint32_t v = colour_evals[threadIdx.x];
+        colour_evals[threadIdx.x] = 0u;
+        if (v) atomicAdd(colour_total, (unsigned long long)v);
+    }
     if (threadIdx.x == 0) {
         counters[1] = s_sum[1];
         atomicAdd(&counters[2], s_sum[1]);
@@ -370,6 +450,7 @@ k_sum_work(const uint4* __restrict__ tile_work, int n_tiles, unsigned long long*
 #pragma unroll
         for (int k = 0; k < 6; ++k) host[k] = counters[k];
         host[6] = (unsigned long long)*n_visible;
+        host[7] = redo_count ? (unsigned long long)*redo_count : 0ull;
         __threadfence_system();
     }
 }

@@ -12,9 +12,6 @@
 #ifndef GSR_K1_THREADS
 #define GSR_K1_THREADS 256
 #endif
-#ifndef GSR_PRELOAD_COLOR
-#define GSR_PRELOAD_COLOR 0   // 1 = fetch the colour chunks before the visibility test (measured slower: K1 is HBM-bound)
-#endif
 
 // ---------------------------------------------------------------------------
 // K0: raw registerUpdate()-layout arrays (already in device memory) -> SoA of
@@ -24,7 +21,7 @@ k_repack(uint32_t n, uint32_t dst0, uint32_t cap, int has_sh,
          const float* __restrict__ P, const uint16_t* __restrict__ Cd, const float* __restrict__ alpha,
          const uint16_t* __restrict__ scale, const uint16_t* __restrict__ orient,
          const uint16_t* __restrict__ shx, const uint16_t* __restrict__ shy, const uint16_t* __restrict__ shz,
-         float4* __restrict__ geoA, uint4* __restrict__ geoB, uint4* __restrict__ col)
+         float4* __restrict__ geoA, uint4* __restrict__ geoB, uint4* __restrict__ col, uint4* __restrict__ colrow)
 {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -48,9 +45,17 @@ k_repack(uint32_t n, uint32_t dst0, uint32_t cap, int has_sh,
         for (int k = 3; k < 48; ++k) h[k] = 0;
     }
     const int nchunk = has_sh ? 6 : 1;
-    for (int c = 0; c < nchunk; ++c)
-        col[(size_t)c * cap + o] = make_uint4(pk(h[8 * c], h[8 * c + 1]), pk(h[8 * c + 2], h[8 * c + 3]),
-                                              pk(h[8 * c + 4], h[8 * c + 5]), pk(h[8 * c + 6], h[8 * c + 7]));
+    for (int c = 0; c < nchunk; ++c) {
+        const uint4 v = make_uint4(pk(h[8 * c], h[8 * c + 1]), pk(h[8 * c + 2], h[8 * c + 3]),
+                                   pk(h[8 * c + 4], h[8 * c + 5]), pk(h[8 * c + 6], h[8 * c + 7]));
+        col[(size_t)c * cap + o] = v;                  // SoA chunks: coalesced for a pass over ALL splats (eager colour)
+        if (has_sh) colrow[(size_t)o * 8 + 1 + c] = v; // and as ONE 128-byte row per splat, gathered by index (lazy colour):
+    }                                                  //   [0] = (P.xyz, opacity), [1..6] = the 48 colour halves, [7] = pad
+    if (has_sh) {
+        colrow[(size_t)o * 8] = make_uint4(__float_as_uint(P[3 * (size_t)i]), __float_as_uint(P[3 * (size_t)i + 1]),
+                                           __float_as_uint(P[3 * (size_t)i + 2]), __float_as_uint(alpha[i]));
+        colrow[(size_t)o * 8 + 7] = make_uint4(0, 0, 0, 0);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -179,6 +184,60 @@ __device__ __forceinline__ bool gsr_covariance_axes(const GsrFrame& f, const flo
     return __builtin_fabsf(lambda1) < 3.0e38f;   // false for inf and NaN
 }
 
+// Colour of one splat: Cd, plus SH evaluated towards the splat when the frame's order is > 0
+// (shaders/GSplatShaderSource.h:224,244-274).  cw = the splat's 48 colour halves (Cd.rgb, sh1.rgb ... sh15.rgb) as six
+// 16-byte words; (x, y, z) = the splat position after the GSplatOrigin round trip.  One function for the eager path
+// (K1), the lazy colour pass and the blend kernel's on-demand fallback: the three produce identical bits.
+#define GSR_COLOUR_PENDING 0x7fc0deadu   // bit pattern of a record's `r` while its colour has not been evaluated (a NaN no
+                                         // arithmetic produces: fp16->fp32 NaNs have zero low mantissa bits)
+__device__ __forceinline__ void gsr_splat_colour(const GsrFrame& f, const uint4* cw, float x, float y, float z,
+                                                 float& cr, float& cg, float& cbl)
+{
+    cr = gsr_h2f(cw[0].x & 0xffffu); cg = gsr_h2f(cw[0].x >> 16); cbl = gsr_h2f(cw[0].y & 0xffffu);
+    if (f.sh_order > 0) {
+        uint32_t w[24];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { w[4 * c] = cw[c].x; w[4 * c + 1] = cw[c].y; w[4 * c + 2] = cw[c].z; w[4 * c + 3] = cw[c].w; }
+        float shr[15], shg[15], shb[15];
+#pragma unroll
+        for (int j = 0; j < 15; ++j) {
+            const int h0 = 3 * (j + 1);
+            shr[j] = gsr_h2f((w[(h0) >> 1] >> (((h0) & 1) * 16)) & 0xffffu);
+            shg[j] = gsr_h2f((w[(h0 + 1) >> 1] >> (((h0 + 1) & 1) * 16)) & 0xffffu);
+            shb[j] = gsr_h2f((w[(h0 + 2) >> 1] >> (((h0 + 2) & 1) * 16)) & 0xffffu);
+        }
+        const float wx = x - f.cam[0], wy = y - f.cam[1], wz = z - f.cam[2];
+        const float ox = lin3(&f.io[0], wx, wy, wz);
+        const float oy = lin3(&f.io[3], wx, wy, wz);
+        const float oz = lin3(&f.io[6], wx, wy, wz);
+        const float len = __builtin_sqrtf(gsr_fma(oz, oz, gsr_fma(oy, oy, ox * ox)));
+        const float dx = ox / len, dy = oy / len, dz = oz / len;
+        cr = gsr_shade_sh(cr, shr, dx, dy, dz, f.sh_order);
+        cg = gsr_shade_sh(cg, shg, dx, dy, dz, f.sh_order);
+        cbl = gsr_shade_sh(cbl, shb, dx, dy, dz, f.sh_order);
+    }
+}
+
+// the splat's 128-byte row (position + 48 colour halves, two sectors) -> colour
+__device__ __forceinline__ void gsr_splat_colour_from_row(const GsrFrame& f, const uint4* __restrict__ colrow, uint32_t idx,
+                                                          float& cr, float& cg, float& cbl)
+{
+    const uint4* row = colrow + (size_t)idx * 8;
+    const uint4 g = row[0];
+    uint4 cw[6];
+    const int nchunk = f.sh_order == 0 ? 1 : (f.sh_order == 1 ? 2 : (f.sh_order == 2 ? 4 : 6));
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        cw[c] = make_uint4(0, 0, 0, 0);
+        if (c < nchunk) cw[c] = row[1 + c];
+    }
+    const float px = __uint_as_float(g.x), py = __uint_as_float(g.y), pz = __uint_as_float(g.z);
+    const float x = (px - f.origin[0]) + f.origin[0];
+    const float y = (py - f.origin[1]) + f.origin[1];
+    const float z = (pz - f.origin[2]) + f.origin[2];
+    gsr_splat_colour(f, cw, x, y, z, cr, cg, cbl);
+}
+
 // K1: one thread per splat.
 //   in : geoA, geoB, col (SoA, coalesced 16 B/lane)
 //   out: rec[i] (48 B), key[i] (f32 distance^2 bits), val[i] = (i, rect), rect[i] (packed tile rect or EMPTY)
@@ -186,26 +245,14 @@ __global__ void __launch_bounds__(GSR_K1_THREADS)
 k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col,
              GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint2* __restrict__ val,
-             float* __restrict__ zwin /* NULL unless the frame is depth-tested */)
+             float* __restrict__ zwin /* NULL unless the frame is depth-tested */, int lazy /* leave SH colours pending */)
 {
     const uint32_t i = blockIdx.x * (uint32_t)GSR_K1_THREADS + threadIdx.x;
     if (i < n) {
-        // geoA and geoB are fetched together; the colour chunks only once the splat is known to be needed
-        // (GSR_PRELOAD_COLOR=1 fetches them up front too -- one round trip instead of two, but the kernel is
-        // HBM-bound and the bytes wasted on culled splats make it slower: 0.293 vs 0.280 ms on C4).
+        // geoA and geoB are fetched together; colour only once the splat is known to be needed (fetching it up front
+        // was measured slower: the bytes wasted on culled splats cost more than the second round trip)
         const float4 a = geoA[i];
         const uint4 b = geoB[i];
-#if GSR_PRELOAD_COLOR
-        uint4 cchunk[6];
-        {
-            const int nchunk_pre = f.sh_order == 0 ? 1 : (f.sh_order == 1 ? 2 : (f.sh_order == 2 ? 4 : 6));
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                cchunk[c] = make_uint4(0, 0, 0, 0);
-                if (c < nchunk_pre) cchunk[c] = col[(size_t)c * cap + i];
-            }
-        }
-#endif
         const float px = a.x, py = a.y, pz = a.z, opacity = a.w;
 
         // sort key: un-offset P vs camera (src/GSplatRenderer.C:197-201).  distance^2 >= 0: its IEEE bits
@@ -276,44 +323,20 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
             if (out_rect != GSR_RECT_EMPTY && gsr_rect_tiles(out_rect, f.shard_index, f.shard_count) == 0)
                 out_rect = GSR_RECT_EMPTY;
             if (out_rect != GSR_RECT_EMPTY) {
-                // colour: Cd, optionally + SH (:224, :244-274)
-#if GSR_PRELOAD_COLOR
-                const uint4 c0 = cchunk[0];
-#else
-                const uint4 c0 = col[i];
-#endif
-                float cr = gsr_h2f(c0.x & 0xffffu), cg = gsr_h2f(c0.x >> 16), cbl = gsr_h2f(c0.y & 0xffffu);
-                if (f.sh_order > 0) {
-                    uint32_t w[24];
-                    w[0] = c0.x; w[1] = c0.y; w[2] = c0.z; w[3] = c0.w;
-                    const int nchunk = f.sh_order == 1 ? 2 : (f.sh_order == 2 ? 4 : 6);
+                // colour: Cd, optionally + SH (:224, :244-274) -- or left PENDING for the lazy colour pass (k_colour.h)
+                float cr, cg, cbl;
+                if (lazy) {
+                    cr = __builtin_bit_cast(float, GSR_COLOUR_PENDING); cg = 0.0f; cbl = 0.0f;
+                } else {
+                    uint4 cw[6];
+                    cw[0] = col[i];
+                    const int nchunk = f.sh_order == 0 ? 1 : (f.sh_order == 1 ? 2 : (f.sh_order == 2 ? 4 : 6));
 #pragma unroll
                     for (int c = 1; c < 6; ++c) {
-#if GSR_PRELOAD_COLOR
-                        const uint4 v = cchunk[c];
-#else
-                        uint4 v = make_uint4(0, 0, 0, 0);
-                        if (c < nchunk) v = col[(size_t)c * cap + i];
-#endif
-                        w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
+                        cw[c] = make_uint4(0, 0, 0, 0);
+                        if (c < nchunk) cw[c] = col[(size_t)c * cap + i];
                     }
-                    float shr[15], shg[15], shb[15];
-#pragma unroll
-                    for (int j = 0; j < 15; ++j) {
-                        const int h0 = 3 * (j + 1);
-                        shr[j] = gsr_h2f((w[(h0) >> 1] >> (((h0) & 1) * 16)) & 0xffffu);
-                        shg[j] = gsr_h2f((w[(h0 + 1) >> 1] >> (((h0 + 1) & 1) * 16)) & 0xffffu);
-                        shb[j] = gsr_h2f((w[(h0 + 2) >> 1] >> (((h0 + 2) & 1) * 16)) & 0xffffu);
-                    }
-                    const float wx = x - f.cam[0], wy = y - f.cam[1], wz = z - f.cam[2];
-                    const float ox = lin3(&f.io[0], wx, wy, wz);
-                    const float oy = lin3(&f.io[3], wx, wy, wz);
-                    const float oz = lin3(&f.io[6], wx, wy, wz);
-                    const float len = __builtin_sqrtf(gsr_fma(oz, oz, gsr_fma(oy, oy, ox * ox)));
-                    const float dx = ox / len, dy = oy / len, dz = oz / len;
-                    cr = gsr_shade_sh(cr, shr, dx, dy, dz, f.sh_order);
-                    cg = gsr_shade_sh(cg, shg, dx, dy, dz, f.sh_order);
-                    cbl = gsr_shade_sh(cbl, shb, dx, dy, dz, f.sh_order);
+                    gsr_splat_colour(f, cw, x, y, z, cr, cg, cbl);
                 }
                 // contract v2: the quad-local coordinate as two affine forms scaled by kappa = sqrt(log2 e)
                 const float k1 = (1.0f / s1) * GSR_KAPPA, k2 = (1.0f / s2) * GSR_KAPPA;

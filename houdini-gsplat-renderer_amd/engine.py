@@ -40,7 +40,7 @@ class gsr_stats(C.Structure):
                 ("super_tile", C.c_int32), ("stiles_x", C.c_int32), ("stiles_y", C.c_int32), ("reserved_", C.c_int32),
                 ("blend_wave_evals_total", C.c_int64), ("stage_ms_total", C.c_double * 5),
                 ("stage_frames", C.c_int64), ("sorts_skipped", C.c_int64), ("frames_requeued", C.c_int64),
-                ("frames_truncated", C.c_int64)]
+                ("lazy_redo_tiles", C.c_int64), ("lazy_colours_total", C.c_int64), ("frames_truncated", C.c_int64)]
 
     def as_dict(self) -> dict:
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -75,7 +75,7 @@ class gsplat_attrs(C.Structure):
 
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_COPY = 0, 1, 2
 MISSING_CD, MISSING_OPACITY, MISSING_SCALE, MISSING_ORIENT, MISSING_SH, BAD_SH_ORDER = 1, 2, 4, 8, 16, 32
-OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE, OPT_SUPER_TILE, OPT_DEBUG_FLAGS, OPT_FRAMES_IN_FLIGHT, OPT_DEFERRED_CHECK = 1, 2, 3, 4, 5, 6, 7
+OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE, OPT_SUPER_TILE, OPT_DEBUG_FLAGS, OPT_FRAMES_IN_FLIGHT, OPT_DEFERRED_CHECK, OPT_LAZY_COLOUR = 1, 2, 3, 4, 5, 6, 7, 8
 
 # every symbol include/gsplat_hip.h and include/GSplatRenderer.h declare
 C_ABI_SYMBOLS = [
@@ -365,6 +365,23 @@ class Engine:
 
     def stitch_bands(self, gathered_ptr: int, count: int, width: int, height: int, out_ptr: int):
         _check(self.L.gsr_stitch_bands(self.h, C.c_void_p(gathered_ptr), count, width, height, C.c_void_p(out_ptr)))
+
+    # ---- one process per GPU: the frame's gather inside the library (gsr_comm_*)
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(self.L.gsr_comm_get_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        _check(self.L.gsr_comm_init(self.h, C.c_char_p(unique_id), int(rank), int(world)))
+        self.shard = (rank, world)
+
+    def comm_render(self, cam_struct: gsr_camera, out_ptr: int, depth_ptr: int = 0):
+        _check(self.L.gsr_comm_render(self.h, C.byref(cam_struct), C.c_void_p(depth_ptr or None), 1, C.c_void_p(out_ptr or None)))
+
+    def comm_destroy(self):
+        _check(self.L.gsr_comm_destroy(self.h))
+        self.shard = (0, 1)
 
     def synchronize(self):
         _check(self.L.gsr_synchronize(self.h))

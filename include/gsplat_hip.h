@@ -87,6 +87,8 @@ typedef struct gsr_stats {
     int64_t stage_frames;
     int64_t sorts_skipped;                 /* frames that reused the cached depth order (GSR_OPT_SORT_CACHE) */
     int64_t frames_requeued;               /* frames whose back end ran twice: the pair count outgrew the list buffer */
+    int64_t lazy_redo_tiles;               /* lazy colour, last frame: tiles composited by the on-demand fallback */
+    int64_t lazy_colours_total;            /* lazy colour: SH evaluations by the ahead-of-time pass, running total */
     int64_t frames_truncated;              /* GSR_OPT_DEFERRED_CHECK only: frames handed over with clamped lists (must stay 0
                                               for exact pixels; the buffer is regrown for the following frames) */
 } gsr_stats;
@@ -225,13 +227,17 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        (preprocess, sorts, binning) overlaps frame f's blend kernel on the GPU.
                                        Per-frame results and their order on the context stream are unchanged. */
 #define GSR_OPT_DEBUG_FLAGS     5   /* A/B switches for profiling: 1 = no alpha-support shrink of the bboxes,
-                                       2 = bbox-only quadrant masks (no separating-axis test) */
+                                       2 = bbox-only quadrant masks (no separating-axis test), 4 = sort all 32 key bits,
+                                       8 = lazy colour without the ahead-of-time pass (every tile takes the fallback) */
 #define GSR_OPT_DEFERRED_CHECK   7   /* 0 (default) / 1: with a DEVICE target, gsr_render returns as soon as the frame is queued --
                                        no host wait at all -- and the frame's pair count is looked at by the next call that
                                        touches the context.  The back end always runs against the list buffer sized from
                                        earlier frames (+25 % headroom); a frame whose pair count outgrows it is composited
                                        from clamped lists and counted in gsr_stats.frames_truncated (the buffer is regrown
                                        for the next frame).  The first frame after a buffer-less start is never deferred. */
+#define GSR_OPT_LAZY_COLOUR      8   /* 1 (default) / 0: evaluate SH colours only for the splats a frame can composite (the front of
+                                       every super-tile list, as deep as the previous frame scanned, with an on-demand fallback)
+                                       instead of for every visible splat.  Same pixels, bit for bit. */
 int  gsr_set_option(gsr_context* ctx, int option, int value);
 
 /* ---- debug / test access (device -> host copies of intermediates) -------- */

@@ -591,10 +591,22 @@ int gso_render_depth(const gso_splats* s, const gso_frame* f, const float* depth
 
 #define GSO_STRIP 8 /* rows per strip for the parallel renderer */
 
+static int blend_parallel_rows(const gso_record* rec, const int32_t* perm, int64_t n, int width, int height,
+                               int row_lo, int row_hi, float* rgba, int threads);
+
 int gso_blend_parallel(const gso_record* rec, const int32_t* perm, int64_t n, int width, int height,
                        float* rgba, int threads)
 {
+    return blend_parallel_rows(rec, perm, n, width, height, 0, height - 1, rgba, threads);
+}
+
+/* rows [row_lo, row_hi] of the frame only (the rest of rgba is left cleared): full-size scenes in affordable pieces */
+static int blend_parallel_rows(const gso_record* rec, const int32_t* perm, int64_t n, int width, int height,
+                               int row_lo, int row_hi, float* rgba, int threads)
+{
     if (!rec || !perm || !rgba || width <= 0 || height <= 0) return -1;
+    if (row_lo < 0) row_lo = 0;
+    if (row_hi > height - 1) row_hi = height - 1;
     begin_frame(rgba, width, height);
     const int nstrips = (height + GSO_STRIP - 1) / GSO_STRIP;
     /* bin splat ranks to strips, in rank order (two passes) */
@@ -634,14 +646,31 @@ int gso_blend_parallel(const gso_record* rec, const int32_t* perm, int64_t n, in
 #endif
 #pragma omp parallel for schedule(dynamic, 1)
     for (int s = 0; s < nstrips; ++s) {
-        const int row_lo = s * GSO_STRIP;
-        const int row_hi = (row_lo + GSO_STRIP - 1 < height - 1) ? row_lo + GSO_STRIP - 1 : height - 1;
+        int lo = s * GSO_STRIP;
+        int hi = (lo + GSO_STRIP - 1 < height - 1) ? lo + GSO_STRIP - 1 : height - 1;
+        if (lo < row_lo) lo = row_lo;
+        if (hi > row_hi) hi = row_hi;
+        if (hi < lo) continue;
         for (int64_t k = start[s]; k < start[s + 1]; ++k)
-            splat_rows(&rec[list[k]], width, height, row_lo, row_hi, rgba);
+            splat_rows(&rec[list[k]], width, height, lo, hi, rgba);
     }
     finish_frame(rgba, width, height);
     free(start); free(slo); free(shi); free(list); free(cur);
     return 0;
+}
+
+int gso_render_rows(const gso_splats* s, const gso_frame* f, int row_lo, int row_hi, float* rgba, int threads)
+{
+    if (!s || !f || !rgba) return -1;
+    gso_record* rec = (gso_record*)malloc((size_t)(s->n + 1) * sizeof(gso_record));
+    int32_t* perm = (int32_t*)malloc((size_t)(s->n + 1) * 4);
+    if (!rec || !perm) { free(rec); free(perm); return -2; }
+    int rc = gso_preprocess(s, f, rec);
+    if (!rc) rc = gso_argsort(rec, s->n, perm);
+    if (!rc) rc = blend_parallel_rows(rec, perm, s->n, f->width, f->height, row_lo, row_hi, rgba, threads);
+    free(rec);
+    free(perm);
+    return rc;
 }
 
 int gso_render(const gso_splats* s, const gso_frame* f, float* rgba, int threads)

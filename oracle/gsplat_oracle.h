@@ -135,6 +135,9 @@ int gso_render_wire(const gso_splats* s, const gso_frame* f, float* rgba);
 /* whole frame: preprocess + argsort + blend.  threads<=1 -> serial blend. */
 int gso_render(const gso_splats* s, const gso_frame* f, float* rgba, int threads);
 
+/* the same frame, rows [row_lo, row_hi] only (other rows stay 0): full-size configs checked in pieces */
+int gso_render_rows(const gso_splats* s, const gso_frame* f, int row_lo, int row_hi, float* rgba, int threads);
+
 /* only the reference's per-camera-move HOST work: distances + argsort
  * (src/GSplatRenderer.C:188-208).  perm[n] out. */
 int gso_host_sort_only(const float* P, int64_t n, const float cam_pos[3], int32_t* perm);

@@ -91,6 +91,7 @@ def lib() -> C.CDLL:
         L.gso_blend_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.gso_render.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p, C.c_int]
         L.gso_render_depth.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p, C.c_void_p]
+        L.gso_render_rows.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.gso_render_wire.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p]
         L.gso_host_sort_only.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p]
         L.gso_max_threads.restype = C.c_int
@@ -185,6 +186,17 @@ def render(splats, cam, origin=(0, 0, 0), threads=1) -> np.ndarray:
     rc = lib().gso_render(C.byref(pk.struct), C.byref(f), out.ctypes.data, threads)
     assert rc == 0
     return out
+
+
+def render_rows(splats, cam, row_lo: int, row_hi: int, origin=(0, 0, 0), threads: int = 0) -> np.ndarray:
+    """rows [row_lo, row_hi) of the frame as an array [row_hi - row_lo, W, 4] (bit-identical to those rows of render())"""
+    pk = _SplatPack(splats)
+    f = make_frame(cam, origin)
+    out = np.zeros((f.height, f.width, 4), dtype=np.float32)
+    rc = lib().gso_render_rows(C.byref(pk.struct), C.byref(f), int(row_lo), int(row_hi) - 1, out.ctypes.data,
+                               int(threads) if threads else max_threads())
+    assert rc == 0
+    return np.ascontiguousarray(out[row_lo:row_hi])
 
 
 def render_depth(splats, cam, depth, origin=(0, 0, 0)) -> np.ndarray:

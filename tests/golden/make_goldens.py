@@ -244,7 +244,7 @@ def h2f(bits: np.ndarray) -> np.ndarray:
     return bits.view(np.float16).astype(np.float32)
 
 
-def render_reference_glsl(es: GLES, splats, cam, origin, perm, ss: int = 1):
+def render_reference_glsl(es: GLES, splats, cam, origin, perm, ss: int = 1, depth=None, window=None, capture=True):
     """One frame of the reference's main program on SwiftShader.
 
     ss (odd): the viewport/FBO is ss x larger than glH_ScreenSize while the uniform keeps the
@@ -253,13 +253,26 @@ def render_reference_glsl(es: GLES, splats, cam, origin, perm, ss: int = 1):
     fragment a nominal-resolution rasteriser would shade -- but SwiftShader's 4-bit sub-pixel
     vertex snapping (1/16 px) shrinks to 1/(16*ss) nominal px, i.e. ss=15 emulates the 8-bit
     sub-pixel precision of hardware rasterisers.
-    Returns (image float32 [H,W,4] row 0 = bottom, vertex-stage capture float32 [n,6,12]:
-    gl_Position xyzw, v_pos xyzw, v_color rgb, v_opacity -- in INSTANCE (sorted) order)."""
+    depth: float32 [H,W] window depth (0..1) left by an opaque pass -> attached as the FBO's depth buffer, depth test
+    ON, depth writes OFF (src/GSplatRenderer.C:595-610; the function is whatever the viewport had -- GL_LEQUAL).
+    window = (x0, y0, w, h): only that window of the nominal frame is rasterised (the viewport is shifted so that the
+    window lands in an FBO of its own size; every shader input is unchanged) -- full-size configs in affordable pieces.
+    capture = False skips the transform-feedback capture (large scenes).
+    Returns (image float32 [h,w,4] row 0 = bottom, vertex-stage capture float32 [n,6,12]:
+    gl_Position xyzw, v_pos xyzw, v_color rgb, v_opacity -- in INSTANCE (sorted) order, or None)."""
     assert ss % 2 == 1
     gl = es.gl
     n = splats.n
     # (the reference skips the index upload when N is exactly 4^k -- SURVEY Q2; this harness always uploads)
     vs, fs = reference_shaders()
+    if window is not None:
+        # HARNESS edit (window rendering only): the viewport transform of a sub-window, applied to the finished clip
+        # position -- x' = (x - cx*w) * W/ww is what a viewport of the full frame's size placed at -x0 would do, without
+        # needing a viewport larger than the rasteriser's limit.  Nothing the reference computes is touched.
+        marker = "gl_Position = out_vertex;"
+        assert vs.count(marker) == 1
+        vs = vs.replace(marker, marker + "\n gl_Position.xy = gl_Position.xy * harness_win.xy + harness_win.zw * gl_Position.w;")
+        vs = vs.replace(ES3_HEADER, ES3_HEADER + "uniform vec4 harness_win;\n", 1)
     prog = es.program(vs, fs, tf_varyings=["gl_Position", "v_pos", "v_color", "v_opacity"])
     gl.glUseProgram(prog)
     origin = np.asarray(origin, np.float32)
@@ -328,22 +341,46 @@ def render_reference_glsl(es: GLES, splats, cam, origin, perm, ss: int = 1):
     es.check("uniforms")
 
     # ---- float render target cleared to transparent black
+    wx0, wy0, ww, wh = window if window is not None else (0, 0, cam.width, cam.height)
     fb_tex = C.c_uint()
     gl.glGenTextures(1, C.byref(fb_tex))
     gl.glActiveTexture(GL_TEXTURE0 + 7)
     gl.glBindTexture(GL_TEXTURE_2D, fb_tex)
-    gl.glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA32F, cam.width * ss, cam.height * ss, 0, GL_RGBA, GL_FLOAT, None)
+    gl.glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA32F, ww * ss, wh * ss, 0, GL_RGBA, GL_FLOAT, None)
     fbo = C.c_uint()
     gl.glGenFramebuffers(1, C.byref(fbo))
     gl.glBindFramebuffer(GL_FRAMEBUFFER, fbo)
     gl.glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, fb_tex, 0)
+    dtex = C.c_uint()
+    if depth is not None:
+        # the opaque pass's depth buffer: every nominal pixel replicated ss x ss
+        d = np.ascontiguousarray(np.asarray(depth, np.float32)[wy0:wy0 + wh, wx0:wx0 + ww].repeat(ss, axis=0).repeat(ss, axis=1))
+        gl.glGenTextures(1, C.byref(dtex))
+        gl.glActiveTexture(GL_TEXTURE0 + 6)
+        gl.glBindTexture(GL_TEXTURE_2D, dtex)
+        gl.glPixelStorei(GL_UNPACK_ALIGNMENT, 1)
+        gl.glTexImage2D(GL_TEXTURE_2D, 0, 0x8CAC, ww * ss, wh * ss, 0, 0x1902, GL_FLOAT, C.c_void_p(d.ctypes.data))  # DEPTH_COMPONENT32F
+        for pn, v in ((GL_TEXTURE_MIN_FILTER, GL_NEAREST), (GL_TEXTURE_MAG_FILTER, GL_NEAREST)):
+            gl.glTexParameteri(GL_TEXTURE_2D, pn, v)
+        gl.glFramebufferTexture2D(GL_FRAMEBUFFER, 0x8D00, GL_TEXTURE_2D, dtex, 0)                                     # DEPTH_ATTACHMENT
+        es.check("depth attachment")
     assert gl.glCheckFramebufferStatus(GL_FRAMEBUFFER) == GL_FRAMEBUFFER_COMPLETE, "RGBA32F FBO incomplete"
-    gl.glViewport(0, 0, cam.width * ss, cam.height * ss)
+    gl.glViewport(0, 0, ww * ss, wh * ss)
+    if window is not None:
+        sx, sy = cam.width / ww, cam.height / wh
+        cx, cy = (2.0 * wx0 + ww) / cam.width - 1.0, (2.0 * wy0 + wh) / cam.height - 1.0
+        gl.glUniform4f.argtypes = [C.c_int] + [C.c_float] * 4
+        gl.glUniform4f(gl.glGetUniformLocation(prog, b"harness_win"), sx, sy, -cx * sx, -cy * sy)
     gl.glClearColor(0.0, 0.0, 0.0, 0.0)
     gl.glClear(GL_COLOR_BUFFER_BIT)
 
-    # ---- GL state (:605-621): no depth attachment (nothing opaque in front), no culling
-    gl.glDisable(GL_DEPTH_TEST)
+    # ---- GL state (:605-621): depth test against the opaque pass (if any), depth writes off, no culling
+    if depth is not None:
+        gl.glEnable(GL_DEPTH_TEST)
+        gl.glDepthFunc(0x0203)        # GL_LEQUAL
+        gl.glDepthMask(0)
+    else:
+        gl.glDisable(GL_DEPTH_TEST)
     gl.glDisable(GL_CULL_FACE)
     gl.glEnable(GL_BLEND)
     gl.glBlendFuncSeparate(GL_ONE_MINUS_DST_ALPHA, GL_ONE, GL_ONE_MINUS_DST_ALPHA, GL_ONE)
@@ -352,31 +389,42 @@ def render_reference_glsl(es: GLES, splats, cam, origin, perm, ss: int = 1):
     gl.glGenVertexArrays(1, C.byref(vao))
     gl.glBindVertexArray(vao)
     # vertex-stage capture (transform feedback), 12 floats per vertex
-    tfb = C.c_uint()
-    gl.glGenBuffers(1, C.byref(tfb))
-    GL_TFB = 0x8C8E
-    gl.glBindBuffer(GL_TFB, tfb)
-    nbytes = n * 6 * 12 * 4
-    gl.glBufferData(GL_TFB, C.c_ssize_t(nbytes), None, 0x88E9)  # GL_DYNAMIC_READ
-    gl.glBindBufferBase(GL_TFB, 0, tfb)
-    gl.glBeginTransformFeedback(GL_TRIANGLES)
+    vs_out = None
+    if capture:
+        tfb = C.c_uint()
+        gl.glGenBuffers(1, C.byref(tfb))
+        GL_TFB = 0x8C8E
+        gl.glBindBuffer(GL_TFB, tfb)
+        nbytes = n * 6 * 12 * 4
+        gl.glBufferData(GL_TFB, C.c_ssize_t(nbytes), None, 0x88E9)  # GL_DYNAMIC_READ
+        gl.glBindBufferBase(GL_TFB, 0, tfb)
+        gl.glBeginTransformFeedback(GL_TRIANGLES)
     gl.glDrawArraysInstanced(GL_TRIANGLES, 0, 6, n)  # drawInstanced(..., splatCount) :647
-    gl.glEndTransformFeedback()
+    if capture:
+        gl.glEndTransformFeedback()
     gl.glFinish()
     es.check("draw")
-    gl.glMapBufferRange.restype = C.c_void_p
-    gl.glMapBufferRange.argtypes = [C.c_uint, C.c_ssize_t, C.c_ssize_t, C.c_uint]
-    ptr = gl.glMapBufferRange(GL_TFB, 0, nbytes, 0x0001)  # GL_MAP_READ_BIT
-    assert ptr, "transform feedback buffer map failed"
-    vs_out = np.frombuffer((C.c_float * (n * 72)).from_address(ptr), dtype=np.float32).reshape(n, 6, 12).copy()
-    gl.glUnmapBuffer(GL_TFB)
-    hi = np.zeros((cam.height * ss, cam.width * ss, 4), np.float32)
+    if capture:
+        gl.glMapBufferRange.restype = C.c_void_p
+        gl.glMapBufferRange.argtypes = [C.c_uint, C.c_ssize_t, C.c_ssize_t, C.c_uint]
+        ptr = gl.glMapBufferRange(GL_TFB, 0, nbytes, 0x0001)  # GL_MAP_READ_BIT
+        assert ptr, "transform feedback buffer map failed"
+        vs_out = np.frombuffer((C.c_float * (n * 72)).from_address(ptr), dtype=np.float32).reshape(n, 6, 12).copy()
+        gl.glUnmapBuffer(GL_TFB)
+        gl.glDeleteBuffers(1, C.byref(tfb))
+    hi = np.zeros((wh * ss, ww * ss, 4), np.float32)
     gl.glPixelStorei(GL_PACK_ALIGNMENT, 1)
-    gl.glReadPixels(0, 0, cam.width * ss, cam.height * ss, GL_RGBA, GL_FLOAT, C.c_void_p(hi.ctypes.data))
+    gl.glReadPixels(0, 0, ww * ss, wh * ss, GL_RGBA, GL_FLOAT, C.c_void_p(hi.ctypes.data))
     es.check("readpixels")
     gl.glBindFramebuffer(GL_FRAMEBUFFER, 0)
+    if depth is not None:
+        gl.glDepthMask(1)
+        gl.glDisable(GL_DEPTH_TEST)
+        gl.glDeleteTextures(1, C.byref(dtex))
+    gl.glDeleteFramebuffers(1, C.byref(fbo))
+    gl.glDeleteTextures(1, C.byref(fb_tex))
     out = np.ascontiguousarray(hi[ss // 2::ss, ss // 2::ss])
-    assert out.shape == (cam.height, cam.width, 4)
+    assert out.shape == (wh, ww, 4)
     return out, vs_out
 
 
@@ -496,6 +544,73 @@ def cases(pkg):
     return out
 
 
+def make_depth_golden(es, pkg, oracle, name="g8_depth_tested"):
+    sc, cm = pkg.scenes, pkg.camera
+    splats = sc.make_scene(3000, seed=18, sh=True, log_scale_range=(-4.2, -2.8))
+    cam = cm.make_camera(256, 192, sh_order=2, frame=6)
+    origin = (0.0, 0.0, 0.0)
+    rec = oracle.preprocess(splats, cam, origin)
+    perm = oracle.argsort(rec)
+    z = np.sort(rec["zwin"][rec["visible"] == 1])
+    def gap_mid(lo, hi):   # the middle of the widest gap between consecutive splat depths in z[lo:hi]: far from any tie
+        k = lo + int(np.argmax(np.diff(z[lo:hi])))
+        return float(0.5 * (z[k] + z[k + 1]))
+    zmid = gap_mid(len(z) * 45 // 100, len(z) * 55 // 100)
+    yy, xx = np.mgrid[0:cam.height, 0:cam.width]
+    depth = np.full((cam.height, cam.width), 1.0, np.float32)
+    depth[(xx // 32 + yy // 32) % 2 == 0] = zmid                       # a checkerboard "wall" through the middle of the cloud
+    depth[:12] = 0.0                                                   # a strip where everything is hidden
+    zq = gap_mid(len(z) * 20 // 100, len(z) * 30 // 100)
+    depth[100:140, 60:200] = zq                                        # a nearer panel
+    ss = 9
+    img_gl, vs_sorted = render_reference_glsl(es, splats, cam, origin, perm, ss, depth=depth)
+    vs_out = np.empty_like(vs_sorted)
+    vs_out[perm] = vs_sorted
+    img_or = oracle.render_depth(splats, cam, depth, origin)
+    err = np.abs(img_gl - img_or)
+    stats = dict(name=name, n=splats.n, size=(cam.width, cam.height), ss=ss, max_err=float(err.max()), mean_err=float(err.mean()),
+                 frac_pixels_within_1e3=float((err.max(axis=2) <= 1e-3).mean()),
+                 differs_from_untested=float(np.abs(img_gl - oracle.render(splats, cam, origin)).max()))
+    print(stats)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), P=splats.P, Cd=splats.Cd, alpha=splats.alpha, scale=splats.scale,
+                        orient=splats.orient, shx=splats.shx, shy=splats.shy, shz=splats.shz,
+                        origin=np.asarray(origin, np.float32), image_reference_glsl=img_gl, supersample=np.int32(ss), vs_out=vs_out,
+                        depth=depth, oracle_sha256=np.frombuffer(hashlib.sha256(img_or.tobytes()).digest(), dtype=np.uint8),
+                        cam_obj_view=cam.obj_view, cam_object=cam.object, cam_inv_object=cam.inv_object, cam_view=cam.view,
+                        cam_proj=cam.proj, cam_pos=cam.cam_pos, cam_whs=np.int32([cam.width, cam.height, cam.sh_order]))
+    return stats
+
+
+def make_c4_band_golden(es, pkg, oracle, name="c4_band_1080p", rows=(520, 584), ss=9, n_override=None):
+    """BASELINE C4 (6M splats, SH 3, 1920x1080) through the reference GLSL: a full-width band of tile rows, rasterised
+    in column blocks (SwiftShader's texture limit) with the viewport shifted, vertex snapping refined by ss."""
+    import time
+    sc, cm = pkg.scenes, pkg.camera
+    splats, cfg = sc.make_config("C4", n_override)
+    cam = cm.make_camera(cfg["width"], cfg["height"], sh_order=3, frame=0)
+    origin = (0.0, 0.0, 0.0)
+    rec = oracle.preprocess(splats, cam, origin)
+    perm = oracle.argsort(rec)
+    y0, y1 = rows
+    band = np.zeros((y1 - y0, cam.width, 4), np.float32)
+    block = 8192 // ss // 16 * 16
+    for x0 in range(0, cam.width, block):
+        w = min(block, cam.width - x0)
+        t0 = time.time()
+        img, _ = render_reference_glsl(es, splats, cam, origin, perm, ss, window=(x0, y0, w, y1 - y0), capture=False)
+        band[:, x0:x0 + w] = img
+        print("   columns", x0, x0 + w, "%.0f s" % (time.time() - t0), flush=True)
+    img_or = oracle.render(splats, cam, origin, threads=oracle.max_threads())[y0:y1]
+    err = np.abs(band - img_or)
+    stats = dict(name=name, n=splats.n, size=(cam.width, cam.height), rows=rows, ss=ss, max_err=float(err.max()),
+                 mean_err=float(err.mean()), frac_pixels_within_1e3=float((err.max(axis=2) <= 1e-3).mean()))
+    print(stats)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), config="C4", n=np.int64(splats.n), rows=np.int32(rows), frame=np.int32(0),
+                        band_reference_glsl=band, supersample=np.int32(ss),
+                        oracle_band_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(img_or).tobytes()).digest(), dtype=np.uint8))
+    return stats
+
+
 def refresh_oracle_sha():
     """The arithmetic contract changed (oracle + kernels together): keep the reference-GLSL images and captures,
     re-check the new oracle against them with the acceptance rule of tests/helpers.py, re-pin its checksum."""
@@ -505,7 +620,7 @@ def refresh_oracle_sha():
     for name in helpers.golden_names():
         path = os.path.join(HERE, name + ".npz")
         d, s, c = helpers.load_golden(name)
-        img = oracle.render(s, c, d["origin"])
+        img = helpers.oracle_render_golden(oracle, d, s, c)
         print(name, helpers.check_against_golden(img, d["image_reference_glsl"]))
         arrays = {k: d[k] for k in d.files}
         arrays["oracle_sha256"] = np.frombuffer(hashlib.sha256(img.tobytes()).digest(), dtype=np.uint8)
@@ -553,6 +668,14 @@ def main():
         if splats.has_sh:
             arrays.update(shx=splats.shx, shy=splats.shy, shz=splats.shz)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    # ---- G8: depth-tested against what an opaque pass left -- depth test on (LEQUAL), depth writes off,
+    #      ONE depth per quad (all corners carry the centre's z and w, shaders/GSplatShaderSource.h:277-279)
+    if not only or "g8_depth_tested" in only:
+        summary.append(make_depth_golden(es, pkg, oracle))
+    # ---- C4 at full resolution: a band of the 1920x1080 frame of the 6M-splat BASELINE scene (inputs are the seeded
+    #      generator's, not stored)
+    if "c4_band_1080p" in only:
+        summary.append(make_c4_band_golden(es, pkg, oracle))
     if only and "w1_wire" not in only:
         return summary
     # ---- wireframe overlay: the reference's wire program as a LOOSE golden -- GL's diamond-exit

@@ -9,9 +9,21 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_names():
-    """beauty-path fixtures (the wireframe fixture w1_wire is handled by its own tests)"""
+    """beauty-path fixtures holding their own inputs (the wireframe fixture w1_wire and the full-size band c4_band_* are
+    handled by their own tests)"""
     return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-                  if not n.startswith("w"))
+                  if not n.startswith("w") and not n.startswith("c4_band"))
+
+
+def oracle_render_golden(oracle, d, s, c, threads=0):
+    """the oracle's frame for a fixture: depth-tested when the fixture carries an opaque pass's depth buffer (N4)"""
+    if "depth" in d.files:
+        return oracle.render_depth(s, c, d["depth"], d["origin"])
+    return oracle.render(s, c, d["origin"], threads=threads) if threads else oracle.render(s, c, d["origin"])
+
+
+def engine_render_golden(engine, d, c):
+    return engine.render_depth(c, d["depth"]) if "depth" in d.files else engine.render(c)
 
 
 def load_golden(name):

@@ -58,9 +58,10 @@ def parse_args():
     ap.add_argument("--no-swizzle", action="store_true", help="disable the XCD-aware tile mapping (A/B)")
     ap.add_argument("--super-tile", type=int, default=0, help="super-tile edge in tiles (0 = auto) (A/B)")
     ap.add_argument("--flags", type=int, default=0, help="GSR_OPT_DEBUG_FLAGS (A/B)")
-    ap.add_argument("--stage-timing", type=int, default=2, choices=(1, 2),
-                    help="HIP events per frame: 2 = every stage (default, feeds stages_ms_last_frame), "
-                         "1 = only around the blend kernel (what the roofline needs)")
+    ap.add_argument("--stage-timing", type=int, default=1, choices=(1, 2),
+                    help="HIP events per frame in the TIMED region: 1 (default) = only around the blend kernel (what the roofline "
+                         "needs; every event costs the GPU ~6 us of idle queue), 2 = around every stage.  The per-stage "
+                         "breakdown is always taken from a short extra leg with level 2 after the timed region")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="timed region: 1 (default) = strictly serial frames, what an interactive viewport does and "
                          "what gives clean per-kernel durations for the roofline; 2 = frame f+1's front end overlaps "
@@ -268,6 +269,17 @@ def main():
                 raise SystemExit("sharded frame differs from the unsharded frame")
         dist.barrier()
     st = eng.stats()
+    # extra leg (untimed, informational): a few more frames with HIP events around EVERY stage -> per-stage breakdown and the
+    # k_preprocess / k_colour_prefix durations.  Kept out of the timed region: six extra events per frame stall the queue ~35 us.
+    eng.set_option(pkg.engine.OPT_STAGE_TIMING, 2)
+    eng.stats_reset()
+    for i in range(min(10, args.warmup + args.steps)):
+        step(i)
+    torch.cuda.synchronize()
+    st_stage = eng.stats()
+    eng.set_option(pkg.engine.OPT_STAGE_TIMING, args.stage_timing)
+    if world > 1:
+        dist.barrier()
     # extra leg (informational): the same K steps with two frames in flight
     pipelined = None
     if args.pipelined and args.frames_in_flight == 1:
@@ -352,15 +364,19 @@ def main():
                         "flop_per_pixel_eval": FLOP_PER_EVAL, "inner_loop_iteration_ns": iter_ns,
                         "inner_loop_issue_bound_ms": issue_ms, "inner_loop_issue_frac": issue_ms / blend_ms if blend_ms > 0 else 0.0,
                         "note": "issue bound = inner-loop instruction mix x issue intervals measured with tools/ubench_valu.hip"}
-    stages = {k: st[k] for k in ("ms_preprocess", "ms_depth_sort", "ms_emit", "ms_tile_sort", "ms_blend", "ms_total")}
+    stages = {k: st_stage[k] for k in ("ms_preprocess", "ms_depth_sort", "ms_emit", "ms_tile_sort", "ms_blend", "ms_total")}
+    stages["note"] = ("one frame of the extra leg with events around every stage: ms_emit = binning count+scans, ms_tile_sort = "
+                      "binning placement + lazy colour pass")
     # the memory-bound kernel next to it: k_preprocess (stage 0 of the frame is exactly this one kernel).  Algorithmic bytes
     # per splat at SH order 3: visible 32 (geometry) + 96 (colour) read, 48 (record) + 12 (key, payload) written; culled or
     # not owned 32 read + 12 written
     roofline_k1 = None
-    if st["stage_frames"] > 0 and world == 1:
-        k1_ms = st["stage_ms_total"][0] / st["stage_frames"]
-        nvis = st["n_visible"]
-        col_b = {0: 16, 1: 32, 2: 64, 3: 96}[order if splats.shx is not None else 0]
+    if st_stage["stage_frames"] > 0 and world == 1:
+        k1_ms = st_stage["stage_ms_total"][0] / st_stage["stage_frames"]
+        nvis = st_stage["n_visible"]
+        lazy_on = bool(args.lazy) and order > 0 and splats.shx is not None
+        # eager: the colour halves are read for every visible splat; lazy: K1 reads geometry only (colours: k_colour_prefix)
+        col_b = 0 if lazy_on else {0: 16, 1: 32, 2: 64, 3: 96}[order if splats.shx is not None else 0]
         k1_bytes = nvis * (32 + col_b + 48 + 12) + (splats.n - nvis) * (32 + 12)
         k1_traffic = None
         try:
@@ -370,7 +386,8 @@ def main():
         k1_gbps = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         roofline_k1 = {"bound": "hbm", "kernel": "k_preprocess", "achieved": k1_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                        "frac": k1_gbps / HBM_PEAK_GBPS, "traffic": k1_traffic, "avg_launch_ms": k1_ms,
-                       "algorithmic_bytes_per_launch": k1_bytes}
+                       "algorithmic_bytes_per_launch": k1_bytes,
+                       "note": "lazy colour: geometry only (32 B in, 48 + 12 B out per visible splat)" if lazy_on else "eager colour"}
 
     if rank == 0:
         line = {
@@ -396,6 +413,7 @@ def main():
             "stages_ms_last_frame": stages,
             "n_visible": st["n_visible"],
             "lazy_colour": {"enabled": bool(args.lazy), "colours_evaluated_per_frame": st["lazy_colours_total"] / max(1, st["frames"]),
+                            "visible_splats": st["n_visible"],
                             "fallback_tiles_last_frame": st["lazy_redo_tiles"]},
         }
         if pipelined is not None:

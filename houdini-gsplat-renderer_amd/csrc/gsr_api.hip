@@ -83,13 +83,17 @@ struct FrameJob {
     bool speculative = false;      // the back end was queued before the pair count was known
     bool deferred = false;         // ... and the frame handed over without waiting for it (GSR_OPT_DEFERRED_CHECK)
     bool lazy = false;             // K1 left the SH colours pending (k_colour.h)
+    bool direct = false;           // the frame runs on the public stream itself
+    uint32_t ticket = 0;           // stamps the frame's pair count in the host mailbox
 };
 
 // Everything one frame in flight owns: its HIP stream, the per-frame HBM arrays, the small
 // mailboxes and the stage events.  Two slots alternate, so that frame f+1's memory-bound front end
 // (k_preprocess, depth sort, binning) overlaps frame f's VALU-bound k_blend on the GPU.
 struct FrameSlot {
-    hipStream_t stream = nullptr;
+    hipStream_t own = nullptr;         // the slot's private stream
+    hipStream_t stream = nullptr;      // the stream its frame runs on: `own` with two frames in flight; with strictly serial
+                                       // frames the context's PUBLIC stream itself (no hand-over events at all)
     hipEvent_t ev_done = nullptr;      // end of the frame on `stream`
     hipEvent_t ev_user = nullptr;      // caller's stream position at gsr_render entry
     hipEvent_t ev_pairs = nullptr;     // the frame's pair count has reached host memory
@@ -120,10 +124,11 @@ struct FrameSlot {
     // small device/host mailboxes
     unsigned long long* counters = nullptr;  // k_sum_work's layout: [1]/[2] records gathered (frame/running), [3]/[4] list entries
                                              // scanned, [5] wave-record evaluations (running)
-    uint32_t* h_total = nullptr;             // pinned + mapped: k_bin_ranges writes the pair count here
-    uint32_t* h_total_dev = nullptr;         // its device-side address
-    unsigned long long* h_counters = nullptr;  // pinned + mapped: k_sum_work writes the frame's bookkeeping here
-    unsigned long long* h_counters_dev = nullptr;
+    unsigned long long* h_total = nullptr;      // pinned + mapped + coherent: k_bin_ranges writes (frame ticket << 32 | pair count)
+    unsigned long long* h_total_dev = nullptr;  // its device-side address
+    uint32_t ticket = 0;                        // ticket of the frame queued last in this slot
+    unsigned long long* h_counters = nullptr;  // host copy of the frame's bookkeeping (fetched from d_frame when stats are asked for)
+    unsigned long long* d_frame = nullptr;     // device: k_sum_work's per-frame summary [8]
     // depth-sort cache: the frame description whose order is in (keyA, valA)
     bool sort_valid = false;
     SortKey sort_key{};
@@ -225,14 +230,15 @@ static int sync_all(gsr_context* c)
     int frc = finish_open_frames(c);   // deferred frames: look at their pair counts now
     if (frc) return frc;
     for (int k = 0; k < GSR_MAX_SLOTS; ++k)
-        if (c->slot[k].stream) HIP_TRY(hipStreamSynchronize(c->slot[k].stream));
+        if (c->slot[k].own) HIP_TRY(hipStreamSynchronize(c->slot[k].own));
     if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
     return GSR_OK;
 }
 
 static bool slot_init(FrameSlot& sl)
 {
-    bool ok = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&sl.own, hipStreamNonBlocking) == hipSuccess;
+    sl.stream = sl.own;
     ok = ok && hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&sl.ev_user, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&sl.ev_pairs, hipEventDisableTiming) == hipSuccess;
@@ -244,11 +250,13 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMemset(sl.lazy_ctr, 0, 2 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.colour_evals), 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.colour_evals, 0, 256 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    if (ok) *sl.h_total = 0ull;
     ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_total_dev), sl.h_total, 0) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess;
-    ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_counters_dev), sl.h_counters, 0) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), 8 * sizeof(unsigned long long), 0) == hipSuccess;
     if (ok) for (int j = 0; j < 8; ++j) sl.h_counters[j] = 0;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_frame), 8 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMemset(sl.d_frame, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMemset(sl.counters, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
     if (ok) {
         for (int k = 0; k < GSR_STAGE_EVENTS; ++k) sl.ev[k] = nullptr;
@@ -275,13 +283,14 @@ static void slot_destroy(FrameSlot& sl)
     dev_free(sl.counters); dev_free(sl.d_n);
     if (sl.h_total) (void)hipHostFree(sl.h_total);
     if (sl.h_counters) (void)hipHostFree(sl.h_counters);
+    dev_free(sl.d_frame);
     if (sl.ev_ok)
         for (int k = 0; k < GSR_STAGE_EVENTS; ++k)
             if (sl.ev[k]) (void)hipEventDestroy(sl.ev[k]);
     if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
     if (sl.ev_user) (void)hipEventDestroy(sl.ev_user);
     if (sl.ev_pairs) (void)hipEventDestroy(sl.ev_pairs);
-    if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    if (sl.own) (void)hipStreamDestroy(sl.own);
 }
 
 extern "C" int gsr_create(int device, gsr_context** out)
@@ -347,6 +356,7 @@ extern "C" int gsr_set_stream(gsr_context* c, void* s)
     int rc = sync_all(c);
     if (rc) return rc;
     c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].stream = c->slot[k].own;   // (re-bound by the next frame)
     return GSR_OK;
 }
 
@@ -435,7 +445,7 @@ extern "C" int gsr_upload_append(gsr_context* c, int64_t n64, const float* P, co
     if (c->has_sh && (!shx || !shy || !shz)) return set_err(GSR_E_INVALID, "gsr_upload_append: SH announced but arrays are NULL");
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t n = (uint32_t)n64;
-    hipStream_t us = c->slot[0].stream;
+    hipStream_t us = c->slot[0].own;
     // raw staging arena: one device allocation shared by the appends of an upload (grown on demand, released by
     // gsr_upload_end / _abort -- it is as large as the geometry itself)
     const size_t al = 256;
@@ -492,7 +502,7 @@ extern "C" int gsr_upload_end(gsr_context* c)
     c->bbox_ok = false;
     if (c->n > 0) {
         HIP_TRY(hipSetDevice(c->device));
-        hipStream_t us = c->slot[0].stream;
+        hipStream_t us = c->slot[0].own;
         const int grid = 512;
         float* d_part = nullptr;
         int rc = dev_alloc(&d_part, (size_t)grid * 6);
@@ -834,7 +844,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
     }
     if ((rc = mark(sl, 5))) return rc;
     if (j.local_tiles > 0) {
-        HIP_TRY(hipStreamWaitEvent(s, sl.ev_user, 0));
+        if (!j.direct) HIP_TRY(hipStreamWaitEvent(s, sl.ev_user, 0));
         GsrBlendArgs a;
         a.width = f.width; a.height = f.height; a.tiles_x = f.tiles_x; a.local_tiles = j.local_tiles;
         a.shard_index = f.shard_index; a.shard_count = f.shard_count; a.band_rows = j.band_rows;
@@ -873,7 +883,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     GsrSumArgs g;
     g.n_tiles = j.local_tiles; g.tiles_x = j.f.tiles_x; g.shard_index = j.f.shard_index; g.shard_count = j.f.shard_count;
     g.super_shift = j.f.super_shift; g.stiles_x = j.f.stiles_x; g.n_super = j.n_super;
-    hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, g, sl.counters, sl.d_n, sl.h_counters_dev,
+    hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, g, sl.counters, sl.d_n, sl.d_frame,
                        j.lazy ? c->prefix : (uint32_t*)nullptr, j.lazy ? reinterpret_cast<const uint32_t*>(sl.lazy_ctr) : (const uint32_t*)nullptr,
                        sl.colour_evals, sl.lazy_ctr + 1);
     HIP_TRY(hipGetLastError());
@@ -885,8 +895,10 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
         HIP_TRY(hipStreamSynchronize(s));
     }
     // results are ordered on the public stream: anything the caller queues there next sees this frame
-    HIP_TRY(hipEventRecord(sl.ev_done, s));
-    HIP_TRY(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
+    if (!j.direct) {
+        HIP_TRY(hipEventRecord(sl.ev_done, s));
+        HIP_TRY(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
+    }
     return GSR_OK;
 }
 
@@ -905,9 +917,26 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
     HIP_TRY(hipSetDevice(c->device));
     uint32_t D = 0;
     if (j.n > 0) {
-        hipError_t e = hipEventSynchronize(sl.ev_pairs);   // the pair count is in host memory; the GPU carries on
-        if (e != hipSuccess) return frame_abort(sl, set_err(GSR_E_HIP, "gsr_render: waiting for the pair count: %s", hipGetErrorString(e)));
-        D = *sl.h_total;
+        // The pair count arrives in mapped host memory, stamped with the frame's ticket, while the GPU carries on: the
+        // host just watches the word -- no event in the stream (an event costs the GPU ~6 us of idle queue), no API call.
+        volatile unsigned long long* box = sl.h_total;
+        unsigned long long v = *box;
+        for (unsigned long spins = 1; (uint32_t)(v >> 32) != j.ticket; ++spins) {
+            if ((spins & 0x3fffu) == 0) {   // every ~16 k reads: is the stream still alive?
+                const hipError_t q = hipStreamQuery(sl.stream);
+                if (q == hipSuccess) {      // everything queued has run: the word must be there now
+                    v = *box;
+                    if ((uint32_t)(v >> 32) != j.ticket)
+                        return frame_abort(sl, set_err(GSR_E_HIP, "gsr_render: the frame finished without delivering its pair count"));
+                    break;
+                }
+                if (q != hipErrorNotReady)
+                    return frame_abort(sl, set_err(GSR_E_HIP, "gsr_render: waiting for the pair count: %s", hipGetErrorString(q)));
+            }
+            __builtin_ia32_pause();
+            v = *box;
+        }
+        D = (uint32_t)v;
         if (D == 0xffffffffu || (unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
             return frame_abort(sl, set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: the frame's super-tile pairs exceed the limit of %lld", GSR_MAX_PAIRS));
         const bool short_buffer = D > sl.pair_cap;
@@ -966,6 +995,13 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     if (used) *used = &sl;
     int rc = frame_finish(c, sl);   // a deferred frame of this slot: look at its pair count now
     if (rc) return rc;
+    // strictly serial frames run on the public stream itself: nothing to hand over, no events; with two frames in flight a
+    // slot runs on its own stream and the result is ordered onto the public stream by an event
+    hipStream_t want = (c->nslots == 1) ? c->stream : sl.own;
+    if (want != sl.stream) {
+        HIP_TRY(hipStreamSynchronize(sl.stream));
+        sl.stream = want;
+    }
     hipStream_t s = sl.stream;
     if (sl.pair_cap > 0 && sl.pair_cap < c->pair_want) {   // the other slot met a frame that outgrew this size
         HIP_TRY(hipStreamSynchronize(s));
@@ -992,11 +1028,13 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     j.out_is_device = out_is_device != 0;
     j.deferred = c->opt_deferred && j.out_is_device;
     j.lazy = c->opt_lazy && f.sh_order > 0;   // order 0: the colour is Cd itself, nothing to defer
+    j.ticket = ++sl.ticket ? sl.ticket : ++sl.ticket;   // (never 0: the mailbox starts at 0)
     if (j.timing) harvest_slot(c, sl);
 
     // the caller's stream position now: the blend kernel (the only writer of caller-visible memory)
     // waits for it, so an output buffer that earlier work on the public stream still reads is safe
-    HIP_TRY(hipEventRecord(sl.ev_user, c->stream));
+    j.direct = sl.stream == c->stream;
+    if (!j.direct) HIP_TRY(hipEventRecord(sl.ev_user, c->stream));
 
     // per-tile bookkeeping + super-tile ranges
     if ((size_t)j.local_tiles + 1 > sl.tile_cap || !sl.sstart) {
@@ -1073,9 +1111,8 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
                            c->shard_count, f.stiles_x, sl.hist, nblk);
         hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals);
         hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, sl.totals, j.n_super, sl.sstart, sl.send, sl.h_total_dev,
-                           (unsigned long long)GSR_MAX_PAIRS, reinterpret_cast<uint32_t*>(sl.lazy_ctr));
+                           j.ticket, (unsigned long long)GSR_MAX_PAIRS, reinterpret_cast<uint32_t*>(sl.lazy_ctr));
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipEventRecord(sl.ev_pairs, s);
     } else {
         e = hipMemsetAsync(sl.sstart, 0, ((size_t)j.n_super + 1) * 4, s);
         if (e == hipSuccess) e = hipMemsetAsync(sl.send, 0, ((size_t)j.n_super + 1) * 4, s);
@@ -1135,7 +1172,7 @@ extern "C" int gsr_render_wire(gsr_context* c, const gsr_camera* cam, float* rgb
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
-    hipStream_t s = c->slot[0].stream;
+    hipStream_t s = c->slot[0].own;
     GsrFrame f;
     build_frame(c, cam, &f);
     const size_t npix = (size_t)cam->width * cam->height;
@@ -1171,6 +1208,14 @@ extern "C" int gsr_synchronize(gsr_context* c)
     return sync_all(c);
 }
 
+// the frame summaries live in device memory (no PCIe writes on the per-frame path); callers have synchronised
+static void fetch_counters(gsr_context* c)
+{
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k)
+        if (c->slot[k].d_frame && c->slot[k].h_counters)
+            (void)hipMemcpy(c->slot[k].h_counters, c->slot[k].d_frame, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+
 // the slot that rendered the most recent frame (NULL before the first frame)
 static FrameSlot* latest_slot(gsr_context* c)
 {
@@ -1186,6 +1231,7 @@ extern "C" int gsr_get_stats(gsr_context* c, gsr_stats* out)
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
+    fetch_counters(c);
     // harvest in submission order so that "last frame" fields end up describing the newest frame
     FrameSlot* last = latest_slot(c);
     for (int k = 0; k < GSR_MAX_SLOTS; ++k)
@@ -1235,6 +1281,7 @@ extern "C" int gsr_stats_reset(gsr_context* c)
         harvest_slot(c, c->slot[k]);
         HIP_TRY(hipMemset(c->slot[k].counters, 0, 8 * sizeof(unsigned long long)));
         for (int j = 0; j < 8; ++j) c->slot[k].h_counters[j] = 0;
+        HIP_TRY(hipMemset(c->slot[k].d_frame, 0, 8 * sizeof(unsigned long long)));
     }
     const int64_t ns = c->st.n_splats;
     {
@@ -1253,7 +1300,11 @@ extern "C" int gsr_stats_reset(gsr_context* c)
 // ---------------------------------------------------------------------------
 // debug / test access: intermediates of the most recent frame
 // number of entries of the depth-sorted list of the last frame (= visible splats of that frame)
-static uint32_t sorted_count(FrameSlot* sl) { return (uint32_t)(sl->h_counters[6] & 0xffffffffull); }
+static uint32_t sorted_count(FrameSlot* sl)
+{
+    (void)hipMemcpy(sl->h_counters, sl->d_frame, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    return (uint32_t)(sl->h_counters[6] & 0xffffffffull);
+}
 
 extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int64_t n)
 {

@@ -118,7 +118,7 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
 // the host is told 0xffffffff -- it reports GSR_E_TOO_MANY_PAIRS instead of compositing wrapped positions.
 __global__ void __launch_bounds__(BN_BINS)
 k_bin_ranges(const uint32_t* __restrict__ totals, int n_super, int32_t* __restrict__ sstart, int32_t* __restrict__ send,
-             volatile uint32_t* __restrict__ host_total /* pinned, mapped */, unsigned long long max_pairs,
+             volatile unsigned long long* __restrict__ host_total /* pinned, mapped */, uint32_t ticket, unsigned long long max_pairs,
              uint32_t* __restrict__ redo_count /* the frame's list of tiles given up by the plain blend kernel starts empty */)
 {
     if (threadIdx.x == 0) *redo_count = 0u;
@@ -136,7 +136,8 @@ k_bin_ranges(const uint32_t* __restrict__ totals, int n_super, int32_t* __restri
         sstart[threadIdx.x] = too_many ? 0 : (int32_t)ex;
         send[threadIdx.x] = too_many ? 0 : (int32_t)(ex + v);
     }
-    if (threadIdx.x == 0) { *host_total = too_many ? 0xffffffffu : tot; __threadfence_system(); }   // the host sizes the list buffer from it
+    // the host sizes the list buffer from it; it recognises THIS frame's count by the ticket in the upper half
+    if (threadIdx.x == 0) { *host_total = ((unsigned long long)ticket << 32) | (too_many ? 0xffffffffull : (unsigned long long)tot); __threadfence_system(); }
 }
 
 // Placement.  Inside a list the order must be the depth order of the splats, so the pairs of one

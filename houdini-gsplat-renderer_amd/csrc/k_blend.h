@@ -383,12 +383,13 @@ k_blend_lazy(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* 
 // [5] (wave-record evaluations, running total) -- a handful of atomics per frame instead of per
 // tile (same-address atomics serialise at ~12 ns each on MI355X).  Last kernel of a frame.
 #define SW_THREADS 1024
+#define SW_UNROLL 8
 struct GsrSumArgs {
     int32_t n_tiles, tiles_x, shard_index, shard_count, super_shift, stiles_x, n_super;
 };
 __global__ void __launch_bounds__(SW_THREADS)
 k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long* __restrict__ counters,
-           const uint32_t* __restrict__ n_visible, volatile unsigned long long* __restrict__ host /* pinned, mapped: [8] */,
+           const uint32_t* __restrict__ n_visible, unsigned long long* __restrict__ summary /* device [8]: fetched by gsr_get_stats */,
            uint32_t* __restrict__ prefix /* [256] lazy colour: list entries to colour per super-tile, next frame (or NULL) */,
            const uint32_t* __restrict__ redo_count /* tiles the plain blend kernel gave up this frame (or NULL) */,
            uint32_t* __restrict__ colour_evals /* [256] per-list counts of the colour pass, cleared here (or NULL) */,
@@ -400,15 +401,15 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
     if (threadIdx.x < 256) s_max[threadIdx.x] = 0;
     __syncthreads();
     unsigned long long sc = 0, fe = 0, ev = 0;
-    for (int i0 = 0; i0 < g.n_tiles; i0 += 4 * SW_THREADS) {
-        uint4 w[4];
+    for (int i0 = 0; i0 < g.n_tiles; i0 += SW_UNROLL * SW_THREADS) {
+        uint4 w[SW_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {   // independent loads: one memory round trip per 4096 tiles
+        for (int u = 0; u < SW_UNROLL; ++u) {   // independent loads: one memory round trip per 8192 tiles
             const int i = i0 + u * SW_THREADS + (int)threadIdx.x;
             w[u] = i < g.n_tiles ? tile_work[i] : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SW_UNROLL; ++u) {
             sc += w[u].x; fe += w[u].y; ev += w[u].z;
             const int i = i0 + u * SW_THREADS + (int)threadIdx.x;
             // deepest scan among the tiles of each super-tile that SATURATED: a tile that ran to the end of its list (the
@@ -444,13 +445,12 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         counters[3] = s_sum[0];
         atomicAdd(&counters[4], s_sum[0]);
         atomicAdd(&counters[5], s_sum[2]);
-        // the frame's bookkeeping goes straight to the host mirror (read in gsr_get_stats after a stream sync):
-        // no copy-engine packets at the end of every frame
+        // the frame's summary stays in device memory (gsr_get_stats copies 64 bytes after its stream sync): writing it
+        // to mapped host memory every frame cost ~10 us of PCIe round trips at the end of the frame
         __threadfence();
 #pragma unroll
-        for (int k = 0; k < 6; ++k) host[k] = counters[k];
-        host[6] = (unsigned long long)*n_visible;
-        host[7] = redo_count ? (unsigned long long)*redo_count : 0ull;
-        __threadfence_system();
+        for (int k = 0; k < 6; ++k) summary[k] = counters[k];
+        summary[6] = (unsigned long long)*n_visible;
+        summary[7] = redo_count ? (unsigned long long)*redo_count : 0ull;
     }
 }

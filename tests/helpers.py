@@ -50,14 +50,14 @@ GOLDEN_MAX_OUTLIER = 0.02    # edge-flip bound: exp(-4) * opacity * T
 GOLDEN_MEAN = 1e-4
 
 
-def check_against_golden(img, golden_img):
+def check_against_golden(img, golden_img, max_bias=2e-5):
     err = np.abs(img.astype(np.float64) - golden_img.astype(np.float64))
     frac = float((err.max(axis=2) <= GOLDEN_TOL).mean())
     assert frac >= GOLDEN_MIN_FRAC, f"only {frac:.5f} of pixels within {GOLDEN_TOL}"
     assert err.max() <= GOLDEN_MAX_OUTLIER, f"outlier {err.max()} exceeds the edge-flip bound"
     assert err.mean() <= GOLDEN_MEAN, f"mean abs error {err.mean()}"
     signed = float((img.astype(np.float64) - golden_img).mean())
-    assert abs(signed) <= 2e-5, f"biased by {signed}"
+    assert abs(signed) <= max_bias, f"biased by {signed}"
     return frac, float(err.max()), float(err.mean())
 
 

@@ -73,8 +73,9 @@ def parse_args():
     ap.add_argument("--emulate-rank", type=int, default=0, help="which shard --emulate-shard renders")
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="single-GPU diagnostic: render only tile-row shard 0 of N (per-rank cost of an N-GPU run, no gather)")
-    ap.add_argument("--lazy", type=int, default=1, choices=(0, 1),
-                    help="GSR_OPT_LAZY_COLOUR: 1 (library default) = SH colours only for the splats a frame can composite; 0 = eager (A/B)")
+    ap.add_argument("--lazy", type=int, default=1, choices=(0, 1, 2),
+                    help="GSR_OPT_LAZY_COLOUR: 1 (library default) = SH colours only for the splats a frame can composite, when the "
+                         "kernels find that it pays; 2 = always; 0 = eager (A/B)")
     ap.add_argument("--torch-gather", action="store_true",
                     help="N>1: gather with torch.distributed (multigpu.FrameGatherer) instead of the in-library RCCL gather")
     ap.add_argument("--verify", action="store_true",
@@ -374,7 +375,7 @@ def main():
     if st_stage["stage_frames"] > 0 and world == 1:
         k1_ms = st_stage["stage_ms_total"][0] / st_stage["stage_frames"]
         nvis = st_stage["n_visible"]
-        lazy_on = bool(args.lazy) and order > 0 and splats.shx is not None
+        lazy_on = st_stage["lazy_colours_total"] > 0
         # eager: the colour halves are read for every visible splat; lazy: K1 reads geometry only (colours: k_colour_prefix)
         col_b = 0 if lazy_on else {0: 16, 1: 32, 2: 64, 3: 96}[order if splats.shx is not None else 0]
         k1_bytes = nvis * (32 + col_b + 48 + 12) + (splats.n - nvis) * (32 + 12)
@@ -412,7 +413,7 @@ def main():
             "roofline_preprocess": roofline_k1,
             "stages_ms_last_frame": stages,
             "n_visible": st["n_visible"],
-            "lazy_colour": {"enabled": bool(args.lazy), "colours_evaluated_per_frame": st["lazy_colours_total"] / max(1, st["frames"]),
+            "lazy_colour": {"mode": args.lazy, "active": st["lazy_colours_total"] > 0, "colours_evaluated_per_frame": st["lazy_colours_total"] / max(1, st["frames"]),
                             "visible_splats": st["n_visible"],
                             "fallback_tiles_last_frame": st["lazy_redo_tiles"]},
         }

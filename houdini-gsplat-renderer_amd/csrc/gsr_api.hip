@@ -184,6 +184,8 @@ struct gsr_context {
     uint64_t frame_no = 0;
     size_t pair_want = 0;              // largest list buffer any frame slot needed so far
     int64_t lazy_base = 0;             // lazy_colours_total at the last gsr_stats_reset
+    uint32_t* lazy_hint = nullptr;     // device: would lazy colour pay? (k_sum_work -> k_bin_ranges -> mailbox -> lazy_pays)
+    bool lazy_pays = false;
     unsigned long long* wire_zbuf = nullptr;   // wireframe overlay: (depth bits, splat index) per pixel ...
     float* wire_out = nullptr;                 // ... and the image staged for a host target
     size_t wire_cap = 0;                       // pixels both hold
@@ -250,8 +252,8 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMemset(sl.lazy_ctr, 0, 2 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.colour_evals), 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.colour_evals, 0, 256 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
-    if (ok) *sl.h_total = 0ull;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    if (ok) { sl.h_total[0] = 0ull; sl.h_total[1] = 0ull; }
     ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_total_dev), sl.h_total, 0) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), 8 * sizeof(unsigned long long), 0) == hipSuccess;
     if (ok) for (int j = 0; j < 8; ++j) sl.h_counters[j] = 0;
@@ -317,7 +319,8 @@ extern "C" int gsr_create(int device, gsr_context** out)
         hipMalloc(reinterpret_cast<void**>(&c->prefix_all), 256 * 4) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->prefix_none), 256 * 4) != hipSuccess ||
         hipMemset(c->prefix, 0xff, 256 * 4) != hipSuccess || hipMemset(c->prefix_all, 0xff, 256 * 4) != hipSuccess ||
-        hipMemset(c->prefix_none, 0, 256 * 4) != hipSuccess) {
+        hipMemset(c->prefix_none, 0, 256 * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->lazy_hint), 4) != hipSuccess || hipMemset(c->lazy_hint, 0, 4) != hipSuccess) {
         gsr_destroy(c);
         return set_err(GSR_E_HIP, "gsr_create: allocating the colour-prefix tables failed");
     }
@@ -344,7 +347,7 @@ extern "C" void gsr_destroy(gsr_context* c)
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) slot_destroy(c->slot[k]);
     dev_free(c->tile_map);
     dev_free(c->wire_zbuf); dev_free(c->wire_out); dev_free(c->stage);
-    dev_free(c->prefix); dev_free(c->prefix_all); dev_free(c->prefix_none);
+    dev_free(c->prefix); dev_free(c->prefix_all); dev_free(c->prefix_none); dev_free(c->lazy_hint);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -372,7 +375,7 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
         break;
     case GSR_OPT_DEBUG_FLAGS: c->opt_flags = value; break;
     case GSR_OPT_DEFERRED_CHECK: c->opt_deferred = value ? 1 : 0; break;
-    case GSR_OPT_LAZY_COLOUR: c->opt_lazy = value ? 1 : 0; break;
+    case GSR_OPT_LAZY_COLOUR: c->opt_lazy = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_SUPER_TILE:
         if (value != 0 && (value < 1 || value > 16 || (value & (value - 1))))
             return set_err(GSR_E_INVALID, "gsr_set_option: super-tile edge must be 0 (auto) or 1,2,4,8,16");
@@ -527,6 +530,7 @@ extern "C" int gsr_upload_end(gsr_context* c)
     c->geo_gen++;
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
     c->prefix_valid = false;           // lazy colour: the first frame of a new cloud colours every list completely
+    c->lazy_pays = false;              // ... and in automatic mode the first frames are eager until the kernels say it pays
     c->st.n_splats = c->n;
     return GSR_OK;
 }
@@ -884,10 +888,11 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     g.n_tiles = j.local_tiles; g.tiles_x = j.f.tiles_x; g.shard_index = j.f.shard_index; g.shard_count = j.f.shard_count;
     g.super_shift = j.f.super_shift; g.stiles_x = j.f.stiles_x; g.n_super = j.n_super;
     hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, g, sl.counters, sl.d_n, sl.d_frame,
-                       j.lazy ? c->prefix : (uint32_t*)nullptr, j.lazy ? reinterpret_cast<const uint32_t*>(sl.lazy_ctr) : (const uint32_t*)nullptr,
-                       sl.colour_evals, sl.lazy_ctr + 1);
+                       (j.f.sh_order > 0 && c->opt_lazy) ? c->prefix : (uint32_t*)nullptr,
+                       j.lazy ? reinterpret_cast<const uint32_t*>(sl.lazy_ctr) : (const uint32_t*)nullptr,
+                       sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint);
     HIP_TRY(hipGetLastError());
-    if (j.lazy) c->prefix_valid = true;
+    if (j.f.sh_order > 0 && c->opt_lazy) c->prefix_valid = true;   // (eager frames keep the scan depths too: the switch to lazy starts predicted)
     sl.last_lazy = j.lazy;
     if (j.timing) { sl.ev_pending = true; sl.ev_all = j.timing_all; }
     if (!j.out_is_device) {
@@ -937,6 +942,7 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
             v = *box;
         }
         D = (uint32_t)v;
+        c->lazy_pays = box[1] != 0ull;   // (written before the ticket) k_sum_work's verdict on the frame before
         if (D == 0xffffffffu || (unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
             return frame_abort(sl, set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: the frame's super-tile pairs exceed the limit of %lld", GSR_MAX_PAIRS));
         const bool short_buffer = D > sl.pair_cap;
@@ -1027,7 +1033,8 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     j.user_out = rgba_out;
     j.out_is_device = out_is_device != 0;
     j.deferred = c->opt_deferred && j.out_is_device;
-    j.lazy = c->opt_lazy && f.sh_order > 0;   // order 0: the colour is Cd itself, nothing to defer
+    // order 0: the colour is Cd itself, nothing to defer; mode 1 follows the kernels' own verdict on the previous frames
+    j.lazy = f.sh_order > 0 && (c->opt_lazy == 2 || (c->opt_lazy == 1 && c->lazy_pays));
     j.ticket = ++sl.ticket ? sl.ticket : ++sl.ticket;   // (never 0: the mailbox starts at 0)
     if (j.timing) harvest_slot(c, sl);
 
@@ -1111,7 +1118,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
                            c->shard_count, f.stiles_x, sl.hist, nblk);
         hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals);
         hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, sl.totals, j.n_super, sl.sstart, sl.send, sl.h_total_dev,
-                           j.ticket, (unsigned long long)GSR_MAX_PAIRS, reinterpret_cast<uint32_t*>(sl.lazy_ctr));
+                           j.ticket, (unsigned long long)GSR_MAX_PAIRS, reinterpret_cast<uint32_t*>(sl.lazy_ctr), c->lazy_hint);
         e = hipGetLastError();
     } else {
         e = hipMemsetAsync(sl.sstart, 0, ((size_t)j.n_super + 1) * 4, s);

@@ -119,9 +119,10 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
 __global__ void __launch_bounds__(BN_BINS)
 k_bin_ranges(const uint32_t* __restrict__ totals, int n_super, int32_t* __restrict__ sstart, int32_t* __restrict__ send,
              volatile unsigned long long* __restrict__ host_total /* pinned, mapped */, uint32_t ticket, unsigned long long max_pairs,
-             uint32_t* __restrict__ redo_count /* the frame's list of tiles given up by the plain blend kernel starts empty */)
+             uint32_t* __restrict__ redo_count /* the frame's list of tiles given up by the plain blend kernel starts empty */,
+             const uint32_t* __restrict__ lazy_hint /* k_sum_work's verdict on the previous frame, forwarded to the host */)
 {
-    if (threadIdx.x == 0) *redo_count = 0u;
+    if (threadIdx.x == 0) { *redo_count = 0u; host_total[1] = (unsigned long long)*lazy_hint; }
     __shared__ uint32_t s_wave[4];
     __shared__ unsigned long long s_sum[4];
     const uint32_t v = ((int)threadIdx.x < n_super) ? totals[threadIdx.x] : 0u;

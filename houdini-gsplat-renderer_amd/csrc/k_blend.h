@@ -384,6 +384,14 @@ k_blend_lazy(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* 
 // tile (same-address atomics serialise at ~12 ns each on MI355X).  Last kernel of a frame.
 #define SW_THREADS 1024
 #define SW_UNROLL 8
+#ifndef SW_HEADROOM_SHIFT
+#define SW_HEADROOM_SHIFT 2
+#endif
+#ifndef SW_HEADROOM_ADD
+#define SW_HEADROOM_ADD 1024u
+#endif
+#define SW_HEADROOM_SHIFT_ SW_HEADROOM_SHIFT
+#define SW_HEADROOM_ADD_ SW_HEADROOM_ADD
 struct GsrSumArgs {
     int32_t n_tiles, tiles_x, shard_index, shard_count, super_shift, stiles_x, n_super;
 };
@@ -393,14 +401,19 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
            uint32_t* __restrict__ prefix /* [256] lazy colour: list entries to colour per super-tile, next frame (or NULL) */,
            const uint32_t* __restrict__ redo_count /* tiles the plain blend kernel gave up this frame (or NULL) */,
            uint32_t* __restrict__ colour_evals /* [256] per-list counts of the colour pass, cleared here (or NULL) */,
-           unsigned long long* __restrict__ colour_total /* running total of the above */)
+           unsigned long long* __restrict__ colour_total /* running total of the above */,
+           const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
+           uint32_t* __restrict__ lazy_hint /* would lazy colour pay for a frame like this one? (read by the next frames) */)
 {
     __shared__ unsigned long long s_sum[3];
     __shared__ uint32_t s_max[256];
+    __shared__ uint32_t s_unsat, s_est;
+    if (threadIdx.x == 0) { s_unsat = 0; s_est = 0; }
     if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
     if (threadIdx.x < 256) s_max[threadIdx.x] = 0;
     __syncthreads();
     unsigned long long sc = 0, fe = 0, ev = 0;
+    uint32_t unsat = 0;   // tiles that composited something and ran to the end of their list: lazy colour sends them to the fallback
     for (int i0 = 0; i0 < g.n_tiles; i0 += SW_UNROLL * SW_THREADS) {
         uint4 w[SW_UNROLL];
 #pragma unroll
@@ -414,6 +427,7 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
             const int i = i0 + u * SW_THREADS + (int)threadIdx.x;
             // deepest scan among the tiles of each super-tile that SATURATED: a tile that ran to the end of its list (the
             // cloud's silhouette) would ask for the whole list; such tiles have few hits and take the on-demand fallback
+            if (i < g.n_tiles && !w[u].w && w[u].y) ++unsat;
             if (prefix && i < g.n_tiles && w[u].w) {
                 const int tx = i % g.tiles_x, gty = (i / g.tiles_x) * g.shard_count + g.shard_index;
                 atomicMax(&s_max[(gty >> g.super_shift) * g.stiles_x + (tx >> g.super_shift)], w[u].x);
@@ -421,17 +435,18 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         }
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); atomicAdd(&s_sum[2], ev); }
+    for (int d = 32; d > 0; d >>= 1) {
+        sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); unsat += __shfl_down(unsat, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); atomicAdd(&s_sum[2], ev); atomicAdd(&s_unsat, unsat); }
     __syncthreads();
     if (prefix && (int)threadIdx.x < g.n_super) {
         const uint32_t m = s_max[threadIdx.x];
-#ifndef SW_HEADROOM_SHIFT
-#define SW_HEADROOM_SHIFT 2
-#endif
-#ifndef SW_HEADROOM_ADD
-#define SW_HEADROOM_ADD 1024u
-#endif
+        {   // how many colour evaluations the lazy pass would make for a frame like this one
+            const uint32_t len = (uint32_t)(send[threadIdx.x] - sstart[threadIdx.x]);
+            const uint32_t want = m + (m >> SW_HEADROOM_SHIFT_) + SW_HEADROOM_ADD_;
+            atomicAdd(&s_est, want < len ? want : len);
+        }
         prefix[threadIdx.x] = m + (m >> SW_HEADROOM_SHIFT) + SW_HEADROOM_ADD;   // headroom for the next frame's camera move
     }
     if (colour_evals && threadIdx.x < 256) {
@@ -439,7 +454,13 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         colour_evals[threadIdx.x] = 0u;
         if (v) atomicAdd(colour_total, (unsigned long long)v);
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        // Lazy colour pays when the colour pass would evaluate well under half of what eager evaluation does (it gathers
+        // rows at random, eager streams them) and (almost) no tile would need the on-demand fallback.  Small or sparse
+        // clouds (BASELINE C2, C3) fail one of the two; the 6 M-splat scenes pass both.
+        if (lazy_hint) *lazy_hint = (prefix && (unsigned long long)s_est * 10ull < (unsigned long long)*n_visible * 4ull &&
+                                     s_unsat * 64u <= (uint32_t)g.n_tiles) ? 1u : 0u;
         counters[1] = s_sum[1];
         atomicAdd(&counters[2], s_sum[1]);
         counters[3] = s_sum[0];

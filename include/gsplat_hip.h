@@ -235,9 +235,11 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        earlier frames (+25 % headroom); a frame whose pair count outgrows it is composited
                                        from clamped lists and counted in gsr_stats.frames_truncated (the buffer is regrown
                                        for the next frame).  The first frame after a buffer-less start is never deferred. */
-#define GSR_OPT_LAZY_COLOUR      8   /* 1 (default) / 0: evaluate SH colours only for the splats a frame can composite (the front of
-                                       every super-tile list, as deep as the previous frame scanned, with an on-demand fallback)
-                                       instead of for every visible splat.  Same pixels, bit for bit. */
+#define GSR_OPT_LAZY_COLOUR      8   /* SH colours only for the splats a frame can composite (the front of every super-tile list, as
+                                       deep as the previous frame scanned, with an on-demand fallback) instead of for every visible
+                                       splat: 0 = never, 2 = always, 1 (default) = when it pays -- the kernels compare, every frame,
+                                       what the colour pass would evaluate with what eager evaluation does (large dense clouds: yes;
+                                       small or sparse ones: no).  Same pixels, bit for bit, in every mode. */
 int  gsr_set_option(gsr_context* ctx, int option, int value);
 
 /* ---- debug / test access (device -> host copies of intermediates) -------- */

@@ -351,7 +351,7 @@ def test_options_do_not_change_pixels(pkg, engine):
     base = engine.render(cam)
     for opt, vals in ((pkg.engine.OPT_XCD_SWIZZLE, (0, 1)), (pkg.engine.OPT_SUPER_TILE, (1, 2, 4, 8, 16, 0)),
                       (pkg.engine.OPT_DEBUG_FLAGS, (1, 2, 4, 7, 8, 15, 0)), (pkg.engine.OPT_FRAMES_IN_FLIGHT, (1, 2)),
-                      (pkg.engine.OPT_LAZY_COLOUR, (0, 1))):
+                      (pkg.engine.OPT_LAZY_COLOUR, (0, 2, 1))):
         for v in vals:
             engine.set_option(opt, v)
             assert np.array_equal(engine.render(cam), base), f"option {opt}={v} changed the image"
@@ -743,7 +743,7 @@ def test_lazy_colour_is_exact_and_predicts(pkg, oracle):
         eng.set_option(pkg.engine.OPT_LAZY_COLOUR, 0)
         want = [eng.render(c) for c in cams]
         _check_image(want[0], oracle.render(splats, cams[0], threads=oracle.max_threads()))
-        eng.set_option(pkg.engine.OPT_LAZY_COLOUR, 1)
+        eng.set_option(pkg.engine.OPT_LAZY_COLOUR, 2)         # always (1 = only when the kernels find that it pays)
         eng.upload(splats)                                    # forget the prediction
         eng.stats_reset()
         redo, colours = [], []

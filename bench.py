@@ -199,18 +199,35 @@ def main():
     if world > 1:
         use_lib = backend == "nccl" and not args.torch_gather
         if use_lib:
+            # every rank must be able to load RCCL, rank 0 must get an id, and every rank's ncclCommInitRank must succeed --
+            # each step agreed on collectively, so that a failure anywhere sends ALL ranks to the torch gather
+            def all_ok(flag: bool) -> bool:
+                t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(t.item())
+            use_lib = all_ok(bool(pkg.load_library().gsr_comm_available()))
             idbuf = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            ok = torch.ones(1, dtype=torch.int32, device="cuda")
-            if rank == 0:
-                try:
-                    idbuf.copy_(torch.frombuffer(bytearray(eng.comm_unique_id()), dtype=torch.uint8))
-                except Exception:
-                    ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            use_lib = bool(ok.item())
+            if use_lib:
+                got = True
+                if rank == 0:
+                    try:
+                        idbuf.copy_(torch.frombuffer(bytearray(eng.comm_unique_id()), dtype=torch.uint8))
+                    except Exception:
+                        got = False
+                use_lib = all_ok(got)
             if use_lib:
                 dist.broadcast(idbuf, src=0)
-                eng.comm_init(bytes(idbuf.cpu().numpy().tobytes()), rank, world)     # collective (ncclCommInitRank)
+                inited = True
+                try:
+                    eng.comm_init(bytes(idbuf.cpu().numpy().tobytes()), rank, world)     # collective (ncclCommInitRank)
+                except Exception as e:  # noqa: BLE001
+                    inited = False
+                    print(f"[rank {rank}] gsr_comm_init failed: {e}", file=sys.stderr)
+                use_lib = all_ok(inited)
+                if not use_lib and inited:
+                    eng.comm_destroy()
+                    eng.set_row_shard(rank, world)
+            if use_lib:
                 final = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
                 gather = "in-library RCCL: gsr_comm_render (ncclSend/ncclRecv group + k_stitch_bands)"
         if not use_lib:

@@ -606,13 +606,13 @@ static int ensure_u32(uint32_t** p, size_t* cap, size_t need)
 
 template <typename V, int DBITS, bool SKIP>
 static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, uint32_t n, const uint32_t* n_dev,
-                      int shift, uint32_t nblk, bool contig)
+                      int shift, uint32_t nblk, bool contig, uint32_t* n_out = nullptr)
 {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS, SKIP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, n,
                        n_dev, shift, sl.hist, nblk, contig);
     hipLaunchKernelGGL(k_scan_rows, dim3(1u << DBITS), dim3(SC_THREADS), 0, sl.stream, sl.hist, nblk, sl.totals);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS, SKIP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA,
-                       vA, kB, vB, n, n_dev, shift, sl.hist, sl.totals, nblk, contig);
+                       vA, kB, vB, n, n_dev, shift, sl.hist, sl.totals, nblk, contig, n_out);
     HIP_TRY(hipGetLastError());
     return GSR_OK;
 }
@@ -640,16 +640,12 @@ static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& v
         const bool skip = compact_to && p == 0;
         const uint32_t* n_dev = (compact_to && p > 0) ? compact_to : nullptr;
         if (use9)
-            rc = skip ? radix_pass<V, 9, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig)
+            rc = skip ? radix_pass<V, 9, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig, compact_to)
                       : radix_pass<V, 9, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig);
         else
-            rc = skip ? radix_pass<V, 8, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig)
+            rc = skip ? radix_pass<V, 8, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig, compact_to)
                       : radix_pass<V, 8, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig);
         if (rc) return rc;
-        if (skip) {
-            hipLaunchKernelGGL(k_sum_totals, dim3(1), dim3(SC_THREADS), 0, sl.stream, sl.totals, 1 << width, compact_to);
-            HIP_TRY(hipGetLastError());
-        }
         uint32_t* t = kA; kA = kB; kB = t;
         V* tv = vA; vA = vB; vB = tv;
     }

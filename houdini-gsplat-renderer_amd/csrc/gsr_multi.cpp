@@ -404,6 +404,8 @@ std::map<gsr_context*, CommState>& comm_table()
 }
 }  // namespace
 
+extern "C" int gsr_comm_available(void) { return rccl().ok ? 1 : 0; }
+
 extern "C" int gsr_comm_get_unique_id(void* id)
 {
     if (!id) return fail(GSR_E_INVALID, "gsr_comm_get_unique_id: NULL");

@@ -349,7 +349,8 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
         // key 0xffffffff (never a real key: keys are distance^2 bits minus key_min) marks a splat the first
         // radix pass drops, so everything after it runs on the visible splats only
         key[i] = (out_rect != GSR_RECT_EMPTY) ? kb : 0xffffffffu;
-        val[i] = make_uint2(i, out_rect);   // sort payload: splat index + tile rect
+        if (out_rect != GSR_RECT_EMPTY) val[i] = make_uint2(i, out_rect);   // sort payload: splat index + tile rect (a dropped
+                                                                            // splat's payload is never read)
     }
 }
 

@@ -150,18 +150,6 @@ k_scan_rows(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ t
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-// number of items that survived a compacting pass = sum of the per-digit totals
-__global__ void __launch_bounds__(SC_THREADS)
-k_sum_totals(const uint32_t* __restrict__ totals, int bins, uint32_t* __restrict__ n_out)
-{
-    __shared__ uint32_t s_wave[4];
-    uint32_t v = 0;
-    for (int b = threadIdx.x; b < bins; b += SC_THREADS) v += totals[b];
-    uint32_t tot;
-    (void)block_excl_scan_256(v, s_wave, &tot);
-    if (threadIdx.x == 0) *n_out = tot;
-}
-
 // V = payload type: uint32_t (4 B) or uint2 (8 B: splat index + packed tile rect).
 // Item order inside a workgroup: wave w owns items [w*RS_WAVE_ITEMS, (w+1)*RS_WAVE_ITEMS) of the
 // tile, round k covers 64 consecutive items -> (wave, round, lane) is input order.
@@ -170,7 +158,8 @@ __global__ void __launch_bounds__(RS_THREADS)
 k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in,
                 uint32_t* __restrict__ keys_out, V* __restrict__ vals_out, uint32_t n_host,
                 const uint32_t* __restrict__ n_dev, int shift,
-                const uint32_t* __restrict__ offs, const uint32_t* __restrict__ totals, uint32_t nblk, bool contig)
+                const uint32_t* __restrict__ offs, const uint32_t* __restrict__ totals, uint32_t nblk, bool contig,
+                uint32_t* __restrict__ n_out /* compacting pass: the number of surviving items (sum of the digit totals), or NULL */)
 {
     constexpr int BINS = 1 << DBITS;
     constexpr uint32_t MASK = BINS - 1;
@@ -199,6 +188,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
         uint32_t ex = block_excl_scan_256(tsum, s_wave, &tot);   // (contains the __syncthreads for wc too)
 #pragma unroll
         for (int k = 0; k < PER; ++k) { gadj[threadIdx.x * PER + k] = ex; ex += tv[k]; }
+        if (n_out && blockIdx.x == 0 && threadIdx.x == 0) *n_out = tot;   // read by the next pass's kernels
     }
     __syncthreads();
 
@@ -212,8 +202,14 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
         bool valid = li < nvalid;
         uint32_t key = 0xffffffffu;
         V val{};
-        if (valid) { key = keys_in[tile_base + li]; val = vals_in[tile_base + li]; }
-        if (SKIP) valid = valid && key != 0xffffffffu;   // compacting pass: sentinel items do not exist
+        if (SKIP) {   // compacting pass: sentinel items do not exist -- and their payload is neither written (K1) nor read
+            if (valid) key = keys_in[tile_base + li];
+            valid = valid && key != 0xffffffffu;
+            if (valid) val = vals_in[tile_base + li];
+        } else if (valid) {
+            key = keys_in[tile_base + li];
+            val = vals_in[tile_base + li];
+        }
         // items that do not exist neither rank nor count nor get written
         const uint32_t d = (key >> shift) & MASK;
         unsigned long long m = __ballot(valid);

@@ -88,7 +88,7 @@ C_ABI_SYMBOLS = [
     "gsr_multi_set_stream", "gsr_multi_set_option", "gsr_multi_upload_begin", "gsr_multi_upload_append",
     "gsr_multi_upload_end", "gsr_multi_upload_abort", "gsr_multi_upload", "gsr_multi_render", "gsr_multi_render_depth",
     "gsr_multi_synchronize", "gsr_multi_get_stats",
-    "gsr_comm_get_unique_id", "gsr_comm_init", "gsr_comm_destroy", "gsr_comm_render",
+    "gsr_comm_available", "gsr_comm_get_unique_id", "gsr_comm_init", "gsr_comm_destroy", "gsr_comm_render",
     "gsplat_renderer_create_multi", "gsplat_renderer_multi",
     "gsplat_prim_create", "gsplat_prim_destroy", "gsplat_prim_update", "gsplat_prim_render", "gsplat_prim_missing",
     "gsplat_prim_sh_order", "gsplat_prim_has_sh", "gsplat_prim_array",

@@ -178,6 +178,7 @@ int  gsr_multi_get_stats(gsr_multi* m, int rank, gsr_stats* out);
  * call per rank: the rank's band is rendered, sent (ncclSend) or received and stitched (root).  Asynchronous, ordered on
  * the context's public stream; rgba_out_device is the FULL frame on the root and ignored elsewhere. */
 #define GSR_COMM_ID_BYTES 128
+int  gsr_comm_available(void);                       /* 1 if librccl could be loaded in this process (no GPU work) */
 int  gsr_comm_get_unique_id(void* id);
 int  gsr_comm_init(gsr_context* ctx, const void* id, int rank, int world);   /* collective; sets the row shard (rank, world) */
 int  gsr_comm_destroy(gsr_context* ctx);

@@ -770,3 +770,34 @@ def test_lazy_colour_is_exact_and_predicts(pkg, oracle):
             assert np.array_equal(dev[f][vis].view(np.uint32), ref[f][vis].view(np.uint32))
     finally:
         eng.close()
+
+
+def test_rccl_entry_points_on_one_gpu(pkg, engine):
+    """The 1-GPU box cannot host two RCCL ranks, but it can run the library's RCCL plumbing with world size 1: librccl is
+    dlopen'ed, ncclGetUniqueId / ncclCommInitRank / ncclCommInitAll / ncclCommDestroy execute on the real GPU, and a frame
+    through gsr_comm_render / gsr_multi_render equals the plain frame."""
+    L = pkg.load_library()
+    assert L.gsr_comm_available() == 1
+    splats = pkg.scenes.make_scene(20000, seed=191, sh=True)
+    cam = pkg.camera.make_camera(320, 200, sh_order=3, frame=2)
+    engine.upload(splats)
+    want = engine.render(cam)
+    eng = pkg.Engine(0)
+    hb = HipBuffers()
+    try:
+        eng.upload(splats)
+        uid = eng.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        eng.comm_init(uid, 0, 1)
+        out = hb.alloc(cam.height * cam.width * 16)
+        eng.comm_render(pkg.engine.camera_struct(cam), out)
+        eng.synchronize()
+        assert np.array_equal(hb.download(out, (cam.height, cam.width, 4)), want)
+        eng.comm_destroy()
+    finally:
+        hb.free()
+        eng.close()
+    with pkg.MultiEngine([0], pkg.engine.TRANSPORT_RCCL) as M:      # ncclCommInitAll over one device
+        assert M.transport == pkg.engine.TRANSPORT_RCCL
+        M.upload(splats)
+        assert np.array_equal(M.render(cam), want)

@@ -70,6 +70,9 @@ def parse_args():
                     help="after the timed region, time the same K steps again with two frames in flight and report "
                          "them as 'pipelined' (off by default so that a rocprofv3 run of the default command sees "
                          "only the serial frames the roofline is computed from)")
+    ap.add_argument("--shard-layout", type=int, default=1, choices=(0, 1),
+                    help="N>1 (and --emulate-shard): 1 (default) = contiguous bands of tile rows -- a rank keeps ~1/N of the splats and "
+                         "K1 drops the rest before the covariance chain; 0 = interleaved tile rows (balances any scene)")
     ap.add_argument("--emulate-rank", type=int, default=0, help="which shard --emulate-shard renders")
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="single-GPU diagnostic: render only tile-row shard 0 of N (per-rank cost of an N-GPU run, no gather)")
@@ -181,6 +184,7 @@ def main():
     eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, args.frames_in_flight)
     eng.set_option(pkg.engine.OPT_STAGE_TIMING, args.stage_timing)
     eng.set_option(pkg.engine.OPT_LAZY_COLOUR, args.lazy)
+    eng.set_option(pkg.engine.OPT_SHARD_LAYOUT, args.shard_layout)
     if world > 1:
         eng.set_row_shard(rank, world)
     elif args.emulate_shard > 1:
@@ -231,7 +235,8 @@ def main():
                 final = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
                 gather = "in-library RCCL: gsr_comm_render (ncclSend/ncclRecv group + k_stitch_bands)"
         if not use_lib:
-            fg = pkg.multigpu.FrameGatherer(dist, rank, world, W, H, "cuda", engine=eng, via_host=(backend != "nccl"))
+            fg = pkg.multigpu.FrameGatherer(dist, rank, world, W, H, "cuda", engine=eng, via_host=(backend != "nccl"),
+                                            layout=args.shard_layout)
             gather = "torch.distributed.gather + gsr_stitch_bands"
     band = torch.zeros((eng.band_rows(H), W, 4), dtype=torch.float32, device="cuda") if fg is None else fg.band
     assert band.shape[0] == eng.band_rows(H)
@@ -330,7 +335,9 @@ def main():
     d_eff = st["blend_pairs_consumed_total"] / launches       # (tile, splat) pairs CONSUMED per launch = records gathered
     scanned = st["blend_entries_scanned_total"] / launches     # list entries (idx + rect) read per launch
     rec_b, pair_b = st["record_bytes"], st["pair_bytes"]
-    own_px = sum(min(16, H - r * 16) for r in range(rank, (H + 15) // 16, world)) * W
+    shards = args.emulate_shard if (world == 1 and args.emulate_shard > 1) else world
+    srank = (args.emulate_rank % shards) if (world == 1 and args.emulate_shard > 1) else rank
+    own_px = sum(min(16, H - r * 16) for r in pkg.multigpu.owned_tile_rows(H, srank, shards, args.shard_layout)) * W
     # unit of work = one consumed (tile, splat) pair = its list entry (8 B) + its projected record (48 B; this
     # build's true sizes), plus one RGBA-f32 store per pixel.  The entries a tile merely SCANS in its super-tile's list to
     # find its own (the price of coarse lists) are NOT algorithmic bytes: they are reported beside it.
@@ -424,7 +431,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {splats.n} synthetic splats (SH deg {order}, seed {cfg['seed']}), "
                                    f"{W}x{H}, orbiting camera (re-sort every frame)",
-                       "parallelism": f"tile-row shard x{world}" if world > 1 else "single GPU", "gather": gather,
+                       "parallelism": (f"tile-row shard x{world}, " + ("contiguous bands" if args.shard_layout else "interleaved rows"))
+                       if world > 1 else "single GPU", "gather": gather,
                        "n_splats": splats.n, "width": W, "height": H, "frames_in_flight": args.frames_in_flight},
             "roofline": roofline,
             "roofline_preprocess": roofline_k1,

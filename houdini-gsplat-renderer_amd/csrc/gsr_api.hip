@@ -60,11 +60,11 @@ static int set_err(int code, const char* fmt, ...)
 // what identifies a depth order: the geometry generation, the shard (a rank sorts only the splats it owns) and the camera
 struct SortKey {
     uint64_t gen = 0;
-    int shard_index = 0, shard_count = 1, flags = 0;
+    int shard_index = 0, shard_count = 1, shard_layout = 0, flags = 0;
     gsr_camera cam{};
     bool same(const SortKey& o) const
     {
-        return gen == o.gen && shard_index == o.shard_index && shard_count == o.shard_count && flags == o.flags &&
+        return gen == o.gen && shard_index == o.shard_index && shard_count == o.shard_count && shard_layout == o.shard_layout && flags == o.flags &&
                std::memcmp(&cam, &o.cam, sizeof(gsr_camera)) == 0;
     }
 };
@@ -175,9 +175,9 @@ struct gsr_context {
 
     int32_t* tile_map = nullptr;       // blockIdx -> tile (XCD-aware order), -1 = idle block
     size_t map_cap = 0;
-    int map_w = 0, map_h = 0, map_si = -1, map_sc = 0, map_shift = -1, map_grid = 0;
+    int map_w = 0, map_h = 0, map_si = -1, map_sc = 0, map_rpb = -1, map_shift = -1, map_grid = 0;
 
-    int shard_index = 0, shard_count = 1;
+    int shard_index = 0, shard_count = 1, shard_layout = 0;   // layout: 0 = interleaved rows, 1 = contiguous bands
     int opt_swizzle = 1, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0, opt_lazy = 1;
 
     gsr_stats st{};
@@ -376,6 +376,7 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
     case GSR_OPT_DEBUG_FLAGS: c->opt_flags = value; break;
     case GSR_OPT_DEFERRED_CHECK: c->opt_deferred = value ? 1 : 0; break;
     case GSR_OPT_LAZY_COLOUR: c->opt_lazy = value < 0 ? 0 : (value > 2 ? 2 : value); break;
+    case GSR_OPT_SHARD_LAYOUT: c->shard_layout = value ? 1 : 0; break;
     case GSR_OPT_SUPER_TILE:
         if (value != 0 && (value < 1 || value > 16 || (value & (value - 1))))
             return set_err(GSR_E_INVALID, "gsr_set_option: super-tile edge must be 0 (auto) or 1,2,4,8,16");
@@ -579,13 +580,15 @@ extern "C" int gsr_band_rows(int height, int index, int count)
 
 extern "C" int gsr_stitch_bands(gsr_context* c, const float* gathered, int count, int width, int height, float* out)
 {
+    // (the bands were rendered with this context's shard layout: GSR_OPT_SHARD_LAYOUT)
     if (!c || !gathered || !out || count < 1 || width <= 0 || height <= 0)
         return set_err(GSR_E_INVALID, "gsr_stitch_bands: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t npx = (size_t)width * height;
     hipLaunchKernelGGL(k_stitch_bands, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream,
-                       reinterpret_cast<const float4*>(gathered), count, gsr_band_rows(height, 0, count), width, height,
-                       reinterpret_cast<float4*>(out));
+                       reinterpret_cast<const float4*>(gathered), count,
+                       (c->shard_layout == 1 && count > 1) ? ((height + GSR_TILE - 1) / GSR_TILE + count - 1) / count : 0,
+                       gsr_band_rows(height, 0, count), width, height, reinterpret_cast<float4*>(out));
     HIP_TRY(hipGetLastError());
     return GSR_OK;
 }
@@ -610,7 +613,8 @@ static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, u
 {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS, SKIP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, n,
                        n_dev, shift, sl.hist, nblk, contig);
-    hipLaunchKernelGGL(k_scan_rows, dim3(1u << DBITS), dim3(SC_THREADS), 0, sl.stream, sl.hist, nblk, sl.totals);
+    hipLaunchKernelGGL(k_scan_rows, dim3(1u << DBITS), dim3(SC_THREADS), 0, sl.stream, sl.hist, nblk, sl.totals, n_dev, n,
+                       (uint32_t)RS_TILE);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS, SKIP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA,
                        vA, kB, vB, n, n_dev, shift, sl.hist, sl.totals, nblk, contig, n_out);
     HIP_TRY(hipGetLastError());
@@ -655,6 +659,31 @@ static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& v
 // ---------------------------------------------------------------------------
 static inline float M4h(const float* m, int r, int c) { return m[c * 4 + r]; }
 
+// upper bound of the largest singular value (squared) of the 3x3 block of a GL column-major 4x4: power iteration on M^T M
+// in double, padded; the Frobenius norm (always an upper bound) if the iteration misbehaves
+static double sigma_max_sq(const float* m)
+{
+    double a[3][3], g[3][3];
+    double fro = 0.0;
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 3; ++k) { a[r][k] = M4h(m, r, k); fro += a[r][k] * a[r][k]; }
+    if (!(fro > 0.0) || !std::isfinite(fro)) return fro;
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) g[i][k] = a[0][i] * a[0][k] + a[1][i] * a[1][k] + a[2][i] * a[2][k];
+    double v[3] = {1.0, 0.7, 0.4}, lam = 0.0;
+    for (int it = 0; it < 64; ++it) {
+        double w[3];
+        for (int i = 0; i < 3; ++i) w[i] = g[i][0] * v[0] + g[i][1] * v[1] + g[i][2] * v[2];
+        const double nrm = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        if (!(nrm > 0.0)) return fro;
+        lam = nrm / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        for (int i = 0; i < 3; ++i) v[i] = w[i] / nrm;
+    }
+    // the iteration converges from below: pad generously (it only feeds a conservative cull), never above Frobenius
+    const double padded = lam * 1.02 + 1e-12;
+    return (std::isfinite(padded) && padded < fro) ? padded : fro;
+}
+
 static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f)
 {
     for (int r = 0; r < 3; ++r)
@@ -679,6 +708,7 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
     volatile float tanFovY = 1.0f / p11a;
     f->limx = 1.3f * tanFovX;
     f->limy = 1.3f * tanFovY;
+    f->sigma_vo2 = (float)(sigma_max_sq(cam->view) * sigma_max_sq(cam->object) * 1.0001);
     f->W = (float)cam->width;
     f->H = (float)cam->height;
     volatile float wp = f->W * p00;
@@ -690,7 +720,13 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
     f->tiles_y = (cam->height + GSR_TILE - 1) / GSR_TILE;
     f->shard_index = c->shard_index;
     f->shard_count = c->shard_count;
-    f->local_tiles_y = (f->tiles_y > c->shard_index) ? (f->tiles_y - c->shard_index + c->shard_count - 1) / c->shard_count : 0;
+    f->shard_rpb = (c->shard_layout == 1 && c->shard_count > 1) ? (f->tiles_y + c->shard_count - 1) / c->shard_count : 0;
+    if (f->shard_rpb > 0) {
+        const int lo = c->shard_index * f->shard_rpb, hi = std::min(lo + f->shard_rpb, f->tiles_y);
+        f->local_tiles_y = hi > lo ? hi - lo : 0;
+    } else {
+        f->local_tiles_y = (f->tiles_y > c->shard_index) ? (f->tiles_y - c->shard_index + c->shard_count - 1) / c->shard_count : 0;
+    }
     // super-tile edge: smallest power of two that leaves <= 256 super-tiles (measured best at 1080p: S=8);
     // an explicit request is a lower bound -- the counting sort (k_binning.h) keeps one LDS bin per super-tile
     int shift = 0;
@@ -731,7 +767,7 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
 static int build_tile_map(gsr_context* c, const GsrFrame& f)
 {
     if (c->map_w == f.width && c->map_h == f.height && c->map_si == c->shard_index && c->map_sc == c->shard_count &&
-        c->map_shift == f.super_shift && c->tile_map)
+        c->map_rpb == f.shard_rpb && c->map_shift == f.super_shift && c->tile_map)
         return GSR_OK;
     int rc = sync_all(c);   // a frame in flight may still be reading the old table
     if (rc) return rc;
@@ -741,8 +777,9 @@ static int build_tile_map(gsr_context* c, const GsrFrame& f)
         std::vector<int32_t>& v = per_xcd[st & 7];
         const int sx = st % f.stiles_x, sy = st / f.stiles_x;
         for (int gty = sy << f.super_shift; gty < ((sy + 1) << f.super_shift) && gty < f.tiles_y; ++gty) {
-            if (gty % c->shard_count != c->shard_index) continue;
-            const int lty = gty / c->shard_count;
+            const GsrShard sh{f.shard_index, f.shard_count, f.shard_rpb};
+            if (!gsr_shard_owns(sh, gty)) continue;
+            const int lty = f.shard_rpb > 0 ? gty - f.shard_index * f.shard_rpb : gty / c->shard_count;
             for (int tx = sx << f.super_shift; tx < ((sx + 1) << f.super_shift) && tx < f.tiles_x; ++tx)
                 v.push_back(lty * f.tiles_x + tx);
         }
@@ -761,7 +798,7 @@ static int build_tile_map(gsr_context* c, const GsrFrame& f)
     }
     HIP_TRY(hipMemcpy(c->tile_map, map.data(), map.size() * 4, hipMemcpyHostToDevice));
     c->map_grid = (int)(chunk * 8);
-    c->map_w = f.width; c->map_h = f.height; c->map_si = c->shard_index; c->map_sc = c->shard_count;
+    c->map_w = f.width; c->map_h = f.height; c->map_si = c->shard_index; c->map_sc = c->shard_count; c->map_rpb = f.shard_rpb;
     c->map_shift = f.super_shift;
     return GSR_OK;
 }
@@ -829,7 +866,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         const uint32_t nblk = div_up(j.n, BN_TILE);
         const size_t lds = (size_t)4 * BN_ITEMS * j.n_super * 8 + (size_t)4 * j.n_super * 4;
         hipLaunchKernelGGL(k_bin_place, dim3(nblk), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n, f.super_shift,
-                           f.shard_index, f.shard_count, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk,
+                           GsrShard{f.shard_index, f.shard_count, f.shard_rpb}, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk,
                            (uint32_t)sl.pair_cap, sl.pvA);
         HIP_TRY(hipGetLastError());
     }
@@ -847,7 +884,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         if (!j.direct) HIP_TRY(hipStreamWaitEvent(s, sl.ev_user, 0));
         GsrBlendArgs a;
         a.width = f.width; a.height = f.height; a.tiles_x = f.tiles_x; a.local_tiles = j.local_tiles;
-        a.shard_index = f.shard_index; a.shard_count = f.shard_count; a.band_rows = j.band_rows;
+        a.shard = GsrShard{f.shard_index, f.shard_count, f.shard_rpb}; a.band_rows = j.band_rows;
         a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
         a.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
         const unsigned grid = a.use_map ? (unsigned)c->map_grid : (unsigned)j.local_tiles;
@@ -881,7 +918,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     const FrameJob& j = sl.job;
     hipStream_t s = sl.stream;
     GsrSumArgs g;
-    g.n_tiles = j.local_tiles; g.tiles_x = j.f.tiles_x; g.shard_index = j.f.shard_index; g.shard_count = j.f.shard_count;
+    g.n_tiles = j.local_tiles; g.tiles_x = j.f.tiles_x; g.shard = GsrShard{j.f.shard_index, j.f.shard_count, j.f.shard_rpb};
     g.super_shift = j.f.super_shift; g.stiles_x = j.f.stiles_x; g.n_super = j.n_super;
     hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, g, sl.counters, sl.d_n, sl.d_frame,
                        (j.f.sh_order > 0 && c->opt_lazy) ? c->prefix : (uint32_t*)nullptr,
@@ -1079,7 +1116,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     // The depth order depends on the camera POSITION only (argsortByDistance re-sorts when the position moves,
     // src/GSplatRenderer.C:165-186) -- but the sorted list holds just the splats visible to the frame that sorted, so
     // it is reused as is only for an identical frame description (a static viewport redraw), per frame slot.
-    const SortKey key_now = {c->geo_gen, c->shard_index, c->shard_count, c->opt_flags, *cam};
+    const SortKey key_now = {c->geo_gen, c->shard_index, c->shard_count, c->shard_layout, c->opt_flags, *cam};
     const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now);
     if (n > 0) {
         // on a cache hit (identical frame description) the sorted (keyA, valA) are kept and K1's key/payload
@@ -1110,9 +1147,9 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         const uint32_t nblk = div_up(n, BN_TILE);
         rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)BN_BINS * nblk + 8);
         if (rc) return frame_abort(sl, rc);
-        hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift, c->shard_index,
-                           c->shard_count, f.stiles_x, sl.hist, nblk);
-        hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals);
+        hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift,
+                           GsrShard{f.shard_index, f.shard_count, f.shard_rpb}, f.stiles_x, sl.hist, nblk);
+        hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals, sl.d_n, n, (uint32_t)BN_TILE);
         hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, sl.totals, j.n_super, sl.sstart, sl.send, sl.h_total_dev,
                            j.ticket, (unsigned long long)GSR_MAX_PAIRS, reinterpret_cast<uint32_t*>(sl.lazy_ctr), c->lazy_hint);
         e = hipGetLastError();

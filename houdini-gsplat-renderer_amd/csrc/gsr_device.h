@@ -46,13 +46,15 @@ struct GsrFrame {
     float cam[3];
     float origin[3];
     float limx, limy;  // 1.3*tanFovX, 1.3*tanFovY
+    float sigma_vo2;   // upper bound of (largest singular value of mat3(view) x that of mat3(object))^2: K1's early ownership test
     float focal;       // (W*P00)*0.5
     float W, H;
     int32_t width, height;
     int32_t sh_order;  // already gated by SH presence
     int32_t tiles_x;   // ceil(width/16)
     int32_t tiles_y;   // ceil(height/16) (whole image)
-    int32_t shard_index, shard_count;  // tile row r is ours iff r % count == index
+    int32_t shard_index, shard_count;  // which tile rows are ours: see GsrShard
+    int32_t shard_rpb;                 // 0 = interleaved rows (r % count == index); > 0 = contiguous bands of rpb tile rows
     int32_t local_tiles_y;             // rows owned by this shard
     int32_t super;                     // super-tile edge in tiles (power of two)
     int32_t super_shift;               // log2(super)
@@ -138,34 +140,40 @@ __device__ __forceinline__ uint32_t gsr_pack_rect(int x0, int y0, int x1, int y1
 }
 #define GSR_RECT_EMPTY 0x00000001u  // x0=1 > x1=0
 
-// number of tile rows in [y0,y1] owned by shard (index,count): rows r with r%count==index
-__device__ __forceinline__ int gsr_owned_rows(int y0, int y1, int index, int count)
+// Tile-row ownership of a rank.  Two layouts:
+//   interleaved (rpb == 0): row r belongs to rank r % count -- balances any scene, but almost every splat reaches a row of
+//                           almost every rank once count is small against the splat's height in rows;
+//   bands       (rpb  > 0): rank g owns rows [g*rpb, (g+1)*rpb) -- a rank keeps ~1/count of the splats (plus a boundary
+//                           strip), and a splat's centre row alone usually tells whether it is ours (early-out in K1).
+struct GsrShard {
+    int32_t index, count, rpb;
+};
+__host__ __device__ __forceinline__ bool gsr_shard_owns(const GsrShard& sh, int r)
 {
+    return sh.rpb > 0 ? (r / sh.rpb == sh.index) : (r % sh.count == sh.index);
+}
+// global tile row of the rank's local row l
+__host__ __device__ __forceinline__ int gsr_shard_global_row(const GsrShard& sh, int l)
+{
+    return sh.rpb > 0 ? sh.index * sh.rpb + l : l * sh.count + sh.index;
+}
+// number of tile rows in [y0,y1] owned by the shard
+__host__ __device__ __forceinline__ int gsr_owned_rows(int y0, int y1, const GsrShard& sh)
+{
+    if (sh.rpb > 0) {
+        const int lo = sh.index * sh.rpb, hi = lo + sh.rpb - 1;
+        const int a = y0 > lo ? y0 : lo, b = y1 < hi ? y1 : hi;
+        return b >= a ? b - a + 1 : 0;
+    }
     // first owned row >= y0
-    int first = y0 + ((index - y0 % count) + count) % count;
+    const int first = y0 + ((sh.index - y0 % sh.count) + sh.count) % sh.count;
     if (first > y1) return 0;
-    return (y1 - first) / count + 1;
+    return (y1 - first) / sh.count + 1;
 }
 
-__device__ __forceinline__ int gsr_rect_tiles(uint32_t rect, int index, int count)
+__device__ __forceinline__ int gsr_rect_tiles(uint32_t rect, const GsrShard& sh)
 {
     int x0 = rect & 255, y0 = (rect >> 8) & 255, x1 = (rect >> 16) & 255, y1 = rect >> 24;
     if (x1 < x0 || y1 < y0) return 0;
-    return (x1 - x0 + 1) * gsr_owned_rows(y0, y1, index, count);
-}
-
-// number of SUPER-tiles (2^shift x 2^shift tiles) the rect reaches through at least one owned tile row
-__device__ __forceinline__ int gsr_rect_supers(uint32_t rect, int shift, int index, int count)
-{
-    const int x0 = rect & 255, y0 = (rect >> 8) & 255, x1 = (rect >> 16) & 255, y1 = rect >> 24;
-    if (x1 < x0 || y1 < y0) return 0;
-    const int w = (x1 >> shift) - (x0 >> shift) + 1;
-    const int sy0 = y0 >> shift, sy1 = y1 >> shift;
-    if (count == 1) return w * (sy1 - sy0 + 1);
-    int rows = 0;
-    for (int sy = sy0; sy <= sy1; ++sy) {
-        const int lo = max(y0, sy << shift), hi = min(y1, ((sy + 1) << shift) - 1);
-        rows += gsr_owned_rows(lo, hi, index, count) > 0 ? 1 : 0;
-    }
-    return w * rows;
+    return (x1 - x0 + 1) * gsr_owned_rows(y0, y1, sh);
 }

@@ -34,15 +34,15 @@
 
 // visit the owned super-tiles of a packed tile rect
 template <typename F>
-__device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, int shard_index, int shard_count, int stiles_x, F&& fn)
+__device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, const GsrShard& sh, int stiles_x, F&& fn)
 {
     const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = (rc >> 16) & 255, y1 = rc >> 24;
     if (x1 < x0 || y1 < y0) return;
     const int sx0 = x0 >> shift, sx1 = x1 >> shift;
     for (int sy = y0 >> shift; sy <= (y1 >> shift); ++sy) {
-        if (shard_count > 1) {
+        if (sh.count > 1) {
             const int lo = max(y0, sy << shift), hi = min(y1, ((sy + 1) << shift) - 1);
-            if (gsr_owned_rows(lo, hi, shard_index, shard_count) == 0) continue;
+            if (gsr_owned_rows(lo, hi, sh) == 0) continue;
         }
         const uint32_t rowkey = (uint32_t)sy * (uint32_t)stiles_x;
         for (int sx = sx0; sx <= sx1; ++sx) fn(rowkey + (uint32_t)sx);
@@ -55,7 +55,7 @@ __device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, int sh
 // same few groups -- so a lane walks its own rect only when it is small; the rect of a big splat
 // is spread over the 64 lanes (the caller's fn never assumes owner_lane == its own lane).
 template <typename F>
-__device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, int shard_index, int shard_count, int stiles_x, F&& fn)
+__device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, const GsrShard& sh, int stiles_x, F&& fn)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t rc = v.y;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, int shard_ind
     const bool some = x1 >= x0 && y1 >= y0;
     const int area = some ? ((x1 >> shift) - (x0 >> shift) + 1) * ((y1 >> shift) - (y0 >> shift) + 1) : 0;
     const bool big = area > BN_BIG;
-    if (!big) bn_for_each_super(rc, shift, shard_index, shard_count, stiles_x, [&](uint32_t d) { fn(lane, v, d); });
+    if (!big) bn_for_each_super(rc, shift, sh, stiles_x, [&](uint32_t d) { fn(lane, v, d); });
     unsigned long long bigs = __ballot(big);
     while (bigs) {
         const int L = __builtin_ctzll(bigs);
@@ -75,9 +75,9 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, int shard_ind
         const int w = (X1 >> shift) - sx0 + 1, h = (Y1 >> shift) - sy0 + 1;
         for (int t = lane; t < w * h; t += 64) {
             const int ry = t / w, sy = sy0 + ry, sx = sx0 + (t - ry * w);
-            if (shard_count > 1) {
+            if (sh.count > 1) {
                 const int lo = max(Y0, sy << shift), hi = min(Y1, ((sy + 1) << shift) - 1);
-                if (gsr_owned_rows(lo, hi, shard_index, shard_count) == 0) continue;
+                if (gsr_owned_rows(lo, hi, sh) == 0) continue;
             }
             fn(L, vL, (uint32_t)sy * (uint32_t)stiles_x + (uint32_t)sx);
         }
@@ -88,23 +88,24 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, int shard_ind
 // sized for the host-side upper bound: surplus blocks publish zeros).  Blocks are handed to XCDs
 // in contiguous eighths (rs_tile_of_block), like the depth sort's.
 __global__ void __launch_bounds__(BN_THREADS)
-k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, int shard_index,
-            int shard_count, int stiles_x, uint32_t* __restrict__ hist, uint32_t nblk)
+k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, GsrShard sh,
+            int stiles_x, uint32_t* __restrict__ hist, uint32_t nblk)
 {
     __shared__ uint32_t h[4][BN_BINS];
     const int wave = threadIdx.x >> 6;
-    for (int b = threadIdx.x; b < 4 * BN_BINS; b += BN_THREADS) (&h[0][0])[b] = 0;
-    __syncthreads();
     const uint32_t n = *n_dev;
     const uint32_t nb = (n + BN_TILE - 1) / BN_TILE;
-    const uint32_t tile = blockIdx.x < nb ? rs_tile_of_block(blockIdx.x, nb, true) : blockIdx.x;
-    if (blockIdx.x < nb) {
+    if (blockIdx.x >= nb) return;   // surplus block of the upper-bound grid: the row scan only reads the blocks that exist
+    for (int b = threadIdx.x; b < 4 * BN_BINS; b += BN_THREADS) (&h[0][0])[b] = 0;
+    __syncthreads();
+    const uint32_t tile = rs_tile_of_block(blockIdx.x, nb, true);
+    {
         const uint32_t base = tile * BN_TILE;
 #pragma unroll 2
         for (int k = 0; k < BN_ITEMS; ++k) {
             const uint32_t i = base + k * BN_THREADS + threadIdx.x;   // (every wave sees 64 consecutive splats)
             const uint2 v = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
-            bn_group_pairs(v, shift, shard_index, shard_count, stiles_x,
+            bn_group_pairs(v, shift, sh, stiles_x,
                            [&](int, uint2, uint32_t d) { atomicAdd(&h[wave][d], 1u); });
         }
     }
@@ -152,8 +153,8 @@ k_bin_ranges(const uint32_t* __restrict__ totals, int n_super, int32_t* __restri
 // total instead of several per group.
 // Dynamic LDS: lmask[4 waves][BN_ITEMS groups][ns] (u64) followed by wbase[4][ns] (u32), ns = n_super.
 __global__ void __launch_bounds__(BN_THREADS)
-k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, int shard_index,
-            int shard_count, int stiles_x, int ns, const uint32_t* __restrict__ offs, const int32_t* __restrict__ sstart,
+k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, GsrShard sh,
+            int stiles_x, int ns, const uint32_t* __restrict__ offs, const int32_t* __restrict__ sstart,
             uint32_t nblk, uint32_t cap, uint2* __restrict__ out)
 {
     extern __shared__ unsigned long long bn_lds[];
@@ -174,7 +175,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     for (int g = 0; g < BN_ITEMS; ++g) {   // (A)
         const uint32_t i = first + g * 64 + lane;
         v[g] = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
-        bn_group_pairs(v[g], shift, shard_index, shard_count, stiles_x,
+        bn_group_pairs(v[g], shift, sh, stiles_x,
                        [&](int L, uint2, uint32_t d) { atomicOr(&lmask[g * ns + d], 1ull << L); });
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -194,7 +195,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < BN_ITEMS; ++g) {   // (B)
-        bn_group_pairs(v[g], shift, shard_index, shard_count, stiles_x, [&](int L, uint2 vL, uint32_t d) {
+        bn_group_pairs(v[g], shift, sh, stiles_x, [&](int L, uint2 vL, uint32_t d) {
             uint32_t pos = wbase[d] + (uint32_t)__builtin_popcountll(lmask[g * ns + d] & ((1ull << L) - 1ull));
 #pragma unroll
             for (int e = 0; e < g; ++e) pos += (uint32_t)__builtin_popcountll(lmask[e * ns + d]);
@@ -203,17 +204,18 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     }
 }
 
-// root side of the multi-GPU path: de-interleave gathered band images.
-// gathered = count bands of band_rows x width pixels; band g holds tile rows
-// g, g+count, ... stacked bottom-up.
+// root side of the multi-GPU path: gathered band images -> frame.
+// gathered = count bands of band_rows x width pixels; band g holds rank g's tile rows stacked bottom-up
+// (interleaved layout: rows g, g+count, ...; band layout, rpb > 0: rows g*rpb ...).
 __global__ void __launch_bounds__(256)
-k_stitch_bands(const float4* __restrict__ gathered, int count, int band_rows, int width, int height,
+k_stitch_bands(const float4* __restrict__ gathered, int count, int rpb, int band_rows, int width, int height,
                float4* __restrict__ out)
 {
     const size_t p = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (p >= (size_t)width * height) return;
     const int x = (int)(p % width), y = (int)(p / width);
-    const int trow = y >> 4, g = trow % count, lrow = trow / count;
+    const int trow = y >> 4;
+    const int g = rpb > 0 ? trow / rpb : trow % count, lrow = rpb > 0 ? trow - g * rpb : trow / count;
     const int by = lrow * GSR_TILE_PX + (y & 15);
     out[p] = gathered[((size_t)g * band_rows + by) * width + x];
 }

@@ -44,7 +44,7 @@ struct GsrBlendArgs {
     int32_t width, height;      // full image
     int32_t tiles_x;            // tiles per row
     int32_t local_tiles;        // tiles_x * local_tiles_y
-    int32_t shard_index, shard_count;
+    GsrShard shard;             // which tile rows this launch owns
     int32_t band_rows;          // pixel rows of the output (band) image
     int32_t super_shift;        // log2(super-tile edge in tiles)
     int32_t stiles_x;
@@ -105,7 +105,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     if (tile < 0 || tile >= a.local_tiles) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % a.tiles_x, lty = tile / a.tiles_x;
-    const int gty = lty * a.shard_count + a.shard_index;
+    const int gty = gsr_shard_global_row(a.shard, lty);
     const int px = tx * GSR_TILE_PX + (wave & 1) * 8 + (lane & 7);
     const int py = gty * GSR_TILE_PX + (wave >> 1) * 8 + (lane >> 3);
     const bool pix_ok = (px < a.width) && (py < a.height);
@@ -393,7 +393,8 @@ k_blend_lazy(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* 
 #define SW_HEADROOM_SHIFT_ SW_HEADROOM_SHIFT
 #define SW_HEADROOM_ADD_ SW_HEADROOM_ADD
 struct GsrSumArgs {
-    int32_t n_tiles, tiles_x, shard_index, shard_count, super_shift, stiles_x, n_super;
+    int32_t n_tiles, tiles_x, super_shift, stiles_x, n_super;
+    GsrShard shard;
 };
 __global__ void __launch_bounds__(SW_THREADS)
 k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long* __restrict__ counters,
@@ -429,7 +430,7 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
             // cloud's silhouette) would ask for the whole list; such tiles have few hits and take the on-demand fallback
             if (i < g.n_tiles && !w[u].w && w[u].y) ++unsat;
             if (prefix && i < g.n_tiles && w[u].w) {
-                const int tx = i % g.tiles_x, gty = (i / g.tiles_x) * g.shard_count + g.shard_index;
+                const int tx = i % g.tiles_x, gty = gsr_shard_global_row(g.shard, i / g.tiles_x);
                 atomicMax(&s_max[(gty >> g.super_shift) * g.stiles_x + (tx >> g.super_shift)], w[u].x);
             }
         }

@@ -296,9 +296,30 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
             const float sx = gsr_h2f(b.x & 0xffffu), sy = gsr_h2f(b.x >> 16), sz = gsr_h2f(b.y & 0xffffu);
             const float qi = gsr_h2f(b.y >> 16), qj = gsr_h2f(b.z & 0xffffu), qk = gsr_h2f(b.z >> 16);
             const float qr = gsr_h2f(b.w & 0xffffu);
+            bool far_from_band = false;
 
-            float ex, ey, s1, s2;
-            const bool finite = gsr_covariance_axes(f, f.ob, x, y, z, sx, sy, sz, qi, qj, qk, qr, ex, ey, s1, s2);
+            // Band layout: most splats lie far from this rank's band of tile rows, and a cheap UPPER BOUND of the quad's
+            // vertical half extent settles that without the covariance chain (lambda1 <= trace(cov2d) <= |J|_F^2 |V|_2^2 |O|_2^2
+            // |diag(s) R^T|_F^2 + 0.6; hy <= 2 sqrt2 s1 1.0001 + 0.01).  Conservative, so it never changes what is drawn.
+            if (f.shard_rpb > 0) {
+                const float r00 = 1.0f - 2.0f * gsr_fma(qj, qj, qk * qk), r01 = 2.0f * gsr_fma(qi, qj, -(qr * qk)), r02 = 2.0f * gsr_fma(qi, qk, qr * qj);
+                const float r10 = 2.0f * gsr_fma(qi, qj, qr * qk), r11 = 1.0f - 2.0f * gsr_fma(qi, qi, qk * qk), r12 = 2.0f * gsr_fma(qj, qk, -(qr * qi));
+                const float r20 = 2.0f * gsr_fma(qi, qk, -(qr * qj)), r21 = 2.0f * gsr_fma(qj, qk, qr * qi), r22 = 1.0f - 2.0f * gsr_fma(qi, qi, qj * qj);
+                const float mf2 = sx * sx * (r00 * r00 + r10 * r10 + r20 * r20) + sy * sy * (r01 * r01 + r11 * r11 + r21 * r21) +
+                                  sz * sz * (r02 * r02 + r12 * r12 + r22 * r22);
+                const float tzb = aff4(&f.vw[8], x, y, z);
+                const float jz = f.focal / tzb;
+                const float trb = jz * jz * (2.0f + f.limx * f.limx + f.limy * f.limy) * f.sigma_vo2 * mf2 * 1.001f + 0.6f;
+                const float hb = 2.8313f * __builtin_fminf(__builtin_sqrtf(2.0f * trb), 4096.0f) + 0.02f;
+                if (hb < 1.0e9f) {   // (false for NaN / inf: those take the full path and its finite-covariance rule)
+                    const float lo_px = cy - hb - 0.5f, hi_px = cy + hb - 0.5f;
+                    const int band_lo = f.shard_index * f.shard_rpb * GSR_TILE_PX;
+                    const int band_hi = band_lo + f.shard_rpb * GSR_TILE_PX - 1;
+                    if (hi_px < (float)band_lo || lo_px > (float)band_hi) far_from_band = true;
+                }
+            }
+            float ex = 1.0f, ey = 0.0f, s1 = 0.0f, s2 = 0.0f;
+            const bool finite = !far_from_band && gsr_covariance_axes(f, f.ob, x, y, z, sx, sy, sz, qi, qj, qk, qr, ex, ey, s1, s2);
             // conservative bbox of the part of the quad where alpha can reach 1/255 (|q| <= rq <= 2)
             const float rq = (f.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius(opacity);
             const float hx = gsr_fma(rq * gsr_fma(s1, __builtin_fabsf(ex), s2 * __builtin_fabsf(ey)), 1.0001f, 0.01f);
@@ -320,7 +341,7 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
 
             // a splat none of whose tiles belong to this context's row shard is dropped here: it costs no
             // colour fetch, no record and (sentinel key below) no sorting
-            if (out_rect != GSR_RECT_EMPTY && gsr_rect_tiles(out_rect, f.shard_index, f.shard_count) == 0)
+            if (out_rect != GSR_RECT_EMPTY && gsr_rect_tiles(out_rect, GsrShard{f.shard_index, f.shard_count, f.shard_rpb}) == 0)
                 out_rect = GSR_RECT_EMPTY;
             if (out_rect != GSR_RECT_EMPTY) {
                 // colour: Cd, optionally + SH (:224, :244-274) -- or left PENDING for the lazy colour pass (k_colour.h)

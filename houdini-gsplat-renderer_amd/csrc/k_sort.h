@@ -94,15 +94,14 @@ k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n_host, const uint32_t*
     constexpr uint32_t MASK = BINS - 1;
     __shared__ uint32_t h[4][BINS];
     const int wave = threadIdx.x >> 6;
-    for (int b = threadIdx.x; b < 4 * BINS; b += RS_THREADS) (&h[0][0])[b] = 0;
-    __syncthreads();
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t nb = (n + RS_TILE - 1) / RS_TILE;   // tiles that exist (<= nblk, the grid's upper bound)
-    const uint32_t tile = blockIdx.x < nb ? rs_tile_of_block(blockIdx.x, nb, contig) : blockIdx.x;
+    if (blockIdx.x >= nb) return;                       // surplus workgroup: k_scan_rows only reads the tiles that exist
+    for (int b = threadIdx.x; b < 4 * BINS; b += RS_THREADS) (&h[0][0])[b] = 0;
+    __syncthreads();
+    const uint32_t tile = rs_tile_of_block(blockIdx.x, nb, contig);
     const uint32_t base = tile * RS_TILE;
-    if (blockIdx.x >= nb) {
-        // surplus workgroup: publishes zeros
-    } else if (base + RS_TILE <= n) {
+    if (base + RS_TILE <= n) {
         const uint4* p = reinterpret_cast<const uint4*>(keys + base);
 #pragma unroll
         for (int k = 0; k < RS_ITEMS / 4; ++k) {
@@ -126,23 +125,29 @@ k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n_host, const uint32_t*
         hist[(size_t)b * nblk + tile] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
 }
 
-// grid = BINS workgroups; workgroup d scans row d of hist in place (exclusive), total -> totals[d]
+// grid = BINS workgroups; workgroup d scans row d of hist in place (exclusive), total -> totals[d].
+// Rows are nblk entries apart; only the first `used` = ceil(items / per_block) of them hold anything (items = *n_dev when
+// the count lives on the device: the grids are sized for the host-side upper bound, the surplus blocks write nothing).
 __global__ void __launch_bounds__(SC_THREADS)
-k_scan_rows(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ totals)
+k_scan_rows(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ totals, const uint32_t* __restrict__ n_dev,
+            uint32_t n_host, uint32_t per_block)
 {
     __shared__ uint32_t s_wave[4];
     uint32_t* row = hist + (size_t)blockIdx.x * nblk;
+    const uint32_t items = n_dev ? *n_dev : n_host;
+    uint32_t used = (items + per_block - 1) / per_block;
+    if (used > nblk) used = nblk;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < nblk; base += SC_THREADS * 4) {
+    for (uint32_t base = 0; base < used; base += SC_THREADS * 4) {
         const uint32_t i0 = base + threadIdx.x * 4;
         uint32_t v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < nblk) ? row[i0 + k] : 0u;
+        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < used) ? row[i0 + k] : 0u;
         uint32_t tot;
         uint32_t ex = carry + block_excl_scan_256(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (i0 + k < nblk) row[i0 + k] = ex;
+            if (i0 + k < used) row[i0 + k] = ex;
             ex += v[k];
         }
         carry += tot;

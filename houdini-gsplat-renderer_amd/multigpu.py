@@ -22,26 +22,31 @@ def band_rows(height: int, count: int) -> int:
     return ((tiles_y(height) + count - 1) // count) * TILE
 
 
-def owned_tile_rows(height: int, index: int, count: int) -> list[int]:
-    return list(range(index, tiles_y(height), count))
+def owned_tile_rows(height: int, index: int, count: int, layout: int = 0) -> list[int]:
+    """layout 0: interleaved rows index, index+count, ...; layout 1: the contiguous band [index*rpb, (index+1)*rpb)"""
+    ty = tiles_y(height)
+    if layout == 1 and count > 1:
+        rpb = (ty + count - 1) // count
+        return list(range(index * rpb, min((index + 1) * rpb, ty)))
+    return list(range(index, ty, count))
 
 
-def extract_band(full: np.ndarray, index: int, count: int) -> np.ndarray:
+def extract_band(full: np.ndarray, index: int, count: int, layout: int = 0) -> np.ndarray:
     """what rank `index` would render: its owned tile rows of `full` stacked bottom-up"""
     h, w = full.shape[0], full.shape[1]
     out = np.zeros((band_rows(h, count), w) + full.shape[2:], dtype=full.dtype)
-    for lrow, trow in enumerate(owned_tile_rows(h, index, count)):
+    for lrow, trow in enumerate(owned_tile_rows(h, index, count, layout)):
         y0, y1 = trow * TILE, min(trow * TILE + TILE, h)
         out[lrow * TILE: lrow * TILE + (y1 - y0)] = full[y0:y1]
     return out
 
 
-def stitch_bands_host(gathered: np.ndarray, height: int) -> np.ndarray:
+def stitch_bands_host(gathered: np.ndarray, height: int, layout: int = 0) -> np.ndarray:
     """gathered [G, band_rows, W, C] -> [H, W, C]; host mirror of the k_stitch_bands kernel"""
     count = gathered.shape[0]
     out = np.zeros((height,) + gathered.shape[2:], dtype=gathered.dtype)
     for g in range(count):
-        for lrow, trow in enumerate(owned_tile_rows(height, g, count)):
+        for lrow, trow in enumerate(owned_tile_rows(height, g, count, layout)):
             y0, y1 = trow * TILE, min(trow * TILE + TILE, height)
             out[y0:y1] = gathered[g, lrow * TILE: lrow * TILE + (y1 - y0)]
     return out
@@ -52,9 +57,10 @@ class FrameGatherer:
     (already initialised: backend nccl == RCCL on ROCm, or gloo on CPU) or None for 1 rank."""
 
     def __init__(self, dist, rank: int, world: int, width: int, height: int, device, engine=None,
-                 via_host: bool = False):
+                 via_host: bool = False, layout: int = 0):
         import torch
 
+        self.layout = layout        # 0 = interleaved tile rows, 1 = contiguous bands (GSR_OPT_SHARD_LAYOUT)
         self.via_host = via_host    # functional-test mode: collective on host copies (backend without GPU support)
         self.dist, self.rank, self.world = dist, rank, world
         self.width, self.height = width, height
@@ -87,5 +93,5 @@ class FrameGatherer:
                                      self.final.data_ptr())
         else:
             import torch
-            self.final.copy_(torch.from_numpy(stitch_bands_host(self.gathered.numpy(), self.height)))
+            self.final.copy_(torch.from_numpy(stitch_bands_host(self.gathered.numpy(), self.height, self.layout)))
         return self.final

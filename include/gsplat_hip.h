@@ -130,9 +130,11 @@ int  gsr_upload(gsr_context* ctx, int64_t n,
                 const float origin[3]);
 
 /* ---- multi-GPU: tile-row shard ------------------------------------------ */
-/* This context renders only tile rows r with r % count == index (interleaved
- * for load balance).  Its output is the compact band image: the owned tile rows
- * stacked bottom-up, gsr_band_rows() pixel rows of `width` RGBA-f32 pixels. */
+/* This context renders only the tile rows of shard `index` of `count`: rows r with r % count == index (layout 0,
+ * interleaved: balances any scene) or the contiguous band [index*rpb, (index+1)*rpb), rpb = ceil(tile rows / count)
+ * (layout 1, GSR_OPT_SHARD_LAYOUT: a rank keeps ~1/count of the splats, so its sort/binning/colour work shrinks too).
+ * Its output is the compact band image: the owned tile rows stacked bottom-up, gsr_band_rows() pixel rows of `width`
+ * RGBA-f32 pixels.  The stitched frame is bit-identical to the unsharded one in either layout. */
 int  gsr_set_row_shard(gsr_context* ctx, int index, int count);
 int  gsr_band_rows(int height, int index, int count);      /* pixel rows in that band image */
 /* Root side: bands[count] gathered back to back (each padded to
@@ -236,6 +238,8 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        earlier frames (+25 % headroom); a frame whose pair count outgrows it is composited
                                        from clamped lists and counted in gsr_stats.frames_truncated (the buffer is regrown
                                        for the next frame).  The first frame after a buffer-less start is never deferred. */
+#define GSR_OPT_SHARD_LAYOUT     9   /* 0 (default) = interleaved tile rows, 1 = contiguous bands; set on every rank AND on the
+                                       context that stitches */
 #define GSR_OPT_LAZY_COLOUR      8   /* SH colours only for the splats a frame can composite (the front of every super-tile list, as
                                        deep as the previous frame scanned, with an on-demand fallback) instead of for every visible
                                        splat: 0 = never, 2 = always, 1 (default) = when it pays -- the kernels compare, every frame,

@@ -88,14 +88,16 @@ def test_radix_sort_pairs(engine, n, bits):
     assert np.array_equal(v, vals[order])
 
 
-@pytest.mark.parametrize("n,w,h,frame,big,shard", [
-    (30000, 400, 300, 0, 0, (0, 1)),
-    (20000, 1280, 720, 1, 3000, (0, 1)),      # 240 super-tiles, thousands of splats covering dozens of them each
-    (20000, 4096, 4096, 2, 500, (0, 1)),      # the maximum: 256 super-tiles of 16x16 tiles
-    (25000, 640, 480, 3, 1500, (1, 3)),       # row shard: a super-tile lists a splat only through an OWNED tile row
-    (25000, 1920, 1080, 4, 1500, (5, 8)),
+@pytest.mark.parametrize("n,w,h,frame,big,shard,layout", [
+    (30000, 400, 300, 0, 0, (0, 1), 0),
+    (20000, 1280, 720, 1, 3000, (0, 1), 0),      # 240 super-tiles, thousands of splats covering dozens of them each
+    (20000, 4096, 4096, 2, 500, (0, 1), 0),      # the maximum: 256 super-tiles of 16x16 tiles
+    (25000, 640, 480, 3, 1500, (1, 3), 0),       # row shard: a super-tile lists a splat only through an OWNED tile row
+    (25000, 1920, 1080, 4, 1500, (5, 8), 0),
+    (25000, 640, 480, 3, 1500, (1, 3), 1),       # contiguous bands (K1 drops far splats before the covariance chain)
+    (25000, 1920, 1080, 4, 1500, (5, 8), 1),
 ])
-def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine, n, w, h, frame, big, shard):
+def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine, n, w, h, frame, big, shard, layout):
     """the counting-sort binning (k_bin_count / k_bin_place): every super-tile's list holds exactly the splats
     whose tile rect reaches it (through an owned tile row), in depth order"""
     splats = pkg.scenes.make_scene(n, seed=21 + frame, sh=False)
@@ -104,6 +106,7 @@ def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine, n,
         splats.scale[:big] = sc
     cam = pkg.camera.make_camera(w, h, sh_order=0, frame=frame)
     engine.upload(splats)
+    engine.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
     engine.set_row_shard(*shard)
     try:
         engine.render(cam)
@@ -112,6 +115,7 @@ def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine, n,
         dev = engine.debug_records(splats.n)
     finally:
         engine.set_row_shard(0, 1)
+        engine.set_option(pkg.engine.OPT_SHARD_LAYOUT, 0)
     S, sx = st["super_tile"], st["stiles_x"]
     assert ls.shape[0] == st["stiles_x"] * st["stiles_y"] <= 256 and st["pairs_total"] == pv.shape[0]
     rec = oracle.preprocess(splats, cam)
@@ -126,6 +130,9 @@ def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine, n,
     ok = (i1 >= i0) & (j1 >= j0)
     tx0, tx1, ty0, ty1 = (i0 // 16).astype(np.int64), (i1 // 16).astype(np.int64), (j0 // 16).astype(np.int64), (j1 // 16).astype(np.int64)
     idx, cnt = shard
+    owned_rows = np.zeros((h + 15) // 16 + 1, np.int64)
+    owned_rows[pkg.multigpu.owned_tile_rows(h, idx, cnt, layout)] = 1
+    owned_before = np.concatenate([[0], np.cumsum(owned_rows)])      # owned rows among [0, r)
     seen = 0
     multi = 0
     for t in range(ls.shape[0]):
@@ -136,8 +143,8 @@ def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine, n,
         X0, Y0 = (t % sx) * S, (t // sx) * S
         X1, Y1 = X0 + S - 1, Y0 + S - 1
         lo, hi = np.maximum(ty0, Y0), np.minimum(ty1, Y1)          # tile rows of the rect inside this super-tile
-        first = lo + ((idx - lo % cnt) + cnt) % cnt                 # first owned row >= lo
-        hit = ok & (tx1 >= X0) & (tx0 <= X1) & (hi >= lo) & (first <= hi)
+        some_owned = (hi >= lo) & (owned_before[np.clip(hi + 1, 0, len(owned_before) - 1)] - owned_before[np.clip(lo, 0, len(owned_before) - 1)] > 0)
+        hit = ok & (tx1 >= X0) & (tx0 <= X1) & some_owned
         assert set(lst.tolist()) == set(vis[hit].tolist()), f"super-tile {t}: membership differs"
     assert seen == pv.shape[0]
     if big:
@@ -167,23 +174,29 @@ def test_edge_cases(pkg, oracle, engine):
     assert img[..., 3].max() <= 1.0 + 1e-6
 
 
-def test_row_shards_stitch_to_the_same_image(pkg, engine):
+@pytest.mark.parametrize("layout", [0, 1])
+def test_row_shards_stitch_to_the_same_image(pkg, engine, layout):
+    """interleaved tile rows (layout 0) and contiguous bands (layout 1, with K1's early ownership test)"""
     splats = pkg.scenes.make_scene(40000, seed=31, sh=True)
+    splats.scale[:300] = pkg.scenes.f16bits(np.random.default_rng(3).uniform(0.2, 2.0, size=(300, 3)))   # some span many rows
     cam = pkg.camera.make_camera(300, 200, sh_order=3, frame=2)
     engine.upload(splats)
     full = engine.render(cam)
-    tiles_y = (cam.height + 15) // 16
-    for count in (2, 3, 8):
-        out = np.zeros_like(full)
-        for idx in range(count):
-            engine.set_row_shard(idx, count)
-            band = engine.render(cam)
-            assert band.shape[0] == engine.band_rows(cam.height)
-            for lrow, trow in enumerate(range(idx, tiles_y, count)):
-                y0, y1 = trow * 16, min(trow * 16 + 16, cam.height)
-                out[y0:y1] = band[lrow * 16: lrow * 16 + (y1 - y0)]
+    engine.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
+    try:
+        for count in (2, 3, 8):
+            bands = []
+            for idx in range(count):
+                engine.set_row_shard(idx, count)
+                band = engine.render(cam)
+                assert band.shape[0] == engine.band_rows(cam.height)
+                bands.append(band)
+            engine.set_row_shard(0, 1)
+            out = pkg.multigpu.stitch_bands_host(np.stack(bands), cam.height, layout)
+            assert np.array_equal(out, full), f"layout {layout}, shard count {count}: stitched image differs"
+    finally:
         engine.set_row_shard(0, 1)
-        assert np.array_equal(out, full), f"shard count {count}: stitched image differs"
+        engine.set_option(pkg.engine.OPT_SHARD_LAYOUT, 0)
 
 
 def test_renderer_shim_frame_protocol(pkg, oracle):
@@ -283,26 +296,31 @@ def test_baseline_config_c5_4k_eight_shards_device_stitch(pkg, oracle, engine):
     G = 8
     hb = HipBuffers()
     try:
-        engine.set_row_shard(0, G)
-        rows = engine.band_rows(H)
-        gathered = hb.alloc(G * rows * W * 16)
-        final = hb.alloc(H * W * 16)
-        for g in range(G):
-            engine.set_row_shard(g, G)
-            assert engine.band_rows(H) == rows
-            engine.render_to_device(cam, gathered + g * rows * W * 16)
-        engine.set_row_shard(0, 1)
-        engine.stitch_bands(gathered, G, W, H, final)
-        engine.synchronize()
-        got = hb.download(final, (H, W, 4))
+        for layout in (0, 1):
+            engine.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
+            engine.set_row_shard(0, G)
+            rows = engine.band_rows(H)
+            gathered = hb.alloc(G * rows * W * 16)
+            final = hb.alloc(H * W * 16)
+            for g in range(G):
+                engine.set_row_shard(g, G)
+                assert engine.band_rows(H) == rows
+                engine.render_to_device(cam, gathered + g * rows * W * 16)
+            engine.set_row_shard(0, 1)
+            engine.stitch_bands(gathered, G, W, H, final)
+            engine.synchronize()
+            got = hb.download(final, (H, W, 4))
+            assert np.array_equal(got, full), f"layout {layout}"
+            hb.free()
     finally:
         engine.set_row_shard(0, 1)
+        engine.set_option(pkg.engine.OPT_SHARD_LAYOUT, 0)
         hb.free()
-    assert np.array_equal(got, full)
 
 
-@pytest.mark.parametrize("w,h,count", [(300, 200, 3), (641, 367, 2), (1920, 1080, 8), (100, 16, 5)])
-def test_stitch_bands_kernel(pkg, engine, w, h, count):
+@pytest.mark.parametrize("w,h,count,layout", [(300, 200, 3, 0), (641, 367, 2, 0), (1920, 1080, 8, 0), (100, 16, 5, 0),
+                                              (300, 200, 3, 1), (1920, 1080, 8, 1), (100, 16, 5, 1)])
+def test_stitch_bands_kernel(pkg, engine, w, h, count, layout):
     """gsr_stitch_bands (k_stitch_bands) against the host restatement of the de-interleave, on random bands"""
     rng = np.random.default_rng(w + h + count)
     rows = pkg.multigpu.band_rows(h, count)
@@ -311,12 +329,14 @@ def test_stitch_bands_kernel(pkg, engine, w, h, count):
     try:
         src = hb.upload(bands)
         dst = hb.alloc(h * w * 16)
+        engine.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
         engine.stitch_bands(src, count, w, h, dst)
         engine.synchronize()
         got = hb.download(dst, (h, w, 4))
     finally:
+        engine.set_option(pkg.engine.OPT_SHARD_LAYOUT, 0)
         hb.free()
-    assert np.array_equal(got, pkg.multigpu.stitch_bands_host(bands, h))
+    assert np.array_equal(got, pkg.multigpu.stitch_bands_host(bands, h, layout))
 
 
 def test_sort_cache_and_rotation_only_camera(pkg, oracle, engine):
@@ -577,14 +597,15 @@ def test_random_frames_match_oracle(pkg, oracle, engine, seed):
 # ---------------------------------------------------------------------------------------------
 # several GPUs from one thread (gsr_multi_*): on the 1-GPU box the ranks are contexts on the same GPU (transport COPY);
 # shard, render, gather, stitch are the code the multi-GPU node runs, only the transport of the gather differs
-@pytest.mark.parametrize("ranks", [2, 3, 8])
-def test_multi_gpu_in_library_matches_single_gpu(pkg, oracle, engine, ranks):
+@pytest.mark.parametrize("ranks,layout", [(2, 0), (3, 0), (8, 0), (3, 1), (8, 1)])
+def test_multi_gpu_in_library_matches_single_gpu(pkg, oracle, engine, ranks, layout):
     splats = pkg.scenes.make_scene(60000, seed=131, sh=True)
     cam = pkg.camera.make_camera(500, 333, sh_order=3, frame=5)
     engine.upload(splats)
     want = engine.render(cam)
     with pkg.MultiEngine([0] * ranks, pkg.engine.TRANSPORT_COPY) as M:
         assert M.count == ranks and M.transport == pkg.engine.TRANSPORT_COPY
+        M.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
         M.upload(splats)
         got = M.render(cam)
         assert np.array_equal(got, want)
@@ -592,7 +613,8 @@ def test_multi_gpu_in_library_matches_single_gpu(pkg, oracle, engine, ranks):
             c = pkg.camera.make_camera(500, 333, sh_order=3, frame=20 + f)
             assert np.array_equal(M.render(c), engine.render(c))
         vis = [M.stats(r)["n_visible"] for r in range(ranks)]
-        assert all(0 < v <= engine.stats()["n_visible"] for v in vis)     # each rank keeps only the splats of its rows
+        # each rank keeps only the splats of its rows (a rank of the band layout may own no row at all: 21 tile rows / 8)
+        assert all(0 <= v <= engine.stats()["n_visible"] for v in vis) and sum(v > 0 for v in vis) >= ranks - 1
         # device target + device depth on the root
         hb = HipBuffers()
         try:

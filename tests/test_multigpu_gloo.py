@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, height, width, q):
+def _worker(rank, world, port, height, width, layout, q):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -34,8 +34,8 @@ def _worker(rank, world, port, height, width, q):
         splats = pkg.scenes.make_scene(3000, seed=77, sh=True)       # every rank holds the full cloud
         cam = pkg.camera.make_camera(width, height, sh_order=3, frame=2)
         full = oracle.render(splats, cam)
-        fg = pkg.multigpu.FrameGatherer(dist, rank, world, width, height, "cpu")
-        fg.band.copy_(torch.from_numpy(pkg.multigpu.extract_band(full, rank, world)))
+        fg = pkg.multigpu.FrameGatherer(dist, rank, world, width, height, "cpu", layout=layout)
+        fg.band.copy_(torch.from_numpy(pkg.multigpu.extract_band(full, rank, world, layout)))
         out = fg.gather_and_stitch()
         if rank == 0:
             q.put(bool(np.array_equal(out.numpy(), full)) and bool(full[..., 3].max() > 0.1))
@@ -44,14 +44,14 @@ def _worker(rank, world, port, height, width, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height,width", [(2, 120, 100), (3, 90, 64), (2, 37, 50)])
-def test_sharded_frame_stitches_bit_identically(world, height, width):
+@pytest.mark.parametrize("world,height,width,layout", [(2, 120, 100, 0), (3, 90, 64, 0), (2, 37, 50, 0), (3, 90, 64, 1), (2, 37, 50, 1)])
+def test_sharded_frame_stitches_bit_identically(world, height, width, layout):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, height, width, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, height, width, layout, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -66,10 +66,13 @@ def test_band_geometry_matches_the_c_abi(pkg):
     for h in (1, 15, 16, 17, 37, 720, 1080, 2160):
         for g in (1, 2, 3, 4, 8):
             assert mg.band_rows(h, g) == L.gsr_band_rows(h, 0, g)
-            rows = sorted(r for i in range(g) for r in mg.owned_tile_rows(h, i, g))
-            assert rows == list(range(mg.tiles_y(h)))                 # a partition of the tile rows
+            for layout in (0, 1):
+                rows = sorted(r for i in range(g) for r in mg.owned_tile_rows(h, i, g, layout))
+                assert rows == list(range(mg.tiles_y(h)))             # a partition of the tile rows
+                assert max(len(mg.owned_tile_rows(h, i, g, layout)) for i in range(g)) * 16 == mg.band_rows(h, g)
     rng = np.random.default_rng(0)
     full = rng.random((37, 20, 4)).astype(np.float32)
     for g in (1, 2, 3, 5):
-        bands = np.stack([mg.extract_band(full, i, g) for i in range(g)])
-        assert np.array_equal(mg.stitch_bands_host(bands, 37), full)
+        for layout in (0, 1):
+            bands = np.stack([mg.extract_band(full, i, g, layout) for i in range(g)])
+            assert np.array_equal(mg.stitch_bands_host(bands, 37, layout), full)

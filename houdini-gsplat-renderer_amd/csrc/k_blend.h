@@ -408,8 +408,20 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
 {
     __shared__ unsigned long long s_sum[3];
     __shared__ uint32_t s_max[256];
-    __shared__ uint32_t s_unsat, s_est;
-    if (threadIdx.x == 0) { s_unsat = 0; s_est = 0; }
+    __shared__ uint32_t s_unsat, s_est, s_cev;
+    // Everything the tail of this kernel needs from memory is fetched NOW, next to the tile_work loads: the kernel is one
+    // workgroup at the very end of the frame, and every dependent global round trip in it (~1-2 us) is frame latency.
+    unsigned long long old2 = 0, old4 = 0, old5 = 0, old_ct = 0;
+    uint32_t nvis = 0, nredo = 0, my_len = 0, my_cev = 0;
+    if (threadIdx.x == 0) {
+        old2 = counters[2]; old4 = counters[4]; old5 = counters[5];
+        nvis = *n_visible;
+        nredo = redo_count ? *redo_count : 0u;
+        if (colour_evals) old_ct = *colour_total;
+    }
+    if (prefix && (int)threadIdx.x < g.n_super) my_len = (uint32_t)(send[threadIdx.x] - sstart[threadIdx.x]);
+    if (colour_evals && threadIdx.x < 256) my_cev = colour_evals[threadIdx.x];
+    if (threadIdx.x == 0) { s_unsat = 0; s_est = 0; s_cev = 0; }
     if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
     if (threadIdx.x < 256) s_max[threadIdx.x] = 0;
     __syncthreads();
@@ -444,35 +456,30 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
     if (prefix && (int)threadIdx.x < g.n_super) {
         const uint32_t m = s_max[threadIdx.x];
         {   // how many colour evaluations the lazy pass would make for a frame like this one
-            const uint32_t len = (uint32_t)(send[threadIdx.x] - sstart[threadIdx.x]);
             const uint32_t want = m + (m >> SW_HEADROOM_SHIFT_) + SW_HEADROOM_ADD_;
-            atomicAdd(&s_est, want < len ? want : len);
+            atomicAdd(&s_est, want < my_len ? want : my_len);
         }
         prefix[threadIdx.x] = m + (m >> SW_HEADROOM_SHIFT) + SW_HEADROOM_ADD;   // headroom for the next frame's camera move
     }
     if (colour_evals && threadIdx.x < 256) {
-        const uint32_t v = colour_evals[threadIdx.x];
         colour_evals[threadIdx.x] = 0u;
-        if (v) atomicAdd(colour_total, (unsigned long long)v);
+        if (my_cev) atomicAdd(&s_cev, my_cev);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         // Lazy colour pays when the colour pass would evaluate well under half of what eager evaluation does (it gathers
         // rows at random, eager streams them) and (almost) no tile would need the on-demand fallback.  Small or sparse
         // clouds (BASELINE C2, C3) fail one of the two; the 6 M-splat scenes pass both.
-        if (lazy_hint) *lazy_hint = (prefix && (unsigned long long)s_est * 10ull < (unsigned long long)*n_visible * 4ull &&
+        if (lazy_hint) *lazy_hint = (prefix && (unsigned long long)s_est * 10ull < (unsigned long long)nvis * 4ull &&
                                      s_unsat * 64u <= (uint32_t)g.n_tiles) ? 1u : 0u;
-        counters[1] = s_sum[1];
-        atomicAdd(&counters[2], s_sum[1]);
-        counters[3] = s_sum[0];
-        atomicAdd(&counters[4], s_sum[0]);
-        atomicAdd(&counters[5], s_sum[2]);
+        // running totals: plain read-modify-write (a slot's frames are serialised on its stream; nothing else touches them)
+        const unsigned long long t2 = old2 + s_sum[1], t4 = old4 + s_sum[0], t5 = old5 + s_sum[2];
+        counters[1] = s_sum[1]; counters[2] = t2; counters[3] = s_sum[0]; counters[4] = t4; counters[5] = t5;
+        if (colour_evals) *colour_total = old_ct + s_cev;
         // the frame's summary stays in device memory (gsr_get_stats copies 64 bytes after its stream sync): writing it
         // to mapped host memory every frame cost ~10 us of PCIe round trips at the end of the frame
-        __threadfence();
-#pragma unroll
-        for (int k = 0; k < 6; ++k) summary[k] = counters[k];
-        summary[6] = (unsigned long long)*n_visible;
-        summary[7] = redo_count ? (unsigned long long)*redo_count : 0ull;
+        summary[0] = 0ull; summary[1] = s_sum[1]; summary[2] = t2; summary[3] = s_sum[0]; summary[4] = t4; summary[5] = t5;
+        summary[6] = (unsigned long long)nvis;
+        summary[7] = (unsigned long long)nredo;
     }
 }

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""One steady-state frame as a timeline, from a rocprofv3 --kernel-trace CSV: python tools/frame_timeline.py <kernel_trace.csv>
+Start of every kernel relative to the frame's first kernel, its duration, and the idle gap before it."""
+import csv
+import sys
+
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+# a frame = from one k_preprocess to the next; take the last complete one
+starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_preprocess")]
+if len(starts) < 3:
+    sys.exit("not enough frames in the trace")
+a, b = starts[-2], starts[-1]
+t0 = int(rows[a]["Start_Timestamp"])
+prev_end = None
+busy = 0
+print("%-34s %9s %9s %8s" % ("kernel", "start us", "dur us", "gap us"))
+for r in rows[a:b]:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    gap = (s - prev_end) / 1e3 if prev_end is not None else 0.0
+    print("%-34s %9.1f %9.1f %8.1f" % (r["Kernel_Name"].split("(")[0][:34], (s - t0) / 1e3, (e - s) / 1e3, gap))
+    busy += e - s
+    prev_end = e
+span = int(rows[b]["Start_Timestamp"]) - t0
+print("frame period %.1f us, kernels busy %.1f us, idle between kernels %.1f us (%d launches)" %
+      (span / 1e3, busy / 1e3, (span - busy) / 1e3, b - a))

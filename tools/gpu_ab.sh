@@ -12,7 +12,7 @@ for v in "$@"; do
   python bench.py --no-cpu-baseline $ARGS 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d.get('stages_ms_last_frame',{})
-print('%-12s fps %7.1f  blend %.3f ' % ('$v', d['value'], d['roofline']['avg_launch_ms']) + ' '.join('%s %.3f' % (k[3:],v) for k,v in s.items()))"
+print('%-12s fps %7.1f  blend %.3f ' % ('$v', d['value'], d['roofline']['avg_launch_ms']) + ' '.join('%s %.3f' % (k[3:],v) for k,v in s.items() if k != 'note'))"
 done
 done
 cp /tmp/orig.so $L

@@ -110,7 +110,7 @@ struct FrameSlot {
     size_t hist_cap = 0;
     uint32_t* totals = nullptr;        // [512] per-digit totals of the current radix pass
     // pairs
-    uint2* pvA = nullptr;                        // super-tile lists: (splat index, packed tile rect) per entry
+    uint2* pvA = nullptr;                        // super-tile lists: (splat index, tile column/row mask) per entry
     size_t pair_cap = 0;
     int32_t *sstart = nullptr, *send = nullptr;  // super-tile ranges
     uint4* tile_work = nullptr;        // per tile: entries scanned, records gathered, wave-record evaluations
@@ -212,6 +212,14 @@ static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; 
 
 // ---------------------------------------------------------------------------
 // for the other translation units of the library (gsr_multi.cpp)
+#ifdef BL_PROFILE
+extern "C" int gsr_debug_blend_profile(unsigned long long* out16, int reset) {
+    hipDeviceSynchronize();
+    if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_blend_prof), 16 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[16] = {0}; z[11] = ~0ull; hipMemcpyToSymbol(HIP_SYMBOL(g_blend_prof), z, sizeof z); }
+    return 0;
+}
+#endif
 __attribute__((visibility("hidden"))) int gsr_internal_set_error(int code, const char* text) { return set_err(code, "%s", text); }
 void gsr_internal_comm_release(gsr_context* c);
 
@@ -984,7 +992,7 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
             dev_free(sl.pvA);
             sl.pair_cap = 0;
             const size_t want = (size_t)D + D / 4 + 4096;
-            int rc = dev_alloc(&sl.pvA, want);
+            int rc = dev_alloc(&sl.pvA, want + 4);   // (+4: the blend kernel scans in 4-entry steps)
             if (rc) return frame_abort(sl, rc);
             sl.pair_cap = want;
             c->pair_want = std::max(c->pair_want, want);   // the other frame slot grows before its next frame
@@ -1046,7 +1054,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         HIP_TRY(hipStreamSynchronize(s));
         dev_free(sl.pvA);
         sl.pair_cap = 0;
-        if ((rc = dev_alloc(&sl.pvA, c->pair_want))) return rc;
+        if ((rc = dev_alloc(&sl.pvA, c->pair_want + 4))) return rc;
         sl.pair_cap = c->pair_want;
     }
 

@@ -32,6 +32,19 @@
 
 #define BN_BIG 8                           // a splat covering more super-tiles than this is expanded by the whole wave
 
+// What a list entry carries instead of the rect: which tile columns (bits 0..15) and tile rows (bits 16..31) of super-tile
+// (sx, sy) the rect reaches.  A tile of the super-tile is inside the rect iff its column bit and its row bit are both set:
+// two instructions in the blend kernel's list scan instead of four byte compares.
+__device__ __forceinline__ uint32_t bn_tile_mask(uint32_t rc, int sx, int sy, int shift)
+{
+    const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = (rc >> 16) & 255, y1 = rc >> 24;
+    const int e = (1 << shift) - 1;
+    const int c0 = max(x0 - (sx << shift), 0), c1 = min(x1 - (sx << shift), e);
+    const int r0 = max(y0 - (sy << shift), 0), r1 = min(y1 - (sy << shift), e);
+    const uint32_t cols = ((2u << c1) - 1u) & ~((1u << c0) - 1u), rows = ((2u << r1) - 1u) & ~((1u << r0) - 1u);
+    return cols | (rows << 16);
+}
+
 // visit the owned super-tiles of a packed tile rect
 template <typename F>
 __device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, const GsrShard& sh, int stiles_x, F&& fn)
@@ -45,7 +58,7 @@ __device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, const 
             if (gsr_owned_rows(lo, hi, sh) == 0) continue;
         }
         const uint32_t rowkey = (uint32_t)sy * (uint32_t)stiles_x;
-        for (int sx = sx0; sx <= sx1; ++sx) fn(rowkey + (uint32_t)sx);
+        for (int sx = sx0; sx <= sx1; ++sx) fn(rowkey + (uint32_t)sx, sx, sy);
     }
 }
 
@@ -63,7 +76,7 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, const GsrShar
     const bool some = x1 >= x0 && y1 >= y0;
     const int area = some ? ((x1 >> shift) - (x0 >> shift) + 1) * ((y1 >> shift) - (y0 >> shift) + 1) : 0;
     const bool big = area > BN_BIG;
-    if (!big) bn_for_each_super(rc, shift, sh, stiles_x, [&](uint32_t d) { fn(lane, v, d); });
+    if (!big) bn_for_each_super(rc, shift, sh, stiles_x, [&](uint32_t d, int sx, int sy) { fn(lane, v, d, sx, sy); });
     unsigned long long bigs = __ballot(big);
     while (bigs) {
         const int L = __builtin_ctzll(bigs);
@@ -79,7 +92,7 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, const GsrShar
                 const int lo = max(Y0, sy << shift), hi = min(Y1, ((sy + 1) << shift) - 1);
                 if (gsr_owned_rows(lo, hi, sh) == 0) continue;
             }
-            fn(L, vL, (uint32_t)sy * (uint32_t)stiles_x + (uint32_t)sx);
+            fn(L, vL, (uint32_t)sy * (uint32_t)stiles_x + (uint32_t)sx, sx, sy);
         }
     }
 }
@@ -106,7 +119,7 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
             const uint32_t i = base + k * BN_THREADS + threadIdx.x;   // (every wave sees 64 consecutive splats)
             const uint2 v = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
             bn_group_pairs(v, shift, sh, stiles_x,
-                           [&](int, uint2, uint32_t d) { atomicAdd(&h[wave][d], 1u); });
+                           [&](int, uint2, uint32_t d, int, int) { atomicAdd(&h[wave][d], 1u); });
         }
     }
     __syncthreads();
@@ -176,7 +189,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
         const uint32_t i = first + g * 64 + lane;
         v[g] = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
         bn_group_pairs(v[g], shift, sh, stiles_x,
-                       [&](int L, uint2, uint32_t d) { atomicOr(&lmask[g * ns + d], 1ull << L); });
+                       [&](int L, uint2, uint32_t d, int, int) { atomicOr(&lmask[g * ns + d], 1ull << L); });
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -195,11 +208,11 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < BN_ITEMS; ++g) {   // (B)
-        bn_group_pairs(v[g], shift, sh, stiles_x, [&](int L, uint2 vL, uint32_t d) {
+        bn_group_pairs(v[g], shift, sh, stiles_x, [&](int L, uint2 vL, uint32_t d, int sx, int sy) {
             uint32_t pos = wbase[d] + (uint32_t)__builtin_popcountll(lmask[g * ns + d] & ((1ull << L) - 1ull));
 #pragma unroll
             for (int e = 0; e < g; ++e) pos += (uint32_t)__builtin_popcountll(lmask[e * ns + d]);
-            if (pos < cap) out[pos] = vL;
+            if (pos < cap) out[pos] = make_uint2(vL.x, bn_tile_mask(vL.y, sx, sy, shift));
         });
     }
 }

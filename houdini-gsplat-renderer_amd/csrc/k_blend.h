@@ -29,16 +29,27 @@
 #include "k_preprocess.h"   // gsr_splat_colour_from_row (on-demand colour of the lazy path)
 
 #ifndef BL_ROUND
-#define BL_ROUND 64           // records composited per round.  The kernel wants waves per SIMD: measured on C4
-                              // 256 -> 0.40 ms (57 KB LDS, 2 workgroups/CU), 128 -> 0.295, 64 -> 0.278, 32 -> 0.30 (barriers)
+#define BL_ROUND 64           // records a wave gathers, tests and stages at a time (= lanes)
 #endif
 #ifndef BL_WAVES_PER_EU
 #define BL_WAVES_PER_EU 6     // 80 VGPRs (8 dwords of spill) instead of 94: 0.278 -> 0.270 ms
 #endif
-#define BL_SCAN_K 4           // list entries scanned per thread per scan step
-#define BL_QCAP 2048          // hit-queue ring capacity (>= BL_ROUND + 2 * BL_SCAN_K * 256)
+#ifndef BL_BATCH
+#define BL_BATCH 256          // queued hits handed to the waves between two workgroup barriers (a multiple of 64): measured on
+                              // C4 64 -> 0.195 ms, 128 -> 0.190, 256 -> 0.187.  Requesting the next sub-round's records ahead of
+                              // the inner loop (12 more registers: 5 waves per SIMD) measured 0.196: latency is covered already
+#endif
+#define BL_QCAP 2048          // hit-queue ring capacity (>= BL_BATCH + the 1024 entries of a scan step)
 #define BL_PAIR_F4_MAX 6      // float4s per staged record PAIR: 5 (80 B), 6 with the depth test
 #define GSR_T_MIN 6.103515625e-05f  // 2^-14
+
+// BL_PROFILE (variant builds only, tools/blend_phases.py): per-wave shader-clock time of each phase, summed over the launch
+#ifdef BL_PROFILE
+__device__ unsigned long long g_blend_prof[16];
+#define BLP(i) { const long long now_ = clock64(); prof[i] += (unsigned long long)(now_ - tlast); tlast = now_; }
+#else
+#define BLP(i)
+#endif
 
 struct GsrBlendArgs {
     int32_t width, height;      // full image
@@ -86,12 +97,9 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     constexpr int PF4 = HAS_DEPTH ? 6 : 5;
     __shared__ float4 slist[4][(BL_ROUND / 2) * PF4];
     __shared__ uint32_t q[BL_QCAP];   // hit queue: splat indices in list (= depth) order
-    __shared__ uint32_t scnt[2][BL_SCAN_K][4];
-    __shared__ unsigned long long swcnt[2][4];   // per gathering wave: 4 x 16-bit counts of records reaching quadrant 0..3
+    __shared__ __attribute__((aligned(16))) uint32_t scnt[2][4];   // hits of each wave in a scan step
     __shared__ uint32_t sdone[2][4];
-    __shared__ uint32_t sfetched, sevals, sredo;
-    __shared__ float4 spark[BL_ROUND];   // the gathered (r, g, b, opacity) waits here between gather and staging: LDS
-                                         // instead of three VGPRs the register allocator would spill to scratch
+    __shared__ uint32_t sevals, sredo;
 
     // Workgroup b runs on XCD b%8 (observed dispatch order, MI355X guide): tile_map hands each
     // XCD whole super-tiles, whose 64 tiles read the same list and gather the same records.
@@ -104,6 +112,11 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     }
     if (tile < 0 || tile >= a.local_tiles) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef BL_PROFILE
+    unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = clock64();
+    const unsigned long long wall0 = wall_clock64();   // constant 100 MHz, the same on every CU
+#endif
     const int tx = tile % a.tiles_x, lty = tile / a.tiles_x;
     const int gty = gsr_shard_global_row(a.shard, lty);
     const int px = tx * GSR_TILE_PX + (wave & 1) * 8 + (lane & 7);
@@ -111,9 +124,10 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     const bool pix_ok = (px < a.width) && (py < a.height);
     // pixel index inside the tile (contract v2: fragment positions are relative to the tile origin)
     const gsr_v2f lx = (gsr_v2f)((float)((wave & 1) * 8 + (lane & 7))), ly = (gsr_v2f)((float)((wave >> 1) * 8 + (lane >> 3)));
-    // tile bounds in pixel-centre coordinates, for the quadrant masks
+    // first pixel centre of the tile, and the centre of this wave's quadrant box of pixel centres
     const float tcx0 = (float)(tx * GSR_TILE_PX) + 0.5f, tcy0 = (float)(gty * GSR_TILE_PX) + 0.5f;
-    if (tid == 0) { sfetched = 0; sevals = 0; sredo = 0; }
+    const float qcx = tcx0 + 3.5f + 8.0f * (float)(wave & 1), qcy = tcy0 + 3.5f + 8.0f * (float)(wave >> 1);
+    if (tid == 0) { sevals = 0; sredo = 0; }
     uint32_t my_evals = 0;            // (wave-uniform) records this wave evaluated for its 64 pixels
     // depth test against what the opaque pass left (depth writes stay off): a fragment survives iff its quad's
     // window depth <= depth[pixel] (src/GSplatRenderer.C:595-610).  No depth buffer = +inf.
@@ -127,174 +141,144 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     gsr_v2f C01 = {0.0f, 0.0f};   // {C0, C1} as a register pair
     float C2 = 0.0f, T = 1.0f;    // blue, transmittance 1 - A
     bool wave_done = false;
-    uint32_t my_fetched = 0;
+    uint32_t fetched = 0;             // (uniform) queued hits handed to the waves
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    auto tile_in = [&](uint32_t rc) {
-        const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = (rc >> 16) & 255, y1 = rc >> 24;
-        return tx >= x0 && tx <= x1 && gty >= y0 && gty <= y1;
-    };
 
     // ---- scan state (identical in every thread)
     int scan_pos = 0;                 // next list entry to scan
     uint32_t q_head = 0, q_tail = 0;  // monotonic; slot = counter & (BL_QCAP-1)
     int spar = 0;
-    uint2 pre[BL_SCAN_K];             // entries of the next scan step, prefetched
-#pragma unroll
-    for (int k = 0; k < BL_SCAN_K; ++k) {
-        const int i = k * 256 + tid;
-        pre[k] = (i < n) ? svals[s + i] : make_uint2(0u, GSR_RECT_EMPTY);
-    }
+    // A list entry is (splat index, tile mask): bit c of the low half = the splat's rect reaches tile column c of the
+    // super-tile, bit 16 + r = tile row r (k_bin_place).  This tile is in the rect iff both of ITS bits are set.
+    const uint32_t sub_mask = (1u << a.super_shift) - 1u;
+    const uint32_t tile_bits = (1u << (tx & sub_mask)) | (0x10000u << (gty & sub_mask));
+    // thread t scans entries 4t .. 4t+3 of a 1024-entry step: two 16-byte loads, prefetched one step ahead
+    typedef uint32_t gsr_u4 __attribute__((ext_vector_type(4), aligned(8)));
+    gsr_u4 preA = {0u, 0u, 0u, 0u}, preB = {0u, 0u, 0u, 0u};
+    auto prefetch = [&]() __attribute__((always_inline)) {
+        const int i = scan_pos + 4 * tid;
+        if (i < n) {   // (may read up to three entries past the list's end: masked below; the buffer is padded)
+            const gsr_u4* src = reinterpret_cast<const gsr_u4*>(svals + s + i);
+            preA = src[0]; preB = src[1];
+        }
+    };
+    prefetch();
     int round = 0;
     bool saturated = false;           // left because every pixel is opaque, not because the list ended
 
+    BLP(0)
     for (;;) {
-        // (1) SCAN until a round's worth of hits is queued, or the list ends
+        // (1) SCAN until a batch of hits is queued, or the list ends
         bool scanned_any = false;
-        while ((int)(q_tail - q_head) < BL_ROUND && scan_pos < n) {
-            uint32_t rank[BL_SCAN_K];
-            bool hit[BL_SCAN_K];
-#pragma unroll
-            for (int k = 0; k < BL_SCAN_K; ++k) {
-                hit[k] = tile_in(pre[k].y);          // padding entries carry an empty rect
-                const unsigned long long bal = __ballot(hit[k]);
-                rank[k] = (uint32_t)__builtin_popcountll(bal & lt_mask);
-                if (lane == 0) scnt[spar][k][wave] = (uint32_t)__builtin_popcountll(bal);
-            }
+        while ((int)(q_tail - q_head) < BL_BATCH && scan_pos < n) {
+            const int rem = n - (scan_pos + 4 * tid);   // entries of this thread that exist
+            const bool h0 = rem > 0 && (preA.y & tile_bits) == tile_bits, h1 = rem > 1 && (preA.w & tile_bits) == tile_bits;
+            const bool h2 = rem > 2 && (preB.y & tile_bits) == tile_bits, h3 = rem > 3 && (preB.w & tile_bits) == tile_bits;
+            const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1), b2 = __ballot(h2), b3 = __ballot(h3);
+            // hits of the lower lanes: v_mbcnt accumulates, eight instructions for the four ballots
+            uint32_t pos = 0;
+            pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, pos));
+            pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, pos));
+            pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, pos));
+            pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, pos));
+            const uint32_t wtot = (uint32_t)(__builtin_popcountll(b0) + __builtin_popcountll(b1) + __builtin_popcountll(b2) +
+                                             __builtin_popcountll(b3));
+            if (lane == 0) scnt[spar][wave] = wtot;
             __syncthreads();
-            uint32_t tot = 0, mybase[BL_SCAN_K];
-#pragma unroll
-            for (int k = 0; k < BL_SCAN_K; ++k)
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    if (w == wave) mybase[k] = tot;
-                    tot += scnt[spar][k][w];
-                }
-#pragma unroll
-            for (int k = 0; k < BL_SCAN_K; ++k)
-                if (hit[k]) q[(q_tail + mybase[k] + rank[k]) & (BL_QCAP - 1)] = pre[k].x;
-            q_tail += tot;
-            scan_pos += BL_SCAN_K * 256;
+            const uint4 wt = *reinterpret_cast<const uint4*>(scnt[spar]);
+            pos += q_tail + (wave > 0 ? wt.x : 0u) + (wave > 1 ? wt.y : 0u) + (wave > 2 ? wt.z : 0u);
+            if (h0) { q[pos & (BL_QCAP - 1)] = preA.x; ++pos; }
+            if (h1) { q[pos & (BL_QCAP - 1)] = preA.z; ++pos; }
+            if (h2) { q[pos & (BL_QCAP - 1)] = preB.x; ++pos; }
+            if (h3) { q[pos & (BL_QCAP - 1)] = preB.z; }
+            q_tail += wt.x + wt.y + wt.z + wt.w;
+            scan_pos += 1024;
             spar ^= 1;
             scanned_any = true;
-#pragma unroll
-            for (int k = 0; k < BL_SCAN_K; ++k) {   // prefetch the next step's entries
-                const int i = scan_pos + k * 256 + tid;
-                pre[k] = (i < n) ? svals[s + i] : make_uint2(0u, GSR_RECT_EMPTY);
-            }
+            prefetch();
         }
         if (scanned_any) __syncthreads();            // queue writes visible to every wave
+        BLP(1)
 
-        // (2) gather this round's records: thread t takes the t-th queued hit
+        // (2) every wave on its own from here to the end of the batch: the queued hits in sub-rounds of 64.  Lane l takes
+        // the l-th hit, loads its record (the four waves load the same lines: L1 hits), tests it against THIS wave's 8x8
+        // quadrant only, and the surviving records go -- still in depth order, by ballot rank -- into the wave's own LDS list.
+        // No other wave reads that list, so nothing between here and the end of the batch needs a workgroup barrier.
         const int avail = (int)(q_tail - q_head);
-        const int take = avail < BL_ROUND ? avail : BL_ROUND;
+        const int take = avail < BL_BATCH ? avail : BL_BATCH;
         if (take == 0) break;                         // list exhausted and queue empty
-        const bool have = tid < take;
-        float4 r0, r1, r2;
-        float rz = 0.0f, c0 = 0.0f, c1 = 0.0f;
-        uint32_t m = 0;
-        if (have) {
-            const uint32_t ridx = q[(q_head + tid) & (BL_QCAP - 1)];
-            const float4* p = reinterpret_cast<const float4*>(recs + ridx);
-            r0 = p[0]; r1 = p[1]; r2 = p[2];
-            const uint32_t tag = __builtin_bit_cast(uint32_t, r2.x);
-            if (tag == GSR_COLOUR_PENDING) {
-                if (LAZY) gsr_splat_colour_from_row(lz.f, lz.colrow, ridx, r2.x, r2.y, r2.z);
-                else sredo = 1u;   // the colour pass did not reach this record: give the tile to the LAZY instantiation
-            }
-            spark[tid] = r2;
-            rz = HAS_DEPTH ? zwin[ridx] : 0.0f;
-            ++my_fetched;
-            // Which 8x8 quadrants can the splat touch?  Separating-axis test of the oriented quad
-            // (shrunk to the radius where alpha can still reach 1/255) against each quadrant's box of
-            // pixel centres: the box axes (= bbox test) and the quad's own two axes.  Conservative.
-            // r0 = (cx, cy, hx, hy), r1 = (a1x, a1y, b1x, b1y) = kappa e/s1, kappa e_perp/s2, r2 = (r, g, b, opacity)
-            const float rqk = (((a.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius(r2.w)) + 1.0e-3f) * GSR_KAPPA;
-            const float bx0 = r0.x - r0.z, bx1 = r0.x + r0.z, by0 = r0.y - r0.w, by1 = r0.y + r0.w;
-            const bool xl = bx0 <= tcx0 + 7.0f, xr = bx1 >= tcx0 + 8.0f;
-            const bool yb = by0 <= tcy0 + 7.0f, yt = by1 >= tcy0 + 8.0f;
-            // radius of a quadrant's box of pixel centres along each (scaled) quad axis
-            const float lim1 = rqk + 3.5f * (__builtin_fabsf(r1.x) + __builtin_fabsf(r1.y));
-            const float lim2 = rqk + 3.5f * (__builtin_fabsf(r1.z) + __builtin_fabsf(r1.w));
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const float ddx = (tcx0 + 3.5f + 8.0f * (float)(qd & 1)) - r0.x;
-                const float ddy = (tcy0 + 3.5f + 8.0f * (float)(qd >> 1)) - r0.y;
-                const float pu = __builtin_fabsf(ddx * r1.x + ddy * r1.y);
-                const float pv = __builtin_fabsf(ddx * r1.z + ddy * r1.w);
-                const bool box = ((qd & 1) ? xr : xl) && ((qd >> 1) ? yt : yb);
-                if (box && (((a.flags & GSR_FLAG_NO_SAT) != 0) || (pu <= lim1 && pv <= lim2))) m |= 1u << qd;
-            }
-            // the record's two affine forms at the tile origin (contract v2, same operations as the oracle)
-            const float d0x = tcx0 - r0.x, d0y = tcy0 - r0.y;
-            c0 = gsr_fma(d0x, r1.x, d0y * r1.y);
-            c1 = gsr_fma(d0x, r1.z, d0y * r1.w);
-        }
-        // (3) per-quadrant list positions: rank inside this gathering wave now, wave bases after the barrier
-        uint32_t rnk[4];
-        unsigned long long wcnt = 0;
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const unsigned long long bal = __ballot((m >> qd) & 1u);
-            rnk[qd] = (uint32_t)__builtin_popcountll(bal & lt_mask);
-            wcnt |= (unsigned long long)__builtin_popcountll(bal) << (16 * qd);
-        }
-        const int rpar = round & 1;
-        if (lane == 0) { swcnt[rpar][wave] = wcnt; sdone[rpar][wave] = wave_done ? 1u : 0u; }
-        __syncthreads();
-        if (!LAZY && sredo) {   // (uniform: read after the barrier that follows every gather)
-            if (tid == 0 && lz.redo) lz.redo[atomicAdd(lz.redo_count, 1u)] = tile;
-            return;
-        }
-        const bool block_done = (sdone[rpar][0] & sdone[rpar][1] & sdone[rpar][2] & sdone[rpar][3]) != 0u;
-        if (block_done) { saturated = true; break; }
-        unsigned long long base = 0, total = 0;   // 4 x 16-bit fields (a field is at most BL_ROUND)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const unsigned long long c = swcnt[rpar][g];
-            if (g < wave) base += c;
-            total += c;
-        }
-        if (m) {
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                if (!((m >> qd) & 1u)) continue;
-                const uint32_t pos = (uint32_t)((base >> (16 * qd)) & 0xffffu) + rnk[qd];
-                float* blk = reinterpret_cast<float*>(&slist[qd][(pos >> 1) * PF4]);
-                const uint32_t h = pos & 1u;
-                blk[0 + h] = r1.x; blk[2 + h] = r1.y; blk[4 + h] = r1.z; blk[6 + h] = r1.w;
-                blk[8 + h] = c0; blk[10 + h] = c1;
-                reinterpret_cast<float4*>(blk)[3 + h] = spark[tid];
-                if (HAS_DEPTH) blk[20 + h] = rz;
-            }
-        }
-        if (tid < 4) {   // odd list: pad with a record that cannot contribute (opacity 0 -> alpha 0 < 1/255)
-            const uint32_t cnt = (uint32_t)((total >> (16 * tid)) & 0xffffu);
-            if (cnt & 1u) {
-                float* blk = reinterpret_cast<float*>(&slist[tid][(cnt >> 1) * PF4]);
-                blk[1] = 0.0f; blk[3] = 0.0f; blk[5] = 0.0f; blk[7] = 0.0f;
-                blk[9] = 0.0f; blk[11] = 0.0f;
-                // colour and opacity 0 (the axes may be stale garbage: a NaN there is rejected by the quad test).  The zero is
-                // made in place: hipcc would otherwise keep a float4 of zeros live across the whole loop -- and spill it.
-                float z;
-                asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-                blk[16] = z; blk[17] = z; blk[18] = z; blk[19] = z;
-                if (HAS_DEPTH) blk[21] = 0.0f;
-            }
-        }
-        q_head += (uint32_t)take;
-        __syncthreads();
-
-        // (4) composite: wave w walks ITS list, two records per iteration in packed FP32
+        fetched += (uint32_t)take;
+        BLP(2)
         if (!wave_done) {
-            // (wave-uniform by construction; readfirstlane tells the compiler, so the loop runs on the scalar unit)
-            const int cnt = __builtin_amdgcn_readfirstlane((int)((total >> (16 * wave)) & 0xffffu));
-            const int npairs = (cnt + 1) >> 1;
-            const float4* L = slist[wave];
-            int p = 0;
-            while (p < npairs) {
-                const int pend = (p + 32 < npairs) ? p + 32 : npairs;
-                for (; p < pend; ++p) {
+            for (int sub = 0; sub < take; sub += 64) {
+                const bool have = sub + lane < take;
+                float4 r1, r2;
+                float rz = 0.0f, c0 = 0.0f, c1 = 0.0f;
+                bool hit = false, pending = false;
+                if (have) {
+                    const uint32_t ridx = q[(q_head + (uint32_t)(sub + lane)) & (BL_QCAP - 1)];
+                    const float4* p = reinterpret_cast<const float4*>(recs + ridx);
+                    const float4 r0 = p[0];
+                    r1 = p[1]; r2 = p[2];
+                    rz = HAS_DEPTH ? zwin[ridx] : 0.0f;
+                    // Can the splat touch this quadrant?  Separating-axis test of the oriented quad (shrunk to the radius
+                    // where alpha can still reach 1/255) against the quadrant's box of pixel centres: the box axes (= bbox
+                    // test) and the quad's own two axes.  Conservative.
+                    // r0 = (cx, cy, hx, hy), r1 = (a1x, a1y, b1x, b1y) = kappa e/s1, kappa e_perp/s2, r2 = (r, g, b, opacity)
+                    const float rqk = (((a.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius_fast(r2.w)) + 1.0e-3f) * GSR_KAPPA;
+                    const float ddx = qcx - r0.x, ddy = qcy - r0.y;
+                    // (hx, hy carry K1's own margin of 1e-4 relative + 0.01 px)
+                    const bool box = __builtin_fmaxf(__builtin_fabsf(ddx) - r0.z, __builtin_fabsf(ddy) - r0.w) <= 3.5f;
+                    // radius of the quadrant's box of pixel centres along each (scaled) quad axis
+                    const float lim1 = rqk + 3.5f * (__builtin_fabsf(r1.x) + __builtin_fabsf(r1.y));
+                    const float lim2 = rqk + 3.5f * (__builtin_fabsf(r1.z) + __builtin_fabsf(r1.w));
+                    const float pu = __builtin_fabsf(ddx * r1.x + ddy * r1.y);
+                    const float pv = __builtin_fabsf(ddx * r1.z + ddy * r1.w);
+                    hit = box && (((a.flags & GSR_FLAG_NO_SAT) != 0) || (pu <= lim1 && pv <= lim2));
+                    pending = __builtin_bit_cast(uint32_t, r2.x) == GSR_COLOUR_PENDING;
+                    if (LAZY) {
+                        if (hit && pending) gsr_splat_colour_from_row(lz.f, lz.colrow, ridx, r2.x, r2.y, r2.z);
+                    }
+                    // the record's two affine forms at the tile origin (contract v2, same operations as the oracle)
+                    const float d0x = tcx0 - r0.x, d0y = tcy0 - r0.y;
+                    c0 = gsr_fma(d0x, r1.x, d0y * r1.y);
+                    c1 = gsr_fma(d0x, r1.z, d0y * r1.w);
+                }
+                if (!LAZY && __any(pending)) {   // the colour pass did not reach this record: the tile goes to the LAZY instantiation
+                    if (lane == 0) sredo = 1u;   // (every wave that is still compositing sees the same records)
+                    wave_done = true;
+                    break;
+                }
+                const unsigned long long bal = __ballot(hit);
+                const int cnt = (int)__builtin_popcountll(bal);     // wave-uniform (scalar)
+                if (hit) {
+                    const uint32_t pos = (uint32_t)__builtin_popcountll(bal & lt_mask);
+                    float* blk = reinterpret_cast<float*>(&slist[wave][(pos >> 1) * PF4]);
+                    const uint32_t h = pos & 1u;
+                    blk[0 + h] = r1.x; blk[2 + h] = r1.y; blk[4 + h] = r1.z; blk[6 + h] = r1.w;
+                    blk[8 + h] = c0; blk[10 + h] = c1;
+                    reinterpret_cast<float4*>(blk)[3 + h] = r2;
+                    if (HAS_DEPTH) blk[20 + h] = rz;
+                }
+                if ((cnt & 1) && lane == 0) {   // odd list: pad with a record that cannot contribute (opacity 0 -> alpha 0 < 1/255)
+                    float* blk = reinterpret_cast<float*>(&slist[wave][(cnt >> 1) * PF4]);
+                    blk[1] = 0.0f; blk[3] = 0.0f; blk[5] = 0.0f; blk[7] = 0.0f;
+                    blk[9] = 0.0f; blk[11] = 0.0f;
+                    // colour and opacity 0 (the axes may be stale garbage: a NaN there is rejected by the quad test)
+                    reinterpret_cast<float4*>(blk)[4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (HAS_DEPTH) blk[21] = 0.0f;
+                }
+                // the list is written and read by this wave only: LDS operations of one wave execute in order
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                BLP(3)
+
+                // (3) composite: the wave walks its list, two records per iteration in packed FP32
+                const int npairs = (cnt + 1) >> 1;
+                const float4* L = slist[wave];
+                auto blend_pair = [&](int p, gsr_v2f& C01, float& C2, float& T) __attribute__((always_inline)) {
                     const float4 v0 = L[p * PF4 + 0], v1 = L[p * PF4 + 1], v2 = L[p * PF4 + 2];
                     const float4 v3 = L[p * PF4 + 3], v4 = L[p * PF4 + 4];
                     // kappa * (quad-local coordinate) of this pixel for the two records
@@ -326,14 +310,33 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     C01 = gsr_fma2((gsr_v2f)(wb), (gsr_v2f){v4.x, v4.y}, C01);
                     C2 = gsr_fma(wb, v4.z, C2);
                     T = T - wb;
+                };
+#ifdef BL_EXP_DOUBLE   // experiment: the inner loop a second time on shadow accumulators (its marginal cost = the time difference)
+                {
+                    gsr_v2f sC01 = C01; float sC2 = C2, sT = T;
+                    for (int p2 = 0; p2 < npairs; ++p2) blend_pair(p2, sC01, sC2, sT);
+                    if (sT == 123.0f) { C2 += sC2 + sC01.x; }
                 }
+#endif
+                for (int p = 0; p < npairs; ++p) blend_pair(p, C01, C2, T);
+                my_evals += (uint32_t)cnt;
+                BLP(4)
                 if (__all(!pix_ok || T < GSR_T_MIN)) { wave_done = true; break; }
+                __builtin_amdgcn_wave_barrier();   // (the next sub-round overwrites the list)
             }
-            const int evald = 2 * p;
-            my_evals += (uint32_t)(evald < cnt ? evald : cnt);
         }
+        q_head += (uint32_t)take;
+        const int rpar = round & 1;
+        if (lane == 0) sdone[rpar][wave] = wave_done ? 1u : 0u;
         ++round;
-        __syncthreads();   // the lists (and consumed queue slots) may be overwritten from here on
+        BLP(5)
+        __syncthreads();   // the consumed queue slots may be overwritten from here on; every wave's verdict is in
+        BLP(6)
+        if (!LAZY && sredo) {   // (uniform: written before the barrier)
+            if (tid == 0 && lz.redo) lz.redo[atomicAdd(lz.redo_count, 1u)] = tile;
+            return;
+        }
+        if ((sdone[rpar][0] & sdone[rpar][1] & sdone[rpar][2] & sdone[rpar][3]) != 0u) { saturated = true; break; }
     }
     if (pix_ok) {
         // (pixel coordinates re-derived from an opaque copy of the thread id: keeping them live across the loop costs a spill)
@@ -344,16 +347,27 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         const int bcol = tx * GSR_TILE_PX + (w2 & 1) * 8 + (l2 & 7);
         out[(size_t)brow * a.width + bcol] = make_float4(C01.x, C01.y, C2, 1.0f - T);
     }
-    // bookkeeping for the roofline: list entries scanned and records gathered by this tile
+    BLP(8)
+#ifdef BL_PROFILE
+    if (lane == 0) {
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) my_fetched += __shfl_down(my_fetched, d, 64);
-    __syncthreads();  // orders the sfetched = 0 store when the list was empty
-    if (lane == 0) { atomicAdd(&sfetched, my_fetched); atomicAdd(&sevals, my_evals); }
+        for (int i = 0; i < 9; ++i) atomicAdd(&g_blend_prof[i], prof[i]);
+        atomicAdd(&g_blend_prof[9], 1ull);
+        atomicAdd(&g_blend_prof[10], (unsigned long long)round);
+        const unsigned long long wall1 = wall_clock64();
+        atomicMin(&g_blend_prof[11], wall0);
+        atomicMax(&g_blend_prof[12], wall1);
+        atomicAdd(&g_blend_prof[13], wall1 - wall0);
+    }
+#endif
+    // bookkeeping for the roofline: list entries scanned and records gathered by this tile
+    __syncthreads();  // orders the sevals = 0 store when the list was empty
+    if (lane == 0) atomicAdd(&sevals, my_evals);
     __syncthreads();
     if (tid == 0) {
         // entries actually read: everything up to scan_pos plus the prefetched step
-        const int rd = scan_pos + BL_SCAN_K * 256;
-        tile_work[tile] = make_uint4((uint32_t)(rd < n ? rd : n), sfetched, sevals, saturated ? 1u : 0u);
+        const int rd = scan_pos + 1024;
+        tile_work[tile] = make_uint4((uint32_t)(rd < n ? rd : n), fetched, sevals, saturated ? 1u : 0u);
     }
 }
 

@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the cpu_baseline leg")
     ap.add_argument("--no-swizzle", action="store_true", help="disable the XCD-aware tile mapping (A/B)")
+    ap.add_argument("--tile-order", type=int, default=2, help="1 = XCD-aware static tile order, 2 = + heaviest tiles first (A/B)")
     ap.add_argument("--super-tile", type=int, default=0, help="super-tile edge in tiles (0 = auto) (A/B)")
     ap.add_argument("--flags", type=int, default=0, help="GSR_OPT_DEBUG_FLAGS (A/B)")
     ap.add_argument("--stage-timing", type=int, default=1, choices=(1, 2),
@@ -178,7 +179,7 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
-    eng.set_option(pkg.engine.OPT_XCD_SWIZZLE, 0 if args.no_swizzle else 1)
+    eng.set_option(pkg.engine.OPT_XCD_SWIZZLE, 0 if args.no_swizzle else args.tile_order)
     eng.set_option(pkg.engine.OPT_SUPER_TILE, args.super_tile)
     eng.set_option(pkg.engine.OPT_DEBUG_FLAGS, args.flags)
     eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, args.frames_in_flight)

@@ -116,6 +116,12 @@ struct FrameSlot {
     uint4* tile_work = nullptr;        // per tile: entries scanned, records gathered, wave-record evaluations
     size_t tile_cap = 0;
     int32_t* redo = nullptr;           // lazy colour: tiles the plain blend kernel gave up (tile_cap entries)
+    int32_t* order = nullptr;          // blockIdx -> tile, heaviest tiles first: written by k_tile_order at the end of a frame
+    size_t order_cap = 0;              //   for this slot's next frame (valid while the tile geometry stays what it was)
+    bool order_valid = false;
+    int order_sig[6] = {0, 0, 0, 0, 0, 0}, order_per_xcd = 0;
+    uint32_t* sup_work = nullptr;      // [2][256] per-super-tile work sums of the blend kernel, by frame parity
+    int sup_par = 0;
     unsigned long long* lazy_ctr = nullptr;   // [0] low word: redo count of the frame, [1]: colours evaluated (running)
     uint32_t* colour_evals = nullptr;         // [256] colours evaluated per super-tile list (this frame; folded into lazy_ctr[1])
     bool last_lazy = false;            // the last frame of this slot left colours pending
@@ -178,7 +184,7 @@ struct gsr_context {
     int map_w = 0, map_h = 0, map_si = -1, map_sc = 0, map_rpb = -1, map_shift = -1, map_grid = 0;
 
     int shard_index = 0, shard_count = 1, shard_layout = 0;   // layout: 0 = interleaved rows, 1 = contiguous bands
-    int opt_swizzle = 1, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0, opt_lazy = 1;
+    int opt_swizzle = 2, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0, opt_lazy = 1;
 
     gsr_stats st{};
     uint64_t frame_no = 0;
@@ -186,6 +192,7 @@ struct gsr_context {
     int64_t lazy_base = 0;             // lazy_colours_total at the last gsr_stats_reset
     uint32_t* lazy_hint = nullptr;     // device: would lazy colour pay? (k_sum_work -> k_bin_ranges -> mailbox -> lazy_pays)
     bool lazy_pays = false;
+    bool order_pays = false;           // k_sum_work's other verdict: the tiles differ enough in work for k_tile_order to pay
     unsigned long long* wire_zbuf = nullptr;   // wireframe overlay: (depth bits, splat index) per pixel ...
     float* wire_out = nullptr;                 // ... and the image staged for a host target
     size_t wire_cap = 0;                       // pixels both hold
@@ -213,10 +220,10 @@ static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; 
 // ---------------------------------------------------------------------------
 // for the other translation units of the library (gsr_multi.cpp)
 #ifdef BL_PROFILE
-extern "C" int gsr_debug_blend_profile(unsigned long long* out16, int reset) {
+extern "C" int gsr_debug_blend_profile(unsigned long long* out, int reset) {   // out: [BLP_MAX_WG][4][16]
     hipDeviceSynchronize();
-    if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_blend_prof), 16 * sizeof(unsigned long long));
-    if (reset) { unsigned long long z[16] = {0}; z[11] = ~0ull; hipMemcpyToSymbol(HIP_SYMBOL(g_blend_prof), z, sizeof z); }
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_prof), sizeof(unsigned long long) * BLP_MAX_WG * 4 * 16);
+    if (reset) { void* p = nullptr; hipGetSymbolAddress(&p, HIP_SYMBOL(g_blend_prof)); hipMemset(p, 0, sizeof(unsigned long long) * BLP_MAX_WG * 4 * 16); }
     return 0;
 }
 #endif
@@ -260,6 +267,8 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMemset(sl.lazy_ctr, 0, 2 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.colour_evals), 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.colour_evals, 0, 256 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.sup_work), 512 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(sl.sup_work, 0, 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
     if (ok) { sl.h_total[0] = 0ull; sl.h_total[1] = 0ull; }
     ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_total_dev), sl.h_total, 0) == hipSuccess;
@@ -288,7 +297,7 @@ static void slot_destroy(FrameSlot& sl)
     slot_free_splat_arrays(sl);
     dev_free(sl.hist); dev_free(sl.totals);
     dev_free(sl.pvA);
-    dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.fb); dev_free(sl.depth_stage);
+    dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.fb); dev_free(sl.depth_stage);
     dev_free(sl.redo); dev_free(sl.lazy_ctr); dev_free(sl.colour_evals);
     dev_free(sl.counters); dev_free(sl.d_n);
     if (sl.h_total) (void)hipHostFree(sl.h_total);
@@ -375,7 +384,7 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
 {
     if (!c) return set_err(GSR_E_INVALID, "gsr_set_option: ctx is NULL");
     switch (option) {
-    case GSR_OPT_XCD_SWIZZLE: c->opt_swizzle = value ? 1 : 0; break;
+    case GSR_OPT_XCD_SWIZZLE: c->opt_swizzle = value < 0 ? 0 : (value > 3 ? 3 : value); break;
     case GSR_OPT_STAGE_TIMING: c->opt_timing = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_SORT_CACHE:
         c->opt_sort_cache = value ? 1 : 0;
@@ -539,6 +548,7 @@ extern "C" int gsr_upload_end(gsr_context* c)
     c->geo_gen++;
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
     c->prefix_valid = false;           // lazy colour: the first frame of a new cloud colours every list completely
+    c->order_pays = false;
     c->lazy_pays = false;              // ... and in automatic mode the first frames are eager until the kernels say it pays
     c->st.n_splats = c->n;
     return GSR_OK;
@@ -895,17 +905,22 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         a.shard = GsrShard{f.shard_index, f.shard_count, f.shard_rpb}; a.band_rows = j.band_rows;
         a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
         a.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
-        const unsigned grid = a.use_map ? (unsigned)c->map_grid : (unsigned)j.local_tiles;
+        a.sup_work = (a.use_map && c->opt_swizzle >= 2 && sl.sup_work) ? sl.sup_work + 256 * sl.sup_par : nullptr;
+        // heaviest-first table of this slot's previous frame, if that frame had the same tiles
+        const int sig[6] = {f.width, f.height, f.shard_index, f.shard_count, f.shard_rpb, f.super_shift};
+        const bool ordered = a.use_map && c->opt_swizzle >= 2 && sl.order_valid && std::memcmp(sig, sl.order_sig, sizeof sig) == 0;
+        const int32_t* tmap = ordered ? sl.order : c->tile_map;
+        const unsigned grid = ordered ? (unsigned)(8 * sl.order_per_xcd) : a.use_map ? (unsigned)c->map_grid : (unsigned)j.local_tiles;
         GsrLazyArgs lz;
         lz.f = f; lz.colrow = c->colrow;
         lz.redo = j.lazy ? sl.redo : nullptr;
         lz.redo_count = reinterpret_cast<uint32_t*>(sl.lazy_ctr);
         float4* tgt = reinterpret_cast<float4*>(j.target);
         if (j.d_depth)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<true>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<true>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
                                sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, c->tile_map, sl.pvA, sl.sstart,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
                                sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
         if (j.lazy) {   // the tiles that met a pending colour, with on-demand evaluation (normally none: the blocks exit at once)
             if (j.d_depth)
@@ -931,8 +946,32 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, g, sl.counters, sl.d_n, sl.d_frame,
                        (j.f.sh_order > 0 && c->opt_lazy) ? c->prefix : (uint32_t*)nullptr,
                        j.lazy ? reinterpret_cast<const uint32_t*>(sl.lazy_ctr) : (const uint32_t*)nullptr,
-                       sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint);
+                       sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint,
+                       sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr);
     HIP_TRY(hipGetLastError());
+    sl.order_valid = false;
+    if (j.use_map && (c->opt_swizzle >= 3 || (c->opt_swizzle == 2 && c->order_pays)) && j.local_tiles > 0 && j.n_super <= 256 &&
+        sl.sup_work) {
+        // the next frame's tile order
+        const int per_xcd = 2 * ((j.n_super + 15) / 16) << (2 * j.f.super_shift);
+        const size_t want = (size_t)8 * per_xcd;
+        if (want > sl.order_cap) {
+            HIP_TRY(hipStreamSynchronize(s));
+            dev_free(sl.order);
+            sl.order_cap = 0;
+            int rc = dev_alloc(&sl.order, want);
+            if (rc) return rc;
+            sl.order_cap = want;
+        }
+        hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(TO_THREADS), 0, s, sl.tile_work, g, j.f.tiles_y, sl.sup_work + 256 * sl.sup_par,
+                           per_xcd, sl.order);
+        HIP_TRY(hipGetLastError());
+        const int sig[6] = {j.f.width, j.f.height, j.f.shard_index, j.f.shard_count, j.f.shard_rpb, j.f.super_shift};
+        std::memcpy(sl.order_sig, sig, sizeof sig);
+        sl.order_per_xcd = per_xcd;
+        sl.order_valid = true;
+    }
+    sl.sup_par ^= 1;
     if (j.f.sh_order > 0 && c->opt_lazy) c->prefix_valid = true;   // (eager frames keep the scan depths too: the switch to lazy starts predicted)
     sl.last_lazy = j.lazy;
     if (j.timing) { sl.ev_pending = true; sl.ev_all = j.timing_all; }
@@ -983,7 +1022,8 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
             v = *box;
         }
         D = (uint32_t)v;
-        c->lazy_pays = box[1] != 0ull;   // (written before the ticket) k_sum_work's verdict on the frame before
+        c->lazy_pays = (box[1] & 1ull) != 0ull;
+        c->order_pays = (box[1] & 2ull) != 0ull;   // (written before the ticket) k_sum_work's verdict on the frame before
         if (D == 0xffffffffu || (unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
             return frame_abort(sl, set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: the frame's super-tile pairs exceed the limit of %lld", GSR_MAX_PAIRS));
         const bool short_buffer = D > sl.pair_cap;
@@ -1436,16 +1476,16 @@ extern "C" int gsr_debug_read_tile_lists(gsr_context* c, int32_t* list_start, in
     return GSR_OK;
 }
 
-extern "C" int gsr_debug_read_tile_work(gsr_context* c, uint32_t* scanned_fetched, int64_t n_tiles)
+extern "C" int gsr_debug_read_tile_work(gsr_context* c, uint32_t* work4, int64_t n_tiles)
 {
-    if (!c || !scanned_fetched) return set_err(GSR_E_INVALID, "gsr_debug_read_tile_work: bad argument");
+    if (!c || !work4) return set_err(GSR_E_INVALID, "gsr_debug_read_tile_work: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
     FrameSlot* sl = latest_slot(c);
     if (!sl || n_tiles != (int64_t)sl->last_tiles_x * sl->last_local_ty)
         return set_err(GSR_E_INVALID, "gsr_debug_read_tile_work: expected %d tiles", sl ? sl->last_tiles_x * sl->last_local_ty : 0);
-    if (n_tiles) HIP_TRY(hipMemcpy2D(scanned_fetched, 8, sl->tile_work, 16, 8, (size_t)n_tiles, hipMemcpyDeviceToHost));
+    if (n_tiles) HIP_TRY(hipMemcpy(work4, sl->tile_work, (size_t)n_tiles * 16, hipMemcpyDeviceToHost));
     return GSR_OK;
 }
 

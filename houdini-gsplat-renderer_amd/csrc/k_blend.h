@@ -45,11 +45,15 @@
 
 // BL_PROFILE (variant builds only, tools/blend_phases.py): per-wave shader-clock time of each phase, summed over the launch
 #ifdef BL_PROFILE
-__device__ unsigned long long g_blend_prof[16];
+#define BLP_MAX_WG 65536
+__device__ unsigned long long g_blend_prof[BLP_MAX_WG][4][16];   // per workgroup and wave: no atomics (they would dominate the run)
 #define BLP(i) { const long long now_ = clock64(); prof[i] += (unsigned long long)(now_ - tlast); tlast = now_; }
 #else
 #define BLP(i)
 #endif
+
+// a tile's work in (roughly) instructions: wave-record evaluations, records gathered, list entries scanned
+__device__ __forceinline__ uint32_t gsr_tile_weight(const uint4& w) { return w.z * 32u + w.y * 8u + (w.x >> 1); }
 
 struct GsrBlendArgs {
     int32_t width, height;      // full image
@@ -62,6 +66,7 @@ struct GsrBlendArgs {
     int32_t use_map;            // blockIdx -> tile through tile_map (XCD-aware order)
     int32_t flags;              // GSR_FLAG_*
     int32_t list_cap;           // entries the list buffer holds (a speculative launch may see ranges beyond it)
+    uint32_t* sup_work;         // [256] work per super-tile, summed over its tiles (or NULL)
 };
 
 // Staging layout: one list PER QUADRANT (= per wave), holding the round's records that reach that
@@ -349,15 +354,11 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     }
     BLP(8)
 #ifdef BL_PROFILE
-    if (lane == 0) {
+    if (lane == 0 && blockIdx.x < BLP_MAX_WG) {
+        unsigned long long* o = g_blend_prof[blockIdx.x][wave];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) atomicAdd(&g_blend_prof[i], prof[i]);
-        atomicAdd(&g_blend_prof[9], 1ull);
-        atomicAdd(&g_blend_prof[10], (unsigned long long)round);
-        const unsigned long long wall1 = wall_clock64();
-        atomicMin(&g_blend_prof[11], wall0);
-        atomicMax(&g_blend_prof[12], wall1);
-        atomicAdd(&g_blend_prof[13], wall1 - wall0);
+        for (int i = 0; i < 9; ++i) o[i] = prof[i];
+        o[9] = 1ull; o[10] = (unsigned long long)round; o[11] = wall0; o[12] = wall_clock64();
     }
 #endif
     // bookkeeping for the roofline: list entries scanned and records gathered by this tile
@@ -367,7 +368,10 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     if (tid == 0) {
         // entries actually read: everything up to scan_pos plus the prefetched step
         const int rd = scan_pos + 1024;
-        tile_work[tile] = make_uint4((uint32_t)(rd < n ? rd : n), fetched, sevals, saturated ? 1u : 0u);
+        const uint4 tw = make_uint4((uint32_t)(rd < n ? rd : n), fetched, sevals, saturated ? 1u : 0u);
+        tile_work[tile] = tw;
+        // work of the tile's super-tile, for k_tile_order (fire and forget: ~60 tiles per address and frame)
+        if (a.sup_work && gsr_tile_weight(tw)) atomicAdd(&a.sup_work[st], gsr_tile_weight(tw));
     }
 }
 
@@ -418,11 +422,13 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
            uint32_t* __restrict__ colour_evals /* [256] per-list counts of the colour pass, cleared here (or NULL) */,
            unsigned long long* __restrict__ colour_total /* running total of the above */,
            const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
-           uint32_t* __restrict__ lazy_hint /* would lazy colour pay for a frame like this one? (read by the next frames) */)
+           uint32_t* __restrict__ lazy_hint /* would lazy colour pay for a frame like this one? (read by the next frames) */,
+           uint32_t* __restrict__ sup_work_next /* [256] the NEXT frame's per-super-tile work sums: cleared here (or NULL) */)
 {
+    if (sup_work_next && threadIdx.x < 256) sup_work_next[threadIdx.x] = 0u;
     __shared__ unsigned long long s_sum[3];
     __shared__ uint32_t s_max[256];
-    __shared__ uint32_t s_unsat, s_est, s_cev;
+    __shared__ uint32_t s_unsat, s_est, s_cev, s_wmax;
     // Everything the tail of this kernel needs from memory is fetched NOW, next to the tile_work loads: the kernel is one
     // workgroup at the very end of the frame, and every dependent global round trip in it (~1-2 us) is frame latency.
     unsigned long long old2 = 0, old4 = 0, old5 = 0, old_ct = 0;
@@ -435,12 +441,16 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
     }
     if (prefix && (int)threadIdx.x < g.n_super) my_len = (uint32_t)(send[threadIdx.x] - sstart[threadIdx.x]);
     if (colour_evals && threadIdx.x < 256) my_cev = colour_evals[threadIdx.x];
-    if (threadIdx.x == 0) { s_unsat = 0; s_est = 0; s_cev = 0; }
+    if (threadIdx.x == 0) { s_unsat = 0; s_est = 0; s_cev = 0; s_wmax = 0; }
     if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
     if (threadIdx.x < 256) s_max[threadIdx.x] = 0;
     __syncthreads();
     unsigned long long sc = 0, fe = 0, ev = 0;
+    uint32_t wmax = 0;    // heaviest tile (gsr_tile_weight)
     uint32_t unsat = 0;   // tiles that composited something and ran to the end of their list: lazy colour sends them to the fallback
+    // tile i = tid + 1024 k walks the (tx, row) grid without a division per tile
+    const int q1k = SW_THREADS / g.tiles_x, r1k = SW_THREADS % g.tiles_x;
+    int tx = (int)threadIdx.x % g.tiles_x, ty = (int)threadIdx.x / g.tiles_x;
     for (int i0 = 0; i0 < g.n_tiles; i0 += SW_UNROLL * SW_THREADS) {
         uint4 w[SW_UNROLL];
 #pragma unroll
@@ -451,21 +461,27 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
 #pragma unroll
         for (int u = 0; u < SW_UNROLL; ++u) {
             sc += w[u].x; fe += w[u].y; ev += w[u].z;
+            { const uint32_t tw = gsr_tile_weight(w[u]); wmax = tw > wmax ? tw : wmax; }
             const int i = i0 + u * SW_THREADS + (int)threadIdx.x;
             // deepest scan among the tiles of each super-tile that SATURATED: a tile that ran to the end of its list (the
             // cloud's silhouette) would ask for the whole list; such tiles have few hits and take the on-demand fallback
             if (i < g.n_tiles && !w[u].w && w[u].y) ++unsat;
             if (prefix && i < g.n_tiles && w[u].w) {
-                const int tx = i % g.tiles_x, gty = gsr_shard_global_row(g.shard, i / g.tiles_x);
+                const int gty = gsr_shard_global_row(g.shard, ty);
                 atomicMax(&s_max[(gty >> g.super_shift) * g.stiles_x + (tx >> g.super_shift)], w[u].x);
             }
+            tx += r1k; ty += q1k;
+            if (tx >= g.tiles_x) { tx -= g.tiles_x; ++ty; }
         }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); unsat += __shfl_down(unsat, d, 64);
+        { const uint32_t o = __shfl_down(wmax, d, 64); wmax = o > wmax ? o : wmax; }
     }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); atomicAdd(&s_sum[2], ev); atomicAdd(&s_unsat, unsat); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); atomicAdd(&s_sum[2], ev); atomicAdd(&s_unsat, unsat); atomicMax(&s_wmax, wmax);
+    }
     __syncthreads();
     if (prefix && (int)threadIdx.x < g.n_super) {
         const uint32_t m = s_max[threadIdx.x];
@@ -484,8 +500,15 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         // Lazy colour pays when the colour pass would evaluate well under half of what eager evaluation does (it gathers
         // rows at random, eager streams them) and (almost) no tile would need the on-demand fallback.  Small or sparse
         // clouds (BASELINE C2, C3) fail one of the two; the 6 M-splat scenes pass both.
-        if (lazy_hint) *lazy_hint = (prefix && (unsigned long long)s_est * 10ull < (unsigned long long)nvis * 4ull &&
-                                     s_unsat * 64u <= (uint32_t)g.n_tiles) ? 1u : 0u;
+        // Bit 1: would a heaviest-first tile order pay (k_tile_order)?  When the heaviest tile alone is more than half of a
+        // workgroup slot's fair share of the frame (1536 slots: 6 workgroups on 256 CUs) raster order leaves a long, thin tail
+        // (C3: heaviest tile = 0.85 of the share); when the tiles are all alike, no order helps (C4: 0.34) and the kernel is skipped.
+        const unsigned long long wsum = s_sum[2] * 32ull + s_sum[1] * 8ull + (s_sum[0] >> 1);
+        // ... and the frame must be long enough for the gain to beat the ordering kernel's ~10 us (C2: heaviest = 1.6 of the
+        // share, but 37 us of work in all: 6 us gained)
+        const uint32_t order_pays = ((unsigned long long)s_wmax * 3072ull > wsum && wsum > 60000000ull) ? 2u : 0u;
+        if (lazy_hint) *lazy_hint = ((prefix && (unsigned long long)s_est * 10ull < (unsigned long long)nvis * 4ull &&
+                                      s_unsat * 64u <= (uint32_t)g.n_tiles) ? 1u : 0u) | order_pays;
         // running totals: plain read-modify-write (a slot's frames are serialised on its stream; nothing else touches them)
         const unsigned long long t2 = old2 + s_sum[1], t4 = old4 + s_sum[0], t5 = old5 + s_sum[2];
         counters[1] = s_sum[1]; counters[2] = t2; counters[3] = s_sum[0]; counters[4] = t4; counters[5] = t5;
@@ -496,4 +519,97 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         summary[6] = (unsigned long long)nvis;
         summary[7] = (unsigned long long)nredo;
     }
+}
+
+// Heaviest tiles first.  The blend kernel's workgroups are dispatched in blockIdx order as slots free up; when a frame's tiles
+// differ widely in work (BASELINE C3: median workgroup 5 us, heaviest 80 us) raster order leaves the second half of the launch
+// nearly empty.  This kernel (end of the frame, launched only when k_sum_work's verdict says it pays) turns the frame's per-tile
+// bookkeeping into the NEXT frame's blockIdx -> tile table: super-tiles keep a home XCD (their tiles share a list and records,
+// so an L2) -- dealt by descending work in snake order, which also balances the XCDs -- and inside an XCD the tiles run in
+// descending order of work.  One workgroup PER XCD builds that XCD's column of the table from its own super-tiles (a single
+// workgroup doing all of it took 25-30 us: one CU's issue rate); the per-super-tile work sums come ready-made from the blend
+// kernel's workgroups (sup_work, one atomic per tile).
+// order[8 * p + x] = the p-th tile of XCD x, -1 = idle; cap = 2 * ceil(n_super / 16) * tiles per super-tile bounds p (a snake
+// period of 16 gives every XCD two super-tiles).
+#define TO_THREADS 1024
+#define TO_LEVELS 128
+__global__ void __launch_bounds__(TO_THREADS)
+k_tile_order(const uint4* __restrict__ tile_work, GsrSumArgs g, int tiles_y, const uint32_t* __restrict__ sup_work, int cap,
+             int32_t* __restrict__ order)
+{
+    __shared__ uint32_t s_sup[256];
+    __shared__ uint32_t s_own[64];             // this XCD's super-tiles
+    __shared__ uint32_t s_hist[TO_LEVELS];
+    __shared__ uint32_t s_nown, s_wmax;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xcd = blockIdx.x;
+    if (tid < 256) s_sup[tid] = tid < g.n_super ? sup_work[tid] : 0u;
+    if (tid < TO_LEVELS) s_hist[tid] = 0u;
+    if (tid == 0) { s_nown = 0u; s_wmax = 0u; }
+    __syncthreads();
+    if (tid < 256) {   // rank of super-tile `tid` by descending work -> its XCD, snake order; keep the ones that are ours
+        bool mine_here = false;
+        if (tid < g.n_super) {
+            const uint32_t mine = s_sup[tid];
+            uint32_t r = 0;
+            for (int u = 0; u < g.n_super; ++u) {
+                const uint32_t o = s_sup[u];
+                r += (o > mine || (o == mine && u < tid)) ? 1u : 0u;
+            }
+            const uint32_t m = r & 15u;
+            mine_here = (int)(m < 8u ? m : 15u - m) == xcd;
+        }
+        if (mine_here) s_own[atomicAdd(&s_nown, 1u)] = (uint32_t)tid;   // (at most 2 * 16 of 256; their order does not matter)
+    }
+    __syncthreads();
+    const int shift2 = 2 * g.super_shift, emask = (1 << g.super_shift) - 1;
+    const int items = (int)s_nown << shift2;
+    // item -> local tile index (or -1: outside the image / another rank's row) and its weight
+    auto tile_of = [&](int it, uint32_t& w) -> int {
+        const int st = (int)s_own[it >> shift2], j = it & ((1 << shift2) - 1);
+        const int sy = st / g.stiles_x, sx = st - sy * g.stiles_x;
+        const int tx = (sx << g.super_shift) + (j & emask), gty = (sy << g.super_shift) + (j >> g.super_shift);
+        w = 0u;
+        if (tx >= g.tiles_x || gty >= tiles_y || !gsr_shard_owns(g.shard, gty)) return -1;
+        const int lty = g.shard.rpb > 0 ? gty - g.shard.index * g.shard.rpb : gty / g.shard.count;
+        const int i = lty * g.tiles_x + tx;
+        if (i >= g.n_tiles) return -1;
+        w = gsr_tile_weight(tile_work[i]);
+        return i;
+    };
+    {
+        uint32_t wmax = 0;
+        for (int it = tid; it < items; it += TO_THREADS) { uint32_t w; (void)tile_of(it, w); wmax = w > wmax ? w : wmax; }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(wmax, d, 64); wmax = o > wmax ? o : wmax; }
+        if (lane == 0 && wmax) atomicMax(&s_wmax, wmax);
+    }
+    __syncthreads();
+    const float scale = s_wmax ? (float)(TO_LEVELS - 2) / (float)s_wmax : 0.0f;
+    // heavy = low level = early; level 127 = the tiles without work
+    auto level_of = [&](uint32_t w) { const int l = w ? (TO_LEVELS - 2) - (int)((float)w * scale) : TO_LEVELS - 1; return l < 0 ? 0 : l; };
+    for (int it = tid; it < items; it += TO_THREADS) {
+        uint32_t w;
+        if (tile_of(it, w) >= 0) atomicAdd(&s_hist[level_of(w)], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {   // exclusive scan of the 128 levels (two per lane)
+        const uint32_t a0 = s_hist[2 * lane], a1 = s_hist[2 * lane + 1];
+        uint32_t x = a0 + a1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        const uint32_t ex = x - (a0 + a1);
+        s_hist[2 * lane] = ex; s_hist[2 * lane + 1] = ex + a0;
+        if (lane == 63) s_nown = x;   // tiles in this XCD's column
+    }
+    __syncthreads();
+    for (int it = tid; it < items; it += TO_THREADS) {
+        uint32_t w;
+        const int i = tile_of(it, w);
+        if (i >= 0) {
+            const uint32_t pos = atomicAdd(&s_hist[level_of(w)], 1u);
+            if ((int)pos < cap) order[8 * (int)pos + xcd] = i;
+        }
+    }
+    for (int p = (int)s_nown + tid; p < cap; p += TO_THREADS) order[8 * p + xcd] = -1;
 }

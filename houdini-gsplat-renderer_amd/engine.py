@@ -419,12 +419,13 @@ class Engine:
         return ts, te, pv[:npairs]
 
     def debug_tile_work(self) -> np.ndarray:
-        """[tiles_y, tiles_x, 2] uint32: list entries scanned / records gathered per tile (last frame)"""
+        """[tiles_y, tiles_x, 4] uint32: list entries scanned / records gathered / wave-record evaluations / saturated flag
+        per tile (last frame)"""
         st = self.stats()
         nt = st["tiles_x"] * st["tiles_y"]
-        out = np.zeros((nt, 2), np.uint32)
+        out = np.zeros((nt, 4), np.uint32)
         _check(self.L.gsr_debug_read_tile_work(self.h, out.ctypes.data, nt))
-        return out.reshape(st["tiles_y"], st["tiles_x"], 2)
+        return out.reshape(st["tiles_y"], st["tiles_x"], 4)
 
     def debug_sort_pairs(self, keys: np.ndarray, vals: np.ndarray, key_bits: int = 32):
         k = np.ascontiguousarray(keys, dtype=np.uint32).copy()

@@ -216,7 +216,9 @@ int  gsr_get_stats(gsr_context* ctx, gsr_stats* out);     /* synchronizes the st
 int  gsr_stats_reset(gsr_context* ctx);
 
 /* ---- knobs (performance only; never change pixels) ---------------------- */
-#define GSR_OPT_XCD_SWIZZLE     1   /* 0/1: XCD-aware tile -> workgroup mapping in the blend kernel */
+#define GSR_OPT_XCD_SWIZZLE     1   /* tile -> workgroup mapping of the blend kernel: 0 = raster order, 1 = every XCD gets whole
+                                       super-tiles, 2 (default) = 1 + heaviest tiles first (from the previous frame's per-tile work) whenever the
+                                       kernels find the tiles unequal enough for it to pay, 3 = heaviest first always */
 #define GSR_OPT_STAGE_TIMING    2   /* HIP events on the frame's stream: 0 = none, 1 = around the blend kernel only
                                        (default; feeds gsr_stats.blend_ms_total), 2 = around every stage (ms_* fields) */
 #define GSR_OPT_SORT_CACHE      3   /* 0/1: skip the depth sort when the frame description (camera, shard, geometry) is
@@ -263,8 +265,9 @@ int  gsr_debug_read_depth_order(gsr_context* ctx, int32_t* perm, int64_t cap, in
 int  gsr_debug_read_tile_lists(gsr_context* ctx, int32_t* list_start, int32_t* list_end, int64_t n_lists,
                                int32_t* pair_splat, int64_t n_pairs);
 
-/* per tile of the last frame: {list entries scanned, records gathered} by the blend kernel (uint32 pairs) */
-int  gsr_debug_read_tile_work(gsr_context* ctx, uint32_t* scanned_fetched, int64_t n_tiles);
+/* per tile of the last frame, four uint32: {list entries scanned, records gathered, wave-record evaluations, 1 if the tile
+ * stopped because every pixel was opaque} as the blend kernel counted them */
+int  gsr_debug_read_tile_work(gsr_context* ctx, uint32_t* work4, int64_t n_tiles);
 
 /* Stand-alone device radix sort of (key,value) u32 pairs on bits [0, key_bits):
  * the sort the pipeline uses, exposed for parity tests (host pointers). */

@@ -369,12 +369,34 @@ def test_options_do_not_change_pixels(pkg, engine):
     cam = pkg.camera.make_camera(640, 400, sh_order=3, frame=3)
     engine.upload(splats)
     base = engine.render(cam)
-    for opt, vals in ((pkg.engine.OPT_XCD_SWIZZLE, (0, 1)), (pkg.engine.OPT_SUPER_TILE, (1, 2, 4, 8, 16, 0)),
+    for opt, vals in ((pkg.engine.OPT_XCD_SWIZZLE, (0, 1, 3, 3, 2)), (pkg.engine.OPT_SUPER_TILE, (1, 2, 4, 8, 16, 0)),
                       (pkg.engine.OPT_DEBUG_FLAGS, (1, 2, 4, 7, 8, 15, 0)), (pkg.engine.OPT_FRAMES_IN_FLIGHT, (1, 2)),
                       (pkg.engine.OPT_LAZY_COLOUR, (0, 2, 1))):
         for v in vals:
             engine.set_option(opt, v)
             assert np.array_equal(engine.render(cam), base), f"option {opt}={v} changed the image"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shard", [(0, 1, 0), (1, 3, 0), (2, 4, 1)])
+def test_heaviest_first_tile_order_is_invisible(pkg, shard):
+    """GSR_OPT_XCD_SWIZZLE = 3: from the second frame on the blend kernel's workgroup -> tile table comes from k_tile_order
+    (the previous frame's per-tile work, heaviest first, per XCD).  Every tile must still be composited exactly once: a moving
+    camera, so a tile left out would show the previous frame's pixels."""
+    idx, count, layout = shard
+    eng = pkg.Engine(0)
+    splats = pkg.scenes.make_scene(50000, seed=67, sh=True)
+    splats.scale[:200] = pkg.scenes.f16bits(np.random.default_rng(5).uniform(0.2, 1.5, size=(200, 3)))
+    eng.upload(splats)
+    eng.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
+    eng.set_row_shard(idx, count)
+    for w, h in ((1000, 700), (300, 2100)):
+        cams = [pkg.camera.make_camera(w, h, sh_order=3, frame=f) for f in range(5)]
+        eng.set_option(pkg.engine.OPT_XCD_SWIZZLE, 0)
+        want = [eng.render(c).copy() for c in cams]
+        eng.set_option(pkg.engine.OPT_XCD_SWIZZLE, 3)
+        for f, c in enumerate(cams):
+            assert np.array_equal(eng.render(c), want[f]), f"{w}x{h} shard {shard}: frame {f} differs with the heaviest-first order"
 
 
 def test_frames_in_flight_keep_every_frame_intact(pkg, oracle, engine):

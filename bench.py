@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the cpu_baseline leg")
     ap.add_argument("--no-swizzle", action="store_true", help="disable the XCD-aware tile mapping (A/B)")
+    ap.add_argument("--cull", type=int, default=1, help="0 = no occlusion culling against the previous frame's depth horizons (A/B)")
     ap.add_argument("--tile-order", type=int, default=2, help="1 = XCD-aware static tile order, 2 = + heaviest tiles first (A/B)")
     ap.add_argument("--super-tile", type=int, default=0, help="super-tile edge in tiles (0 = auto) (A/B)")
     ap.add_argument("--flags", type=int, default=0, help="GSR_OPT_DEBUG_FLAGS (A/B)")
@@ -179,6 +180,7 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
+    eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, args.cull)
     eng.set_option(pkg.engine.OPT_XCD_SWIZZLE, 0 if args.no_swizzle else args.tile_order)
     eng.set_option(pkg.engine.OPT_SUPER_TILE, args.super_tile)
     eng.set_option(pkg.engine.OPT_DEBUG_FLAGS, args.flags)
@@ -442,6 +444,11 @@ def main():
             "lazy_colour": {"mode": args.lazy, "active": st["lazy_colours_total"] > 0, "colours_evaluated_per_frame": st["lazy_colours_total"] / max(1, st["frames"]),
                             "visible_splats": st["n_visible"],
                             "fallback_tiles_last_frame": st["lazy_redo_tiles"]},
+            "occlusion_culling": {"enabled": bool(args.cull), "frames_culled": st["frames_culled"], "frames_repaired": st["frames_repaired"],
+                                  "frames": st["frames"],
+                                  "note": "splats behind the previous frame's per-super-tile depth horizons are dropped before projection and "
+                                          "sorting; every culled frame verifies itself and is rendered again without culling if a horizon "
+                                          "broke (frames_repaired; those frames are inside the timed region)"},
         }
         if pipelined is not None:
             line["pipelined"] = pipelined

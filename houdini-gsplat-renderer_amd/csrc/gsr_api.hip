@@ -83,6 +83,7 @@ struct FrameJob {
     bool speculative = false;      // the back end was queued before the pair count was known
     bool deferred = false;         // ... and the frame handed over without waiting for it (GSR_OPT_DEFERRED_CHECK)
     bool lazy = false;             // K1 left the SH colours pending (k_colour.h)
+    bool cull = false;             // occlusion culling: K1 and the binning cut at the slot's depth horizons
     bool direct = false;           // the frame runs on the public stream itself
     uint32_t ticket = 0;           // stamps the frame's pair count in the host mailbox
 };
@@ -122,6 +123,17 @@ struct FrameSlot {
     int order_sig[6] = {0, 0, 0, 0, 0, 0}, order_per_xcd = 0;
     uint32_t* sup_work = nullptr;      // [2][256] per-super-tile work sums of the blend kernel, by frame parity
     int sup_par = 0;
+    // Depth horizons (occlusion culling): per super-tile, the distance^2 beyond which this slot's NEXT frame drops splats --
+    // written by k_sum_work at the end of every frame from how deep the frame's tiles had to look.  A culled frame checks
+    // itself (a tile that ran off its cut list without going opaque raises `violation`); k_sum_work reports that to the
+    // mapped word h_end, and the host renders a frame that failed again, without culling, before it hands it over.
+    float* horizon = nullptr;          // [256] device
+    uint32_t* violation = nullptr;     // device word
+    unsigned long long* h_end = nullptr;      // pinned + mapped: ticket << 32 | violation
+    unsigned long long* h_end_dev = nullptr;
+    bool horizon_valid = false;
+    int horizon_sig[7] = {0, 0, 0, 0, 0, 0, 0};   // tile geometry + geometry generation the horizons belong to
+    bool sorted_culled = false;        // the cached depth order holds a culled frame's splats only
     unsigned long long* lazy_ctr = nullptr;   // [0] low word: redo count of the frame, [1]: colours evaluated (running)
     uint32_t* colour_evals = nullptr;         // [256] colours evaluated per super-tile list (this frame; folded into lazy_ctr[1])
     bool last_lazy = false;            // the last frame of this slot left colours pending
@@ -184,7 +196,7 @@ struct gsr_context {
     int map_w = 0, map_h = 0, map_si = -1, map_sc = 0, map_rpb = -1, map_shift = -1, map_grid = 0;
 
     int shard_index = 0, shard_count = 1, shard_layout = 0;   // layout: 0 = interleaved rows, 1 = contiguous bands
-    int opt_swizzle = 2, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0, opt_lazy = 1;
+    int opt_swizzle = 2, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0, opt_lazy = 1, opt_cull = 1;
 
     gsr_stats st{};
     uint64_t frame_no = 0;
@@ -192,6 +204,9 @@ struct gsr_context {
     int64_t lazy_base = 0;             // lazy_colours_total at the last gsr_stats_reset
     uint32_t* lazy_hint = nullptr;     // device: would lazy colour pay? (k_sum_work -> k_bin_ranges -> mailbox -> lazy_pays)
     bool lazy_pays = false;
+    uint32_t vis_unculled = 0;         // splats kept by the last frame that was not culled
+    bool cull_pays = false;            // ... and its third: most super-tile lists have a depth horizon (occlusion culling)
+    int cull_holdoff = 0, cull_backoff = 8, cull_streak = 0;   // frames without culling after a broken horizon (doubling, <= 256)
     bool order_pays = false;           // k_sum_work's other verdict: the tiles differ enough in work for k_tile_order to pay
     unsigned long long* wire_zbuf = nullptr;   // wireframe overlay: (depth bits, splat index) per pixel ...
     float* wire_out = nullptr;                 // ... and the image staged for a host target
@@ -267,6 +282,12 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMemset(sl.lazy_ctr, 0, 2 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.colour_evals), 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.colour_evals, 0, 256 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.horizon), 256 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.violation), sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(sl.violation, 0, sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_end), sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    if (ok) sl.h_end[0] = 0ull;
+    ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_end_dev), sl.h_end, 0) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.sup_work), 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.sup_work, 0, 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
@@ -297,7 +318,9 @@ static void slot_destroy(FrameSlot& sl)
     slot_free_splat_arrays(sl);
     dev_free(sl.hist); dev_free(sl.totals);
     dev_free(sl.pvA);
-    dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.fb); dev_free(sl.depth_stage);
+    dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.fb);
+    dev_free(sl.horizon); dev_free(sl.violation);
+    if (sl.h_end) (void)hipHostFree(sl.h_end); dev_free(sl.depth_stage);
     dev_free(sl.redo); dev_free(sl.lazy_ctr); dev_free(sl.colour_evals);
     dev_free(sl.counters); dev_free(sl.d_n);
     if (sl.h_total) (void)hipHostFree(sl.h_total);
@@ -392,6 +415,7 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
         break;
     case GSR_OPT_DEBUG_FLAGS: c->opt_flags = value; break;
     case GSR_OPT_DEFERRED_CHECK: c->opt_deferred = value ? 1 : 0; break;
+    case GSR_OPT_OCCLUSION_CULL: c->opt_cull = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_LAZY_COLOUR: c->opt_lazy = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_SHARD_LAYOUT: c->shard_layout = value ? 1 : 0; break;
     case GSR_OPT_SUPER_TILE:
@@ -549,6 +573,7 @@ extern "C" int gsr_upload_end(gsr_context* c)
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
     c->prefix_valid = false;           // lazy colour: the first frame of a new cloud colours every list completely
     c->order_pays = false;
+    c->cull_pays = false; c->cull_holdoff = 0; c->cull_backoff = 8; c->cull_streak = 0; c->vis_unculled = 0;
     c->lazy_pays = false;              // ... and in automatic mode the first frames are eager until the kernels say it pays
     c->st.n_splats = c->n;
     return GSR_OK;
@@ -645,7 +670,8 @@ static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, u
 // written to *compact_to (device); the remaining passes and the caller's later kernels read it there.
 template <typename V>
 static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& vB, uint32_t n, int bits,
-                      bool allow9 = true, uint32_t* compact_to = nullptr, bool contig = false)
+                      bool allow9 = true, uint32_t* compact_to = nullptr, bool contig = false,
+                      const uint32_t* first_n_dev = nullptr /* the item count lives on the device (n = its upper bound) */)
 {
     if (n == 0) {
         if (compact_to) HIP_TRY(hipMemsetAsync(compact_to, 0, 4, sl.stream));
@@ -660,7 +686,7 @@ static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& v
     const int passes = use9 ? p9 : p8, width = use9 ? 9 : 8;
     for (int p = 0; p < passes; ++p) {
         const bool skip = compact_to && p == 0;
-        const uint32_t* n_dev = (compact_to && p > 0) ? compact_to : nullptr;
+        const uint32_t* n_dev = (compact_to && p > 0) ? compact_to : (p == 0 ? first_n_dev : nullptr);
         if (use9)
             rc = skip ? radix_pass<V, 9, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig, compact_to)
                       : radix_pass<V, 9, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig);
@@ -885,7 +911,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         const size_t lds = (size_t)4 * BN_ITEMS * j.n_super * 8 + (size_t)4 * j.n_super * 4;
         hipLaunchKernelGGL(k_bin_place, dim3(nblk), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n, f.super_shift,
                            GsrShard{f.shard_index, f.shard_count, f.shard_rpb}, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk,
-                           (uint32_t)sl.pair_cap, sl.pvA);
+                           (uint32_t)sl.pair_cap, sl.pvA, sl.keyA, j.cull ? sl.horizon : (const float*)nullptr, f.key_min, f.key_max);
         HIP_TRY(hipGetLastError());
     }
     if ((rc = mark(sl, 4))) return rc;
@@ -906,6 +932,8 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
         a.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
         a.sup_work = (a.use_map && c->opt_swizzle >= 2 && sl.sup_work) ? sl.sup_work + 256 * sl.sup_par : nullptr;
+        a.horizon = j.cull ? sl.horizon : nullptr;
+        a.violation = sl.violation;
         // heaviest-first table of this slot's previous frame, if that frame had the same tiles
         const int sig[6] = {f.width, f.height, f.shard_index, f.shard_count, f.shard_rpb, f.super_shift};
         const bool ordered = a.use_map && c->opt_swizzle >= 2 && sl.order_valid && std::memcmp(sig, sl.order_sig, sizeof sig) == 0;
@@ -943,12 +971,25 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     GsrSumArgs g;
     g.n_tiles = j.local_tiles; g.tiles_x = j.f.tiles_x; g.shard = GsrShard{j.f.shard_index, j.f.shard_count, j.f.shard_rpb};
     g.super_shift = j.f.super_shift; g.stiles_x = j.f.stiles_x; g.n_super = j.n_super;
+    GsrHorizonArgs hz{};
+    // (below a few hundred thousand splats in the sort the frame is bound by launch floors: nothing for culling to win)
+    if (c->opt_cull && j.n > 0 && j.n_super <= 256 && (c->opt_cull >= 2 || j.cull || c->vis_unculled >= 300000u)) {
+        hz.horizon = sl.horizon; hz.culled = j.cull ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
+        hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
+        hz.violation = sl.violation;
+        hz.host_end = j.cull ? sl.h_end_dev : nullptr; hz.ticket = j.ticket;
+    }
     hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, g, sl.counters, sl.d_n, sl.d_frame,
                        (j.f.sh_order > 0 && c->opt_lazy) ? c->prefix : (uint32_t*)nullptr,
                        j.lazy ? reinterpret_cast<const uint32_t*>(sl.lazy_ctr) : (const uint32_t*)nullptr,
                        sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint,
-                       sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr);
+                       sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr, hz);
     HIP_TRY(hipGetLastError());
+    sl.horizon_valid = hz.horizon != nullptr;
+    if (sl.horizon_valid) {
+        const int sig[7] = {j.f.width, j.f.height, j.f.shard_index, j.f.shard_count, j.f.shard_rpb, j.f.super_shift, (int)c->geo_gen};
+        std::memcpy(sl.horizon_sig, sig, sizeof sig);
+    }
     sl.order_valid = false;
     if (j.use_map && (c->opt_swizzle >= 3 || (c->opt_swizzle == 2 && c->order_pays)) && j.local_tiles > 0 && j.n_super <= 256 &&
         sl.sup_work) {
@@ -1023,6 +1064,13 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
         }
         D = (uint32_t)v;
         c->lazy_pays = (box[1] & 1ull) != 0ull;
+        c->cull_pays = (box[1] & 4ull) != 0ull;
+        {   // occlusion culling earns its keep only if it drops a good part of what an unculled frame keeps
+            const uint32_t kept = (uint32_t)(box[1] >> 32);
+            if (!j.cull) c->vis_unculled = kept;
+            else if (c->opt_cull == 1 && c->vis_unculled > 0 && (unsigned long long)kept * 10ull > (unsigned long long)c->vis_unculled * 7ull)
+                c->cull_holdoff = 256;
+        }
         c->order_pays = (box[1] & 2ull) != 0ull;   // (written before the ticket) k_sum_work's verdict on the frame before
         if (D == 0xffffffffu || (unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
             return frame_abort(sl, set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: the frame's super-tile pairs exceed the limit of %lld", GSR_MAX_PAIRS));
@@ -1055,6 +1103,31 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
     return GSR_OK;
 }
 
+// Occlusion culling: wait for k_sum_work's word on the frame just queued (it is the first thing that kernel writes, so the
+// host is back in time to queue the next frame behind it): did a tile run off a list cut at its horizon?
+static int frame_verdict(gsr_context* c, FrameSlot& sl, bool* broke)
+{
+    (void)c;
+    const FrameJob& j = sl.job;
+    volatile unsigned long long* box = sl.h_end;
+    unsigned long long v = *box;
+    for (unsigned long spins = 1; (uint32_t)(v >> 32) != j.ticket; ++spins) {
+        if ((spins & 0x3fffu) == 0) {
+            const hipError_t q = hipStreamQuery(sl.stream);
+            if (q == hipSuccess) {
+                v = *box;
+                if ((uint32_t)(v >> 32) != j.ticket) return set_err(GSR_E_HIP, "gsr_render: the frame finished without its culling verdict");
+                break;
+            }
+            if (q != hipErrorNotReady) return set_err(GSR_E_HIP, "gsr_render: waiting for the culling verdict: %s", hipGetErrorString(q));
+        }
+        __builtin_ia32_pause();
+        v = *box;
+    }
+    *broke = (v & 1ull) != 0ull;
+    return GSR_OK;
+}
+
 static int finish_open_frames(gsr_context* c)
 {
     int rc = GSR_OK;
@@ -1066,7 +1139,7 @@ static int finish_open_frames(gsr_context* c)
 }
 
 static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth, int depth_is_device,
-                       float* rgba_out, int out_is_device, FrameSlot** used)
+                       float* rgba_out, int out_is_device, FrameSlot** used, bool allow_cull)
 {
     if (!c || !cam || !rgba_out) return set_err(GSR_E_INVALID, "gsr_render: NULL argument");
     if (c->uploading) return set_err(GSR_E_INVALID, "gsr_render: upload in progress");
@@ -1116,6 +1189,18 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     j.deferred = c->opt_deferred && j.out_is_device;
     // order 0: the colour is Cd itself, nothing to defer; mode 1 follows the kernels' own verdict on the previous frames
     j.lazy = f.sh_order > 0 && (c->opt_lazy == 2 || (c->opt_lazy == 1 && c->lazy_pays));
+    {
+        const int sig[7] = {f.width, f.height, f.shard_index, f.shard_count, f.shard_rpb, f.super_shift, (int)c->geo_gen};
+        j.cull = allow_cull && c->opt_cull && !j.deferred && n > 0 && sl.horizon_valid && std::memcmp(sig, sl.horizon_sig, sizeof sig) == 0 &&
+                 !(c->opt_flags & GSR_FLAG_FULL_KEYS) && (c->opt_cull >= 2 || (c->cull_pays && c->cull_holdoff == 0));
+        if (allow_cull && c->cull_holdoff > 0) c->cull_holdoff -= 1;
+        if (j.cull) {
+            c->st.frames_culled += 1;
+            // the lists now end about where the colour pass stops anyway: colour lazily (the hint would compare the pass with
+            // the few splats that are left, and choose eager evaluation of sparse rows)
+            if (f.sh_order > 0 && c->opt_lazy) j.lazy = true;
+        }
+    }
     j.ticket = ++sl.ticket ? sl.ticket : ++sl.ticket;   // (never 0: the mailbox starts at 0)
     if (j.timing) harvest_slot(c, sl);
 
@@ -1165,13 +1250,14 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     // src/GSplatRenderer.C:165-186) -- but the sorted list holds just the splats visible to the frame that sorted, so
     // it is reused as is only for an identical frame description (a static viewport redraw), per frame slot.
     const SortKey key_now = {c->geo_gen, c->shard_index, c->shard_count, c->shard_layout, c->opt_flags, *cam};
-    const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now);
+    // (a culled frame's order holds only the splats in front of ITS horizons, and the horizons move: no reuse either way)
+    const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now) && !j.cull && !sl.sorted_culled;
     if (n > 0) {
         // on a cache hit (identical frame description) the sorted (keyA, valA) are kept and K1's key/payload
         // output goes to the scratch buffers
         hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, GSR_K1_THREADS)), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, cache_hit ? sl.keyB : sl.keyA, cache_hit ? sl.valB : sl.valA,
-                           j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0);
+                           j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.cull ? sl.horizon : (const float*)nullptr);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return frame_abort(sl, set_err(GSR_E_HIP, "k_preprocess: %s", hipGetErrorString(e)));
     }
@@ -1187,6 +1273,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         sl.key_min = f.key_min;
         sl.sort_valid = true;
         sl.sort_key = key_now;
+        sl.sorted_culled = j.cull;
     }
     if ((rc = mark(sl, 2))) return frame_abort(sl, rc);
     hipError_t e = hipSuccess;
@@ -1196,10 +1283,11 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)BN_BINS * nblk + 8);
         if (rc) return frame_abort(sl, rc);
         hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift,
-                           GsrShard{f.shard_index, f.shard_count, f.shard_rpb}, f.stiles_x, sl.hist, nblk);
+                           GsrShard{f.shard_index, f.shard_count, f.shard_rpb}, f.stiles_x, sl.hist, nblk,
+                           sl.keyA, j.cull ? sl.horizon : (const float*)nullptr, f.key_min, f.key_max);
         hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals, sl.d_n, n, (uint32_t)BN_TILE);
         hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, sl.totals, j.n_super, sl.sstart, sl.send, sl.h_total_dev,
-                           j.ticket, (unsigned long long)GSR_MAX_PAIRS, reinterpret_cast<uint32_t*>(sl.lazy_ctr), c->lazy_hint);
+                           j.ticket, (unsigned long long)GSR_MAX_PAIRS, reinterpret_cast<uint32_t*>(sl.lazy_ctr), c->lazy_hint, sl.d_n);
         e = hipGetLastError();
     } else {
         e = hipMemsetAsync(sl.sstart, 0, ((size_t)j.n_super + 1) * 4, s);
@@ -1233,9 +1321,26 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
                                 float* rgba_out, int out_is_device)
 {
     FrameSlot* sl = nullptr;
-    int rc = frame_begin(c, cam, depth, depth_is_device, rgba_out, out_is_device, &sl);
+    int rc = frame_begin(c, cam, depth, depth_is_device, rgba_out, out_is_device, &sl, true);
     if (rc) return rc;
     if (sl->job.deferred) return GSR_OK;   // GSR_OPT_DEFERRED_CHECK: the pair count is looked at by the next call that syncs
+    if ((rc = frame_finish(c, *sl))) return rc;
+    if (!sl->job.cull) return GSR_OK;
+    // a culled frame is handed over only once it has checked itself
+    bool broke = false;
+    if ((rc = frame_verdict(c, *sl, &broke))) return rc;
+    if (!broke) {
+        if (++c->cull_streak >= 64) { c->cull_streak = 0; c->cull_backoff = 8; }
+        return GSR_OK;
+    }
+    c->st.frames_repaired += 1;
+    c->cull_holdoff = std::max(c->cull_holdoff, c->cull_backoff);   // the view is changing faster than the horizons follow: leave it alone for a while
+    c->cull_backoff = c->cull_backoff >= 256 ? 256 : 2 * c->cull_backoff;
+    c->cull_streak = 0;
+    c->frame_no -= 1;          // the same frame again, in the same slot, complete this time
+    c->st.frames -= 1;
+    rc = frame_begin(c, cam, depth, depth_is_device, rgba_out, out_is_device, &sl, false);
+    if (rc) return rc;
     return frame_finish(c, *sl);
 }
 
@@ -1243,7 +1348,7 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
 __attribute__((visibility("hidden"))) int gsr_internal_frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth,
                                                                     int depth_is_device, float* out_dev)
 {
-    return frame_begin(c, cam, depth, depth_is_device, out_dev, 1, nullptr);
+    return frame_begin(c, cam, depth, depth_is_device, out_dev, 1, nullptr, false);
 }
 __attribute__((visibility("hidden"))) int gsr_internal_frame_finish(gsr_context* c) { return c ? finish_open_frames(c) : GSR_OK; }
 __attribute__((visibility("hidden"))) void* gsr_internal_stream(gsr_context* c) { return c ? (void*)c->stream : nullptr; }

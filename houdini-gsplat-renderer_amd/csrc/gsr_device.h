@@ -141,6 +141,16 @@ __device__ __forceinline__ float gsr_support_radius_fast(float opacity)
     return __builtin_fminf(2.0f, __builtin_amdgcn_sqrtf(__builtin_fmaxf(L, 0.0f) + 1.0e-4f) + 1.0e-3f);
 }
 
+// A depth horizon (distance^2 from the camera; +inf or NaN = none) in a frame's sort-key domain: K1 and the binning kernels
+// compare keys with this, so they agree exactly on what lies beyond it.
+__host__ __device__ __forceinline__ uint32_t gsr_horizon_key(float h, uint32_t key_min, uint32_t key_max)
+{
+    if (!(h < 3.0e38f)) return 0xffffffffu;
+    uint32_t b = __builtin_bit_cast(uint32_t, h > 0.0f ? h : 0.0f);
+    b = b < key_min ? key_min : (b > key_max ? key_max : b);
+    return b - key_min;
+}
+
 // rect packing: tile coords < 256 (GSR_MAX_DIM 4096 / 16)
 __device__ __forceinline__ uint32_t gsr_pack_rect(int x0, int y0, int x1, int y1)
 {

@@ -67,6 +67,8 @@ struct GsrBlendArgs {
     int32_t flags;              // GSR_FLAG_*
     int32_t list_cap;           // entries the list buffer holds (a speculative launch may see ranges beyond it)
     uint32_t* sup_work;         // [256] work per super-tile, summed over its tiles (or NULL)
+    const float* horizon;       // [256] occlusion culling: this frame's lists end at these depth horizons (or NULL: complete lists)
+    uint32_t* violation;        // set when a tile runs off a list cut at its horizon without going opaque: the frame is redone
 };
 
 // Staging layout: one list PER QUADRANT (= per wave), holding the round's records that reach that
@@ -369,6 +371,8 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         // entries actually read: everything up to scan_pos plus the prefetched step
         const int rd = scan_pos + 1024;
         const uint4 tw = make_uint4((uint32_t)(rd < n ? rd : n), fetched, sevals, saturated ? 1u : 0u);
+        // occlusion culling: what this tile saw is complete only up to its super-tile's horizon
+        if (a.horizon && !saturated && a.horizon[st] < 3.0e38f) *a.violation = 1u;
         tile_work[tile] = tw;
         // work of the tile's super-tile, for k_tile_order (fire and forget: ~60 tiles per address and frame)
         if (a.sup_work && gsr_tile_weight(tw)) atomicAdd(&a.sup_work[st], gsr_tile_weight(tw));
@@ -414,6 +418,18 @@ struct GsrSumArgs {
     int32_t n_tiles, tiles_x, super_shift, stiles_x, n_super;
     GsrShard shard;
 };
+// Depth horizons (occlusion culling): at the end of a frame k_sum_work turns the depth its tiles scanned to into the horizon
+// the slot's next frame culls against and tells the host whether THIS frame broke its own horizons.
+struct GsrHorizonArgs {
+    float* horizon;                 // [256] in: this frame's (if culled), out: the next frame's; NULL = feature off
+    int32_t culled;                 // this frame's lists were cut at `horizon`
+    const uint2* lists;             // the super-tile lists
+    const float4* geoA;             // xyz = position
+    float cam[3];
+    uint32_t* violation;            // read, reported, cleared
+    unsigned long long* host_end;   // mapped host word: ticket << 32 | violation
+    uint32_t ticket;
+};
 __global__ void __launch_bounds__(SW_THREADS)
 k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long* __restrict__ counters,
            const uint32_t* __restrict__ n_visible, unsigned long long* __restrict__ summary /* device [8]: fetched by gsr_get_stats */,
@@ -423,12 +439,21 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
            unsigned long long* __restrict__ colour_total /* running total of the above */,
            const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
            uint32_t* __restrict__ lazy_hint /* would lazy colour pay for a frame like this one? (read by the next frames) */,
-           uint32_t* __restrict__ sup_work_next /* [256] the NEXT frame's per-super-tile work sums: cleared here (or NULL) */)
+           uint32_t* __restrict__ sup_work_next /* [256] the NEXT frame's per-super-tile work sums: cleared here (or NULL) */,
+           GsrHorizonArgs hz)
 {
+    // first thing: the frame's verdict to the host, which is waiting for it before it queues the next frame
+    if (hz.host_end && threadIdx.x == 0) {
+        const uint32_t v = hz.violation ? *hz.violation : 0u;
+        *hz.host_end = ((unsigned long long)hz.ticket << 32) | (unsigned long long)(v ? 1u : 0u);
+        if (hz.violation) *hz.violation = 0u;
+    }
+    __shared__ uint32_t s_open[256];   // super-tiles with a tile that did not go opaque: no horizon there
+    if (threadIdx.x < 256) s_open[threadIdx.x] = 0u;
     if (sup_work_next && threadIdx.x < 256) sup_work_next[threadIdx.x] = 0u;
     __shared__ unsigned long long s_sum[3];
     __shared__ uint32_t s_max[256];
-    __shared__ uint32_t s_unsat, s_est, s_cev, s_wmax;
+    __shared__ uint32_t s_unsat, s_est, s_cev, s_wmax, s_nfin, s_nused;
     // Everything the tail of this kernel needs from memory is fetched NOW, next to the tile_work loads: the kernel is one
     // workgroup at the very end of the frame, and every dependent global round trip in it (~1-2 us) is frame latency.
     unsigned long long old2 = 0, old4 = 0, old5 = 0, old_ct = 0;
@@ -441,7 +466,7 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
     }
     if (prefix && (int)threadIdx.x < g.n_super) my_len = (uint32_t)(send[threadIdx.x] - sstart[threadIdx.x]);
     if (colour_evals && threadIdx.x < 256) my_cev = colour_evals[threadIdx.x];
-    if (threadIdx.x == 0) { s_unsat = 0; s_est = 0; s_cev = 0; s_wmax = 0; }
+    if (threadIdx.x == 0) { s_unsat = 0; s_est = 0; s_cev = 0; s_wmax = 0; s_nfin = 0; s_nused = 0; }
     if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
     if (threadIdx.x < 256) s_max[threadIdx.x] = 0;
     __syncthreads();
@@ -466,9 +491,11 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
             // deepest scan among the tiles of each super-tile that SATURATED: a tile that ran to the end of its list (the
             // cloud's silhouette) would ask for the whole list; such tiles have few hits and take the on-demand fallback
             if (i < g.n_tiles && !w[u].w && w[u].y) ++unsat;
-            if (prefix && i < g.n_tiles && w[u].w) {
+            if ((prefix || hz.horizon) && i < g.n_tiles) {
                 const int gty = gsr_shard_global_row(g.shard, ty);
-                atomicMax(&s_max[(gty >> g.super_shift) * g.stiles_x + (tx >> g.super_shift)], w[u].x);
+                const int st = (gty >> g.super_shift) * g.stiles_x + (tx >> g.super_shift);
+                if (w[u].w) atomicMax(&s_max[st], w[u].x);
+                else s_open[st] = 1u;
             }
             tx += r1k; ty += q1k;
             if (tx >= g.tiles_x) { tx -= g.tiles_x; ++ty; }
@@ -483,6 +510,28 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); atomicAdd(&s_sum[2], ev); atomicAdd(&s_unsat, unsat); atomicMax(&s_wmax, wmax);
     }
     __syncthreads();
+    if (hz.horizon && (int)threadIdx.x < g.n_super) {
+        // The next frame's horizon: the distance of the list entry a quarter (+1024 entries) beyond the deepest scan -- the
+        // same headroom the lazy colour pass uses.  A list that was itself cut at a horizon may be too short for that: then the
+        // horizon it was cut at is pushed out by 5 % (in distance^2) instead.
+        const uint32_t m = s_max[threadIdx.x];
+        const uint32_t len = (uint32_t)(send[threadIdx.x] - sstart[threadIdx.x]);
+        const uint32_t want = m + (m >> 2) + 1024u;
+        const float old = hz.horizon[threadIdx.x];
+        float h = __builtin_inff();
+        if (!s_open[threadIdx.x] && len > 0u) {
+            if (want < len) {
+                const uint32_t idx = hz.lists[(uint32_t)sstart[threadIdx.x] + want].x;
+                const float4 P = hz.geoA[idx];
+                const float dx = P.x - hz.cam[0], dy = P.y - hz.cam[1], dz = P.z - hz.cam[2];
+                h = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
+            } else if (hz.culled && old < 3.0e38f) {
+                h = old * 1.05f;
+            }
+        }
+        hz.horizon[threadIdx.x] = h;
+        if (len > 0u) { atomicAdd(&s_nused, 1u); if (h < 3.0e38f) atomicAdd(&s_nfin, 1u); }
+    }
     if (prefix && (int)threadIdx.x < g.n_super) {
         const uint32_t m = s_max[threadIdx.x];
         {   // how many colour evaluations the lazy pass would make for a frame like this one
@@ -508,7 +557,9 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         // share, but 37 us of work in all: 6 us gained)
         const uint32_t order_pays = ((unsigned long long)s_wmax * 3072ull > wsum && wsum > 60000000ull) ? 2u : 0u;
         if (lazy_hint) *lazy_hint = ((prefix && (unsigned long long)s_est * 10ull < (unsigned long long)nvis * 4ull &&
-                                      s_unsat * 64u <= (uint32_t)g.n_tiles) ? 1u : 0u) | order_pays;
+                                      s_unsat * 64u <= (uint32_t)g.n_tiles) ? 1u : 0u) | order_pays |
+                                    // bit 2: occlusion culling has something to work with (most lists got a horizon)
+                                    ((hz.horizon && s_nfin * 2u >= s_nused && s_nused > 0u) ? 4u : 0u);
         // running totals: plain read-modify-write (a slot's frames are serialised on its stream; nothing else touches them)
         const unsigned long long t2 = old2 + s_sum[1], t4 = old4 + s_sum[0], t5 = old5 + s_sum[2];
         counters[1] = s_sum[1]; counters[2] = t2; counters[3] = s_sum[0]; counters[4] = t4; counters[5] = t5;

@@ -30,7 +30,23 @@ k_repack(uint32_t n, uint32_t dst0, uint32_t cap, int has_sh,
     auto pk = [](uint16_t lo, uint16_t hi) { return (uint32_t)lo | ((uint32_t)hi << 16); };
     const uint16_t* s = scale + 3 * (size_t)i;
     const uint16_t* q = orient + 4 * (size_t)i;
-    geoB[o] = make_uint4(pk(s[0], s[1]), pk(s[2], q[0]), pk(q[1], q[2]), pk(q[3], 0));
+    // eighth half of geoB: an upper bound of |diag(scale) R(orient)^T|_F, the only thing K1's cheap extent bound needs of the
+    // scale and the (unnormalised) quaternion -- so the bound costs a dozen instructions per splat instead of ninety
+    uint16_t mf_h;
+    {
+        const float sx = gsr_h2f(s[0]), sy = gsr_h2f(s[1]), sz = gsr_h2f(s[2]);
+        const float qi = gsr_h2f(q[0]), qj = gsr_h2f(q[1]), qk = gsr_h2f(q[2]), qr = gsr_h2f(q[3]);
+        const float r00 = 1.0f - 2.0f * gsr_fma(qj, qj, qk * qk), r01 = 2.0f * gsr_fma(qi, qj, -(qr * qk)), r02 = 2.0f * gsr_fma(qi, qk, qr * qj);
+        const float r10 = 2.0f * gsr_fma(qi, qj, qr * qk), r11 = 1.0f - 2.0f * gsr_fma(qi, qi, qk * qk), r12 = 2.0f * gsr_fma(qj, qk, -(qr * qi));
+        const float r20 = 2.0f * gsr_fma(qi, qk, -(qr * qj)), r21 = 2.0f * gsr_fma(qj, qk, qr * qi), r22 = 1.0f - 2.0f * gsr_fma(qi, qi, qj * qj);
+        const float mf2 = sx * sx * (r00 * r00 + r10 * r10 + r20 * r20) + sy * sy * (r01 * r01 + r11 * r11 + r21 * r21) +
+                          sz * sz * (r02 * r02 + r12 * r12 + r22 * r22);
+        const float mf = __builtin_sqrtf(mf2) * 1.001f;
+        const _Float16 hh = (_Float16)mf;               // rounded up (to nearest, then one step if that fell short): mf >= 0
+        mf_h = __builtin_bit_cast(uint16_t, hh);
+        if ((float)hh < mf) mf_h += 1;                  // (0x7bff + 1 = inf; inf / NaN stay what they are: K1 then takes the full path)
+    }
+    geoB[o] = make_uint4(pk(s[0], s[1]), pk(s[2], q[0]), pk(q[1], q[2]), pk(q[3], mf_h));
     uint16_t h[48];
     h[0] = Cd[3 * (size_t)i]; h[1] = Cd[3 * (size_t)i + 1]; h[2] = Cd[3 * (size_t)i + 2];
     if (has_sh) {
@@ -238,140 +254,187 @@ __device__ __forceinline__ void gsr_splat_colour_from_row(const GsrFrame& f, con
     gsr_splat_colour(f, cw, x, y, z, cr, cg, cbl);
 }
 
-// K1: one thread per splat.
+// K1: the per-splat vertex stage.
 //   in : geoA, geoB, col (SoA, coalesced 16 B/lane)
-//   out: rec[i] (48 B), key[i] (f32 distance^2 bits), val[i] = (i, rect), rect[i] (packed tile rect or EMPTY)
+//   out: rec[i] (48 B), key[i] (f32 distance^2 bits), val[i] = (i, rect)
+// Two halves.  gsr_k1_front: key, clip test, centre, and -- band layout, from a cheap bound of the quad's extent -- whether the
+// splat lies far from this rank's band of tile rows.  gsr_k1_back: covariance chain, tile rect, occlusion cull, colour, record.
+// (Measured and dropped: culling BEFORE the covariance chain from the cheap bound, with the survivors compacted -- per
+// workgroup, per wave, or into dense arrays by a second kernel.  The chain is not what this kernel waits for; every variant
+// replaced one streaming pass by scattered 16-128-byte accesses, which run at a third of the streaming rate here, and lost.)
+struct GsrK1Front {
+    uint32_t kb;        // sort key (distance^2 bits, range-reduced)
+    float x, y, z;      // fl32(P - origin) + origin
+    float cx, cy, opacity;
+    bool keep;          // passes the clip tests
+    bool far;           // ... but cannot touch this rank's rows / lies behind every horizon it can reach
+};
+
+__device__ __forceinline__ GsrK1Front
+gsr_k1_front(const GsrFrame& f, const float4 a, const uint4 b, float* __restrict__ zwin_i)
+{
+    GsrK1Front o;
+    const float px = a.x, py = a.y, pz = a.z;
+    o.opacity = a.w;
+    // sort key: un-offset P vs camera (src/GSplatRenderer.C:197-201).  distance^2 >= 0: its IEEE bits
+    // are monotone.  The host bounds them for this frame from the cloud's bounding box
+    // (key_min/key_max), so the sort only has to cover key_max - key_min.
+    {
+        float dx = px - f.cam[0], dy = py - f.cam[1], dz = pz - f.cam[2];
+        float k = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
+        uint32_t kb = __builtin_bit_cast(uint32_t, k);
+        kb = kb < f.key_min ? f.key_min : (kb > f.key_max ? f.key_max : kb);
+        o.kb = kb - f.key_min;
+    }
+    // fl32(P - origin) + origin  (src/GSplatRenderer.C:459-461, shader :201-202)
+    const float x = (px - f.origin[0]) + f.origin[0];
+    const float y = (py - f.origin[1]) + f.origin[1];
+    const float z = (pz - f.origin[2]) + f.origin[2];
+    o.x = x; o.y = y; o.z = z;
+
+    const float tvx = aff4(&f.ov[0], x, y, z);
+    const float tvy = aff4(&f.ov[4], x, y, z);
+    const float tvz = aff4(&f.ov[8], x, y, z);
+    const float ftvy = -tvy;  // flipYMatrix (:204-207)
+    const float clx = aff4(&f.pr[0], tvx, ftvy, tvz);
+    const float cly = aff4(&f.pr[4], tvx, ftvy, tvz);
+    const float clz = aff4(&f.pr[8], tvx, ftvy, tvz);
+    const float clw = aff4(&f.pr[12], tvx, ftvy, tvz);
+
+    // w<=0 (:209-214); near/far clip of a constant-z quad; alpha = e*opacity <= opacity
+    // can never reach 1/255 when opacity < 1/255 (e <= 1), so those splats draw nothing.
+    o.keep = (clw > 0.0f) && !(clz < -clw || clz > clw) && (o.opacity >= (1.0f / 255.0f));
+    o.far = false;
+    o.cx = 0.0f; o.cy = 0.0f;
+    if (o.keep) {
+        const float ndcx = clx / clw;
+        const float ndcy = (-cly) / clw;
+        const float cx = gsr_fma(ndcx, 0.5f, 0.5f) * f.W;
+        const float cy = gsr_fma(ndcy, 0.5f, 0.5f) * f.H;
+        o.cx = cx; o.cy = cy;
+        // every corner carries the centre's z and w: one window depth per quad (depth range 0..1)
+        if (zwin_i) *zwin_i = gsr_fma(clz / clw, 0.5f, 0.5f);
+
+        // A cheap UPPER BOUND of the quad's half extent in pixels, without the covariance chain (lambda1 <= trace(cov2d) <=
+        // |J|_F^2 |V|_2^2 |O|_2^2 |diag(s) R^T|_F^2 + 0.6; h <= 2 sqrt2 s1 1.0001 + 0.01).  Conservative, so what it
+        // decides never changes what is drawn.  Band layout: most splats lie far from this rank's band of tile rows.
+        if (f.shard_rpb > 0) {
+            const float mf = gsr_h2f(b.w >> 16);   // >= |diag(scale) R^T|_F, from k_repack
+            const float mf2 = mf * mf;
+            const float tzb = aff4(&f.vw[8], x, y, z);
+            const float jz = f.focal / tzb;
+            const float trb = jz * jz * (2.0f + f.limx * f.limx + f.limy * f.limy) * f.sigma_vo2 * mf2 * 1.001f + 0.6f;
+            const float hb = 2.8313f * __builtin_fminf(__builtin_sqrtf(2.0f * trb), 4096.0f) + 0.02f;
+            if (hb < 1.0e9f) {   // (false for NaN / inf: those take the full path and its finite-covariance rule)
+                const float lo_px = cy - hb - 0.5f, hi_px = cy + hb - 0.5f;
+                if (f.shard_rpb > 0) {
+                    const int band_lo = f.shard_index * f.shard_rpb * GSR_TILE_PX;
+                    const int band_hi = band_lo + f.shard_rpb * GSR_TILE_PX - 1;
+                    if (hi_px < (float)band_lo || lo_px > (float)band_hi) o.far = true;
+                }
+            }
+        }
+    }
+    return o;
+}
+
+// returns the packed tile rect (GSR_RECT_EMPTY: the splat draws nothing here); writes the record of a splat that draws
+__device__ __forceinline__ uint32_t
+gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, const uint4 b, const uint4* __restrict__ col,
+            GsrRecord* __restrict__ rec, int lazy, const float* __restrict__ horizon)
+{
+    uint32_t out_rect = GSR_RECT_EMPTY;
+    const float x = o.x, y = o.y, z = o.z, cx = o.cx, cy = o.cy, opacity = o.opacity;
+    const float sx = gsr_h2f(b.x & 0xffffu), sy = gsr_h2f(b.x >> 16), sz = gsr_h2f(b.y & 0xffffu);
+    const float qi = gsr_h2f(b.y >> 16), qj = gsr_h2f(b.z & 0xffffu), qk = gsr_h2f(b.z >> 16);
+    const float qr = gsr_h2f(b.w & 0xffffu);
+    float ex = 1.0f, ey = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    const bool finite = gsr_covariance_axes(f, f.ob, x, y, z, sx, sy, sz, qi, qj, qk, qr, ex, ey, s1, s2);
+    // conservative bbox of the part of the quad where alpha can reach 1/255 (|q| <= rq <= 2)
+    const float rq = (f.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius(opacity);
+    const float hx = gsr_fma(rq * gsr_fma(s1, __builtin_fabsf(ex), s2 * __builtin_fabsf(ey)), 1.0001f, 0.01f);
+    const float hy = gsr_fma(rq * gsr_fma(s1, __builtin_fabsf(ey), s2 * __builtin_fabsf(ex)), 1.0001f, 0.01f);
+
+    // pixel range of the conservative bbox -> tile rect
+    const float xlo = cx - hx - 0.5f, xhi = cx + hx - 0.5f;
+    const float ylo = cy - hy - 0.5f, yhi = cy + hy - 0.5f;
+    const float wm1 = (float)(f.width - 1), hm1 = (float)(f.height - 1);
+    if (finite && xhi >= 0.0f && xlo <= wm1 && yhi >= 0.0f && ylo <= hm1) {
+        const int i0 = (int)__builtin_ceilf(__builtin_fmaxf(xlo, 0.0f));
+        const int i1 = (int)__builtin_floorf(__builtin_fminf(xhi, wm1));
+        const int j0 = (int)__builtin_ceilf(__builtin_fmaxf(ylo, 0.0f));
+        const int j1 = (int)__builtin_floorf(__builtin_fminf(yhi, hm1));
+        if (i1 >= i0 && j1 >= j0) out_rect = gsr_pack_rect(i0 >> 4, j0 >> 4, i1 >> 4, j1 >> 4);
+    }
+    // a splat none of whose tiles belong to this context's row shard is dropped here: it costs no
+    // colour fetch, no record and (sentinel key) no sorting
+    if (out_rect != GSR_RECT_EMPTY && gsr_rect_tiles(out_rect, GsrShard{f.shard_index, f.shard_count, f.shard_rpb}) == 0)
+        out_rect = GSR_RECT_EMPTY;
+    // Occlusion culling against the previous frame's depth horizons (gsr_api.hip: "depth horizons"): in a super-tile all of
+    // whose tiles went opaque, nothing behind the depth at which the last of them did can show.  A splat whose key lies beyond
+    // the horizon of EVERY super-tile its rect reaches is dropped here -- no colour, no record, no sorting, no binning; the
+    // binning kernels cut every list at its horizon with the same comparison, so a list holds exactly the splats in front of
+    // its horizon -- and a tile that runs off such a list without going opaque reports the frame, which is then rendered
+    // again without culling.  (The 1-KB table is read through the cache: one gather per super-tile of the rect, usually one.)
+    if (horizon && out_rect != GSR_RECT_EMPTY) {
+        const int u0 = (int)(out_rect & 255u) >> f.super_shift, v0 = (int)((out_rect >> 8) & 255u) >> f.super_shift;
+        const int u1 = (int)((out_rect >> 16) & 255u) >> f.super_shift, v1 = (int)(out_rect >> 24) >> f.super_shift;
+        if ((u1 - u0 + 1) * (v1 - v0 + 1) <= 6) {
+            uint32_t hmax = 0u;
+            for (int v = v0; v <= v1; ++v)
+                for (int u = u0; u <= u1; ++u) {
+                    const uint32_t h = gsr_horizon_key(horizon[v * f.stiles_x + u], f.key_min, f.key_max);
+                    hmax = h > hmax ? h : hmax;
+                }
+            if (o.kb > hmax) out_rect = GSR_RECT_EMPTY;
+        }
+    }
+    if (out_rect != GSR_RECT_EMPTY) {
+        // colour: Cd, optionally + SH (:224, :244-274) -- or left PENDING for the lazy colour pass (k_colour.h)
+        float cr, cg, cbl;
+        if (lazy) {
+            cr = __builtin_bit_cast(float, GSR_COLOUR_PENDING); cg = 0.0f; cbl = 0.0f;
+        } else {
+            uint4 cw[6];
+            cw[0] = col[i];
+            const int nchunk = f.sh_order == 0 ? 1 : (f.sh_order == 1 ? 2 : (f.sh_order == 2 ? 4 : 6));
+#pragma unroll
+            for (int c = 1; c < 6; ++c) {
+                cw[c] = make_uint4(0, 0, 0, 0);
+                if (c < nchunk) cw[c] = col[(size_t)c * cap + i];
+            }
+            gsr_splat_colour(f, cw, x, y, z, cr, cg, cbl);
+        }
+        // contract v2: the quad-local coordinate as two affine forms scaled by kappa = sqrt(log2 e)
+        const float k1 = (1.0f / s1) * GSR_KAPPA, k2 = (1.0f / s2) * GSR_KAPPA;
+        float4* dst = reinterpret_cast<float4*>(rec + i);
+        dst[0] = make_float4(cx, cy, hx, hy);
+        dst[1] = make_float4(ex * k1, ey * k1, -(ey * k2), ex * k2);
+        dst[2] = make_float4(cr, cg, cbl, opacity);
+    }
+    return out_rect;
+}
+
 __global__ void __launch_bounds__(GSR_K1_THREADS)
 k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col,
              GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint2* __restrict__ val,
-             float* __restrict__ zwin /* NULL unless the frame is depth-tested */, int lazy /* leave SH colours pending */)
+             float* __restrict__ zwin /* NULL unless the frame is depth-tested */, int lazy /* leave SH colours pending */,
+             const float* __restrict__ horizon /* [256] depth horizon (distance^2) per super-tile, or NULL: no occlusion culling */)
 {
+    // key 0xffffffff (never a real key: keys are distance^2 bits minus key_min) marks a splat the first radix pass drops,
+    // so everything after it runs on the surviving splats only; a dropped splat's payload is never read
     const uint32_t i = blockIdx.x * (uint32_t)GSR_K1_THREADS + threadIdx.x;
     if (i < n) {
         // geoA and geoB are fetched together; colour only once the splat is known to be needed (fetching it up front
         // was measured slower: the bytes wasted on culled splats cost more than the second round trip)
         const float4 a = geoA[i];
         const uint4 b = geoB[i];
-        const float px = a.x, py = a.y, pz = a.z, opacity = a.w;
-
-        // sort key: un-offset P vs camera (src/GSplatRenderer.C:197-201).  distance^2 >= 0: its IEEE bits
-        // are monotone.  The host bounds them for this frame from the cloud's bounding box
-        // (key_min/key_max), so the sort only has to cover key_max - key_min.
-        uint32_t kb;
-        {
-            float dx = px - f.cam[0], dy = py - f.cam[1], dz = pz - f.cam[2];
-            float k = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
-            kb = __builtin_bit_cast(uint32_t, k);
-            kb = kb < f.key_min ? f.key_min : (kb > f.key_max ? f.key_max : kb);
-            kb -= f.key_min;
-        }
+        const GsrK1Front o = gsr_k1_front(f, a, b, zwin ? zwin + i : nullptr);
         uint32_t out_rect = GSR_RECT_EMPTY;
-
-        // fl32(P - origin) + origin  (src/GSplatRenderer.C:459-461, shader :201-202)
-        const float x = (px - f.origin[0]) + f.origin[0];
-        const float y = (py - f.origin[1]) + f.origin[1];
-        const float z = (pz - f.origin[2]) + f.origin[2];
-
-        const float tvx = aff4(&f.ov[0], x, y, z);
-        const float tvy = aff4(&f.ov[4], x, y, z);
-        const float tvz = aff4(&f.ov[8], x, y, z);
-        const float ftvy = -tvy;  // flipYMatrix (:204-207)
-        const float clx = aff4(&f.pr[0], tvx, ftvy, tvz);
-        const float cly = aff4(&f.pr[4], tvx, ftvy, tvz);
-        const float clz = aff4(&f.pr[8], tvx, ftvy, tvz);
-        const float clw = aff4(&f.pr[12], tvx, ftvy, tvz);
-
-        // w<=0 (:209-214); near/far clip of a constant-z quad; alpha = e*opacity <= opacity
-        // can never reach 1/255 when opacity < 1/255 (e <= 1), so those splats draw nothing.
-        const bool keep = (clw > 0.0f) && !(clz < -clw || clz > clw) && (opacity >= (1.0f / 255.0f));
-        if (keep) {
-            const float ndcx = clx / clw;
-            const float ndcy = (-cly) / clw;
-            const float cx = gsr_fma(ndcx, 0.5f, 0.5f) * f.W;
-            const float cy = gsr_fma(ndcy, 0.5f, 0.5f) * f.H;
-            // every corner carries the centre's z and w: one window depth per quad (depth range 0..1)
-            if (zwin) zwin[i] = gsr_fma(clz / clw, 0.5f, 0.5f);
-
-            const float sx = gsr_h2f(b.x & 0xffffu), sy = gsr_h2f(b.x >> 16), sz = gsr_h2f(b.y & 0xffffu);
-            const float qi = gsr_h2f(b.y >> 16), qj = gsr_h2f(b.z & 0xffffu), qk = gsr_h2f(b.z >> 16);
-            const float qr = gsr_h2f(b.w & 0xffffu);
-            bool far_from_band = false;
-
-            // Band layout: most splats lie far from this rank's band of tile rows, and a cheap UPPER BOUND of the quad's
-            // vertical half extent settles that without the covariance chain (lambda1 <= trace(cov2d) <= |J|_F^2 |V|_2^2 |O|_2^2
-            // |diag(s) R^T|_F^2 + 0.6; hy <= 2 sqrt2 s1 1.0001 + 0.01).  Conservative, so it never changes what is drawn.
-            if (f.shard_rpb > 0) {
-                const float r00 = 1.0f - 2.0f * gsr_fma(qj, qj, qk * qk), r01 = 2.0f * gsr_fma(qi, qj, -(qr * qk)), r02 = 2.0f * gsr_fma(qi, qk, qr * qj);
-                const float r10 = 2.0f * gsr_fma(qi, qj, qr * qk), r11 = 1.0f - 2.0f * gsr_fma(qi, qi, qk * qk), r12 = 2.0f * gsr_fma(qj, qk, -(qr * qi));
-                const float r20 = 2.0f * gsr_fma(qi, qk, -(qr * qj)), r21 = 2.0f * gsr_fma(qj, qk, qr * qi), r22 = 1.0f - 2.0f * gsr_fma(qi, qi, qj * qj);
-                const float mf2 = sx * sx * (r00 * r00 + r10 * r10 + r20 * r20) + sy * sy * (r01 * r01 + r11 * r11 + r21 * r21) +
-                                  sz * sz * (r02 * r02 + r12 * r12 + r22 * r22);
-                const float tzb = aff4(&f.vw[8], x, y, z);
-                const float jz = f.focal / tzb;
-                const float trb = jz * jz * (2.0f + f.limx * f.limx + f.limy * f.limy) * f.sigma_vo2 * mf2 * 1.001f + 0.6f;
-                const float hb = 2.8313f * __builtin_fminf(__builtin_sqrtf(2.0f * trb), 4096.0f) + 0.02f;
-                if (hb < 1.0e9f) {   // (false for NaN / inf: those take the full path and its finite-covariance rule)
-                    const float lo_px = cy - hb - 0.5f, hi_px = cy + hb - 0.5f;
-                    const int band_lo = f.shard_index * f.shard_rpb * GSR_TILE_PX;
-                    const int band_hi = band_lo + f.shard_rpb * GSR_TILE_PX - 1;
-                    if (hi_px < (float)band_lo || lo_px > (float)band_hi) far_from_band = true;
-                }
-            }
-            float ex = 1.0f, ey = 0.0f, s1 = 0.0f, s2 = 0.0f;
-            const bool finite = !far_from_band && gsr_covariance_axes(f, f.ob, x, y, z, sx, sy, sz, qi, qj, qk, qr, ex, ey, s1, s2);
-            // conservative bbox of the part of the quad where alpha can reach 1/255 (|q| <= rq <= 2)
-            const float rq = (f.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius(opacity);
-            const float hx = gsr_fma(rq * gsr_fma(s1, __builtin_fabsf(ex), s2 * __builtin_fabsf(ey)), 1.0001f, 0.01f);
-            const float hy = gsr_fma(rq * gsr_fma(s1, __builtin_fabsf(ey), s2 * __builtin_fabsf(ex)), 1.0001f, 0.01f);
-
-            // pixel range of the conservative bbox -> tile rect
-            const float xlo = cx - hx - 0.5f, xhi = cx + hx - 0.5f;
-            const float ylo = cy - hy - 0.5f, yhi = cy + hy - 0.5f;
-            const float wm1 = (float)(f.width - 1), hm1 = (float)(f.height - 1);
-            if (finite && xhi >= 0.0f && xlo <= wm1 && yhi >= 0.0f && ylo <= hm1) {
-                const int i0 = (int)__builtin_ceilf(__builtin_fmaxf(xlo, 0.0f));
-                const int i1 = (int)__builtin_floorf(__builtin_fminf(xhi, wm1));
-                const int j0 = (int)__builtin_ceilf(__builtin_fmaxf(ylo, 0.0f));
-                const int j1 = (int)__builtin_floorf(__builtin_fminf(yhi, hm1));
-                if (i1 >= i0 && j1 >= j0) {
-                    out_rect = gsr_pack_rect(i0 >> 4, j0 >> 4, i1 >> 4, j1 >> 4);
-                }
-            }
-
-            // a splat none of whose tiles belong to this context's row shard is dropped here: it costs no
-            // colour fetch, no record and (sentinel key below) no sorting
-            if (out_rect != GSR_RECT_EMPTY && gsr_rect_tiles(out_rect, GsrShard{f.shard_index, f.shard_count, f.shard_rpb}) == 0)
-                out_rect = GSR_RECT_EMPTY;
-            if (out_rect != GSR_RECT_EMPTY) {
-                // colour: Cd, optionally + SH (:224, :244-274) -- or left PENDING for the lazy colour pass (k_colour.h)
-                float cr, cg, cbl;
-                if (lazy) {
-                    cr = __builtin_bit_cast(float, GSR_COLOUR_PENDING); cg = 0.0f; cbl = 0.0f;
-                } else {
-                    uint4 cw[6];
-                    cw[0] = col[i];
-                    const int nchunk = f.sh_order == 0 ? 1 : (f.sh_order == 1 ? 2 : (f.sh_order == 2 ? 4 : 6));
-#pragma unroll
-                    for (int c = 1; c < 6; ++c) {
-                        cw[c] = make_uint4(0, 0, 0, 0);
-                        if (c < nchunk) cw[c] = col[(size_t)c * cap + i];
-                    }
-                    gsr_splat_colour(f, cw, x, y, z, cr, cg, cbl);
-                }
-                // contract v2: the quad-local coordinate as two affine forms scaled by kappa = sqrt(log2 e)
-                const float k1 = (1.0f / s1) * GSR_KAPPA, k2 = (1.0f / s2) * GSR_KAPPA;
-                float4* dst = reinterpret_cast<float4*>(rec + i);
-                dst[0] = make_float4(cx, cy, hx, hy);
-                dst[1] = make_float4(ex * k1, ey * k1, -(ey * k2), ex * k2);
-                dst[2] = make_float4(cr, cg, cbl, opacity);
-            }
-        }
-        // key 0xffffffff (never a real key: keys are distance^2 bits minus key_min) marks a splat the first
-        // radix pass drops, so everything after it runs on the visible splats only
-        key[i] = (out_rect != GSR_RECT_EMPTY) ? kb : 0xffffffffu;
-        if (out_rect != GSR_RECT_EMPTY) val[i] = make_uint2(i, out_rect);   // sort payload: splat index + tile rect (a dropped
-                                                                            // splat's payload is never read)
+        if (o.keep && !o.far) out_rect = gsr_k1_back(f, i, cap, o, b, col, rec, lazy, horizon);
+        key[i] = (out_rect != GSR_RECT_EMPTY) ? o.kb : 0xffffffffu;
+        if (out_rect != GSR_RECT_EMPTY) val[i] = make_uint2(i, out_rect);   // sort payload: splat index + tile rect
     }
 }
 

@@ -40,7 +40,8 @@ class gsr_stats(C.Structure):
                 ("super_tile", C.c_int32), ("stiles_x", C.c_int32), ("stiles_y", C.c_int32), ("reserved_", C.c_int32),
                 ("blend_wave_evals_total", C.c_int64), ("stage_ms_total", C.c_double * 5),
                 ("stage_frames", C.c_int64), ("sorts_skipped", C.c_int64), ("frames_requeued", C.c_int64),
-                ("lazy_redo_tiles", C.c_int64), ("lazy_colours_total", C.c_int64), ("frames_truncated", C.c_int64)]
+                ("lazy_redo_tiles", C.c_int64), ("lazy_colours_total", C.c_int64), ("frames_truncated", C.c_int64),
+                ("frames_culled", C.c_int64), ("frames_repaired", C.c_int64)]
 
     def as_dict(self) -> dict:
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -76,6 +77,7 @@ class gsplat_attrs(C.Structure):
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_COPY = 0, 1, 2
 MISSING_CD, MISSING_OPACITY, MISSING_SCALE, MISSING_ORIENT, MISSING_SH, BAD_SH_ORDER = 1, 2, 4, 8, 16, 32
 OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE, OPT_SUPER_TILE, OPT_DEBUG_FLAGS, OPT_FRAMES_IN_FLIGHT, OPT_DEFERRED_CHECK, OPT_LAZY_COLOUR, OPT_SHARD_LAYOUT = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_OCCLUSION_CULL = 10
 
 # every symbol include/gsplat_hip.h and include/GSplatRenderer.h declare
 C_ABI_SYMBOLS = [

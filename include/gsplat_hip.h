@@ -91,6 +91,8 @@ typedef struct gsr_stats {
     int64_t lazy_colours_total;            /* lazy colour: SH evaluations by the ahead-of-time pass, running total */
     int64_t frames_truncated;              /* GSR_OPT_DEFERRED_CHECK only: frames handed over with clamped lists (must stay 0
                                               for exact pixels; the buffer is regrown for the following frames) */
+    int64_t frames_culled;                 /* GSR_OPT_OCCLUSION_CULL: frames rendered against the previous frame's depth horizons */
+    int64_t frames_repaired;               /* ... of which this many broke a horizon and were rendered again without culling */
 } gsr_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -242,6 +244,12 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        for the next frame).  The first frame after a buffer-less start is never deferred. */
 #define GSR_OPT_SHARD_LAYOUT     9   /* 0 (default) = interleaved tile rows, 1 = contiguous bands; set on every rank AND on the
                                        context that stitches */
+#define GSR_OPT_OCCLUSION_CULL  10   /* 0 / 1 (default: when the kernels find horizons for most lists, and not for a while after a
+                                       horizon broke) / 2 (whenever possible): splats behind the depth at which every tile of the super-tiles they reach went
+                                       opaque in the previous frame are dropped before projection, sorting and binning.  Exact: the lists
+                                       are cut at those horizons, a tile that runs off a cut list without going opaque reports the
+                                       frame, and gsr_render renders it again without culling before it returns (gsr_stats.frames_repaired).
+                                       Off for GSR_OPT_DEFERRED_CHECK frames and the gsr_multi / gsr_comm paths. */
 #define GSR_OPT_LAZY_COLOUR      8   /* SH colours only for the splats a frame can composite (the front of every super-tile list, as
                                        deep as the previous frame scanned, with an on-demand fallback) instead of for every visible
                                        splat: 0 = never, 2 = always, 1 (default) = when it pays -- the kernels compare, every frame,

@@ -773,6 +773,53 @@ def test_prim_ingest_renders_like_the_oracle(pkg, oracle, scheme):
         P.close(); R.close()
 
 
+@pytest.mark.parametrize("shard", [(0, 1, 0), (1, 2, 1)])
+def test_occlusion_culling_is_exact(pkg, oracle, shard):
+    """GSR_OPT_OCCLUSION_CULL: from a slot's second frame on, splats behind the previous frame's depth horizons are dropped
+    before projection, sorting and binning.  Every frame must equal the unculled render bit for bit: in a steady orbit
+    (culling engaged, horizons hold), across a camera jump and a jump in distance (horizons break: the frame is rendered
+    again), with a depth buffer, and with two frames in flight."""
+    idx, count, layout = shard
+    eng = pkg.Engine(0)
+    try:
+        splats = pkg.scenes.make_scene(400000, seed=191, sh=True, radius=1.0)
+        w, h = 960, 540
+        eng.upload(splats)
+        eng.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
+        eng.set_row_shard(idx, count)
+        cams = [pkg.camera.make_camera(w, h, sh_order=3, frame=i) for i in (0, 1, 2, 3, 4, 40, 41, 42)]
+        cams += [pkg.camera.make_camera(w, h, sh_order=3, frame=43, distance=d) for d in (2.2, 2.25, 6.0, 5.9)]
+        eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, 0)
+        want = [eng.render(c).copy() for c in cams]
+        if count == 1:
+            _check_image(want[0], oracle.render(splats, cams[0], threads=oracle.max_threads()))
+        vis_full = eng.stats()["n_visible"]
+        for fif in (1, 2):
+            eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, fif)
+            eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)         # whenever a slot has horizons (1 = when it is found to pay)
+            eng.upload(splats)                                    # forget the horizons
+            eng.stats_reset()
+            vis = []
+            for k, (c, ref) in enumerate(zip(cams, want)):
+                assert np.array_equal(eng.render(c), ref), f"frames in flight {fif}: frame {k} differs with occlusion culling"
+                vis.append(eng.stats()["n_visible"])
+            st = eng.stats()
+            assert st["frames_culled"] >= len(cams) - 2 * fif - 1, st
+            assert st["frames_repaired"] <= 4, st
+            assert min(vis) < 0.8 * vis_full, (vis, vis_full)   # it does cull
+        # with the opaque pass's depth in front of part of the cloud fewer tiles go opaque: still exact
+        rng = np.random.default_rng(7)
+        depth = np.where(rng.random((h, w)) < 0.5, 0.2, 1.0).astype(np.float32)
+        eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, 0)
+        want_d = [eng.render_depth(c, depth).copy() for c in cams[:4]]
+        eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)
+        eng.upload(splats)
+        for k, (c, ref) in enumerate(zip(cams[:4], want_d)):
+            assert np.array_equal(eng.render_depth(c, depth), ref), f"depth-tested frame {k} differs with occlusion culling"
+    finally:
+        eng.close()
+
+
 def test_lazy_colour_is_exact_and_predicts(pkg, oracle):
     """k_colour.h: SH colours are evaluated ahead of time only for the front of every super-tile list (as deep as the
     previous frame scanned); tiles that meet a pending colour fall back to on-demand evaluation.  Pixels equal eager

@@ -6,7 +6,7 @@ import sys
 
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 # a frame = from one k_preprocess to the next; take the last complete one
-starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_preprocess")]
+starts = [i for i, r in enumerate(rows) if "k_preprocess" in r["Kernel_Name"]]
 if len(starts) < 3:
     sys.exit("not enough frames in the trace")
 a, b = starts[-2], starts[-1]

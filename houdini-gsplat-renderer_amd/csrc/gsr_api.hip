@@ -206,7 +206,7 @@ struct gsr_context {
     bool lazy_pays = false;
     uint32_t vis_unculled = 0;         // splats kept by the last frame that was not culled
     bool cull_pays = false;            // ... and its third: most super-tile lists have a depth horizon (occlusion culling)
-    int cull_holdoff = 0, cull_backoff = 8, cull_streak = 0;   // frames without culling after a broken horizon (doubling, <= 256)
+    int cull_holdoff = 0, cull_backoff = 8, cull_streak = 0;   // frames without culling after a broken horizon (x4 each time, <= 1024; back to 8 after 64 good frames)
     bool order_pays = false;           // k_sum_work's other verdict: the tiles differ enough in work for k_tile_order to pay
     unsigned long long* wire_zbuf = nullptr;   // wireframe overlay: (depth bits, splat index) per pixel ...
     float* wire_out = nullptr;                 // ... and the image staged for a host target
@@ -973,7 +973,8 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     g.super_shift = j.f.super_shift; g.stiles_x = j.f.stiles_x; g.n_super = j.n_super;
     GsrHorizonArgs hz{};
     // (below a few hundred thousand splats in the sort the frame is bound by launch floors: nothing for culling to win)
-    if (c->opt_cull && j.n > 0 && j.n_super <= 256 && (c->opt_cull >= 2 || j.cull || c->vis_unculled >= 300000u)) {
+    // ... and while culling is held off nobody needs horizons: they are prepared again two frames before it may resume
+    if (c->opt_cull && j.n > 0 && j.n_super <= 256 && (c->opt_cull >= 2 || j.cull || (c->vis_unculled >= 300000u && c->cull_holdoff <= 2))) {
         hz.horizon = sl.horizon; hz.culled = j.cull ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
         hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
         hz.violation = sl.violation;
@@ -1312,6 +1313,31 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     return GSR_OK;
 }
 
+static FrameSlot* latest_slot(gsr_context* c);
+// a culled frame is handed over only once it has checked itself; one that broke a horizon is rendered again, complete
+static int frame_check(gsr_context* c, FrameSlot& slot, const gsr_camera* cam, const float* depth, int depth_is_device,
+                       float* rgba_out, int out_is_device)
+{
+    if (!slot.job.cull) return GSR_OK;
+    bool broke = false;
+    int rc = frame_verdict(c, slot, &broke);
+    if (rc) return rc;
+    if (!broke) {
+        if (++c->cull_streak >= 64) { c->cull_streak = 0; c->cull_backoff = 8; }
+        return GSR_OK;
+    }
+    c->st.frames_repaired += 1;
+    c->cull_holdoff = std::max(c->cull_holdoff, c->cull_backoff);   // the view is changing faster than the horizons follow: leave it alone for a while
+    c->cull_backoff = c->cull_backoff >= 256 ? 1024 : 4 * c->cull_backoff;   // 8, 32, 128, 512, 1024 frames
+    c->cull_streak = 0;
+    c->frame_no -= 1;          // the same frame again, in the same slot
+    c->st.frames -= 1;
+    FrameSlot* sl = nullptr;
+    rc = frame_begin(c, cam, depth, depth_is_device, rgba_out, out_is_device, &sl, false);
+    if (rc) return rc;
+    return frame_finish(c, *sl);
+}
+
 extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out, int out_is_device)
 {
     return gsr_render_depth(c, cam, nullptr, 0, rgba_out, out_is_device);
@@ -1325,32 +1351,23 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
     if (rc) return rc;
     if (sl->job.deferred) return GSR_OK;   // GSR_OPT_DEFERRED_CHECK: the pair count is looked at by the next call that syncs
     if ((rc = frame_finish(c, *sl))) return rc;
-    if (!sl->job.cull) return GSR_OK;
-    // a culled frame is handed over only once it has checked itself
-    bool broke = false;
-    if ((rc = frame_verdict(c, *sl, &broke))) return rc;
-    if (!broke) {
-        if (++c->cull_streak >= 64) { c->cull_streak = 0; c->cull_backoff = 8; }
-        return GSR_OK;
-    }
-    c->st.frames_repaired += 1;
-    c->cull_holdoff = std::max(c->cull_holdoff, c->cull_backoff);   // the view is changing faster than the horizons follow: leave it alone for a while
-    c->cull_backoff = c->cull_backoff >= 256 ? 256 : 2 * c->cull_backoff;
-    c->cull_streak = 0;
-    c->frame_no -= 1;          // the same frame again, in the same slot, complete this time
-    c->st.frames -= 1;
-    rc = frame_begin(c, cam, depth, depth_is_device, rgba_out, out_is_device, &sl, false);
-    if (rc) return rc;
-    return frame_finish(c, *sl);
+    return frame_check(c, *sl, cam, depth, depth_is_device, rgba_out, out_is_device);
 }
 
 // split form for callers that drive several contexts from one thread (gsr_multi.cpp)
 __attribute__((visibility("hidden"))) int gsr_internal_frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth,
                                                                     int depth_is_device, float* out_dev)
 {
-    return frame_begin(c, cam, depth, depth_is_device, out_dev, 1, nullptr, false);
+    return frame_begin(c, cam, depth, depth_is_device, out_dev, 1, nullptr, true);
 }
 __attribute__((visibility("hidden"))) int gsr_internal_frame_finish(gsr_context* c) { return c ? finish_open_frames(c) : GSR_OK; }
+// third step of the split form: the newest frame's occlusion-culling verdict (and the repair, if it broke a horizon)
+__attribute__((visibility("hidden"))) int gsr_internal_frame_check(gsr_context* c, const gsr_camera* cam, const float* depth,
+                                                                    int depth_is_device, float* out_dev)
+{
+    FrameSlot* sl = c ? latest_slot(c) : nullptr;
+    return sl ? frame_check(c, *sl, cam, depth, depth_is_device, out_dev, 1) : GSR_OK;
+}
 __attribute__((visibility("hidden"))) void* gsr_internal_stream(gsr_context* c) { return c ? (void*)c->stream : nullptr; }
 __attribute__((visibility("hidden"))) int gsr_internal_device(gsr_context* c) { return c ? c->device : -1; }
 

@@ -30,6 +30,7 @@
 // hooks into gsr_api.hip (hidden symbols of the same library)
 int gsr_internal_frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth, int depth_is_device, float* out_dev);
 int gsr_internal_frame_finish(gsr_context* c);
+int gsr_internal_frame_check(gsr_context* c, const gsr_camera* cam, const float* depth, int depth_is_device, float* out_dev);
 void* gsr_internal_stream(gsr_context* c);
 int gsr_internal_device(gsr_context* c);
 int gsr_internal_set_error(int code, const char* text);
@@ -334,6 +335,13 @@ extern "C" int gsr_multi_render_depth(gsr_multi* m, const gsr_camera* cam, const
     // 2. ... then look at the pair counts (each GPU keeps working while the host reads the others')
     for (int g = 0; g < G; ++g) {
         const int r = gsr_internal_frame_finish(m->ctx[g]);
+        if (r && !rc) rc = r;
+    }
+    if (rc) return rc;
+    // (occlusion culling: a rank whose frame broke a depth horizon renders it again before its band travels)
+    for (int g = 0; g < G; ++g) {
+        float* band = g == 0 ? m->gathered.p : m->band[g].p;
+        const int r = gsr_internal_frame_check(m->ctx[g], cam, dptr[g], depth_is_device, band);
         if (r && !rc) rc = r;
     }
     if (rc) return rc;

@@ -530,7 +530,8 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
             }
         }
         hz.horizon[threadIdx.x] = h;
-        if (len > 0u) { atomicAdd(&s_nused, 1u); if (h < 3.0e38f) atomicAdd(&s_nfin, 1u); }
+        // what the horizons would cut off, in list entries (of a complete list: a cut one has lost its tail already)
+        if (len > 0u) { atomicAdd(&s_nused, len); if (h < 3.0e38f && want < len) atomicAdd(&s_nfin, len - want); }
     }
     if (prefix && (int)threadIdx.x < g.n_super) {
         const uint32_t m = s_max[threadIdx.x];
@@ -558,8 +559,10 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         const uint32_t order_pays = ((unsigned long long)s_wmax * 3072ull > wsum && wsum > 60000000ull) ? 2u : 0u;
         if (lazy_hint) *lazy_hint = ((prefix && (unsigned long long)s_est * 10ull < (unsigned long long)nvis * 4ull &&
                                       s_unsat * 64u <= (uint32_t)g.n_tiles) ? 1u : 0u) | order_pays |
-                                    // bit 2: occlusion culling has something to work with (most lists got a horizon)
-                                    ((hz.horizon && s_nfin * 2u >= s_nused && s_nused > 0u) ? 4u : 0u);
+                                    // bit 2: occlusion culling has something to work with: the horizons would cut at least 30 % of
+                                    // the list entries (judged on unculled frames; a culled frame keeps the verdict it was given)
+                                    ((hz.horizon && (hz.culled || ((unsigned long long)s_nfin * 10ull >= (unsigned long long)s_nused * 3ull &&
+                                                                   s_nused > 0u))) ? 4u : 0u);
         // running totals: plain read-modify-write (a slot's frames are serialised on its stream; nothing else touches them)
         const unsigned long long t2 = old2 + s_sum[1], t4 = old4 + s_sum[0], t5 = old5 + s_sum[2];
         counters[1] = s_sum[1]; counters[2] = t2; counters[3] = s_sum[0]; counters[4] = t4; counters[5] = t5;

@@ -249,7 +249,7 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        opaque in the previous frame are dropped before projection, sorting and binning.  Exact: the lists
                                        are cut at those horizons, a tile that runs off a cut list without going opaque reports the
                                        frame, and gsr_render renders it again without culling before it returns (gsr_stats.frames_repaired).
-                                       Off for GSR_OPT_DEFERRED_CHECK frames and the gsr_multi / gsr_comm paths. */
+                                       Off for GSR_OPT_DEFERRED_CHECK frames.  Every rank of gsr_multi / gsr_comm culls and checks its own band. */
 #define GSR_OPT_LAZY_COLOUR      8   /* SH colours only for the splats a frame can composite (the front of every super-tile list, as
                                        deep as the previous frame scanned, with an on-demand fallback) instead of for every visible
                                        splat: 0 = never, 2 = always, 1 (default) = when it pays -- the kernels compare, every frame,

@@ -807,6 +807,18 @@ def test_occlusion_culling_is_exact(pkg, oracle, shard):
             assert st["frames_culled"] >= len(cams) - 2 * fif - 1, st
             assert st["frames_repaired"] <= 4, st
             assert min(vis) < 0.8 * vis_full, (vis, vis_full)   # it does cull
+        if count == 1:   # several GPUs' worth of contexts behind gsr_multi: every rank culls and checks its own band
+            eng.set_row_shard(0, 1)
+            M = pkg.MultiEngine([0, 0, 0], transport=pkg.engine.TRANSPORT_COPY)
+            try:
+                M.set_option(pkg.engine.OPT_SHARD_LAYOUT, 1)
+                M.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)
+                M.upload(splats)
+                for k, (c, ref) in enumerate(zip(cams, want)):
+                    assert np.array_equal(M.render(c), ref), f"gsr_multi: frame {k} differs with occlusion culling"
+            finally:
+                M.close()
+            eng.set_row_shard(idx, count)
         # with the opaque pass's depth in front of part of the cloud fewer tiles go opaque: still exact
         rng = np.random.default_rng(7)
         depth = np.where(rng.random((h, w)) < 0.5, 0.2, 1.0).astype(np.float32)

@@ -446,8 +446,8 @@ def main():
                             "fallback_tiles_last_frame": st["lazy_redo_tiles"]},
             "occlusion_culling": {"enabled": bool(args.cull), "frames_culled": st["frames_culled"], "frames_repaired": st["frames_repaired"],
                                   "frames": st["frames"],
-                                  "note": "splats behind the previous frame's per-super-tile depth horizons are dropped before projection and "
-                                          "sorting; every culled frame verifies itself and is rendered again without culling if a horizon "
+                                  "note": "splats whose tile rect lies wholly behind the previous frame's per-super-tile depth horizons get no colour, no record, and "
+                                          "no place in the sort and the lists; every culled frame verifies itself and is rendered again without culling if a horizon "
                                           "broke (frames_repaired; those frames are inside the timed region)"},
         }
         if pipelined is not None:

@@ -101,6 +101,7 @@ struct FrameSlot {
     // per-splat frame buffers
     GsrRecord* rec = nullptr;
     uint32_t *keyA = nullptr, *keyB = nullptr;
+    uint32_t* blk_cnt = nullptr;       // splats each K1 workgroup kept (their keys/payloads head the workgroup's 256 slots)
     uint2 *valA = nullptr, *valB = nullptr;      // depth-sort payload: (splat index, packed tile rect)
     uint32_t* d_n = nullptr;           // splats that survived culling = items after the first sort pass
     float* zwin = nullptr;             // per-splat window depth (depth-tested frames)
@@ -308,7 +309,7 @@ static bool slot_init(FrameSlot& sl)
 
 static void slot_free_splat_arrays(FrameSlot& sl)
 {
-    dev_free(sl.rec); dev_free(sl.keyA); dev_free(sl.keyB); dev_free(sl.valA); dev_free(sl.valB);
+    dev_free(sl.rec); dev_free(sl.keyA); dev_free(sl.keyB); dev_free(sl.valA); dev_free(sl.valB); dev_free(sl.blk_cnt);
     dev_free(sl.zwin);
     sl.sort_valid = false;
 }
@@ -458,9 +459,10 @@ extern "C" int gsr_upload_begin(gsr_context* c, int64_t total, int has_sh, const
         }
         for (int k = 0; k < GSR_MAX_SLOTS; ++k) {
             FrameSlot& sl = c->slot[k];
-            if ((rc = dev_alloc(&sl.rec, cap)) || (rc = dev_alloc(&sl.keyA, cap)) || (rc = dev_alloc(&sl.keyB, cap)) ||
-                (rc = dev_alloc(&sl.valA, cap)) || (rc = dev_alloc(&sl.valB, cap)) ||
-                (rc = dev_alloc(&sl.zwin, cap))) {
+            // (+256: K1 writes what it keeps at the head of its workgroup's 256 slots)
+            if ((rc = dev_alloc(&sl.rec, cap)) || (rc = dev_alloc(&sl.keyA, cap + 256)) || (rc = dev_alloc(&sl.keyB, cap + 256)) ||
+                (rc = dev_alloc(&sl.valA, cap + 256)) || (rc = dev_alloc(&sl.valB, cap + 256)) ||
+                (rc = dev_alloc(&sl.zwin, cap)) || (rc = dev_alloc(&sl.blk_cnt, cap / 256 + 16))) {
                 free_geometry(c);
                 return rc;
             }
@@ -650,28 +652,28 @@ static int ensure_u32(uint32_t** p, size_t* cap, size_t need)
     return GSR_OK;
 }
 
-template <typename V, int DBITS, bool SKIP>
+template <typename V, int DBITS, bool GATHER>
 static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, uint32_t n, const uint32_t* n_dev,
-                      int shift, uint32_t nblk, bool contig, uint32_t* n_out = nullptr)
+                      int shift, uint32_t nblk, bool contig, uint32_t* n_out = nullptr, const uint32_t* src_cnt = nullptr)
 {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS, SKIP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, n,
-                       n_dev, shift, sl.hist, nblk, contig);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS, GATHER>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, n,
+                       n_dev, shift, sl.hist, nblk, contig, src_cnt);
     hipLaunchKernelGGL(k_scan_rows, dim3(1u << DBITS), dim3(SC_THREADS), 0, sl.stream, sl.hist, nblk, sl.totals, n_dev, n,
                        (uint32_t)RS_TILE);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS, SKIP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA,
-                       vA, kB, vB, n, n_dev, shift, sl.hist, sl.totals, nblk, contig, n_out);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS, GATHER>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA,
+                       vA, kB, vB, n, n_dev, shift, sl.hist, sl.totals, nblk, contig, n_out, src_cnt);
     HIP_TRY(hipGetLastError());
     return GSR_OK;
 }
 
 // stable LSD sort on key bits [0, bits); ping-pongs (kA,vA) <-> (kB,vB) and leaves the result
 // in (kA,vA) by swapping the pointers.  9-bit digits are used when they save a pass.
-// compact_to != NULL: the first pass drops items whose key is 0xffffffff and the surviving count is
-// written to *compact_to (device); the remaining passes and the caller's later kernels read it there.
+// compact_to != NULL: the input is K1's block-compacted layout (src_cnt items at the head of every 256 slots, n slots);
+// the first pass gathers them and writes their number to *compact_to (device); the remaining passes and the caller's
+// later kernels read it there.
 template <typename V>
 static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& vB, uint32_t n, int bits,
-                      bool allow9 = true, uint32_t* compact_to = nullptr, bool contig = false,
-                      const uint32_t* first_n_dev = nullptr /* the item count lives on the device (n = its upper bound) */)
+                      bool allow9 = true, uint32_t* compact_to = nullptr, bool contig = false, const uint32_t* src_cnt = nullptr)
 {
     if (n == 0) {
         if (compact_to) HIP_TRY(hipMemsetAsync(compact_to, 0, 4, sl.stream));
@@ -686,12 +688,12 @@ static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& v
     const int passes = use9 ? p9 : p8, width = use9 ? 9 : 8;
     for (int p = 0; p < passes; ++p) {
         const bool skip = compact_to && p == 0;
-        const uint32_t* n_dev = (compact_to && p > 0) ? compact_to : (p == 0 ? first_n_dev : nullptr);
+        const uint32_t* n_dev = (compact_to && p > 0) ? compact_to : nullptr;
         if (use9)
-            rc = skip ? radix_pass<V, 9, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig, compact_to)
+            rc = skip ? radix_pass<V, 9, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig, compact_to, src_cnt)
                       : radix_pass<V, 9, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig);
         else
-            rc = skip ? radix_pass<V, 8, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig, compact_to)
+            rc = skip ? radix_pass<V, 8, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig, compact_to, src_cnt)
                       : radix_pass<V, 8, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig);
         if (rc) return rc;
         uint32_t* t = kA; kA = kB; kB = t;
@@ -1258,7 +1260,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         // output goes to the scratch buffers
         hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, GSR_K1_THREADS)), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, cache_hit ? sl.keyB : sl.keyA, cache_hit ? sl.valB : sl.valA,
-                           j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.cull ? sl.horizon : (const float*)nullptr);
+                           j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.cull ? sl.horizon : (const float*)nullptr, sl.blk_cnt);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return frame_abort(sl, set_err(GSR_E_HIP, "k_preprocess: %s", hipGetErrorString(e)));
     }
@@ -1269,7 +1271,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         int key_bits = 1;
         while (key_bits < 32 && ((f.key_max - f.key_min) >> key_bits) != 0u) ++key_bits;
         rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n, key_bits, !(c->opt_flags & GSR_FLAG_FULL_KEYS),
-                        sl.d_n, RS_XCD_DEPTH != 0);
+                        sl.d_n, RS_XCD_DEPTH != 0, sl.blk_cnt);
         if (rc) return frame_abort(sl, rc);
         sl.key_min = f.key_min;
         sl.sort_valid = true;

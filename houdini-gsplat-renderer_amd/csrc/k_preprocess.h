@@ -420,22 +420,39 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col,
              GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint2* __restrict__ val,
              float* __restrict__ zwin /* NULL unless the frame is depth-tested */, int lazy /* leave SH colours pending */,
-             const float* __restrict__ horizon /* [256] depth horizon (distance^2) per super-tile, or NULL: no occlusion culling */)
+             const float* __restrict__ horizon /* [256] depth horizon (distance^2) per super-tile, or NULL: no occlusion culling */,
+             uint32_t* __restrict__ blk_cnt /* [workgroups] splats of each workgroup that stay */)
 {
-    // key 0xffffffff (never a real key: keys are distance^2 bits minus key_min) marks a splat the first radix pass drops,
-    // so everything after it runs on the surviving splats only; a dropped splat's payload is never read
     const uint32_t i = blockIdx.x * (uint32_t)GSR_K1_THREADS + threadIdx.x;
+    uint32_t out_rect = GSR_RECT_EMPTY, kb = 0;
     if (i < n) {
         // geoA and geoB are fetched together; colour only once the splat is known to be needed (fetching it up front
         // was measured slower: the bytes wasted on culled splats cost more than the second round trip)
         const float4 a = geoA[i];
         const uint4 b = geoB[i];
         const GsrK1Front o = gsr_k1_front(f, a, b, zwin ? zwin + i : nullptr);
-        uint32_t out_rect = GSR_RECT_EMPTY;
         if (o.keep && !o.far) out_rect = gsr_k1_back(f, i, cap, o, b, col, rec, lazy, horizon);
-        key[i] = (out_rect != GSR_RECT_EMPTY) ? o.kb : 0xffffffffu;
-        if (out_rect != GSR_RECT_EMPTY) val[i] = make_uint2(i, out_rect);   // sort payload: splat index + tile rect
+        kb = o.kb;
     }
+    // The keys and payloads of the splats that stay leave compacted PER WORKGROUP, in thread (= splat index) order, at the head
+    // of the workgroup's 256 slots, with their number in blk_cnt: the depth sort's first pass gathers those prefixes
+    // (k_sort.h, GATHER) instead of reading one key per splat -- after occlusion culling one splat in thirteen stays --
+    // and, being in index order, equal keys still leave the stable sort in index order.
+    __shared__ uint32_t s_wcnt[GSR_K1_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool stays = out_rect != GSR_RECT_EMPTY;
+    const unsigned long long bal = __ballot(stays);
+    if (lane == 0) s_wcnt[wave] = (uint32_t)__builtin_popcountll(bal);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < GSR_K1_THREADS / 64; ++w) { const uint32_t c = s_wcnt[w]; before += w < wave ? c : 0u; total += c; }
+    if (stays) {
+        const uint32_t pos = blockIdx.x * (uint32_t)GSR_K1_THREADS + before + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        key[pos] = kb;
+        val[pos] = make_uint2(i, out_rect);   // sort payload: splat index + tile rect
+    }
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = total;
 }
 
 // upload time: per-workgroup partial bounding boxes of the positions (finished on the host)

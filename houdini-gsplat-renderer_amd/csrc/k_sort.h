@@ -84,11 +84,39 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_
 //                            LDS), stable ranking, LDS reorder, coalesced runs out
 // n_dev != NULL: the item count lives in device memory (it is the output of a compacting first
 // pass); the grid is sized for the host-side upper bound and surplus workgroups just publish zeros.
-// SKIP: items whose key is the sentinel 0xffffffff do not exist (compacting first pass).
-template <int DBITS, bool SKIP>
+// GATHER (the compacting first pass): the input is K1's block-compacted layout -- every RS_SRC_BLOCK slots begin with
+// src_cnt[block] items, in order, and the rest of the block's slots hold nothing.  A wave takes the valid prefixes of its
+// RS_WAVE_ITEMS / RS_SRC_BLOCK blocks one behind the other, so a pass over a frame that kept one splat in thirteen costs one
+// round per wave instead of twelve, and the items still arrive in slot (= splat index) order.
+#define RS_SRC_BLOCK 256
+#define RS_WAVE_BLOCKS (RS_WAVE_ITEMS / RS_SRC_BLOCK)
+static_assert(RS_WAVE_ITEMS % RS_SRC_BLOCK == 0, "a wave's share of a tile is whole K1 blocks");
+// the wave's blocks' counts -> total; rs_gather_slot: q-th valid item of the wave -> its slot
+__device__ __forceinline__ uint32_t rs_gather_counts(const uint32_t* __restrict__ src_cnt, uint32_t first_block, uint32_t n_src_blocks,
+                                                      uint32_t (&c)[RS_WAVE_BLOCKS])
+{
+    uint32_t tot = 0;
+#pragma unroll
+    for (int j = 0; j < RS_WAVE_BLOCKS; ++j) {
+        const uint32_t gb = first_block + (uint32_t)j;
+        c[j] = gb < n_src_blocks ? src_cnt[gb] : 0u;
+        tot += c[j];
+    }
+    return tot;
+}
+__device__ __forceinline__ uint32_t rs_gather_slot(uint32_t q, uint32_t first_block, const uint32_t (&c)[RS_WAVE_BLOCKS])
+{
+    uint32_t j = 0, before = 0;
+#pragma unroll
+    for (int t = 0; t < RS_WAVE_BLOCKS - 1; ++t)
+        if (q >= before + c[t] && j == (uint32_t)t) { before += c[t]; j = (uint32_t)t + 1u; }
+    return (first_block + j) * (uint32_t)RS_SRC_BLOCK + (q - before);
+}
+
+template <int DBITS, bool GATHER>
 __global__ void __launch_bounds__(RS_THREADS)
 k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n_host, const uint32_t* __restrict__ n_dev, int shift,
-             uint32_t* __restrict__ hist, uint32_t nblk, bool contig)
+             uint32_t* __restrict__ hist, uint32_t nblk, bool contig, const uint32_t* __restrict__ src_cnt)
 {
     constexpr int BINS = 1 << DBITS;
     constexpr uint32_t MASK = BINS - 1;
@@ -101,23 +129,26 @@ k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n_host, const uint32_t*
     __syncthreads();
     const uint32_t tile = rs_tile_of_block(blockIdx.x, nb, contig);
     const uint32_t base = tile * RS_TILE;
-    if (base + RS_TILE <= n) {
+    if (GATHER) {
+        const uint32_t first_block = (base + (uint32_t)wave * RS_WAVE_ITEMS) / RS_SRC_BLOCK;
+        uint32_t c[RS_WAVE_BLOCKS];
+        const uint32_t tot = rs_gather_counts(src_cnt, first_block, (n + RS_SRC_BLOCK - 1) / RS_SRC_BLOCK, c);
+        for (uint32_t q = threadIdx.x & 63u; q < tot; q += 64u)
+            atomicAdd(&h[wave][(keys[rs_gather_slot(q, first_block, c)] >> shift) & MASK], 1u);
+    } else if (base + RS_TILE <= n) {
         const uint4* p = reinterpret_cast<const uint4*>(keys + base);
 #pragma unroll
         for (int k = 0; k < RS_ITEMS / 4; ++k) {
             uint4 v = p[k * RS_THREADS + threadIdx.x];
-            if (!SKIP || v.x != 0xffffffffu) atomicAdd(&h[wave][(v.x >> shift) & MASK], 1u);
-            if (!SKIP || v.y != 0xffffffffu) atomicAdd(&h[wave][(v.y >> shift) & MASK], 1u);
-            if (!SKIP || v.z != 0xffffffffu) atomicAdd(&h[wave][(v.z >> shift) & MASK], 1u);
-            if (!SKIP || v.w != 0xffffffffu) atomicAdd(&h[wave][(v.w >> shift) & MASK], 1u);
+            atomicAdd(&h[wave][(v.x >> shift) & MASK], 1u);
+            atomicAdd(&h[wave][(v.y >> shift) & MASK], 1u);
+            atomicAdd(&h[wave][(v.z >> shift) & MASK], 1u);
+            atomicAdd(&h[wave][(v.w >> shift) & MASK], 1u);
         }
     } else {
         for (int k = 0; k < RS_ITEMS; ++k) {
             uint32_t i = base + k * RS_THREADS + threadIdx.x;
-            if (i < n) {
-                const uint32_t key = keys[i];
-                if (!SKIP || key != 0xffffffffu) atomicAdd(&h[wave][(key >> shift) & MASK], 1u);
-            }
+            if (i < n) atomicAdd(&h[wave][(keys[i] >> shift) & MASK], 1u);
         }
     }
     __syncthreads();
@@ -158,13 +189,14 @@ k_scan_rows(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ t
 // V = payload type: uint32_t (4 B) or uint2 (8 B: splat index + packed tile rect).
 // Item order inside a workgroup: wave w owns items [w*RS_WAVE_ITEMS, (w+1)*RS_WAVE_ITEMS) of the
 // tile, round k covers 64 consecutive items -> (wave, round, lane) is input order.
-template <typename V, int DBITS, bool SKIP>
+template <typename V, int DBITS, bool GATHER>
 __global__ void __launch_bounds__(RS_THREADS)
 k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in,
                 uint32_t* __restrict__ keys_out, V* __restrict__ vals_out, uint32_t n_host,
                 const uint32_t* __restrict__ n_dev, int shift,
                 const uint32_t* __restrict__ offs, const uint32_t* __restrict__ totals, uint32_t nblk, bool contig,
-                uint32_t* __restrict__ n_out /* compacting pass: the number of surviving items (sum of the digit totals), or NULL */)
+                uint32_t* __restrict__ n_out /* compacting pass: the number of surviving items (sum of the digit totals), or NULL */,
+                const uint32_t* __restrict__ src_cnt /* GATHER: items at the head of every RS_SRC_BLOCK slots */)
 {
     constexpr int BINS = 1 << DBITS;
     constexpr uint32_t MASK = BINS - 1;
@@ -201,16 +233,24 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
     __shared__ uint32_t s_tile_items;
     V v_[RS_ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t gc[RS_WAVE_BLOCKS];
+    const uint32_t g_first = (tile_base + (uint32_t)wave * RS_WAVE_ITEMS) / RS_SRC_BLOCK;
+    const uint32_t g_tot = GATHER ? rs_gather_counts(src_cnt, g_first, (n + RS_SRC_BLOCK - 1) / RS_SRC_BLOCK, gc) : 0u;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;
         bool valid = li < nvalid;
         uint32_t key = 0xffffffffu;
         V val{};
-        if (SKIP) {   // compacting pass: sentinel items do not exist -- and their payload is neither written (K1) nor read
-            if (valid) key = keys_in[tile_base + li];
-            valid = valid && key != 0xffffffffu;
-            if (valid) val = vals_in[tile_base + li];
+        if (GATHER) {   // compacting pass: the valid prefixes of the wave's source blocks, one behind the other
+            if ((uint32_t)(r * 64) >= g_tot) { k_[r] = key; v_[r] = val; meta[r] = 0xffffffffu; continue; }   // (wave-uniform)
+            const uint32_t q = (uint32_t)(r * 64 + lane);
+            valid = q < g_tot;
+            if (valid) {
+                const uint32_t slot = rs_gather_slot(q, g_first, gc);
+                key = keys_in[slot];
+                val = vals_in[slot];
+            }
         } else if (valid) {
             key = keys_in[tile_base + li];
             val = vals_in[tile_base + li];

@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the cpu_baseline leg")
     ap.add_argument("--no-swizzle", action="store_true", help="disable the XCD-aware tile mapping (A/B)")
+    ap.add_argument("--morton", action="store_true", help="experiment: hand the splats over in Morton order of their positions")
     ap.add_argument("--cull", type=int, default=1, help="0 = no occlusion culling against the previous frame's depth horizons (A/B)")
     ap.add_argument("--tile-order", type=int, default=2, help="1 = XCD-aware static tile order, 2 = + heaviest tiles first (A/B)")
     ap.add_argument("--super-tile", type=int, default=0, help="super-tile edge in tiles (0 = auto) (A/B)")
@@ -173,6 +174,17 @@ def main():
 
     pkg = ge.load_package()
     splats, cfg = pkg.scenes.make_config(args.config, args.splats)
+    if args.morton:
+        P = splats.P.astype(np.float64)
+        q = ((P - P.min(axis=0)) / np.maximum(np.ptp(P, axis=0), 1e-30) * 1023.0).astype(np.uint64)
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            v = (v | (v << 2)) & 0x09249249
+            return v
+        code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        splats = splats.subset(np.argsort(code, kind="stable"))
     W, H, order = cfg["width"], cfg["height"], cfg["sh_order"]
 
     eng = pkg.Engine(dev_index)

@@ -917,7 +917,11 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         HIP_TRY(hipGetLastError());
     }
     if ((rc = mark(sl, 4))) return rc;
-    if (j.lazy && j.n > 0) {
+    if (j.lazy && j.cull && j.n > 0) {
+        // an occlusion-culled frame: one evaluation per splat K1 kept (they are about what the frame composites)
+        hipLaunchKernelGGL(k_colour_kept, dim3(1024), dim3(CL_THREADS), 0, s, f, sl.valA, sl.d_n, c->colrow, sl.rec, sl.colour_evals);
+        HIP_TRY(hipGetLastError());
+    } else if (j.lazy && j.n > 0) {
         // colours for the front of every super-tile list: as deep as the previous frame's tiles scanned (+ headroom)
         const bool predict = c->prefix_valid && !(f.flags & GSR_FLAG_LAZY_NO_PREFIX);
         hipLaunchKernelGGL(k_colour_prefix, dim3((unsigned)(j.n_super * CL_BLOCKS_PER_LIST)), dim3(CL_THREADS), 0, s, f, sl.pvA,
@@ -952,7 +956,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
                                sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
-        if (j.lazy) {   // the tiles that met a pending colour, with on-demand evaluation (normally none: the blocks exit at once)
+        if (j.lazy && !j.cull) {   // the tiles that met a pending colour, with on-demand evaluation (normally none: the blocks exit at once)
             if (j.d_depth)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<true>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
                                    sl.pvA, sl.sstart, sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
@@ -977,7 +981,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     // (below a few hundred thousand splats in the sort the frame is bound by launch floors: nothing for culling to win)
     // ... and while culling is held off nobody needs horizons: they are prepared again two frames before it may resume
     if (c->opt_cull && j.n > 0 && j.n_super <= 256 && (c->opt_cull >= 2 || j.cull || (c->vis_unculled >= 300000u && c->cull_holdoff <= 2))) {
-        hz.horizon = sl.horizon; hz.culled = j.cull ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
+        hz.horizon = sl.horizon; hz.culled = j.cull ? 1 : 0; hz.fallback_skipped = (j.cull && j.lazy) ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
         hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
         hz.violation = sl.violation;
         hz.host_end = j.cull ? sl.h_end_dev : nullptr; hz.ticket = j.ticket;

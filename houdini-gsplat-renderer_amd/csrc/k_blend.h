@@ -423,6 +423,8 @@ struct GsrSumArgs {
 struct GsrHorizonArgs {
     float* horizon;                 // [256] in: this frame's (if culled), out: the next frame's; NULL = feature off
     int32_t culled;                 // this frame's lists were cut at `horizon`
+    int32_t fallback_skipped;       // ... and its colours came from k_colour_kept, so no on-demand fallback was launched: a tile
+                                    // that still met a pending colour (it cannot) would have been left undrawn -> report the frame
     const uint2* lists;             // the super-tile lists
     const float4* geoA;             // xyz = position
     float cam[3];
@@ -444,7 +446,8 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
 {
     // first thing: the frame's verdict to the host, which is waiting for it before it queues the next frame
     if (hz.host_end && threadIdx.x == 0) {
-        const uint32_t v = hz.violation ? *hz.violation : 0u;
+        uint32_t v = hz.violation ? *hz.violation : 0u;
+        if (hz.fallback_skipped && redo_count && *redo_count) v = 1u;
         *hz.host_end = ((unsigned long long)hz.ticket << 32) | (unsigned long long)(v ? 1u : 0u);
         if (hz.violation) *hz.violation = 0u;
     }

@@ -31,22 +31,14 @@
 // splats are fetched COOPERATIVELY -- eight lanes per row, eight rows per load instruction, each instruction eight full
 // lines -- into LDS, each lane then reads its own row from there, and the result goes out as ONE 16-byte store.
 #define CL_ROW_DW 36   // LDS row pitch in dwords (32 + 4: neighbouring lanes' rows start in different banks)
-__global__ void __launch_bounds__(CL_THREADS)
-k_colour_prefix(GsrFrame f, const uint2* __restrict__ lists, const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
-                const uint32_t* __restrict__ prefix, int list_cap, const uint4* __restrict__ colrow /* 8 x 16 B per splat */,
-                GsrRecord* __restrict__ rec,
-                uint32_t* __restrict__ evals /* [256] colours evaluated per super-tile list this frame (diagnostics; summed by k_sum_work) */)
+// colours of list entries e = first, first + step, ... < hi (wave-uniform bounds; the wave takes 64 consecutive entries per trip)
+__device__ __forceinline__ uint32_t
+cl_colour_span(const GsrFrame& f, const uint2* __restrict__ lists, int first, int hi, int step, const uint4* __restrict__ colrow,
+               GsrRecord* __restrict__ rec, uint32_t* srow, uint32_t* sidx)
 {
-    __shared__ uint32_t srow[CL_THREADS * CL_ROW_DW];
-    __shared__ uint32_t sidx[CL_THREADS];
     const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
-    const int s = blockIdx.x / CL_BLOCKS_PER_LIST, part = blockIdx.x % CL_BLOCKS_PER_LIST;
-    const int lo = sstart[s];
-    int hi = send[s] < list_cap ? send[s] : list_cap;
-    const uint32_t want = prefix[s];
-    if (want != 0xffffffffu && (long long)lo + (long long)want < (long long)hi) hi = lo + (int)want;
     uint32_t mine = 0;
-    for (int e0 = lo + part * CL_THREADS + wbase; e0 < hi; e0 += CL_BLOCKS_PER_LIST * CL_THREADS) {   // (wave-uniform trip count)
+    for (int e0 = first; e0 < hi; e0 += step) {   // (wave-uniform trip count)
         const int e = e0 + lane;
         const bool live = e < hi;
         const uint32_t idx = live ? lists[e].x : 0xffffffffu;
@@ -77,8 +69,42 @@ k_colour_prefix(GsrFrame f, const uint2* __restrict__ lists, const int32_t* __re
         }
         __builtin_amdgcn_wave_barrier();   // the rows are overwritten by the next trip
     }
+    return mine;
+}
+
+__global__ void __launch_bounds__(CL_THREADS)
+k_colour_prefix(GsrFrame f, const uint2* __restrict__ lists, const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
+                const uint32_t* __restrict__ prefix, int list_cap, const uint4* __restrict__ colrow /* 8 x 16 B per splat */,
+                GsrRecord* __restrict__ rec,
+                uint32_t* __restrict__ evals /* [256] colours evaluated per super-tile list this frame (diagnostics; summed by k_sum_work) */)
+{
+    __shared__ uint32_t srow[CL_THREADS * CL_ROW_DW];
+    __shared__ uint32_t sidx[CL_THREADS];
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
+    const int s = blockIdx.x / CL_BLOCKS_PER_LIST, part = blockIdx.x % CL_BLOCKS_PER_LIST;
+    const int lo = sstart[s];
+    int hi = send[s] < list_cap ? send[s] : list_cap;
+    const uint32_t want = prefix[s];
+    if (want != 0xffffffffu && (long long)lo + (long long)want < (long long)hi) hi = lo + (int)want;
+    uint32_t mine = cl_colour_span(f, lists, lo + part * CL_THREADS + wbase, hi, CL_BLOCKS_PER_LIST * CL_THREADS, colrow, rec, srow, sidx);
     // (one counter per list: atomics on ONE address serialise at ~12 ns each -- 8640 waves would cost 0.1 ms)
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
     if (lane == 0 && mine) atomicAdd(&evals[s], mine);
+}
+
+// Occlusion-culled frames: what K1 kept IS (about) what the frame composites, so the colours are evaluated once per kept splat
+// -- over the dense, sorted payload array -- instead of once per list entry of every prefix (a splat sits in ~2 lists), and no
+// record is left pending: no bail-outs, no fallback launch.  Grid-stride over the *n_dev entries.
+__global__ void __launch_bounds__(CL_THREADS)
+k_colour_kept(GsrFrame f, const uint2* __restrict__ vals, const uint32_t* __restrict__ n_dev, const uint4* __restrict__ colrow,
+              GsrRecord* __restrict__ rec, uint32_t* __restrict__ evals)
+{
+    __shared__ uint32_t srow[CL_THREADS * CL_ROW_DW];
+    __shared__ uint32_t sidx[CL_THREADS];
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
+    uint32_t mine = cl_colour_span(f, vals, (int)blockIdx.x * CL_THREADS + wbase, (int)*n_dev, (int)gridDim.x * CL_THREADS, colrow, rec, srow, sidx);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if (lane == 0 && mine) atomicAdd(&evals[blockIdx.x & 255u], mine);
 }

@@ -843,6 +843,7 @@ def test_lazy_colour_is_exact_and_predicts(pkg, oracle):
         w, h = 960, 540
         eng.upload(splats)
         cams = [pkg.camera.make_camera(w, h, sh_order=3, frame=i) for i in (0, 1, 2, 3, 40, 41)]   # 3 deg steps, then a jump
+        eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, 0)      # (culled frames colour what K1 kept instead: their own test)
         eng.set_option(pkg.engine.OPT_LAZY_COLOUR, 0)
         want = [eng.render(c) for c in cams]
         _check_image(want[0], oracle.render(splats, cams[0], threads=oracle.max_threads()))

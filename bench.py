@@ -57,6 +57,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the cpu_baseline leg")
     ap.add_argument("--no-swizzle", action="store_true", help="disable the XCD-aware tile mapping (A/B)")
     ap.add_argument("--morton", action="store_true", help="experiment: hand the splats over in Morton order of their positions")
+    ap.add_argument("--time-every", type=int, default=0, help="HIP events around the blend kernel of every N-th frame of the timed region; "
+                    "0 = min(8, steps / 16), so that at least 16 launches are timed "
+                    "(each pair idles the queue ~12 us; the roofline's launch time is the mean over the sampled launches)")
     ap.add_argument("--cull", type=int, default=1, help="0 = no occlusion culling against the previous frame's depth horizons (A/B)")
     ap.add_argument("--tile-order", type=int, default=2, help="1 = XCD-aware static tile order, 2 = + heaviest tiles first (A/B)")
     ap.add_argument("--super-tile", type=int, default=0, help="super-tile edge in tiles (0 = auto) (A/B)")
@@ -193,6 +196,7 @@ def main():
     torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
     eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, args.cull)
+    eng.set_option(pkg.engine.OPT_TIMING_EVERY, args.time_every if args.time_every > 0 else max(1, min(8, args.steps // 16)))
     eng.set_option(pkg.engine.OPT_XCD_SWIZZLE, 0 if args.no_swizzle else args.tile_order)
     eng.set_option(pkg.engine.OPT_SUPER_TILE, args.super_tile)
     eng.set_option(pkg.engine.OPT_DEBUG_FLAGS, args.flags)
@@ -318,6 +322,21 @@ def main():
     eng.set_option(pkg.engine.OPT_STAGE_TIMING, args.stage_timing)
     if world > 1:
         dist.barrier()
+    # extra leg (informational, single GPU): the same frames with occlusion culling switched off
+    unculled = None
+    if world == 1 and args.cull:
+        eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, 0)
+        for i in range(min(5, args.warmup + args.steps)):
+            step(i)
+        torch.cuda.synchronize()
+        k2 = min(40, args.steps)
+        t0 = time.perf_counter()
+        for i in range(k2):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        unculled = {"value": k2 / (time.perf_counter() - t0), "unit": "frames/sec", "steps": k2,
+                    "note": "GSR_OPT_OCCLUSION_CULL=0: every clip-visible splat is coloured (lazily), sorted and binned"}
+        eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, args.cull)
     # extra leg (informational): the same K steps with two frames in flight
     pipelined = None
     if args.pipelined and args.frames_in_flight == 1:
@@ -345,10 +364,11 @@ def main():
                      "note": "GSR_OPT_FRAMES_IN_FLIGHT=2: frame f+1's front end overlaps frame f's blend kernel"}
         eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, args.frames_in_flight)
     # blend-kernel roofline, measured with HIP events on the kernel's own stream
-    launches = max(1, st["blend_launches"])
+    launches = max(1, st["blend_launches"])                    # launches bracketed by events (every --time-every-th frame)
+    frames_done = max(1, st["frames"])                         # launches in all: the kernel's own counters cover every one
     blend_ms = st["blend_ms_total"] / launches
-    d_eff = st["blend_pairs_consumed_total"] / launches       # (tile, splat) pairs CONSUMED per launch = records gathered
-    scanned = st["blend_entries_scanned_total"] / launches     # list entries (idx + rect) read per launch
+    d_eff = st["blend_pairs_consumed_total"] / frames_done     # (tile, splat) pairs CONSUMED per launch = records gathered
+    scanned = st["blend_entries_scanned_total"] / frames_done  # list entries (idx + mask) read per launch
     rec_b, pair_b = st["record_bytes"], st["pair_bytes"]
     shards = args.emulate_shard if (world == 1 and args.emulate_shard > 1) else world
     srank = (args.emulate_rank % shards) if (world == 1 and args.emulate_shard > 1) else rank
@@ -377,7 +397,8 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": "k_blend", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_replayed_from": traffic_from,
-        "avg_launch_ms": blend_ms, "algorithmic_bytes_per_launch": bytes_blend,
+        "avg_launch_ms": blend_ms, "launches_timed": int(st["blend_launches"]), "launches": int(st["frames"]),
+        "algorithmic_bytes_per_launch": bytes_blend,
         "pairs_consumed_per_launch": d_eff, "bytes_per_consumed_pair": pair_b + rec_b,
         "entries_scanned_per_launch": scanned, "list_scan_bytes": pair_b * scanned,
         "scan_amplification": scanned / d_eff if d_eff > 0 else None,
@@ -390,7 +411,7 @@ def main():
     # (fma = 2: affine forms 8, power 3, contract-exp2 13, opacity+clamp 2, under-blend 8), counted
     # per 64-lane wave evaluation by the kernel itself (lanes outside the quad execute the same instructions)
     FLOP_PER_EVAL = 34.0
-    wave_evals = st["blend_wave_evals_total"] / launches
+    wave_evals = st["blend_wave_evals_total"] / frames_done
     valu_tflops = wave_evals * 64 * FLOP_PER_EVAL / (blend_ms * 1e-3) / 1e12 if blend_ms > 0 else 0.0
     # ... and against the ISSUE RATES measured on this GPU (tools/ubench_valu.hip -> profiles/ubench_valu_mi355x.txt).
     # One inner-loop iteration = two wave-record evaluations (ISA of k_blend<false>, tools/kernel_resources.py --isa):
@@ -457,7 +478,7 @@ def main():
                             "visible_splats": st["n_visible"],
                             "fallback_tiles_last_frame": st["lazy_redo_tiles"]},
             "occlusion_culling": {"enabled": bool(args.cull), "frames_culled": st["frames_culled"], "frames_repaired": st["frames_repaired"],
-                                  "frames": st["frames"],
+                                  "frames": st["frames"], "without": unculled,
                                   "note": "splats whose tile rect lies wholly behind the previous frame's per-super-tile depth horizons get no colour, no record, and "
                                           "no place in the sort and the lists; every culled frame verifies itself and is rendered again without culling if a horizon "
                                           "broke (frames_repaired; those frames are inside the timed region)"},

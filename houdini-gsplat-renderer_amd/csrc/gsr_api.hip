@@ -21,6 +21,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <algorithm>
 #include <new>
 #include <vector>
@@ -31,6 +32,10 @@
 #include "k_blend.h"
 #include "k_colour.h"
 #include "k_preprocess.h"
+#ifdef GSR_HOST_TIMING
+static double g_t_verdict = 0, g_acc_py = 0, g_acc_pre = 0, g_acc_launch = 0; static long g_acc_n = 0;
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#endif
 #include "k_sort.h"
 #include "k_wire.h"
 
@@ -197,7 +202,7 @@ struct gsr_context {
     int map_w = 0, map_h = 0, map_si = -1, map_sc = 0, map_rpb = -1, map_shift = -1, map_grid = 0;
 
     int shard_index = 0, shard_count = 1, shard_layout = 0;   // layout: 0 = interleaved rows, 1 = contiguous bands
-    int opt_swizzle = 2, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0, opt_lazy = 1, opt_cull = 1;
+    int opt_swizzle = 2, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0, opt_lazy = 1, opt_cull = 1, opt_timing_every = 1;
 
     gsr_stats st{};
     uint64_t frame_no = 0;
@@ -416,6 +421,7 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
         break;
     case GSR_OPT_DEBUG_FLAGS: c->opt_flags = value; break;
     case GSR_OPT_DEFERRED_CHECK: c->opt_deferred = value ? 1 : 0; break;
+    case GSR_OPT_TIMING_EVERY: c->opt_timing_every = value < 1 ? 1 : (value > 1024 ? 1024 : value); break;
     case GSR_OPT_OCCLUSION_CULL: c->opt_cull = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_LAZY_COLOUR: c->opt_lazy = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_SHARD_LAYOUT: c->shard_layout = value ? 1 : 0; break;
@@ -1153,6 +1159,9 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     if (cam->width <= 0 || cam->height <= 0 || cam->width > GSR_MAX_DIM || cam->height > GSR_MAX_DIM)
         return set_err(GSR_E_INVALID, "gsr_render: bad framebuffer size %dx%d (max %d)", cam->width, cam->height, GSR_MAX_DIM);
     if (c->geo_gen == 0) return set_err(GSR_E_NO_GEOMETRY, "gsr_render: nothing uploaded");
+#ifdef GSR_HOST_TIMING
+    const double t_enter = now_us();
+#endif
     HIP_TRY(hipSetDevice(c->device));
 
     // Frames alternate between the slots.  Everything up to the blend kernel touches only the slot's
@@ -1188,7 +1197,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     j.band_rows = (c->shard_count > 1) ? gsr_band_rows(cam->height, c->shard_index, c->shard_count) : cam->height;
     j.out_px = (size_t)j.band_rows * cam->width;
     j.n_super = f.stiles_x * f.stiles_y;
-    j.timing = c->opt_timing != 0;
+    j.timing = c->opt_timing != 0 && (c->opt_timing >= 2 || c->frame_no % (uint64_t)c->opt_timing_every == 0);
     j.timing_all = c->opt_timing >= 2;   // level 1 brackets only the blend kernel (events 5 and 6)
     j.use_map = c->opt_swizzle != 0;
     j.user_out = rgba_out;
@@ -1260,12 +1269,25 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     // (a culled frame's order holds only the splats in front of ITS horizons, and the horizons move: no reuse either way)
     const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now) && !j.cull && !sl.sorted_culled;
     if (n > 0) {
+#ifdef GSR_HOST_TIMING
+        const double t_pre = now_us();
+#endif
         // on a cache hit (identical frame description) the sorted (keyA, valA) are kept and K1's key/payload
         // output goes to the scratch buffers
         hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, GSR_K1_THREADS)), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, cache_hit ? sl.keyB : sl.keyA, cache_hit ? sl.valB : sl.valA,
                            j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.cull ? sl.horizon : (const float*)nullptr, sl.blk_cnt);
         hipError_t e = hipGetLastError();
+#ifdef GSR_HOST_TIMING
+        if (g_t_verdict > 0) {
+            const double t_l = now_us();
+            g_acc_py += t_enter - g_t_verdict; g_acc_pre += t_pre - t_enter; g_acc_launch += t_l - t_pre; ++g_acc_n;
+            if (g_acc_n % 100 == 0)
+                fprintf(stderr, "[host timing] verdict -> gsr_render %.1f us, frame_begin before K1 %.1f us, K1 launch %.1f us (avg of %ld)\n",
+                        g_acc_py / g_acc_n, g_acc_pre / g_acc_n, g_acc_launch / g_acc_n, g_acc_n);
+            g_t_verdict = 0;
+        }
+#endif
         if (e != hipSuccess) return frame_abort(sl, set_err(GSR_E_HIP, "k_preprocess: %s", hipGetErrorString(e)));
     }
     if ((rc = mark(sl, 1))) return frame_abort(sl, rc);
@@ -1330,6 +1352,9 @@ static int frame_check(gsr_context* c, FrameSlot& slot, const gsr_camera* cam, c
     if (rc) return rc;
     if (!broke) {
         if (++c->cull_streak >= 64) { c->cull_streak = 0; c->cull_backoff = 8; }
+#ifdef GSR_HOST_TIMING
+        g_t_verdict = now_us();
+#endif
         return GSR_OK;
     }
     c->st.frames_repaired += 1;

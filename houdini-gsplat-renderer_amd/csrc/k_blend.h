@@ -449,6 +449,7 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         uint32_t v = hz.violation ? *hz.violation : 0u;
         if (hz.fallback_skipped && redo_count && *redo_count) v = 1u;
         *hz.host_end = ((unsigned long long)hz.ticket << 32) | (unsigned long long)(v ? 1u : 0u);
+        __threadfence_system();   // out to the host NOW (without it the word left with the kernel's end: a 13 us bubble before the next frame)
         if (hz.violation) *hz.violation = 0u;
     }
     __shared__ uint32_t s_open[256];   // super-tiles with a tile that did not go opaque: no horizon there

@@ -244,6 +244,8 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        for the next frame).  The first frame after a buffer-less start is never deferred. */
 #define GSR_OPT_SHARD_LAYOUT     9   /* 0 (default) = interleaved tile rows, 1 = contiguous bands; set on every rank AND on the
                                        context that stitches */
+#define GSR_OPT_TIMING_EVERY    11   /* timing level 1 brackets the blend kernel of every N-th frame only (default 1): a pair of events in
+                                       the stream costs the GPU ~12 us of idle queue, and an average wants a sample, not a census */
 #define GSR_OPT_OCCLUSION_CULL  10   /* 0 / 1 (default: when the kernels find horizons for most lists, and not for a while after a
                                        horizon broke) / 2 (whenever possible): splats behind the depth at which every tile of the super-tiles they reach went
                                        opaque in the previous frame are dropped before projection, sorting and binning.  Exact: the lists

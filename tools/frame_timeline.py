@@ -9,7 +9,9 @@ rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Time
 starts = [i for i, r in enumerate(rows) if "k_preprocess" in r["Kernel_Name"]]
 if len(starts) < 3:
     sys.exit("not enough frames in the trace")
-a, b = starts[-2], starts[-1]
+# optional second argument: which frame (index into the frames of the trace; default: the last complete one)
+which = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) - 2
+a, b = starts[which], starts[which + 1]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = None
 busy = 0

@@ -127,6 +127,7 @@ struct FrameSlot {
     size_t order_cap = 0;              //   for this slot's next frame (valid while the tile geometry stays what it was)
     bool order_valid = false;
     int order_sig[6] = {0, 0, 0, 0, 0, 0}, order_per_xcd = 0;
+    uint32_t* st_scan = nullptr;       // [512] per super-tile: deepest scan of its opaque tiles / "a tile stayed open" (k_blend -> k_sum_work)
     uint32_t* sup_work = nullptr;      // [2][256] per-super-tile work sums of the blend kernel, by frame parity
     int sup_par = 0;
     // Depth horizons (occlusion culling): per super-tile, the distance^2 beyond which this slot's NEXT frame drops splats --
@@ -240,6 +241,13 @@ static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; 
 
 // ---------------------------------------------------------------------------
 // for the other translation units of the library (gsr_multi.cpp)
+#ifdef SW_PROFILE
+extern "C" int gsr_debug_sw_profile(unsigned long long* out8) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sw_prof), 64);
+    return 0;
+}
+#endif
 #ifdef BL_PROFILE
 extern "C" int gsr_debug_blend_profile(unsigned long long* out, int reset) {   // out: [BLP_MAX_WG][4][16]
     hipDeviceSynchronize();
@@ -294,6 +302,8 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_end), sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
     if (ok) sl.h_end[0] = 0ull;
     ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_end_dev), sl.h_end, 0) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.st_scan), 512 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(sl.st_scan, 0, 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.sup_work), 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.sup_work, 0, 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
@@ -324,7 +334,7 @@ static void slot_destroy(FrameSlot& sl)
     slot_free_splat_arrays(sl);
     dev_free(sl.hist); dev_free(sl.totals);
     dev_free(sl.pvA);
-    dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.fb);
+    dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.st_scan); dev_free(sl.fb);
     dev_free(sl.horizon); dev_free(sl.violation);
     if (sl.h_end) (void)hipHostFree(sl.h_end); dev_free(sl.depth_stage);
     dev_free(sl.redo); dev_free(sl.lazy_ctr); dev_free(sl.colour_evals);
@@ -944,6 +954,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
         a.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
         a.sup_work = (a.use_map && c->opt_swizzle >= 2 && sl.sup_work) ? sl.sup_work + 256 * sl.sup_par : nullptr;
+        a.st_scan = sl.st_scan;
         a.horizon = j.cull ? sl.horizon : nullptr;
         a.violation = sl.violation;
         // heaviest-first table of this slot's previous frame, if that frame had the same tiles
@@ -996,7 +1007,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
                        (j.f.sh_order > 0 && c->opt_lazy) ? c->prefix : (uint32_t*)nullptr,
                        j.lazy ? reinterpret_cast<const uint32_t*>(sl.lazy_ctr) : (const uint32_t*)nullptr,
                        sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint,
-                       sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr, hz);
+                       sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr, hz, sl.st_scan);
     HIP_TRY(hipGetLastError());
     sl.horizon_valid = hz.horizon != nullptr;
     if (sl.horizon_valid) {

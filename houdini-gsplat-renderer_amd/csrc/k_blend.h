@@ -67,6 +67,8 @@ struct GsrBlendArgs {
     int32_t flags;              // GSR_FLAG_*
     int32_t list_cap;           // entries the list buffer holds (a speculative launch may see ranges beyond it)
     uint32_t* sup_work;         // [256] work per super-tile, summed over its tiles (or NULL)
+    uint32_t* st_scan;          // [512] per super-tile: [st] deepest scan among its tiles that went opaque, [256 + st] set if one did
+                                // not -- what k_sum_work turns into colour prefixes and depth horizons without walking the tiles
     const float* horizon;       // [256] occlusion culling: this frame's lists end at these depth horizons (or NULL: complete lists)
     uint32_t* violation;        // set when a tile runs off a list cut at its horizon without going opaque: the frame is redone
 };
@@ -374,6 +376,10 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         // occlusion culling: what this tile saw is complete only up to its super-tile's horizon
         if (a.horizon && !saturated && a.horizon[st] < 3.0e38f) *a.violation = 1u;
         tile_work[tile] = tw;
+        if (a.st_scan) {   // (fire and forget, like the work sums below)
+            if (saturated) atomicMax(&a.st_scan[st], tw.x);
+            else a.st_scan[256 + st] = 1u;
+        }
         // work of the tile's super-tile, for k_tile_order (fire and forget: ~60 tiles per address and frame)
         if (a.sup_work && gsr_tile_weight(tw)) atomicAdd(&a.sup_work[st], gsr_tile_weight(tw));
     }
@@ -404,8 +410,14 @@ k_blend_lazy(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* 
 // [2] (records, running total), [3] (entries scanned, this frame), [4] (entries, running total),
 // [5] (wave-record evaluations, running total) -- a handful of atomics per frame instead of per
 // tile (same-address atomics serialise at ~12 ns each on MI355X).  Last kernel of a frame.
+#ifdef SW_PROFILE
+__device__ unsigned long long g_sw_prof[8];
+#define SWP(i) { if (threadIdx.x == 0) g_sw_prof[i] = clock64(); }
+#else
+#define SWP(i)
+#endif
 #define SW_THREADS 1024
-#define SW_UNROLL 8
+#define SW_UNROLL 12
 #ifndef SW_HEADROOM_SHIFT
 #define SW_HEADROOM_SHIFT 2
 #endif
@@ -442,8 +454,9 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
            const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
            uint32_t* __restrict__ lazy_hint /* would lazy colour pay for a frame like this one? (read by the next frames) */,
            uint32_t* __restrict__ sup_work_next /* [256] the NEXT frame's per-super-tile work sums: cleared here (or NULL) */,
-           GsrHorizonArgs hz)
+           GsrHorizonArgs hz, uint32_t* __restrict__ st_scan /* [512] per super-tile scan depths / open flags from k_blend: read, cleared */)
 {
+    SWP(0)
     // first thing: the frame's verdict to the host, which is waiting for it before it queues the next frame
     if (hz.host_end && threadIdx.x == 0) {
         uint32_t v = hz.violation ? *hz.violation : 0u;
@@ -452,104 +465,99 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         __threadfence_system();   // out to the host NOW (without it the word left with the kernel's end: a 13 us bubble before the next frame)
         if (hz.violation) *hz.violation = 0u;
     }
-    __shared__ uint32_t s_open[256];   // super-tiles with a tile that did not go opaque: no horizon there
-    if (threadIdx.x < 256) s_open[threadIdx.x] = 0u;
     if (sup_work_next && threadIdx.x < 256) sup_work_next[threadIdx.x] = 0u;
     __shared__ unsigned long long s_sum[3];
-    __shared__ uint32_t s_max[256];
     __shared__ uint32_t s_unsat, s_est, s_cev, s_wmax, s_nfin, s_nused;
-    // Everything the tail of this kernel needs from memory is fetched NOW, next to the tile_work loads: the kernel is one
-    // workgroup at the very end of the frame, and every dependent global round trip in it (~1-2 us) is frame latency.
+    // The kernel is one workgroup at the very end of the frame and the next frame's K1 waits for it: every dependent global
+    // round trip (~2 us) is frame latency.  So the work is split by wave.  Waves 0-3 (one thread per super-tile) turn the
+    // blend kernel's per-super-tile scan depths into the next frame's colour prefixes and depth horizons -- three dependent
+    // loads: depth, list entry, position -- WHILE waves 4-15 walk the per-tile bookkeeping for the statistics and hints;
+    // everything else either half needs from memory is fetched up front.
     unsigned long long old2 = 0, old4 = 0, old5 = 0, old_ct = 0;
-    uint32_t nvis = 0, nredo = 0, my_len = 0, my_cev = 0;
+    uint32_t nvis = 0, nredo = 0, my_cev = 0;
     if (threadIdx.x == 0) {
         old2 = counters[2]; old4 = counters[4]; old5 = counters[5];
         nvis = *n_visible;
         nredo = redo_count ? *redo_count : 0u;
         if (colour_evals) old_ct = *colour_total;
     }
-    if (prefix && (int)threadIdx.x < g.n_super) my_len = (uint32_t)(send[threadIdx.x] - sstart[threadIdx.x]);
     if (colour_evals && threadIdx.x < 256) my_cev = colour_evals[threadIdx.x];
     if (threadIdx.x == 0) { s_unsat = 0; s_est = 0; s_cev = 0; s_wmax = 0; s_nfin = 0; s_nused = 0; }
     if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
-    if (threadIdx.x < 256) s_max[threadIdx.x] = 0;
     __syncthreads();
-    unsigned long long sc = 0, fe = 0, ev = 0;
-    uint32_t wmax = 0;    // heaviest tile (gsr_tile_weight)
-    uint32_t unsat = 0;   // tiles that composited something and ran to the end of their list: lazy colour sends them to the fallback
-    // tile i = tid + 1024 k walks the (tx, row) grid without a division per tile
-    const int q1k = SW_THREADS / g.tiles_x, r1k = SW_THREADS % g.tiles_x;
-    int tx = (int)threadIdx.x % g.tiles_x, ty = (int)threadIdx.x / g.tiles_x;
-    for (int i0 = 0; i0 < g.n_tiles; i0 += SW_UNROLL * SW_THREADS) {
-        uint4 w[SW_UNROLL];
-#pragma unroll
-        for (int u = 0; u < SW_UNROLL; ++u) {   // independent loads: one memory round trip per 8192 tiles
-            const int i = i0 + u * SW_THREADS + (int)threadIdx.x;
-            w[u] = i < g.n_tiles ? tile_work[i] : make_uint4(0u, 0u, 0u, 0u);
-        }
-#pragma unroll
-        for (int u = 0; u < SW_UNROLL; ++u) {
-            sc += w[u].x; fe += w[u].y; ev += w[u].z;
-            { const uint32_t tw = gsr_tile_weight(w[u]); wmax = tw > wmax ? tw : wmax; }
-            const int i = i0 + u * SW_THREADS + (int)threadIdx.x;
-            // deepest scan among the tiles of each super-tile that SATURATED: a tile that ran to the end of its list (the
-            // cloud's silhouette) would ask for the whole list; such tiles have few hits and take the on-demand fallback
-            if (i < g.n_tiles && !w[u].w && w[u].y) ++unsat;
-            if ((prefix || hz.horizon) && i < g.n_tiles) {
-                const int gty = gsr_shard_global_row(g.shard, ty);
-                const int st = (gty >> g.super_shift) * g.stiles_x + (tx >> g.super_shift);
-                if (w[u].w) atomicMax(&s_max[st], w[u].x);
-                else s_open[st] = 1u;
+    SWP(2)
+    if (threadIdx.x < 256) {
+        const int st = (int)threadIdx.x;
+        if (st < g.n_super && st_scan) {
+            const uint32_t m = st_scan[st], open = st_scan[256 + st];
+            const int ss = sstart[st], se = send[st];
+            const float old = hz.horizon ? hz.horizon[st] : 0.0f;
+            st_scan[st] = 0u; st_scan[256 + st] = 0u;   // (for the slot's next frame)
+            const uint32_t len = (uint32_t)(se - ss);
+            if (hz.horizon) {
+                // The next frame's horizon: the distance of the list entry a quarter (+1024 entries) beyond the deepest scan --
+                // the same headroom the lazy colour pass uses.  A list that was itself cut at a horizon may be too short for
+                // that: then the horizon it was cut at is pushed out by 5 % (in distance^2) instead.
+                const uint32_t want = m + (m >> 2) + 1024u;
+                float h = __builtin_inff();
+                if (!open && len > 0u) {
+                    if (want < len) {
+                        const uint32_t idx = hz.lists[(uint32_t)ss + want].x;
+                        const float4 P = hz.geoA[idx];
+                        const float dx = P.x - hz.cam[0], dy = P.y - hz.cam[1], dz = P.z - hz.cam[2];
+                        h = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
+                    } else if (hz.culled && old < 3.0e38f) {
+                        h = old * 1.05f;
+                    }
+                }
+                hz.horizon[st] = h;
+                // what the horizons would cut off, in list entries (of a complete list: a cut one has lost its tail already)
+                if (len > 0u) { atomicAdd(&s_nused, len); if (h < 3.0e38f && want < len) atomicAdd(&s_nfin, len - want); }
             }
-            tx += r1k; ty += q1k;
-            if (tx >= g.tiles_x) { tx -= g.tiles_x; ++ty; }
-        }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); unsat += __shfl_down(unsat, d, 64);
-        { const uint32_t o = __shfl_down(wmax, d, 64); wmax = o > wmax ? o : wmax; }
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); atomicAdd(&s_sum[2], ev); atomicAdd(&s_unsat, unsat); atomicMax(&s_wmax, wmax);
-    }
-    __syncthreads();
-    if (hz.horizon && (int)threadIdx.x < g.n_super) {
-        // The next frame's horizon: the distance of the list entry a quarter (+1024 entries) beyond the deepest scan -- the
-        // same headroom the lazy colour pass uses.  A list that was itself cut at a horizon may be too short for that: then the
-        // horizon it was cut at is pushed out by 5 % (in distance^2) instead.
-        const uint32_t m = s_max[threadIdx.x];
-        const uint32_t len = (uint32_t)(send[threadIdx.x] - sstart[threadIdx.x]);
-        const uint32_t want = m + (m >> 2) + 1024u;
-        const float old = hz.horizon[threadIdx.x];
-        float h = __builtin_inff();
-        if (!s_open[threadIdx.x] && len > 0u) {
-            if (want < len) {
-                const uint32_t idx = hz.lists[(uint32_t)sstart[threadIdx.x] + want].x;
-                const float4 P = hz.geoA[idx];
-                const float dx = P.x - hz.cam[0], dy = P.y - hz.cam[1], dz = P.z - hz.cam[2];
-                h = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
-            } else if (hz.culled && old < 3.0e38f) {
-                h = old * 1.05f;
+            if (prefix) {
+                {   // how many colour evaluations the lazy pass would make for a frame like this one
+                    const uint32_t want = m + (m >> SW_HEADROOM_SHIFT_) + SW_HEADROOM_ADD_;
+                    atomicAdd(&s_est, want < len ? want : len);
+                }
+                prefix[st] = m + (m >> SW_HEADROOM_SHIFT) + SW_HEADROOM_ADD;   // headroom for the next frame's camera move
             }
         }
-        hz.horizon[threadIdx.x] = h;
-        // what the horizons would cut off, in list entries (of a complete list: a cut one has lost its tail already)
-        if (len > 0u) { atomicAdd(&s_nused, len); if (h < 3.0e38f && want < len) atomicAdd(&s_nfin, len - want); }
-    }
-    if (prefix && (int)threadIdx.x < g.n_super) {
-        const uint32_t m = s_max[threadIdx.x];
-        {   // how many colour evaluations the lazy pass would make for a frame like this one
-            const uint32_t want = m + (m >> SW_HEADROOM_SHIFT_) + SW_HEADROOM_ADD_;
-            atomicAdd(&s_est, want < my_len ? want : my_len);
+    } else {
+        constexpr int TL = SW_THREADS - 256;   // threads of the tile walk
+        const int t = (int)threadIdx.x - 256;
+        unsigned long long sc = 0, fe = 0, ev = 0;
+        uint32_t wmax = 0;    // heaviest tile (gsr_tile_weight)
+        uint32_t unsat = 0;   // tiles that composited something and ran to the end of their list: lazy colour sends them to the fallback
+        for (int i0 = 0; i0 < g.n_tiles; i0 += SW_UNROLL * TL) {
+            uint4 w[SW_UNROLL];
+#pragma unroll
+            for (int u = 0; u < SW_UNROLL; ++u) {   // independent loads: one memory round trip per sweep
+                const int i = i0 + u * TL + t;
+                w[u] = i < g.n_tiles ? tile_work[i] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < SW_UNROLL; ++u) {
+                sc += w[u].x; fe += w[u].y; ev += w[u].z;
+                { const uint32_t tw = gsr_tile_weight(w[u]); wmax = tw > wmax ? tw : wmax; }
+                if (!w[u].w && w[u].y) ++unsat;
+            }
         }
-        prefix[threadIdx.x] = m + (m >> SW_HEADROOM_SHIFT) + SW_HEADROOM_ADD;   // headroom for the next frame's camera move
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); unsat += __shfl_down(unsat, d, 64);
+            { const uint32_t o = __shfl_down(wmax, d, 64); wmax = o > wmax ? o : wmax; }
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); atomicAdd(&s_sum[2], ev); atomicAdd(&s_unsat, unsat); atomicMax(&s_wmax, wmax);
+        }
     }
+    SWP(3)
     if (colour_evals && threadIdx.x < 256) {
         colour_evals[threadIdx.x] = 0u;
         if (my_cev) atomicAdd(&s_cev, my_cev);
     }
     __syncthreads();
+    SWP(4)
     if (threadIdx.x == 0) {
         // Lazy colour pays when the colour pass would evaluate well under half of what eager evaluation does (it gathers
         // rows at random, eager streams them) and (almost) no tile would need the on-demand fallback.  Small or sparse
@@ -577,6 +585,7 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         summary[6] = (unsigned long long)nvis;
         summary[7] = (unsigned long long)nredo;
     }
+    SWP(5)
 }
 
 // Heaviest tiles first.  The blend kernel's workgroups are dispatched in blockIdx order as slots free up; when a frame's tiles

@@ -127,14 +127,8 @@ __device__ __forceinline__ gsr_v2f gsr_exp2n2(gsr_v2f x)
 // Largest |q| at which alpha = exp(-|q|^2)*opacity can still reach 1/255 (capped at the quad's
 // half width 2).  Conservative: fast log (abs error < 1e-5 here) plus margins, so it only ever
 // removes pixels the fragment test would discard anyway.  Not part of the parity contract.
-__device__ __forceinline__ float gsr_support_radius(float opacity)
-{
-    const float L = __logf(255.0f * opacity);
-    return __builtin_fminf(2.0f, __builtin_sqrtf(__builtin_fmaxf(L, 0.0f) + 1.0e-4f) + 1.0e-3f);
-}
-
-// The same radius for the blend kernel's per-quadrant culling, on the native v_log_f32 / v_sqrt_f32 (1 ulp each; the IEEE
-// versions above are ~45 instructions): the 1e-3 margins dwarf the difference, and culling is conservative either way.
+// On the native v_log_f32 / v_sqrt_f32 (1 ulp each; the IEEE versions are ~45 instructions): the radius only feeds conservative
+// culling (K1's bbox, the blend kernel's quadrant test), and the 1e-3 margins dwarf the difference.
 __device__ __forceinline__ float gsr_support_radius_fast(float opacity)
 {
     const float L = __builtin_amdgcn_logf(255.0f * opacity) * 0.693147181f;

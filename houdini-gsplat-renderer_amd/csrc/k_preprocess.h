@@ -351,7 +351,8 @@ gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, co
     float ex = 1.0f, ey = 0.0f, s1 = 0.0f, s2 = 0.0f;
     const bool finite = gsr_covariance_axes(f, f.ob, x, y, z, sx, sy, sz, qi, qj, qk, qr, ex, ey, s1, s2);
     // conservative bbox of the part of the quad where alpha can reach 1/255 (|q| <= rq <= 2)
-    const float rq = (f.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius(opacity);
+    // (native log / sqrt: the bbox is not parity-relevant, only conservative -- the margins dwarf their 1-ulp error)
+    const float rq = (f.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius_fast(opacity);
     const float hx = gsr_fma(rq * gsr_fma(s1, __builtin_fabsf(ex), s2 * __builtin_fabsf(ey)), 1.0001f, 0.01f);
     const float hy = gsr_fma(rq * gsr_fma(s1, __builtin_fabsf(ey), s2 * __builtin_fabsf(ex)), 1.0001f, 0.01f);
 

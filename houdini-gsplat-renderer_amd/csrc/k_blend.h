@@ -34,6 +34,9 @@
 #ifndef BL_WAVES_PER_EU
 #define BL_WAVES_PER_EU 6     // 80 VGPRs (8 dwords of spill) instead of 94: 0.278 -> 0.270 ms
 #endif
+#ifndef BL_CHECK
+#define BL_CHECK 4            // pair iterations between two "is the wave opaque?" tests inside a list (a power of two)
+#endif
 #ifndef BL_BATCH
 #define BL_BATCH 256          // queued hits handed to the waves between two workgroup barriers (a multiple of 64): measured on
                               // C4 64 -> 0.195 ms, 128 -> 0.190, 256 -> 0.187.  Requesting the next sub-round's records ahead of
@@ -327,8 +330,14 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     if (sT == 123.0f) { C2 += sC2 + sC01.x; }
                 }
 #endif
-                for (int p = 0; p < npairs; ++p) blend_pair(p, C01, C2, T);
-                my_evals += (uint32_t)cnt;
+                // (the wave looks every BL_CHECK pairs whether its pixels are all opaque: on average it goes opaque half-way
+                //  through a list, and the rest of that list -- ~6 of the tile's ~60 pair iterations -- would be wasted)
+                int p = 0;
+                for (; p < npairs; ++p) {
+                    blend_pair(p, C01, C2, T);
+                    if ((p & (BL_CHECK - 1)) == BL_CHECK - 1 && __all(!pix_ok || T < GSR_T_MIN)) { ++p; break; }
+                }
+                my_evals += (uint32_t)(2 * p < cnt ? 2 * p : cnt);
                 BLP(4)
                 if (__all(!pix_ok || T < GSR_T_MIN)) { wave_done = true; break; }
                 __builtin_amdgcn_wave_barrier();   // (the next sub-round overwrites the list)

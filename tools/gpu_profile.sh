@@ -16,6 +16,6 @@ cd "$REPO"
 find /tmp/rp_$TAG -name '*kernel_stats*' -exec cp {} "$OUT/kernel_stats.csv" \;
 find /tmp/rp_$TAG -name '*domain_stats*' -exec cp {} "$OUT/domain_stats.csv" \;
 T=$(find /tmp/rp_$TAG -name '*kernel_trace.csv' | head -1)
-[ -n "$T" ] && python tools/frame_timeline.py "$T" > "$OUT/frame_timeline.txt" 2>&1
+[ -n "$T" ] && python tools/frame_timeline.py "$T" 30 > "$OUT/frame_timeline.txt" 2>&1   # (a frame of the timed leg: the last legs are informational)
 ls -la /tmp/rp_$TAG/* | head
 head -30 "$OUT/kernel_stats.csv"

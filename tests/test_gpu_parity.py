@@ -796,6 +796,7 @@ def test_occlusion_culling_is_exact(pkg, oracle, shard):
         vis_full = eng.stats()["n_visible"]
         for fif in (1, 2):
             eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, fif)
+            eng.set_option(pkg.engine.OPT_XCD_SWIZZLE, 3 if fif == 2 else 2)   # (with the heaviest-first tile order on top)
             eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)         # whenever a slot has horizons (1 = when it is found to pay)
             eng.upload(splats)                                    # forget the horizons
             eng.stats_reset()

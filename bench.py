@@ -428,9 +428,9 @@ def main():
     stages = {k: st_stage[k] for k in ("ms_preprocess", "ms_depth_sort", "ms_emit", "ms_tile_sort", "ms_blend", "ms_total")}
     stages["note"] = ("one frame of the extra leg with events around every stage: ms_emit = binning count+scans, ms_tile_sort = "
                       "binning placement + lazy colour pass")
-    # the memory-bound kernel next to it: k_preprocess (stage 0 of the frame is exactly this one kernel).  Algorithmic bytes
-    # per splat at SH order 3: visible 32 (geometry) + 96 (colour) read, 48 (record) + 12 (key, payload) written; culled or
-    # not owned 32 read + 12 written
+    # the kernel next to it: k_preprocess (stage 0 of the frame is exactly this one kernel).  Algorithmic bytes per splat at SH
+    # order 3: 32 (geometry) read by every splat; one that stays also reads 96 (colour; eager mode only) and writes 48 (record)
+    # + 12 (key, payload, compacted per workgroup); a dropped one writes nothing
     roofline_k1 = None
     if st_stage["stage_frames"] > 0 and world == 1:
         k1_ms = st_stage["stage_ms_total"][0] / st_stage["stage_frames"]
@@ -438,7 +438,7 @@ def main():
         lazy_on = st_stage["lazy_colours_total"] > 0
         # eager: the colour halves are read for every visible splat; lazy: K1 reads geometry only (colours: k_colour_prefix)
         col_b = 0 if lazy_on else {0: 16, 1: 32, 2: 64, 3: 96}[order if splats.shx is not None else 0]
-        k1_bytes = nvis * (32 + col_b + 48 + 12) + (splats.n - nvis) * (32 + 12)
+        k1_bytes = nvis * (32 + col_b + 48 + 12) + (splats.n - nvis) * 32 + (splats.n // 256 + 1) * 4
         k1_traffic = None
         try:
             k1_traffic = float(tj["k_preprocess"]["hbm_bytes_per_launch"]) if tj is not None else None
@@ -448,7 +448,9 @@ def main():
         roofline_k1 = {"bound": "hbm", "kernel": "k_preprocess", "achieved": k1_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                        "frac": k1_gbps / HBM_PEAK_GBPS, "traffic": k1_traffic, "avg_launch_ms": k1_ms,
                        "algorithmic_bytes_per_launch": k1_bytes,
-                       "note": "lazy colour: geometry only (32 B in, 48 + 12 B out per visible splat)" if lazy_on else "eager colour"}
+                       "splats_kept": int(nvis),
+                       "note": ("lazy colour: geometry only (32 B in per splat, 48 + 12 B out per splat that stays)" if lazy_on else "eager colour") +
+                               "; VALU-bound once occlusion culling leaves one splat in thirteen (DESIGN.md section 8)"}
 
     if rank == 0:
         line = {

@@ -246,6 +246,13 @@ def test_golden_reference_glsl_images(pkg, oracle, engine, name):
     vis = dev["visible"] == 1
     if vis.any():
         assert np.abs(vs[vis, 0, 8:11] - np.stack([dev["r"][vis], dev["g"][vis], dev["b"][vis]], 1)).max() <= 1e-6
+    # the same frame again with occlusion culling forced on (it engages from the slot's second frame): same pixels
+    engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)
+    try:
+        for _ in range(3):
+            assert np.array_equal(engine_render_golden(engine, d, c), img), "the culled frame differs from the first, unculled one"
+    finally:
+        engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 1)
 
 
 def test_baseline_config_c2_full_size(pkg, oracle, engine):

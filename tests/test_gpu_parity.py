@@ -840,6 +840,40 @@ def test_occlusion_culling_is_exact(pkg, oracle, shard):
         eng.close()
 
 
+@pytest.mark.parametrize("seed", [3, 4])
+def test_occlusion_culling_random_walk(pkg, seed):
+    """a random walk of the camera (orbit steps, jumps, distance changes), of the resolution and of the engine's options, with
+    occlusion culling forced on: every frame equals the same frame of an engine that never culls, bit for bit"""
+    rng = np.random.default_rng(seed)
+    splats = pkg.scenes.make_scene(300000, seed=200 + seed, sh=True, radius=1.0)
+    ref, eng = pkg.Engine(0), pkg.Engine(0)
+    try:
+        ref.set_option(pkg.engine.OPT_OCCLUSION_CULL, 0)
+        eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)
+        ref.upload(splats); eng.upload(splats)
+        frame, dist, size = 0, 2.2, (800, 450)
+        repaired = 0
+        for step in range(40):
+            u = rng.random()
+            if u < 0.70: frame += 1                                    # a steady orbit step
+            elif u < 0.80: frame += int(rng.integers(10, 60))           # a jump
+            elif u < 0.90: dist = float(rng.choice([1.6, 2.2, 3.0, 5.0]))
+            else: size = (800, 450) if size != (800, 450) else (512, 512)
+            if rng.random() < 0.15:
+                eng.set_option(pkg.engine.OPT_SUPER_TILE, int(rng.choice([0, 4, 8])))
+            if rng.random() < 0.15:
+                eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, int(rng.choice([1, 2])))
+            if rng.random() < 0.10:
+                eng.set_option(pkg.engine.OPT_XCD_SWIZZLE, int(rng.choice([1, 2, 3])))
+            order = int(rng.choice([0, 3, 3, 3]))
+            cam = pkg.camera.make_camera(size[0], size[1], sh_order=order, frame=frame, distance=dist)
+            assert np.array_equal(eng.render(cam), ref.render(cam)), f"step {step}: frame {frame}, distance {dist}, {size}, SH {order}"
+        st = eng.stats()
+        assert st["frames_culled"] >= 10, st          # (culling was really exercised, and some horizons really broke)
+    finally:
+        ref.close(); eng.close()
+
+
 def test_lazy_colour_is_exact_and_predicts(pkg, oracle):
     """k_colour.h: SH colours are evaluated ahead of time only for the front of every super-tile list (as deep as the
     previous frame scanned); tiles that meet a pending colour fall back to on-demand evaluation.  Pixels equal eager

@@ -152,12 +152,23 @@ def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine, n,
         assert (cover > 8).sum() > 50       # the cooperative big-splat path was exercised
 
 
+def _same_with_culling(pkg, engine, cam, img):
+    """the same camera again with occlusion culling forced on (it engages from the slot's second frame): same pixels"""
+    engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)
+    try:
+        for _ in range(3):
+            assert np.array_equal(engine.render(cam), img, equal_nan=True), "the culled frame differs from the unculled one"
+    finally:
+        engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 1)
+
+
 def test_edge_cases(pkg, oracle, engine):
     # empty cloud
     empty = pkg.scenes.make_scene(0, seed=1, sh=False)
     cam = pkg.camera.make_camera(64, 48, sh_order=0)
     engine.upload(empty)
     assert np.count_nonzero(engine.render(cam)) == 0
+    _same_with_culling(pkg, engine, cam, np.zeros((48, 64, 4), np.float32))
     # everything behind the camera
     s = pkg.scenes.make_scene(1000, seed=2, sh=False)
     s.P[:] += np.float32(20.0) * cam.cam_pos / np.linalg.norm(cam.cam_pos)
@@ -172,6 +183,7 @@ def test_edge_cases(pkg, oracle, engine):
     ref = oracle.render(s, cam)
     _check_image(img, ref)
     assert img[..., 3].max() <= 1.0 + 1e-6
+    _same_with_culling(pkg, engine, cam, img)
 
 
 @pytest.mark.parametrize("layout", [0, 1])
@@ -491,6 +503,7 @@ def test_adversarial_inputs(pkg, oracle, engine):
         assert np.array_equal(np.isfinite(img), ok)              # non-finite colours propagate identically
         err = np.abs(img[ok] - ref[ok])
         assert err.max() <= TOL, err.max()
+        _same_with_culling(pkg, engine, cam, img)
 
 
 def test_maximum_size_through_the_shim(pkg, oracle):

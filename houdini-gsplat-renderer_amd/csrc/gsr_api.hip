@@ -2,7 +2,8 @@
 // per-frame kernel pipeline and the C ABI declared in include/gsplat_hip.h.
 //
 // Pipeline per gsr_render (all on one HIP stream):
-//   K1 k_preprocess        N splats -> record, key, (idx, rect)            (HBM)
+//   k_cluster_cull         clusters of 64 Morton-ordered splats vs clip planes / screen / band / depth horizons (k_cluster.h)
+//   K1 k_preprocess        the splats of the surviving clusters -> record, key, (idx, rect)            (HBM)
 //   depth sort             3 x {hist, row scan, scatter}; the FIRST pass drops culled splats,
 //                          so everything downstream runs on the visible ones (count in HBM)
 //   binning (k_binning.h)  counting sort of the (splat, super-tile) pairs into per-super-tile, depth-ordered lists:
@@ -30,6 +31,7 @@
 #include "gsr_device.h"
 #include "k_binning.h"
 #include "k_blend.h"
+#include "k_cluster.h"
 #include "k_colour.h"
 #include "k_preprocess.h"
 #ifdef GSR_HOST_TIMING
@@ -38,10 +40,12 @@ static double now_us() { return std::chrono::duration<double, std::micro>(std::c
 #endif
 #include "k_sort.h"
 #include "k_wire.h"
+static_assert(RS_SRC_BLOCK == GSR_K1_THREADS, "the gathering sort pass reads K1's per-workgroup compaction: 256 slots each");
 
 #define GSR_VERSION_STR "gsplat_hip 0.1.0 (gfx950)"
 #define GSR_MAX_SLOTS 2
 #define GSR_STAGE_EVENTS 7
+#define GSR_SPIN_US 300          // how long a host wait for a mailbox word spins before it blocks in the runtime
 
 static thread_local char g_err[512] = "";
 
@@ -127,15 +131,19 @@ struct FrameSlot {
     size_t order_cap = 0;              //   for this slot's next frame (valid while the tile geometry stays what it was)
     bool order_valid = false;
     int order_sig[6] = {0, 0, 0, 0, 0, 0}, order_per_xcd = 0;
-    uint32_t* st_scan = nullptr;       // [512] per super-tile: deepest scan of its opaque tiles / "a tile stayed open" (k_blend -> k_sum_work)
     uint32_t* sup_work = nullptr;      // [2][256] per-super-tile work sums of the blend kernel, by frame parity
     int sup_par = 0;
-    // Depth horizons (occlusion culling): per super-tile, the distance^2 beyond which this slot's NEXT frame drops splats --
-    // written by k_sum_work at the end of every frame from how deep the frame's tiles had to look.  A culled frame checks
-    // itself (a tile that ran off its cut list without going opaque raises `violation`); k_sum_work reports that to the
-    // mapped word h_end, and the host renders a frame that failed again, without culling, before it hands it over.
-    float* horizon = nullptr;          // [256] device
-    uint32_t* violation = nullptr;     // device word
+    // Depth horizons (occlusion culling): per TILE, the distance^2 beyond which this slot's NEXT frame needs nothing -- a max
+    // pyramid written by k_sum_work at the end of every frame from how deep the frame's tiles had to look.  A culled frame is
+    // checked there too (did a tile look past the horizon its splats were culled against?); the verdict goes to the mapped word
+    // h_end, and the host renders a frame that failed again, without culling, before it hands it over.
+    float* hpyr2[2] = {nullptr, nullptr};   // pyramid levels 0..3 (k_cluster.h), GSR_PYR_FLOATS floats each: k_sum_work reads one, writes the other
+    int hpyr_cur = 0;                  // the pyramid the slot's next frame culls against
+    // cluster culling (k_cluster.h): the ordered list of surviving clusters of the frame, as per-workgroup segments
+    uint32_t* cseg = nullptr;          // [ngroups * per]
+    uint32_t* ccnt = nullptr;          // [CC_MAX_GROUPS]
+    uint32_t* d_counts = nullptr;      // [0] slots K1 filled, [1] surviving clusters
+    uint32_t surv_hint = 0;            // surviving clusters of this slot's last frame (sizes K1's grid; 0 = unknown)
     unsigned long long* h_end = nullptr;      // pinned + mapped: ticket << 32 | violation
     unsigned long long* h_end_dev = nullptr;
     bool horizon_valid = false;
@@ -149,7 +157,7 @@ struct FrameSlot {
     // small device/host mailboxes
     unsigned long long* counters = nullptr;  // k_sum_work's layout: [1]/[2] records gathered (frame/running), [3]/[4] list entries
                                              // scanned, [5] wave-record evaluations (running)
-    unsigned long long* h_total = nullptr;      // pinned + mapped + coherent: k_bin_ranges writes (frame ticket << 32 | pair count)
+    unsigned long long* h_total = nullptr;      // pinned + mapped + coherent [4]: k_bin_ranges writes (frame ticket << 32 | pair count), hints, survivors
     unsigned long long* h_total_dev = nullptr;  // its device-side address
     uint32_t ticket = 0;                        // ticket of the frame queued last in this slot
     unsigned long long* h_counters = nullptr;  // host copy of the frame's bookkeeping (fetched from d_frame when stats are asked for)
@@ -185,6 +193,11 @@ struct gsr_context {
     uint4* col = nullptr;              // colour halves as SoA chunks (eager colour in K1)
     uint4* colrow = nullptr;           // ... and as one contiguous row per splat (lazy colour gathers by index)
     int col_chunks = 0;
+    // spatially ordered storage (k_cluster.h): storage slot j holds the perm[j]-th splat of the upload; clusters of 64 slots
+    uint32_t* perm = nullptr;          // NULL = upload order
+    std::vector<int32_t> h_perm;       // host copy (debug read-backs un-permute through it), fetched on demand
+    float4 *clusA = nullptr, *clusB = nullptr;
+    uint32_t nclus = 0;
     uint32_t* prefix = nullptr;        // lazy colour: per super-tile, list entries to colour next frame (k_sum_work writes it)
     uint32_t* prefix_all = nullptr;    // 256 x 0xffffffff: colour every list completely (first frame, debug read-back)
     uint32_t* prefix_none = nullptr;   // 256 x 0: colour nothing ahead of time (GSR_FLAG_LAZY_NO_PREFIX: every tile takes the fallback)
@@ -204,6 +217,7 @@ struct gsr_context {
 
     int shard_index = 0, shard_count = 1, shard_layout = 0;   // layout: 0 = interleaved rows, 1 = contiguous bands
     int opt_swizzle = 2, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0, opt_lazy = 1, opt_cull = 1, opt_timing_every = 1;
+    int opt_cluster = 1, opt_morton = 1;
 
     gsr_stats st{};
     uint64_t frame_no = 0;
@@ -214,6 +228,7 @@ struct gsr_context {
     uint32_t vis_unculled = 0;         // splats kept by the last frame that was not culled
     bool cull_pays = false;            // ... and its third: most super-tile lists have a depth horizon (occlusion culling)
     int cull_holdoff = 0, cull_backoff = 8, cull_streak = 0;   // frames without culling after a broken horizon (x4 each time, <= 1024; back to 8 after 64 good frames)
+    int cull_dilate = 2;               // tiles by which rects are widened before they are compared with the horizons (grows when horizons break)
     bool order_pays = false;           // k_sum_work's other verdict: the tiles differ enough in work for k_tile_order to pay
     unsigned long long* wire_zbuf = nullptr;   // wireframe overlay: (depth bits, splat index) per pixel ...
     float* wire_out = nullptr;                 // ... and the image staged for a host target
@@ -296,18 +311,18 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMemset(sl.lazy_ctr, 0, 2 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.colour_evals), 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.colour_evals, 0, 256 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.horizon), 256 * sizeof(float)) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.violation), sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMemset(sl.violation, 0, sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr2[0]), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr2[1]), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.ccnt), CC_MAX_GROUPS * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_counts), 2 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(sl.d_counts, 0, 2 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_end), sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
     if (ok) sl.h_end[0] = 0ull;
     ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_end_dev), sl.h_end, 0) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.st_scan), 512 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMemset(sl.st_scan, 0, 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.sup_work), 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.sup_work, 0, 512 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
-    if (ok) { sl.h_total[0] = 0ull; sl.h_total[1] = 0ull; }
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), 4 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    if (ok) { sl.h_total[0] = 0ull; sl.h_total[1] = 0ull; sl.h_total[2] = 0ull; sl.h_total[3] = 0ull; }
     ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_total_dev), sl.h_total, 0) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), 8 * sizeof(unsigned long long), 0) == hipSuccess;
     if (ok) for (int j = 0; j < 8; ++j) sl.h_counters[j] = 0;
@@ -325,7 +340,7 @@ static bool slot_init(FrameSlot& sl)
 static void slot_free_splat_arrays(FrameSlot& sl)
 {
     dev_free(sl.rec); dev_free(sl.keyA); dev_free(sl.keyB); dev_free(sl.valA); dev_free(sl.valB); dev_free(sl.blk_cnt);
-    dev_free(sl.zwin);
+    dev_free(sl.zwin); dev_free(sl.cseg);
     sl.sort_valid = false;
 }
 
@@ -334,8 +349,8 @@ static void slot_destroy(FrameSlot& sl)
     slot_free_splat_arrays(sl);
     dev_free(sl.hist); dev_free(sl.totals);
     dev_free(sl.pvA);
-    dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.st_scan); dev_free(sl.fb);
-    dev_free(sl.horizon); dev_free(sl.violation);
+    dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.fb);
+    dev_free(sl.hpyr2[0]); dev_free(sl.hpyr2[1]); dev_free(sl.ccnt); dev_free(sl.d_counts);
     if (sl.h_end) (void)hipHostFree(sl.h_end); dev_free(sl.depth_stage);
     dev_free(sl.redo); dev_free(sl.lazy_ctr); dev_free(sl.colour_evals);
     dev_free(sl.counters); dev_free(sl.d_n);
@@ -389,6 +404,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
 static void free_geometry(gsr_context* c)
 {
     dev_free(c->geoA); dev_free(c->geoB); dev_free(c->col); dev_free(c->colrow);
+    dev_free(c->perm); dev_free(c->clusA); dev_free(c->clusB); c->nclus = 0; c->h_perm.clear();
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) slot_free_splat_arrays(c->slot[k]);
     c->cap = 0; c->n = 0;
 }
@@ -435,6 +451,8 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
     case GSR_OPT_OCCLUSION_CULL: c->opt_cull = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_LAZY_COLOUR: c->opt_lazy = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_SHARD_LAYOUT: c->shard_layout = value ? 1 : 0; break;
+    case GSR_OPT_CLUSTER_CULL: c->opt_cluster = value ? 1 : 0; break;
+    case GSR_OPT_STORAGE_ORDER: c->opt_morton = value ? 1 : 0; break;   // (takes effect at the next upload)
     case GSR_OPT_SUPER_TILE:
         if (value != 0 && (value < 1 || value > 16 || (value & (value - 1))))
             return set_err(GSR_E_INVALID, "gsr_set_option: super-tile edge must be 0 (auto) or 1,2,4,8,16");
@@ -478,7 +496,8 @@ extern "C" int gsr_upload_begin(gsr_context* c, int64_t total, int has_sh, const
             // (+256: K1 writes what it keeps at the head of its workgroup's 256 slots)
             if ((rc = dev_alloc(&sl.rec, cap)) || (rc = dev_alloc(&sl.keyA, cap + 256)) || (rc = dev_alloc(&sl.keyB, cap + 256)) ||
                 (rc = dev_alloc(&sl.valA, cap + 256)) || (rc = dev_alloc(&sl.valB, cap + 256)) ||
-                (rc = dev_alloc(&sl.zwin, cap)) || (rc = dev_alloc(&sl.blk_cnt, cap / 256 + 16))) {
+                (rc = dev_alloc(&sl.zwin, cap)) || (rc = dev_alloc(&sl.blk_cnt, cap / 256 + 16)) ||
+                (rc = dev_alloc(&sl.cseg, cap / GSR_CLUSTER + (size_t)CC_THREADS * 64 + 16))) {
                 free_geometry(c);
                 return rc;
             }
@@ -493,6 +512,8 @@ extern "C" int gsr_upload_begin(gsr_context* c, int64_t total, int has_sh, const
     c->uploading = true;
     for (int k = 0; k < 3; ++k) c->origin[k] = origin ? origin[k] : 0.0f;
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
+    dev_free(c->perm); dev_free(c->clusA); dev_free(c->clusB);   // (the arrays are filled in upload order again)
+    c->nclus = 0; c->h_perm.clear();
     return GSR_OK;
 }
 
@@ -552,6 +573,8 @@ extern "C" int gsr_upload_append(gsr_context* c, int64_t n64, const float* P, co
     return GSR_OK;
 }
 
+static int order_and_cluster(gsr_context* c);
+
 extern "C" int gsr_upload_end(gsr_context* c)
 {
     if (!c || !c->uploading) return set_err(GSR_E_INVALID, "gsr_upload_end: no upload in progress");
@@ -586,12 +609,15 @@ extern "C" int gsr_upload_end(gsr_context* c)
                 c->bb_hi[k] = std::max(c->bb_hi[k], (double)hi);
             }
         c->bbox_ok = ok;
+        rc = order_and_cluster(c);
+        if (rc) return rc;
     }
     c->geo_gen++;
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
     c->prefix_valid = false;           // lazy colour: the first frame of a new cloud colours every list completely
     c->order_pays = false;
-    c->cull_pays = false; c->cull_holdoff = 0; c->cull_backoff = 8; c->cull_streak = 0; c->vis_unculled = 0;
+    c->cull_pays = false; c->cull_holdoff = 0; c->cull_backoff = 8; c->cull_streak = 0; c->vis_unculled = 0; c->cull_dilate = 2;
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k) { c->slot[k].surv_hint = 0; c->slot[k].horizon_valid = false; }
     c->lazy_pays = false;              // ... and in automatic mode the first frames are eager until the kernels say it pays
     c->st.n_splats = c->n;
     return GSR_OK;
@@ -684,12 +710,13 @@ static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, u
 
 // stable LSD sort on key bits [0, bits); ping-pongs (kA,vA) <-> (kB,vB) and leaves the result
 // in (kA,vA) by swapping the pointers.  9-bit digits are used when they save a pass.
-// compact_to != NULL: the input is K1's block-compacted layout (src_cnt items at the head of every 256 slots, n slots);
+// compact_to != NULL: the input is K1's block-compacted layout (src_cnt items at the head of every 256 slots, *src_n_dev <= n slots);
 // the first pass gathers them and writes their number to *compact_to (device); the remaining passes and the caller's
 // later kernels read it there.
 template <typename V>
 static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& vB, uint32_t n, int bits,
-                      bool allow9 = true, uint32_t* compact_to = nullptr, bool contig = false, const uint32_t* src_cnt = nullptr)
+                      bool allow9 = true, uint32_t* compact_to = nullptr, bool contig = false, const uint32_t* src_cnt = nullptr,
+                      const uint32_t* src_n_dev = nullptr /* compacting pass: the number of source SLOTS, on the device (<= n) */)
 {
     if (n == 0) {
         if (compact_to) HIP_TRY(hipMemsetAsync(compact_to, 0, 4, sl.stream));
@@ -704,7 +731,7 @@ static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& v
     const int passes = use9 ? p9 : p8, width = use9 ? 9 : 8;
     for (int p = 0; p < passes; ++p) {
         const bool skip = compact_to && p == 0;
-        const uint32_t* n_dev = (compact_to && p > 0) ? compact_to : nullptr;
+        const uint32_t* n_dev = compact_to ? (p > 0 ? compact_to : src_n_dev) : nullptr;
         if (use9)
             rc = skip ? radix_pass<V, 9, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig, compact_to, src_cnt)
                       : radix_pass<V, 9, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig);
@@ -715,6 +742,66 @@ static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& v
         uint32_t* t = kA; kA = kB; kB = t;
         V* tv = vA; vA = vB; vB = tv;
     }
+    return GSR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// End of an upload: the splats go into MORTON ORDER of their positions (k_cluster.h) -- a stable sort of 30-bit codes, so
+// equal codes keep their upload order and the storage order is a pure function of the positions -- and every 64 consecutive
+// slots get their cluster bounds.  c->perm[j] = upload index of the splat in slot j (NULL: upload order kept).
+static void cluster_grid(uint32_t nclus, int* rounds, uint32_t* ngroups)
+{
+    int r = 1;
+    while ((uint64_t)CC_THREADS * (uint64_t)r * (uint64_t)CC_MAX_GROUPS < (uint64_t)nclus) ++r;
+    *rounds = r;
+    *ngroups = nclus ? div_up(nclus, (uint32_t)CC_THREADS * (uint32_t)r) : 0u;
+}
+
+static int order_and_cluster(gsr_context* c)
+{
+    const uint32_t n = c->n;
+    FrameSlot& sl = c->slot[0];
+    hipStream_t us = sl.stream;
+    int rc = GSR_OK;
+    if (c->opt_morton && c->bbox_ok && n > 1) {
+        uint32_t *kA = nullptr, *kB = nullptr, *vA = nullptr, *vB = nullptr;
+        float4* nA = nullptr; uint4 *nB = nullptr, *ncol = nullptr, *nrow = nullptr;
+        auto drop = [&]() { dev_free(kA); dev_free(kB); dev_free(vB); dev_free(nA); dev_free(nB); dev_free(ncol); dev_free(nrow); };
+        if ((rc = dev_alloc(&kA, n)) || (rc = dev_alloc(&kB, n)) || (rc = dev_alloc(&vA, n)) || (rc = dev_alloc(&vB, n)) ||
+            (rc = dev_alloc(&nA, c->cap)) || (rc = dev_alloc(&nB, c->cap)) || (rc = dev_alloc(&ncol, (size_t)c->cap * c->col_chunks)) ||
+            (c->has_sh && (rc = dev_alloc(&nrow, (size_t)c->cap * 8)))) {
+            drop(); dev_free(vA);
+            return rc;
+        }
+        float lo[3], sc[3];
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = (float)c->bb_lo[k];
+            const double ext = c->bb_hi[k] - c->bb_lo[k];
+            sc[k] = ext > 0.0 ? (float)(1023.999 / ext) : 0.0f;
+            if (!std::isfinite(sc[k])) sc[k] = 0.0f;
+        }
+        hipLaunchKernelGGL(k_morton_codes, dim3(div_up(n, 256)), dim3(256), 0, us, c->geoA, n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], kA, vA);
+        rc = radix_sort(sl, kA, vA, kB, vB, n, 30, true, (uint32_t*)nullptr, RS_XCD_DEPTH != 0);
+        if (!rc) {
+            hipLaunchKernelGGL(k_permute_geo, dim3(div_up(n, 256)), dim3(256), 0, us, n, c->cap, c->col_chunks, vA, c->geoA, c->geoB, c->col, nA, nB, ncol);
+            if (c->has_sh)
+                hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, us, n, vA, c->colrow, nrow);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(us);
+            if (e != hipSuccess) rc = set_err(GSR_E_HIP, "gsr_upload_end: ordering the splats: %s", hipGetErrorString(e));
+        }
+        if (rc) { drop(); dev_free(vA); return rc; }
+        std::swap(c->geoA, nA); std::swap(c->geoB, nB); std::swap(c->col, ncol);
+        if (c->has_sh) std::swap(c->colrow, nrow);
+        c->perm = vA;
+        drop();   // (now the upload-ordered arrays and the sort scratch)
+    }
+    c->nclus = div_up(n, GSR_CLUSTER);
+    if ((rc = dev_alloc(&c->clusA, c->nclus)) || (rc = dev_alloc(&c->clusB, c->nclus))) return rc;
+    hipLaunchKernelGGL(k_cluster_bounds, dim3(div_up(n, 256)), dim3(256), 0, us, n, c->geoA, c->geoB, c->clusA, c->clusB);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(us);
+    if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_upload_end: cluster bounds: %s", hipGetErrorString(e));
     return GSR_OK;
 }
 
@@ -821,6 +908,12 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
     f->super = 1 << shift;
     f->stiles_x = ((f->tiles_x - 1) >> shift) + 1;
     f->stiles_y = ((f->tiles_y - 1) >> shift) + 1;
+    int off = 0;
+    for (int l = 0; l < GSR_PYR_LEVELS; ++l) {
+        f->pyr_off[l] = off;
+        off += gsr_pyr_dim(f->tiles_x, l) * gsr_pyr_dim(f->tiles_y, l);
+    }
+    f->cull_dilate = c->cull_dilate;
 }
 
 // blockIdx -> tile table for the blend kernel.  Workgroup b lands on XCD b % 8; XCD x is
@@ -929,7 +1022,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         const size_t lds = (size_t)4 * BN_ITEMS * j.n_super * 8 + (size_t)4 * j.n_super * 4;
         hipLaunchKernelGGL(k_bin_place, dim3(nblk), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n, f.super_shift,
                            GsrShard{f.shard_index, f.shard_count, f.shard_rpb}, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk,
-                           (uint32_t)sl.pair_cap, sl.pvA, sl.keyA, j.cull ? sl.horizon : (const float*)nullptr, f.key_min, f.key_max);
+                           (uint32_t)sl.pair_cap, sl.pvA);
         HIP_TRY(hipGetLastError());
     }
     if ((rc = mark(sl, 4))) return rc;
@@ -954,9 +1047,6 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
         a.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
         a.sup_work = (a.use_map && c->opt_swizzle >= 2 && sl.sup_work) ? sl.sup_work + 256 * sl.sup_par : nullptr;
-        a.st_scan = sl.st_scan;
-        a.horizon = j.cull ? sl.horizon : nullptr;
-        a.violation = sl.violation;
         // heaviest-first table of this slot's previous frame, if that frame had the same tiles
         const int sig[6] = {f.width, f.height, f.shard_index, f.shard_count, f.shard_rpb, f.super_shift};
         const bool ordered = a.use_map && c->opt_swizzle >= 2 && sl.order_valid && std::memcmp(sig, sl.order_sig, sizeof sig) == 0;
@@ -992,25 +1082,28 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     const FrameJob& j = sl.job;
     hipStream_t s = sl.stream;
     GsrSumArgs g;
-    g.n_tiles = j.local_tiles; g.tiles_x = j.f.tiles_x; g.shard = GsrShard{j.f.shard_index, j.f.shard_count, j.f.shard_rpb};
+    g.n_tiles = j.local_tiles; g.tiles_x = j.f.tiles_x; g.tiles_y = j.f.tiles_y; g.shard = GsrShard{j.f.shard_index, j.f.shard_count, j.f.shard_rpb};
     g.super_shift = j.f.super_shift; g.stiles_x = j.f.stiles_x; g.n_super = j.n_super;
     GsrHorizonArgs hz{};
+    hz.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
     // (below a few hundred thousand splats in the sort the frame is bound by launch floors: nothing for culling to win)
-    // ... and while culling is held off nobody needs horizons: they are prepared again two frames before it may resume
-    if (c->opt_cull && j.n > 0 && j.n_super <= 256 && (c->opt_cull >= 2 || j.cull || (c->vis_unculled >= 300000u && c->cull_holdoff <= 2))) {
-        hz.horizon = sl.horizon; hz.culled = j.cull ? 1 : 0; hz.fallback_skipped = (j.cull && j.lazy) ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
+    // ... and while culling is held off nobody needs horizons: they are prepared again two frames before it may resume.
+    // A deferred frame (handed over before its pair count was known) never culls and may have clamped lists: no horizons from it.
+    if (c->opt_cull && j.n > 0 && !j.deferred && (c->opt_cull >= 2 || j.cull || (c->vis_unculled >= 300000u && c->cull_holdoff <= 2))) {
+        hz.pyr = sl.hpyr2[sl.hpyr_cur ^ 1]; hz.pyr_in = sl.hpyr2[sl.hpyr_cur]; hz.dilate = j.f.cull_dilate; hz.culled = j.cull ? 1 : 0; hz.fallback_skipped = (j.cull && j.lazy) ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
+        for (int l = 0; l < GSR_PYR_LEVELS; ++l) hz.pyr_off[l] = j.f.pyr_off[l];
         hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
-        hz.violation = sl.violation;
         hz.host_end = j.cull ? sl.h_end_dev : nullptr; hz.ticket = j.ticket;
     }
     hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, g, sl.counters, sl.d_n, sl.d_frame,
                        (j.f.sh_order > 0 && c->opt_lazy) ? c->prefix : (uint32_t*)nullptr,
                        j.lazy ? reinterpret_cast<const uint32_t*>(sl.lazy_ctr) : (const uint32_t*)nullptr,
                        sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint,
-                       sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr, hz, sl.st_scan);
+                       sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr, hz);
     HIP_TRY(hipGetLastError());
-    sl.horizon_valid = hz.horizon != nullptr;
+    sl.horizon_valid = hz.pyr != nullptr;
     if (sl.horizon_valid) {
+        sl.hpyr_cur ^= 1;
         const int sig[7] = {j.f.width, j.f.height, j.f.shard_index, j.f.shard_count, j.f.shard_rpb, j.f.super_shift, (int)c->geo_gen};
         std::memcpy(sl.horizon_sig, sig, sizeof sig);
     }
@@ -1060,6 +1153,31 @@ static int frame_abort(FrameSlot& sl, int rc)
     return rc;
 }
 
+// A mailbox word in mapped host memory carries (frame ticket << 32 | value); the GPU writes it mid-stream while it carries on
+// -- no event in the stream (an event costs the GPU ~6 us of idle queue), no API call.  The host watches the word: a bounded
+// spin (the word normally arrives within tens of microseconds), then it stops burning the caller's core and blocks in
+// hipStreamSynchronize -- by then the frame is a long one and the extra latency no longer matters.
+static int wait_mailbox(FrameSlot& sl, volatile unsigned long long* box, uint32_t ticket, const char* what, unsigned long long* out)
+{
+    unsigned long long v = *box;
+    if ((uint32_t)(v >> 32) != ticket) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned long spins = 1; (uint32_t)(v >> 32) != ticket; ++spins) {
+            if ((spins & 0xffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(GSR_SPIN_US)) {
+                const hipError_t q = hipStreamSynchronize(sl.stream);   // everything queued has run: the word must be there now
+                if (q != hipSuccess) return set_err(GSR_E_HIP, "gsr_render: waiting for the %s: %s", what, hipGetErrorString(q));
+                v = *box;
+                if ((uint32_t)(v >> 32) != ticket) return set_err(GSR_E_HIP, "gsr_render: the frame finished without delivering its %s", what);
+                break;
+            }
+            __builtin_ia32_pause();
+            v = *box;
+        }
+    }
+    *out = v;
+    return GSR_OK;
+}
+
 static int frame_finish(gsr_context* c, FrameSlot& sl)
 {
     if (!sl.job.open) return GSR_OK;
@@ -1070,22 +1188,9 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
         // The pair count arrives in mapped host memory, stamped with the frame's ticket, while the GPU carries on: the
         // host just watches the word -- no event in the stream (an event costs the GPU ~6 us of idle queue), no API call.
         volatile unsigned long long* box = sl.h_total;
-        unsigned long long v = *box;
-        for (unsigned long spins = 1; (uint32_t)(v >> 32) != j.ticket; ++spins) {
-            if ((spins & 0x3fffu) == 0) {   // every ~16 k reads: is the stream still alive?
-                const hipError_t q = hipStreamQuery(sl.stream);
-                if (q == hipSuccess) {      // everything queued has run: the word must be there now
-                    v = *box;
-                    if ((uint32_t)(v >> 32) != j.ticket)
-                        return frame_abort(sl, set_err(GSR_E_HIP, "gsr_render: the frame finished without delivering its pair count"));
-                    break;
-                }
-                if (q != hipErrorNotReady)
-                    return frame_abort(sl, set_err(GSR_E_HIP, "gsr_render: waiting for the pair count: %s", hipGetErrorString(q)));
-            }
-            __builtin_ia32_pause();
-            v = *box;
-        }
+        unsigned long long v = 0;
+        const int wrc = wait_mailbox(sl, box, j.ticket, "pair count", &v);
+        if (wrc) return frame_abort(sl, wrc);
         D = (uint32_t)v;
         c->lazy_pays = (box[1] & 1ull) != 0ull;
         c->cull_pays = (box[1] & 4ull) != 0ull;
@@ -1096,6 +1201,7 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
                 c->cull_holdoff = 256;
         }
         c->order_pays = (box[1] & 2ull) != 0ull;   // (written before the ticket) k_sum_work's verdict on the frame before
+        sl.surv_hint = (uint32_t)box[2];           // clusters that survived k_cluster_cull: sizes the next frame's K1 grid
         if (D == 0xffffffffu || (unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
             return frame_abort(sl, set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: the frame's super-tile pairs exceed the limit of %lld", GSR_MAX_PAIRS));
         const bool short_buffer = D > sl.pair_cap;
@@ -1113,7 +1219,11 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
             // the frame was handed over before its pair count was known; if the lists were clamped it misses their tails
             if (short_buffer) c->st.frames_truncated += 1;
         } else if (short_buffer || !j.speculative) {
-            if (short_buffer && j.speculative) c->st.frames_requeued += 1;
+            if (short_buffer && j.speculative) {
+                c->st.frames_requeued += 1;
+                // the first, clamped back end has already added its tiles' work to the sums k_tile_order reads
+                if (sl.sup_work) (void)hipMemsetAsync(sl.sup_work + 256 * sl.sup_par, 0, 256 * sizeof(uint32_t), sl.stream);
+            }
             int rc = queue_back_end(c, sl);
             if (rc) return frame_abort(sl, rc);
         }
@@ -1134,20 +1244,9 @@ static int frame_verdict(gsr_context* c, FrameSlot& sl, bool* broke)
     (void)c;
     const FrameJob& j = sl.job;
     volatile unsigned long long* box = sl.h_end;
-    unsigned long long v = *box;
-    for (unsigned long spins = 1; (uint32_t)(v >> 32) != j.ticket; ++spins) {
-        if ((spins & 0x3fffu) == 0) {
-            const hipError_t q = hipStreamQuery(sl.stream);
-            if (q == hipSuccess) {
-                v = *box;
-                if ((uint32_t)(v >> 32) != j.ticket) return set_err(GSR_E_HIP, "gsr_render: the frame finished without its culling verdict");
-                break;
-            }
-            if (q != hipErrorNotReady) return set_err(GSR_E_HIP, "gsr_render: waiting for the culling verdict: %s", hipGetErrorString(q));
-        }
-        __builtin_ia32_pause();
-        v = *box;
-    }
+    unsigned long long v = 0;
+    const int wrc = wait_mailbox(sl, box, j.ticket, "culling verdict", &v);
+    if (wrc) return wrc;
     *broke = (v & 1ull) != 0ull;
     return GSR_OK;
 }
@@ -1283,11 +1382,22 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
 #ifdef GSR_HOST_TIMING
         const double t_pre = now_us();
 #endif
+        // cluster culling (k_cluster.h): which clusters of 64 storage-ordered splats can draw anything in this frame
+        int rounds; uint32_t ngroups;
+        cluster_grid(c->nclus, &rounds, &ngroups);
+        hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, c->opt_cluster,
+                           j.cull ? sl.hpyr2[sl.hpyr_cur] : (const float*)nullptr, sl.cseg, sl.ccnt);
+        // K1 over the survivors, four clusters per workgroup-iteration; the grid follows the slot's previous frame (+25 %), and
+        // a frame that keeps more simply loops
+        const uint32_t all_iter = div_up(c->nclus, 4u);
+        uint32_t k1_grid = all_iter;
+        if (sl.surv_hint > 0) k1_grid = std::min<uint32_t>(all_iter, div_up(sl.surv_hint, 4u) * 5u / 4u + 64u);
         // on a cache hit (identical frame description) the sorted (keyA, valA) are kept and K1's key/payload
         // output goes to the scratch buffers
-        hipLaunchKernelGGL(k_preprocess, dim3(div_up(n, GSR_K1_THREADS)), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
+        hipLaunchKernelGGL(k_preprocess, dim3(k1_grid ? k1_grid : 1u), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, cache_hit ? sl.keyB : sl.keyA, cache_hit ? sl.valB : sl.valA,
-                           j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.cull ? sl.horizon : (const float*)nullptr, sl.blk_cnt);
+                           j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.cull ? sl.hpyr2[sl.hpyr_cur] : (const float*)nullptr, sl.blk_cnt,
+                           sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts);
         hipError_t e = hipGetLastError();
 #ifdef GSR_HOST_TIMING
         if (g_t_verdict > 0) {
@@ -1307,8 +1417,9 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     } else {
         int key_bits = 1;
         while (key_bits < 32 && ((f.key_max - f.key_min) >> key_bits) != 0u) ++key_bits;
-        rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n, key_bits, !(c->opt_flags & GSR_FLAG_FULL_KEYS),
-                        sl.d_n, RS_XCD_DEPTH != 0, sl.blk_cnt);
+        // (the sort's grids are sized for the slots K1 could fill at most; the number it did fill is in d_counts[0])
+        rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n ? div_up(c->nclus, 4u) * (uint32_t)GSR_K1_THREADS : 0u, key_bits,
+                        !(c->opt_flags & GSR_FLAG_FULL_KEYS), sl.d_n, RS_XCD_DEPTH != 0, sl.blk_cnt, sl.d_counts);
         if (rc) return frame_abort(sl, rc);
         sl.key_min = f.key_min;
         sl.sort_valid = true;
@@ -1323,11 +1434,10 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)BN_BINS * nblk + 8);
         if (rc) return frame_abort(sl, rc);
         hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift,
-                           GsrShard{f.shard_index, f.shard_count, f.shard_rpb}, f.stiles_x, sl.hist, nblk,
-                           sl.keyA, j.cull ? sl.horizon : (const float*)nullptr, f.key_min, f.key_max);
+                           GsrShard{f.shard_index, f.shard_count, f.shard_rpb}, f.stiles_x, sl.hist, nblk);
         hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals, sl.d_n, n, (uint32_t)BN_TILE);
         hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, sl.totals, j.n_super, sl.sstart, sl.send, sl.h_total_dev,
-                           j.ticket, (unsigned long long)GSR_MAX_PAIRS, reinterpret_cast<uint32_t*>(sl.lazy_ctr), c->lazy_hint, sl.d_n);
+                           j.ticket, (unsigned long long)GSR_MAX_PAIRS, reinterpret_cast<uint32_t*>(sl.lazy_ctr), c->lazy_hint, sl.d_n, sl.d_counts);
         e = hipGetLastError();
     } else {
         e = hipMemsetAsync(sl.sstart, 0, ((size_t)j.n_super + 1) * 4, s);
@@ -1362,7 +1472,7 @@ static int frame_check(gsr_context* c, FrameSlot& slot, const gsr_camera* cam, c
     int rc = frame_verdict(c, slot, &broke);
     if (rc) return rc;
     if (!broke) {
-        if (++c->cull_streak >= 64) { c->cull_streak = 0; c->cull_backoff = 8; }
+        if (++c->cull_streak >= 64) { c->cull_streak = 0; c->cull_backoff = 8; if (c->cull_dilate > 2) c->cull_dilate -= 1; }
 #ifdef GSR_HOST_TIMING
         g_t_verdict = now_us();
 #endif
@@ -1371,6 +1481,7 @@ static int frame_check(gsr_context* c, FrameSlot& slot, const gsr_camera* cam, c
     c->st.frames_repaired += 1;
     c->cull_holdoff = std::max(c->cull_holdoff, c->cull_backoff);   // the view is changing faster than the horizons follow: leave it alone for a while
     c->cull_backoff = c->cull_backoff >= 256 ? 1024 : 4 * c->cull_backoff;   // 8, 32, 128, 512, 1024 frames
+    c->cull_dilate = std::min(2 * c->cull_dilate, 16);   // ... and compare rects with the horizons of a wider neighbourhood afterwards
     c->cull_streak = 0;
     c->frame_no -= 1;          // the same frame again, in the same slot
     c->st.frames -= 1;
@@ -1558,6 +1669,27 @@ static uint32_t sorted_count(FrameSlot* sl)
     return (uint32_t)(sl->h_counters[6] & 0xffffffffull);
 }
 
+// storage slot -> upload index, on the host (debug read-backs speak upload indices); empty = identity
+static int host_perm(gsr_context* c)
+{
+    if (!c->perm || c->h_perm.size() == c->n) return GSR_OK;
+    c->h_perm.resize(c->n);
+    if (c->n) HIP_TRY(hipMemcpy(c->h_perm.data(), c->perm, (size_t)c->n * 4, hipMemcpyDeviceToHost));
+    return GSR_OK;
+}
+static inline uint32_t to_upload_index(const gsr_context* c, uint32_t slot) { return c->perm && slot < c->h_perm.size() ? (uint32_t)c->h_perm[slot] : slot; }
+
+extern "C" int gsr_debug_read_storage_order(gsr_context* c, int32_t* perm, int64_t n)
+{
+    if (!c || !perm || n < 0 || (uint64_t)n != c->n) return set_err(GSR_E_INVALID, "gsr_debug_read_storage_order: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    if ((rc = host_perm(c))) return rc;
+    for (int64_t j = 0; j < n; ++j) perm[j] = (int32_t)to_upload_index(c, (uint32_t)j);
+    return GSR_OK;
+}
+
 extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int64_t n)
 {
     if (!c || !out || n < 0 || (uint64_t)n > c->n) return set_err(GSR_E_INVALID, "gsr_debug_read_records: bad argument");
@@ -1574,7 +1706,10 @@ extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(sl->stream));
     }
+    if ((src = host_perm(c))) return src;
     const uint32_t ns = sorted_count(sl);
+    const int64_t n_out = n;
+    n = (int64_t)c->n;   // (records live at storage slots: read them all, hand back the caller's first n_out upload indices)
     GsrRecord* hr = new (std::nothrow) GsrRecord[n ? n : 1];
     uint32_t* hk = new (std::nothrow) uint32_t[ns ? ns : 1];
     uint2* hv = new (std::nothrow) uint2[ns ? ns : 1];
@@ -1589,12 +1724,14 @@ extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int
         if (e != hipSuccess) rc = set_err(GSR_E_HIP, "gsr_debug_read_records: %s", hipGetErrorString(e));
     }
     if (!rc) {
-        for (int64_t i = 0; i < n; ++i) std::memset(&out[i], 0, sizeof(out[i]));
+        for (int64_t i = 0; i < n_out; ++i) std::memset(&out[i], 0, sizeof(out[i]));
         for (uint32_t r = 0; r < ns; ++r) {
-            const uint32_t i = hv[r].x;
-            if ((int64_t)i >= n) continue;
+            const uint32_t slot = hv[r].x;
+            if ((int64_t)slot >= n) continue;
+            const uint32_t i = to_upload_index(c, slot);
+            if ((int64_t)i >= n_out) continue;
             gsr_debug_record& o = out[i];
-            const GsrRecord& q = hr[i];
+            const GsrRecord& q = hr[slot];
             o.visible = 1;
             o.cx = q.cx; o.cy = q.cy; o.a1x = q.a1x; o.a1y = q.a1y; o.b1x = q.b1x; o.b1y = q.b1y;
             o.hx = q.hx; o.hy = q.hy; o.r = q.r; o.g = q.g; o.b = q.b; o.opacity = q.opacity;
@@ -1618,6 +1755,8 @@ extern "C" int gsr_debug_read_depth_order(gsr_context* c, int32_t* perm, int64_t
     *n_sorted = ns;
     const int64_t m = (int64_t)ns < cap ? (int64_t)ns : cap;
     if (m) HIP_TRY(hipMemcpy2D(perm, 4, sl->valA, 8, 4, (size_t)m, hipMemcpyDeviceToHost));
+    if ((rc = host_perm(c))) return rc;
+    for (int64_t r = 0; r < m; ++r) perm[r] = (int32_t)to_upload_index(c, (uint32_t)perm[r]);
     return GSR_OK;
 }
 
@@ -1637,6 +1776,8 @@ extern "C" int gsr_debug_read_tile_lists(gsr_context* c, int32_t* list_start, in
         HIP_TRY(hipMemcpy(list_end, sl->send, (size_t)n_lists * 4, hipMemcpyDeviceToHost));
     }
     if (n_pairs) HIP_TRY(hipMemcpy2D(pair_splat, 4, sl->pvA, 8, 4, (size_t)n_pairs, hipMemcpyDeviceToHost));
+    if ((rc = host_perm(c))) return rc;
+    for (int64_t r = 0; r < n_pairs; ++r) pair_splat[r] = (int32_t)to_upload_index(c, (uint32_t)pair_splat[r]);
     return GSR_OK;
 }
 

@@ -370,6 +370,14 @@ extern "C" int gsr_multi_render_depth(gsr_multi* m, const gsr_camera* cam, const
             if (m->dev[g] == m->dev[0]) HIP_OK(hipMemcpyAsync(dst, m->band[g].p, bf * 4, hipMemcpyDeviceToDevice, s0));
             else HIP_OK(hipMemcpyPeerAsync(dst, m->dev[0], m->band[g].p, m->dev[g], bf * 4, s0));
         }
+        // the peers' band buffers are read by the root's stream: a peer's NEXT frame must not overwrite its band before that
+        // copy has run (the host returns after the pair counts, not after the copies, and a light rank finishes early)
+        HIP_OK(hipEventRecord(m->ev[0], s0));
+        for (int g = 1; g < G; ++g) {
+            HIP_OK(hipSetDevice(m->dev[g]));
+            HIP_OK(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(gsr_internal_stream(m->ctx[g])), m->ev[0], 0));
+        }
+        HIP_OK(hipSetDevice(m->dev[0]));
     }
     // 4. de-interleave on the root, on its public stream
     if ((rc = gsr_stitch_bands(m->ctx[0], m->gathered.p, G, cam->width, cam->height, target))) return rc;

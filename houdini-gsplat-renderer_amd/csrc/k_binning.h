@@ -46,11 +46,10 @@ __device__ __forceinline__ uint32_t bn_tile_mask(uint32_t rc, int sx, int sy, in
 }
 
 // visit the owned super-tiles of a packed tile rect
-// sH != NULL: the depth horizons of the frame in its key domain (occlusion culling, k_preprocess.h): the pair (splat, d)
-// exists only while the splat's key kb does not lie beyond super-tile d's horizon -- every list ends at its horizon.
+// (occlusion culling needs nothing here: K1 keeps a splat iff one of the tiles of its rect may still need it, and then it
+//  enters every list its rect reaches -- a tile that does not need it has gone opaque before it gets there)
 template <typename F>
-__device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, const GsrShard& sh, int stiles_x, uint32_t kb,
-                                                  const uint32_t* sH, F&& fn)
+__device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, const GsrShard& sh, int stiles_x, F&& fn)
 {
     const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = (rc >> 16) & 255, y1 = rc >> 24;
     if (x1 < x0 || y1 < y0) return;
@@ -61,10 +60,7 @@ __device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, const 
             if (gsr_owned_rows(lo, hi, sh) == 0) continue;
         }
         const uint32_t rowkey = (uint32_t)sy * (uint32_t)stiles_x;
-        for (int sx = sx0; sx <= sx1; ++sx) {
-            if (sH && kb > sH[rowkey + (uint32_t)sx]) continue;
-            fn(rowkey + (uint32_t)sx, sx, sy);
-        }
+        for (int sx = sx0; sx <= sx1; ++sx) fn(rowkey + (uint32_t)sx, sx, sy);
     }
 }
 
@@ -74,7 +70,7 @@ __device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, const 
 // same few groups -- so a lane walks its own rect only when it is small; the rect of a big splat
 // is spread over the 64 lanes (the caller's fn never assumes owner_lane == its own lane).
 template <typename F>
-__device__ __forceinline__ void bn_group_pairs(uint2 v, uint32_t kb, const uint32_t* sH, int shift, const GsrShard& sh, int stiles_x, F&& fn)
+__device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, const GsrShard& sh, int stiles_x, F&& fn)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t rc = v.y;
@@ -82,13 +78,12 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, uint32_t kb, const uint3
     const bool some = x1 >= x0 && y1 >= y0;
     const int area = some ? ((x1 >> shift) - (x0 >> shift) + 1) * ((y1 >> shift) - (y0 >> shift) + 1) : 0;
     const bool big = area > BN_BIG;
-    if (!big) bn_for_each_super(rc, shift, sh, stiles_x, kb, sH, [&](uint32_t d, int sx, int sy) { fn(lane, v, d, sx, sy); });
+    if (!big) bn_for_each_super(rc, shift, sh, stiles_x, [&](uint32_t d, int sx, int sy) { fn(lane, v, d, sx, sy); });
     unsigned long long bigs = __ballot(big);
     while (bigs) {
         const int L = __builtin_ctzll(bigs);
         bigs &= bigs - 1ull;
         const uint2 vL = make_uint2((uint32_t)__shfl((int)v.x, L, 64), (uint32_t)__shfl((int)v.y, L, 64));
-        const uint32_t kbL = (uint32_t)__shfl((int)kb, L, 64);
         const uint32_t r = vL.y;
         const int X0 = r & 255, Y0 = (r >> 8) & 255, X1 = (r >> 16) & 255, Y1 = r >> 24;
         const int sx0 = X0 >> shift, sy0 = Y0 >> shift;
@@ -100,7 +95,6 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, uint32_t kb, const uint3
                 if (gsr_owned_rows(lo, hi, sh) == 0) continue;
             }
             const uint32_t dd = (uint32_t)sy * (uint32_t)stiles_x + (uint32_t)sx;
-            if (sH && kbL > sH[dd]) continue;
             fn(L, vL, dd, sx, sy);
         }
     }
@@ -111,19 +105,14 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, uint32_t kb, const uint3
 // in contiguous eighths (rs_tile_of_block), like the depth sort's.
 __global__ void __launch_bounds__(BN_THREADS)
 k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, GsrShard sh,
-            int stiles_x, uint32_t* __restrict__ hist, uint32_t nblk,
-            const uint32_t* __restrict__ keys /* sorted keys */, const float* __restrict__ horizon /* or NULL */,
-            uint32_t key_min, uint32_t key_max)
+            int stiles_x, uint32_t* __restrict__ hist, uint32_t nblk)
 {
     __shared__ uint32_t h[4][BN_BINS];
-    __shared__ uint32_t s_H[BN_BINS];
-    const uint32_t* sH = horizon ? s_H : nullptr;
     const int wave = threadIdx.x >> 6;
     const uint32_t n = *n_dev;
     const uint32_t nb = (n + BN_TILE - 1) / BN_TILE;
     if (blockIdx.x >= nb) return;   // surplus block of the upper-bound grid: the row scan only reads the blocks that exist
     for (int b = threadIdx.x; b < 4 * BN_BINS; b += BN_THREADS) (&h[0][0])[b] = 0;
-    if (horizon) for (int b = threadIdx.x; b < BN_BINS; b += BN_THREADS) s_H[b] = gsr_horizon_key(horizon[b], key_min, key_max);
     __syncthreads();
     const uint32_t tile = rs_tile_of_block(blockIdx.x, nb, true);
     {
@@ -132,8 +121,7 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
         for (int k = 0; k < BN_ITEMS; ++k) {
             const uint32_t i = base + k * BN_THREADS + threadIdx.x;   // (every wave sees 64 consecutive splats)
             const uint2 v = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
-            const uint32_t kb = (horizon && i < n) ? keys[i] : 0u;
-            bn_group_pairs(v, kb, sH, shift, sh, stiles_x,
+            bn_group_pairs(v, shift, sh, stiles_x,
                            [&](int, uint2, uint32_t d, int, int) { atomicAdd(&h[wave][d], 1u); });
         }
     }
@@ -150,10 +138,15 @@ k_bin_ranges(const uint32_t* __restrict__ totals, int n_super, int32_t* __restri
              volatile unsigned long long* __restrict__ host_total /* pinned, mapped */, uint32_t ticket, unsigned long long max_pairs,
              uint32_t* __restrict__ redo_count /* the frame's list of tiles given up by the plain blend kernel starts empty */,
              const uint32_t* __restrict__ lazy_hint /* k_sum_work's verdict on the previous frame, forwarded to the host */,
-             const uint32_t* __restrict__ n_sorted /* splats that reached the depth sort (what the frame kept) */)
+             const uint32_t* __restrict__ n_sorted /* splats that reached the depth sort (what the frame kept) */,
+             const uint32_t* __restrict__ k1_counts /* [1] = clusters that survived k_cluster_cull */)
 {
-    // word 1 of the mailbox: the hints in the low half, the frame's splat count in the high half
-    if (threadIdx.x == 0) { *redo_count = 0u; host_total[1] = ((unsigned long long)*n_sorted << 32) | (unsigned long long)*lazy_hint; }
+    // word 1 of the mailbox: the hints in the low half, the frame's splat count in the high half; word 2: surviving clusters
+    if (threadIdx.x == 0) {
+        *redo_count = 0u;
+        host_total[1] = ((unsigned long long)*n_sorted << 32) | (unsigned long long)*lazy_hint;
+        host_total[2] = (unsigned long long)k1_counts[1];
+    }
     __shared__ uint32_t s_wave[4];
     __shared__ unsigned long long s_sum[4];
     const uint32_t v = ((int)threadIdx.x < n_super) ? totals[threadIdx.x] : 0u;
@@ -185,17 +178,9 @@ k_bin_ranges(const uint32_t* __restrict__ totals, int n_super, int32_t* __restri
 __global__ void __launch_bounds__(BN_THREADS)
 k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, GsrShard sh,
             int stiles_x, int ns, const uint32_t* __restrict__ offs, const int32_t* __restrict__ sstart,
-            uint32_t nblk, uint32_t cap, uint2* __restrict__ out,
-            const uint32_t* __restrict__ keys /* sorted keys */, const float* __restrict__ horizon /* or NULL */,
-            uint32_t key_min, uint32_t key_max)
+            uint32_t nblk, uint32_t cap, uint2* __restrict__ out)
 {
     extern __shared__ unsigned long long bn_lds[];
-    __shared__ uint32_t s_H[BN_BINS];
-    const uint32_t* sH = horizon ? s_H : nullptr;
-    if (horizon) {
-        for (int b = threadIdx.x; b < BN_BINS; b += BN_THREADS) s_H[b] = gsr_horizon_key(horizon[b], key_min, key_max);
-        __syncthreads();
-    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long* lmask = bn_lds + (size_t)wave * BN_ITEMS * ns;                       // [g][d] of this wave
     uint32_t* wbase_all = reinterpret_cast<uint32_t*>(bn_lds + (size_t)4 * BN_ITEMS * ns);   // [wave][d]
@@ -209,13 +194,11 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     uint2 v[BN_ITEMS];
-    uint32_t kbv[BN_ITEMS];
 #pragma unroll
     for (int g = 0; g < BN_ITEMS; ++g) {   // (A)
         const uint32_t i = first + g * 64 + lane;
         v[g] = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
-        kbv[g] = (horizon && i < n) ? keys[i] : 0u;
-        bn_group_pairs(v[g], kbv[g], sH, shift, sh, stiles_x,
+        bn_group_pairs(v[g], shift, sh, stiles_x,
                        [&](int L, uint2, uint32_t d, int, int) { atomicOr(&lmask[g * ns + d], 1ull << L); });
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -235,7 +218,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < BN_ITEMS; ++g) {   // (B)
-        bn_group_pairs(v[g], kbv[g], sH, shift, sh, stiles_x, [&](int L, uint2 vL, uint32_t d, int sx, int sy) {
+        bn_group_pairs(v[g], shift, sh, stiles_x, [&](int L, uint2 vL, uint32_t d, int sx, int sy) {
             uint32_t pos = wbase[d] + (uint32_t)__builtin_popcountll(lmask[g * ns + d] & ((1ull << L) - 1ull));
 #pragma unroll
             for (int e = 0; e < g; ++e) pos += (uint32_t)__builtin_popcountll(lmask[e * ns + d]);

@@ -9,16 +9,14 @@
 // Geometry: one 256-thread workgroup per 16x16 tile; wave w owns the 8x8
 // quadrant (w&1, w>>1), lane l the pixel (l&7, l>>3) of it -- a wave64 is
 // exactly one 8x8 pixel block, so all culling is wave-uniform.
-// Data flow (scan -> compact -> composite): the tile walks the depth-ordered list of its
-// SUPER-tile 1024 entries at a time (idx + packed tile rect, 8 B each, coalesced, prefetched one
-// step ahead); entries whose rect contains this tile are COMPACTED, in list order, into an LDS hit
-// queue (wave ballots + a 16-entry cross-wave prefix).  Compositing then runs in rounds of BL_ROUND
-// hits: each thread gathers one 48-B record (3 x dwordx4), computes a 4-bit quadrant-overlap mask
-// (separating-axis test) and appends the record, still in depth order, to the LDS list of every
-// quadrant it reaches (ballot ranks + a cross-wave prefix); each wave then walks only its own
-// list, two records per iteration in packed FP32, the pair pre-interleaved in LDS so the operands
-// arrive as register pairs.  Scanning is 4 entries/thread/step and SAT/staging run on fully
-// populated waves, so sparse lists cost little.
+// Data flow (scan -> every wave on its own: gather, test, stage, composite): the tile walks the depth-ordered list of its
+// SUPER-tile 1024 entries at a time (splat index + tile mask, 8 B each, coalesced, prefetched one step ahead); entries whose
+// mask contains this tile are COMPACTED, in list order, into an LDS hit queue (wave ballots + one count per wave through
+// LDS).  A batch of <= BL_BATCH queued hits is then handled by every wave ON ITS OWN, in sub-rounds of 64: lane l gathers
+// the l-th hit's 48-B record (3 x dwordx4; the four waves load the same lines), forms its two affine forms at the tile
+// origin, tests it against THIS wave's 8x8 quadrant only (bbox + separating axes), and the survivors go, by ballot rank =
+// still in depth order, into the wave's own LDS list, two records interleaved per block so that the operands of the
+// packed-FP32 inner loop arrive as register pairs.  No barrier between the batch barriers.
 // Early-out: a PIXEL stops accumulating once 1-A < 2^-14 (dropped contribution
 // <= 2^-14 * max colour, inside the 1e-3 budget; being per pixel it does not
 // depend on chunking, so sharded and unsharded frames are bit-identical); a wave
@@ -27,12 +25,13 @@
 #pragma once
 #include "gsr_device.h"
 #include "k_preprocess.h"   // gsr_splat_colour_from_row (on-demand colour of the lazy path)
+#include "k_cluster.h"      // the depth-horizon pyramid
 
 #ifndef BL_ROUND
 #define BL_ROUND 64           // records a wave gathers, tests and stages at a time (= lanes)
 #endif
 #ifndef BL_WAVES_PER_EU
-#define BL_WAVES_PER_EU 6     // 80 VGPRs (8 dwords of spill) instead of 94: 0.278 -> 0.270 ms
+#define BL_WAVES_PER_EU 6     // 6 waves per SIMD: the kernel needs 68 VGPRs, no scratch
 #endif
 #ifndef BL_CHECK
 #define BL_CHECK 4            // pair iterations between two "is the wave opaque?" tests inside a list (a power of two)
@@ -70,10 +69,6 @@ struct GsrBlendArgs {
     int32_t flags;              // GSR_FLAG_*
     int32_t list_cap;           // entries the list buffer holds (a speculative launch may see ranges beyond it)
     uint32_t* sup_work;         // [256] work per super-tile, summed over its tiles (or NULL)
-    uint32_t* st_scan;          // [512] per super-tile: [st] deepest scan among its tiles that went opaque, [256 + st] set if one did
-                                // not -- what k_sum_work turns into colour prefixes and depth horizons without walking the tiles
-    const float* horizon;       // [256] occlusion culling: this frame's lists end at these depth horizons (or NULL: complete lists)
-    uint32_t* violation;        // set when a tile runs off a list cut at its horizon without going opaque: the frame is redone
 };
 
 // Staging layout: one list PER QUADRANT (= per wave), holding the round's records that reach that
@@ -382,13 +377,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         // entries actually read: everything up to scan_pos plus the prefetched step
         const int rd = scan_pos + 1024;
         const uint4 tw = make_uint4((uint32_t)(rd < n ? rd : n), fetched, sevals, saturated ? 1u : 0u);
-        // occlusion culling: what this tile saw is complete only up to its super-tile's horizon
-        if (a.horizon && !saturated && a.horizon[st] < 3.0e38f) *a.violation = 1u;
-        tile_work[tile] = tw;
-        if (a.st_scan) {   // (fire and forget, like the work sums below)
-            if (saturated) atomicMax(&a.st_scan[st], tw.x);
-            else a.st_scan[256 + st] = 1u;
-        }
+        tile_work[tile] = tw;   // (k_sum_work turns these into colour prefixes, depth horizons and the frame's culling verdict)
         // work of the tile's super-tile, for k_tile_order (fire and forget: ~60 tiles per address and frame)
         if (a.sup_work && gsr_tile_weight(tw)) atomicAdd(&a.sup_work[st], gsr_tile_weight(tw));
     }
@@ -415,10 +404,13 @@ k_blend_lazy(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* 
     gsr_blend_tile<HAS_DEPTH, true>(a, tile_map, svals, sstart, send, recs, out, tile_work, zwin, depth, lz);
 }
 
-// One workgroup sums the per-tile bookkeeping into counters[1] (records gathered, this frame),
-// [2] (records, running total), [3] (entries scanned, this frame), [4] (entries, running total),
-// [5] (wave-record evaluations, running total) -- a handful of atomics per frame instead of per
-// tile (same-address atomics serialise at ~12 ns each on MI355X).  Last kernel of a frame.
+// k_sum_work -- last kernel of a frame, one workgroup.  From the per-tile bookkeeping of the blend kernel it makes
+//   * the frame's counters: counters[1] (records gathered, this frame), [2] (records, running total), [3] (entries scanned, this
+//     frame), [4] (entries, running total), [5] (wave-record evaluations, running total) -- a handful of plain stores instead of
+//     atomics per tile (same-address atomics serialise at ~12 ns each on MI355X);
+//   * the lazy-colour prefixes and the hints (lazy colour / tile order / occlusion culling pay?) for the next frames;
+//   * the DEPTH HORIZONS the slot's next frame culls against, per TILE, as a 4-level max pyramid (k_cluster.h), and
+//   * the verdict on THIS frame's culling: did a tile have to look beyond the horizon its splats were culled against?
 #ifdef SW_PROFILE
 __device__ unsigned long long g_sw_prof[8];
 #define SWP(i) { if (threadIdx.x == 0) g_sw_prof[i] = clock64(); }
@@ -426,31 +418,38 @@ __device__ unsigned long long g_sw_prof[8];
 #define SWP(i)
 #endif
 #define SW_THREADS 1024
-#define SW_UNROLL 12
+#define SW_CHUNK 8            // 8x8-tile blocks a wave has in flight at a time
 #ifndef SW_HEADROOM_SHIFT
 #define SW_HEADROOM_SHIFT 2
 #endif
 #ifndef SW_HEADROOM_ADD
 #define SW_HEADROOM_ADD 1024u
 #endif
-#define SW_HEADROOM_SHIFT_ SW_HEADROOM_SHIFT
-#define SW_HEADROOM_ADD_ SW_HEADROOM_ADD
 struct GsrSumArgs {
-    int32_t n_tiles, tiles_x, super_shift, stiles_x, n_super;
+    int32_t n_tiles, tiles_x, tiles_y /* whole image */, super_shift, stiles_x, n_super;
     GsrShard shard;
 };
-// Depth horizons (occlusion culling): at the end of a frame k_sum_work turns the depth its tiles scanned to into the horizon
-// the slot's next frame culls against and tells the host whether THIS frame broke its own horizons.
+// Depth horizons (occlusion culling).  A tile that went opaque after scanning `rd` entries of its super-tile's list will, in
+// the slot's next frame, need nothing behind the entry a quarter (+1024 entries) further down: that entry's distance^2 is the
+// tile's horizon (+inf for a tile that stayed open).  K1 and k_cluster_cull drop what lies beyond the horizon of every tile
+// it can reach, so every list still holds, for each of its tiles, all splats in front of that tile's horizon -- and a tile of
+// a culled frame is complete iff it went opaque without scanning past the horizon its splats were compared with (at least
+// that of the tile's own dilated neighbourhood).  That is checked here, per tile, from the key of the last entry the tile
+// scanned; a frame that fails is rendered again without culling (gsr_api.hip).  Two pyramids alternate: this kernel reads
+// the one the frame was culled against while it writes the next frame's.
 struct GsrHorizonArgs {
-    float* horizon;                 // [256] in: this frame's (if culled), out: the next frame's; NULL = feature off
-    int32_t culled;                 // this frame's lists were cut at `horizon`
-    int32_t fallback_skipped;       // ... and its colours came from k_colour_kept, so no on-demand fallback was launched: a tile
+    float* pyr;                     // out: the pyramid the slot's next frame culls against; NULL = off
+    const float* pyr_in;            // the pyramid this frame was culled against (if `culled`; never the same buffer as pyr)
+    int32_t pyr_off[4];
+    int32_t culled;                 // K1 / k_cluster_cull dropped splats behind `pyr_in`
+    int32_t dilate;                 // ... after widening every rect by this many tiles
+    int32_t fallback_skipped;       // ... and the colours came from k_colour_kept, so no on-demand fallback was launched: a tile
                                     // that still met a pending colour (it cannot) would have been left undrawn -> report the frame
     const uint2* lists;             // the super-tile lists
+    int32_t list_cap;               // entries the list buffer holds
     const float4* geoA;             // xyz = position
     float cam[3];
-    uint32_t* violation;            // read, reported, cleared
-    unsigned long long* host_end;   // mapped host word: ticket << 32 | violation
+    unsigned long long* host_end;   // mapped host word: ticket << 32 | "a horizon broke"
     uint32_t ticket;
 };
 __global__ void __launch_bounds__(SW_THREADS)
@@ -463,25 +462,16 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
            const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
            uint32_t* __restrict__ lazy_hint /* would lazy colour pay for a frame like this one? (read by the next frames) */,
            uint32_t* __restrict__ sup_work_next /* [256] the NEXT frame's per-super-tile work sums: cleared here (or NULL) */,
-           GsrHorizonArgs hz, uint32_t* __restrict__ st_scan /* [512] per super-tile scan depths / open flags from k_blend: read, cleared */)
+           GsrHorizonArgs hz)
 {
     SWP(0)
-    // first thing: the frame's verdict to the host, which is waiting for it before it queues the next frame
-    if (hz.host_end && threadIdx.x == 0) {
-        uint32_t v = hz.violation ? *hz.violation : 0u;
-        if (hz.fallback_skipped && redo_count && *redo_count) v = 1u;
-        *hz.host_end = ((unsigned long long)hz.ticket << 32) | (unsigned long long)(v ? 1u : 0u);
-        __threadfence_system();   // out to the host NOW (without it the word left with the kernel's end: a 13 us bubble before the next frame)
-        if (hz.violation) *hz.violation = 0u;
-    }
     if (sup_work_next && threadIdx.x < 256) sup_work_next[threadIdx.x] = 0u;
     __shared__ unsigned long long s_sum[3];
-    __shared__ uint32_t s_unsat, s_est, s_cev, s_wmax, s_nfin, s_nused;
-    // The kernel is one workgroup at the very end of the frame and the next frame's K1 waits for it: every dependent global
-    // round trip (~2 us) is frame latency.  So the work is split by wave.  Waves 0-3 (one thread per super-tile) turn the
-    // blend kernel's per-super-tile scan depths into the next frame's colour prefixes and depth horizons -- three dependent
-    // loads: depth, list entry, position -- WHILE waves 4-15 walk the per-tile bookkeeping for the statistics and hints;
-    // everything else either half needs from memory is fetched up front.
+    __shared__ uint32_t s_unsat, s_est, s_cev, s_wmax, s_nfin, s_nused, s_viol;
+    __shared__ uint32_t s_m[256], s_open[256];   // per super-tile: deepest scan of its opaque tiles / a tile stayed open
+    // The kernel is one workgroup at the very end of the frame and the next frame waits for it: every dependent global round
+    // trip (~2 us) is frame latency.  So everything either half needs from memory is fetched up front, and the tile walk keeps
+    // SW_CHUNK independent chains (bookkeeping -> list entry -> position) in flight per lane.
     unsigned long long old2 = 0, old4 = 0, old5 = 0, old_ct = 0;
     uint32_t nvis = 0, nredo = 0, my_cev = 0;
     if (threadIdx.x == 0) {
@@ -489,81 +479,150 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         nvis = *n_visible;
         nredo = redo_count ? *redo_count : 0u;
         if (colour_evals) old_ct = *colour_total;
+        s_unsat = 0; s_est = 0; s_cev = 0; s_wmax = 0; s_nfin = 0; s_nused = 0; s_viol = 0;
     }
     if (colour_evals && threadIdx.x < 256) my_cev = colour_evals[threadIdx.x];
-    if (threadIdx.x == 0) { s_unsat = 0; s_est = 0; s_cev = 0; s_wmax = 0; s_nfin = 0; s_nused = 0; }
+    if (threadIdx.x < 256) { s_m[threadIdx.x] = 0u; s_open[threadIdx.x] = 0u; }
     if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
     __syncthreads();
     SWP(2)
-    if (threadIdx.x < 256) {
-        const int st = (int)threadIdx.x;
-        if (st < g.n_super && st_scan) {
-            const uint32_t m = st_scan[st], open = st_scan[256 + st];
-            const int ss = sstart[st], se = send[st];
-            const float old = hz.horizon ? hz.horizon[st] : 0.0f;
-            st_scan[st] = 0u; st_scan[256 + st] = 0u;   // (for the slot's next frame)
-            const uint32_t len = (uint32_t)(se - ss);
-            if (hz.horizon) {
-                // The next frame's horizon: the distance of the list entry a quarter (+1024 entries) beyond the deepest scan --
-                // the same headroom the lazy colour pass uses.  A list that was itself cut at a horizon may be too short for
-                // that: then the horizon it was cut at is pushed out by 5 % (in distance^2) instead.
-                const uint32_t want = m + (m >> 2) + 1024u;
-                float h = __builtin_inff();
-                if (!open && len > 0u) {
-                    if (want < len) {
-                        const uint32_t idx = hz.lists[(uint32_t)ss + want].x;
-                        const float4 P = hz.geoA[idx];
-                        const float dx = P.x - hz.cam[0], dy = P.y - hz.cam[1], dz = P.z - hz.cam[2];
-                        h = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
-                    } else if (hz.culled && old < 3.0e38f) {
-                        h = old * 1.05f;
+    {
+        // a wave takes whole 8x8-tile blocks, lane = tile in Morton order inside the block: the pyramid's levels 1..3 are wave shuffles
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+        const int nbx = (g.tiles_x + 7) >> 3, nby = (g.tiles_y + 7) >> 3, nblocks = nbx * nby;
+        unsigned long long sc = 0, fe = 0, ev = 0;
+        uint32_t wmax = 0, unsat = 0, nused = 0, nfin = 0, viol = 0;
+        for (int b0 = wave; b0 < nblocks; b0 += (SW_THREADS / 64) * SW_CHUNK) {
+            uint32_t rd[SW_CHUNK], want[SW_CHUNK], len[SW_CHUNK], flag[SW_CHUNK];   // flag: 1 in image, 2 owned, 4 opaque
+            int ss[SW_CHUNK];
+            float hold[SW_CHUNK], klast[SW_CHUNK], hnew[SW_CHUNK];
+            uint32_t i1[SW_CHUNK], i2[SW_CHUNK];
+#pragma unroll
+            for (int u = 0; u < SW_CHUNK; ++u) {   // (A) bookkeeping, list range, the horizon the tile was culled against
+                const int b = b0 + u * (SW_THREADS / 64);
+                rd[u] = 0; want[u] = 0; len[u] = 0; flag[u] = 0; ss[u] = 0; hold[u] = __builtin_inff();
+                if (b < nblocks) {
+                    const int by = b / nbx, bx = b - by * nbx;
+                    const int tx = bx * 8 + lx, gty = by * 8 + ly;
+                    if (tx < g.tiles_x && gty < g.tiles_y) {
+                        flag[u] = 1u;
+                        if (gsr_shard_owns(g.shard, gty)) {
+                            const int lty = g.shard.rpb > 0 ? gty - g.shard.index * g.shard.rpb : gty / g.shard.count;
+                            const int i = lty * g.tiles_x + tx;
+                            if (i < g.n_tiles) {
+                                const uint4 w = tile_work[i];
+                                const int st = (gty >> g.super_shift) * g.stiles_x + (tx >> g.super_shift);
+                                const int s0 = sstart[st];
+                                int e0 = send[st];
+                                e0 = e0 < hz.list_cap ? e0 : hz.list_cap;
+                                ss[u] = s0; len[u] = e0 > s0 ? (uint32_t)(e0 - s0) : 0u;
+                                rd[u] = w.x;
+                                flag[u] = 3u | (w.w ? 4u : 0u);
+                                // what every splat touching this tile was compared with, at least: the value of the tile's own
+                                // dilated neighbourhood (gsr_pyr_max is monotone)
+                                if (hz.pyr && hz.culled)
+                                    hold[u] = gsr_pyr_max(hz.pyr_in, hz.pyr_off, g.tiles_x, max(tx - hz.dilate, 0), max(gty - hz.dilate, 0),
+                                                          min(tx + hz.dilate, g.tiles_x - 1), min(gty + hz.dilate, g.tiles_y - 1));
+                                sc += w.x; fe += w.y; ev += w.z;
+                                { const uint32_t tw = gsr_tile_weight(w); wmax = tw > wmax ? tw : wmax; }
+                                if (!w.w && w.y) ++unsat;
+                                if (st < 256) { if (w.w) atomicMax(&s_m[st], w.x); else s_open[st] = 1u; }
+                            }
+                        }
                     }
                 }
-                hz.horizon[st] = h;
-                // what the horizons would cut off, in list entries (of a complete list: a cut one has lost its tail already)
-                if (len > 0u) { atomicAdd(&s_nused, len); if (h < 3.0e38f && want < len) atomicAdd(&s_nfin, len - want); }
             }
-            if (prefix) {
-                {   // how many colour evaluations the lazy pass would make for a frame like this one
-                    const uint32_t want = m + (m >> SW_HEADROOM_SHIFT_) + SW_HEADROOM_ADD_;
-                    atomicAdd(&s_est, want < len ? want : len);
+            if (hz.pyr) {
+#pragma unroll
+                for (int u = 0; u < SW_CHUNK; ++u) {   // (B) the last entry the tile scanned, and the entry its next horizon sits at
+                    i1[u] = 0xffffffffu; i2[u] = 0xffffffffu;
+                    want[u] = rd[u] + (rd[u] >> 2) + 1024u;
+                    if ((flag[u] & 4u) && rd[u] > 0u && rd[u] <= len[u]) {
+                        if (hold[u] < 3.0e38f) i1[u] = hz.lists[(uint32_t)ss[u] + rd[u] - 1u].x;
+                        if (want[u] < len[u]) i2[u] = hz.lists[(uint32_t)ss[u] + want[u]].x;
+                    }
                 }
-                prefix[st] = m + (m >> SW_HEADROOM_SHIFT) + SW_HEADROOM_ADD;   // headroom for the next frame's camera move
-            }
-        }
-    } else {
-        constexpr int TL = SW_THREADS - 256;   // threads of the tile walk
-        const int t = (int)threadIdx.x - 256;
-        unsigned long long sc = 0, fe = 0, ev = 0;
-        uint32_t wmax = 0;    // heaviest tile (gsr_tile_weight)
-        uint32_t unsat = 0;   // tiles that composited something and ran to the end of their list: lazy colour sends them to the fallback
-        for (int i0 = 0; i0 < g.n_tiles; i0 += SW_UNROLL * TL) {
-            uint4 w[SW_UNROLL];
 #pragma unroll
-            for (int u = 0; u < SW_UNROLL; ++u) {   // independent loads: one memory round trip per sweep
-                const int i = i0 + u * TL + t;
-                w[u] = i < g.n_tiles ? tile_work[i] : make_uint4(0u, 0u, 0u, 0u);
-            }
+                for (int u = 0; u < SW_CHUNK; ++u) {   // (C) their distance^2 (the sort key of k_preprocess.h, same operations)
+                    klast[u] = 0.0f; hnew[u] = __builtin_inff();
+                    if (i1[u] != 0xffffffffu) {
+                        const float4 P = hz.geoA[i1[u]];
+                        const float dx = P.x - hz.cam[0], dy = P.y - hz.cam[1], dz = P.z - hz.cam[2];
+                        klast[u] = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
+                    }
+                    if (i2[u] != 0xffffffffu) {
+                        const float4 P = hz.geoA[i2[u]];
+                        const float dx = P.x - hz.cam[0], dy = P.y - hz.cam[1], dz = P.z - hz.cam[2];
+                        hnew[u] = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
+                    }
+                }
 #pragma unroll
-            for (int u = 0; u < SW_UNROLL; ++u) {
-                sc += w[u].x; fe += w[u].y; ev += w[u].z;
-                { const uint32_t tw = gsr_tile_weight(w[u]); wmax = tw > wmax ? tw : wmax; }
-                if (!w[u].w && w[u].y) ++unsat;
+                for (int u = 0; u < SW_CHUNK; ++u) {   // (D) verdict, next horizon, pyramid
+                    const int b = b0 + u * (SW_THREADS / 64);
+                    if (b >= nblocks) continue;        // (wave-uniform)
+                    float h = 0.0f;                    // outside the image / another rank's tile: nothing is needed there
+                    if (flag[u] & 2u) {
+                        const bool opaque = (flag[u] & 4u) != 0u;
+                        // this frame: a tile with a horizon must have gone opaque without looking past it
+                        if (hold[u] < 3.0e38f && (!opaque || !(klast[u] <= hold[u]))) viol = 1u;
+                        // next frame: the key a quarter (+1024 entries) beyond the scan; a list too short for that was itself
+                        // thinned by culling -- then the old horizon is pushed out by 5 % (in distance^2) instead
+                        h = __builtin_inff();
+                        if (opaque) {
+                            if (want[u] < len[u]) h = hnew[u];
+                            else if (hold[u] < 3.0e38f) h = hold[u] * 1.05f;
+                        }
+                        if (len[u] > 0u) { ++nused; if (h < 3.0e38f && (unsigned long long)want[u] * 10ull <= (unsigned long long)len[u] * 7ull) ++nfin; }
+                    }
+                    const int by = b / nbx, bx = b - by * nbx;
+                    const int tx = bx * 8 + lx, gty = by * 8 + ly;
+                    if (flag[u] & 1u) hz.pyr[hz.pyr_off[0] + gty * g.tiles_x + tx] = h;
+                    float v = (flag[u] & 1u) ? h : 0.0f;
+                    v = __builtin_fmaxf(v, __shfl_xor(v, 1, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 2, 64));
+                    if ((lane & 3) == 0 && (flag[u] & 1u)) hz.pyr[hz.pyr_off[1] + (gty >> 1) * gsr_pyr_dim(g.tiles_x, 1) + (tx >> 1)] = v;
+                    v = __builtin_fmaxf(v, __shfl_xor(v, 4, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 8, 64));
+                    if ((lane & 15) == 0 && (flag[u] & 1u)) hz.pyr[hz.pyr_off[2] + (gty >> 2) * gsr_pyr_dim(g.tiles_x, 2) + (tx >> 2)] = v;
+                    v = __builtin_fmaxf(v, __shfl_xor(v, 16, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 32, 64));
+                    if (lane == 0) hz.pyr[hz.pyr_off[3] + by * nbx + bx] = v;
+                }
             }
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
             sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); unsat += __shfl_down(unsat, d, 64);
+            nused += __shfl_down(nused, d, 64); nfin += __shfl_down(nfin, d, 64);
             { const uint32_t o = __shfl_down(wmax, d, 64); wmax = o > wmax ? o : wmax; }
         }
-        if ((threadIdx.x & 63) == 0) {
+        if (__ballot(viol != 0u) && lane == 0) s_viol = 1u;
+        if (lane == 0) {
             atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); atomicAdd(&s_sum[2], ev); atomicAdd(&s_unsat, unsat); atomicMax(&s_wmax, wmax);
+            atomicAdd(&s_nused, nused); atomicAdd(&s_nfin, nfin);
         }
     }
     SWP(3)
-    if (colour_evals && threadIdx.x < 256) {
-        colour_evals[threadIdx.x] = 0u;
-        if (my_cev) atomicAdd(&s_cev, my_cev);
+    __syncthreads();
+    // the frame's verdict to the host, which is waiting for it before it hands the frame over and queues the next one
+    if (hz.host_end && threadIdx.x == 0) {
+        uint32_t v = s_viol;
+        if (hz.fallback_skipped && nredo) v = 1u;
+        *hz.host_end = ((unsigned long long)hz.ticket << 32) | (unsigned long long)(v ? 1u : 0u);
+        __threadfence_system();   // out to the host NOW (without it the word left with the kernel's end: a 13 us bubble before the next frame)
+    }
+    if (threadIdx.x < 256) {
+        const int st = (int)threadIdx.x;
+        if (st < g.n_super && prefix) {
+            const uint32_t m = s_m[st];
+            const int s0 = sstart[st], e0 = send[st];
+            const uint32_t len = e0 > s0 ? (uint32_t)(e0 - s0) : 0u;
+            const uint32_t want = m + (m >> SW_HEADROOM_SHIFT) + SW_HEADROOM_ADD;   // headroom for the next frame's camera move
+            atomicAdd(&s_est, want < len ? want : len);   // colour evaluations the lazy pass would make for a frame like this one
+            prefix[st] = want;
+        }
+        if (colour_evals) {
+            colour_evals[threadIdx.x] = 0u;
+            if (my_cev) atomicAdd(&s_cev, my_cev);
+        }
     }
     __syncthreads();
     SWP(4)
@@ -580,10 +639,11 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         const uint32_t order_pays = ((unsigned long long)s_wmax * 3072ull > wsum && wsum > 60000000ull) ? 2u : 0u;
         if (lazy_hint) *lazy_hint = ((prefix && (unsigned long long)s_est * 10ull < (unsigned long long)nvis * 4ull &&
                                       s_unsat * 64u <= (uint32_t)g.n_tiles) ? 1u : 0u) | order_pays |
-                                    // bit 2: occlusion culling has something to work with: the horizons would cut at least 30 % of
-                                    // the list entries (judged on unculled frames; a culled frame keeps the verdict it was given)
-                                    ((hz.horizon && (hz.culled || ((unsigned long long)s_nfin * 10ull >= (unsigned long long)s_nused * 3ull &&
-                                                                   s_nused > 0u))) ? 4u : 0u);
+                                    // bit 2: occlusion culling has something to work with: at least 30 % of the tiles that draw anything
+                                    // went opaque in the first 70 % of their list (judged on unculled frames; a culled frame keeps the
+                                    // verdict it was given)
+                                    ((hz.pyr && (hz.culled || ((unsigned long long)s_nfin * 10ull >= (unsigned long long)s_nused * 3ull &&
+                                                               s_nused > 0u))) ? 4u : 0u);
         // running totals: plain read-modify-write (a slot's frames are serialised on its stream; nothing else touches them)
         const unsigned long long t2 = old2 + s_sum[1], t4 = old4 + s_sum[0], t5 = old5 + s_sum[2];
         counters[1] = s_sum[1]; counters[2] = t2; counters[3] = s_sum[0]; counters[4] = t4; counters[5] = t5;

@@ -1,0 +1,297 @@
+// k_cluster.h -- spatially ordered storage and cluster culling in front of K1.
+//
+// The reference streams every splat through its vertex shader every frame
+// (/root/reference/gsplat_plugin/src/GSplatRenderer.C:647: one instanced quad per splat) and sorts all of them on the
+// CPU (:176-216).  Here the splats are stored in MORTON ORDER of their positions (an upload-time permutation; ties in the
+// depth sort are broken by this storage order -- the reference's own tie order is unspecified, :206-207), so that 64
+// consecutive splats = one CLUSTER = one wavefront of K1 occupy a small box in space, and every frame starts with
+//   k_cluster_cull   one thread per cluster: the cluster's box (AABB of the positions + the largest splat extent in it)
+//                    against the clip planes, the frame's screen / this rank's band of tile rows, and the depth horizons
+//                    of the tiles its screen bound reaches -> the ordered list of the clusters that may draw something.
+// K1 and everything behind it run over the survivors only.  Every test is CONSERVATIVE with respect to the per-splat
+// rules of k_preprocess.h (a cluster is dropped only if each of its splats would have been dropped there, or would have
+// left no list entry), so frames are bit-identical with the stage switched off (GSR_OPT_CLUSTER_CULL = 0).
+#pragma once
+#include "gsr_device.h"
+
+#define GSR_CLUSTER 64                 // splats per cluster = lanes of a wavefront
+#define CC_THREADS 256                 // threads of a k_cluster_cull workgroup (one cluster each per round)
+#define CC_MAX_GROUPS 4096             // count entries K1's prologue can search (64 x 64)
+
+// ---- upload time ------------------------------------------------------------------------------------------------------
+// 30-bit Morton code of the position inside the cloud's bounding box (10 bits per axis); non-finite positions sort last
+__device__ __forceinline__ uint32_t cc_spread10(uint32_t v)
+{
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ void __launch_bounds__(256)
+k_morton_codes(const float4* __restrict__ geoA, uint32_t n, float lx, float ly, float lz, float sx, float sy, float sz,
+               uint32_t* __restrict__ code, uint32_t* __restrict__ idx)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = geoA[i];
+    uint32_t c = 0x3fffffffu;
+    if (__builtin_fabsf(a.x) < 3.0e38f && __builtin_fabsf(a.y) < 3.0e38f && __builtin_fabsf(a.z) < 3.0e38f) {
+        const float qx = __builtin_fminf(__builtin_fmaxf((a.x - lx) * sx, 0.0f), 1023.0f);
+        const float qy = __builtin_fminf(__builtin_fmaxf((a.y - ly) * sy, 0.0f), 1023.0f);
+        const float qz = __builtin_fminf(__builtin_fmaxf((a.z - lz) * sz, 0.0f), 1023.0f);
+        c = cc_spread10((uint32_t)qx) | (cc_spread10((uint32_t)qy) << 1) | (cc_spread10((uint32_t)qz) << 2);
+    }
+    code[i] = c;
+    idx[i] = i;
+}
+
+// storage slot j <- splat perm[j] of the upload order
+__global__ void __launch_bounds__(256)
+k_permute_geo(uint32_t n, uint32_t cap, int chunks, const uint32_t* __restrict__ perm,
+              const float4* __restrict__ sA, const uint4* __restrict__ sB, const uint4* __restrict__ scol,
+              float4* __restrict__ dA, uint4* __restrict__ dB, uint4* __restrict__ dcol)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t i = perm[j];
+    dA[j] = sA[i];
+    dB[j] = sB[i];
+    for (int c = 0; c < chunks; ++c) dcol[(size_t)c * cap + j] = scol[(size_t)c * cap + i];
+}
+// ... and the 128-byte colour rows: eight lanes per row
+__global__ void __launch_bounds__(256)
+k_permute_rows(uint32_t n, const uint32_t* __restrict__ perm, const uint4* __restrict__ srow, uint4* __restrict__ drow)
+{
+    const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
+    const size_t j = t >> 3;
+    if (j >= n) return;
+    drow[j * 8 + (t & 7)] = srow[(size_t)perm[j] * 8 + (t & 7)];
+}
+
+// Per cluster: clusA = (lo.xyz of the positions, the largest |diag(scale) R^T|_F bound of k_repack), clusB = (hi.xyz, flag);
+// flag != 0: a position or an extent bound is not finite -- the cluster is never culled.  One wavefront per cluster.
+__global__ void __launch_bounds__(256)
+k_cluster_bounds(uint32_t n, const float4* __restrict__ geoA, const uint4* __restrict__ geoB,
+                 float4* __restrict__ clusA, float4* __restrict__ clusB)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t cl = i / GSR_CLUSTER;
+    if (cl * GSR_CLUSTER >= n) return;            // (wave-uniform)
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, mf = 0.0f;
+    bool bad = false;
+    if (i < n) {
+        const float4 a = geoA[i];
+        const uint4 b = geoB[i];
+        const float m = gsr_h2f(b.w >> 16);
+        bad = !(__builtin_fabsf(a.x) < 3.0e38f) || !(__builtin_fabsf(a.y) < 3.0e38f) || !(__builtin_fabsf(a.z) < 3.0e38f) || !(m < 6.0e4f);
+        lo[0] = hi[0] = a.x; lo[1] = hi[1] = a.y; lo[2] = hi[2] = a.z;
+        mf = m;
+    }
+    const bool any_bad = __ballot(bad) != 0ull;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = __builtin_fminf(lo[k], __shfl_xor(lo[k], d, 64));
+            hi[k] = __builtin_fmaxf(hi[k], __shfl_xor(hi[k], d, 64));
+        }
+        mf = __builtin_fmaxf(mf, __shfl_xor(mf, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        clusA[cl] = make_float4(lo[0], lo[1], lo[2], mf);
+        clusB[cl] = make_float4(hi[0], hi[1], hi[2], any_bad ? 1.0f : 0.0f);
+    }
+}
+
+// ---- per frame ----------------------------------------------------------------------------------------------------------
+// Depth horizons live in a 4-level max pyramid over the tile grid (k_blend.h: k_sum_work builds it): level l cell (x, y)
+// = the largest horizon of the tiles [x 2^l, (x+1) 2^l) x [y 2^l, (y+1) 2^l); +inf = no horizon (nothing may be culled
+// there), 0 = a tile of another rank (nothing is needed there).
+#define GSR_PYR_LEVELS 4
+#define GSR_PYR_FLOATS (512 * 512 + 256 * 256 + 128 * 128 + 64 * 64 + 16)   // a grid of up to 512 x 512 tiles
+__host__ __device__ __forceinline__ int gsr_pyr_dim(int tiles, int level) { return ((tiles - 1) >> level) + 1; }
+// largest horizon over the tile rect [x0, x1] x [y0, y1] (inside the grid), widened to at most 2 x 2 cells of one level
+// (or <= 3 x 3 cells of the top level); +inf when the rect is larger than that.  MONOTONE: a rect that contains another
+// never gets a smaller value (its cells are unions of the other's), which is what lets k_sum_work check a tile against
+// the value of the tile's own dilated neighbourhood -- every splat that touches the tile was compared with at least that.
+__device__ __forceinline__ float gsr_pyr_max(const float* __restrict__ pyr, const int32_t* pyr_off, int tiles_x, int x0, int y0, int x1, int y1)
+{
+    const int span = max(x1 - x0, y1 - y0);
+    int L = 31 - __builtin_clz((uint32_t)span | 1u);
+    if (((x1 >> L) - (x0 >> L)) > 1 || ((y1 >> L) - (y0 >> L)) > 1) ++L;
+    if (L < GSR_PYR_LEVELS) {
+        const int w = gsr_pyr_dim(tiles_x, L);
+        const float* p = pyr + pyr_off[L];
+        const int a0 = x0 >> L, a1 = x1 >> L, b0 = y0 >> L, b1 = y1 >> L;
+        return __builtin_fmaxf(__builtin_fmaxf(p[b0 * w + a0], p[b0 * w + a1]), __builtin_fmaxf(p[b1 * w + a0], p[b1 * w + a1]));
+    }
+    const int T = GSR_PYR_LEVELS - 1;
+    const int a0 = x0 >> T, a1 = x1 >> T, b0 = y0 >> T, b1 = y1 >> T;
+    if (a1 - a0 > 2 || b1 - b0 > 2) return __builtin_inff();
+    const int w = gsr_pyr_dim(tiles_x, T);
+    const float* p = pyr + pyr_off[T];
+    float h = 0.0f;
+    for (int b = b0; b <= b1; ++b)
+        for (int a = a0; a <= a1; ++a) h = __builtin_fmaxf(h, p[b * w + a]);
+    return h;
+}
+
+// one thread per cluster; workgroup b handles the clusters [b * per, (b + 1) * per), per = CC_THREADS * rounds, and leaves
+// the ones that stay, in cluster order, at seg[b * per ...] with their number in cnt[b]
+__global__ void __launch_bounds__(CC_THREADS)
+k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __restrict__ clusB, uint32_t nclus, int rounds,
+               int enabled, const float* __restrict__ hpyr /* or NULL: no occlusion test */,
+               uint32_t* __restrict__ seg, uint32_t* __restrict__ cnt)
+{
+    __shared__ uint32_t s_w[CC_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t per = (uint32_t)CC_THREADS * (uint32_t)rounds;
+    uint32_t kept = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const uint32_t cl = blockIdx.x * per + (uint32_t)r * CC_THREADS + threadIdx.x;
+        bool keep = cl < nclus;
+        if (keep && enabled) {
+            const float4 A = clusA[cl], B = clusB[cl];
+            if (B.w == 0.0f) {
+                // the box, widened by what the GSplatOrigin round trip (fl32(P - origin) + origin) can move a position
+                const float plo[3] = {A.x, A.y, A.z}, phi[3] = {B.x, B.y, B.z};
+                float lo[3] = {A.x, A.y, A.z}, hi[3] = {B.x, B.y, B.z};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float e = 1.0e-6f * (__builtin_fmaxf(__builtin_fabsf(lo[k]), __builtin_fabsf(hi[k])) + __builtin_fabsf(f.origin[k])) + 1.0e-30f;
+                    lo[k] -= e; hi[k] += e;
+                }
+                // clip coordinates are affine in the position: their extrema over the box are at its corners
+                float wmin = 3.0e38f, wmax = -3.0e38f, zpw_max = -3.0e38f, wmz_max = -3.0e38f, tz_min = 3.0e38f, tz_max = -3.0e38f;
+                float cxmin = 3.0e38f, cxmax = -3.0e38f, cymin = 3.0e38f, cymax = -3.0e38f, mag = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float x = (c & 1) ? hi[0] : lo[0], y = (c & 2) ? hi[1] : lo[1], z = (c & 4) ? hi[2] : lo[2];
+                    const float tvx = gsr_fma(f.ov[0], x, gsr_fma(f.ov[1], y, gsr_fma(f.ov[2], z, f.ov[3])));
+                    const float tvy = -gsr_fma(f.ov[4], x, gsr_fma(f.ov[5], y, gsr_fma(f.ov[6], z, f.ov[7])));
+                    const float tvz = gsr_fma(f.ov[8], x, gsr_fma(f.ov[9], y, gsr_fma(f.ov[10], z, f.ov[11])));
+                    const float clx = gsr_fma(f.pr[0], tvx, gsr_fma(f.pr[1], tvy, gsr_fma(f.pr[2], tvz, f.pr[3])));
+                    const float cly = gsr_fma(f.pr[4], tvx, gsr_fma(f.pr[5], tvy, gsr_fma(f.pr[6], tvz, f.pr[7])));
+                    const float clz = gsr_fma(f.pr[8], tvx, gsr_fma(f.pr[9], tvy, gsr_fma(f.pr[10], tvz, f.pr[11])));
+                    const float clw = gsr_fma(f.pr[12], tvx, gsr_fma(f.pr[13], tvy, gsr_fma(f.pr[14], tvz, f.pr[15])));
+                    const float tz = gsr_fma(f.vw[8], x, gsr_fma(f.vw[9], y, gsr_fma(f.vw[10], z, f.vw[11])));
+                    mag = __builtin_fmaxf(mag, __builtin_fabsf(tvx) + __builtin_fabsf(tvy) + __builtin_fabsf(tvz) + 1.0f);
+                    wmin = __builtin_fminf(wmin, clw); wmax = __builtin_fmaxf(wmax, clw);
+                    zpw_max = __builtin_fmaxf(zpw_max, clz + clw);     // < 0 everywhere: in front of the near plane
+                    wmz_max = __builtin_fmaxf(wmz_max, clw - clz);     // < 0 everywhere: beyond the far plane
+                    tz_min = __builtin_fminf(tz_min, tz); tz_max = __builtin_fmaxf(tz_max, tz);
+                    const float iw = 1.0f / clw;
+                    const float px = gsr_fma(clx * iw, 0.5f, 0.5f) * f.W, py = gsr_fma((-cly) * iw, 0.5f, 0.5f) * f.H;
+                    cxmin = __builtin_fminf(cxmin, px); cxmax = __builtin_fmaxf(cxmax, px);
+                    cymin = __builtin_fminf(cymin, py); cymax = __builtin_fmaxf(cymax, py);
+                }
+                // rounding of the affine forms (here and in K1): a few ulp of the largest term
+                float prn = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) prn = __builtin_fmaxf(prn, __builtin_fabsf(f.pr[k]));
+                const float eps = 1.0e-5f * mag * (prn + 1.0f);
+                if (wmax < -eps || zpw_max < -eps || wmz_max < -eps) {
+                    keep = false;                                       // w <= 0, or z outside [-w, w], for every splat
+                } else if (wmin > eps && (tz_max < -1.0e-6f * mag || tz_min > 1.0e-6f * mag) && mag < 1.0e15f) {
+                    // wholly in front of the eye: the screen positions of its splats lie inside the hull of the projected
+                    // corners, and every quad inside its centre +- hb: the cheap extent bound of gsr_k1_front, taken at the
+                    // largest |diag(scale) R^T|_F and the smallest |view z| of the cluster
+                    const float tzn = __builtin_fminf(__builtin_fabsf(tz_min), __builtin_fabsf(tz_max)) * (1.0f - 1.0e-5f);
+                    const float jz = f.focal / tzn;
+                    const float mf = A.w * 1.001f;
+                    const float trb = jz * jz * (2.0f + f.limx * f.limx + f.limy * f.limy) * f.sigma_vo2 * (mf * mf) * 1.002f + 0.6f;
+                    const float hb = 2.8313f * __builtin_fminf(__builtin_sqrtf(2.0f * trb), 4096.0f) + 0.02f;
+                    const float slack = 1.0f + 1.0e-4f * (__builtin_fabsf(cxmin) + __builtin_fabsf(cxmax) + __builtin_fabsf(cymin) + __builtin_fabsf(cymax));
+                    const float xlo = cxmin - hb - 0.5f - slack, xhi = cxmax + hb - 0.5f + slack;
+                    const float ylo = cymin - hb - 0.5f - slack, yhi = cymax + hb - 0.5f + slack;
+                    const float wm1 = (float)(f.width - 1), hm1 = (float)(f.height - 1);
+                    if (hb < 1.0e9f && xlo < 1.0e9f && xhi > -1.0e9f && ylo < 1.0e9f && yhi > -1.0e9f) {   // (false for NaN / inf)
+                        if (xhi < 0.0f || xlo > wm1 || yhi < 0.0f || ylo > hm1) {
+                            keep = false;                               // off screen
+                        } else {
+                            const int tx0 = (int)__builtin_fmaxf(xlo, 0.0f) >> 4, tx1 = (int)__builtin_fminf(xhi, wm1) >> 4;
+                            const int ty0 = (int)__builtin_fmaxf(ylo, 0.0f) >> 4, ty1 = (int)__builtin_fminf(yhi, hm1) >> 4;
+                            if (gsr_owned_rows(ty0, ty1, GsrShard{f.shard_index, f.shard_count, f.shard_rpb}) == 0) {
+                                keep = false;                           // none of its tile rows is ours
+                            } else if (hpyr) {
+                                // behind the depth horizon of every tile it can reach (widened by the dilation radius)?  The sort key
+                                // is the distance^2 of the UN-offset position (k_preprocess.h): a lower bound from the raw box
+                                float d2 = 0.0f;
+#pragma unroll
+                                for (int k = 0; k < 3; ++k) {
+                                    const float d = __builtin_fmaxf(__builtin_fmaxf(plo[k] - f.cam[k], f.cam[k] - phi[k]), 0.0f);
+                                    d2 = gsr_fma(d, d, d2);
+                                }
+                                d2 *= (1.0f - 1.0e-5f);
+                                uint32_t kb = __builtin_bit_cast(uint32_t, d2);
+                                kb = kb < f.key_min ? f.key_min : (kb > f.key_max ? f.key_max : kb);
+                                kb -= f.key_min;
+                                const int r_ = f.cull_dilate;
+                                const float h = gsr_pyr_max(hpyr, f.pyr_off, f.tiles_x, max(tx0 - r_, 0), max(ty0 - r_, 0), min(tx1 + r_, f.tiles_x - 1), min(ty1 + r_, f.tiles_y - 1));
+                                if (kb > gsr_horizon_key(h, f.key_min, f.key_max)) keep = false;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ordered compaction: ballot ranks inside the wave, wave counts through LDS
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_w[wave] = (uint32_t)__builtin_popcountll(bal);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < CC_THREADS / 64; ++w) { const uint32_t c = s_w[w]; before += w < wave ? c : 0u; total += c; }
+        if (keep) seg[(size_t)blockIdx.x * per + kept + before + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] = cl;
+        kept += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cnt[blockIdx.x] = kept;
+}
+
+// K1's prologue: the inclusive prefix of the cnt[] of k_cluster_cull, in LDS (ngroups <= CC_MAX_GROUPS), returns the
+// number of surviving clusters.  All 256 threads; contains barriers.
+__device__ __forceinline__ uint32_t cc_prefix_to_lds(const uint32_t* __restrict__ cnt, uint32_t ngroups, uint32_t* s_inc /*[CC_MAX_GROUPS]*/,
+                                                     uint32_t* s_wave /*[4]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < ngroups; base += 256u) {
+        const uint32_t g = base + threadIdx.x;
+        const uint32_t v = g < ngroups ? cnt[g] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t wb = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const uint32_t t = s_wave[w]; wb += w < wave ? t : 0u; tot += t; }
+        if (g < ngroups) s_inc[g] = carry + wb + inc;
+        carry += tot;
+        __syncthreads();
+    }
+    return carry;
+}
+// the rank-th surviving cluster (rank < total): 64-ary search of the inclusive prefix, two LDS reads per lane
+__device__ __forceinline__ uint32_t cc_find_cluster(const uint32_t* s_inc, uint32_t ngroups, uint32_t rank,
+                                                    const uint32_t* __restrict__ seg, uint32_t per)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t stride = (ngroups + 63u) / 64u;
+    // chunk c = groups [c * stride, (c + 1) * stride): the first chunk whose last inclusive prefix exceeds rank
+    const uint32_t last = min((lane + 1u) * stride, ngroups) - 1u;
+    const bool in1 = lane * stride < ngroups && s_inc[last] > rank;
+    const unsigned long long b1 = __ballot(in1);
+    const uint32_t c = (uint32_t)__builtin_ctzll(b1 | (1ull << 63));
+    uint32_t g = c * stride;
+    for (uint32_t base = 0; base < stride; base += 64u) {      // (stride <= 64: one trip)
+        const uint32_t gg = c * stride + base + lane;
+        const bool in2 = base + lane < stride && gg < ngroups && s_inc[gg] > rank;
+        const unsigned long long b2 = __ballot(in2);
+        if (b2) { g = c * stride + base + (uint32_t)__builtin_ctzll(b2); break; }
+    }
+    const uint32_t before = g ? s_inc[g - 1u] : 0u;
+    return seg[(size_t)g * per + (rank - before)];
+}

@@ -8,6 +8,7 @@
 // (128 B read + 60 B written per splat at SH order 3; ~250 flop).
 #pragma once
 #include "gsr_device.h"
+#include "k_cluster.h"
 
 #ifndef GSR_K1_THREADS
 #define GSR_K1_THREADS 256
@@ -341,7 +342,7 @@ gsr_k1_front(const GsrFrame& f, const float4 a, const uint4 b, float* __restrict
 // returns the packed tile rect (GSR_RECT_EMPTY: the splat draws nothing here); writes the record of a splat that draws
 __device__ __forceinline__ uint32_t
 gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, const uint4 b, const uint4* __restrict__ col,
-            GsrRecord* __restrict__ rec, int lazy, const float* __restrict__ horizon)
+            GsrRecord* __restrict__ rec, int lazy, const float* __restrict__ hpyr)
 {
     uint32_t out_rect = GSR_RECT_EMPTY;
     const float x = o.x, y = o.y, z = o.z, cx = o.cx, cy = o.cy, opacity = o.opacity;
@@ -371,24 +372,17 @@ gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, co
     // colour fetch, no record and (sentinel key) no sorting
     if (out_rect != GSR_RECT_EMPTY && gsr_rect_tiles(out_rect, GsrShard{f.shard_index, f.shard_count, f.shard_rpb}) == 0)
         out_rect = GSR_RECT_EMPTY;
-    // Occlusion culling against the previous frame's depth horizons (gsr_api.hip: "depth horizons"): in a super-tile all of
-    // whose tiles went opaque, nothing behind the depth at which the last of them did can show.  A splat whose key lies beyond
-    // the horizon of EVERY super-tile its rect reaches is dropped here -- no colour, no record, no sorting, no binning; the
-    // binning kernels cut every list at its horizon with the same comparison, so a list holds exactly the splats in front of
-    // its horizon -- and a tile that runs off such a list without going opaque reports the frame, which is then rendered
-    // again without culling.  (The 1-KB table is read through the cache: one gather per super-tile of the rect, usually one.)
-    if (horizon && out_rect != GSR_RECT_EMPTY) {
-        const int u0 = (int)(out_rect & 255u) >> f.super_shift, v0 = (int)((out_rect >> 8) & 255u) >> f.super_shift;
-        const int u1 = (int)((out_rect >> 16) & 255u) >> f.super_shift, v1 = (int)(out_rect >> 24) >> f.super_shift;
-        if ((u1 - u0 + 1) * (v1 - v0 + 1) <= 6) {
-            uint32_t hmax = 0u;
-            for (int v = v0; v <= v1; ++v)
-                for (int u = u0; u <= u1; ++u) {
-                    const uint32_t h = gsr_horizon_key(horizon[v * f.stiles_x + u], f.key_min, f.key_max);
-                    hmax = h > hmax ? h : hmax;
-                }
-            if (o.kb > hmax) out_rect = GSR_RECT_EMPTY;
-        }
+    // Occlusion culling against the previous frame's depth horizons (k_blend.h, k_sum_work): a tile that went opaque at some
+    // depth needs nothing behind it.  A splat whose key lies beyond the horizon of EVERY tile its rect reaches (widened by the
+    // frame's dilation radius: the view moves between frames) is dropped here -- no colour, no record, no sorting, no binning.
+    // Every list therefore holds, for each of its tiles, all the splats in front of that tile's horizon; a tile that had to
+    // look further than its horizon reports the frame, which is then rendered again without culling (k_sum_work).
+    // (The pyramid is read through the cache: at most four gathers, usually of one or two lines.)
+    if (hpyr && out_rect != GSR_RECT_EMPTY) {
+        const int x0 = (int)(out_rect & 255u), y0 = (int)((out_rect >> 8) & 255u), x1 = (int)((out_rect >> 16) & 255u), y1 = (int)(out_rect >> 24);
+        const int r = f.cull_dilate;
+        const float h = gsr_pyr_max(hpyr, f.pyr_off, f.tiles_x, max(x0 - r, 0), max(y0 - r, 0), min(x1 + r, f.tiles_x - 1), min(y1 + r, f.tiles_y - 1));
+        if (o.kb > gsr_horizon_key(h, f.key_min, f.key_max)) out_rect = GSR_RECT_EMPTY;
     }
     if (out_rect != GSR_RECT_EMPTY) {
         // colour: Cd, optionally + SH (:224, :244-274) -- or left PENDING for the lazy colour pass (k_colour.h)
@@ -416,44 +410,62 @@ gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, co
     return out_rect;
 }
 
+// One wavefront per surviving cluster (k_cluster.h): workgroup-iteration k takes the clusters of rank 4k .. 4k+3 of
+// k_cluster_cull's ordered list, so its 256 slots are in storage order like the list itself.  The grid is sized from the
+// previous frame's survivor count (gsr_api.hip); a frame that keeps more simply loops.
 __global__ void __launch_bounds__(GSR_K1_THREADS)
 k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col,
              GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint2* __restrict__ val,
              float* __restrict__ zwin /* NULL unless the frame is depth-tested */, int lazy /* leave SH colours pending */,
-             const float* __restrict__ horizon /* [256] depth horizon (distance^2) per super-tile, or NULL: no occlusion culling */,
-             uint32_t* __restrict__ blk_cnt /* [workgroups] splats of each workgroup that stay */)
+             const float* __restrict__ hpyr /* depth-horizon pyramid, or NULL: no occlusion culling */,
+             uint32_t* __restrict__ blk_cnt /* [workgroup-iterations] splats of each that stay */,
+             const uint32_t* __restrict__ cseg, const uint32_t* __restrict__ ccnt, uint32_t ngroups, uint32_t cper /* k_cluster_cull's output */,
+             uint32_t* __restrict__ d_counts /* [0] = slots K1 filled (256 per workgroup-iteration), [1] = surviving clusters */)
 {
-    const uint32_t i = blockIdx.x * (uint32_t)GSR_K1_THREADS + threadIdx.x;
-    uint32_t out_rect = GSR_RECT_EMPTY, kb = 0;
-    if (i < n) {
-        // geoA and geoB are fetched together; colour only once the splat is known to be needed (fetching it up front
-        // was measured slower: the bytes wasted on culled splats cost more than the second round trip)
-        const float4 a = geoA[i];
-        const uint4 b = geoB[i];
-        const GsrK1Front o = gsr_k1_front(f, a, b, zwin ? zwin + i : nullptr);
-        if (o.keep && !o.far) out_rect = gsr_k1_back(f, i, cap, o, b, col, rec, lazy, horizon);
-        kb = o.kb;
-    }
-    // The keys and payloads of the splats that stay leave compacted PER WORKGROUP, in thread (= splat index) order, at the head
-    // of the workgroup's 256 slots, with their number in blk_cnt: the depth sort's first pass gathers those prefixes
-    // (k_sort.h, GATHER) instead of reading one key per splat -- after occlusion culling one splat in thirteen stays --
-    // and, being in index order, equal keys still leave the stable sort in index order.
-    __shared__ uint32_t s_wcnt[GSR_K1_THREADS / 64];
+    static_assert(GSR_K1_THREADS == 4 * GSR_CLUSTER, "a K1 workgroup is four clusters");
+    __shared__ uint32_t s_inc[CC_MAX_GROUPS];
+    __shared__ uint32_t s_wcnt[2][GSR_K1_THREADS / 64];
+    __shared__ uint32_t s_scan[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool stays = out_rect != GSR_RECT_EMPTY;
-    const unsigned long long bal = __ballot(stays);
-    if (lane == 0) s_wcnt[wave] = (uint32_t)__builtin_popcountll(bal);
-    __syncthreads();
-    uint32_t before = 0, total = 0;
+    const uint32_t nsurv = cc_prefix_to_lds(ccnt, ngroups, s_inc, s_scan);
+    const uint32_t niter = (nsurv + 3u) / 4u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d_counts[0] = niter * (uint32_t)GSR_K1_THREADS; d_counts[1] = nsurv; }
+    int par = 0;
+    for (uint32_t k = blockIdx.x; k < niter; k += gridDim.x, par ^= 1) {
+        const uint32_t rank = 4u * k + (uint32_t)wave;
+        uint32_t out_rect = GSR_RECT_EMPTY, kb = 0, i = 0;
+        if (rank < nsurv) {                                   // (wave-uniform)
+            const uint32_t cl = cc_find_cluster(s_inc, ngroups, rank, cseg, cper);
+            i = cl * (uint32_t)GSR_CLUSTER + (uint32_t)lane;
+            if (i < n) {
+                // geoA and geoB are fetched together; colour only once the splat is known to be needed (fetching it up front
+                // was measured slower: the bytes wasted on culled splats cost more than the second round trip)
+                const float4 a = geoA[i];
+                const uint4 b = geoB[i];
+                const GsrK1Front o = gsr_k1_front(f, a, b, zwin ? zwin + i : nullptr);
+                if (o.keep && !o.far) out_rect = gsr_k1_back(f, i, cap, o, b, col, rec, lazy, hpyr);
+                kb = o.kb;
+            }
+        }
+        // The keys and payloads of the splats that stay leave compacted PER WORKGROUP-ITERATION, in thread (= storage) order, at
+        // the head of its 256 slots, with their number in blk_cnt: the depth sort's first pass gathers those prefixes (k_sort.h,
+        // GATHER) instead of reading one key per splat, and, the slots being in storage order, equal keys leave the stable
+        // sort in storage order.
+        const bool stays = out_rect != GSR_RECT_EMPTY;
+        const unsigned long long bal = __ballot(stays);
+        if (lane == 0) s_wcnt[par][wave] = (uint32_t)__builtin_popcountll(bal);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < GSR_K1_THREADS / 64; ++w) { const uint32_t c = s_wcnt[w]; before += w < wave ? c : 0u; total += c; }
-    if (stays) {
-        const uint32_t pos = blockIdx.x * (uint32_t)GSR_K1_THREADS + before + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
-        key[pos] = kb;
-        val[pos] = make_uint2(i, out_rect);   // sort payload: splat index + tile rect
+        for (int w = 0; w < GSR_K1_THREADS / 64; ++w) { const uint32_t c = s_wcnt[par][w]; before += w < wave ? c : 0u; total += c; }
+        if (stays) {
+            const uint32_t pos = k * (uint32_t)GSR_K1_THREADS + before + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+            key[pos] = kb;
+            val[pos] = make_uint2(i, out_rect);   // sort payload: storage index + tile rect
+        }
+        if (threadIdx.x == 0) blk_cnt[k] = total;
     }
-    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = total;
 }
 
 // upload time: per-workgroup partial bounding boxes of the positions (finished on the host)

@@ -79,13 +79,15 @@ MISSING_CD, MISSING_OPACITY, MISSING_SCALE, MISSING_ORIENT, MISSING_SH, BAD_SH_O
 OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE, OPT_SUPER_TILE, OPT_DEBUG_FLAGS, OPT_FRAMES_IN_FLIGHT, OPT_DEFERRED_CHECK, OPT_LAZY_COLOUR, OPT_SHARD_LAYOUT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPT_OCCLUSION_CULL = 10
 OPT_TIMING_EVERY = 11
+OPT_CLUSTER_CULL = 12
+OPT_STORAGE_ORDER = 13
 
 # every symbol include/gsplat_hip.h and include/GSplatRenderer.h declare
 C_ABI_SYMBOLS = [
     "gsr_device_count", "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_version", "gsr_set_stream",
     "gsr_upload_begin", "gsr_upload_append", "gsr_upload_end", "gsr_upload_abort", "gsr_upload", "gsr_set_row_shard", "gsr_band_rows",
     "gsr_stitch_bands", "gsr_render", "gsr_render_depth", "gsr_render_wire", "gsr_synchronize", "gsr_get_stats", "gsr_stats_reset", "gsr_set_option",
-    "gsr_debug_read_records", "gsr_debug_read_depth_order", "gsr_debug_read_tile_lists", "gsr_debug_sort_pairs",
+    "gsr_debug_read_records", "gsr_debug_read_depth_order", "gsr_debug_read_storage_order", "gsr_debug_read_tile_lists", "gsr_debug_sort_pairs",
     "gsr_debug_read_tile_work",
     "gsr_multi_create", "gsr_multi_destroy", "gsr_multi_count", "gsr_multi_transport", "gsr_multi_context",
     "gsr_multi_set_stream", "gsr_multi_set_option", "gsr_multi_upload_begin", "gsr_multi_upload_append",
@@ -145,6 +147,7 @@ def load_library() -> C.CDLL:
     L.gsr_debug_read_records.argtypes = [vp, vp, i64]
     L.gsr_debug_read_depth_order.argtypes = [vp, vp, i64, C.POINTER(C.c_int64)]
     L.gsr_debug_read_tile_lists.argtypes = [vp, vp, vp, i64, vp, i64]
+    L.gsr_debug_read_storage_order.argtypes = [vp, vp, i64]
     L.gsr_debug_sort_pairs.argtypes = [vp, vp, vp, i64, i32]
     L.gsr_debug_read_tile_work.argtypes = [vp, vp, i64]
     # host shim wrappers
@@ -409,6 +412,13 @@ class Engine:
         cnt = C.c_int64()
         _check(self.L.gsr_debug_read_depth_order(self.h, out.ctypes.data, n, C.byref(cnt)))
         return out[:cnt.value]
+
+    def debug_storage_order(self, n: int) -> np.ndarray:
+        """perm[j] = upload index of the splat in storage slot j (Morton order of the positions by default): what breaks ties in
+        the depth sort"""
+        out = np.zeros(n, dtype=np.int32)
+        _check(self.L.gsr_debug_read_storage_order(self.h, out.ctypes.data, n))
+        return out
 
     def debug_tile_lists(self):
         """per-SUPER-tile [start, end) + the depth-ordered splat list of the last frame"""

@@ -257,6 +257,13 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        splat: 0 = never, 2 = always, 1 (default) = when it pays -- the kernels compare, every frame,
                                        what the colour pass would evaluate with what eager evaluation does (large dense clouds: yes;
                                        small or sparse ones: no).  Same pixels, bit for bit, in every mode. */
+#define GSR_OPT_CLUSTER_CULL    12   /* 1 (default) / 0: every frame starts by testing CLUSTERS of 64 spatially adjacent splats (their box + largest
+                                       extent) against the clip planes, the screen, this rank's band of tile rows and the depth
+                                       horizons; the per-splat stage runs over the surviving clusters only.  Conservative: same pixels. */
+#define GSR_OPT_STORAGE_ORDER   13   /* 1 (default) = the splats are stored in Morton order of their positions (takes effect at the next
+                                       upload), 0 = in upload order.  The storage order is what breaks ties in the depth sort (the
+                                       reference's own tie order is unspecified: unstable tbb::parallel_sort, src/GSplatRenderer.C:206-207);
+                                       gsr_debug_read_storage_order returns it. */
 int  gsr_set_option(gsr_context* ctx, int option, int value);
 
 /* ---- debug / test access (device -> host copies of intermediates) -------- */
@@ -270,6 +277,9 @@ int  gsr_debug_read_records(gsr_context* ctx, gsr_debug_record* out, int64_t n);
 /* depth order (nearest first) of the splats that survived culling in the last frame; writes min(cap, count)
  * indices and the count */
 int  gsr_debug_read_depth_order(gsr_context* ctx, int32_t* perm, int64_t cap, int64_t* n_sorted);
+/* the storage order of the uploaded splats: perm[j] = upload index of the splat in storage slot j (n = uploaded count).
+ * Equal sort keys leave the depth sort in this order. */
+int  gsr_debug_read_storage_order(gsr_context* ctx, int32_t* perm, int64_t n);
 /* per-SUPER-tile [start,end) into the sorted pair list + the list itself (splat indices);
  * n_lists = stiles_x*stiles_y, n_pairs = pairs_total of the last frame */
 int  gsr_debug_read_tile_lists(gsr_context* ctx, int32_t* list_start, int32_t* list_end, int64_t n_lists,

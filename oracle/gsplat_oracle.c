@@ -413,7 +413,10 @@ int gso_preprocess(const gso_splats* s, const gso_frame* f, gso_record* rec)
 /* stable LSD radix argsort on the IEEE bits of non-negative float keys.
  * The reference uses an unstable tbb::parallel_sort (src/GSplatRenderer.C:206)
  * whose tie order is unspecified; the contract fixes (key, index).          */
-static int argsort_keys(const float* keys, int64_t n, int32_t* perm)
+/* order0 (or NULL = index order): the order ties are left in -- the product stores the splats in an upload-time
+ * order of its own (Morton order of the positions) and its stable sort breaks ties by that STORAGE order; a test
+ * that compares depth orders index for index hands the storage order in.                                       */
+static int argsort_keys_from(const float* keys, int64_t n, int32_t* perm, const int32_t* order0)
 {
     uint32_t* k0 = (uint32_t*)malloc((size_t)n * 4 + 4);
     uint32_t* k1 = (uint32_t*)malloc((size_t)n * 4 + 4);
@@ -425,8 +428,13 @@ static int argsort_keys(const float* keys, int64_t n, int32_t* perm)
         /* keys are sums of squares: >= +0 or NaN; map to an order-preserving
          * uint (general form, handles -0 too) */
         b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-        k0[i] = b;
-        perm[i] = (int32_t)i;
+        k1[i] = b;
+    }
+    for (int64_t j = 0; j < n; ++j) {
+        const int32_t i = order0 ? order0[j] : (int32_t)j;
+        if (i < 0 || (int64_t)i >= n) { free(k0); free(k1); free(p1); return -1; }
+        k0[j] = k1[i];
+        perm[j] = i;
     }
     uint32_t* ks = k0; uint32_t* kd = k1;
     int32_t* ps = perm; int32_t* pd = p1;
@@ -449,17 +457,113 @@ static int argsort_keys(const float* keys, int64_t n, int32_t* perm)
     return 0;
 }
 
-int gso_argsort(const gso_record* rec, int64_t n, int32_t* perm)
+int gso_argsort_from(const gso_record* rec, int64_t n, const int32_t* order0, int32_t* perm);
+/* ------------------------------------------------------------------------- */
+/* Tie order.  The reference's tbb::parallel_sort is unstable (src/GSplatRenderer.C:206-207): which of two splats at
+ * exactly the same distance is drawn first is unspecified there.  The contract fixes it: equal keys are drawn in STORAGE
+ * ORDER, and the storage order is the stable order of the 30-bit Morton codes of the positions, quantised to 10 bits per
+ * axis inside the bounding box of the cloud (upload order if a position is not finite, or by request).  The product
+ * stores its splats in that order (k_cluster.h); this is the independent restatement.                              */
+static int g_tie_upload_order = 0;
+void gso_set_tie_order(int upload_order) { g_tie_upload_order = upload_order ? 1 : 0; }
+
+static uint32_t spread10(uint32_t v)
+{
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+int gso_storage_order(const float* P, int64_t n, int32_t* order)
+{
+    if (!order || (n > 0 && !P)) return -1;
+    for (int64_t i = 0; i < n; ++i) order[i] = (int32_t)i;
+    if (g_tie_upload_order || n < 2) return 0;
+    double lo[3] = {3.0e38, 3.0e38, 3.0e38}, hi[3] = {-3.0e38, -3.0e38, -3.0e38};
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const float v = P[3 * i + k];
+            if (!(fabsf(v) < 3.0e38f)) return 0;          /* inf / NaN: upload order */
+            if (v < lo[k]) lo[k] = v;
+            if (v > hi[k]) hi[k] = v;
+        }
+    float flo[3], fsc[3];
+    for (int k = 0; k < 3; ++k) {
+        const double ext = hi[k] - lo[k];
+        flo[k] = (float)lo[k];
+        fsc[k] = ext > 0.0 ? (float)(1023.999 / ext) : 0.0f;
+        if (!(fabsf(fsc[k]) < 3.0e38f)) fsc[k] = 0.0f;
+    }
+    uint32_t* code = (uint32_t*)malloc((size_t)n * 4 + 4);
+    uint32_t* c1 = (uint32_t*)malloc((size_t)n * 4 + 4);
+    int32_t* o1 = (int32_t*)malloc((size_t)n * 4 + 4);
+    if (!code || !c1 || !o1) { free(code); free(c1); free(o1); return -2; }
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t q[3];
+        for (int k = 0; k < 3; ++k) {
+            float t = (P[3 * i + k] - flo[k]) * fsc[k];
+            t = fminf(fmaxf(t, 0.0f), 1023.0f);
+            q[k] = (uint32_t)t;
+        }
+        code[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    }
+    /* stable LSD radix sort of (code, index), 4 x 8 bits */
+    uint32_t* ks = code; uint32_t* kd = c1;
+    int32_t* ps = order; int32_t* pd = o1;
+    for (int pass = 0; pass < 4; ++pass) {
+        int64_t cnt[257];
+        memset(cnt, 0, sizeof(cnt));
+        const int sh = pass * 8;
+        for (int64_t i = 0; i < n; ++i) ++cnt[((ks[i] >> sh) & 255u) + 1];
+        for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t dst = cnt[(ks[i] >> sh) & 255u]++;
+            kd[dst] = ks[i];
+            pd[dst] = ps[i];
+        }
+        uint32_t* tk = ks; ks = kd; kd = tk;
+        int32_t* tp = ps; ps = pd; pd = tp;
+    }
+    free(code); free(c1); free(o1);
+    return 0;
+}
+
+/* argsort of the records' keys, ties in the storage order of the positions P */
+static int argsort_records(const gso_record* rec, const float* P, int64_t n, int32_t* perm)
+{
+    int32_t* order = (int32_t*)malloc((size_t)n * 4 + 4);
+    if (!order) return -2;
+    int rc = gso_storage_order(P, n, order);
+    if (!rc) rc = gso_argsort_from(rec, n, order, perm);
+    free(order);
+    return rc;
+}
+
+int gso_argsort_from(const gso_record* rec, int64_t n, const int32_t* order0, int32_t* perm)
 {
     float* keys = (float*)malloc((size_t)n * 4 + 4);
     if (!keys) return -2;
     for (int64_t i = 0; i < n; ++i) keys[i] = rec[i].key;
-    int rc = argsort_keys(keys, n, perm);
+    int rc = argsort_keys_from(keys, n, perm, order0);
     free(keys);
     return rc;
 }
 
+int gso_argsort(const gso_record* rec, int64_t n, int32_t* perm) { return gso_argsort_from(rec, n, (const int32_t*)0, perm); }
+
 int gso_host_sort_only(const float* P, int64_t n, const float cam_pos[3], int32_t* perm)
+{
+    int32_t* order = (int32_t*)malloc((size_t)n * 4 + 4);
+    if (!order) return -2;
+    int rc = gso_storage_order(P, n, order);
+    if (!rc) rc = gso_host_sort_from(P, n, cam_pos, order, perm);
+    free(order);
+    return rc;
+}
+
+int gso_host_sort_from(const float* P, int64_t n, const float cam_pos[3], const int32_t* order0, int32_t* perm)
 {
     float* keys = (float*)malloc((size_t)n * 4 + 4);
     if (!keys) return -2;
@@ -468,7 +572,7 @@ int gso_host_sort_only(const float* P, int64_t n, const float cam_pos[3], int32_
         float dx = P[3 * i] - cam_pos[0], dy = P[3 * i + 1] - cam_pos[1], dz = P[3 * i + 2] - cam_pos[2];
         keys[i] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     }
-    int rc = argsort_keys(keys, n, perm);
+    int rc = argsort_keys_from(keys, n, perm, order0);
     free(keys);
     return rc;
 }
@@ -582,7 +686,7 @@ int gso_render_depth(const gso_splats* s, const gso_frame* f, const float* depth
     int32_t* perm = (int32_t*)malloc((size_t)(s->n + 1) * 4);
     if (!rec || !perm) { free(rec); free(perm); return -2; }
     int rc = gso_preprocess(s, f, rec);
-    if (!rc) rc = gso_argsort(rec, s->n, perm);
+    if (!rc) rc = argsort_records(rec, s->P, s->n, perm);
     if (!rc) rc = gso_blend_serial_depth(rec, perm, s->n, f->width, f->height, depth, rgba);
     free(rec);
     free(perm);
@@ -666,7 +770,7 @@ int gso_render_rows(const gso_splats* s, const gso_frame* f, int row_lo, int row
     int32_t* perm = (int32_t*)malloc((size_t)(s->n + 1) * 4);
     if (!rec || !perm) { free(rec); free(perm); return -2; }
     int rc = gso_preprocess(s, f, rec);
-    if (!rc) rc = gso_argsort(rec, s->n, perm);
+    if (!rc) rc = argsort_records(rec, s->P, s->n, perm);
     if (!rc) rc = blend_parallel_rows(rec, perm, s->n, f->width, f->height, row_lo, row_hi, rgba, threads);
     free(rec);
     free(perm);
@@ -680,7 +784,7 @@ int gso_render(const gso_splats* s, const gso_frame* f, float* rgba, int threads
     int32_t* perm = (int32_t*)malloc((size_t)(s->n + 1) * 4);
     if (!rec || !perm) { free(rec); free(perm); return -2; }
     int rc = gso_preprocess(s, f, rec);
-    if (!rc) rc = gso_argsort(rec, s->n, perm);
+    if (!rc) rc = argsort_records(rec, s->P, s->n, perm);
     if (!rc) {
         if (threads > 1)
             rc = gso_blend_parallel(rec, perm, s->n, f->width, f->height, rgba, threads);

@@ -109,8 +109,18 @@ unsigned gso_closest_sqrt_power_of_2(int n);      /* src/GSplatRenderer.C:155-16
 /* vertex stage for all splats; rec[n] */
 int gso_preprocess(const gso_splats* s, const gso_frame* f, gso_record* rec);
 
-/* stable ascending argsort of rec[i].key over ALL n splats (ties: lower index first) */
+/* Tie order of the contract (the reference's own is unspecified: unstable tbb::parallel_sort, src/GSplatRenderer.C:206-207):
+ * equal keys are drawn in STORAGE ORDER = the stable order of the 30-bit Morton codes of the positions (10 bits per axis
+ * inside the cloud's bounding box); upload order when a position is not finite.  order[j] = index of the j-th splat.
+ * gso_set_tie_order(1) makes the storage order the upload order (the product's GSR_OPT_STORAGE_ORDER = 0).  Every whole-
+ * frame entry point below (gso_render*, gso_host_sort_only) sorts with it. */
+int gso_storage_order(const float* P, int64_t n, int32_t* order);
+void gso_set_tie_order(int upload_order);
+
+/* stable ascending argsort of rec[i].key over ALL n splats; ties: lower index first (gso_argsort), or left in the order of
+ * order0[], a permutation of 0..n-1 (gso_argsort_from; NULL = index order) */
 int gso_argsort(const gso_record* rec, int64_t n, int32_t* perm);
+int gso_argsort_from(const gso_record* rec, int64_t n, const int32_t* order0, int32_t* perm);
 
 /* fragment + blend stage, literal serial form.  rgba = float[height*width*4],
  * premultiplied, row 0 = bottom row (GL window coords), cleared to 0 first. */
@@ -139,8 +149,9 @@ int gso_render(const gso_splats* s, const gso_frame* f, float* rgba, int threads
 int gso_render_rows(const gso_splats* s, const gso_frame* f, int row_lo, int row_hi, float* rgba, int threads);
 
 /* only the reference's per-camera-move HOST work: distances + argsort
- * (src/GSplatRenderer.C:188-208).  perm[n] out. */
+ * (src/GSplatRenderer.C:188-208).  perm[n] out.  Ties in storage order (gso_host_sort_only) / in the order of order0. */
 int gso_host_sort_only(const float* P, int64_t n, const float cam_pos[3], int32_t* perm);
+int gso_host_sort_from(const float* P, int64_t n, const float cam_pos[3], const int32_t* order0, int32_t* perm);
 
 /* number of OpenMP threads the parallel entry points would use */
 int gso_max_threads(void);

@@ -87,6 +87,8 @@ def lib() -> C.CDLL:
         L.gso_closest_sqrt_power_of_2.argtypes = [C.c_int]
         L.gso_preprocess.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p]
         L.gso_argsort.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.gso_argsort_from.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.gso_host_sort_from.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
         L.gso_blend_serial.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         L.gso_blend_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.gso_render.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p, C.c_int]
@@ -95,6 +97,9 @@ def lib() -> C.CDLL:
         L.gso_render_wire.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p]
         L.gso_host_sort_only.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p]
         L.gso_max_threads.restype = C.c_int
+        L.gso_storage_order.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.gso_set_tie_order.argtypes = [C.c_int]
+        L.gso_set_tie_order.restype = None
         _lib = L
     return _lib
 
@@ -156,10 +161,12 @@ def preprocess(splats, cam, origin=(0, 0, 0)) -> np.ndarray:
     return rec
 
 
-def argsort(rec: np.ndarray) -> np.ndarray:
+def argsort(rec: np.ndarray, order0=None) -> np.ndarray:
+    """stable ascending argsort of the keys; ties stay in the order of ``order0`` (a permutation; None = index order)"""
     rec = np.ascontiguousarray(rec)
     perm = np.zeros(rec.shape[0], dtype=np.int32)
-    rc = lib().gso_argsort(rec.ctypes.data, rec.shape[0], perm.ctypes.data)
+    o = None if order0 is None else np.ascontiguousarray(order0, dtype=np.int32)
+    rc = lib().gso_argsort_from(rec.ctypes.data, rec.shape[0], None if o is None else o.ctypes.data, perm.ctypes.data)
     assert rc == 0
     return perm
 
@@ -219,11 +226,30 @@ def render_wire(splats, cam) -> np.ndarray:
     return out
 
 
-def host_sort_only(P, cam_pos) -> np.ndarray:
+def storage_order(P) -> np.ndarray:
+    """the contract's tie order: order[j] = index of the j-th splat in Morton order of the positions (see gsplat_oracle.h)"""
+    P = _c(P, np.float32).reshape(-1, 3)
+    order = np.zeros(P.shape[0], dtype=np.int32)
+    rc = lib().gso_storage_order(P.ctypes.data, P.shape[0], order.ctypes.data)
+    assert rc == 0
+    return order
+
+
+def set_tie_order(upload_order: bool):
+    """True: ties in upload order (the product's GSR_OPT_STORAGE_ORDER = 0); False (default): in Morton storage order"""
+    lib().gso_set_tie_order(int(bool(upload_order)))
+
+
+def host_sort_only(P, cam_pos, order0=None) -> np.ndarray:
+    """(distance^2, tie order) ascending; order0 None = the contract's storage order"""
     P = _c(P, np.float32).reshape(-1, 3)
     perm = np.zeros(P.shape[0], dtype=np.int32)
     cp = (C.c_float * 3)(*np.asarray(cam_pos, dtype=np.float32).tolist())
-    rc = lib().gso_host_sort_only(P.ctypes.data, P.shape[0], cp, perm.ctypes.data)
+    if order0 is None:
+        rc = lib().gso_host_sort_only(P.ctypes.data, P.shape[0], cp, perm.ctypes.data)
+    else:
+        o = np.ascontiguousarray(order0, dtype=np.int32)
+        rc = lib().gso_host_sort_from(P.ctypes.data, P.shape[0], cp, o.ctypes.data, perm.ctypes.data)
     assert rc == 0
     return perm
 

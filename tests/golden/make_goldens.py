@@ -625,6 +625,19 @@ def refresh_oracle_sha():
         arrays = {k: d[k] for k in d.files}
         arrays["oracle_sha256"] = np.frombuffer(hashlib.sha256(img.tobytes()).digest(), dtype=np.uint8)
         np.savez_compressed(path, **arrays)
+    # the band of the full BASELINE C4 frame (the fixture holds only the reference image; inputs come from the seeded generator)
+    path = os.path.join(HERE, "c4_band_1080p.npz")
+    if os.path.exists(path):
+        pkg = ge.load_package()
+        d = np.load(path)
+        splats, cfg = pkg.scenes.make_config("C4")
+        cam = pkg.camera.make_camera(cfg["width"], cfg["height"], sh_order=3, frame=int(d["frame"]))
+        y0, y1 = [int(v) for v in d["rows"]]
+        band = oracle.render_rows(splats, cam, y0, y1)
+        print("c4_band_1080p", helpers.check_against_golden(band, d["band_reference_glsl"]))
+        arrays = {k: d[k] for k in d.files}
+        arrays["oracle_band_sha256"] = np.frombuffer(hashlib.sha256(band.tobytes()).digest(), dtype=np.uint8)
+        np.savez_compressed(path, **arrays)
 
 
 def main():

@@ -67,7 +67,11 @@ def test_depth_order_matches_oracle(pkg, oracle, engine):
     engine.upload(splats)
     engine.render(cam)
     dev = engine.debug_depth_order(splats.n)          # the splats that survived culling, nearest first
-    ref = oracle.host_sort_only(splats.P, cam.cam_pos)  # all splats, (distance^2, index) ascending
+    # ties are broken by the storage order: the Morton order of the positions, which the oracle restates independently
+    order0 = engine.debug_storage_order(splats.n)
+    assert sorted(order0.tolist()) == list(range(splats.n)) and not np.array_equal(order0, np.arange(splats.n))
+    assert np.array_equal(order0, oracle.storage_order(splats.P))
+    ref = oracle.host_sort_only(splats.P, cam.cam_pos)  # all splats, (distance^2, storage position) ascending
     assert dev.shape[0] > 0.9 * splats.n
     keep = np.zeros(splats.n, bool)
     keep[dev] = True
@@ -119,7 +123,7 @@ def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine, n,
     S, sx = st["super_tile"], st["stiles_x"]
     assert ls.shape[0] == st["stiles_x"] * st["stiles_y"] <= 256 and st["pairs_total"] == pv.shape[0]
     rec = oracle.preprocess(splats, cam)
-    perm = oracle.argsort(rec)
+    perm = oracle.argsort(rec, oracle.storage_order(splats.P))
     rank = np.empty(splats.n, np.int64)
     rank[perm] = np.arange(splats.n)
     # expected membership from the (device-identical) pixel bbox -> tile rect
@@ -883,6 +887,57 @@ def test_occlusion_culling_random_walk(pkg, seed):
             assert np.array_equal(eng.render(cam), ref.render(cam)), f"step {step}: frame {frame}, distance {dist}, {size}, SH {order}"
         st = eng.stats()
         assert st["frames_culled"] >= 10, st          # (culling was really exercised, and some horizons really broke)
+    finally:
+        ref.close(); eng.close()
+
+
+def test_cluster_culling_and_storage_order_are_invisible(pkg, oracle):
+    """k_cluster.h: the splats are stored in Morton order and every frame starts by culling clusters of 64 of them (clip
+    planes, screen, band, depth horizons).  The cluster stage may not change a pixel: frames with it switched off
+    (GSR_OPT_CLUSTER_CULL = 0) are bit-identical, sharded and with occlusion culling on top too, and without occlusion culling
+    exactly the same splats reach the depth sort.  The storage order (GSR_OPT_STORAGE_ORDER) only decides the order of splats at
+    exactly the same distance, as the oracle's tie order does: each order matches the oracle told the same."""
+    splats = pkg.scenes.make_scene(300000, seed=77, sh=True, radius=1.0)
+    w, h = 800, 450
+    cams = [pkg.camera.make_camera(w, h, sh_order=3, frame=i) for i in (0, 1, 2, 3)]
+    cams += [pkg.camera.make_camera(w, h, sh_order=3, frame=7, distance=d) for d in (0.3, 0.9, 1.6, 8.0)]   # inside the cloud, ..., far away
+    cams += [pkg.camera.make_camera(w, h, sh_order=3, frame=9, distance=2.5, pivot=(1.5, 0.4, 0.0))]          # most of the cloud off screen
+    ref = pkg.Engine(0)
+    eng = pkg.Engine(0)
+    try:
+        for storage in (1, 0):
+            for e in (ref, eng):
+                e.set_row_shard(0, 1)
+                e.set_option(pkg.engine.OPT_STORAGE_ORDER, storage)
+                e.upload(splats)
+            ref.set_option(pkg.engine.OPT_CLUSTER_CULL, 0)
+            ref.set_option(pkg.engine.OPT_OCCLUSION_CULL, 0)
+            order0 = eng.debug_storage_order(splats.n)
+            oracle.set_tie_order(storage == 0)
+            try:
+                assert np.array_equal(order0, oracle.storage_order(splats.P))
+                assert np.array_equal(order0, np.arange(splats.n)) == (storage == 0)
+                want, vis = [], []
+                for c in cams:
+                    want.append(ref.render(c).copy())
+                    vis.append(ref.stats()["n_visible"])
+                _check_image(want[0], oracle.render(splats, cams[0], threads=oracle.max_threads()))
+            finally:
+                oracle.set_tie_order(False)
+            for cull in (0, 2):
+                eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, cull)
+                for k, (c, img) in enumerate(zip(cams, want)):
+                    assert np.array_equal(eng.render(c), img), f"storage {storage}, occlusion culling {cull}: frame {k} differs"
+                    if cull == 0:
+                        assert eng.stats()["n_visible"] == vis[k]
+            # a row shard on top (band layout: clusters outside the band are culled as a whole)
+            for e in (ref, eng):
+                e.set_option(pkg.engine.OPT_SHARD_LAYOUT, 1)
+                e.set_row_shard(1, 3)
+            for k, c in enumerate(cams[:5]):
+                assert np.array_equal(eng.render(c), ref.render(c)), f"storage {storage}, band 1/3: frame {k} differs"
+            for e in (ref, eng):
+                e.set_option(pkg.engine.OPT_SHARD_LAYOUT, 0)
     finally:
         ref.close(); eng.close()
 

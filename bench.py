@@ -61,6 +61,9 @@ def parse_args():
                     "0 = min(8, steps / 16), so that at least 16 launches are timed "
                     "(each pair idles the queue ~12 us; the roofline's launch time is the mean over the sampled launches)")
     ap.add_argument("--cull", type=int, default=1, help="0 = no occlusion culling against the previous frame's depth horizons (A/B)")
+    ap.add_argument("--cluster-cull", type=int, default=1, help="0 = no cluster culling in front of K1 (A/B)")
+    ap.add_argument("--storage-order", type=int, default=1, help="0 = splats stored in upload order instead of Morton order (A/B)")
+    ap.add_argument("--dilate", type=int, default=-1, help="GSR_OPT_CULL_DILATE (A/B; -1 = library default)")
     ap.add_argument("--tile-order", type=int, default=2, help="1 = XCD-aware static tile order, 2 = + heaviest tiles first (A/B)")
     ap.add_argument("--super-tile", type=int, default=0, help="super-tile edge in tiles (0 = auto) (A/B)")
     ap.add_argument("--flags", type=int, default=0, help="GSR_OPT_DEBUG_FLAGS (A/B)")
@@ -87,6 +90,9 @@ def parse_args():
                          "kernels find that it pays; 2 = always; 0 = eager (A/B)")
     ap.add_argument("--torch-gather", action="store_true",
                     help="N>1: gather with torch.distributed (multigpu.FrameGatherer) instead of the in-library RCCL gather")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="run ONLY the warm-up and the timed region (no per-stage leg, no culling-off leg, no pipelined leg): what a "
+                         "rocprofv3 run should see, so that its per-kernel averages describe one regime")
     ap.add_argument("--verify", action="store_true",
                     help="N>1: also render the last frame unsharded on rank 0 and require the stitched frame to be bit-identical")
     return ap.parse_args()
@@ -196,6 +202,10 @@ def main():
     torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
     eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, args.cull)
+    eng.set_option(pkg.engine.OPT_CLUSTER_CULL, args.cluster_cull)
+    if args.dilate >= 0:
+        eng.set_option(pkg.engine.OPT_CULL_DILATE, args.dilate)
+    eng.set_option(pkg.engine.OPT_STORAGE_ORDER, args.storage_order)
     eng.set_option(pkg.engine.OPT_TIMING_EVERY, args.time_every if args.time_every > 0 else max(1, min(8, args.steps // 16)))
     eng.set_option(pkg.engine.OPT_XCD_SWIZZLE, 0 if args.no_swizzle else args.tile_order)
     eng.set_option(pkg.engine.OPT_SUPER_TILE, args.super_tile)
@@ -313,18 +323,20 @@ def main():
     st = eng.stats()
     # extra leg (untimed, informational): a few more frames with HIP events around EVERY stage -> per-stage breakdown and the
     # k_preprocess / k_colour_prefix durations.  Kept out of the timed region: six extra events per frame stall the queue ~35 us.
-    eng.set_option(pkg.engine.OPT_STAGE_TIMING, 2)
-    eng.stats_reset()
-    for i in range(min(10, args.warmup + args.steps)):
-        step(i)
-    torch.cuda.synchronize()
-    st_stage = eng.stats()
-    eng.set_option(pkg.engine.OPT_STAGE_TIMING, args.stage_timing)
+    st_stage = None
+    if not args.no_extra_legs:
+        eng.set_option(pkg.engine.OPT_STAGE_TIMING, 2)
+        eng.stats_reset()
+        for i in range(min(10, args.warmup + args.steps)):
+            step(i)
+        torch.cuda.synchronize()
+        st_stage = eng.stats()
+        eng.set_option(pkg.engine.OPT_STAGE_TIMING, args.stage_timing)
     if world > 1:
         dist.barrier()
     # extra leg (informational, single GPU): the same frames with occlusion culling switched off
     unculled = None
-    if world == 1 and args.cull:
+    if world == 1 and args.cull and not args.no_extra_legs:
         eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, 0)
         for i in range(min(5, args.warmup + args.steps)):
             step(i)
@@ -339,7 +351,7 @@ def main():
         eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, args.cull)
     # extra leg (informational): the same K steps with two frames in flight
     pipelined = None
-    if args.pipelined and args.frames_in_flight == 1:
+    if args.pipelined and args.frames_in_flight == 1 and not args.no_extra_legs:
         eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, 2)
         for i in range(args.warmup):
             step(i)
@@ -425,14 +437,14 @@ def main():
                         "flop_per_pixel_eval": FLOP_PER_EVAL, "inner_loop_iteration_ns": iter_ns,
                         "inner_loop_issue_bound_ms": issue_ms, "inner_loop_issue_frac": issue_ms / blend_ms if blend_ms > 0 else 0.0,
                         "note": "issue bound = inner-loop instruction mix x issue intervals measured with tools/ubench_valu.hip"}
-    stages = {k: st_stage[k] for k in ("ms_preprocess", "ms_depth_sort", "ms_emit", "ms_tile_sort", "ms_blend", "ms_total")}
+    stages = {k: st_stage[k] for k in ("ms_preprocess", "ms_depth_sort", "ms_emit", "ms_tile_sort", "ms_blend", "ms_total")} if st_stage else {}
     stages["note"] = ("one frame of the extra leg with events around every stage: ms_emit = binning count+scans, ms_tile_sort = "
                       "binning placement + lazy colour pass")
     # the kernel next to it: k_preprocess (stage 0 of the frame is exactly this one kernel).  Algorithmic bytes per splat at SH
     # order 3: 32 (geometry) read by every splat; one that stays also reads 96 (colour; eager mode only) and writes 48 (record)
     # + 12 (key, payload, compacted per workgroup); a dropped one writes nothing
     roofline_k1 = None
-    if st_stage["stage_frames"] > 0 and world == 1:
+    if st_stage and st_stage["stage_frames"] > 0 and world == 1:
         k1_ms = st_stage["stage_ms_total"][0] / st_stage["stage_frames"]
         nvis = st_stage["n_visible"]
         lazy_on = st_stage["lazy_colours_total"] > 0
@@ -476,6 +488,7 @@ def main():
             "roofline_preprocess": roofline_k1,
             "stages_ms_last_frame": stages,
             "n_visible": st["n_visible"],
+            "cluster_culling": {"clusters": st["clusters_total"], "kept_last_frame": st["clusters_kept"], "splats_per_cluster": 64},
             "lazy_colour": {"mode": args.lazy, "active": st["lazy_colours_total"] > 0, "colours_evaluated_per_frame": st["lazy_colours_total"] / max(1, st["frames"]),
                             "visible_splats": st["n_visible"],
                             "fallback_tiles_last_frame": st["lazy_redo_tiles"]},

@@ -131,6 +131,8 @@ struct FrameSlot {
     size_t order_cap = 0;              //   for this slot's next frame (valid while the tile geometry stays what it was)
     bool order_valid = false;
     int order_sig[6] = {0, 0, 0, 0, 0, 0}, order_per_xcd = 0;
+    uint32_t* st_scan = nullptr;       // [512] per super-tile: deepest scan of its opaque tiles / "a tile stayed open" (k_tile_pass -> k_sum_work)
+    GsrTilePartial* partial = nullptr; // [4096] per 8x8-tile block: partial sums of the frame's counters (k_tile_pass -> k_sum_work)
     uint32_t* sup_work = nullptr;      // [2][256] per-super-tile work sums of the blend kernel, by frame parity
     int sup_par = 0;
     // Depth horizons (occlusion culling): per TILE, the distance^2 beyond which this slot's NEXT frame needs nothing -- a max
@@ -229,6 +231,7 @@ struct gsr_context {
     bool cull_pays = false;            // ... and its third: most super-tile lists have a depth horizon (occlusion culling)
     int cull_holdoff = 0, cull_backoff = 8, cull_streak = 0;   // frames without culling after a broken horizon (x4 each time, <= 1024; back to 8 after 64 good frames)
     int cull_dilate = 2;               // tiles by which rects are widened before they are compared with the horizons (grows when horizons break)
+    int opt_dilate = 2;                // ... its starting (and smallest) value
     bool order_pays = false;           // k_sum_work's other verdict: the tiles differ enough in work for k_tile_order to pay
     unsigned long long* wire_zbuf = nullptr;   // wireframe overlay: (depth bits, splat index) per pixel ...
     float* wire_out = nullptr;                 // ... and the image staged for a host target
@@ -319,6 +322,9 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_end), sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
     if (ok) sl.h_end[0] = 0ull;
     ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_end_dev), sl.h_end, 0) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.st_scan), 512 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(sl.st_scan, 0, 512 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.partial), 4096 * sizeof(GsrTilePartial)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.sup_work), 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.sup_work, 0, 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), 4 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
@@ -350,7 +356,7 @@ static void slot_destroy(FrameSlot& sl)
     dev_free(sl.hist); dev_free(sl.totals);
     dev_free(sl.pvA);
     dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.fb);
-    dev_free(sl.hpyr2[0]); dev_free(sl.hpyr2[1]); dev_free(sl.ccnt); dev_free(sl.d_counts);
+    dev_free(sl.hpyr2[0]); dev_free(sl.hpyr2[1]); dev_free(sl.ccnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
     if (sl.h_end) (void)hipHostFree(sl.h_end); dev_free(sl.depth_stage);
     dev_free(sl.redo); dev_free(sl.lazy_ctr); dev_free(sl.colour_evals);
     dev_free(sl.counters); dev_free(sl.d_n);
@@ -452,6 +458,7 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
     case GSR_OPT_LAZY_COLOUR: c->opt_lazy = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_SHARD_LAYOUT: c->shard_layout = value ? 1 : 0; break;
     case GSR_OPT_CLUSTER_CULL: c->opt_cluster = value ? 1 : 0; break;
+    case GSR_OPT_CULL_DILATE: c->opt_dilate = value < 0 ? 0 : (value > 64 ? 64 : value); c->cull_dilate = c->opt_dilate; break;
     case GSR_OPT_STORAGE_ORDER: c->opt_morton = value ? 1 : 0; break;   // (takes effect at the next upload)
     case GSR_OPT_SUPER_TILE:
         if (value != 0 && (value < 1 || value > 16 || (value & (value - 1))))
@@ -616,7 +623,7 @@ extern "C" int gsr_upload_end(gsr_context* c)
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
     c->prefix_valid = false;           // lazy colour: the first frame of a new cloud colours every list completely
     c->order_pays = false;
-    c->cull_pays = false; c->cull_holdoff = 0; c->cull_backoff = 8; c->cull_streak = 0; c->vis_unculled = 0; c->cull_dilate = 2;
+    c->cull_pays = false; c->cull_holdoff = 0; c->cull_backoff = 8; c->cull_streak = 0; c->vis_unculled = 0; c->cull_dilate = c->opt_dilate;
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) { c->slot[k].surv_hint = 0; c->slot[k].horizon_valid = false; }
     c->lazy_pays = false;              // ... and in automatic mode the first frames are eager until the kernels say it pays
     c->st.n_splats = c->n;
@@ -908,11 +915,15 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
     f->super = 1 << shift;
     f->stiles_x = ((f->tiles_x - 1) >> shift) + 1;
     f->stiles_y = ((f->tiles_y - 1) >> shift) + 1;
-    int off = 0;
-    for (int l = 0; l < GSR_PYR_LEVELS; ++l) {
+    int off = 0, levels = 0;
+    for (int l = 0; l < GSR_PYR_MAX_LEVELS; ++l) {
         f->pyr_off[l] = off;
-        off += gsr_pyr_dim(f->tiles_x, l) * gsr_pyr_dim(f->tiles_y, l);
+        if (levels == 0) {
+            off += gsr_pyr_dim(f->tiles_x, l) * gsr_pyr_dim(f->tiles_y, l);
+            if (gsr_pyr_dim(f->tiles_x, l) == 1 && gsr_pyr_dim(f->tiles_y, l) == 1) levels = l + 1;   // the top: one cell
+        }
     }
+    f->pyr_levels = levels ? levels : GSR_PYR_MAX_LEVELS;
     f->cull_dilate = c->cull_dilate;
 }
 
@@ -1091,15 +1102,18 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     // A deferred frame (handed over before its pair count was known) never culls and may have clamped lists: no horizons from it.
     if (c->opt_cull && j.n > 0 && !j.deferred && (c->opt_cull >= 2 || j.cull || (c->vis_unculled >= 300000u && c->cull_holdoff <= 2))) {
         hz.pyr = sl.hpyr2[sl.hpyr_cur ^ 1]; hz.pyr_in = sl.hpyr2[sl.hpyr_cur]; hz.dilate = j.f.cull_dilate; hz.culled = j.cull ? 1 : 0; hz.fallback_skipped = (j.cull && j.lazy) ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
-        for (int l = 0; l < GSR_PYR_LEVELS; ++l) hz.pyr_off[l] = j.f.pyr_off[l];
+        for (int l = 0; l < GSR_PYR_MAX_LEVELS; ++l) hz.pyr_off[l] = j.f.pyr_off[l];
+        hz.pyr_levels = j.f.pyr_levels;
         hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
         hz.host_end = j.cull ? sl.h_end_dev : nullptr; hz.ticket = j.ticket;
     }
-    hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.tile_work, g, sl.counters, sl.d_n, sl.d_frame,
+    const int nblocks8 = ((j.f.tiles_x + 7) >> 3) * ((j.f.tiles_y + 7) >> 3);
+    hipLaunchKernelGGL(k_tile_pass, dim3((unsigned)nblocks8), dim3(64), 0, s, sl.tile_work, g, sl.sstart, sl.send, hz, sl.partial, sl.st_scan);
+    hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.partial, nblocks8, g, sl.counters, sl.d_n, sl.d_frame,
                        (j.f.sh_order > 0 && c->opt_lazy) ? c->prefix : (uint32_t*)nullptr,
                        j.lazy ? reinterpret_cast<const uint32_t*>(sl.lazy_ctr) : (const uint32_t*)nullptr,
                        sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint,
-                       sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr, hz);
+                       sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr, hz, sl.st_scan);
     HIP_TRY(hipGetLastError());
     sl.horizon_valid = hz.pyr != nullptr;
     if (sl.horizon_valid) {
@@ -1472,7 +1486,7 @@ static int frame_check(gsr_context* c, FrameSlot& slot, const gsr_camera* cam, c
     int rc = frame_verdict(c, slot, &broke);
     if (rc) return rc;
     if (!broke) {
-        if (++c->cull_streak >= 64) { c->cull_streak = 0; c->cull_backoff = 8; if (c->cull_dilate > 2) c->cull_dilate -= 1; }
+        if (++c->cull_streak >= 64) { c->cull_streak = 0; c->cull_backoff = 8; if (c->cull_dilate > c->opt_dilate) c->cull_dilate -= 1; }
 #ifdef GSR_HOST_TIMING
         g_t_verdict = now_us();
 #endif
@@ -1481,7 +1495,7 @@ static int frame_check(gsr_context* c, FrameSlot& slot, const gsr_camera* cam, c
     c->st.frames_repaired += 1;
     c->cull_holdoff = std::max(c->cull_holdoff, c->cull_backoff);   // the view is changing faster than the horizons follow: leave it alone for a while
     c->cull_backoff = c->cull_backoff >= 256 ? 1024 : 4 * c->cull_backoff;   // 8, 32, 128, 512, 1024 frames
-    c->cull_dilate = std::min(2 * c->cull_dilate, 16);   // ... and compare rects with the horizons of a wider neighbourhood afterwards
+    c->cull_dilate = std::min(std::max(2 * c->cull_dilate, 1), 64);   // ... and compare rects with the horizons of a wider neighbourhood afterwards
     c->cull_streak = 0;
     c->frame_no -= 1;          // the same frame again, in the same slot
     c->st.frames -= 1;
@@ -1607,6 +1621,8 @@ extern "C" int gsr_get_stats(gsr_context* c, gsr_stats* out)
         c->st.pairs_consumed = (int64_t)sl.h_counters[1];
         c->st.entries_scanned = (int64_t)sl.h_counters[3];
         c->st.pairs_total = sl.last_pairs;
+        c->st.clusters_total = c->nclus;
+        c->st.clusters_kept = sl.surv_hint;
         c->st.tiles_x = sl.last_tiles_x;
         c->st.tiles_y = sl.last_local_ty;
         c->st.super_tile = sl.super_tile;

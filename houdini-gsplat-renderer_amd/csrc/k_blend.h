@@ -404,21 +404,26 @@ k_blend_lazy(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* 
     gsr_blend_tile<HAS_DEPTH, true>(a, tile_map, svals, sstart, send, recs, out, tile_work, zwin, depth, lz);
 }
 
-// k_sum_work -- last kernel of a frame, one workgroup.  From the per-tile bookkeeping of the blend kernel it makes
-//   * the frame's counters: counters[1] (records gathered, this frame), [2] (records, running total), [3] (entries scanned, this
-//     frame), [4] (entries, running total), [5] (wave-record evaluations, running total) -- a handful of plain stores instead of
-//     atomics per tile (same-address atomics serialise at ~12 ns each on MI355X);
-//   * the lazy-colour prefixes and the hints (lazy colour / tile order / occlusion culling pay?) for the next frames;
-//   * the DEPTH HORIZONS the slot's next frame culls against, per TILE, as a 4-level max pyramid (k_cluster.h), and
-//   * the verdict on THIS frame's culling: did a tile have to look beyond the horizon its splats were culled against?
+// The end of a frame, two small kernels.
+//   k_tile_pass   one WAVEFRONT per 8x8 block of tiles, lane = tile (Morton order inside the block).  From the blend kernel's
+//                 per-tile bookkeeping it forms the DEPTH HORIZONS the slot's next frame culls against (levels 0..3 of the max
+//                 pyramid of k_cluster.h are wave shuffles), checks THIS frame's culling tile by tile, and leaves per-block
+//                 partial sums of the counters.
+//   k_sum_work    one workgroup: partial sums -> the frame's counters; the culling verdict to the host; the lazy-colour
+//                 prefixes and the hints (lazy colour / tile order / occlusion culling pay?) for the next frames; the upper
+//                 levels of the pyramid.
+// (One workgroup doing the tile walk as well took 36 us at 1080p -- a single CU issuing a few thousand instructions for each
+//  of 16 waves; spread over the chip the walk is three dependent round trips.)
+// counters[1] (records gathered, this frame), [2] (records, running total), [3] (entries scanned, this frame), [4] (entries,
+// running total), [5] (wave-record evaluations, running total): a handful of plain stores instead of atomics per tile
+// (same-address atomics serialise at ~12 ns each on MI355X).
 #ifdef SW_PROFILE
 __device__ unsigned long long g_sw_prof[8];
 #define SWP(i) { if (threadIdx.x == 0) g_sw_prof[i] = clock64(); }
 #else
 #define SWP(i)
 #endif
-#define SW_THREADS 1024
-#define SW_CHUNK 8            // 8x8-tile blocks a wave has in flight at a time
+#define SW_THREADS 256
 #ifndef SW_HEADROOM_SHIFT
 #define SW_HEADROOM_SHIFT 2
 #endif
@@ -434,13 +439,14 @@ struct GsrSumArgs {
 // tile's horizon (+inf for a tile that stayed open).  K1 and k_cluster_cull drop what lies beyond the horizon of every tile
 // it can reach, so every list still holds, for each of its tiles, all splats in front of that tile's horizon -- and a tile of
 // a culled frame is complete iff it went opaque without scanning past the horizon its splats were compared with (at least
-// that of the tile's own dilated neighbourhood).  That is checked here, per tile, from the key of the last entry the tile
-// scanned; a frame that fails is rendered again without culling (gsr_api.hip).  Two pyramids alternate: this kernel reads
-// the one the frame was culled against while it writes the next frame's.
+// that of the tile's own dilated neighbourhood).  That is checked per tile, from the key of the last entry the tile scanned;
+// a frame that fails is rendered again without culling (gsr_api.hip).  Two pyramids alternate: the frame's last kernels
+// read the one the frame was culled against while they write the next frame's.
 struct GsrHorizonArgs {
     float* pyr;                     // out: the pyramid the slot's next frame culls against; NULL = off
     const float* pyr_in;            // the pyramid this frame was culled against (if `culled`; never the same buffer as pyr)
-    int32_t pyr_off[4];
+    int32_t pyr_off[GSR_PYR_MAX_LEVELS];
+    int32_t pyr_levels;
     int32_t culled;                 // K1 / k_cluster_cull dropped splats behind `pyr_in`
     int32_t dilate;                 // ... after widening every rect by this many tiles
     int32_t fallback_skipped;       // ... and the colours came from k_colour_kept, so no on-demand fallback was launched: a tile
@@ -452,8 +458,110 @@ struct GsrHorizonArgs {
     unsigned long long* host_end;   // mapped host word: ticket << 32 | "a horizon broke"
     uint32_t ticket;
 };
+// per-block partial sums of k_tile_pass
+struct __attribute__((aligned(16))) GsrTilePartial {
+    unsigned long long scanned, fetched, evals;
+    uint32_t wmax, unsat, nused, nfin, viol, pad_;
+};
+__global__ void __launch_bounds__(64)
+k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
+            GsrHorizonArgs hz, GsrTilePartial* __restrict__ partial /* [blocks] */,
+            uint32_t* __restrict__ st_scan /* [512] per super-tile: deepest scan of its opaque tiles / a tile stayed open (cleared by k_sum_work) */)
+{
+    const int lane = threadIdx.x;
+    const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const int nbx = (g.tiles_x + 7) >> 3;
+    const int b = (int)blockIdx.x, by = b / nbx, bx = b - by * nbx;
+    const int tx = bx * 8 + lx, gty = by * 8 + ly;
+    const bool inside = tx < g.tiles_x && gty < g.tiles_y;
+    bool own = false;
+    int ti = 0, st = 0;
+    if (inside && gsr_shard_owns(g.shard, gty)) {
+        const int lty = g.shard.rpb > 0 ? gty - g.shard.index * g.shard.rpb : gty / g.shard.count;
+        const int i = lty * g.tiles_x + tx;
+        if (i < g.n_tiles) { own = true; ti = i; st = (gty >> g.super_shift) * g.stiles_x + (tx >> g.super_shift); }
+    }
+    // every phase issues its loads unconditionally (tiles that do not exist read a safe address and discard the value)
+    uint4 w = tile_work[ti];
+    const int s0 = sstart[st];
+    int e0 = send[st];
+    float hold = __builtin_inff();
+    if (hz.pyr && hz.culled && inside)   // (at least) the value of the tile's own dilated neighbourhood: gsr_pyr_max is monotone
+        hold = gsr_pyr_max(hz.pyr_in, hz.pyr_off, g.tiles_x, max(tx - hz.dilate, 0), max(gty - hz.dilate, 0),
+                           min(tx + hz.dilate, g.tiles_x - 1), min(gty + hz.dilate, g.tiles_y - 1));
+    if (!own) { w = make_uint4(0u, 0u, 0u, 0u); hold = __builtin_inff(); }
+    e0 = e0 < hz.list_cap ? e0 : hz.list_cap;
+    const uint32_t len = (own && e0 > s0) ? (uint32_t)(e0 - s0) : 0u;
+    const uint32_t rd = w.x, want = w.x + (w.x >> 2) + 1024u;
+    const bool opaque = own && w.w != 0u;
+    {   // per super-tile: deepest scan of its opaque tiles, and whether one stayed open.  The tiles of a super-tile are CONSECUTIVE
+        // lanes (Morton order): reduce over them first -- atomics that share a cache line serialise like atomics on one address
+        // (8160 of them on five lines took 20 us).
+        const int gs = g.super_shift < 3 ? g.super_shift : 3;     // the part of a super-tile inside this 8x8 block: 4^gs lanes
+        uint32_t m = opaque ? rd : 0u, open = (own && !opaque) ? 1u : 0u, any = own ? 1u : 0u;
+        for (int d = 1; d < (1 << (2 * gs)); d <<= 1) {
+            const uint32_t om = __shfl_xor(m, d, 64), oo = __shfl_xor(open, d, 64), oa = __shfl_xor(any, d, 64);
+            m = om > m ? om : m; open |= oo; any |= oa;
+        }
+        // (the group's first lane may lie outside the image or belong to another rank: its super-tile index comes from its coordinates)
+        const int gst = (gty >> g.super_shift) * g.stiles_x + (tx >> g.super_shift);
+        if ((lane & ((1 << (2 * gs)) - 1)) == 0 && any && gst < 256 && (tx >> g.super_shift) < g.stiles_x) {
+            if (m) atomicMax(&st_scan[gst], m);
+            if (open) st_scan[256 + gst] = 1u;
+        }
+    }
+    uint32_t viol = 0u, nused = 0u, nfin = 0u;
+    if (hz.pyr) {
+        const bool ok = opaque && rd > 0u && rd <= len;
+        const bool c1 = ok && hold < 3.0e38f, c2 = ok && want < len;
+        const uint32_t i1 = hz.lists[c1 ? (uint32_t)s0 + rd - 1u : 0u].x;   // the last entry the tile scanned
+        const uint32_t i2 = hz.lists[c2 ? (uint32_t)s0 + want : 0u].x;      // the entry its next horizon sits at
+        const float4 P1 = hz.geoA[c1 ? i1 : 0u], P2 = hz.geoA[c2 ? i2 : 0u];
+        // distance^2 = the sort key of k_preprocess.h, same operations
+        float klast, hnew;
+        { const float dx = P1.x - hz.cam[0], dy = P1.y - hz.cam[1], dz = P1.z - hz.cam[2]; klast = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx)); }
+        { const float dx = P2.x - hz.cam[0], dy = P2.y - hz.cam[1], dz = P2.z - hz.cam[2]; hnew = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx)); }
+        float h = 0.0f;                    // outside the image / another rank's tile: nothing is needed there
+        if (own) {
+            // this frame: a tile with a horizon must have gone opaque without looking past it
+            if (hold < 3.0e38f && (!opaque || !c1 || !(klast <= hold))) viol = 1u;
+            // next frame: the key a quarter (+1024 entries) beyond the scan; a list too short for that was itself thinned by
+            // culling -- then the old horizon is pushed out by 5 % (in distance^2) instead
+            h = __builtin_inff();
+            if (opaque) {
+                if (c2) h = hnew;
+                else if (hold < 3.0e38f) h = hold * 1.05f;
+            }
+            if (len > 0u) { nused = 1u; if (h < 3.0e38f && (unsigned long long)want * 10ull <= (unsigned long long)len * 7ull) nfin = 1u; }
+        }
+        if (inside) hz.pyr[hz.pyr_off[0] + gty * g.tiles_x + tx] = h;
+        float v = inside ? h : 0.0f;
+        v = __builtin_fmaxf(v, __shfl_xor(v, 1, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 2, 64));
+        if ((lane & 3) == 0 && inside && hz.pyr_levels > 1) hz.pyr[hz.pyr_off[1] + (gty >> 1) * gsr_pyr_dim(g.tiles_x, 1) + (tx >> 1)] = v;
+        v = __builtin_fmaxf(v, __shfl_xor(v, 4, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 8, 64));
+        if ((lane & 15) == 0 && inside && hz.pyr_levels > 2) hz.pyr[hz.pyr_off[2] + (gty >> 2) * gsr_pyr_dim(g.tiles_x, 2) + (tx >> 2)] = v;
+        v = __builtin_fmaxf(v, __shfl_xor(v, 16, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 32, 64));
+        if (lane == 0 && hz.pyr_levels > 3) hz.pyr[hz.pyr_off[3] + by * nbx + bx] = v;
+    }
+    unsigned long long sc = w.x, fe = w.y, ev = w.z;
+    uint32_t wmax = gsr_tile_weight(w), unsat = (own && !w.w && w.y) ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); unsat += __shfl_down(unsat, d, 64);
+        nused += __shfl_down(nused, d, 64); nfin += __shfl_down(nfin, d, 64);
+        { const uint32_t o = __shfl_down(wmax, d, 64); wmax = o > wmax ? o : wmax; }
+    }
+    const bool any_viol = __ballot(viol != 0u) != 0ull;
+    if (lane == 0) {
+        GsrTilePartial p;
+        p.scanned = sc; p.fetched = fe; p.evals = ev; p.wmax = wmax; p.unsat = unsat; p.nused = nused; p.nfin = nfin;
+        p.viol = any_viol ? 1u : 0u; p.pad_ = 0u;
+        partial[b] = p;
+    }
+}
+
 __global__ void __launch_bounds__(SW_THREADS)
-k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long* __restrict__ counters,
+k_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g, unsigned long long* __restrict__ counters,
            const uint32_t* __restrict__ n_visible, unsigned long long* __restrict__ summary /* device [8]: fetched by gsr_get_stats */,
            uint32_t* __restrict__ prefix /* [256] lazy colour: list entries to colour per super-tile, next frame (or NULL) */,
            const uint32_t* __restrict__ redo_count /* tiles the plain blend kernel gave up this frame (or NULL) */,
@@ -462,18 +570,16 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
            const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
            uint32_t* __restrict__ lazy_hint /* would lazy colour pay for a frame like this one? (read by the next frames) */,
            uint32_t* __restrict__ sup_work_next /* [256] the NEXT frame's per-super-tile work sums: cleared here (or NULL) */,
-           GsrHorizonArgs hz)
+           GsrHorizonArgs hz, uint32_t* __restrict__ st_scan /* [512] from k_tile_pass: read, cleared */)
 {
     SWP(0)
-    if (sup_work_next && threadIdx.x < 256) sup_work_next[threadIdx.x] = 0u;
     __shared__ unsigned long long s_sum[3];
     __shared__ uint32_t s_unsat, s_est, s_cev, s_wmax, s_nfin, s_nused, s_viol;
-    __shared__ uint32_t s_m[256], s_open[256];   // per super-tile: deepest scan of its opaque tiles / a tile stayed open
-    // The kernel is one workgroup at the very end of the frame and the next frame waits for it: every dependent global round
-    // trip (~2 us) is frame latency.  So everything either half needs from memory is fetched up front, and the tile walk keeps
-    // SW_CHUNK independent chains (bookkeeping -> list entry -> position) in flight per lane.
+    __shared__ float s_lvl[2][1024];   // pyramid levels above 3, two at a time (level 4 has <= 32 x 32 cells)
+    // everything this workgroup needs from memory is requested up front: every dependent round trip (~2 us) is frame latency
     unsigned long long old2 = 0, old4 = 0, old5 = 0, old_ct = 0;
-    uint32_t nvis = 0, nredo = 0, my_cev = 0;
+    uint32_t nvis = 0, nredo = 0, my_cev = 0, my_m = 0;
+    int my_s0 = 0, my_e0 = 0;
     if (threadIdx.x == 0) {
         old2 = counters[2]; old4 = counters[4]; old5 = counters[5];
         nvis = *n_visible;
@@ -481,147 +587,73 @@ k_sum_work(const uint4* __restrict__ tile_work, GsrSumArgs g, unsigned long long
         if (colour_evals) old_ct = *colour_total;
         s_unsat = 0; s_est = 0; s_cev = 0; s_wmax = 0; s_nfin = 0; s_nused = 0; s_viol = 0;
     }
-    if (colour_evals && threadIdx.x < 256) my_cev = colour_evals[threadIdx.x];
-    if (threadIdx.x < 256) { s_m[threadIdx.x] = 0u; s_open[threadIdx.x] = 0u; }
     if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+    if (colour_evals) my_cev = colour_evals[threadIdx.x];
+    if ((int)threadIdx.x < g.n_super) { my_m = st_scan[threadIdx.x]; my_s0 = sstart[threadIdx.x]; my_e0 = send[threadIdx.x]; }
+    unsigned long long sc = 0, fe = 0, ev = 0;
+    uint32_t wmax = 0, unsat = 0, nused = 0, nfin = 0, viol = 0;
+    for (int i = (int)threadIdx.x; i < nblocks; i += SW_THREADS) {
+        const GsrTilePartial p = partial[i];
+        sc += p.scanned; fe += p.fetched; ev += p.evals; unsat += p.unsat; nused += p.nused; nfin += p.nfin; viol |= p.viol;
+        wmax = p.wmax > wmax ? p.wmax : wmax;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); unsat += __shfl_down(unsat, d, 64);
+        nused += __shfl_down(nused, d, 64); nfin += __shfl_down(nfin, d, 64);
+        { const uint32_t o = __shfl_down(wmax, d, 64); wmax = o > wmax ? o : wmax; }
+    }
+    const bool any_viol = __ballot(viol != 0u) != 0ull;
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); atomicAdd(&s_sum[2], ev); atomicAdd(&s_unsat, unsat); atomicMax(&s_wmax, wmax);
+        atomicAdd(&s_nused, nused); atomicAdd(&s_nfin, nfin);
+        if (any_viol) s_viol = 1u;
+    }
     __syncthreads();
     SWP(2)
-    {
-        // a wave takes whole 8x8-tile blocks, lane = tile in Morton order inside the block: the pyramid's levels 1..3 are wave shuffles
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
-        const int nbx = (g.tiles_x + 7) >> 3, nby = (g.tiles_y + 7) >> 3, nblocks = nbx * nby;
-        unsigned long long sc = 0, fe = 0, ev = 0;
-        uint32_t wmax = 0, unsat = 0, nused = 0, nfin = 0, viol = 0;
-        for (int b0 = wave; b0 < nblocks; b0 += (SW_THREADS / 64) * SW_CHUNK) {
-            uint32_t rd[SW_CHUNK], want[SW_CHUNK], len[SW_CHUNK], flag[SW_CHUNK];   // flag: 1 in image, 2 owned, 4 opaque
-            int ss[SW_CHUNK];
-            float hold[SW_CHUNK], klast[SW_CHUNK], hnew[SW_CHUNK];
-            uint32_t i1[SW_CHUNK], i2[SW_CHUNK];
-#pragma unroll
-            for (int u = 0; u < SW_CHUNK; ++u) {   // (A) bookkeeping, list range, the horizon the tile was culled against
-                const int b = b0 + u * (SW_THREADS / 64);
-                rd[u] = 0; want[u] = 0; len[u] = 0; flag[u] = 0; ss[u] = 0; hold[u] = __builtin_inff();
-                if (b < nblocks) {
-                    const int by = b / nbx, bx = b - by * nbx;
-                    const int tx = bx * 8 + lx, gty = by * 8 + ly;
-                    if (tx < g.tiles_x && gty < g.tiles_y) {
-                        flag[u] = 1u;
-                        if (gsr_shard_owns(g.shard, gty)) {
-                            const int lty = g.shard.rpb > 0 ? gty - g.shard.index * g.shard.rpb : gty / g.shard.count;
-                            const int i = lty * g.tiles_x + tx;
-                            if (i < g.n_tiles) {
-                                const uint4 w = tile_work[i];
-                                const int st = (gty >> g.super_shift) * g.stiles_x + (tx >> g.super_shift);
-                                const int s0 = sstart[st];
-                                int e0 = send[st];
-                                e0 = e0 < hz.list_cap ? e0 : hz.list_cap;
-                                ss[u] = s0; len[u] = e0 > s0 ? (uint32_t)(e0 - s0) : 0u;
-                                rd[u] = w.x;
-                                flag[u] = 3u | (w.w ? 4u : 0u);
-                                // what every splat touching this tile was compared with, at least: the value of the tile's own
-                                // dilated neighbourhood (gsr_pyr_max is monotone)
-                                if (hz.pyr && hz.culled)
-                                    hold[u] = gsr_pyr_max(hz.pyr_in, hz.pyr_off, g.tiles_x, max(tx - hz.dilate, 0), max(gty - hz.dilate, 0),
-                                                          min(tx + hz.dilate, g.tiles_x - 1), min(gty + hz.dilate, g.tiles_y - 1));
-                                sc += w.x; fe += w.y; ev += w.z;
-                                { const uint32_t tw = gsr_tile_weight(w); wmax = tw > wmax ? tw : wmax; }
-                                if (!w.w && w.y) ++unsat;
-                                if (st < 256) { if (w.w) atomicMax(&s_m[st], w.x); else s_open[st] = 1u; }
-                            }
-                        }
-                    }
-                }
-            }
-            if (hz.pyr) {
-#pragma unroll
-                for (int u = 0; u < SW_CHUNK; ++u) {   // (B) the last entry the tile scanned, and the entry its next horizon sits at
-                    i1[u] = 0xffffffffu; i2[u] = 0xffffffffu;
-                    want[u] = rd[u] + (rd[u] >> 2) + 1024u;
-                    if ((flag[u] & 4u) && rd[u] > 0u && rd[u] <= len[u]) {
-                        if (hold[u] < 3.0e38f) i1[u] = hz.lists[(uint32_t)ss[u] + rd[u] - 1u].x;
-                        if (want[u] < len[u]) i2[u] = hz.lists[(uint32_t)ss[u] + want[u]].x;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < SW_CHUNK; ++u) {   // (C) their distance^2 (the sort key of k_preprocess.h, same operations)
-                    klast[u] = 0.0f; hnew[u] = __builtin_inff();
-                    if (i1[u] != 0xffffffffu) {
-                        const float4 P = hz.geoA[i1[u]];
-                        const float dx = P.x - hz.cam[0], dy = P.y - hz.cam[1], dz = P.z - hz.cam[2];
-                        klast[u] = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
-                    }
-                    if (i2[u] != 0xffffffffu) {
-                        const float4 P = hz.geoA[i2[u]];
-                        const float dx = P.x - hz.cam[0], dy = P.y - hz.cam[1], dz = P.z - hz.cam[2];
-                        hnew[u] = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < SW_CHUNK; ++u) {   // (D) verdict, next horizon, pyramid
-                    const int b = b0 + u * (SW_THREADS / 64);
-                    if (b >= nblocks) continue;        // (wave-uniform)
-                    float h = 0.0f;                    // outside the image / another rank's tile: nothing is needed there
-                    if (flag[u] & 2u) {
-                        const bool opaque = (flag[u] & 4u) != 0u;
-                        // this frame: a tile with a horizon must have gone opaque without looking past it
-                        if (hold[u] < 3.0e38f && (!opaque || !(klast[u] <= hold[u]))) viol = 1u;
-                        // next frame: the key a quarter (+1024 entries) beyond the scan; a list too short for that was itself
-                        // thinned by culling -- then the old horizon is pushed out by 5 % (in distance^2) instead
-                        h = __builtin_inff();
-                        if (opaque) {
-                            if (want[u] < len[u]) h = hnew[u];
-                            else if (hold[u] < 3.0e38f) h = hold[u] * 1.05f;
-                        }
-                        if (len[u] > 0u) { ++nused; if (h < 3.0e38f && (unsigned long long)want[u] * 10ull <= (unsigned long long)len[u] * 7ull) ++nfin; }
-                    }
-                    const int by = b / nbx, bx = b - by * nbx;
-                    const int tx = bx * 8 + lx, gty = by * 8 + ly;
-                    if (flag[u] & 1u) hz.pyr[hz.pyr_off[0] + gty * g.tiles_x + tx] = h;
-                    float v = (flag[u] & 1u) ? h : 0.0f;
-                    v = __builtin_fmaxf(v, __shfl_xor(v, 1, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 2, 64));
-                    if ((lane & 3) == 0 && (flag[u] & 1u)) hz.pyr[hz.pyr_off[1] + (gty >> 1) * gsr_pyr_dim(g.tiles_x, 1) + (tx >> 1)] = v;
-                    v = __builtin_fmaxf(v, __shfl_xor(v, 4, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 8, 64));
-                    if ((lane & 15) == 0 && (flag[u] & 1u)) hz.pyr[hz.pyr_off[2] + (gty >> 2) * gsr_pyr_dim(g.tiles_x, 2) + (tx >> 2)] = v;
-                    v = __builtin_fmaxf(v, __shfl_xor(v, 16, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 32, 64));
-                    if (lane == 0) hz.pyr[hz.pyr_off[3] + by * nbx + bx] = v;
-                }
-            }
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); unsat += __shfl_down(unsat, d, 64);
-            nused += __shfl_down(nused, d, 64); nfin += __shfl_down(nfin, d, 64);
-            { const uint32_t o = __shfl_down(wmax, d, 64); wmax = o > wmax ? o : wmax; }
-        }
-        if (__ballot(viol != 0u) && lane == 0) s_viol = 1u;
-        if (lane == 0) {
-            atomicAdd(&s_sum[0], sc); atomicAdd(&s_sum[1], fe); atomicAdd(&s_sum[2], ev); atomicAdd(&s_unsat, unsat); atomicMax(&s_wmax, wmax);
-            atomicAdd(&s_nused, nused); atomicAdd(&s_nfin, nfin);
-        }
-    }
-    SWP(3)
-    __syncthreads();
-    // the frame's verdict to the host, which is waiting for it before it hands the frame over and queues the next one
+    // first thing: the frame's verdict to the host, which is waiting for it before it hands the frame over and queues the next one
     if (hz.host_end && threadIdx.x == 0) {
         uint32_t v = s_viol;
         if (hz.fallback_skipped && nredo) v = 1u;
         *hz.host_end = ((unsigned long long)hz.ticket << 32) | (unsigned long long)(v ? 1u : 0u);
         __threadfence_system();   // out to the host NOW (without it the word left with the kernel's end: a 13 us bubble before the next frame)
     }
-    if (threadIdx.x < 256) {
+    if (sup_work_next) sup_work_next[threadIdx.x] = 0u;
+    {
         const int st = (int)threadIdx.x;
-        if (st < g.n_super && prefix) {
-            const uint32_t m = s_m[st];
-            const int s0 = sstart[st], e0 = send[st];
-            const uint32_t len = e0 > s0 ? (uint32_t)(e0 - s0) : 0u;
-            const uint32_t want = m + (m >> SW_HEADROOM_SHIFT) + SW_HEADROOM_ADD;   // headroom for the next frame's camera move
-            atomicAdd(&s_est, want < len ? want : len);   // colour evaluations the lazy pass would make for a frame like this one
-            prefix[st] = want;
+        if (st < g.n_super) {
+            st_scan[st] = 0u; st_scan[256 + st] = 0u;   // (for the slot's next frame)
+            if (prefix) {
+                const uint32_t len = my_e0 > my_s0 ? (uint32_t)(my_e0 - my_s0) : 0u;
+                const uint32_t want = my_m + (my_m >> SW_HEADROOM_SHIFT) + SW_HEADROOM_ADD;   // headroom for the next frame's camera move
+                atomicAdd(&s_est, want < len ? want : len);   // colour evaluations the lazy pass would make for a frame like this one
+                prefix[st] = want;
+            }
         }
         if (colour_evals) {
             colour_evals[threadIdx.x] = 0u;
             if (my_cev) atomicAdd(&s_cev, my_cev);
+        }
+    }
+    // the pyramid's levels above 3: each from the one below, through LDS
+    if (hz.pyr && hz.pyr_levels > 4) {
+        int src = 0;
+        for (int L = 4; L < hz.pyr_levels; ++L, src ^= 1) {
+            const int w = gsr_pyr_dim(g.tiles_x, L), h = gsr_pyr_dim(g.tiles_y, L);
+            const int wc = gsr_pyr_dim(g.tiles_x, L - 1), hc = gsr_pyr_dim(g.tiles_y, L - 1);
+            for (int cidx = (int)threadIdx.x; cidx < w * h; cidx += SW_THREADS) {
+                const int cy = cidx / w, cx = cidx - cy * w;
+                float v = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int x = 2 * cx + (q & 1), y = 2 * cy + (q >> 1);
+                    if (x < wc && y < hc) v = __builtin_fmaxf(v, L == 4 ? hz.pyr[hz.pyr_off[3] + y * wc + x] : s_lvl[src][y * wc + x]);
+                }
+                hz.pyr[hz.pyr_off[L] + cidx] = v;
+                s_lvl[src ^ 1][cidx] = v;
+            }
+            __syncthreads();
         }
     }
     __syncthreads();

@@ -105,36 +105,25 @@ k_cluster_bounds(uint32_t n, const float4* __restrict__ geoA, const uint4* __res
 }
 
 // ---- per frame ----------------------------------------------------------------------------------------------------------
-// Depth horizons live in a 4-level max pyramid over the tile grid (k_blend.h: k_sum_work builds it): level l cell (x, y)
-// = the largest horizon of the tiles [x 2^l, (x+1) 2^l) x [y 2^l, (y+1) 2^l); +inf = no horizon (nothing may be culled
-// there), 0 = a tile of another rank (nothing is needed there).
-#define GSR_PYR_LEVELS 4
-#define GSR_PYR_FLOATS (512 * 512 + 256 * 256 + 128 * 128 + 64 * 64 + 16)   // a grid of up to 512 x 512 tiles
+// Depth horizons live in a max pyramid over the tile grid (k_blend.h: k_tile_pass / k_sum_work build it): level l cell (x, y)
+// = the largest horizon of the tiles [x 2^l, (x+1) 2^l) x [y 2^l, (y+1) 2^l), up to the level that is a single cell; +inf =
+// no horizon (nothing may be culled there), 0 = a tile of another rank (nothing is needed there).
+#define GSR_PYR_MAX_LEVELS 10          // a grid of up to 512 x 512 tiles
+#define GSR_PYR_FLOATS (512 * 512 + 256 * 256 + 128 * 128 + 64 * 64 + 32 * 32 + 16 * 16 + 8 * 8 + 4 * 4 + 2 * 2 + 1 + 16)
 __host__ __device__ __forceinline__ int gsr_pyr_dim(int tiles, int level) { return ((tiles - 1) >> level) + 1; }
-// largest horizon over the tile rect [x0, x1] x [y0, y1] (inside the grid), widened to at most 2 x 2 cells of one level
-// (or <= 3 x 3 cells of the top level); +inf when the rect is larger than that.  MONOTONE: a rect that contains another
-// never gets a smaller value (its cells are unions of the other's), which is what lets k_sum_work check a tile against
-// the value of the tile's own dilated neighbourhood -- every splat that touches the tile was compared with at least that.
+// largest horizon over the tile rect [x0, x1] x [y0, y1] (inside the grid), widened to the 2 x 2 cells of the finest level
+// at which it spans no more than that.  MONOTONE: a rect that contains another never gets a smaller value (its cells are
+// unions of the other's), which is what lets k_tile_pass check a tile against the value of the tile's own dilated
+// neighbourhood -- every splat that touches the tile was compared with at least that.
 __device__ __forceinline__ float gsr_pyr_max(const float* __restrict__ pyr, const int32_t* pyr_off, int tiles_x, int x0, int y0, int x1, int y1)
 {
     const int span = max(x1 - x0, y1 - y0);
     int L = 31 - __builtin_clz((uint32_t)span | 1u);
     if (((x1 >> L) - (x0 >> L)) > 1 || ((y1 >> L) - (y0 >> L)) > 1) ++L;
-    if (L < GSR_PYR_LEVELS) {
-        const int w = gsr_pyr_dim(tiles_x, L);
-        const float* p = pyr + pyr_off[L];
-        const int a0 = x0 >> L, a1 = x1 >> L, b0 = y0 >> L, b1 = y1 >> L;
-        return __builtin_fmaxf(__builtin_fmaxf(p[b0 * w + a0], p[b0 * w + a1]), __builtin_fmaxf(p[b1 * w + a0], p[b1 * w + a1]));
-    }
-    const int T = GSR_PYR_LEVELS - 1;
-    const int a0 = x0 >> T, a1 = x1 >> T, b0 = y0 >> T, b1 = y1 >> T;
-    if (a1 - a0 > 2 || b1 - b0 > 2) return __builtin_inff();
-    const int w = gsr_pyr_dim(tiles_x, T);
-    const float* p = pyr + pyr_off[T];
-    float h = 0.0f;
-    for (int b = b0; b <= b1; ++b)
-        for (int a = a0; a <= a1; ++a) h = __builtin_fmaxf(h, p[b * w + a]);
-    return h;
+    const int w = gsr_pyr_dim(tiles_x, L);
+    const float* p = pyr + pyr_off[L];
+    const int a0 = x0 >> L, a1 = x1 >> L, b0 = y0 >> L, b1 = y1 >> L;
+    return __builtin_fmaxf(__builtin_fmaxf(p[b0 * w + a0], p[b0 * w + a1]), __builtin_fmaxf(p[b1 * w + a0], p[b1 * w + a1]));
 }
 
 // one thread per cluster; workgroup b handles the clusters [b * per, (b + 1) * per), per = CC_THREADS * rounds, and leaves
@@ -197,11 +186,14 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                     // wholly in front of the eye: the screen positions of its splats lie inside the hull of the projected
                     // corners, and every quad inside its centre +- hb: the cheap extent bound of gsr_k1_front, taken at the
                     // largest |diag(scale) R^T|_F and the smallest |view z| of the cluster
+                    // the bbox half extents of a quad are rq (s1 |ex| + s2 |ey|) <= 2 sqrt(s1^2 + s2^2) = 2 sqrt(2 (lambda1 + lambda2)) <=
+                    // 2 sqrt(2 (trace(cov2d) + 0.6)), and trace(J W S W^T J^T) <= |J|_2^2 |W|_2^2 trace(S) with |J|_2^2 = (f/tz)^2 (1 + (tx/tz)^2 +
+                    // (ty/tz)^2) <= (f/tz)^2 (1 + limx^2 + limy^2), trace(S) = |diag(s) R^T O^T|_F^2 <= |O|_2^2 mf^2
                     const float tzn = __builtin_fminf(__builtin_fabsf(tz_min), __builtin_fabsf(tz_max)) * (1.0f - 1.0e-5f);
                     const float jz = f.focal / tzn;
                     const float mf = A.w * 1.001f;
-                    const float trb = jz * jz * (2.0f + f.limx * f.limx + f.limy * f.limy) * f.sigma_vo2 * (mf * mf) * 1.002f + 0.6f;
-                    const float hb = 2.8313f * __builtin_fminf(__builtin_sqrtf(2.0f * trb), 4096.0f) + 0.02f;
+                    const float trb = jz * jz * (1.0f + f.limx * f.limx + f.limy * f.limy) * f.sigma_vo2 * (mf * mf) * 1.002f + 0.8f;
+                    const float hb = 2.0005f * __builtin_fminf(__builtin_sqrtf(2.0f * trb), 5793.0f) + 0.02f;
                     const float slack = 1.0f + 1.0e-4f * (__builtin_fabsf(cxmin) + __builtin_fabsf(cxmax) + __builtin_fabsf(cymin) + __builtin_fabsf(cymax));
                     const float xlo = cxmin - hb - 0.5f - slack, xhi = cxmax + hb - 0.5f + slack;
                     const float ylo = cymin - hb - 0.5f - slack, yhi = cymax + hb - 0.5f + slack;

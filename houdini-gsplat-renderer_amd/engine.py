@@ -41,7 +41,8 @@ class gsr_stats(C.Structure):
                 ("blend_wave_evals_total", C.c_int64), ("stage_ms_total", C.c_double * 5),
                 ("stage_frames", C.c_int64), ("sorts_skipped", C.c_int64), ("frames_requeued", C.c_int64),
                 ("lazy_redo_tiles", C.c_int64), ("lazy_colours_total", C.c_int64), ("frames_truncated", C.c_int64),
-                ("frames_culled", C.c_int64), ("frames_repaired", C.c_int64)]
+                ("frames_culled", C.c_int64), ("frames_repaired", C.c_int64),
+                ("clusters_total", C.c_int64), ("clusters_kept", C.c_int64)]
 
     def as_dict(self) -> dict:
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -81,6 +82,7 @@ OPT_OCCLUSION_CULL = 10
 OPT_TIMING_EVERY = 11
 OPT_CLUSTER_CULL = 12
 OPT_STORAGE_ORDER = 13
+OPT_CULL_DILATE = 14
 
 # every symbol include/gsplat_hip.h and include/GSplatRenderer.h declare
 C_ABI_SYMBOLS = [

@@ -93,6 +93,8 @@ typedef struct gsr_stats {
                                               for exact pixels; the buffer is regrown for the following frames) */
     int64_t frames_culled;                 /* GSR_OPT_OCCLUSION_CULL: frames rendered against the previous frame's depth horizons */
     int64_t frames_repaired;               /* ... of which this many broke a horizon and were rendered again without culling */
+    int64_t clusters_total;                /* clusters of 64 storage-ordered splats (k_cluster.h) */
+    int64_t clusters_kept;                 /* ... that survived the cluster culling of the last frame whose count reached the host */
 } gsr_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -264,6 +266,10 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        upload), 0 = in upload order.  The storage order is what breaks ties in the depth sort (the
                                        reference's own tie order is unspecified: unstable tbb::parallel_sort, src/GSplatRenderer.C:206-207);
                                        gsr_debug_read_storage_order returns it. */
+#define GSR_OPT_CULL_DILATE     14   /* occlusion culling: tiles by which a splat's (or cluster's) tile rect is widened before it is compared with the
+                                       depth horizons of the previous frame (default 2; 0..64).  The view moves between frames: a wider
+                                       neighbourhood culls less but breaks less often.  The library doubles it whenever a frame had to be
+                                       repaired and lets it shrink back to this value while frames hold. */
 int  gsr_set_option(gsr_context* ctx, int option, int value);
 
 /* ---- debug / test access (device -> host copies of intermediates) -------- */

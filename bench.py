@@ -51,7 +51,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="C4", help="BASELINE config (C1..C5); C4 is the headline workload")
+    ap.add_argument("--config", default="C4", help="BASELINE config (C1..C5); C4 is the headline workload.  T1 (a landscape under "
+                    "open sky) and S1 (a thin wall) are extra scenes with silhouettes")
     ap.add_argument("--splats", type=int, default=None, help="override the splat count (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the cpu_baseline leg")
@@ -220,7 +221,7 @@ def main():
         eng.set_row_shard(args.emulate_rank % args.emulate_shard, args.emulate_shard)
     eng.upload(splats)  # once: geometry stays resident in HBM
 
-    cams = [pkg.engine.camera_struct(pkg.camera.make_camera(W, H, sh_order=order, frame=i))
+    cams = [pkg.engine.camera_struct(pkg.scenes.config_camera(args.config, pkg.camera, W, H, order, i))
             for i in range(args.warmup + args.steps)]
     # N>1: the frame's ONE collective -- band images -> rank 0 over xGMI -- lives INSIDE the library (gsr_comm_render:
     # render band -> ncclSend / ncclRecv x (N-1) in one group -> k_stitch_bands on the root).  torch.distributed only
@@ -492,7 +493,7 @@ def main():
             "lazy_colour": {"mode": args.lazy, "active": st["lazy_colours_total"] > 0, "colours_evaluated_per_frame": st["lazy_colours_total"] / max(1, st["frames"]),
                             "visible_splats": st["n_visible"],
                             "fallback_tiles_last_frame": st["lazy_redo_tiles"]},
-            "occlusion_culling": {"enabled": bool(args.cull), "frames_culled": st["frames_culled"], "frames_repaired": st["frames_repaired"],
+            "occlusion_culling": {"enabled": bool(args.cull), "policy_bits": st["policy_bits"], "dilate_tiles": st["cull_dilate"], "holdoff_frames": st["cull_holdoff"], "frames_culled": st["frames_culled"], "frames_repaired": st["frames_repaired"],
                                   "frames": st["frames"], "without": unculled,
                                   "note": "splats whose tile rect lies wholly behind the previous frame's per-super-tile depth horizons get no colour, no record, and "
                                           "no place in the sort and the lists; every culled frame verifies itself and is rendered again without culling if a horizon "

@@ -92,7 +92,8 @@ struct FrameJob {
     bool speculative = false;      // the back end was queued before the pair count was known
     bool deferred = false;         // ... and the frame handed over without waiting for it (GSR_OPT_DEFERRED_CHECK)
     bool lazy = false;             // K1 left the SH colours pending (k_colour.h)
-    bool cull = false;             // occlusion culling: K1 and the binning cut at the slot's depth horizons
+    bool cull = false;             // occlusion culling: k_cluster_cull and K1 drop what lies behind the slot's depth horizons
+    bool colour_kept = false;      // ... and the colours are evaluated once per kept splat (k_colour_kept), with no fallback launch
     bool direct = false;           // the frame runs on the public stream itself
     uint32_t ticket = 0;           // stamps the frame's pair count in the host mailbox
 };
@@ -139,8 +140,9 @@ struct FrameSlot {
     // pyramid written by k_sum_work at the end of every frame from how deep the frame's tiles had to look.  A culled frame is
     // checked there too (did a tile look past the horizon its splats were culled against?); the verdict goes to the mapped word
     // h_end, and the host renders a frame that failed again, without culling, before it hands it over.
-    float* hpyr2[2] = {nullptr, nullptr};   // pyramid levels 0..3 (k_cluster.h), GSR_PYR_FLOATS floats each: k_sum_work reads one, writes the other
-    int hpyr_cur = 0;                  // the pyramid the slot's next frame culls against
+    float* hpyr = nullptr;             // pyramid levels 0..3 (k_cluster.h), GSR_PYR_FLOATS floats: what the slot's next frame culls against
+    float* hraw = nullptr;             // per-tile horizons before dilation (k_tile_pass -> k_horizon_dilate)
+    int hpyr_re = 0;                   // the dilation radius built into hpyr
     // cluster culling (k_cluster.h): the ordered list of surviving clusters of the frame, as per-workgroup segments
     uint32_t* cseg = nullptr;          // [ngroups * per]
     uint32_t* ccnt = nullptr;          // [CC_MAX_GROUPS]
@@ -229,6 +231,8 @@ struct gsr_context {
     bool lazy_pays = false;
     uint32_t vis_unculled = 0;         // splats kept by the last frame that was not culled
     bool cull_pays = false;            // ... and its third: most super-tile lists have a depth horizon (occlusion culling)
+    bool cull_weak = false;            // the last culled frame kept > 70 % of what an unculled frame keeps
+    bool prefix_cheaper = false;       // the list-prefix colour pass would evaluate fewer colours than one per kept splat
     int cull_holdoff = 0, cull_backoff = 8, cull_streak = 0;   // frames without culling after a broken horizon (x4 each time, <= 1024; back to 8 after 64 good frames)
     int cull_dilate = 2;               // tiles by which rects are widened before they are compared with the horizons (grows when horizons break)
     int opt_dilate = 2;                // ... its starting (and smallest) value
@@ -314,8 +318,8 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMemset(sl.lazy_ctr, 0, 2 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.colour_evals), 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.colour_evals, 0, 256 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr2[0]), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr2[1]), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hraw), 512 * 512 * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.ccnt), CC_MAX_GROUPS * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_counts), 2 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.d_counts, 0, 2 * sizeof(uint32_t)) == hipSuccess;
@@ -356,7 +360,7 @@ static void slot_destroy(FrameSlot& sl)
     dev_free(sl.hist); dev_free(sl.totals);
     dev_free(sl.pvA);
     dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.fb);
-    dev_free(sl.hpyr2[0]); dev_free(sl.hpyr2[1]); dev_free(sl.ccnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
+    dev_free(sl.hpyr); dev_free(sl.hraw); dev_free(sl.ccnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
     if (sl.h_end) (void)hipHostFree(sl.h_end); dev_free(sl.depth_stage);
     dev_free(sl.redo); dev_free(sl.lazy_ctr); dev_free(sl.colour_evals);
     dev_free(sl.counters); dev_free(sl.d_n);
@@ -915,15 +919,11 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
     f->super = 1 << shift;
     f->stiles_x = ((f->tiles_x - 1) >> shift) + 1;
     f->stiles_y = ((f->tiles_y - 1) >> shift) + 1;
-    int off = 0, levels = 0;
-    for (int l = 0; l < GSR_PYR_MAX_LEVELS; ++l) {
+    int off = 0;
+    for (int l = 0; l < GSR_PYR_LEVELS; ++l) {
         f->pyr_off[l] = off;
-        if (levels == 0) {
-            off += gsr_pyr_dim(f->tiles_x, l) * gsr_pyr_dim(f->tiles_y, l);
-            if (gsr_pyr_dim(f->tiles_x, l) == 1 && gsr_pyr_dim(f->tiles_y, l) == 1) levels = l + 1;   // the top: one cell
-        }
+        off += gsr_pyr_dim(f->tiles_x, l) * gsr_pyr_dim(f->tiles_y, l);
     }
-    f->pyr_levels = levels ? levels : GSR_PYR_MAX_LEVELS;
     f->cull_dilate = c->cull_dilate;
 }
 
@@ -1037,7 +1037,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         HIP_TRY(hipGetLastError());
     }
     if ((rc = mark(sl, 4))) return rc;
-    if (j.lazy && j.cull && j.n > 0) {
+    if (j.colour_kept && j.n > 0) {
         // an occlusion-culled frame: one evaluation per splat K1 kept (they are about what the frame composites)
         hipLaunchKernelGGL(k_colour_kept, dim3(1024), dim3(CL_THREADS), 0, s, f, sl.valA, sl.d_n, c->colrow, sl.rec, sl.colour_evals);
         HIP_TRY(hipGetLastError());
@@ -1074,7 +1074,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
                                sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
-        if (j.lazy && !j.cull) {   // the tiles that met a pending colour, with on-demand evaluation (normally none: the blocks exit at once)
+        if (j.lazy && !j.colour_kept) {   // the tiles that met a pending colour, with on-demand evaluation (normally none: the blocks exit at once)
             if (j.d_depth)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<true>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
                                    sl.pvA, sl.sstart, sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
@@ -1101,9 +1101,8 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     // ... and while culling is held off nobody needs horizons: they are prepared again two frames before it may resume.
     // A deferred frame (handed over before its pair count was known) never culls and may have clamped lists: no horizons from it.
     if (c->opt_cull && j.n > 0 && !j.deferred && (c->opt_cull >= 2 || j.cull || (c->vis_unculled >= 300000u && c->cull_holdoff <= 2))) {
-        hz.pyr = sl.hpyr2[sl.hpyr_cur ^ 1]; hz.pyr_in = sl.hpyr2[sl.hpyr_cur]; hz.dilate = j.f.cull_dilate; hz.culled = j.cull ? 1 : 0; hz.fallback_skipped = (j.cull && j.lazy) ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
-        for (int l = 0; l < GSR_PYR_MAX_LEVELS; ++l) hz.pyr_off[l] = j.f.pyr_off[l];
-        hz.pyr_levels = j.f.pyr_levels;
+        hz.raw = sl.hraw; hz.pyr_in = sl.hpyr; hz.pyr_out = sl.hpyr; hz.dilate = j.f.cull_dilate; hz.culled = j.cull ? 1 : 0; hz.fallback_skipped = j.colour_kept ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
+        for (int l = 0; l < GSR_PYR_LEVELS; ++l) hz.pyr_off[l] = j.f.pyr_off[l];
         hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
         hz.host_end = j.cull ? sl.h_end_dev : nullptr; hz.ticket = j.ticket;
     }
@@ -1115,9 +1114,13 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
                        sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint,
                        sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr, hz, sl.st_scan);
     HIP_TRY(hipGetLastError());
-    sl.horizon_valid = hz.pyr != nullptr;
+    sl.horizon_valid = hz.raw != nullptr;
     if (sl.horizon_valid) {
-        sl.hpyr_cur ^= 1;
+        // the next frame's pyramid: every tile's horizon widened to its neighbourhood (behind k_sum_work: it runs while the
+        // host is still reacting to the verdict)
+        sl.hpyr_re = std::min(c->cull_dilate, GSR_DILATE_EXACT_MAX);
+        hipLaunchKernelGGL(k_horizon_dilate, dim3((unsigned)nblocks8), dim3(64), 0, s, sl.hraw, j.f.tiles_x, j.f.tiles_y, sl.hpyr_re, hz, sl.hpyr);
+        HIP_TRY(hipGetLastError());
         const int sig[7] = {j.f.width, j.f.height, j.f.shard_index, j.f.shard_count, j.f.shard_rpb, j.f.super_shift, (int)c->geo_gen};
         std::memcpy(sl.horizon_sig, sig, sizeof sig);
     }
@@ -1208,11 +1211,14 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
         D = (uint32_t)v;
         c->lazy_pays = (box[1] & 1ull) != 0ull;
         c->cull_pays = (box[1] & 4ull) != 0ull;
+        c->prefix_cheaper = (box[1] & 8ull) != 0ull;
         {   // occlusion culling earns its keep only if it drops a good part of what an unculled frame keeps
             const uint32_t kept = (uint32_t)(box[1] >> 32);
             if (!j.cull) c->vis_unculled = kept;
-            else if (c->opt_cull == 1 && c->vis_unculled > 0 && (unsigned long long)kept * 10ull > (unsigned long long)c->vis_unculled * 7ull)
-                c->cull_holdoff = 256;
+            else {
+                c->cull_weak = c->vis_unculled > 0 && (unsigned long long)kept * 10ull > (unsigned long long)c->vis_unculled * 7ull;
+                if (c->opt_cull == 1 && c->cull_weak) c->cull_holdoff = 256;
+            }
         }
         c->order_pays = (box[1] & 2ull) != 0ull;   // (written before the ticket) k_sum_work's verdict on the frame before
         sl.surv_hint = (uint32_t)box[2];           // clusters that survived k_cluster_cull: sizes the next frame's K1 grid
@@ -1334,11 +1340,14 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         j.cull = allow_cull && c->opt_cull && !j.deferred && n > 0 && sl.horizon_valid && std::memcmp(sig, sl.horizon_sig, sizeof sig) == 0 &&
                  !(c->opt_flags & GSR_FLAG_FULL_KEYS) && (c->opt_cull >= 2 || (c->cull_pays && c->cull_holdoff == 0));
         if (allow_cull && c->cull_holdoff > 0) c->cull_holdoff -= 1;
+        j.f.cull_dilate = std::max(c->cull_dilate - sl.hpyr_re, 0);   // (the rest of the radius is built into the slot's pyramid)
         if (j.cull) {
             c->st.frames_culled += 1;
             // the lists now end about where the colour pass stops anyway: colour lazily (the hint would compare the pass with
             // the few splats that are left, and choose eager evaluation of sparse rows)
             if (f.sh_order > 0 && c->opt_lazy) j.lazy = true;
+            // one evaluation per kept splat, unless the frame keeps far more than its tiles look at (then: list prefixes + fallback)
+            j.colour_kept = j.lazy && !(c->prefix_cheaper && c->prefix_valid);
         }
     }
     j.ticket = ++sl.ticket ? sl.ticket : ++sl.ticket;   // (never 0: the mailbox starts at 0)
@@ -1400,7 +1409,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         int rounds; uint32_t ngroups;
         cluster_grid(c->nclus, &rounds, &ngroups);
         hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, c->opt_cluster,
-                           j.cull ? sl.hpyr2[sl.hpyr_cur] : (const float*)nullptr, sl.cseg, sl.ccnt);
+                           j.cull ? sl.hpyr : (const float*)nullptr, sl.cseg, sl.ccnt);
         // K1 over the survivors, four clusters per workgroup-iteration; the grid follows the slot's previous frame (+25 %), and
         // a frame that keeps more simply loops
         const uint32_t all_iter = div_up(c->nclus, 4u);
@@ -1410,7 +1419,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         // output goes to the scratch buffers
         hipLaunchKernelGGL(k_preprocess, dim3(k1_grid ? k1_grid : 1u), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, cache_hit ? sl.keyB : sl.keyA, cache_hit ? sl.valB : sl.valA,
-                           j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.cull ? sl.hpyr2[sl.hpyr_cur] : (const float*)nullptr, sl.blk_cnt,
+                           j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.cull ? sl.hpyr : (const float*)nullptr, sl.blk_cnt,
                            sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts);
         hipError_t e = hipGetLastError();
 #ifdef GSR_HOST_TIMING
@@ -1493,9 +1502,15 @@ static int frame_check(gsr_context* c, FrameSlot& slot, const gsr_camera* cam, c
         return GSR_OK;
     }
     c->st.frames_repaired += 1;
-    c->cull_holdoff = std::max(c->cull_holdoff, c->cull_backoff);   // the view is changing faster than the horizons follow: leave it alone for a while
-    c->cull_backoff = c->cull_backoff >= 256 ? 1024 : 4 * c->cull_backoff;   // 8, 32, 128, 512, 1024 frames
-    c->cull_dilate = std::min(std::max(2 * c->cull_dilate, 1), 64);   // ... and compare rects with the horizons of a wider neighbourhood afterwards
+    // The view is changing faster than the horizons follow.  First answer: compare rects with the horizons of a wider
+    // neighbourhood from now on (the repaired frame leaves fresh horizons, and the radius shrinks back while frames hold);
+    // only when that is exhausted, leave culling alone for a while (8, 32, 128, 512, 1024 frames).
+    if (c->cull_dilate < 16) {
+        c->cull_dilate = std::max(2 * c->cull_dilate, 1);
+    } else {
+        c->cull_holdoff = std::max(c->cull_holdoff, c->cull_backoff);
+        c->cull_backoff = c->cull_backoff >= 256 ? 1024 : 4 * c->cull_backoff;
+    }
     c->cull_streak = 0;
     c->frame_no -= 1;          // the same frame again, in the same slot
     c->st.frames -= 1;
@@ -1623,6 +1638,9 @@ extern "C" int gsr_get_stats(gsr_context* c, gsr_stats* out)
         c->st.pairs_total = sl.last_pairs;
         c->st.clusters_total = c->nclus;
         c->st.clusters_kept = sl.surv_hint;
+        c->st.policy_bits = (c->lazy_pays ? 1 : 0) | (c->order_pays ? 2 : 0) | (c->cull_pays ? 4 : 0) | (c->cull_weak ? 8 : 0) | (c->prefix_cheaper ? 16 : 0);
+        c->st.cull_dilate = c->cull_dilate;
+        c->st.cull_holdoff = c->cull_holdoff;
         c->st.tiles_x = sl.last_tiles_x;
         c->st.tiles_y = sl.last_local_ty;
         c->st.super_tile = sl.super_tile;

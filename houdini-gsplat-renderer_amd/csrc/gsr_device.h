@@ -61,9 +61,9 @@ struct GsrFrame {
     int32_t stiles_x, stiles_y;        // super-tile grid over the whole image
     int32_t flags;                     // GSR_FLAG_* (A/B switches; never change pixels)
     uint32_t key_min, key_max;         // sort keys are stored as clamp(bits, key_min, key_max) - key_min
-    int32_t pyr_off[10];               // depth-horizon pyramid: first cell of level l (k_cluster.h; GSR_PYR_MAX_LEVELS)
-    int32_t pyr_levels;                // levels of the pyramid: the last one is a single cell
-    int32_t cull_dilate;               // tiles by which a rect is widened before it is compared with the horizons
+    int32_t pyr_off[6];                // depth-horizon pyramid: first cell of level l (k_cluster.h; GSR_PYR_LEVELS)
+    int32_t cull_dilate;               // tiles by which a rect is widened before it is compared with the horizons (on top of the
+                                       // dilation built into the pyramid)
 };
 #define GSR_FLAG_NO_ALPHA_RADIUS 1   // bbox from the full +-2 quad instead of the alpha>=1/255 support
 #define GSR_FLAG_NO_SAT          2   // quadrant masks from the bbox only

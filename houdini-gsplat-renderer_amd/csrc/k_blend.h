@@ -107,6 +107,8 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     __shared__ __attribute__((aligned(16))) uint32_t scnt[2][4];   // hits of each wave in a scan step
     __shared__ uint32_t sdone[2][4];
     __shared__ uint32_t sevals, sredo;
+    __shared__ uint32_t stail[32];    // hits queued after each of the last 32 scan steps (ring): which step held a given hit?
+    __shared__ uint32_t slast[4];     // per wave: how many of the tile's hits it has gathered (exclusive count)
 
     // Workgroup b runs on XCD b%8 (observed dispatch order, MI355X guide): tile_map hands each
     // XCD whole super-tiles, whose 64 tiles read the same list and gather the same records.
@@ -135,7 +137,9 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     const float tcx0 = (float)(tx * GSR_TILE_PX) + 0.5f, tcy0 = (float)(gty * GSR_TILE_PX) + 0.5f;
     const float qcx = tcx0 + 3.5f + 8.0f * (float)(wave & 1), qcy = tcy0 + 3.5f + 8.0f * (float)(wave >> 1);
     if (tid == 0) { sevals = 0; sredo = 0; }
+    if (tid < 4) slast[tid] = 0u;
     uint32_t my_evals = 0;            // (wave-uniform) records this wave evaluated for its 64 pixels
+    uint32_t my_last = 0;             // (wave-uniform) hits of the tile this wave has gathered so far: all of the sub-rounds it entered
     // depth test against what the opaque pass left (depth writes stay off): a fragment survives iff its quad's
     // window depth <= depth[pixel] (src/GSplatRenderer.C:595-610).  No depth buffer = +inf.
     const float dpx = (HAS_DEPTH && pix_ok) ? depth[(size_t)py * a.width + px] : __builtin_inff();
@@ -172,6 +176,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     };
     prefetch();
     int round = 0;
+    int first_hit_step = -1;          // (uniform) scan step (1024 entries each) that queued the tile's first hit
     bool saturated = false;           // left because every pixel is opaque, not because the list ended
 
     BLP(0)
@@ -200,6 +205,8 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
             if (h2) { q[pos & (BL_QCAP - 1)] = preB.x; ++pos; }
             if (h3) { q[pos & (BL_QCAP - 1)] = preB.z; }
             q_tail += wt.x + wt.y + wt.z + wt.w;
+            if (tid == 0) stail[(scan_pos >> 10) & 31] = q_tail;
+            if (first_hit_step < 0 && q_tail != 0u) first_hit_step = scan_pos >> 10;
             scan_pos += 1024;
             spar ^= 1;
             scanned_any = true;
@@ -219,6 +226,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         BLP(2)
         if (!wave_done) {
             for (int sub = 0; sub < take; sub += 64) {
+                my_last = q_head + (uint32_t)(sub + 64 < take ? sub + 64 : take);
                 const bool have = sub + lane < take;
                 float4 r1, r2;
                 float rz = 0.0f, c0 = 0.0f, c1 = 0.0f;
@@ -340,7 +348,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         }
         q_head += (uint32_t)take;
         const int rpar = round & 1;
-        if (lane == 0) sdone[rpar][wave] = wave_done ? 1u : 0u;
+        if (lane == 0) { sdone[rpar][wave] = wave_done ? 1u : 0u; slast[wave] = my_last; }
         ++round;
         BLP(5)
         __syncthreads();   // the consumed queue slots may be overwritten from here on; every wave's verdict is in
@@ -373,10 +381,27 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     __syncthreads();  // orders the sevals = 0 store when the list was empty
     if (lane == 0) atomicAdd(&sevals, my_evals);
     __syncthreads();
+    // How deep did the tile have to LOOK?  Not as deep as it scanned (the scan runs a batch of hits and a prefetched step ahead):
+    // the deepest hit any wave gathered sits in the first scan step after which at least that many hits were queued.
+    int ext_steps = 0;
+    {
+        const uint32_t c = max(max(slast[0], slast[1]), max(slast[2], slast[3]));
+        const int cur = (scan_pos >> 10) - 1;            // the last step that was scanned
+        if (wave == 0 && c > 0u && cur >= 0) {
+            const bool reached = lane < 32 && cur - lane >= 0 && stail[(cur - lane) & 31] >= c;
+            const unsigned long long m = __ballot(reached);   // bit l: after step cur - l the queue already held the hit
+            const int k = __builtin_ctzll(~m);               // (bit 0 is always set: everything was queued by the last step)
+            ext_steps = cur - (k - 1) + 1;
+        }
+    }
     if (tid == 0) {
         // entries actually read: everything up to scan_pos plus the prefetched step
         const int rd = scan_pos + 1024;
-        const uint4 tw = make_uint4((uint32_t)(rd < n ? rd : n), fetched, sevals, saturated ? 1u : 0u);
+        // (.w: bit 0 = went opaque; bits 1..15 = the 1024-entry scan step that held the tile's first hit; bits 16..31 = the number of
+        //  scan steps that hold everything the tile gathered, 0xffff = unknown / too many: fall back to .x)
+        const uint32_t fs = (uint32_t)(first_hit_step < 0 ? 0 : (first_hit_step > 0x7fff ? 0x7fff : first_hit_step));
+        const uint32_t es = (uint32_t)(ext_steps <= 0 || ext_steps > 0xfffe ? 0xffff : ext_steps);
+        const uint4 tw = make_uint4((uint32_t)(rd < n ? rd : n), fetched, sevals, (saturated ? 1u : 0u) | (fs << 1) | (es << 16));
         tile_work[tile] = tw;   // (k_sum_work turns these into colour prefixes, depth horizons and the frame's culling verdict)
         // work of the tile's super-tile, for k_tile_order (fire and forget: ~60 tiles per address and frame)
         if (a.sup_work && gsr_tile_weight(tw)) atomicAdd(&a.sup_work[st], gsr_tile_weight(tw));
@@ -405,13 +430,15 @@ k_blend_lazy(GsrBlendArgs a, const int32_t* __restrict__ tile_map, const uint2* 
 }
 
 // The end of a frame, two small kernels.
-//   k_tile_pass   one WAVEFRONT per 8x8 block of tiles, lane = tile (Morton order inside the block).  From the blend kernel's
-//                 per-tile bookkeeping it forms the DEPTH HORIZONS the slot's next frame culls against (levels 0..3 of the max
-//                 pyramid of k_cluster.h are wave shuffles), checks THIS frame's culling tile by tile, and leaves per-block
-//                 partial sums of the counters.
-//   k_sum_work    one workgroup: partial sums -> the frame's counters; the culling verdict to the host; the lazy-colour
-//                 prefixes and the hints (lazy colour / tile order / occlusion culling pay?) for the next frames; the upper
-//                 levels of the pyramid.
+//   k_tile_pass       one WAVEFRONT per 8x8 block of tiles, lane = tile.  From the blend kernel's per-tile bookkeeping it forms
+//                     the DEPTH HORIZON of every tile for the slot's next frame, checks THIS frame's culling tile by tile, and
+//                     leaves per-block partial sums of the counters.
+//   k_sum_work        one workgroup: partial sums -> the frame's counters; the culling verdict to the host; the lazy-colour
+//                     prefixes and the hints (lazy colour / tile order / occlusion culling pay?) for the next frames.
+//   k_horizon_dilate  one wavefront per 8x8 block of tiles (Morton order inside the block): every tile's horizon becomes the
+//                     largest of its (2r+1)^2 neighbourhood -- the view moves between frames -- and the levels of the max
+//                     pyramid of k_cluster.h are wave shuffles.  Queued BEHIND k_sum_work: it runs while the host is still
+//                     reacting to the verdict.
 // (One workgroup doing the tile walk as well took 36 us at 1080p -- a single CU issuing a few thousand instructions for each
 //  of 16 waves; spread over the chip the walk is three dependent round trips.)
 // counters[1] (records gathered, this frame), [2] (records, running total), [3] (entries scanned, this frame), [4] (entries,
@@ -443,10 +470,10 @@ struct GsrSumArgs {
 // a frame that fails is rendered again without culling (gsr_api.hip).  Two pyramids alternate: the frame's last kernels
 // read the one the frame was culled against while they write the next frame's.
 struct GsrHorizonArgs {
-    float* pyr;                     // out: the pyramid the slot's next frame culls against; NULL = off
-    const float* pyr_in;            // the pyramid this frame was culled against (if `culled`; never the same buffer as pyr)
-    int32_t pyr_off[GSR_PYR_MAX_LEVELS];
-    int32_t pyr_levels;
+    float* raw;                     // out: per-tile horizons for the slot's next frame (k_horizon_dilate makes the pyramid); NULL = off
+    const float* pyr_in;            // the pyramid this frame was culled against (if `culled`)
+    float* pyr_out;                 // the pyramid k_horizon_dilate fills for the next frame (the same buffer: k_tile_pass is done with it)
+    int32_t pyr_off[GSR_PYR_LEVELS];
     int32_t culled;                 // K1 / k_cluster_cull dropped splats behind `pyr_in`
     int32_t dilate;                 // ... after widening every rect by this many tiles
     int32_t fallback_skipped;       // ... and the colours came from k_colour_kept, so no on-demand fallback was launched: a tile
@@ -486,14 +513,20 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
     const int s0 = sstart[st];
     int e0 = send[st];
     float hold = __builtin_inff();
-    if (hz.pyr && hz.culled && inside)   // (at least) the value of the tile's own dilated neighbourhood: gsr_pyr_max is monotone
+    if (hz.raw && hz.culled && inside)   // (at least) the value of the tile itself, widened like every rect: gsr_pyr_max is monotone
         hold = gsr_pyr_max(hz.pyr_in, hz.pyr_off, g.tiles_x, max(tx - hz.dilate, 0), max(gty - hz.dilate, 0),
                            min(tx + hz.dilate, g.tiles_x - 1), min(gty + hz.dilate, g.tiles_y - 1));
     if (!own) { w = make_uint4(0u, 0u, 0u, 0u); hold = __builtin_inff(); }
     e0 = e0 < hz.list_cap ? e0 : hz.list_cap;
     const uint32_t len = (own && e0 > s0) ? (uint32_t)(e0 - s0) : 0u;
-    const uint32_t rd = w.x, want = w.x + (w.x >> 2) + 1024u;
-    const bool opaque = own && w.w != 0u;
+    // how deep the tile looked: the scan steps that hold everything it gathered (k_blend), never more than it read
+    const uint32_t es = w.w >> 16;
+    const uint32_t rd = (es == 0xffffu || (es << 10) > w.x) ? w.x : (es << 10);
+    const bool opaque = own && (w.w & 1u) != 0u;
+    const uint32_t first = ((w.w >> 1) & 0x7fffu) << 10;   // list position (1024-entry granularity) of the tile's first hit
+    // where the tile's next horizon sits: a quarter of what it scanned from its first hit on (+1024 entries) beyond the scan -- a
+    // tile high up in a super-tile over oblique ground starts deep in the shared list, and that part is not its depth range
+    const uint32_t want = rd + ((rd > first ? rd - first : 0u) >> 2) + 1024u;
     {   // per super-tile: deepest scan of its opaque tiles, and whether one stayed open.  The tiles of a super-tile are CONSECUTIVE
         // lanes (Morton order): reduce over them first -- atomics that share a cache line serialise like atomics on one address
         // (8160 of them on five lines took 20 us).
@@ -511,7 +544,7 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
         }
     }
     uint32_t viol = 0u, nused = 0u, nfin = 0u;
-    if (hz.pyr) {
+    if (hz.raw) {
         const bool ok = opaque && rd > 0u && rd <= len;
         const bool c1 = ok && hold < 3.0e38f, c2 = ok && want < len;
         const uint32_t i1 = hz.lists[c1 ? (uint32_t)s0 + rd - 1u : 0u].x;   // the last entry the tile scanned
@@ -534,17 +567,10 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
             }
             if (len > 0u) { nused = 1u; if (h < 3.0e38f && (unsigned long long)want * 10ull <= (unsigned long long)len * 7ull) nfin = 1u; }
         }
-        if (inside) hz.pyr[hz.pyr_off[0] + gty * g.tiles_x + tx] = h;
-        float v = inside ? h : 0.0f;
-        v = __builtin_fmaxf(v, __shfl_xor(v, 1, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 2, 64));
-        if ((lane & 3) == 0 && inside && hz.pyr_levels > 1) hz.pyr[hz.pyr_off[1] + (gty >> 1) * gsr_pyr_dim(g.tiles_x, 1) + (tx >> 1)] = v;
-        v = __builtin_fmaxf(v, __shfl_xor(v, 4, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 8, 64));
-        if ((lane & 15) == 0 && inside && hz.pyr_levels > 2) hz.pyr[hz.pyr_off[2] + (gty >> 2) * gsr_pyr_dim(g.tiles_x, 2) + (tx >> 2)] = v;
-        v = __builtin_fmaxf(v, __shfl_xor(v, 16, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 32, 64));
-        if (lane == 0 && hz.pyr_levels > 3) hz.pyr[hz.pyr_off[3] + by * nbx + bx] = v;
+        if (inside) hz.raw[gty * g.tiles_x + tx] = h;
     }
     unsigned long long sc = w.x, fe = w.y, ev = w.z;
-    uint32_t wmax = gsr_tile_weight(w), unsat = (own && !w.w && w.y) ? 1u : 0u;
+    uint32_t wmax = gsr_tile_weight(w), unsat = (own && !(w.w & 1u) && w.y) ? 1u : 0u;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); unsat += __shfl_down(unsat, d, 64);
@@ -575,7 +601,6 @@ k_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g
     SWP(0)
     __shared__ unsigned long long s_sum[3];
     __shared__ uint32_t s_unsat, s_est, s_cev, s_wmax, s_nfin, s_nused, s_viol;
-    __shared__ float s_lvl[2][1024];   // pyramid levels above 3, two at a time (level 4 has <= 32 x 32 cells)
     // everything this workgroup needs from memory is requested up front: every dependent round trip (~2 us) is frame latency
     unsigned long long old2 = 0, old4 = 0, old5 = 0, old_ct = 0;
     uint32_t nvis = 0, nredo = 0, my_cev = 0, my_m = 0;
@@ -620,6 +645,10 @@ k_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g
         __threadfence_system();   // out to the host NOW (without it the word left with the kernel's end: a 13 us bubble before the next frame)
     }
     if (sup_work_next) sup_work_next[threadIdx.x] = 0u;
+    if (hz.raw) {   // levels 4 and 5 of the next frame's pyramid are max-reduced by k_horizon_dilate's workgroups: clear them
+        const int n45 = gsr_pyr_dim(g.tiles_x, 4) * gsr_pyr_dim(g.tiles_y, 4) + gsr_pyr_dim(g.tiles_x, 5) * gsr_pyr_dim(g.tiles_y, 5);
+        for (int i = (int)threadIdx.x; i < n45; i += SW_THREADS) hz.pyr_out[hz.pyr_off[4] + i] = 0.0f;
+    }
     {
         const int st = (int)threadIdx.x;
         if (st < g.n_super) {
@@ -634,26 +663,6 @@ k_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g
         if (colour_evals) {
             colour_evals[threadIdx.x] = 0u;
             if (my_cev) atomicAdd(&s_cev, my_cev);
-        }
-    }
-    // the pyramid's levels above 3: each from the one below, through LDS
-    if (hz.pyr && hz.pyr_levels > 4) {
-        int src = 0;
-        for (int L = 4; L < hz.pyr_levels; ++L, src ^= 1) {
-            const int w = gsr_pyr_dim(g.tiles_x, L), h = gsr_pyr_dim(g.tiles_y, L);
-            const int wc = gsr_pyr_dim(g.tiles_x, L - 1), hc = gsr_pyr_dim(g.tiles_y, L - 1);
-            for (int cidx = (int)threadIdx.x; cidx < w * h; cidx += SW_THREADS) {
-                const int cy = cidx / w, cx = cidx - cy * w;
-                float v = 0.0f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int x = 2 * cx + (q & 1), y = 2 * cy + (q >> 1);
-                    if (x < wc && y < hc) v = __builtin_fmaxf(v, L == 4 ? hz.pyr[hz.pyr_off[3] + y * wc + x] : s_lvl[src][y * wc + x]);
-                }
-                hz.pyr[hz.pyr_off[L] + cidx] = v;
-                s_lvl[src ^ 1][cidx] = v;
-            }
-            __syncthreads();
         }
     }
     __syncthreads();
@@ -674,7 +683,10 @@ k_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g
                                     // bit 2: occlusion culling has something to work with: at least 30 % of the tiles that draw anything
                                     // went opaque in the first 70 % of their list (judged on unculled frames; a culled frame keeps the
                                     // verdict it was given)
-                                    ((hz.pyr && (hz.culled || ((unsigned long long)s_nfin * 10ull >= (unsigned long long)s_nused * 3ull &&
+                                    // bit 3: in a frame like this one the list-prefix colour pass would evaluate fewer colours than one per
+                                    // kept splat (a culled frame that still keeps a lot: oblique ground, silhouettes)
+                                    ((prefix && (unsigned long long)s_est * 3ull < (unsigned long long)nvis * 2ull) ? 8u : 0u) |
+                                    ((hz.raw && (hz.culled || ((unsigned long long)s_nfin * 10ull >= (unsigned long long)s_nused * 3ull &&
                                                                s_nused > 0u))) ? 4u : 0u);
         // running totals: plain read-modify-write (a slot's frames are serialised on its stream; nothing else touches them)
         const unsigned long long t2 = old2 + s_sum[1], t4 = old4 + s_sum[0], t5 = old5 + s_sum[2];
@@ -687,6 +699,38 @@ k_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g
         summary[7] = (unsigned long long)nredo;
     }
     SWP(5)
+}
+
+// raw = per-tile horizons (k_tile_pass); pyr = the pyramid the slot's next frame culls against: level 0 = every tile's horizon
+// widened to the largest of its (2r+1)^2 neighbourhood, levels 1..3 from wave shuffles (lane = tile in Morton order).
+__global__ void __launch_bounds__(64)
+k_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int r, GsrHorizonArgs hz, float* __restrict__ pyr)
+{
+    const int lane = threadIdx.x;
+    const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const int nbx = (tiles_x + 7) >> 3;
+    const int b = (int)blockIdx.x, by = b / nbx, bx = b - by * nbx;
+    const int tx = bx * 8 + lx, ty = by * 8 + ly;
+    const bool inside = tx < tiles_x && ty < tiles_y;
+    float v = 0.0f;
+    if (inside) {
+        const int x0 = max(tx - r, 0), x1 = min(tx + r, tiles_x - 1), y0 = max(ty - r, 0), y1 = min(ty + r, tiles_y - 1);
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) v = __builtin_fmaxf(v, raw[y * tiles_x + x]);
+        pyr[hz.pyr_off[0] + ty * tiles_x + tx] = v;
+    }
+    v = __builtin_fmaxf(v, __shfl_xor(v, 1, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 2, 64));
+    if ((lane & 3) == 0 && inside) pyr[hz.pyr_off[1] + (ty >> 1) * gsr_pyr_dim(tiles_x, 1) + (tx >> 1)] = v;
+    v = __builtin_fmaxf(v, __shfl_xor(v, 4, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 8, 64));
+    if ((lane & 15) == 0 && inside) pyr[hz.pyr_off[2] + (ty >> 2) * gsr_pyr_dim(tiles_x, 2) + (tx >> 2)] = v;
+    v = __builtin_fmaxf(v, __shfl_xor(v, 16, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 32, 64));
+    if (lane == 0) {
+        pyr[hz.pyr_off[3] + by * nbx + bx] = v;
+        // levels 4 and 5 (cleared by k_sum_work, which runs before this kernel): horizons are >= 0, so their bit patterns order like
+        // unsigned integers
+        atomicMax(reinterpret_cast<uint32_t*>(pyr) + hz.pyr_off[4] + (by >> 1) * gsr_pyr_dim(tiles_x, 4) + (bx >> 1), __float_as_uint(v));
+        atomicMax(reinterpret_cast<uint32_t*>(pyr) + hz.pyr_off[5] + (by >> 2) * gsr_pyr_dim(tiles_x, 5) + (bx >> 2), __float_as_uint(v));
+    }
 }
 
 // Heaviest tiles first.  The blend kernel's workgroups are dispatched in blockIdx order as slots free up; when a frame's tiles

@@ -105,25 +105,40 @@ k_cluster_bounds(uint32_t n, const float4* __restrict__ geoA, const uint4* __res
 }
 
 // ---- per frame ----------------------------------------------------------------------------------------------------------
-// Depth horizons live in a max pyramid over the tile grid (k_blend.h: k_tile_pass / k_sum_work build it): level l cell (x, y)
-// = the largest horizon of the tiles [x 2^l, (x+1) 2^l) x [y 2^l, (y+1) 2^l), up to the level that is a single cell; +inf =
-// no horizon (nothing may be culled there), 0 = a tile of another rank (nothing is needed there).
-#define GSR_PYR_MAX_LEVELS 10          // a grid of up to 512 x 512 tiles
-#define GSR_PYR_FLOATS (512 * 512 + 256 * 256 + 128 * 128 + 64 * 64 + 32 * 32 + 16 * 16 + 8 * 8 + 4 * 4 + 2 * 2 + 1 + 16)
+// Depth horizons live in a 6-level max pyramid over the tile grid (k_blend.h: k_tile_pass forms the per-tile horizons,
+// k_horizon_dilate widens each by the frame's dilation radius and builds the levels): level l cell (x, y) = the largest
+// (dilated) horizon of the tiles [x 2^l, (x+1) 2^l) x [y 2^l, (y+1) 2^l); +inf = no horizon (nothing may be culled there), 0 =
+// a tile of another rank (nothing is needed there).
+#define GSR_PYR_LEVELS 6
+#define GSR_PYR_FLOATS (512 * 512 + 256 * 256 + 128 * 128 + 64 * 64 + 32 * 32 + 16 * 16 + 16)   // a grid of up to 512 x 512 tiles
+#define GSR_DILATE_EXACT_MAX 3         // the dilation k_horizon_dilate applies tile by tile; what a frame wants beyond that
+                                       // is added by widening the rects at look-up time
 __host__ __device__ __forceinline__ int gsr_pyr_dim(int tiles, int level) { return ((tiles - 1) >> level) + 1; }
-// largest horizon over the tile rect [x0, x1] x [y0, y1] (inside the grid), widened to the 2 x 2 cells of the finest level
-// at which it spans no more than that.  MONOTONE: a rect that contains another never gets a smaller value (its cells are
-// unions of the other's), which is what lets k_tile_pass check a tile against the value of the tile's own dilated
-// neighbourhood -- every splat that touches the tile was compared with at least that.
+// largest horizon over the tile rect [x0, x1] x [y0, y1] (inside the grid), widened to the 2 x 2 cells of the finest level at
+// which it spans no more than that -- or, beyond the top level, to up to 4 x 4 of its cells; +inf for a still larger rect.
+// MONOTONE: a rect that contains another never gets a smaller value (its cells are unions of the other's), which is what lets
+// k_tile_pass check a tile against the value of the tile itself -- every splat that touches the tile was compared with at
+// least that.
 __device__ __forceinline__ float gsr_pyr_max(const float* __restrict__ pyr, const int32_t* pyr_off, int tiles_x, int x0, int y0, int x1, int y1)
 {
     const int span = max(x1 - x0, y1 - y0);
     int L = 31 - __builtin_clz((uint32_t)span | 1u);
     if (((x1 >> L) - (x0 >> L)) > 1 || ((y1 >> L) - (y0 >> L)) > 1) ++L;
-    const int w = gsr_pyr_dim(tiles_x, L);
-    const float* p = pyr + pyr_off[L];
-    const int a0 = x0 >> L, a1 = x1 >> L, b0 = y0 >> L, b1 = y1 >> L;
-    return __builtin_fmaxf(__builtin_fmaxf(p[b0 * w + a0], p[b0 * w + a1]), __builtin_fmaxf(p[b1 * w + a0], p[b1 * w + a1]));
+    if (L < GSR_PYR_LEVELS) {
+        const int w = gsr_pyr_dim(tiles_x, L);
+        const float* p = pyr + pyr_off[L];
+        const int a0 = x0 >> L, a1 = x1 >> L, b0 = y0 >> L, b1 = y1 >> L;
+        return __builtin_fmaxf(__builtin_fmaxf(p[b0 * w + a0], p[b0 * w + a1]), __builtin_fmaxf(p[b1 * w + a0], p[b1 * w + a1]));
+    }
+    const int T = GSR_PYR_LEVELS - 1;
+    const int a0 = x0 >> T, a1 = x1 >> T, b0 = y0 >> T, b1 = y1 >> T;
+    if (a1 - a0 > 3 || b1 - b0 > 3) return __builtin_inff();
+    const int w = gsr_pyr_dim(tiles_x, T);
+    const float* p = pyr + pyr_off[T];
+    float h = 0.0f;
+    for (int b = b0; b <= b1; ++b)
+        for (int a = a0; a <= a1; ++a) h = __builtin_fmaxf(h, p[b * w + a]);
+    return h;
 }
 
 // one thread per cluster; workgroup b handles the clusters [b * per, (b + 1) * per), per = CC_THREADS * rounds, and leaves

@@ -42,7 +42,8 @@ class gsr_stats(C.Structure):
                 ("stage_frames", C.c_int64), ("sorts_skipped", C.c_int64), ("frames_requeued", C.c_int64),
                 ("lazy_redo_tiles", C.c_int64), ("lazy_colours_total", C.c_int64), ("frames_truncated", C.c_int64),
                 ("frames_culled", C.c_int64), ("frames_repaired", C.c_int64),
-                ("clusters_total", C.c_int64), ("clusters_kept", C.c_int64)]
+                ("clusters_total", C.c_int64), ("clusters_kept", C.c_int64),
+                ("policy_bits", C.c_int32), ("cull_dilate", C.c_int32), ("cull_holdoff", C.c_int32), ("reserved2_", C.c_int32)]
 
     def as_dict(self) -> dict:
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -435,7 +436,7 @@ class Engine:
 
     def debug_tile_work(self) -> np.ndarray:
         """[tiles_y, tiles_x, 4] uint32: list entries scanned / records gathered / wave-record evaluations / saturated flag
-        per tile (last frame)"""
+        per tile (last frame; the fourth word: bit 0 = went opaque, the rest = the 1024-entry scan step that held its first hit)"""
         st = self.stats()
         nt = st["tiles_x"] * st["tiles_y"]
         out = np.zeros((nt, 4), np.uint32)

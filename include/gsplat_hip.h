@@ -95,6 +95,13 @@ typedef struct gsr_stats {
     int64_t frames_repaired;               /* ... of which this many broke a horizon and were rendered again without culling */
     int64_t clusters_total;                /* clusters of 64 storage-ordered splats (k_cluster.h) */
     int64_t clusters_kept;                 /* ... that survived the cluster culling of the last frame whose count reached the host */
+    int32_t policy_bits;                   /* what the kernels told the host about the last frames: 1 = lazy colour pays, 2 = a heaviest-first
+                                              tile order pays, 4 = occlusion culling has something to work with, 8 = the last culled frame
+                                              kept more than 70 % of what an unculled one keeps (culling suspended), 16 = colouring list prefixes is
+                                              cheaper than colouring every kept splat */
+    int32_t cull_dilate;                   /* occlusion culling: current dilation radius in tiles (GSR_OPT_CULL_DILATE, grown by repairs) */
+    int32_t cull_holdoff;                  /* ... frames for which it stays switched off */
+    int32_t reserved2_;
 } gsr_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -291,7 +298,7 @@ int  gsr_debug_read_storage_order(gsr_context* ctx, int32_t* perm, int64_t n);
 int  gsr_debug_read_tile_lists(gsr_context* ctx, int32_t* list_start, int32_t* list_end, int64_t n_lists,
                                int32_t* pair_splat, int64_t n_pairs);
 
-/* per tile of the last frame, four uint32: {list entries scanned, records gathered, wave-record evaluations, 1 if the tile
+/* per tile of the last frame, four uint32: {list entries scanned, records gathered, wave-record evaluations, bit 0: the tile
  * stopped because every pixel was opaque} as the blend kernel counted them */
 int  gsr_debug_read_tile_work(gsr_context* ctx, uint32_t* work4, int64_t n_tiles);
 

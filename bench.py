@@ -34,6 +34,20 @@ import __graft_entry__ as ge  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def measured_hbm_peak():
+    """what this GPU's HBM delivers to a 16-byte-per-lane streaming kernel (tools/ubench_hbm.hip, built by __graft_entry__.build()):
+    the second denominator of the rooflines.  None when the binary is missing."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "ubench_hbm")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1]
+        return json.loads(out)
+    except Exception:
+        return None
+
+
 def kernel_source_sha() -> str:
     """fingerprint of the kernel sources: ties profiles/pmc_traffic.json to the kernels it was collected with"""
     import hashlib
@@ -55,7 +69,7 @@ def parse_args():
                     "open sky) and S1 (a thin wall) are extra scenes with silhouettes")
     ap.add_argument("--splats", type=int, default=None, help="override the splat count (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="wall budget of the cpu_baseline leg (23 frames of a sample sized to fit)")
     ap.add_argument("--no-swizzle", action="store_true", help="disable the XCD-aware tile mapping (A/B)")
     ap.add_argument("--morton", action="store_true", help="experiment: hand the splats over in Morton order of their positions")
     ap.add_argument("--time-every", type=int, default=0, help="HIP events around the blend kernel of every N-th frame of the timed region; "
@@ -65,6 +79,7 @@ def parse_args():
     ap.add_argument("--cluster-cull", type=int, default=1, help="0 = no cluster culling in front of K1 (A/B)")
     ap.add_argument("--storage-order", type=int, default=1, help="0 = splats stored in upload order instead of Morton order (A/B)")
     ap.add_argument("--dilate", type=int, default=-1, help="GSR_OPT_CULL_DILATE (A/B; -1 = library default)")
+    ap.add_argument("--local-sort", type=int, default=1, help="GSR_OPT_LOCAL_SORT (A/B)")
     ap.add_argument("--tile-order", type=int, default=2, help="1 = XCD-aware static tile order, 2 = + heaviest tiles first (A/B)")
     ap.add_argument("--super-tile", type=int, default=0, help="super-tile edge in tiles (0 = auto) (A/B)")
     ap.add_argument("--flags", type=int, default=0, help="GSR_OPT_DEBUG_FLAGS (A/B)")
@@ -104,27 +119,25 @@ def cpu_baseline(oracle, splats, cam0, pkg, budget_s: float) -> dict:
     HDK/GL path cannot run without Houdini) timed on the host cores, bounded in wall time."""
     threads = oracle.max_threads()
     n = splats.n
-    # probe on 1/16 of the scene to size the sample
-    probe_n = max(1, n // 16)
+    # BASELINE.md asks for the median of >= 20 frames after 3 warm-ups; the contract bounds the leg to tens of seconds.  So the
+    # SAMPLE is a prefix of the scene sized (from a probe on 1/32 of it) so that 23 frames fit the budget.
+    probe_n = max(1, n // 32)
     sub = splats.subset(slice(0, probe_n))
+    oracle.render(sub, cam0, threads=threads)
     t0 = time.perf_counter()
     oracle.render(sub, cam0, threads=threads)
     t_probe = time.perf_counter() - t0
-    est_full = t_probe * 16.0
-    frac = 1.0 if est_full * 2.0 <= budget_s else max(1.0 / 16.0, min(1.0, budget_s / (2.0 * est_full)))
+    frames_wanted, warm = 20, 3
+    frac = min(1.0, max(1.0 / 64.0, budget_s / ((frames_wanted + warm) * t_probe * 32.0)))
     sample_n = max(1, int(n * frac))
     sub = splats if sample_n == n else splats.subset(slice(0, sample_n))
     times = []
-    t_start = time.perf_counter()
-    frame = 0
-    while True:
+    for frame in range(warm + frames_wanted):
         cam = pkg.camera.make_camera(cam0.width, cam0.height, sh_order=cam0.sh_order, frame=frame)
         t0 = time.perf_counter()
         oracle.render(sub, cam, threads=threads)
-        times.append(time.perf_counter() - t0)
-        frame += 1
-        if time.perf_counter() - t_start > budget_s * 0.6 or frame >= 20:
-            break
+        if frame >= warm:
+            times.append(time.perf_counter() - t0)
     t_med = float(np.median(times))
     fps_sample = 1.0 / t_med
     # the reference's own per-camera-move HOST stage (squared distances + parallel comparison argsort of the indices,
@@ -143,9 +156,10 @@ def cpu_baseline(oracle, splats, cam0, pkg, budget_s: float) -> dict:
         "kind": "port",
         "sample": (f"oracle (C/OpenMP port of the reference semantics: per-splat SH+projection, argsort, per-pixel "
                    f"gaussian + under-blend) on the first {sample_n} of {n} splats, {cam0.width}x{cam0.height}, "
-                   f"{len(times)} frames, median {t_med * 1e3:.1f} ms/frame; value = sample fps x {sample_n}/{n} "
-                   f"(work is linear in splats)"),
+                   f"median of {len(times)} frames after 3 warm-ups: {t_med * 1e3:.1f} ms/frame; value = sample fps x {sample_n}/{n} "
+                   f"(per-splat work is linear in splats; per-pixel work grows more slowly, so this flatters the CPU)"),
         "sample_fps": fps_sample,
+        "frames": len(times),
         "reference_host_stage_ms": host_stage_ms,
         "reference_host_stage": (f"argsortByDistance restated (distance^2 + __gnu_parallel::sort of int indices by indirect float "
                                  f"compare, standing in for tbb::parallel_sort) on all {n} splats, {threads} threads: median of 3"),
@@ -204,6 +218,7 @@ def main():
     eng.set_stream(stream.cuda_stream)
     eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, args.cull)
     eng.set_option(pkg.engine.OPT_CLUSTER_CULL, args.cluster_cull)
+    eng.set_option(pkg.engine.OPT_LOCAL_SORT, args.local_sort)
     if args.dilate >= 0:
         eng.set_option(pkg.engine.OPT_CULL_DILATE, args.dilate)
     eng.set_option(pkg.engine.OPT_STORAGE_ORDER, args.storage_order)
@@ -326,9 +341,15 @@ def main():
     # k_preprocess / k_colour_prefix durations.  Kept out of the timed region: six extra events per frame stall the queue ~35 us.
     st_stage = None
     if not args.no_extra_legs:
+        # ... in the regime of the timed region: the orbit simply continues (re-rendering its last frames), and the leg's first
+        # two frames -- which still see the horizons / hints of the frame before the leg -- are not counted
         eng.set_option(pkg.engine.OPT_STAGE_TIMING, 2)
+        last = args.warmup + args.steps
+        for i in range(max(0, last - 12), max(0, last - 10)):
+            step(i)
+        torch.cuda.synchronize()
         eng.stats_reset()
-        for i in range(min(10, args.warmup + args.steps)):
+        for i in range(max(0, last - 10), last):
             step(i)
         torch.cuda.synchronize()
         st_stage = eng.stats()
@@ -397,19 +418,23 @@ def main():
     traffic, traffic_from = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     tj = None
+    regime = "culled" if st["frames_culled"] * 2 > st["frames"] else "unculled"
     if os.path.exists(tpath) and world == 1 and args.config == "C4" and args.splats is None:
         try:
-            tj = json.load(open(tpath))
-            if tj.get("_kernel_source_sha") != kernel_source_sha():
-                tj = None       # stale: collected with other kernels
-            else:
+            tall = json.load(open(tpath))
+            if tall.get("_kernel_source_sha") == kernel_source_sha():   # (else stale: collected with other kernels)
+                tj = tall.get(regime)
                 traffic = float(next(v for k, v in tj.items() if "k_blend" in k)["hbm_bytes_per_launch"])
-                traffic_from = "profiles/pmc_traffic.json (" + str(tj.get("_collected", "rocprofv3 --pmc passes of this command")) + ")"
+                traffic_from = f"profiles/pmc_traffic.json[{regime}] (" + str(tall.get("_collected", "rocprofv3 --pmc passes of this command")) + ")"
         except Exception:
             traffic, tj = None, None
+    hbm = measured_hbm_peak() if rank == 0 else None
+    peak_meas = hbm["copy_GBps"] if hbm else None
     roofline = {
         "bound": "hbm", "kernel": "k_blend", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_replayed_from": traffic_from,
+        "frac": achieved / HBM_PEAK_GBPS, "peak_measured": peak_meas, "frac_of_measured": (achieved / peak_meas) if peak_meas else None,
+        "peak_measured_by": "tools/ubench_hbm.hip: float4 copy over 1 GiB arrays on this GPU" if hbm else None, "hbm_ubench": hbm,
+        "regime": regime, "traffic": traffic, "traffic_replayed_from": traffic_from,
         "avg_launch_ms": blend_ms, "launches_timed": int(st["blend_launches"]), "launches": int(st["frames"]),
         "algorithmic_bytes_per_launch": bytes_blend,
         "pairs_consumed_per_launch": d_eff, "bytes_per_consumed_pair": pair_b + rec_b,
@@ -459,7 +484,8 @@ def main():
             k1_traffic = None
         k1_gbps = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         roofline_k1 = {"bound": "hbm", "kernel": "k_preprocess", "achieved": k1_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                       "frac": k1_gbps / HBM_PEAK_GBPS, "traffic": k1_traffic, "avg_launch_ms": k1_ms,
+                       "frac": k1_gbps / HBM_PEAK_GBPS, "peak_measured": peak_meas, "frac_of_measured": (k1_gbps / peak_meas) if peak_meas else None,
+                       "traffic": k1_traffic, "avg_launch_ms": k1_ms,
                        "algorithmic_bytes_per_launch": k1_bytes,
                        "splats_kept": int(nvis),
                        "note": ("lazy colour: geometry only (32 B in per splat, 48 + 12 B out per splat that stays)" if lazy_on else "eager colour") +

@@ -45,7 +45,9 @@ static_assert(RS_SRC_BLOCK == GSR_K1_THREADS, "the gathering sort pass reads K1'
 #define GSR_VERSION_STR "gsplat_hip 0.1.0 (gfx950)"
 #define GSR_MAX_SLOTS 2
 #define GSR_STAGE_EVENTS 7
-#define GSR_SPIN_US 300          // how long a host wait for a mailbox word spins before it blocks in the runtime
+#ifndef GSR_SPIN_US
+#define GSR_SPIN_US 2000         // how long a host wait for a mailbox word spins before it blocks in the runtime
+#endif
 
 static thread_local char g_err[512] = "";
 
@@ -90,6 +92,9 @@ struct FrameJob {
     const float* d_depth = nullptr;
     bool out_is_device = false, timing = false, timing_all = false, use_map = false;
     bool speculative = false;      // the back end was queued before the pair count was known
+    bool local_sort = false;       // the depth sort took the small-frame form (k_sort.h) ...
+    bool sort_failed = false;      // ... and gave a bucket up: the frame is rendered again with the three global passes
+    bool ranges_folded = false;    // ... and k_bin_place forms the list ranges and posts the pair count itself (no k_bin_ranges launch)
     bool deferred = false;         // ... and the frame handed over without waiting for it (GSR_OPT_DEFERRED_CHECK)
     bool lazy = false;             // K1 left the SH colours pending (k_colour.h)
     bool cull = false;             // occlusion culling: k_cluster_cull and K1 drop what lies behind the slot's depth horizons
@@ -146,8 +151,11 @@ struct FrameSlot {
     // cluster culling (k_cluster.h): the ordered list of surviving clusters of the frame, as per-workgroup segments
     uint32_t* cseg = nullptr;          // [ngroups * per]
     uint32_t* ccnt = nullptr;          // [CC_MAX_GROUPS]
-    uint32_t* d_counts = nullptr;      // [0] slots K1 filled, [1] surviving clusters
+    uint32_t* d_counts = nullptr;      // [0] slots K1 filled, [1] surviving clusters, [2] the small-frame sort gave a bucket up
     uint32_t surv_hint = 0;            // surviving clusters of this slot's last frame (sizes K1's grid; 0 = unknown)
+    uint32_t kept_hint = 0;            // splats that reached the depth sort in this slot's last frame (picks the sort; 0 = unknown)
+    uint32_t kept_lo = 0, kept_hi = 0; // ... and the smallest / largest of their keys, as float bits of the distance^2 (0, 0 = unknown)
+    bool kept_culled = false;          // ... in a frame that was occlusion-culled (an unculled one keeps ten times as much: no prediction across)
     unsigned long long* h_end = nullptr;      // pinned + mapped: ticket << 32 | violation
     unsigned long long* h_end_dev = nullptr;
     bool horizon_valid = false;
@@ -221,7 +229,8 @@ struct gsr_context {
 
     int shard_index = 0, shard_count = 1, shard_layout = 0;   // layout: 0 = interleaved rows, 1 = contiguous bands
     int opt_swizzle = 2, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0, opt_lazy = 1, opt_cull = 1, opt_timing_every = 1;
-    int opt_cluster = 1, opt_morton = 1;
+    int opt_cluster = 1, opt_morton = 1, opt_local_sort = 1;
+    bool classic_once = false;         // the next frame sorts with the three global passes whatever the prediction says
 
     gsr_stats st{};
     uint64_t frame_no = 0;
@@ -267,6 +276,14 @@ static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; 
 extern "C" int gsr_debug_sw_profile(unsigned long long* out8) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sw_prof), 64);
+    return 0;
+}
+#endif
+#ifdef GSR_DEBUG_XCC
+extern "C" int gsr_debug_xcc(unsigned* out4, int reset) {
+    hipDeviceSynchronize();
+    if (out4) hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_dbg_xcc), 16);
+    if (reset) { void* p = nullptr; hipGetSymbolAddress(&p, HIP_SYMBOL(g_dbg_xcc)); hipMemset(p, 0, 16); }
     return 0;
 }
 #endif
@@ -321,8 +338,8 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hraw), 512 * 512 * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.ccnt), CC_MAX_GROUPS * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_counts), 2 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMemset(sl.d_counts, 0, 2 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_counts), 4 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(sl.d_counts, 0, 4 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_end), sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
     if (ok) sl.h_end[0] = 0ull;
     ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_end_dev), sl.h_end, 0) == hipSuccess;
@@ -462,6 +479,7 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
     case GSR_OPT_LAZY_COLOUR: c->opt_lazy = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_SHARD_LAYOUT: c->shard_layout = value ? 1 : 0; break;
     case GSR_OPT_CLUSTER_CULL: c->opt_cluster = value ? 1 : 0; break;
+    case GSR_OPT_LOCAL_SORT: c->opt_local_sort = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_CULL_DILATE: c->opt_dilate = value < 0 ? 0 : (value > 64 ? 64 : value); c->cull_dilate = c->opt_dilate; break;
     case GSR_OPT_STORAGE_ORDER: c->opt_morton = value ? 1 : 0; break;   // (takes effect at the next upload)
     case GSR_OPT_SUPER_TILE:
@@ -628,7 +646,7 @@ extern "C" int gsr_upload_end(gsr_context* c)
     c->prefix_valid = false;           // lazy colour: the first frame of a new cloud colours every list completely
     c->order_pays = false;
     c->cull_pays = false; c->cull_holdoff = 0; c->cull_backoff = 8; c->cull_streak = 0; c->vis_unculled = 0; c->cull_dilate = c->opt_dilate;
-    for (int k = 0; k < GSR_MAX_SLOTS; ++k) { c->slot[k].surv_hint = 0; c->slot[k].horizon_valid = false; }
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k) { c->slot[k].surv_hint = 0; c->slot[k].kept_hint = 0; c->slot[k].kept_lo = c->slot[k].kept_hi = 0; c->slot[k].horizon_valid = false; }
     c->lazy_pays = false;              // ... and in automatic mode the first frames are eager until the kernels say it pays
     c->st.n_splats = c->n;
     return GSR_OK;
@@ -705,16 +723,16 @@ static int ensure_u32(uint32_t** p, size_t* cap, size_t need)
     return GSR_OK;
 }
 
-template <typename V, int DBITS, bool GATHER>
+template <typename V, int DBITS, bool GATHER, bool CLAMP = false>
 static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, uint32_t n, const uint32_t* n_dev,
-                      int shift, uint32_t nblk, bool contig, uint32_t* n_out = nullptr, const uint32_t* src_cnt = nullptr)
+                      int shift, uint32_t nblk, bool contig, uint32_t* n_out = nullptr, const uint32_t* src_cnt = nullptr, uint32_t lo = 0u)
 {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS, GATHER>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, n,
-                       n_dev, shift, sl.hist, nblk, contig, src_cnt);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS, GATHER, CLAMP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, n,
+                       n_dev, shift, sl.hist, nblk, contig, src_cnt, lo);
     hipLaunchKernelGGL(k_scan_rows, dim3(1u << DBITS), dim3(SC_THREADS), 0, sl.stream, sl.hist, nblk, sl.totals, n_dev, n,
                        (uint32_t)RS_TILE);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS, GATHER>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA,
-                       vA, kB, vB, n, n_dev, shift, sl.hist, sl.totals, nblk, contig, n_out, src_cnt);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS, GATHER, CLAMP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA,
+                       vA, kB, vB, n, n_dev, shift, sl.hist, sl.totals, nblk, contig, n_out, src_cnt, lo);
     HIP_TRY(hipGetLastError());
     return GSR_OK;
 }
@@ -1021,6 +1039,16 @@ static inline int mark(FrameSlot& sl, int k)
 // kernels clamp to the buffer's capacity) and the host reads D while the GPU is already placing: the stream
 // never drains mid-frame.  Only if D turns out to exceed the capacity (first frame, or the pair count grew by
 // more than the 25 % headroom) is the buffer regrown and the back end run again.
+static GsrRangeArgs range_args(gsr_context* c, FrameSlot& sl)
+{
+    const FrameJob& j = sl.job;
+    GsrRangeArgs a;
+    a.totals = sl.totals; a.n_super = j.n_super; a.sstart = sl.sstart; a.send = sl.send; a.host_total = sl.h_total_dev;
+    a.ticket = j.ticket; a.max_pairs = (unsigned long long)GSR_MAX_PAIRS; a.redo_count = reinterpret_cast<uint32_t*>(sl.lazy_ctr);
+    a.lazy_hint = c->lazy_hint; a.n_sorted = sl.d_n; a.k1_counts = sl.d_counts; a.sorted_keys = sl.keyA;
+    return a;
+}
+
 static int queue_back_end(gsr_context* c, FrameSlot& sl)
 {
     const FrameJob& j = sl.job;
@@ -1033,7 +1061,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         const size_t lds = (size_t)4 * BN_ITEMS * j.n_super * 8 + (size_t)4 * j.n_super * 4;
         hipLaunchKernelGGL(k_bin_place, dim3(nblk), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n, f.super_shift,
                            GsrShard{f.shard_index, f.shard_count, f.shard_rpb}, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk,
-                           (uint32_t)sl.pair_cap, sl.pvA);
+                           (uint32_t)sl.pair_cap, sl.pvA, j.ranges_folded ? range_args(c, sl) : GsrRangeArgs{});
         HIP_TRY(hipGetLastError());
     }
     if ((rc = mark(sl, 4))) return rc;
@@ -1222,6 +1250,24 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
         }
         c->order_pays = (box[1] & 2ull) != 0ull;   // (written before the ticket) k_sum_work's verdict on the frame before
         sl.surv_hint = (uint32_t)box[2];           // clusters that survived k_cluster_cull: sizes the next frame's K1 grid
+        sl.kept_hint = (uint32_t)(box[1] >> 32);   // ... and how many splats reached the depth sort: picks the next frame's sort
+        sl.kept_culled = j.cull;
+        j.sort_failed = j.local_sort && (box[1] & 32ull) != 0ull;
+        if (j.sort_failed) {
+            // the small-frame sort gave a bucket up: this frame's order, lists and pair count mean nothing.  frame_check renders it
+            // again (three global passes); nothing of it is kept -- not the order (sort cache), not its bookkeeping (no frame end)
+            sl.sort_valid = false;
+            sl.kept_hint = 0; sl.kept_lo = sl.kept_hi = 0;
+            sl.last_pairs = 0;
+            j.open = false;
+            return GSR_OK;
+        }
+        if (sl.kept_hint > 0) {                    // ... between which keys (stored relative to THIS frame's key_min)
+            sl.kept_lo = (uint32_t)box[3] + j.f.key_min;
+            sl.kept_hi = (uint32_t)(box[3] >> 32) + j.f.key_min;
+        } else {
+            sl.kept_lo = sl.kept_hi = 0;
+        }
         if (D == 0xffffffffu || (unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
             return frame_abort(sl, set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: the frame's super-tile pairs exceed the limit of %lld", GSR_MAX_PAIRS));
         const bool short_buffer = D > sl.pair_cap;
@@ -1441,8 +1487,46 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         int key_bits = 1;
         while (key_bits < 32 && ((f.key_max - f.key_min) >> key_bits) != 0u) ++key_bits;
         // (the sort's grids are sized for the slots K1 could fill at most; the number it did fill is in d_counts[0])
-        rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n ? div_up(c->nclus, 4u) * (uint32_t)GSR_K1_THREADS : 0u, key_bits,
-                        !(c->opt_flags & GSR_FLAG_FULL_KEYS), sl.d_n, RS_XCD_DEPTH != 0, sl.blk_cnt, sl.d_counts);
+        const uint32_t n_slots = n ? div_up(c->nclus, 4u) * (uint32_t)GSR_K1_THREADS : 0u;
+        // A frame that keeps few splats (occlusion culling; small clouds) sorts them with ONE global pass on the top 9 key bits and
+        // one local kernel (k_sort.h) instead of three global passes: 4 launches instead of 9.  Correct for any count; chosen
+        // from what the slot's previous frame kept.
+        // (not for deferred frames: nobody could render them again; and no prediction from a culled frame for an unculled one)
+        const bool local = n_slots > 0 && key_bits > 9 && !(c->opt_flags & GSR_FLAG_FULL_KEYS) && sl.kept_hi > sl.kept_lo && !j.deferred &&
+                           !c->classic_once && sl.kept_culled == j.cull &&
+                           (c->opt_local_sort >= 2 || (c->opt_local_sort == 1 && sl.kept_hint > 0 && sl.kept_hint <= 1200000u));
+        c->classic_once = false;
+        j.local_sort = local;
+        if (local) {
+            // 512 buckets of equal width over the key range the previous frame kept, widened by a sixteenth on either side (the
+            // view moves); in this frame's key domain (keys are stored relative to key_min)
+            const uint64_t span = (uint64_t)sl.kept_hi - sl.kept_lo, margin = span / 16 + 64;
+            const uint64_t lo_abs = sl.kept_lo > margin ? sl.kept_lo - margin : 0, hi_abs = (uint64_t)sl.kept_hi + margin;
+            const uint32_t lo = lo_abs > f.key_min ? (uint32_t)(lo_abs - f.key_min) : 0u;
+            const uint64_t width = (hi_abs > f.key_min ? hi_abs - f.key_min : 0) - lo + 1;
+            int bshift = 0;
+            while (bshift < 31 && (width >> bshift) > 512) ++bshift;
+            const uint32_t nblk = div_up(n_slots, RS_TILE);
+            rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)512 * nblk + 8);
+            if (!rc) rc = radix_pass<uint2, 9, true, true>(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n_slots, sl.d_counts, bshift, nblk, RS_XCD_DEPTH != 0,
+                                                           sl.d_n, sl.blk_cnt, lo);
+            if (!rc) {   // buckets (keyB, valB) -> sorted (keyA, valA)
+#ifdef GSR_DEBUG_LOCAL_TIMING
+                static double acc = 0; static long cnt = 0;
+                const auto t0_ = std::chrono::steady_clock::now();
+#endif
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_local<uint2>), dim3(512), dim3(RL_THREADS), 0, s, sl.totals, 512, bshift, key_bits, lo,
+                                   sl.keyB, sl.valB, sl.keyA, sl.valA, sl.d_counts + 2);
+#ifdef GSR_DEBUG_LOCAL_TIMING
+                acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0_).count();
+                if (++cnt % 50 == 0) fprintf(stderr, "[k_radix_local launch] host %.1f us avg, bshift %d lo %u key_bits %d kept_hint %u\n", acc / cnt, bshift, lo, key_bits, sl.kept_hint);
+#endif
+                if (hipGetLastError() != hipSuccess) rc = set_err(GSR_E_HIP, "k_radix_local: launch failed");
+            }
+        } else {
+            rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n_slots, key_bits,
+                            !(c->opt_flags & GSR_FLAG_FULL_KEYS), sl.d_n, RS_XCD_DEPTH != 0, sl.blk_cnt, sl.d_counts);
+        }
         if (rc) return frame_abort(sl, rc);
         sl.key_min = f.key_min;
         sl.sort_valid = true;
@@ -1459,8 +1543,9 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift,
                            GsrShard{f.shard_index, f.shard_count, f.shard_rpb}, f.stiles_x, sl.hist, nblk);
         hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals, sl.d_n, n, (uint32_t)BN_TILE);
-        hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, sl.totals, j.n_super, sl.sstart, sl.send, sl.h_total_dev,
-                           j.ticket, (unsigned long long)GSR_MAX_PAIRS, reinterpret_cast<uint32_t*>(sl.lazy_ctr), c->lazy_hint, sl.d_n, sl.d_counts);
+        // the list ranges and the pair count: formed by k_bin_place itself (queue_back_end) when the back end is queued
+        // speculatively; a frame without a list buffer needs the count first
+        if (!(sl.pair_cap > 0)) hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, range_args(c, sl));
         e = hipGetLastError();
     } else {
         e = hipMemsetAsync(sl.sstart, 0, ((size_t)j.n_super + 1) * 4, s);
@@ -1468,6 +1553,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     }
     if (e != hipSuccess) return frame_abort(sl, set_err(GSR_E_HIP, "gsr_render: binning: %s", hipGetErrorString(e)));
     j.speculative = n > 0 && sl.pair_cap > 0;
+    j.ranges_folded = j.speculative;
     if (j.speculative || n == 0) {
         if ((rc = queue_back_end(c, sl))) return frame_abort(sl, rc);
     } else {
@@ -1490,6 +1576,18 @@ static FrameSlot* latest_slot(gsr_context* c);
 static int frame_check(gsr_context* c, FrameSlot& slot, const gsr_camera* cam, const float* depth, int depth_is_device,
                        float* rgba_out, int out_is_device)
 {
+    if (slot.job.sort_failed) {
+        // the small-frame sort met a bucket far beyond its prediction and left it unsorted: the frame again, with the global sort
+        // (and without culling: a prediction that far off means the view jumped, and the horizons with it)
+        c->st.frames_resorted += 1;
+        c->classic_once = true;
+        c->frame_no -= 1;
+        c->st.frames -= 1;
+        FrameSlot* sl2 = nullptr;
+        int rc2 = frame_begin(c, cam, depth, depth_is_device, rgba_out, out_is_device, &sl2, false);
+        if (rc2) return rc2;
+        return frame_finish(c, *sl2);
+    }
     if (!slot.job.cull) return GSR_OK;
     bool broke = false;
     int rc = frame_verdict(c, slot, &broke);
@@ -1529,11 +1627,29 @@ extern "C" int gsr_render_depth(gsr_context* c, const gsr_camera* cam, const flo
                                 float* rgba_out, int out_is_device)
 {
     FrameSlot* sl = nullptr;
+#ifdef GSR_HOST_PHASES
+    static double acc[4] = {0, 0, 0, 0}, t_last_exit = 0; static long cnt = 0;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+#endif
     int rc = frame_begin(c, cam, depth, depth_is_device, rgba_out, out_is_device, &sl, true);
     if (rc) return rc;
     if (sl->job.deferred) return GSR_OK;   // GSR_OPT_DEFERRED_CHECK: the pair count is looked at by the next call that syncs
+#ifdef GSR_HOST_PHASES
+    const double t1 = now();
+#endif
     if ((rc = frame_finish(c, *sl))) return rc;
-    return frame_check(c, *sl, cam, depth, depth_is_device, rgba_out, out_is_device);
+#ifdef GSR_HOST_PHASES
+    const double t2 = now();
+#endif
+    rc = frame_check(c, *sl, cam, depth, depth_is_device, rgba_out, out_is_device);
+#ifdef GSR_HOST_PHASES
+    const double t3 = now();
+    acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; if (t_last_exit > 0) acc[3] += t0 - t_last_exit;
+    t_last_exit = t3;
+    if (++cnt % 50 == 0) { fprintf(stderr, "[host phases] begin %.1f  finish(pair wait + frame end) %.1f  check(verdict wait) %.1f  outside gsr_render %.1f us\n", acc[0] / 50, acc[1] / 50, acc[2] / 50, acc[3] / 50); acc[0] = acc[1] = acc[2] = acc[3] = 0; }
+#endif
+    return rc;
 }
 
 // split form for callers that drive several contexts from one thread (gsr_multi.cpp)
@@ -1828,7 +1944,20 @@ extern "C" int gsr_debug_read_tile_work(gsr_context* c, uint32_t* work4, int64_t
     return GSR_OK;
 }
 
+static int debug_sort_pairs(gsr_context* c, uint32_t* keys, uint32_t* vals, int64_t n64, int key_bits, bool local);
 extern "C" int gsr_debug_sort_pairs(gsr_context* c, uint32_t* keys, uint32_t* vals, int64_t n64, int key_bits)
+{
+    return debug_sort_pairs(c, keys, vals, n64, key_bits, false);
+}
+static thread_local uint32_t dbg_lo = 0;
+static thread_local int dbg_shift = 0;
+extern "C" int gsr_debug_sort_pairs_local(gsr_context* c, uint32_t* keys, uint32_t* vals, int64_t n64, int key_bits, uint32_t bucket_lo, int bucket_shift)
+{
+    if (bucket_shift < 0 || bucket_shift > 31) return set_err(GSR_E_INVALID, "gsr_debug_sort_pairs_local: bad bucket shift");
+    dbg_lo = bucket_lo; dbg_shift = bucket_shift;
+    return debug_sort_pairs(c, keys, vals, n64, key_bits, true);
+}
+static int debug_sort_pairs(gsr_context* c, uint32_t* keys, uint32_t* vals, int64_t n64, int key_bits, bool local)
 {
     if (!c || n64 < 0 || n64 > 0x7fffffffll || key_bits < 1 || key_bits > 32 || (n64 > 0 && (!keys || !vals)))
         return set_err(GSR_E_INVALID, "gsr_debug_sort_pairs: bad argument");
@@ -1846,7 +1975,17 @@ extern "C" int gsr_debug_sort_pairs(gsr_context* c, uint32_t* keys, uint32_t* va
     hipError_t e = hipMemcpyAsync(kA, keys, (size_t)n * 4, hipMemcpyHostToDevice, sl.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(vA, vals, (size_t)n * 4, hipMemcpyHostToDevice, sl.stream);
     if (e == hipSuccess) {
-        rc = radix_sort(sl, kA, vA, kB, vB, n, key_bits, true, (uint32_t*)nullptr, RS_XCD_DEPTH != 0);
+        if (local) {   // one global pass into 512 buckets of width 2^shift from lo, then every bucket on its own (k_radix_local)
+            const uint32_t nblk = div_up(n, RS_TILE);
+            rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)512 * nblk + 8);
+            // (the test hands the bucket range over in vals[n]: lo, and the bucket shift in key_bits' upper byte)
+            if (!rc) rc = radix_pass<uint32_t, 9, false, true>(sl, kA, vA, kB, vB, n, (const uint32_t*)nullptr, dbg_shift, nblk, RS_XCD_DEPTH != 0,
+                                                                (uint32_t*)nullptr, (const uint32_t*)nullptr, dbg_lo);
+            if (!rc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_local<uint32_t>), dim3(512), dim3(RL_THREADS), 0, sl.stream, sl.totals, 512,
+                                        dbg_shift, key_bits, dbg_lo, kB, vB, kA, vA, (uint32_t*)nullptr);
+        } else {
+            rc = radix_sort(sl, kA, vA, kB, vB, n, key_bits, true, (uint32_t*)nullptr, RS_XCD_DEPTH != 0);
+        }
         if (!rc) {
             e = hipMemcpyAsync(keys, kA, (size_t)n * 4, hipMemcpyDeviceToHost, sl.stream);
             if (e == hipSuccess) e = hipMemcpyAsync(vals, vA, (size_t)n * 4, hipMemcpyDeviceToHost, sl.stream);

@@ -12,7 +12,8 @@
 //   k_bin_count   per block of BN_TILE depth-ranked splats: how many of its (splat, super-tile)
 //                 pairs fall into each super-tile            -> hist[super][block]
 //   k_scan_rows   (k_sort.h) exclusive scan of every super-tile's row over the blocks
-//   k_bin_ranges  exclusive scan of the per-super-tile totals -> list ranges, pair count D
+//   (k_bin_ranges exclusive scan of the per-super-tile totals -> list ranges, pair count D: folded into k_bin_place, a launch of
+//                 its own only for a frame that has no list buffer yet)
 //   k_bin_place   every block re-derives its pairs and writes (splat index, tile rect) straight
 //                 to its final list position, in depth order
 // versus emit pairs -> radix pass (histogram + scatter) -> find ranges: 8 B written per pair
@@ -130,39 +131,60 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
         hist[(size_t)b * nblk + tile] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
 }
 
-// one workgroup: list range of every super-tile = exclusive scan of the totals; *host_total = pair count.
+// list range of every super-tile = exclusive scan of the totals; the pair count and the frame's other news go to the host.
 // The count is formed in 64 bits as well: past max_pairs (list positions are int32) every range is left empty and
 // the host is told 0xffffffff -- it reports GSR_E_TOO_MANY_PAIRS instead of compositing wrapped positions.
-__global__ void __launch_bounds__(BN_BINS)
-k_bin_ranges(const uint32_t* __restrict__ totals, int n_super, int32_t* __restrict__ sstart, int32_t* __restrict__ send,
-             volatile unsigned long long* __restrict__ host_total /* pinned, mapped */, uint32_t ticket, unsigned long long max_pairs,
-             uint32_t* __restrict__ redo_count /* the frame's list of tiles given up by the plain blend kernel starts empty */,
-             const uint32_t* __restrict__ lazy_hint /* k_sum_work's verdict on the previous frame, forwarded to the host */,
-             const uint32_t* __restrict__ n_sorted /* splats that reached the depth sort (what the frame kept) */,
-             const uint32_t* __restrict__ k1_counts /* [1] = clusters that survived k_cluster_cull */)
+struct GsrRangeArgs {
+    const uint32_t* totals;            // [256] pairs per super-tile (k_scan_rows)
+    int32_t n_super;
+    int32_t *sstart, *send;            // out: list ranges
+    volatile unsigned long long* host_total;   // pinned, mapped [4]: ticket << 32 | pair count; hints; surviving clusters; key range
+    uint32_t ticket;
+    unsigned long long max_pairs;
+    uint32_t* redo_count;              // the frame's list of tiles given up by the plain blend kernel starts empty
+    const uint32_t* lazy_hint;         // k_sum_work's verdict on the previous frame, forwarded to the host
+    const uint32_t* n_sorted;          // splats that reached the depth sort (what the frame kept)
+    const uint32_t* k1_counts;         // [1] = clusters that survived k_cluster_cull, [2] = the small-frame sort gave a bucket up
+    const uint32_t* sorted_keys;       // the frame's keys in depth order
+};
+// all 256 threads of a workgroup; returns this thread's (= super-tile's) list start.  publish: also write the ranges and the mailbox
+__device__ __forceinline__ uint32_t bn_ranges(const GsrRangeArgs& a, bool publish, uint32_t* s_wave /*[4]*/, unsigned long long* s_sum /*[4]*/)
 {
-    // word 1 of the mailbox: the hints in the low half, the frame's splat count in the high half; word 2: surviving clusters
-    if (threadIdx.x == 0) {
-        *redo_count = 0u;
-        host_total[1] = ((unsigned long long)*n_sorted << 32) | (unsigned long long)*lazy_hint;
-        host_total[2] = (unsigned long long)k1_counts[1];
+    if (publish && threadIdx.x == 0) {
+        // word 1 of the mailbox: the hints in the low half, the frame's splat count in the high half; word 2: surviving clusters;
+        // word 3: the smallest and the largest key of the frame (predicts the next frame's sort buckets, k_sort.h)
+        *a.redo_count = 0u;
+        const uint32_t ns = *a.n_sorted;
+        // (bit 5 of the hints: the small-frame sort gave a bucket up -- the lists of this frame are not to be trusted)
+        a.host_total[1] = ((unsigned long long)ns << 32) | (unsigned long long)(*a.lazy_hint & 31u) | (a.k1_counts[2] ? 32ull : 0ull);
+        a.host_total[2] = (unsigned long long)a.k1_counts[1];
+        a.host_total[3] = ns ? ((unsigned long long)a.sorted_keys[ns - 1u] << 32) | (unsigned long long)a.sorted_keys[0] : 0ull;
     }
-    __shared__ uint32_t s_wave[4];
-    __shared__ unsigned long long s_sum[4];
-    const uint32_t v = ((int)threadIdx.x < n_super) ? totals[threadIdx.x] : 0u;
+    const uint32_t v = ((int)threadIdx.x < a.n_super) ? a.totals[threadIdx.x] : 0u;
     unsigned long long w = v;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) w += __shfl_down(w, d, 64);
     if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = w;
     uint32_t tot;
     const uint32_t ex = block_excl_scan_256(v, s_wave, &tot);   // (its barriers publish s_sum too)
-    const bool too_many = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3] > max_pairs;
-    if ((int)threadIdx.x < n_super) {
-        sstart[threadIdx.x] = too_many ? 0 : (int32_t)ex;
-        send[threadIdx.x] = too_many ? 0 : (int32_t)(ex + v);
+    const bool too_many = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3] > a.max_pairs;
+    if (publish) {
+        if ((int)threadIdx.x < a.n_super) {
+            a.sstart[threadIdx.x] = too_many ? 0 : (int32_t)ex;
+            a.send[threadIdx.x] = too_many ? 0 : (int32_t)(ex + v);
+        }
+        // the host sizes the list buffer from it; it recognises THIS frame's count by the ticket in the upper half
+        if (threadIdx.x == 0) { *a.host_total = ((unsigned long long)a.ticket << 32) | (too_many ? 0xffffffffull : (unsigned long long)tot); __threadfence_system(); }
     }
-    // the host sizes the list buffer from it; it recognises THIS frame's count by the ticket in the upper half
-    if (threadIdx.x == 0) { *host_total = ((unsigned long long)ticket << 32) | (too_many ? 0xffffffffull : (unsigned long long)tot); __threadfence_system(); }
+    return too_many ? 0u : ex;
+}
+// on its own: only a frame whose list buffer does not exist yet (the host has to size it before anything is placed)
+__global__ void __launch_bounds__(BN_BINS)
+k_bin_ranges(GsrRangeArgs a)
+{
+    __shared__ uint32_t s_wave[4];
+    __shared__ unsigned long long s_sum[4];
+    (void)bn_ranges(a, true, s_wave, s_sum);
 }
 
 // Placement.  Inside a list the order must be the depth order of the splats, so the pairs of one
@@ -175,12 +197,24 @@ k_bin_ranges(const uint32_t* __restrict__ totals, int n_super, int32_t* __restri
 // Nothing is mutated between A and B, so a wave pays a handful of dependent LDS round trips in
 // total instead of several per group.
 // Dynamic LDS: lmask[4 waves][BN_ITEMS groups][ns] (u64) followed by wbase[4][ns] (u32), ns = n_super.
+// ranges.totals != NULL: the list ranges are formed HERE (every workgroup scans the 256 totals itself; workgroup 0 also writes
+// them out and posts the pair count) instead of by a k_bin_ranges launch in front: one launch floor less per frame.
 __global__ void __launch_bounds__(BN_THREADS)
 k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, GsrShard sh,
             int stiles_x, int ns, const uint32_t* __restrict__ offs, const int32_t* __restrict__ sstart,
-            uint32_t nblk, uint32_t cap, uint2* __restrict__ out)
+            uint32_t nblk, uint32_t cap, uint2* __restrict__ out, GsrRangeArgs ranges)
 {
+    static_assert(BN_THREADS == BN_BINS, "one thread per super-tile in the range scan");
     extern __shared__ unsigned long long bn_lds[];
+    __shared__ uint32_t s_start[BN_BINS];
+    __shared__ uint32_t s_rwave[4];
+    __shared__ unsigned long long s_rsum[4];
+    if (ranges.totals) {
+        s_start[threadIdx.x] = bn_ranges(ranges, blockIdx.x == 0, s_rwave, s_rsum);
+    } else {
+        s_start[threadIdx.x] = ((int)threadIdx.x < ns) ? (uint32_t)sstart[threadIdx.x] : 0u;
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long* lmask = bn_lds + (size_t)wave * BN_ITEMS * ns;                       // [g][d] of this wave
     uint32_t* wbase_all = reinterpret_cast<uint32_t*>(bn_lds + (size_t)4 * BN_ITEMS * ns);   // [wave][d]
@@ -211,7 +245,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     }
     __syncthreads();
     for (int d = threadIdx.x; d < ns; d += BN_THREADS) {   // counts -> first list position of each wave
-        uint32_t p = (uint32_t)sstart[d] + offs[(size_t)d * nblk + tile];
+        uint32_t p = s_start[d] + offs[(size_t)d * nblk + tile];
 #pragma unroll
         for (int w = 0; w < 4; ++w) { const uint32_t c = wbase_all[w * ns + d]; wbase_all[w * ns + d] = p; p += c; }
     }

@@ -57,6 +57,9 @@ __device__ unsigned long long g_blend_prof[BLP_MAX_WG][4][16];   // per workgrou
 // a tile's work in (roughly) instructions: wave-record evaluations, records gathered, list entries scanned
 __device__ __forceinline__ uint32_t gsr_tile_weight(const uint4& w) { return w.z * 32u + w.y * 8u + (w.x >> 1); }
 
+#ifdef GSR_DEBUG_XCC
+__device__ uint32_t g_dbg_xcc[4];
+#endif
 struct GsrBlendArgs {
     int32_t width, height;      // full image
     int32_t tiles_x;            // tiles per row
@@ -119,6 +122,15 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     } else {
         tile = a.use_map ? tile_map[blockIdx.x] : (int)blockIdx.x;
     }
+#ifdef GSR_DEBUG_XCC
+    if (threadIdx.x == 0) {   // does workgroup b really run on XCD b % 8?
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xfu;
+        atomicAdd(&g_dbg_xcc[(xcc == (blockIdx.x & 7u)) ? 0 : 1], 1u);
+        if (blockIdx.x == 0) g_dbg_xcc[2] = xcc;
+    }
+#endif
     if (tile < 0 || tile >= a.local_tiles) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef BL_PROFILE

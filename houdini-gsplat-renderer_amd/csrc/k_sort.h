@@ -113,10 +113,21 @@ __device__ __forceinline__ uint32_t rs_gather_slot(uint32_t q, uint32_t first_bl
     return (first_block + j) * (uint32_t)RS_SRC_BLOCK + (q - before);
 }
 
-template <int DBITS, bool GATHER>
+// the digit of a pass.  CLAMP (the bucket pass of the small-frame sort, below): digit = min((key - lo) >> shift, BINS - 1), 0 for
+// keys below lo -- monotone in the key, so the buckets are consecutive key ranges whatever [lo, lo + BINS << shift) turns out
+// to miss
+template <bool CLAMP>
+__device__ __forceinline__ uint32_t rs_digit(uint32_t key, int shift, uint32_t lo, uint32_t mask)
+{
+    if (!CLAMP) return (key >> shift) & mask;
+    const uint32_t t = key > lo ? (key - lo) >> shift : 0u;
+    return t < mask ? t : mask;
+}
+
+template <int DBITS, bool GATHER, bool CLAMP = false>
 __global__ void __launch_bounds__(RS_THREADS)
 k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n_host, const uint32_t* __restrict__ n_dev, int shift,
-             uint32_t* __restrict__ hist, uint32_t nblk, bool contig, const uint32_t* __restrict__ src_cnt)
+             uint32_t* __restrict__ hist, uint32_t nblk, bool contig, const uint32_t* __restrict__ src_cnt, uint32_t lo = 0u)
 {
     constexpr int BINS = 1 << DBITS;
     constexpr uint32_t MASK = BINS - 1;
@@ -134,21 +145,21 @@ k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n_host, const uint32_t*
         uint32_t c[RS_WAVE_BLOCKS];
         const uint32_t tot = rs_gather_counts(src_cnt, first_block, (n + RS_SRC_BLOCK - 1) / RS_SRC_BLOCK, c);
         for (uint32_t q = threadIdx.x & 63u; q < tot; q += 64u)
-            atomicAdd(&h[wave][(keys[rs_gather_slot(q, first_block, c)] >> shift) & MASK], 1u);
+            atomicAdd(&h[wave][rs_digit<CLAMP>(keys[rs_gather_slot(q, first_block, c)], shift, lo, MASK)], 1u);
     } else if (base + RS_TILE <= n) {
         const uint4* p = reinterpret_cast<const uint4*>(keys + base);
 #pragma unroll
         for (int k = 0; k < RS_ITEMS / 4; ++k) {
             uint4 v = p[k * RS_THREADS + threadIdx.x];
-            atomicAdd(&h[wave][(v.x >> shift) & MASK], 1u);
-            atomicAdd(&h[wave][(v.y >> shift) & MASK], 1u);
-            atomicAdd(&h[wave][(v.z >> shift) & MASK], 1u);
-            atomicAdd(&h[wave][(v.w >> shift) & MASK], 1u);
+            atomicAdd(&h[wave][rs_digit<CLAMP>(v.x, shift, lo, MASK)], 1u);
+            atomicAdd(&h[wave][rs_digit<CLAMP>(v.y, shift, lo, MASK)], 1u);
+            atomicAdd(&h[wave][rs_digit<CLAMP>(v.z, shift, lo, MASK)], 1u);
+            atomicAdd(&h[wave][rs_digit<CLAMP>(v.w, shift, lo, MASK)], 1u);
         }
     } else {
         for (int k = 0; k < RS_ITEMS; ++k) {
             uint32_t i = base + k * RS_THREADS + threadIdx.x;
-            if (i < n) atomicAdd(&h[wave][(keys[i] >> shift) & MASK], 1u);
+            if (i < n) atomicAdd(&h[wave][rs_digit<CLAMP>(keys[i], shift, lo, MASK)], 1u);
         }
     }
     __syncthreads();
@@ -189,14 +200,14 @@ k_scan_rows(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ t
 // V = payload type: uint32_t (4 B) or uint2 (8 B: splat index + packed tile rect).
 // Item order inside a workgroup: wave w owns items [w*RS_WAVE_ITEMS, (w+1)*RS_WAVE_ITEMS) of the
 // tile, round k covers 64 consecutive items -> (wave, round, lane) is input order.
-template <typename V, int DBITS, bool GATHER>
+template <typename V, int DBITS, bool GATHER, bool CLAMP = false>
 __global__ void __launch_bounds__(RS_THREADS)
 k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in,
                 uint32_t* __restrict__ keys_out, V* __restrict__ vals_out, uint32_t n_host,
                 const uint32_t* __restrict__ n_dev, int shift,
                 const uint32_t* __restrict__ offs, const uint32_t* __restrict__ totals, uint32_t nblk, bool contig,
                 uint32_t* __restrict__ n_out /* compacting pass: the number of surviving items (sum of the digit totals), or NULL */,
-                const uint32_t* __restrict__ src_cnt /* GATHER: items at the head of every RS_SRC_BLOCK slots */)
+                const uint32_t* __restrict__ src_cnt /* GATHER: items at the head of every RS_SRC_BLOCK slots */, uint32_t lo = 0u)
 {
     constexpr int BINS = 1 << DBITS;
     constexpr uint32_t MASK = BINS - 1;
@@ -256,7 +267,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
             val = vals_in[tile_base + li];
         }
         // items that do not exist neither rank nor count nor get written
-        const uint32_t d = (key >> shift) & MASK;
+        const uint32_t d = rs_digit<CLAMP>(key, shift, lo, MASK);
         unsigned long long m = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < DBITS; ++b) {
@@ -315,9 +326,199 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
         const uint32_t j = r * RS_THREADS + threadIdx.x;
         if (j < tile_items) {
             const uint32_t key = skeys[j];
-            const uint32_t pos = gadj[(key >> shift) & MASK] + j;
+            const uint32_t pos = gadj[rs_digit<CLAMP>(key, shift, lo, MASK)] + j;
             keys_out[pos] = key;
             vals_out[pos] = svals[j];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Small sorts: MSD bucket pass + ONE local kernel.
+// After occlusion culling a frame sorts a few hundred thousand keys, and the three LSD passes above are nine launches at
+// their latency floors (65 us for 0.3 M keys on MI355X).  Instead: ONE global pass (the same k_radix_hist / k_scan_rows /
+// k_radix_scatter, stable) drops the keys into 512 buckets of equal width over the key range the slot's PREVIOUS frame kept
+// (+ margins; what falls outside goes to the first / last bucket), and k_radix_local sorts every bucket on the bits the
+// bucket index does not fix -- one workgroup per bucket, LSD passes of 8 bits that never leave the CU for a bucket of up to
+// RL_CHUNK keys (registers + LDS), chunked through global memory for a larger one.  Correct for ANY prediction and any
+// count (the prediction only decides how even the buckets are); stable, so equal keys still leave in storage order.
+#define RL_THREADS 256
+#ifndef RL_ITEMS
+#define RL_ITEMS 16
+#endif
+#define RL_CHUNK (RL_THREADS * RL_ITEMS)     // 4096 items: 16 KB of keys + 32 KB of payloads in LDS
+#define RL_WAVE_ITEMS (RL_CHUNK / 4)
+#define RL_BINS 256
+
+// one stable 8-bit pass over the n (<= RL_CHUNK) items a workgroup holds in registers in (wave, round, lane) order:
+// on return skeys / svals hold them sorted by the digit, and dcount[d] = items with digit d, dbase[d] = their first position
+template <typename V>
+__device__ __forceinline__ void rl_pass_in_lds(uint32_t (&k_)[RL_ITEMS], V (&v_)[RL_ITEMS], uint32_t n, int shift, uint32_t sub,
+                                               uint32_t (*wc)[RL_BINS], uint32_t* dbase, uint32_t* dcount, uint32_t* s_wave,
+                                               uint32_t* skeys, V* svals)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int b = threadIdx.x; b < 4 * RL_BINS; b += RL_THREADS) (&wc[0][0])[b] = 0;
+    __syncthreads();
+    uint32_t meta[RL_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RL_ITEMS; ++r) {
+        const uint32_t li = (uint32_t)wave * RL_WAVE_ITEMS + (uint32_t)r * 64u + (uint32_t)lane;
+        const bool valid = li < n;
+        const uint32_t d = ((k_[r] - sub) >> shift) & (RL_BINS - 1);
+        unsigned long long m = __ballot(valid);
+        if (m == 0ull) { meta[r] = 0xffffffffu; continue; }   // (wave-uniform)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        const uint32_t rank = (uint32_t)__builtin_popcountll(m & lt_mask);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+        uint32_t prev = 0;
+        if (valid && rank == 0) { prev = wc[wave][d]; wc[wave][d] = prev + cnt; }
+        const int leader = m ? __builtin_ctzll(m) : 0;
+        prev = __shfl(prev, leader, 64);
+        meta[r] = valid ? (d | ((prev + rank) << 8)) : 0xffffffffu;
+    }
+    __syncthreads();
+    {   // thread t owns digit t: wave bases, the digit's count and first sorted position
+        const int d = threadIdx.x;
+        const uint32_t c0 = wc[0][d], c1 = wc[1][d], c2 = wc[2][d], c3 = wc[3][d];
+        wc[0][d] = 0; wc[1][d] = c0; wc[2][d] = c0 + c1; wc[3][d] = c0 + c1 + c2;
+        const uint32_t tot_d = c0 + c1 + c2 + c3;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_256(tot_d, s_wave, &tot);
+        dbase[d] = ex;
+        dcount[d] = tot_d;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RL_ITEMS; ++r) {
+        if (meta[r] == 0xffffffffu) continue;
+        const uint32_t d = meta[r] & (RL_BINS - 1);
+        const uint32_t lp = dbase[d] + wc[wave][d] + (meta[r] >> 8);
+        skeys[lp] = k_[r];
+        svals[lp] = v_[r];
+    }
+    __syncthreads();
+}
+
+// grid = buckets of the bucket pass (digit = rs_digit<true>(key, low_bits, lo, buckets - 1)).  src = its output (bucket b = the
+// totals[b] items after those of the buckets before it), dst = the other buffer pair: the sorted buckets are left in dst, at the
+// same positions.  A middle bucket holds keys of [lo + b << low_bits, lo + (b + 1) << low_bits): it is sorted on the low_bits
+// low bits of key - lo; the first and the last bucket also hold whatever fell outside the predicted range: all full_bits bits.
+// A bucket beyond RL_MAX_BUCKET keys means the prediction missed badly (a camera jump; a frame that keeps ten times what the
+// previous one kept): one workgroup would sort it for milliseconds.  It is copied over UNSORTED (so that what follows still
+// reads this frame's valid payloads) and *failed is set -- the host renders the frame again with the three global passes
+// (gsr_api.hip).
+#define RL_MAX_BUCKET (8 * RL_CHUNK)
+template <typename V>
+__global__ void __launch_bounds__(RL_THREADS)
+k_radix_local(const uint32_t* __restrict__ totals, int buckets, int low_bits, int full_bits, uint32_t lo,
+              uint32_t* __restrict__ ksrc, V* __restrict__ vsrc, uint32_t* __restrict__ kdst, V* __restrict__ vdst,
+              uint32_t* __restrict__ failed)
+{
+    __shared__ uint32_t wc[4][RL_BINS];
+    __shared__ uint32_t dbase[RL_BINS], dcount[RL_BINS], gbase[RL_BINS];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t skeys[RL_CHUNK];
+    __shared__ V svals[RL_CHUNK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = (int)blockIdx.x;
+    // the bucket's range: sum of the totals of the buckets before it
+    uint32_t before = 0;
+    for (int d = threadIdx.x; d < b; d += RL_THREADS) before += totals[d];
+    uint32_t tot;
+    (void)block_excl_scan_256(before, s_wave, &tot);
+    const uint32_t start = tot, n = totals[b];
+    if (n == 0u) return;
+    if (failed && n > (uint32_t)RL_MAX_BUCKET) {   // (failed == NULL: sort whatever it takes)
+        if (threadIdx.x == 0) *failed = 1u;
+        for (uint32_t j = threadIdx.x; j < n; j += RL_THREADS) { kdst[start + j] = ksrc[start + j]; vdst[start + j] = vsrc[start + j]; }
+        return;
+    }
+    const bool middle = b > 0 && b < buckets - 1;
+    const int sort_bits = middle ? low_bits : full_bits;
+    const uint32_t sub = middle ? lo : 0u;
+    const int npass = sort_bits <= 0 ? 0 : (sort_bits + 7) / 8;
+    uint32_t k_[RL_ITEMS];
+    V v_[RL_ITEMS];
+    if (n <= (uint32_t)RL_CHUNK) {
+        // the whole bucket lives in registers + LDS for all passes
+#pragma unroll
+        for (int r = 0; r < RL_ITEMS; ++r) {
+            const uint32_t li = (uint32_t)wave * RL_WAVE_ITEMS + (uint32_t)r * 64u + (uint32_t)lane;
+            k_[r] = 0u; v_[r] = V{};
+            if (li < n) { k_[r] = ksrc[start + li]; v_[r] = vsrc[start + li]; }
+        }
+        for (int p = 0; p < npass; ++p) {
+            rl_pass_in_lds(k_, v_, n, 8 * p, sub, wc, dbase, dcount, s_wave, skeys, svals);
+            if (p + 1 < npass) {
+#pragma unroll
+                for (int r = 0; r < RL_ITEMS; ++r) {
+                    const uint32_t li = (uint32_t)wave * RL_WAVE_ITEMS + (uint32_t)r * 64u + (uint32_t)lane;
+                    if (li < n) { k_[r] = skeys[li]; v_[r] = svals[li]; }
+                }
+                __syncthreads();
+            }
+        }
+        if (npass == 0) {
+#pragma unroll
+            for (int r = 0; r < RL_ITEMS; ++r) {
+                const uint32_t li = (uint32_t)wave * RL_WAVE_ITEMS + (uint32_t)r * 64u + (uint32_t)lane;
+                if (li < n) { kdst[start + li] = k_[r]; vdst[start + li] = v_[r]; }
+            }
+        } else {
+            for (uint32_t j = threadIdx.x; j < n; j += RL_THREADS) { kdst[start + j] = skeys[j]; vdst[start + j] = svals[j]; }
+        }
+        return;
+    }
+    // a bucket larger than one chunk: every pass goes through global memory, chunk by chunk in order (src -> dst -> src ...)
+    uint32_t* ka = ksrc; V* va = vsrc;
+    uint32_t* kb = kdst; V* vb = vdst;
+    for (int p = 0; p < npass; ++p) {
+        const int shift = 8 * p;
+        // digit counts of the whole bucket -> first position of every digit
+        for (int d = threadIdx.x; d < 4 * RL_BINS; d += RL_THREADS) (&wc[0][0])[d] = 0;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < n; j += RL_THREADS) atomicAdd(&wc[wave][((ka[start + j] - sub) >> shift) & (RL_BINS - 1)], 1u);
+        __syncthreads();
+        {
+            const int d = threadIdx.x;
+            const uint32_t c = wc[0][d] + wc[1][d] + wc[2][d] + wc[3][d];
+            uint32_t t2;
+            gbase[d] = block_excl_scan_256(c, s_wave, &t2);
+        }
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < n; c0 += RL_CHUNK) {
+            const uint32_t m = n - c0 < (uint32_t)RL_CHUNK ? n - c0 : (uint32_t)RL_CHUNK;
+#pragma unroll
+            for (int r = 0; r < RL_ITEMS; ++r) {
+                const uint32_t li = (uint32_t)wave * RL_WAVE_ITEMS + (uint32_t)r * 64u + (uint32_t)lane;
+                k_[r] = 0u; v_[r] = V{};
+                if (li < m) { k_[r] = ka[start + c0 + li]; v_[r] = va[start + c0 + li]; }
+            }
+            rl_pass_in_lds(k_, v_, m, shift, sub, wc, dbase, dcount, s_wave, skeys, svals);
+            for (uint32_t j = threadIdx.x; j < m; j += RL_THREADS) {
+                const uint32_t key = skeys[j];
+                const uint32_t d = ((key - sub) >> shift) & (RL_BINS - 1);
+                const uint32_t pos = start + gbase[d] + (j - dbase[d]);
+                kb[pos] = key;
+                vb[pos] = svals[j];
+            }
+            __syncthreads();
+            gbase[threadIdx.x] += dcount[threadIdx.x];     // (thread t owns digit t)
+            __syncthreads();
+        }
+        __threadfence();    // this workgroup re-reads what it wrote (other lanes' stores) in the next pass
+        __syncthreads();
+        uint32_t* tk = ka; ka = kb; kb = tk;
+        V* tv = va; va = vb; vb = tv;
+    }
+    if (ka != kdst) {   // an even number of passes left the bucket in src: copy it over
+        for (uint32_t j = threadIdx.x; j < n; j += RL_THREADS) { kdst[start + j] = ka[start + j]; vdst[start + j] = va[start + j]; }
     }
 }

@@ -43,7 +43,8 @@ class gsr_stats(C.Structure):
                 ("lazy_redo_tiles", C.c_int64), ("lazy_colours_total", C.c_int64), ("frames_truncated", C.c_int64),
                 ("frames_culled", C.c_int64), ("frames_repaired", C.c_int64),
                 ("clusters_total", C.c_int64), ("clusters_kept", C.c_int64),
-                ("policy_bits", C.c_int32), ("cull_dilate", C.c_int32), ("cull_holdoff", C.c_int32), ("reserved2_", C.c_int32)]
+                ("policy_bits", C.c_int32), ("cull_dilate", C.c_int32), ("cull_holdoff", C.c_int32), ("reserved2_", C.c_int32),
+                ("frames_resorted", C.c_int64)]
 
     def as_dict(self) -> dict:
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -84,13 +85,14 @@ OPT_TIMING_EVERY = 11
 OPT_CLUSTER_CULL = 12
 OPT_STORAGE_ORDER = 13
 OPT_CULL_DILATE = 14
+OPT_LOCAL_SORT = 15
 
 # every symbol include/gsplat_hip.h and include/GSplatRenderer.h declare
 C_ABI_SYMBOLS = [
     "gsr_device_count", "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_version", "gsr_set_stream",
     "gsr_upload_begin", "gsr_upload_append", "gsr_upload_end", "gsr_upload_abort", "gsr_upload", "gsr_set_row_shard", "gsr_band_rows",
     "gsr_stitch_bands", "gsr_render", "gsr_render_depth", "gsr_render_wire", "gsr_synchronize", "gsr_get_stats", "gsr_stats_reset", "gsr_set_option",
-    "gsr_debug_read_records", "gsr_debug_read_depth_order", "gsr_debug_read_storage_order", "gsr_debug_read_tile_lists", "gsr_debug_sort_pairs",
+    "gsr_debug_read_records", "gsr_debug_read_depth_order", "gsr_debug_read_storage_order", "gsr_debug_read_tile_lists", "gsr_debug_sort_pairs", "gsr_debug_sort_pairs_local",
     "gsr_debug_read_tile_work",
     "gsr_multi_create", "gsr_multi_destroy", "gsr_multi_count", "gsr_multi_transport", "gsr_multi_context",
     "gsr_multi_set_stream", "gsr_multi_set_option", "gsr_multi_upload_begin", "gsr_multi_upload_append",
@@ -152,6 +154,7 @@ def load_library() -> C.CDLL:
     L.gsr_debug_read_tile_lists.argtypes = [vp, vp, vp, i64, vp, i64]
     L.gsr_debug_read_storage_order.argtypes = [vp, vp, i64]
     L.gsr_debug_sort_pairs.argtypes = [vp, vp, vp, i64, i32]
+    L.gsr_debug_sort_pairs_local.argtypes = [vp, vp, vp, i64, i32, C.c_uint32, i32]
     L.gsr_debug_read_tile_work.argtypes = [vp, vp, i64]
     # host shim wrappers
     L.gsplat_renderer_create.restype = vp
@@ -443,10 +446,15 @@ class Engine:
         _check(self.L.gsr_debug_read_tile_work(self.h, out.ctypes.data, nt))
         return out.reshape(st["tiles_y"], st["tiles_x"], 4)
 
-    def debug_sort_pairs(self, keys: np.ndarray, vals: np.ndarray, key_bits: int = 32):
+    def debug_sort_pairs(self, keys: np.ndarray, vals: np.ndarray, key_bits: int = 32, local=None):
+        """the pipeline's stable radix sort on host arrays; local = (bucket_lo, bucket_shift): the small-frame form (512 buckets of
+        width 2^shift from lo globally, then every bucket on its own)"""
         k = np.ascontiguousarray(keys, dtype=np.uint32).copy()
         v = np.ascontiguousarray(vals, dtype=np.uint32).copy()
-        _check(self.L.gsr_debug_sort_pairs(self.h, k.ctypes.data, v.ctypes.data, k.shape[0], key_bits))
+        if local is None:
+            _check(self.L.gsr_debug_sort_pairs(self.h, k.ctypes.data, v.ctypes.data, k.shape[0], key_bits))
+        else:
+            _check(self.L.gsr_debug_sort_pairs_local(self.h, k.ctypes.data, v.ctypes.data, k.shape[0], key_bits, int(local[0]), int(local[1])))
         return k, v
 
 

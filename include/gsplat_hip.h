@@ -102,6 +102,8 @@ typedef struct gsr_stats {
     int32_t cull_dilate;                   /* occlusion culling: current dilation radius in tiles (GSR_OPT_CULL_DILATE, grown by repairs) */
     int32_t cull_holdoff;                  /* ... frames for which it stays switched off */
     int32_t reserved2_;
+    int64_t frames_resorted;               /* GSR_OPT_LOCAL_SORT: frames whose small-frame sort met a bucket far beyond its prediction and were
+                                              rendered again with the three global passes */
 } gsr_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -277,6 +279,10 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        depth horizons of the previous frame (default 2; 0..64).  The view moves between frames: a wider
                                        neighbourhood culls less but breaks less often.  The library doubles it whenever a frame had to be
                                        repaired and lets it shrink back to this value while frames hold. */
+#define GSR_OPT_LOCAL_SORT      15   /* depth sort of frames that keep few splats: 1 (default) = when the slot's previous frame kept <= 1.2 M, one global
+                                       pass into 512 buckets over the key range that frame kept + one kernel that sorts every bucket locally
+                                       (4 launches instead of 9); 0 = always three global LSD passes; 2 = the local form whenever a previous
+                                       frame's key range is known.  Same order either way. */
 int  gsr_set_option(gsr_context* ctx, int option, int value);
 
 /* ---- debug / test access (device -> host copies of intermediates) -------- */
@@ -305,6 +311,10 @@ int  gsr_debug_read_tile_work(gsr_context* ctx, uint32_t* work4, int64_t n_tiles
 /* Stand-alone device radix sort of (key,value) u32 pairs on bits [0, key_bits):
  * the sort the pipeline uses, exposed for parity tests (host pointers). */
 int  gsr_debug_sort_pairs(gsr_context* ctx, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits);
+/* ... the form small frames use: one global pass into 512 buckets of width 2^bucket_shift starting at bucket_lo (keys outside
+ * land in the first / last bucket), then every bucket sorted by one workgroup (k_radix_local).  Any lo / shift gives the same order. */
+int  gsr_debug_sort_pairs_local(gsr_context* ctx, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits,
+                                uint32_t bucket_lo, int bucket_shift);
 
 #ifdef __cplusplus
 }

@@ -90,6 +90,14 @@ def test_radix_sort_pairs(engine, n, bits):
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(k, keys[order])
     assert np.array_equal(v, vals[order])
+    # the small-frame form (k_radix_local): 512 buckets of width 2^shift from lo globally, then every bucket on its own -- the same
+    # order, ties included, WHATEVER the predicted range: exact (even buckets), far too narrow (nearly everything in the last
+    # bucket, larger than a chunk: the path through global memory), too wide (one bucket), off to one side
+    if n > 0:
+        span_bits = max(int(keys.max()).bit_length(), 1)
+        for lo, shift in ((0, max(span_bits - 9, 0)), (int(keys.min()), 0), (0, min(span_bits, 31)), (int(keys.max()) // 2, max(span_bits - 12, 0))):
+            k2, v2 = engine.debug_sort_pairs(keys, vals, bits, local=(lo, shift))
+            assert np.array_equal(k2, k) and np.array_equal(v2, v), (lo, shift)
 
 
 @pytest.mark.parametrize("n,w,h,frame,big,shard,layout", [
@@ -1025,6 +1033,40 @@ def test_occlusion_culling_engages_on_a_ball_under_open_sky(pkg):
         assert np.median(vis) < 0.5 * vis_full, (np.median(vis), vis_full)
     finally:
         ref.close(); eng.close()
+
+
+def test_small_frame_sort_survives_mispredictions(pkg):
+    """GSR_OPT_LOCAL_SORT (k_sort.h): a frame that keeps few splats is sorted by one global bucket pass over the key range the
+    PREVIOUS frame kept + one local kernel.  The prediction only shapes the buckets: frames equal those of the three-pass sort
+    bit for bit through steady orbits, camera jumps and jumps in distance (a bucket far beyond the prediction is given up and
+    the frame rendered again with the global sort: frames_resorted), culled and unculled, static redraws included."""
+    splats = pkg.scenes.make_scene(400000, seed=191, sh=True, radius=1.0)
+    w, h = 960, 540
+    cams = [pkg.camera.make_camera(w, h, sh_order=3, frame=i) for i in (0, 1, 2, 3, 4, 40, 41, 42)]
+    cams += [pkg.camera.make_camera(w, h, sh_order=3, frame=43, distance=d) for d in (2.2, 2.25, 2.25, 6.0, 5.9, 5.9)]   # (with static redraws)
+    ref = pkg.Engine(0)
+    try:
+        ref.set_option(pkg.engine.OPT_OCCLUSION_CULL, 0)
+        ref.set_option(pkg.engine.OPT_LOCAL_SORT, 0)
+        ref.upload(splats)
+        want = [ref.render(c).copy() for c in cams]
+    finally:
+        ref.close()
+    for local, cull in ((1, 2), (1, 0), (2, 2), (2, 0)):
+        eng = pkg.Engine(0)
+        try:
+            eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, cull)
+            eng.set_option(pkg.engine.OPT_LOCAL_SORT, local)
+            eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, 1)    # (one frame slot: a static redraw meets the order it left)
+            eng.upload(splats)
+            for k, (c, img) in enumerate(zip(cams, want)):
+                assert np.array_equal(eng.render(c), img), f"local sort {local}, culling {cull}: frame {k} differs"
+            st = eng.stats()
+            assert st["frames_resorted"] >= 1, st          # the jumps in distance did overrun a bucket
+            if cull == 0:
+                assert st["sorts_skipped"] >= 2, st        # ... and the static redraws reused the (good) order
+        finally:
+            eng.close()
 
 
 def test_lazy_colour_is_exact_and_predicts(pkg, oracle):

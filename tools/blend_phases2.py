@@ -1,0 +1,47 @@
+"""k_blend under back-to-back frames (what bench.py times): per-phase wave time and the launch's span, for the small-frame sort on / off.
+Needs the -DBL_PROFILE variant copied over libgsplat_hip.so.   python tools/blend_phases2.py C5 <local-sort 0|1>"""
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, '.')
+import __graft_entry__ as ge
+import torch
+pkg = ge.load_package()
+name = sys.argv[1]; local = int(sys.argv[2])
+splats, cfg = pkg.scenes.make_config(name)
+W, H, order = cfg["width"], cfg["height"], cfg["sh_order"]
+eng = pkg.Engine(0)
+eng.set_option(pkg.engine.OPT_LOCAL_SORT, local)
+eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, 1)
+eng.upload(splats)
+lib = pkg.engine.load_library()
+fn = lib.gsr_debug_blend_profile
+fn.argtypes = [C.c_void_p, C.c_int]
+band = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+cams = [pkg.engine.camera_struct(pkg.scenes.config_camera(name, pkg.camera, W, H, order, i)) for i in range(40)]
+for i in range(39): eng.render_struct_to_device(cams[i], band.data_ptr())
+torch.cuda.synchronize()
+fn(None, 1)
+import time
+t0 = time.perf_counter()
+for i in range(20, 40): eng.render_struct_to_device(cams[i], band.data_ptr())
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 20
+buf = np.zeros((65536, 4, 16), dtype=np.uint64)
+fn(buf.ctypes.data, 0)
+live = buf[:, :, 9] > 0
+v = buf[live].astype(np.float64)
+names = ["prologue", "scan (+its barriers)", "batch bookkeeping", "gather + quadrant test + staging", "composite",
+         "batch tail", "wait: batch-end barrier", "-", "epilogue (store)"]
+tot = v[:, :9].sum()
+start, end = v[:, 11], v[:, 12]
+span = (end.max() - start.min()) / 100.0
+res = (end - start).sum() / 100.0
+print("%s local-sort %d: %.1f us per frame (host clock); last launch: %d waves, span %.1f us, summed residency %.0f us = %.0f waves resident on average" %
+      (name, local, dt * 1e6, v.shape[0], span, res, res / span))
+for n, x in zip(names, v[:, :9].sum(axis=0)):
+    print("  %-34s %6.2f %%   %7.2f us/wave" % (n, 100 * x / tot, x / tot * res / v.shape[0]))
+life = (end - start) / 100.0
+print("wave lifetime us: median %.1f  p90 %.1f  p99 %.1f  max %.1f" % tuple(np.quantile(life, [0.5, 0.9, 0.99, 1.0])))
+t0_ = start.min()
+edges = np.linspace(0, span * 100.0, 11)
+occ = [(np.minimum(end - t0_, edges[i + 1]) - np.maximum(start - t0_, edges[i])).clip(min=0).sum() / (edges[i + 1] - edges[i]) for i in range(10)]
+print("resident waves per tenth of the launch:", " ".join("%.0f" % o for o in occ))

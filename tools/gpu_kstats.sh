@@ -6,7 +6,8 @@ R=$GRAFT_REPO_ROOT
 rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --no-cpu-baseline --config $CFG --steps 100 --warmup 10 "$@" > /tmp/ks.log 2>&1
 python - <<'PY'
 import csv, glob
-f = glob.glob('/tmp/ks/**/*kernel_stats.csv', recursive=True)[0]
+import os
+f = max(glob.glob('/tmp/ks/**/*kernel_stats.csv', recursive=True), key=os.path.getsize)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: -float(r['TotalDurationNs']))
 for r in rows[:22]:

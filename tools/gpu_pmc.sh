@@ -1,7 +1,8 @@
 #!/bin/bash
 # Usage (GPU box, repo root): bash tools/gpu_pmc.sh <tag> [bench args...]
 # PMC counters per kernel, one rocprofv3 pass per counter group (never combined with tracing
-# domains other than --kernel-trace).  Summaries -> gpurun_out/pmc_<tag>/summary.txt
+# domains other than --kernel-trace).  bench.py runs with --no-extra-legs: ONE regime per run -- collect the culled
+# (default) and the unculled (--cull 0) regime with two tags and merge them with tools/merge_traffic.py.  Summaries -> gpurun_out/pmc_<tag>/summary.txt
 set -u
 TAG=${1:-r1}; shift || true
 REPO=$(pwd)
@@ -19,7 +20,7 @@ for GROUP in \
   i=$((i+1))
   rm -rf /tmp/pmc_${TAG}_$i
   rocprofv3 --kernel-trace --pmc $GROUP --output-format csv -d /tmp/pmc_${TAG}_$i -o pmc -- \
-      python "$REPO/bench.py" --no-cpu-baseline "$@" > "$OUT/pass$i.log" 2>&1
+      python "$REPO/bench.py" --no-cpu-baseline --no-extra-legs "$@" > "$OUT/pass$i.log" 2>&1
   f=$(find /tmp/pmc_${TAG}_$i -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then cp "$f" "$OUT/pass$i.csv"; else echo "pass $i produced no counter csv" ; tail -5 "$OUT/pass$i.log"; fi
 done

@@ -42,5 +42,5 @@ try:
     traffic["_kernel_source_sha"] = bench.kernel_source_sha()
 except Exception as e:  # noqa: BLE001
     traffic["_kernel_source_sha"] = "unknown: " + str(e)
-traffic["_collected"] = "rocprofv3 --kernel-trace --pmc passes of `python bench.py --no-cpu-baseline` (tools/gpu_pmc.sh " + os.path.basename(out.rstrip("/")) + ")"
+traffic["_collected"] = "rocprofv3 --kernel-trace --pmc passes of `python bench.py --no-cpu-baseline --no-extra-legs ...` (tools/gpu_pmc.sh " + os.path.basename(out.rstrip("/")) + ")"
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)

@@ -152,6 +152,9 @@ struct FrameSlot {
     uint32_t* cseg = nullptr;          // [ngroups * per]
     uint32_t* ccnt = nullptr;          // [CC_MAX_GROUPS]
     uint32_t* d_counts = nullptr;      // [0] slots K1 filled, [1] surviving clusters, [2] the small-frame sort gave a bucket up
+    uint32_t* bkt_key = nullptr;       // small-frame sort (k_sort.h): the bucket regions, BK_BUCKETS x BK_CAP keys ...
+    uint2* bkt_val = nullptr;          // ... and payloads
+    uint32_t* bkt_cnt = nullptr;       // ... and the bucket counters, BK_STRIDE apart
     uint32_t surv_hint = 0;            // surviving clusters of this slot's last frame (sizes K1's grid; 0 = unknown)
     uint32_t kept_hint = 0;            // splats that reached the depth sort in this slot's last frame (picks the sort; 0 = unknown)
     uint32_t kept_lo = 0, kept_hi = 0; // ... and the smallest / largest of their keys, as float bits of the distance^2 (0, 0 = unknown)
@@ -338,6 +341,10 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hraw), 512 * 512 * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.ccnt), CC_MAX_GROUPS * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.bkt_key), (size_t)BK_BUCKETS * BK_CAP * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.bkt_val), (size_t)BK_BUCKETS * BK_CAP * sizeof(uint2)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.bkt_cnt), (size_t)BK_BUCKETS * BK_STRIDE * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(sl.bkt_cnt, 0, (size_t)BK_BUCKETS * BK_STRIDE * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.d_counts), 4 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.d_counts, 0, 4 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_end), sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
@@ -377,7 +384,7 @@ static void slot_destroy(FrameSlot& sl)
     dev_free(sl.hist); dev_free(sl.totals);
     dev_free(sl.pvA);
     dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.fb);
-    dev_free(sl.hpyr); dev_free(sl.hraw); dev_free(sl.ccnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
+    dev_free(sl.hpyr); dev_free(sl.hraw); dev_free(sl.ccnt); dev_free(sl.bkt_key); dev_free(sl.bkt_val); dev_free(sl.bkt_cnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
     if (sl.h_end) (void)hipHostFree(sl.h_end); dev_free(sl.depth_stage);
     dev_free(sl.redo); dev_free(sl.lazy_ctr); dev_free(sl.colour_evals);
     dev_free(sl.counters); dev_free(sl.d_n);
@@ -1447,6 +1454,18 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     const SortKey key_now = {c->geo_gen, c->shard_index, c->shard_count, c->shard_layout, c->opt_flags, *cam};
     // (a culled frame's order holds only the splats in front of ITS horizons, and the horizons move: no reuse either way)
     const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now) && !j.cull && !sl.sorted_culled;
+    // which depth sort: A frame that keeps few splats (occlusion culling; small clouds) is sorted by ONE bucket scatter + one local
+    // kernel (k_sort.h) instead of three global passes: 2 launches instead of 9.  Chosen from what the slot's previous frame kept
+    // (correct whatever it chooses).  Not for deferred frames: nobody could render them again; and no prediction from a culled
+    // frame for an unculled one.
+    int key_bits = 1;
+    while (key_bits < 32 && ((f.key_max - f.key_min) >> key_bits) != 0u) ++key_bits;
+    const uint32_t n_slots = n ? div_up(c->nclus, 4u) * (uint32_t)GSR_K1_THREADS : 0u;   // the slots K1 can fill at most
+    const bool local = !cache_hit && n_slots > 0 && key_bits > 9 && !(c->opt_flags & GSR_FLAG_FULL_KEYS) && sl.kept_hi > sl.kept_lo && !j.deferred &&
+                       !c->classic_once && sl.kept_culled == j.cull &&
+                       (c->opt_local_sort >= 2 || (c->opt_local_sort == 1 && sl.kept_hint > 0 && sl.kept_hint <= 1200000u));
+    if (!cache_hit) c->classic_once = false;
+    j.local_sort = local;
     if (n > 0) {
 #ifdef GSR_HOST_TIMING
         const double t_pre = now_us();
@@ -1466,7 +1485,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         hipLaunchKernelGGL(k_preprocess, dim3(k1_grid ? k1_grid : 1u), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, cache_hit ? sl.keyB : sl.keyA, cache_hit ? sl.valB : sl.valA,
                            j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.cull ? sl.hpyr : (const float*)nullptr, sl.blk_cnt,
-                           sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts);
+                           sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts, local ? sl.bkt_cnt : (uint32_t*)nullptr, local ? sl.d_n : (uint32_t*)nullptr);
         hipError_t e = hipGetLastError();
 #ifdef GSR_HOST_TIMING
         if (g_t_verdict > 0) {
@@ -1484,19 +1503,6 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     if (cache_hit) {
         c->st.sorts_skipped += 1;
     } else {
-        int key_bits = 1;
-        while (key_bits < 32 && ((f.key_max - f.key_min) >> key_bits) != 0u) ++key_bits;
-        // (the sort's grids are sized for the slots K1 could fill at most; the number it did fill is in d_counts[0])
-        const uint32_t n_slots = n ? div_up(c->nclus, 4u) * (uint32_t)GSR_K1_THREADS : 0u;
-        // A frame that keeps few splats (occlusion culling; small clouds) sorts them with ONE global pass on the top 9 key bits and
-        // one local kernel (k_sort.h) instead of three global passes: 4 launches instead of 9.  Correct for any count; chosen
-        // from what the slot's previous frame kept.
-        // (not for deferred frames: nobody could render them again; and no prediction from a culled frame for an unculled one)
-        const bool local = n_slots > 0 && key_bits > 9 && !(c->opt_flags & GSR_FLAG_FULL_KEYS) && sl.kept_hi > sl.kept_lo && !j.deferred &&
-                           !c->classic_once && sl.kept_culled == j.cull &&
-                           (c->opt_local_sort >= 2 || (c->opt_local_sort == 1 && sl.kept_hint > 0 && sl.kept_hint <= 1200000u));
-        c->classic_once = false;
-        j.local_sort = local;
         if (local) {
             // 512 buckets of equal width over the key range the previous frame kept, widened by a sixteenth on either side (the
             // view moves); in this frame's key domain (keys are stored relative to key_min)
@@ -1507,22 +1513,12 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
             int bshift = 0;
             while (bshift < 31 && (width >> bshift) > 512) ++bshift;
             const uint32_t nblk = div_up(n_slots, RS_TILE);
-            rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)512 * nblk + 8);
-            if (!rc) rc = radix_pass<uint2, 9, true, true>(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n_slots, sl.d_counts, bshift, nblk, RS_XCD_DEPTH != 0,
-                                                           sl.d_n, sl.blk_cnt, lo);
-            if (!rc) {   // buckets (keyB, valB) -> sorted (keyA, valA)
-#ifdef GSR_DEBUG_LOCAL_TIMING
-                static double acc = 0; static long cnt = 0;
-                const auto t0_ = std::chrono::steady_clock::now();
-#endif
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_local<uint2>), dim3(512), dim3(RL_THREADS), 0, s, sl.totals, 512, bshift, key_bits, lo,
-                                   sl.keyB, sl.valB, sl.keyA, sl.valA, sl.d_counts + 2);
-#ifdef GSR_DEBUG_LOCAL_TIMING
-                acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0_).count();
-                if (++cnt % 50 == 0) fprintf(stderr, "[k_radix_local launch] host %.1f us avg, bshift %d lo %u key_bits %d kept_hint %u\n", acc / cnt, bshift, lo, key_bits, sl.kept_hint);
-#endif
-                if (hipGetLastError() != hipSuccess) rc = set_err(GSR_E_HIP, "k_radix_local: launch failed");
-            }
+            // K1's compacted slots -> bucket regions (counters and *d_n were cleared by K1) -> sorted (keyA, valA)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter<uint2, true>), dim3(nblk), dim3(RS_THREADS), 0, s, sl.keyA, sl.valA, n_slots, sl.d_counts,
+                               bshift, lo, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, sl.d_n, sl.d_counts + 2);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_local<uint2>), dim3(BK_BUCKETS), dim3(RL_THREADS), 0, s, sl.bkt_cnt, bshift, key_bits, lo,
+                               sl.bkt_key, sl.bkt_val, sl.keyA, sl.valA, sl.d_counts + 2);
+            if (hipGetLastError() != hipSuccess) rc = set_err(GSR_E_HIP, "small-frame sort: launch failed");
         } else {
             rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n_slots, key_bits,
                             !(c->opt_flags & GSR_FLAG_FULL_KEYS), sl.d_n, RS_XCD_DEPTH != 0, sl.blk_cnt, sl.d_counts);
@@ -1975,14 +1971,20 @@ static int debug_sort_pairs(gsr_context* c, uint32_t* keys, uint32_t* vals, int6
     hipError_t e = hipMemcpyAsync(kA, keys, (size_t)n * 4, hipMemcpyHostToDevice, sl.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(vA, vals, (size_t)n * 4, hipMemcpyHostToDevice, sl.stream);
     if (e == hipSuccess) {
-        if (local) {   // one global pass into 512 buckets of width 2^shift from lo, then every bucket on its own (k_radix_local)
+        if (local) {   // one scatter into 512 buckets of width 2^shift from lo, then every bucket on its own (k_radix_local)
+            // (uint32 payloads in the slot's bucket regions: the payload region is large enough for either type)
             const uint32_t nblk = div_up(n, RS_TILE);
-            rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)512 * nblk + 8);
-            // (the test hands the bucket range over in vals[n]: lo, and the bucket shift in key_bits' upper byte)
-            if (!rc) rc = radix_pass<uint32_t, 9, false, true>(sl, kA, vA, kB, vB, n, (const uint32_t*)nullptr, dbg_shift, nblk, RS_XCD_DEPTH != 0,
-                                                                (uint32_t*)nullptr, (const uint32_t*)nullptr, dbg_lo);
-            if (!rc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_local<uint32_t>), dim3(512), dim3(RL_THREADS), 0, sl.stream, sl.totals, 512,
-                                        dbg_shift, key_bits, dbg_lo, kB, vB, kA, vA, (uint32_t*)nullptr);
+            hipError_t e2 = hipMemsetAsync(sl.bkt_cnt, 0, (size_t)BK_BUCKETS * BK_STRIDE * sizeof(uint32_t), sl.stream);
+            if (e2 == hipSuccess) e2 = hipMemsetAsync(sl.d_counts + 2, 0, 4, sl.stream);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter<uint32_t, false>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, vA, n, (const uint32_t*)nullptr,
+                               dbg_shift, dbg_lo, (const uint32_t*)nullptr, sl.bkt_cnt, sl.bkt_key, reinterpret_cast<uint32_t*>(sl.bkt_val), (uint32_t*)nullptr, sl.d_counts + 2);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_local<uint32_t>), dim3(BK_BUCKETS), dim3(RL_THREADS), 0, sl.stream, sl.bkt_cnt, dbg_shift, key_bits, dbg_lo,
+                               sl.bkt_key, reinterpret_cast<uint32_t*>(sl.bkt_val), kA, vA, (uint32_t*)nullptr);
+            uint32_t over = 0;
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(&over, sl.d_counts + 2, 4, hipMemcpyDeviceToHost, sl.stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(sl.stream);
+            if (e2 != hipSuccess) rc = set_err(GSR_E_HIP, "gsr_debug_sort_pairs_local: %s", hipGetErrorString(e2));
+            else if (over) rc = set_err(GSR_E_INVALID, "gsr_debug_sort_pairs_local: a bucket overflowed its region of %d keys (the pipeline would fall back to the global sort)", BK_CAP);
         } else {
             rc = radix_sort(sl, kA, vA, kB, vB, n, key_bits, true, (uint32_t*)nullptr, RS_XCD_DEPTH != 0);
         }

@@ -108,6 +108,8 @@ __global__ void __launch_bounds__(BN_THREADS)
 k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, GsrShard sh,
             int stiles_x, uint32_t* __restrict__ hist, uint32_t nblk)
 {
+    // (d < BN_BINS below: a frame whose small-frame sort overflowed a bucket is rendered again, but until then its payloads may
+    //  be another frame's -- they must not index past the bins)
     __shared__ uint32_t h[4][BN_BINS];
     const int wave = threadIdx.x >> 6;
     const uint32_t n = *n_dev;
@@ -123,7 +125,7 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
             const uint32_t i = base + k * BN_THREADS + threadIdx.x;   // (every wave sees 64 consecutive splats)
             const uint2 v = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
             bn_group_pairs(v, shift, sh, stiles_x,
-                           [&](int, uint2, uint32_t d, int, int) { atomicAdd(&h[wave][d], 1u); });
+                           [&](int, uint2, uint32_t d, int, int) { if (d < (uint32_t)BN_BINS) atomicAdd(&h[wave][d], 1u); });
         }
     }
     __syncthreads();
@@ -233,7 +235,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
         const uint32_t i = first + g * 64 + lane;
         v[g] = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
         bn_group_pairs(v[g], shift, sh, stiles_x,
-                       [&](int L, uint2, uint32_t d, int, int) { atomicOr(&lmask[g * ns + d], 1ull << L); });
+                       [&](int L, uint2, uint32_t d, int, int) { if (d < (uint32_t)ns) atomicOr(&lmask[g * ns + d], 1ull << L); });
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -253,6 +255,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
 #pragma unroll
     for (int g = 0; g < BN_ITEMS; ++g) {   // (B)
         bn_group_pairs(v[g], shift, sh, stiles_x, [&](int L, uint2 vL, uint32_t d, int sx, int sy) {
+            if (d >= (uint32_t)ns) return;
             uint32_t pos = wbase[d] + (uint32_t)__builtin_popcountll(lmask[g * ns + d] & ((1ull << L) - 1ull));
 #pragma unroll
             for (int e = 0; e < g; ++e) pos += (uint32_t)__builtin_popcountll(lmask[e * ns + d]);

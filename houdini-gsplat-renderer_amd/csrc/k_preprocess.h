@@ -425,7 +425,9 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              uint32_t* __restrict__ blk_cnt /* [workgroup-iterations] splats of each that stay */,
              const uint32_t* __restrict__ cseg, const uint32_t* __restrict__ ccnt, uint32_t ngroups, uint32_t cper /* k_cluster_cull's output */,
              uint32_t* __restrict__ d_counts /* [0] = slots K1 filled (256 per workgroup-iteration), [1] = surviving clusters, [2] = "the small-frame sort
-                                                gave a bucket up" (cleared here, set by k_radix_local) */)
+                                                gave a bucket up" (cleared here, set by k_bucket_scatter / k_radix_local) */,
+             uint32_t* __restrict__ zero_cnt /* the small-frame sort's bucket counters (BK_BUCKETS, BK_STRIDE apart), cleared here */,
+             uint32_t* __restrict__ zero_n /* ... and the count its scatter accumulates */)
 {
     static_assert(GSR_K1_THREADS == 4 * GSR_CLUSTER, "a K1 workgroup is four clusters");
     __shared__ uint32_t s_inc[CC_MAX_GROUPS];
@@ -434,7 +436,10 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nsurv = cc_prefix_to_lds(ccnt, ngroups, s_inc, s_scan);
     const uint32_t niter = (nsurv + 3u) / 4u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d_counts[0] = niter * (uint32_t)GSR_K1_THREADS; d_counts[1] = nsurv; d_counts[2] = 0u; }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) { d_counts[0] = niter * (uint32_t)GSR_K1_THREADS; d_counts[1] = nsurv; d_counts[2] = 0u; if (zero_n) *zero_n = 0u; }
+        if (zero_cnt) for (int d = threadIdx.x; d < 512; d += GSR_K1_THREADS) zero_cnt[(size_t)d * 64] = 0u;
+    }
     int par = 0;
     for (uint32_t k = blockIdx.x; k < niter; k += gridDim.x, par ^= 1) {
         const uint32_t rank = 4u * k + (uint32_t)wave;

@@ -334,14 +334,20 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
 }
 
 // ---------------------------------------------------------------------------
-// Small sorts: MSD bucket pass + ONE local kernel.
+// Small sorts: ONE bucket kernel + ONE local kernel.
 // After occlusion culling a frame sorts a few hundred thousand keys, and the three LSD passes above are nine launches at
-// their latency floors (65 us for 0.3 M keys on MI355X).  Instead: ONE global pass (the same k_radix_hist / k_scan_rows /
-// k_radix_scatter, stable) drops the keys into 512 buckets of equal width over the key range the slot's PREVIOUS frame kept
-// (+ margins; what falls outside goes to the first / last bucket), and k_radix_local sorts every bucket on the bits the
-// bucket index does not fix -- one workgroup per bucket, LSD passes of 8 bits that never leave the CU for a bucket of up to
-// RL_CHUNK keys (registers + LDS), chunked through global memory for a larger one.  Correct for ANY prediction and any
-// count (the prediction only decides how even the buckets are); stable, so equal keys still leave in storage order.
+// their latency floors (65 us for 0.3 M keys on MI355X).  Instead:
+//   k_bucket_scatter  drops every key into one of 512 buckets of equal width over the key range the slot's PREVIOUS frame kept
+//                     (+ margins; what falls outside goes to the first / last bucket).  Every bucket owns a fixed region of
+//                     BK_CAP slots; a workgroup counts its keys per bucket in LDS and reserves room with one atomic per bucket
+//                     (counters 256 bytes apart: atomics that share a cache line serialise) -- no histogram / scan launches;
+//   k_radix_local     one workgroup per bucket sorts it on the bits the bucket index does not fix -- LSD passes of 8 bits that
+//                     never leave the CU for up to RL_CHUNK keys (registers + LDS), chunked through global memory beyond --
+//                     and writes it to its place in the dense output (exclusive prefix of the bucket counts).
+// The order INSIDE a bucket after the scatter is whatever the atomics made it, so the contract's tie order (equal keys in
+// storage order) is restored explicitly: runs of equal keys are re-ordered by their payload's splat index.
+// Correct for ANY prediction; what it cannot do in reasonable time -- a bucket that overflows its region, an endless run of
+// equal keys -- raises *failed, and the host renders the frame again with the three global passes (gsr_api.hip).
 #define RL_THREADS 256
 #ifndef RL_ITEMS
 #define RL_ITEMS 16
@@ -349,6 +355,76 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
 #define RL_CHUNK (RL_THREADS * RL_ITEMS)     // 4096 items: 16 KB of keys + 32 KB of payloads in LDS
 #define RL_WAVE_ITEMS (RL_CHUNK / 4)
 #define RL_BINS 256
+#define BK_BUCKETS 512
+#define BK_CAP (2 * RL_CHUNK)                // slots of a bucket's region
+#define BK_STRIDE 64                         // uint32 between two bucket counters
+#define RL_MAX_RUN 64                        // longest run of equal keys re-ordered in place
+
+__device__ __forceinline__ uint32_t rl_id(uint32_t v) { return v; }
+__device__ __forceinline__ uint32_t rl_id(uint2 v) { return v.x; }
+
+template <typename V, bool GATHER>
+__global__ void __launch_bounds__(RS_THREADS)
+k_bucket_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in, uint32_t n_host, const uint32_t* __restrict__ n_dev,
+                 int shift, uint32_t lo, const uint32_t* __restrict__ src_cnt /* GATHER: items at the head of every RS_SRC_BLOCK slots */,
+                 uint32_t* __restrict__ gcnt /* [BK_BUCKETS * BK_STRIDE], zero on entry */, uint32_t* __restrict__ kout, V* __restrict__ vout,
+                 uint32_t* __restrict__ n_out /* += keys scattered (zero on entry), or NULL */, uint32_t* __restrict__ failed)
+{
+    __shared__ uint32_t h[BK_BUCKETS];
+    __shared__ uint32_t s_wave[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t nb = (n + RS_TILE - 1) / RS_TILE;
+    if (blockIdx.x >= nb) return;
+    for (int b = threadIdx.x; b < BK_BUCKETS; b += RS_THREADS) h[b] = 0;
+    __syncthreads();
+    const uint32_t tile_base = blockIdx.x * RS_TILE;
+    const uint32_t nvalid = (n - tile_base < RS_TILE) ? (n - tile_base) : RS_TILE;
+    uint32_t k_[RS_ITEMS], meta[RS_ITEMS];   // meta = bucket | rank in (workgroup, bucket) << 9, 0xffffffff = no item
+    V v_[RS_ITEMS];
+    uint32_t gc[RS_WAVE_BLOCKS];
+    const uint32_t g_first = (tile_base + (uint32_t)wave * RS_WAVE_ITEMS) / RS_SRC_BLOCK;
+    const uint32_t g_tot = GATHER ? rs_gather_counts(src_cnt, g_first, (n + RS_SRC_BLOCK - 1) / RS_SRC_BLOCK, gc) : 0u;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;
+        bool valid = li < nvalid;
+        uint32_t key = 0u;
+        V val{};
+        if (GATHER) {
+            const uint32_t q = (uint32_t)(r * 64 + lane);
+            valid = q < g_tot;
+            if (valid) { const uint32_t slot = rs_gather_slot(q, g_first, gc); key = keys_in[slot]; val = vals_in[slot]; }
+        } else if (valid) {
+            key = keys_in[tile_base + li]; val = vals_in[tile_base + li];
+        }
+        k_[r] = key; v_[r] = val; meta[r] = 0xffffffffu;
+        if (valid) {
+            const uint32_t d = rs_digit<true>(key, shift, lo, BK_BUCKETS - 1);
+            meta[r] = d | (atomicAdd(&h[d], 1u) << 9);
+            ++mine;
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < BK_BUCKETS; d += RS_THREADS) {   // one reservation per bucket this workgroup has keys for
+        const uint32_t c = h[d];
+        h[d] = c ? atomicAdd(&gcnt[(size_t)d * BK_STRIDE], c) : 0u;
+    }
+    if (n_out) {
+        uint32_t tot;
+        (void)block_excl_scan_256(mine, s_wave, &tot);
+        if (threadIdx.x == 0 && tot) atomicAdd(n_out, tot);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        if (meta[r] == 0xffffffffu) continue;
+        const uint32_t d = meta[r] & (BK_BUCKETS - 1), p = h[d] + (meta[r] >> 9);
+        if (p < (uint32_t)BK_CAP) { kout[(size_t)d * BK_CAP + p] = k_[r]; vout[(size_t)d * BK_CAP + p] = v_[r]; }
+        else if (failed) *failed = 1u;            // the bucket's region is full: the prediction missed badly
+    }
+}
 
 // one stable 8-bit pass over the n (<= RL_CHUNK) items a workgroup holds in registers in (wave, round, lane) order:
 // on return skeys / svals hold them sorted by the digit, and dcount[d] = items with digit d, dbase[d] = their first position
@@ -406,18 +482,34 @@ __device__ __forceinline__ void rl_pass_in_lds(uint32_t (&k_)[RL_ITEMS], V (&v_)
     __syncthreads();
 }
 
-// grid = buckets of the bucket pass (digit = rs_digit<true>(key, low_bits, lo, buckets - 1)).  src = its output (bucket b = the
-// totals[b] items after those of the buckets before it), dst = the other buffer pair: the sorted buckets are left in dst, at the
-// same positions.  A middle bucket holds keys of [lo + b << low_bits, lo + (b + 1) << low_bits): it is sorted on the low_bits
-// low bits of key - lo; the first and the last bucket also hold whatever fell outside the predicted range: all full_bits bits.
-// A bucket beyond RL_MAX_BUCKET keys means the prediction missed badly (a camera jump; a frame that keeps ten times what the
-// previous one kept): one workgroup would sort it for milliseconds.  It is copied over UNSORTED (so that what follows still
-// reads this frame's valid payloads) and *failed is set -- the host renders the frame again with the three global passes
-// (gsr_api.hip).
-#define RL_MAX_BUCKET (8 * RL_CHUNK)
+// equal keys in storage order: every run of equal keys in keys[0, n) (sorted) is re-ordered by its payloads' splat index.
+// One thread per run (they are rare and short); a run beyond RL_MAX_RUN raises *failed instead.  All threads; ends in a barrier.
+template <typename V>
+__device__ __forceinline__ void rl_fix_ties(uint32_t* keys, V* vals, uint32_t n, uint32_t* failed)
+{
+    for (uint32_t j = threadIdx.x; j + 1u < n; j += RL_THREADS) {
+        const uint32_t key = keys[j];
+        if (keys[j + 1u] != key || (j > 0u && keys[j - 1u] == key)) continue;    // not the start of a run
+        uint32_t e = j + 2u;
+        while (e < n && keys[e] == key) ++e;
+        if (failed && e - j > (uint32_t)RL_MAX_RUN) { *failed = 1u; continue; }   // (failed == NULL: whatever it takes)
+        for (uint32_t a = j + 1u; a < e; ++a) {          // insertion sort of vals[j, e) by splat index
+            const V x = vals[a];
+            uint32_t b = a;
+            while (b > j && rl_id(vals[b - 1u]) > rl_id(x)) { vals[b] = vals[b - 1u]; --b; }
+            vals[b] = x;
+        }
+    }
+    __syncthreads();
+}
+
+// grid = BK_BUCKETS.  Bucket b = the cnt[b * BK_STRIDE] keys at src + b * BK_CAP (k_bucket_scatter); it is sorted and written to
+// dst at the exclusive prefix of the counts.  A middle bucket holds keys of [lo + b << low_bits, lo + (b + 1) << low_bits): sorted
+// on the low_bits low bits of key - lo; the first and the last bucket also hold whatever fell outside the predicted range: all
+// full_bits bits.  failed == NULL (tests): long runs of equal keys are re-ordered whatever it takes.
 template <typename V>
 __global__ void __launch_bounds__(RL_THREADS)
-k_radix_local(const uint32_t* __restrict__ totals, int buckets, int low_bits, int full_bits, uint32_t lo,
+k_radix_local(const uint32_t* __restrict__ cnt, int low_bits, int full_bits, uint32_t lo,
               uint32_t* __restrict__ ksrc, V* __restrict__ vsrc, uint32_t* __restrict__ kdst, V* __restrict__ vdst,
               uint32_t* __restrict__ failed)
 {
@@ -428,19 +520,20 @@ k_radix_local(const uint32_t* __restrict__ totals, int buckets, int low_bits, in
     __shared__ V svals[RL_CHUNK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = (int)blockIdx.x;
-    // the bucket's range: sum of the totals of the buckets before it
+    // where the bucket goes: the (clamped) counts of the buckets before it
     uint32_t before = 0;
-    for (int d = threadIdx.x; d < b; d += RL_THREADS) before += totals[d];
+    for (int d = threadIdx.x; d < b; d += RL_THREADS) { const uint32_t c = cnt[(size_t)d * BK_STRIDE]; before += c < (uint32_t)BK_CAP ? c : (uint32_t)BK_CAP; }
     uint32_t tot;
     (void)block_excl_scan_256(before, s_wave, &tot);
-    const uint32_t start = tot, n = totals[b];
+    const uint32_t start = tot;
+    uint32_t n = cnt[(size_t)b * BK_STRIDE];
+    n = n < (uint32_t)BK_CAP ? n : (uint32_t)BK_CAP;
     if (n == 0u) return;
-    if (failed && n > (uint32_t)RL_MAX_BUCKET) {   // (failed == NULL: sort whatever it takes)
-        if (threadIdx.x == 0) *failed = 1u;
-        for (uint32_t j = threadIdx.x; j < n; j += RL_THREADS) { kdst[start + j] = ksrc[start + j]; vdst[start + j] = vsrc[start + j]; }
-        return;
-    }
-    const bool middle = b > 0 && b < buckets - 1;
+    uint32_t* ks = ksrc + (size_t)b * BK_CAP;
+    V* vs = vsrc + (size_t)b * BK_CAP;
+    uint32_t* kd = kdst + start;
+    V* vd = vdst + start;
+    const bool middle = b > 0 && b < BK_BUCKETS - 1;
     const int sort_bits = middle ? low_bits : full_bits;
     const uint32_t sub = middle ? lo : 0u;
     const int npass = sort_bits <= 0 ? 0 : (sort_bits + 7) / 8;
@@ -452,7 +545,15 @@ k_radix_local(const uint32_t* __restrict__ totals, int buckets, int low_bits, in
         for (int r = 0; r < RL_ITEMS; ++r) {
             const uint32_t li = (uint32_t)wave * RL_WAVE_ITEMS + (uint32_t)r * 64u + (uint32_t)lane;
             k_[r] = 0u; v_[r] = V{};
-            if (li < n) { k_[r] = ksrc[start + li]; v_[r] = vsrc[start + li]; }
+            if (li < n) { k_[r] = ks[li]; v_[r] = vs[li]; }
+        }
+        if (npass == 0) {      // (a bucket one key wide: nothing to sort but the ties)
+#pragma unroll
+            for (int r = 0; r < RL_ITEMS; ++r) {
+                const uint32_t li = (uint32_t)wave * RL_WAVE_ITEMS + (uint32_t)r * 64u + (uint32_t)lane;
+                if (li < n) { skeys[li] = k_[r]; svals[li] = v_[r]; }
+            }
+            __syncthreads();
         }
         for (int p = 0; p < npass; ++p) {
             rl_pass_in_lds(k_, v_, n, 8 * p, sub, wc, dbase, dcount, s_wave, skeys, svals);
@@ -465,26 +566,19 @@ k_radix_local(const uint32_t* __restrict__ totals, int buckets, int low_bits, in
                 __syncthreads();
             }
         }
-        if (npass == 0) {
-#pragma unroll
-            for (int r = 0; r < RL_ITEMS; ++r) {
-                const uint32_t li = (uint32_t)wave * RL_WAVE_ITEMS + (uint32_t)r * 64u + (uint32_t)lane;
-                if (li < n) { kdst[start + li] = k_[r]; vdst[start + li] = v_[r]; }
-            }
-        } else {
-            for (uint32_t j = threadIdx.x; j < n; j += RL_THREADS) { kdst[start + j] = skeys[j]; vdst[start + j] = svals[j]; }
-        }
+        rl_fix_ties(skeys, svals, n, failed);
+        for (uint32_t j = threadIdx.x; j < n; j += RL_THREADS) { kd[j] = skeys[j]; vd[j] = svals[j]; }
         return;
     }
     // a bucket larger than one chunk: every pass goes through global memory, chunk by chunk in order (src -> dst -> src ...)
-    uint32_t* ka = ksrc; V* va = vsrc;
-    uint32_t* kb = kdst; V* vb = vdst;
+    uint32_t* ka = ks; V* va = vs;
+    uint32_t* kb = kd; V* vb = vd;
     for (int p = 0; p < npass; ++p) {
         const int shift = 8 * p;
         // digit counts of the whole bucket -> first position of every digit
         for (int d = threadIdx.x; d < 4 * RL_BINS; d += RL_THREADS) (&wc[0][0])[d] = 0;
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < n; j += RL_THREADS) atomicAdd(&wc[wave][((ka[start + j] - sub) >> shift) & (RL_BINS - 1)], 1u);
+        for (uint32_t j = threadIdx.x; j < n; j += RL_THREADS) atomicAdd(&wc[wave][((ka[j] - sub) >> shift) & (RL_BINS - 1)], 1u);
         __syncthreads();
         {
             const int d = threadIdx.x;
@@ -499,13 +593,13 @@ k_radix_local(const uint32_t* __restrict__ totals, int buckets, int low_bits, in
             for (int r = 0; r < RL_ITEMS; ++r) {
                 const uint32_t li = (uint32_t)wave * RL_WAVE_ITEMS + (uint32_t)r * 64u + (uint32_t)lane;
                 k_[r] = 0u; v_[r] = V{};
-                if (li < m) { k_[r] = ka[start + c0 + li]; v_[r] = va[start + c0 + li]; }
+                if (li < m) { k_[r] = ka[c0 + li]; v_[r] = va[c0 + li]; }
             }
             rl_pass_in_lds(k_, v_, m, shift, sub, wc, dbase, dcount, s_wave, skeys, svals);
             for (uint32_t j = threadIdx.x; j < m; j += RL_THREADS) {
                 const uint32_t key = skeys[j];
                 const uint32_t d = ((key - sub) >> shift) & (RL_BINS - 1);
-                const uint32_t pos = start + gbase[d] + (j - dbase[d]);
+                const uint32_t pos = gbase[d] + (j - dbase[d]);
                 kb[pos] = key;
                 vb[pos] = svals[j];
             }
@@ -518,7 +612,10 @@ k_radix_local(const uint32_t* __restrict__ totals, int buckets, int low_bits, in
         uint32_t* tk = ka; ka = kb; kb = tk;
         V* tv = va; va = vb; vb = tv;
     }
-    if (ka != kdst) {   // an even number of passes left the bucket in src: copy it over
-        for (uint32_t j = threadIdx.x; j < n; j += RL_THREADS) { kdst[start + j] = ka[start + j]; vdst[start + j] = va[start + j]; }
+    if (ka != kd) {   // an even number of passes left the bucket in its region of src: copy it over
+        for (uint32_t j = threadIdx.x; j < n; j += RL_THREADS) { kd[j] = ka[j]; vd[j] = va[j]; }
+        __threadfence();
+        __syncthreads();
     }
+    rl_fix_ties(kd, vd, n, failed);
 }

@@ -80,7 +80,7 @@ def test_depth_order_matches_oracle(pkg, oracle, engine):
 
 
 @pytest.mark.parametrize("n,bits", [(0, 32), (1, 32), (63, 8), (4096, 32), (4097, 13), (250001, 32), (1 << 20, 16)])
-def test_radix_sort_pairs(engine, n, bits):
+def test_radix_sort_pairs(pkg, engine, n, bits):
     rng = np.random.default_rng(n + bits)
     keys = rng.integers(0, 1 << bits, n, dtype=np.uint64).astype(np.uint32)
     if n > 100:
@@ -90,12 +90,18 @@ def test_radix_sort_pairs(engine, n, bits):
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(k, keys[order])
     assert np.array_equal(v, vals[order])
-    # the small-frame form (k_radix_local): 512 buckets of width 2^shift from lo globally, then every bucket on its own -- the same
-    # order, ties included, WHATEVER the predicted range: exact (even buckets), far too narrow (nearly everything in the last
-    # bucket, larger than a chunk: the path through global memory), too wide (one bucket), off to one side
+    # the small-frame form (k_bucket_scatter + k_radix_local): 512 buckets of width 2^shift from lo, filled with atomics, every
+    # bucket sorted on its own and its ties put back into payload order -- the same order, ties included, WHATEVER the predicted
+    # range, as long as no bucket outgrows its region of 8192 keys (then the call reports it; the pipeline falls back)
     if n > 0:
         span_bits = max(int(keys.max()).bit_length(), 1)
-        for lo, shift in ((0, max(span_bits - 9, 0)), (int(keys.min()), 0), (0, min(span_bits, 31)), (int(keys.max()) // 2, max(span_bits - 12, 0))):
+        for lo, shift in ((0, max(span_bits - 9, 0)), (int(keys.min()), 0), (0, min(span_bits, 31)), (int(keys.max()) // 2, max(span_bits - 12, 0)),
+                          (int(keys.max()) // 3, max(span_bits - 10, 0))):
+            d = np.where(keys > lo, (keys.astype(np.int64) - lo) >> shift, 0).clip(0, 511)
+            if np.bincount(d, minlength=512).max() > 8192:
+                with pytest.raises(pkg.GsrError):
+                    engine.debug_sort_pairs(keys, vals, bits, local=(lo, shift))
+                continue
             k2, v2 = engine.debug_sort_pairs(keys, vals, bits, local=(lo, shift))
             assert np.array_equal(k2, k) and np.array_equal(v2, v), (lo, shift)
 
@@ -1111,6 +1117,35 @@ def test_lazy_colour_is_exact_and_predicts(pkg, oracle):
             assert np.array_equal(dev[f][vis].view(np.uint32), ref[f][vis].view(np.uint32))
     finally:
         eng.close()
+
+
+def test_multi_gpu_over_rccl_matches_single_gpu(pkg, engine):
+    """The frame's one collective between REAL GPUs: gsr_multi over min(visible, 8) devices with the RCCL transport (band images
+    -> devices[0] by ncclSend / ncclRecv in one group, stitched there), occlusion culling on every rank, both shard layouts:
+    bit-identical to the single-GPU frame.  Needs >= 2 GPUs (the 1-GPU box runs the same path over the COPY transport in
+    test_multi_gpu_in_library_matches_single_gpu)."""
+    ndev = int(pkg.load_library().gsr_device_count())
+    if ndev < 2:
+        pytest.skip("needs at least two GPUs")
+    splats = pkg.scenes.make_scene(500000, seed=61, sh=True, radius=1.0)
+    cams = [pkg.camera.make_camera(1280, 720, sh_order=3, frame=i) for i in (0, 1, 2, 3, 30, 31)]
+    engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 0)
+    engine.upload(splats)
+    try:
+        want = [engine.render(c).copy() for c in cams]
+    finally:
+        engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 1)
+    for layout in (1, 0):
+        M = pkg.MultiEngine(list(range(min(ndev, 8))), transport=pkg.engine.TRANSPORT_RCCL)
+        try:
+            assert M.transport == pkg.engine.TRANSPORT_RCCL
+            M.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
+            M.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)
+            M.upload(splats)
+            for k, (c, img) in enumerate(zip(cams, want)):
+                assert np.array_equal(M.render(c), img), f"layout {layout}: frame {k} differs between {M.count} GPUs and one"
+        finally:
+            M.close()
 
 
 def test_rccl_entry_points_on_one_gpu(pkg, engine):

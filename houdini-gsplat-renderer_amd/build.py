@@ -12,7 +12,7 @@ SOURCES = ["gsr_api.hip", "gsr_multi.cpp", "GSplatRenderer.cpp", "gsplat_ingest.
 HEADERS = ["gsr_device.h", "k_cluster.h", "k_preprocess.h", "k_sort.h", "k_binning.h", "k_blend.h", "k_colour.h", "k_wire.h"]
 # -ffp-contract=off: only explicit fmaf() fuses (the float32 op-order contract)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-result", "-ldl"]
+         "-Wall", "-Wno-unused-result", "-ldl", "-pthread"]
 
 
 def hipcc() -> str:

@@ -6,11 +6,29 @@
 // (per-redraw verbs) and src/GEO_GSplat.C:338-351 (barycentre).
 #include "../../include/GSplatPrim.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
+#include <vector>
 
 namespace {
+
+// The reference quantises and packs in a tbb::parallel_for over the points (src/GR_GSplat.C:302-372).  Same here with plain
+// threads: fn(begin, end) over disjoint ranges of [0, n); small inputs stay on the calling thread.
+template <typename F>
+void parallel_ranges(int64_t n, int64_t grain, F&& fn)
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int64_t parts = std::min<int64_t>(std::min<int64_t>(hw, 64), (n + grain - 1) / grain);
+    if (parts <= 1) { fn(static_cast<int64_t>(0), n); return; }
+    std::vector<std::thread> pool;
+    pool.reserve(static_cast<size_t>(parts));
+    const int64_t step = (n + parts - 1) / parts;
+    for (int64_t b = 0; b < n; b += step) pool.emplace_back([&fn, b, step, n] { fn(b, std::min(n, b + step)); });
+    for (auto& t : pool) t.join();
+}
 
 // binary32 -> binary16, round to nearest even, overflow to infinity (what HDK's fpreal16 constructors do)
 inline uint16_t to_half(float f)
@@ -43,14 +61,15 @@ extern "C" {
 
 void gsplat_quantize_half(const float* in, uint16_t* out, int64_t count)
 {
-    for (int64_t i = 0; i < count; ++i) out[i] = to_half(in[i]);
+    parallel_ranges(count, 1 << 16, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) out[i] = to_half(in[i]); });
 }
 
 // The reference keeps SH in three 4x4 half matrices per splat (x/y/z channel), coefficient j (= sh(j+1)) in flat
 // slot j; slot 15 stays 0.
 void gsplat_pack_sh_from_vec3(const float* const sh[15], int64_t n, uint16_t* shx, uint16_t* shy, uint16_t* shz)
 {
-    for (int64_t i = 0; i < n; ++i) {
+    parallel_ranges(n, 1 << 13, [&](int64_t b_, int64_t e_) {
+    for (int64_t i = b_; i < e_; ++i) {
         uint16_t *x = shx + 16 * i, *y = shy + 16 * i, *z = shz + 16 * i;
         for (int j = 0; j < 16; ++j) {
             const float* v = (j < 15 && sh[j]) ? sh[j] + 3 * i : nullptr;
@@ -59,11 +78,13 @@ void gsplat_pack_sh_from_vec3(const float* const sh[15], int64_t n, uint16_t* sh
             z[j] = v ? to_half(v[2]) : 0;
         }
     }
+    });
 }
 
 void gsplat_pack_sh_from_frest(const float* const f_rest[45], int64_t n, uint16_t* shx, uint16_t* shy, uint16_t* shz)
 {
-    for (int64_t i = 0; i < n; ++i) {
+    parallel_ranges(n, 1 << 13, [&](int64_t b_, int64_t e_) {
+    for (int64_t i = b_; i < e_; ++i) {
         uint16_t *x = shx + 16 * i, *y = shy + 16 * i, *z = shz + 16 * i;
         for (int j = 0; j < 15; ++j) {   // channel-major INRIA layout: (f_rest_j, f_rest_{j+15}, f_rest_{j+30})
             x[j] = f_rest[j] ? to_half(f_rest[j][i]) : 0;
@@ -72,13 +93,15 @@ void gsplat_pack_sh_from_frest(const float* const f_rest[45], int64_t n, uint16_
         }
         x[15] = y[15] = z[15] = 0;
     }
+    });
 }
 
 void gsplat_pack_sh_from_array(const float* coeffs, int64_t n, int vec3_per_point, uint16_t* shx, uint16_t* shy, uint16_t* shz)
 {
     const int have = vec3_per_point < 0 ? 0 : vec3_per_point;
     const int used = have > 16 ? 16 : have;
-    for (int64_t i = 0; i < n; ++i) {
+    parallel_ranges(n, 1 << 13, [&](int64_t b_, int64_t e_) {
+    for (int64_t i = b_; i < e_; ++i) {
         const float* v = coeffs + static_cast<size_t>(i) * have * 3;
         uint16_t *x = shx + 16 * i, *y = shy + 16 * i, *z = shz + 16 * i;
         for (int j = 0; j < 16; ++j) {
@@ -87,6 +110,7 @@ void gsplat_pack_sh_from_array(const float* coeffs, int64_t n, int vec3_per_poin
             z[j] = j < used ? to_half(v[3 * j + 2]) : 0;
         }
     }
+    });
 }
 
 }  // extern "C"

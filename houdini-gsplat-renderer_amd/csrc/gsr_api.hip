@@ -611,6 +611,84 @@ extern "C" int gsr_upload_append(gsr_context* c, int64_t n64, const float* P, co
 
 static int order_and_cluster(gsr_context* c);
 
+extern "C" int gsr_upload_append_raw(gsr_context* c, int64_t n64, const gsr_raw_attrs* a)
+{
+    if (!c || !c->uploading) return set_err(GSR_E_INVALID, "gsr_upload_append_raw: no upload in progress");
+    if (!a) return set_err(GSR_E_INVALID, "gsr_upload_append_raw: attrs is NULL");
+    if (n64 < 0 || (uint64_t)n64 + c->up_filled > c->up_total)
+        return set_err(GSR_E_INVALID, "gsr_upload_append_raw: %lld splats exceed the %u announced", (long long)n64, c->up_total);
+    if (n64 == 0) return GSR_OK;
+    if (!a->P) return set_err(GSR_E_INVALID, "gsr_upload_append_raw: P is NULL");
+    if (a->sh_scheme < 0 || a->sh_scheme > 3 || (a->sh_scheme == 1 && (!a->sh_array || a->sh_vec3_per_point < 1)) || (a->sh_scheme >= 2 && !a->sh_ptr))
+        return set_err(GSR_E_INVALID, "gsr_upload_append_raw: bad spherical-harmonics description");
+    if (c->has_sh != (a->sh_scheme != 0)) return set_err(GSR_E_INVALID, "gsr_upload_append_raw: SH presence differs from gsr_upload_begin");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n = (uint32_t)n64;
+    hipStream_t us = c->slot[0].own;
+    const size_t al = 256;
+    auto pad = [&](size_t b) { return (b + al - 1) / al * al; };
+    // staging arena: the half arrays k_repack takes, then the raw float arrays they are made from
+    const int nsh = a->sh_scheme == 2 ? 15 : (a->sh_scheme == 3 ? 45 : 0);
+    int sh_live = 0;                 // schemes 2 / 3: the arrays before the first gap
+    if (nsh) while (sh_live < nsh && a->sh_ptr[sh_live]) ++sh_live;
+    const size_t bP = pad((size_t)n * 12), bA = pad((size_t)n * 4), bC = pad((size_t)n * 6), bS = pad((size_t)n * 6), bO = pad((size_t)n * 8),
+                 bH = c->has_sh ? pad((size_t)n * 32) : 0;
+    const size_t rC = a->Cd ? pad((size_t)n * 12) : 0, rS = a->scale ? pad((size_t)n * 12) : 0, rO = a->orient ? pad((size_t)n * 16) : 0;
+    const size_t rArr = a->sh_scheme == 1 ? pad((size_t)n * a->sh_vec3_per_point * 12) : 0;
+    const size_t rEach = a->sh_scheme == 2 ? pad((size_t)n * 12) : (a->sh_scheme == 3 ? pad((size_t)n * 4) : 0);
+    const size_t need = bP + bA + bC + bS + bO + 3 * bH + rC + rS + rO + rArr + rEach * sh_live;
+    if (need > c->stage_cap) {
+        HIP_TRY(hipStreamSynchronize(us));
+        dev_free(c->stage);
+        c->stage_cap = 0;
+        int rc = dev_alloc(&c->stage, need);
+        if (rc) return rc;
+        c->stage_cap = need;
+    }
+    char* base = c->stage;
+    auto take = [&](size_t bytes) { char* p = base; base += bytes; return p; };
+    float* dP = reinterpret_cast<float*>(take(bP));
+    float* dA = reinterpret_cast<float*>(take(bA));
+    uint16_t* dCd = reinterpret_cast<uint16_t*>(take(bC));
+    uint16_t* dS = reinterpret_cast<uint16_t*>(take(bS));
+    uint16_t* dO = reinterpret_cast<uint16_t*>(take(bO));
+    uint16_t *dX = nullptr, *dY = nullptr, *dZ = nullptr;
+    if (c->has_sh) { dX = reinterpret_cast<uint16_t*>(take(bH)); dY = reinterpret_cast<uint16_t*>(take(bH)); dZ = reinterpret_cast<uint16_t*>(take(bH)); }
+    hipError_t e = hipSuccess;
+    auto h2d = [&](void* d, const void* h, size_t bytes) { if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, us); };
+    h2d(dP, a->P, (size_t)n * 12);
+    std::vector<float> ones;
+    if (a->alpha) h2d(dA, a->alpha, (size_t)n * 4);
+    else { ones.assign(n, 1.0f); h2d(dA, ones.data(), (size_t)n * 4); }     // missing opacity: opaque
+    const float *rCd = nullptr, *rSc = nullptr, *rOr = nullptr;
+    if (a->Cd) { float* p = reinterpret_cast<float*>(take(rC)); h2d(p, a->Cd, (size_t)n * 12); rCd = p; }
+    if (a->scale) { float* p = reinterpret_cast<float*>(take(rS)); h2d(p, a->scale, (size_t)n * 12); rSc = p; }
+    if (a->orient) { float* p = reinterpret_cast<float*>(take(rO)); h2d(p, a->orient, (size_t)n * 16); rOr = p; }
+    GsrRawSh sh{};
+    sh.scheme = a->sh_scheme;
+    sh.vec3_per_point = a->sh_vec3_per_point > 16 ? 16 : a->sh_vec3_per_point;
+    if (a->sh_scheme == 1) {
+        // (only the first 16 vec3 of a longer array are used: copy them compactly)
+        float* p = reinterpret_cast<float*>(take(rArr));
+        if (a->sh_vec3_per_point <= 16) h2d(p, a->sh_array, (size_t)n * a->sh_vec3_per_point * 12);
+        else if (e == hipSuccess)
+            e = hipMemcpy2DAsync(p, (size_t)16 * 12, a->sh_array, (size_t)a->sh_vec3_per_point * 12, (size_t)16 * 12, n, hipMemcpyHostToDevice, us);
+        sh.array = p;
+    } else {
+        for (int j = 0; j < sh_live; ++j) { float* p = reinterpret_cast<float*>(take(rEach)); h2d(p, a->sh_ptr[j], a->sh_scheme == 2 ? (size_t)n * 12 : (size_t)n * 4); sh.ptr[j] = p; }
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_quantize_raw, dim3(div_up(n, 256)), dim3(256), 0, us, n, rCd, rSc, rOr, sh, dCd, dS, dO, dX, dY, dZ);
+        hipLaunchKernelGGL(k_repack, dim3(div_up(n, 256)), dim3(256), 0, us, n, c->up_filled, c->cap,
+                           c->has_sh ? 1 : 0, dP, dCd, dA, dS, dO, dX, dY, dZ, c->geoA, c->geoB, c->col, c->colrow);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(us);   // the caller's arrays may be freed on return
+    if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_upload_append_raw: %s", hipGetErrorString(e));
+    c->up_filled += n;
+    return GSR_OK;
+}
+
 extern "C" int gsr_upload_end(gsr_context* c)
 {
     if (!c || !c->uploading) return set_err(GSR_E_INVALID, "gsr_upload_end: no upload in progress");
@@ -1511,7 +1589,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
             const uint32_t lo = lo_abs > f.key_min ? (uint32_t)(lo_abs - f.key_min) : 0u;
             const uint64_t width = (hi_abs > f.key_min ? hi_abs - f.key_min : 0) - lo + 1;
             int bshift = 0;
-            while (bshift < 31 && (width >> bshift) > 512) ++bshift;
+            while (bshift < 31 && (width >> bshift) > (uint64_t)BK_BUCKETS) ++bshift;
             const uint32_t nblk = div_up(n_slots, RS_TILE);
             // K1's compacted slots -> bucket regions (counters and *d_n were cleared by K1) -> sorted (keyA, valA)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter<uint2, true>), dim3(nblk), dim3(RS_THREADS), 0, s, sl.keyA, sl.valA, n_slots, sl.d_counts,

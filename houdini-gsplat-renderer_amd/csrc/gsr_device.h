@@ -70,6 +70,15 @@ struct GsrFrame {
 #define GSR_FLAG_FULL_KEYS       4   // sort all 32 key bits (no key-range reduction, 8-bit digits)
 #define GSR_FLAG_LAZY_NO_PREFIX  8   // lazy colour: colour nothing ahead of time, so that every tile takes the on-demand fallback
 
+// small-frame depth sort (k_sort.h): bucket regions
+#ifndef BK_BUCKETS
+#define BK_BUCKETS 1024                      // (measured on C4: 512 buckets x 4096-key chunks 45 us, 1024 x 2048 31 us, 2048 x 1024 30 us)
+#endif
+#ifndef BK_CAP
+#define BK_CAP 8192                          // slots of a bucket's region
+#endif
+#define BK_STRIDE 64                         // uint32 between two bucket counters (256 bytes: atomics on one line serialise)
+
 // ---- scalar helpers ---------------------------------------------------------
 __device__ __forceinline__ float gsr_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 

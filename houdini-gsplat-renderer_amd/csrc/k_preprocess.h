@@ -76,6 +76,57 @@ k_repack(uint32_t n, uint32_t dst0, uint32_t cap, int has_sh,
 }
 
 // ---------------------------------------------------------------------------
+// K0': raw float32 point attributes (as a Houdini detail holds them) -> the half arrays k_repack takes.  What
+// GR_PrimGsplat::update does on the CPU in a tbb::parallel_for (/root/reference/gsplat_plugin/src/GR_GSplat.C:302-372):
+// fp32 -> fp16 (HDK's fpreal16: round to nearest even, overflow to infinity -- what v_cvt_f16_f32 does), the defaults for
+// missing attributes, and the three spherical-harmonics naming schemes -> coefficient j in flat slot j of the x / y / z rows.
+__device__ __forceinline__ uint16_t gsr_f2h(float f)
+{
+    const _Float16 h = (_Float16)f;      // v_cvt_f16_f32: round to nearest even
+    return __builtin_bit_cast(uint16_t, h);
+}
+struct GsrRawSh {
+    int32_t scheme;              // 0 none, 1 = one array of `vec3_per_point` vec3 per point, 2 = sh1..sh15 (vec3 arrays), 3 = f_rest_0..44 (float arrays)
+    int32_t vec3_per_point;      // scheme 1
+    const float* array;          // scheme 1
+    const float* ptr[45];        // scheme 2: [0..14] (NULL from the first gap on), scheme 3: [0..44] (likewise)
+};
+__global__ void __launch_bounds__(256)
+k_quantize_raw(uint32_t n, const float* __restrict__ Cd, const float* __restrict__ scale, const float* __restrict__ orient, GsrRawSh sh,
+               uint16_t* __restrict__ oCd, uint16_t* __restrict__ oS, uint16_t* __restrict__ oO,
+               uint16_t* __restrict__ ox, uint16_t* __restrict__ oy, uint16_t* __restrict__ oz)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        oCd[3 * (size_t)i + k] = Cd ? gsr_f2h(Cd[3 * (size_t)i + k]) : (uint16_t)0;            // missing Cd: black
+        oS[3 * (size_t)i + k] = scale ? gsr_f2h(scale[3 * (size_t)i + k]) : (uint16_t)0x3c00;  // missing scale: 1
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) oO[4 * (size_t)i + k] = orient ? gsr_f2h(orient[4 * (size_t)i + k]) : (uint16_t)(k == 3 ? 0x3c00 : 0);   // (0, 0, 0, 1)
+    if (sh.scheme == 0) return;
+    for (int j = 0; j < 16; ++j) {
+        float x = 0.0f, y = 0.0f, z = 0.0f;
+        bool have = false;
+        if (sh.scheme == 1) {
+            have = j < sh.vec3_per_point;
+            if (have) { const float* v = sh.array + ((size_t)i * sh.vec3_per_point + j) * 3; x = v[0]; y = v[1]; z = v[2]; }
+        } else if (sh.scheme == 2) {
+            have = j < 15 && sh.ptr[j];
+            if (have) { const float* v = sh.ptr[j] + 3 * (size_t)i; x = v[0]; y = v[1]; z = v[2]; }
+        } else if (j < 15) {   // channel-major INRIA layout: (f_rest_j, f_rest_{j+15}, f_rest_{j+30}); a missing array leaves zeros
+            have = true;
+            x = sh.ptr[j] ? sh.ptr[j][i] : 0.0f; y = sh.ptr[j + 15] ? sh.ptr[j + 15][i] : 0.0f; z = sh.ptr[j + 30] ? sh.ptr[j + 30][i] : 0.0f;
+        }
+        // (a slot without data is a zero HALF, not the conversion of 0.0f: the same bits, said explicitly)
+        ox[16 * (size_t)i + j] = have ? gsr_f2h(x) : (uint16_t)0;
+        oy[16 * (size_t)i + j] = have ? gsr_f2h(y) : (uint16_t)0;
+        oz[16 * (size_t)i + j] = have ? gsr_f2h(z) : (uint16_t)0;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // SH evaluation for one channel; expressions are written and associated exactly
 // as in the oracle (and in shaders/GSplatShaderCoreLib.h:146-175).
 __device__ __forceinline__ float gsr_shade_sh(float base, const float* sh, float x, float y, float z, int order)
@@ -438,7 +489,7 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
     const uint32_t niter = (nsurv + 3u) / 4u;
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) { d_counts[0] = niter * (uint32_t)GSR_K1_THREADS; d_counts[1] = nsurv; d_counts[2] = 0u; if (zero_n) *zero_n = 0u; }
-        if (zero_cnt) for (int d = threadIdx.x; d < 512; d += GSR_K1_THREADS) zero_cnt[(size_t)d * 64] = 0u;
+        if (zero_cnt) for (int d = threadIdx.x; d < BK_BUCKETS; d += GSR_K1_THREADS) zero_cnt[(size_t)d * BK_STRIDE] = 0u;
     }
     int par = 0;
     for (uint32_t k = blockIdx.x; k < niter; k += gridDim.x, par ^= 1) {

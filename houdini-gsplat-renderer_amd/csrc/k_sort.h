@@ -337,7 +337,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
 // Small sorts: ONE bucket kernel + ONE local kernel.
 // After occlusion culling a frame sorts a few hundred thousand keys, and the three LSD passes above are nine launches at
 // their latency floors (65 us for 0.3 M keys on MI355X).  Instead:
-//   k_bucket_scatter  drops every key into one of 512 buckets of equal width over the key range the slot's PREVIOUS frame kept
+//   k_bucket_scatter  drops every key into one of BK_BUCKETS (1024) buckets of equal width over the key range the slot's PREVIOUS frame kept
 //                     (+ margins; what falls outside goes to the first / last bucket).  Every bucket owns a fixed region of
 //                     BK_CAP slots; a workgroup counts its keys per bucket in LDS and reserves room with one atomic per bucket
 //                     (counters 256 bytes apart: atomics that share a cache line serialise) -- no histogram / scan launches;
@@ -350,14 +350,12 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
 // equal keys -- raises *failed, and the host renders the frame again with the three global passes (gsr_api.hip).
 #define RL_THREADS 256
 #ifndef RL_ITEMS
-#define RL_ITEMS 16
+#define RL_ITEMS 8
 #endif
-#define RL_CHUNK (RL_THREADS * RL_ITEMS)     // 4096 items: 16 KB of keys + 32 KB of payloads in LDS
+#define RL_CHUNK (RL_THREADS * RL_ITEMS)     // 2048 items: 8 KB of keys + 16 KB of payloads in LDS, 86 VGPRs
 #define RL_WAVE_ITEMS (RL_CHUNK / 4)
 #define RL_BINS 256
-#define BK_BUCKETS 512
-#define BK_CAP (2 * RL_CHUNK)                // slots of a bucket's region
-#define BK_STRIDE 64                         // uint32 between two bucket counters
+static_assert(BK_CAP >= RL_CHUNK, "a bucket's region holds at least one chunk");
 #define RL_MAX_RUN 64                        // longest run of equal keys re-ordered in place
 
 __device__ __forceinline__ uint32_t rl_id(uint32_t v) { return v; }
@@ -380,7 +378,8 @@ k_bucket_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ val
     __syncthreads();
     const uint32_t tile_base = blockIdx.x * RS_TILE;
     const uint32_t nvalid = (n - tile_base < RS_TILE) ? (n - tile_base) : RS_TILE;
-    uint32_t k_[RS_ITEMS], meta[RS_ITEMS];   // meta = bucket | rank in (workgroup, bucket) << 9, 0xffffffff = no item
+    uint32_t k_[RS_ITEMS], meta[RS_ITEMS];   // meta = bucket | rank in (workgroup, bucket) << 12, 0xffffffff = no item
+    static_assert(BK_BUCKETS <= 4096 && RS_TILE < (1 << 20), "meta packing");
     V v_[RS_ITEMS];
     uint32_t gc[RS_WAVE_BLOCKS];
     const uint32_t g_first = (tile_base + (uint32_t)wave * RS_WAVE_ITEMS) / RS_SRC_BLOCK;
@@ -402,7 +401,7 @@ k_bucket_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ val
         k_[r] = key; v_[r] = val; meta[r] = 0xffffffffu;
         if (valid) {
             const uint32_t d = rs_digit<true>(key, shift, lo, BK_BUCKETS - 1);
-            meta[r] = d | (atomicAdd(&h[d], 1u) << 9);
+            meta[r] = d | (atomicAdd(&h[d], 1u) << 12);
             ++mine;
         }
     }
@@ -420,7 +419,7 @@ k_bucket_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ val
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         if (meta[r] == 0xffffffffu) continue;
-        const uint32_t d = meta[r] & (BK_BUCKETS - 1), p = h[d] + (meta[r] >> 9);
+        const uint32_t d = meta[r] & 4095u, p = h[d] + (meta[r] >> 12);
         if (p < (uint32_t)BK_CAP) { kout[(size_t)d * BK_CAP + p] = k_[r]; vout[(size_t)d * BK_CAP + p] = v_[r]; }
         else if (failed) *failed = 1u;            // the bucket's region is full: the prediction missed badly
     }

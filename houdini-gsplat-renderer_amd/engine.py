@@ -70,6 +70,11 @@ class GSplatRenderContext(C.Structure):
                 ("depth", C.c_void_p), ("depth_is_device", C.c_int32)]
 
 
+class gsr_raw_attrs(C.Structure):
+    _fields_ = [("P", C.c_void_p), ("Cd", C.c_void_p), ("alpha", C.c_void_p), ("scale", C.c_void_p), ("orient", C.c_void_p),
+                ("sh_scheme", C.c_int32), ("sh_vec3_per_point", C.c_int32), ("sh_array", C.c_void_p), ("sh_ptr", C.POINTER(C.c_void_p))]
+
+
 class gsplat_attrs(C.Structure):
     _fields_ = [("count", C.c_int64), ("P", C.c_void_p), ("Cd", C.c_void_p), ("opacity", C.c_void_p), ("Alpha", C.c_void_p),
                 ("scale", C.c_void_p), ("orient", C.c_void_p), ("sh_coefficients", C.c_void_p),
@@ -90,7 +95,7 @@ OPT_LOCAL_SORT = 15
 # every symbol include/gsplat_hip.h and include/GSplatRenderer.h declare
 C_ABI_SYMBOLS = [
     "gsr_device_count", "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_version", "gsr_set_stream",
-    "gsr_upload_begin", "gsr_upload_append", "gsr_upload_end", "gsr_upload_abort", "gsr_upload", "gsr_set_row_shard", "gsr_band_rows",
+    "gsr_upload_begin", "gsr_upload_append", "gsr_upload_append_raw", "gsr_upload_end", "gsr_upload_abort", "gsr_upload", "gsr_set_row_shard", "gsr_band_rows",
     "gsr_stitch_bands", "gsr_render", "gsr_render_depth", "gsr_render_wire", "gsr_synchronize", "gsr_get_stats", "gsr_stats_reset", "gsr_set_option",
     "gsr_debug_read_records", "gsr_debug_read_depth_order", "gsr_debug_read_storage_order", "gsr_debug_read_tile_lists", "gsr_debug_sort_pairs", "gsr_debug_sort_pairs_local",
     "gsr_debug_read_tile_work",
@@ -136,6 +141,7 @@ def load_library() -> C.CDLL:
     L.gsr_set_stream.argtypes = [vp, vp]
     L.gsr_upload_begin.argtypes = [vp, i64, i32, f32p]
     L.gsr_upload_append.argtypes = [vp, i64] + [vp] * 8
+    L.gsr_upload_append_raw.argtypes = [vp, i64, C.POINTER(gsr_raw_attrs)]
     L.gsr_upload_end.argtypes = [vp]
     L.gsr_upload_abort.argtypes = [vp]
     L.gsr_upload.argtypes = [vp, i64] + [vp] * 8 + [f32p]
@@ -328,6 +334,34 @@ class Engine:
                 p[5:] = [None, None, None]
             _check(self.L.gsr_upload_append(self.h, a.n, *p))
         _check(self.L.gsr_upload_end(self.h))
+
+    def upload_raw(self, attrs: dict, origin=(0.0, 0.0, 0.0)):
+        """raw float32 point attributes (dict keyed like a Houdini detail: P, Cd, opacity / Alpha resolved by the caller into
+        'alpha', scale, orient, and ONE of sh_coefficients / sh1..sh15 / f_rest_0..44): quantised and packed on the GPU"""
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        keep = {k: f32(v) for k, v in attrs.items()}
+        n = int(keep["P"].reshape(-1, 3).shape[0])
+        a = gsr_raw_attrs()
+        for name in ("P", "Cd", "alpha", "scale", "orient"):
+            setattr(a, name, keep[name].ctypes.data if name in keep else None)
+        ptrs = None
+        if "sh_coefficients" in keep:
+            a.sh_scheme, a.sh_array = 1, keep["sh_coefficients"].ctypes.data
+            a.sh_vec3_per_point = int(keep["sh_coefficients"].size // max(n, 1) // 3)
+        elif "sh1" in keep:
+            ptrs = (C.c_void_p * 15)(*[keep[f"sh{k + 1}"].ctypes.data if f"sh{k + 1}" in keep else None for k in range(15)])
+            a.sh_scheme, a.sh_ptr = 2, ptrs
+        elif "f_rest_0" in keep:
+            ptrs = (C.c_void_p * 45)(*[keep[f"f_rest_{k}"].ctypes.data if f"f_rest_{k}" in keep else None for k in range(45)])
+            a.sh_scheme, a.sh_ptr = 3, ptrs
+        _check(self.L.gsr_upload_begin(self.h, n, int(a.sh_scheme != 0), _f3(origin)))
+        try:
+            _check(self.L.gsr_upload_append_raw(self.h, n, C.byref(a)))
+            _check(self.L.gsr_upload_end(self.h))
+        except GsrError:
+            self.L.gsr_upload_abort(self.h)
+            raise
+        return n
 
     # ---- configuration
     def set_stream(self, hip_stream: int | None):

@@ -132,6 +132,26 @@ int  gsr_upload_append(gsr_context* ctx, int64_t n,
                        const float* P, const uint16_t* Cd, const float* alpha,
                        const uint16_t* scale, const uint16_t* orient,
                        const uint16_t* shx, const uint16_t* shy, const uint16_t* shz);
+/* The same, from RAW float32 point attributes (what a Houdini detail holds): the GPU quantises to fp16 (round to nearest even,
+ * overflow to infinity: HDK's fpreal16) and packs -- the work GR_PrimGsplat::update does in a tbb::parallel_for on the CPU
+ * (src/GR_GSplat.C:302-372).  NULL Cd / alpha / scale / orient = the reference's defaults (0 / 1 / 1 / (0,0,0,1), :233-272,309-312).
+ * SH in any of the three naming schemes (:93-189): sh_scheme 0 = none; 1 = sh_array: sh_vec3_per_point vec3 per point (the first 16
+ * are used); 2 = sh_ptr[0..14] = sh1..sh15, float[3n] each; 3 = sh_ptr[0..44] = f_rest_0..44, float[n] each (channel-major: coefficient
+ * j = (f_rest_j, f_rest_{j+15}, f_rest_{j+30})).  In schemes 2 and 3 the arrays after the first NULL one count as absent.
+ * Attribute precedence (Alpha over opacity), which scheme applies and the gsplat__sh_order rule stay with the caller (GSplatPrim).
+ * The SoA left in HBM is bit-identical to gsr_upload_append of the host-quantised arrays. */
+typedef struct gsr_raw_attrs {
+    const float* P;            /* float[3n], required */
+    const float* Cd;           /* float[3n] or NULL */
+    const float* alpha;        /* float[n] or NULL */
+    const float* scale;        /* float[3n] or NULL */
+    const float* orient;       /* float[4n] (x, y, z, w) or NULL */
+    int32_t sh_scheme;
+    int32_t sh_vec3_per_point;
+    const float* sh_array;
+    const float* const* sh_ptr;
+} gsr_raw_attrs;
+int  gsr_upload_append_raw(gsr_context* ctx, int64_t n, const gsr_raw_attrs* attrs);
 int  gsr_upload_end(gsr_context* ctx);
 /* gives up an upload that failed between begin and end: the context holds no geometry afterwards */
 int  gsr_upload_abort(gsr_context* ctx);
@@ -280,8 +300,8 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        neighbourhood culls less but breaks less often.  The library doubles it whenever a frame had to be
                                        repaired and lets it shrink back to this value while frames hold. */
 #define GSR_OPT_LOCAL_SORT      15   /* depth sort of frames that keep few splats: 1 (default) = when the slot's previous frame kept <= 1.2 M, one global
-                                       pass into 512 buckets over the key range that frame kept + one kernel that sorts every bucket locally
-                                       (4 launches instead of 9); 0 = always three global LSD passes; 2 = the local form whenever a previous
+                                       scatter into 1024 buckets over the key range that frame kept + one kernel that sorts every bucket locally
+                                       (2 launches instead of 9); 0 = always three global LSD passes; 2 = the local form whenever a previous
                                        frame's key range is known.  Same order either way. */
 int  gsr_set_option(gsr_context* ctx, int option, int value);
 
@@ -311,8 +331,9 @@ int  gsr_debug_read_tile_work(gsr_context* ctx, uint32_t* work4, int64_t n_tiles
 /* Stand-alone device radix sort of (key,value) u32 pairs on bits [0, key_bits):
  * the sort the pipeline uses, exposed for parity tests (host pointers). */
 int  gsr_debug_sort_pairs(gsr_context* ctx, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits);
-/* ... the form small frames use: one global pass into 512 buckets of width 2^bucket_shift starting at bucket_lo (keys outside
- * land in the first / last bucket), then every bucket sorted by one workgroup (k_radix_local).  Any lo / shift gives the same order. */
+/* ... the form small frames use: one scatter into 1024 buckets of width 2^bucket_shift starting at bucket_lo (keys outside
+ * land in the first / last bucket), then every bucket sorted by one workgroup (k_radix_local).  Any lo / shift gives the same order;
+ * GSR_E_INVALID if a bucket outgrows its region of 8192 keys (the pipeline then falls back to the global sort). */
 int  gsr_debug_sort_pairs_local(gsr_context* ctx, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits,
                                 uint32_t bucket_lo, int bucket_shift);
 

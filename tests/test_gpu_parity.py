@@ -90,15 +90,15 @@ def test_radix_sort_pairs(pkg, engine, n, bits):
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(k, keys[order])
     assert np.array_equal(v, vals[order])
-    # the small-frame form (k_bucket_scatter + k_radix_local): 512 buckets of width 2^shift from lo, filled with atomics, every
+    # the small-frame form (k_bucket_scatter + k_radix_local): 1024 buckets of width 2^shift from lo, filled with atomics, every
     # bucket sorted on its own and its ties put back into payload order -- the same order, ties included, WHATEVER the predicted
     # range, as long as no bucket outgrows its region of 8192 keys (then the call reports it; the pipeline falls back)
     if n > 0:
         span_bits = max(int(keys.max()).bit_length(), 1)
-        for lo, shift in ((0, max(span_bits - 9, 0)), (int(keys.min()), 0), (0, min(span_bits, 31)), (int(keys.max()) // 2, max(span_bits - 12, 0)),
-                          (int(keys.max()) // 3, max(span_bits - 10, 0))):
-            d = np.where(keys > lo, (keys.astype(np.int64) - lo) >> shift, 0).clip(0, 511)
-            if np.bincount(d, minlength=512).max() > 8192:
+        for lo, shift in ((0, max(span_bits - 10, 0)), (int(keys.min()), 0), (0, min(span_bits, 31)), (int(keys.max()) // 2, max(span_bits - 13, 0)),
+                          (int(keys.max()) // 3, max(span_bits - 11, 0))):
+            d = np.where(keys > lo, (keys.astype(np.int64) - lo) >> shift, 0).clip(0, 1023)
+            if np.bincount(d, minlength=1024).max() > 8192:
                 with pytest.raises(pkg.GsrError):
                     engine.debug_sort_pairs(keys, vals, bits, local=(lo, shift))
                 continue
@@ -1146,6 +1146,73 @@ def test_multi_gpu_over_rccl_matches_single_gpu(pkg, engine):
                 assert np.array_equal(M.render(c), img), f"layout {layout}: frame {k} differs between {M.count} GPUs and one"
         finally:
             M.close()
+
+
+@pytest.mark.parametrize("scheme", ["array", "vec3", "f_rest", "none"])
+def test_raw_ingest_on_the_gpu_matches_the_host_quantisation(pkg, scheme):
+    """gsr_upload_append_raw: raw float32 attributes are quantised (fp16, round to nearest even, overflow to infinity) and packed
+    on the GPU.  The frame -- records, keys, pixels -- is bit-identical to the one from GSplatPrim's host-side quantisation
+    (src/GR_GSplat.C:302-372 restated) of the same attributes, in every SH naming scheme, with missing attributes taking the
+    reference's defaults, and with values on every edge of the conversion: subnormal halves, the 65504 / 65520 rounding
+    boundary, +-inf, NaN, -0, ties to even."""
+    n = 40000
+    s = pkg.scenes.make_scene(n, seed=271, sh=True)
+    rng = np.random.default_rng(272)
+    f16 = lambda bits: bits.view(np.float16).astype(np.float32)
+    coef = rng.normal(0, 0.15, (n, 15, 3)).astype(np.float32)
+    scale = f16(s.scale) * np.float32(1.0003)                              # not fp16-exact
+    Cd = f16(s.Cd) + np.float32(3e-5)
+    orient = f16(s.orient) * np.float32(0.99991)
+    edge = np.float32([6.0e-8, 5.9604645e-8, 2.9802322e-8, 2.98023224e-8 * 1.0000001, 6.1e-5, 6.097e-5, 65504.0, 65519.99, 65520.0, 65536.0, 1e9,
+                       np.inf, -np.inf, np.nan, -0.0, 0.0, 1.00048828125, 1.0009765625 + 0.00048828125, -2.0009765625 - 0.0009765625, 0.333333343])
+    k = edge.size
+    coef[:k, 3, 1] = edge; coef[k:2 * k, 0, 0] = -edge          # SH slots
+    Cd[:k, 2] = edge                                            # colour
+    scale[2 * k:3 * k, 1] = edge                                # scales (huge / inf / NaN ones drop their splat on both paths)
+    orient[3 * k:4 * k, 0] = edge
+    raw = {"P": s.P, "Cd": Cd, "alpha": s.alpha, "scale": scale, "orient": orient}
+    if scheme == "array":
+        raw["sh_coefficients"] = np.concatenate([coef.reshape(n, 45), rng.normal(0, 1, (n, 9)).astype(np.float32)], axis=1)   # 18 vec3: 16 are used
+    elif scheme == "vec3":
+        raw.update({f"sh{j + 1}": np.ascontiguousarray(coef[:, j, :]) for j in range(12)})                                      # sh13.. absent: zeros
+    elif scheme == "f_rest":
+        raw.update({f"f_rest_{j + 15 * ch}": np.ascontiguousarray(coef[:, j, ch]) for j in range(15) for ch in range(3)})
+    # the host path: GSplatPrim's quantisers (parallel C++), then the half arrays through gsr_upload
+    q = pkg.engine.quantize_half
+    host = pkg.scenes.Splats(s.P, q(Cd), s.alpha, q(scale), q(orient))
+    if scheme != "none":
+        L = pkg.load_library()
+        import ctypes as C
+        sh = [np.zeros((n, 16), np.uint16) for _ in range(3)]
+        if scheme == "array":
+            arr = np.ascontiguousarray(raw["sh_coefficients"])
+            L.gsplat_pack_sh_from_array(arr.ctypes.data, n, 18, sh[0].ctypes.data, sh[1].ctypes.data, sh[2].ctypes.data)
+        elif scheme == "vec3":
+            ptrs = (C.c_void_p * 15)(*[raw[f"sh{j + 1}"].ctypes.data if j < 12 else None for j in range(15)])
+            L.gsplat_pack_sh_from_vec3(ptrs, n, sh[0].ctypes.data, sh[1].ctypes.data, sh[2].ctypes.data)
+        else:
+            ptrs = (C.c_void_p * 45)(*[raw[f"f_rest_{j}"].ctypes.data for j in range(45)])
+            L.gsplat_pack_sh_from_frest(ptrs, n, sh[0].ctypes.data, sh[1].ctypes.data, sh[2].ctypes.data)
+        host.shx, host.shy, host.shz = sh
+    assert np.array_equal(q(edge)[:15], edge[:15].astype(np.float16).view(np.uint16))     # (the host quantiser itself, against numpy)
+    cam = pkg.camera.make_camera(480, 320, sh_order=3 if scheme != "none" else 0, frame=5)
+    a, b = pkg.Engine(0), pkg.Engine(0)
+    try:
+        a.upload(host, origin=(0.1, 0.2, -0.3))
+        b.upload_raw(raw, origin=(0.1, 0.2, -0.3))
+        ia, ib = a.render(cam), b.render(cam)
+        assert np.array_equal(ia, ib, equal_nan=True) and ia[..., 3].max() > 0.5
+        ra, rb = a.debug_records(n), b.debug_records(n)
+        assert np.array_equal(ra.view(np.uint8), rb.view(np.uint8))
+        # missing attributes: the reference's defaults on both paths
+        bare_raw = {"P": s.P}
+        bare = pkg.scenes.Splats(s.P, np.zeros((n, 3), np.uint16), np.ones(n, np.float32), np.full((n, 3), 0x3c00, np.uint16),
+                                 np.tile(np.uint16([0, 0, 0, 0x3c00]), (n, 1)))
+        cam0 = pkg.camera.make_camera(200, 150, sh_order=0, frame=1, distance=60.0)
+        a.upload(bare); b.upload_raw(bare_raw)
+        assert np.array_equal(a.render(cam0), b.render(cam0), equal_nan=True)
+    finally:
+        a.close(); b.close()
 
 
 def test_rccl_entry_points_on_one_gpu(pkg, engine):

@@ -9,7 +9,7 @@ for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}
   [ "$defs" = "$spec" ] && defs=""
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $defs \
-      -o $P/variants/libgsplat_hip_$name.so $P/csrc/gsr_api.hip $P/csrc/gsr_multi.cpp $P/csrc/GSplatRenderer.cpp $P/csrc/gsplat_ingest.cpp -ldl \
+      -o $P/variants/libgsplat_hip_$name.so $P/csrc/gsr_api.hip $P/csrc/gsr_multi.cpp $P/csrc/GSplatRenderer.cpp $P/csrc/gsplat_ingest.cpp -ldl -pthread \
       > /tmp/variant_$name.log 2>&1 &
 done
 wait

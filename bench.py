@@ -477,7 +477,11 @@ def main():
         lazy_on = st_stage["lazy_colours_total"] > 0
         # eager: the colour halves are read for every visible splat; lazy: K1 reads geometry only (colours: k_colour_prefix)
         col_b = 0 if lazy_on else {0: 16, 1: 32, 2: 64, 3: 96}[order if splats.shx is not None else 0]
-        k1_bytes = nvis * (32 + col_b + 48 + 12) + (splats.n - nvis) * 32 + (splats.n // 256 + 1) * 4
+        # stage 0 = k_cluster_cull + k_preprocess.  Algorithmic bytes: 32 B of bounds per cluster; 32 B of geometry for every splat of a
+        # SURVIVING cluster (64 each); a splat that stays also reads its colour halves (eager mode only) and writes 48 (record) + 12
+        # (key, payload); 4 B per cluster for the ordered survivor list (written and read)
+        ckept, call = st_stage["clusters_kept"], st_stage["clusters_total"]
+        k1_bytes = call * 32 + ckept * 64 * 32 + nvis * (col_b + 48 + 12) + ckept * 8
         k1_traffic = None
         try:
             k1_traffic = float(tj["k_preprocess"]["hbm_bytes_per_launch"]) if tj is not None else None
@@ -488,9 +492,10 @@ def main():
                        "frac": k1_gbps / HBM_PEAK_GBPS, "peak_measured": peak_meas, "frac_of_measured": (k1_gbps / peak_meas) if peak_meas else None,
                        "traffic": k1_traffic, "avg_launch_ms": k1_ms,
                        "algorithmic_bytes_per_launch": k1_bytes,
-                       "splats_kept": int(nvis),
-                       "note": ("lazy colour: geometry only (32 B in per splat, 48 + 12 B out per splat that stays)" if lazy_on else "eager colour") +
-                               "; VALU-bound once occlusion culling leaves one splat in thirteen (DESIGN.md section 8)"}
+                       "splats_kept": int(nvis), "clusters_kept": int(ckept), "clusters": int(call),
+                       "note": "k_cluster_cull + k_preprocess (stage 0 of the frame); " +
+                               ("lazy colour: geometry only" if lazy_on else "eager colour: + the colour halves of every splat that stays") +
+                               "; K1 is FP32-issue bound (the 250-instruction covariance chain for every clip-visible splat of a surviving cluster)"}
 
     if rank == 0:
         line = {

@@ -1541,7 +1541,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     const uint32_t n_slots = n ? div_up(c->nclus, 4u) * (uint32_t)GSR_K1_THREADS : 0u;   // the slots K1 can fill at most
     const bool local = !cache_hit && n_slots > 0 && key_bits > 9 && !(c->opt_flags & GSR_FLAG_FULL_KEYS) && sl.kept_hi > sl.kept_lo && !j.deferred &&
                        !c->classic_once && sl.kept_culled == j.cull &&
-                       (c->opt_local_sort >= 2 || (c->opt_local_sort == 1 && sl.kept_hint > 0 && sl.kept_hint <= 1200000u));
+                       (c->opt_local_sort >= 2 || (c->opt_local_sort == 1 && sl.kept_hint > 0 && sl.kept_hint <= 500000u));
     if (!cache_hit) c->classic_once = false;
     j.local_sort = local;
     if (n > 0) {

@@ -299,7 +299,7 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        depth horizons of the previous frame (default 2; 0..64).  The view moves between frames: a wider
                                        neighbourhood culls less but breaks less often.  The library doubles it whenever a frame had to be
                                        repaired and lets it shrink back to this value while frames hold. */
-#define GSR_OPT_LOCAL_SORT      15   /* depth sort of frames that keep few splats: 1 (default) = when the slot's previous frame kept <= 1.2 M, one global
+#define GSR_OPT_LOCAL_SORT      15   /* depth sort of frames that keep few splats: 1 (default) = when the slot's previous frame kept <= 0.5 M, one global
                                        scatter into 1024 buckets over the key range that frame kept + one kernel that sorts every bucket locally
                                        (2 launches instead of 9); 0 = always three global LSD passes; 2 = the local form whenever a previous
                                        frame's key range is known.  Same order either way. */

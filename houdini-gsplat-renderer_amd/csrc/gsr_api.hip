@@ -1551,6 +1551,10 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         // cluster culling (k_cluster.h): which clusters of 64 storage-ordered splats can draw anything in this frame
         int rounds; uint32_t ngroups;
         cluster_grid(c->nclus, &rounds, &ngroups);
+        if ((c->opt_flags & GSR_FLAG_CULL_ROUNDS) && c->nclus > 0) {   // (test hook: the several-rounds-per-workgroup form clouds beyond 33 M splats take)
+            rounds = std::max(rounds, 3);
+            ngroups = div_up(c->nclus, (uint32_t)CC_THREADS * (uint32_t)rounds);
+        }
         hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, c->opt_cluster,
                            j.cull ? sl.hpyr : (const float*)nullptr, sl.cseg, sl.ccnt);
         // K1 over the survivors, four clusters per workgroup-iteration; the grid follows the slot's previous frame (+25 %), and

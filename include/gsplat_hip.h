@@ -266,7 +266,8 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        Per-frame results and their order on the context stream are unchanged. */
 #define GSR_OPT_DEBUG_FLAGS     5   /* A/B switches for profiling: 1 = no alpha-support shrink of the bboxes,
                                        2 = bbox-only quadrant masks (no separating-axis test), 4 = sort all 32 key bits,
-                                       8 = lazy colour without the ahead-of-time pass (every tile takes the fallback) */
+                                       8 = lazy colour without the ahead-of-time pass (every tile takes the fallback), 16 = cluster culling in the
+                                       several-rounds-per-workgroup form of clouds beyond 33 M splats */
 #define GSR_OPT_DEFERRED_CHECK   7   /* 0 (default) / 1: with a DEVICE target, gsr_render returns as soon as the frame is queued --
                                        no host wait at all -- and the frame's pair count is looked at by the next call that
                                        touches the context.  The back end always runs against the list buffer sized from

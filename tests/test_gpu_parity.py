@@ -944,6 +944,11 @@ def test_cluster_culling_and_storage_order_are_invisible(pkg, oracle):
                     assert np.array_equal(eng.render(c), img), f"storage {storage}, occlusion culling {cull}: frame {k} differs"
                     if cull == 0:
                         assert eng.stats()["n_visible"] == vis[k]
+            # the cull kernel's several-rounds-per-workgroup form (clouds beyond 33 M splats), forced by a debug flag
+            eng.set_option(pkg.engine.OPT_DEBUG_FLAGS, 16)
+            for k, (c, img) in enumerate(zip(cams, want)):
+                assert np.array_equal(eng.render(c), img), f"storage {storage}, three cull rounds per workgroup: frame {k} differs"
+            eng.set_option(pkg.engine.OPT_DEBUG_FLAGS, 0)
             # a row shard on top (band layout: clusters outside the band are culled as a whole)
             for e in (ref, eng):
                 e.set_option(pkg.engine.OPT_SHARD_LAYOUT, 1)

@@ -98,7 +98,6 @@ struct FrameJob {
     bool deferred = false;         // ... and the frame handed over without waiting for it (GSR_OPT_DEFERRED_CHECK)
     bool lazy = false;             // K1 left the SH colours pending (k_colour.h)
     bool cull = false;             // occlusion culling: k_cluster_cull and K1 drop what lies behind the slot's depth horizons
-    bool colour_kept = false;      // ... and the colours are evaluated once per kept splat (k_colour_kept), with no fallback launch
     bool direct = false;           // the frame runs on the public stream itself
     uint32_t ticket = 0;           // stamps the frame's pair count in the host mailbox
 };
@@ -1150,11 +1149,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         HIP_TRY(hipGetLastError());
     }
     if ((rc = mark(sl, 4))) return rc;
-    if (j.colour_kept && j.n > 0) {
-        // an occlusion-culled frame: one evaluation per splat K1 kept (they are about what the frame composites)
-        hipLaunchKernelGGL(k_colour_kept, dim3(1024), dim3(CL_THREADS), 0, s, f, sl.valA, sl.d_n, c->colrow, sl.rec, sl.colour_evals);
-        HIP_TRY(hipGetLastError());
-    } else if (j.lazy && j.n > 0) {
+    if (j.lazy && j.n > 0) {
         // colours for the front of every super-tile list: as deep as the previous frame's tiles scanned (+ headroom)
         const bool predict = c->prefix_valid && !(f.flags & GSR_FLAG_LAZY_NO_PREFIX);
         hipLaunchKernelGGL(k_colour_prefix, dim3((unsigned)(j.n_super * CL_BLOCKS_PER_LIST)), dim3(CL_THREADS), 0, s, f, sl.pvA,
@@ -1187,7 +1182,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
                                sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
-        if (j.lazy && !j.colour_kept) {   // the tiles that met a pending colour, with on-demand evaluation (normally none: the blocks exit at once)
+        if (j.lazy) {   // the tiles that met a pending colour, with on-demand evaluation (normally none: the blocks exit at once)
             if (j.d_depth)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<true>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
                                    sl.pvA, sl.sstart, sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
@@ -1214,7 +1209,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     // ... and while culling is held off nobody needs horizons: they are prepared again two frames before it may resume.
     // A deferred frame (handed over before its pair count was known) never culls and may have clamped lists: no horizons from it.
     if (c->opt_cull && j.n > 0 && !j.deferred && (c->opt_cull >= 2 || j.cull || (c->vis_unculled >= 300000u && c->cull_holdoff <= 2))) {
-        hz.raw = sl.hraw; hz.pyr_in = sl.hpyr; hz.pyr_out = sl.hpyr; hz.dilate = j.f.cull_dilate; hz.culled = j.cull ? 1 : 0; hz.fallback_skipped = j.colour_kept ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
+        hz.raw = sl.hraw; hz.pyr_in = sl.hpyr; hz.pyr_out = sl.hpyr; hz.dilate = j.f.cull_dilate; hz.culled = j.cull ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
         for (int l = 0; l < GSR_PYR_LEVELS; ++l) hz.pyr_off[l] = j.f.pyr_off[l];
         hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
         hz.host_end = j.cull ? sl.h_end_dev : nullptr; hz.ticket = j.ticket;
@@ -1474,11 +1469,11 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         j.f.cull_dilate = std::max(c->cull_dilate - sl.hpyr_re, 0);   // (the rest of the radius is built into the slot's pyramid)
         if (j.cull) {
             c->st.frames_culled += 1;
-            // the lists now end about where the colour pass stops anyway: colour lazily (the hint would compare the pass with
-            // the few splats that are left, and choose eager evaluation of sparse rows)
-            if (f.sh_order > 0 && c->opt_lazy) j.lazy = true;
-            // one evaluation per kept splat, unless the frame keeps far more than its tiles look at (then: list prefixes + fallback)
-            j.colour_kept = j.lazy && !(c->prefix_cheaper && c->prefix_valid);
+            // What K1 keeps is about what the frame composites: it evaluates the colours itself (eager: the SoA colour chunks of a
+            // cluster's 64 consecutive splats are coalesced reads) -- unless the frame keeps far more than its tiles look at
+            // (oblique ground, silhouettes: then list prefixes + fallback), or lazy colour is forced.  (Round 2 ran a separate pass
+            // over the sorted payloads, k_colour_kept: 16 us of scattered 128-byte rows against 9 us more in K1.)
+            if (f.sh_order > 0 && c->opt_lazy) j.lazy = c->opt_lazy >= 2 || (c->prefix_cheaper && c->prefix_valid);
         }
     }
     j.ticket = ++sl.ticket ? sl.ticket : ++sl.ticket;   // (never 0: the mailbox starts at 0)

@@ -488,8 +488,6 @@ struct GsrHorizonArgs {
     int32_t pyr_off[GSR_PYR_LEVELS];
     int32_t culled;                 // K1 / k_cluster_cull dropped splats behind `pyr_in`
     int32_t dilate;                 // ... after widening every rect by this many tiles
-    int32_t fallback_skipped;       // ... and the colours came from k_colour_kept, so no on-demand fallback was launched: a tile
-                                    // that still met a pending colour (it cannot) would have been left undrawn -> report the frame
     const uint2* lists;             // the super-tile lists
     int32_t list_cap;               // entries the list buffer holds
     const float4* geoA;             // xyz = position
@@ -652,7 +650,6 @@ k_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g
     // first thing: the frame's verdict to the host, which is waiting for it before it hands the frame over and queues the next one
     if (hz.host_end && threadIdx.x == 0) {
         uint32_t v = s_viol;
-        if (hz.fallback_skipped && nredo) v = 1u;
         *hz.host_end = ((unsigned long long)hz.ticket << 32) | (unsigned long long)(v ? 1u : 0u);
         __threadfence_system();   // out to the host NOW (without it the word left with the kernel's end: a 13 us bubble before the next frame)
     }

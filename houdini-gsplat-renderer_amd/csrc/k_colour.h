@@ -92,19 +92,3 @@ k_colour_prefix(GsrFrame f, const uint2* __restrict__ lists, const int32_t* __re
     for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
     if (lane == 0 && mine) atomicAdd(&evals[s], mine);
 }
-
-// Occlusion-culled frames: what K1 kept IS (about) what the frame composites, so the colours are evaluated once per kept splat
-// -- over the dense, sorted payload array -- instead of once per list entry of every prefix (a splat sits in ~2 lists), and no
-// record is left pending: no bail-outs, no fallback launch.  Grid-stride over the *n_dev entries.
-__global__ void __launch_bounds__(CL_THREADS)
-k_colour_kept(GsrFrame f, const uint2* __restrict__ vals, const uint32_t* __restrict__ n_dev, const uint4* __restrict__ colrow,
-              GsrRecord* __restrict__ rec, uint32_t* __restrict__ evals)
-{
-    __shared__ uint32_t srow[CL_THREADS * CL_ROW_DW];
-    __shared__ uint32_t sidx[CL_THREADS];
-    const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
-    uint32_t mine = cl_colour_span(f, vals, (int)blockIdx.x * CL_THREADS + wbase, (int)*n_dev, (int)gridDim.x * CL_THREADS, colrow, rec, srow, sidx);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
-    if (lane == 0 && mine) atomicAdd(&evals[blockIdx.x & 255u], mine);
-}

@@ -995,6 +995,10 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
     if (c->opt_super > 0)
         while ((1 << shift) < c->opt_super) ++shift;
     while ((((f->tiles_x - 1) >> shift) + 1) * (((f->tiles_y - 1) >> shift) + 1) > 256) ++shift;
+    // more than 256 tiles a side (> 4096 pixels): rects are packed in pairs of tiles (gsr_device.h); a super-tile is then at least
+    // a pair wide (512 tiles a side cannot give <= 256 super-tiles otherwise)
+    f->rect_shift = (f->tiles_x > 256 || f->tiles_y > 256) ? 1 : 0;
+    if (shift < f->rect_shift) shift = f->rect_shift;
     f->super_shift = shift;
     f->flags = c->opt_flags;
     // sort-key range of this frame: distance^2 from cam_pos to the cloud's bounding box, as float bits
@@ -1143,8 +1147,8 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
     if (j.n > 0) {
         const uint32_t nblk = div_up(j.n, BN_TILE);
         const size_t lds = (size_t)4 * BN_ITEMS * j.n_super * 8 + (size_t)4 * j.n_super * 4;
-        hipLaunchKernelGGL(k_bin_place, dim3(nblk), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n, f.super_shift,
-                           GsrShard{f.shard_index, f.shard_count, f.shard_rpb}, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk,
+        hipLaunchKernelGGL(k_bin_place, dim3(nblk), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n, f.super_shift - f.rect_shift,
+                           GsrShard{f.shard_index, f.shard_count, f.shard_rpb, f.rect_shift}, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk,
                            (uint32_t)sl.pair_cap, sl.pvA, j.ranges_folded ? range_args(c, sl) : GsrRangeArgs{});
         HIP_TRY(hipGetLastError());
     }
@@ -1163,7 +1167,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         GsrBlendArgs a;
         a.width = f.width; a.height = f.height; a.tiles_x = f.tiles_x; a.local_tiles = j.local_tiles;
         a.shard = GsrShard{f.shard_index, f.shard_count, f.shard_rpb}; a.band_rows = j.band_rows;
-        a.super_shift = f.super_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
+        a.super_shift = f.super_shift; a.rect_shift = f.rect_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
         a.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
         a.sup_work = (a.use_map && c->opt_swizzle >= 2 && sl.sup_work) ? sl.sup_work + 256 * sl.sup_par : nullptr;
         // heaviest-first table of this slot's previous frame, if that frame had the same tiles
@@ -1613,8 +1617,8 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         const uint32_t nblk = div_up(n, BN_TILE);
         rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)BN_BINS * nblk + 8);
         if (rc) return frame_abort(sl, rc);
-        hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift,
-                           GsrShard{f.shard_index, f.shard_count, f.shard_rpb}, f.stiles_x, sl.hist, nblk);
+        hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift - f.rect_shift,
+                           GsrShard{f.shard_index, f.shard_count, f.shard_rpb, f.rect_shift}, f.stiles_x, sl.hist, nblk);
         hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals, sl.d_n, n, (uint32_t)BN_TILE);
         // the list ranges and the pair count: formed by k_bin_place itself (queue_back_end) when the back end is queued
         // speculatively; a frame without a list buffer needs the count first

@@ -64,6 +64,7 @@ struct GsrFrame {
     int32_t pyr_off[6];                // depth-horizon pyramid: first cell of level l (k_cluster.h; GSR_PYR_LEVELS)
     int32_t cull_dilate;               // tiles by which a rect is widened before it is compared with the horizons (on top of the
                                        // dilation built into the pyramid)
+    int32_t rect_shift;                // tile rects are packed in units of (1 << rect_shift) tiles: 0 up to 256 tiles a side, 1 up to 512
 };
 #define GSR_FLAG_NO_ALPHA_RADIUS 1   // bbox from the full +-2 quad instead of the alpha>=1/255 support
 #define GSR_FLAG_NO_SAT          2   // quadrant masks from the bbox only
@@ -158,7 +159,10 @@ __host__ __device__ __forceinline__ uint32_t gsr_horizon_key(float h, uint32_t k
     return b - key_min;
 }
 
-// rect packing: tile coords < 256 (GSR_MAX_DIM 4096 / 16)
+// rect packing: four 8-bit coordinates in RECT UNITS of (1 << g) tiles, g = GsrFrame.rect_shift: tile coords < 256 << g.
+// A frame of more than 4096 pixels a side (g = 1) carries rects rounded outwards to pairs of tiles: everything that reads
+// a rect -- ownership, horizons, super-tile lists, the blend kernel's tile filter -- errs towards "touches", and the exact
+// test against the pixels happens in k_blend as always.
 __device__ __forceinline__ uint32_t gsr_pack_rect(int x0, int y0, int x1, int y1)
 {
     return (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
@@ -172,6 +176,7 @@ __device__ __forceinline__ uint32_t gsr_pack_rect(int x0, int y0, int x1, int y1
 //                           strip), and a splat's centre row alone usually tells whether it is ours (early-out in K1).
 struct GsrShard {
     int32_t index, count, rpb;
+    int32_t g;                         // GsrFrame.rect_shift (rects -> tile rows), 0 where no rect is involved
 };
 __host__ __device__ __forceinline__ bool gsr_shard_owns(const GsrShard& sh, int r)
 {
@@ -196,9 +201,15 @@ __host__ __device__ __forceinline__ int gsr_owned_rows(int y0, int y1, const Gsr
     return (y1 - first) / sh.count + 1;
 }
 
+// tile rows [lo, hi] of the rect rows [y0, y1]
+__device__ __forceinline__ int gsr_owned_rect_rows(int y0, int y1, const GsrShard& sh)
+{
+    return gsr_owned_rows(y0 << sh.g, ((y1 + 1) << sh.g) - 1, sh);
+}
+// 0 iff the shard owns none of the rect's rows (otherwise an upper bound of its tiles there)
 __device__ __forceinline__ int gsr_rect_tiles(uint32_t rect, const GsrShard& sh)
 {
     int x0 = rect & 255, y0 = (rect >> 8) & 255, x1 = (rect >> 16) & 255, y1 = rect >> 24;
     if (x1 < x0 || y1 < y0) return 0;
-    return (x1 - x0 + 1) * gsr_owned_rows(y0, y1, sh);
+    return ((x1 - x0 + 1) << sh.g) * gsr_owned_rect_rows(y0, y1, sh);
 }

@@ -33,7 +33,8 @@
 
 #define BN_BIG 8                           // a splat covering more super-tiles than this is expanded by the whole wave
 
-// What a list entry carries instead of the rect: which tile columns (bits 0..15) and tile rows (bits 16..31) of super-tile
+// (`shift` in this file = log2 of the super-tile edge in RECT UNITS = GsrFrame.super_shift - rect_shift; sh.g = rect_shift.)
+// What a list entry carries instead of the rect: which columns (bits 0..15) and rows (bits 16..31), in rect units, of super-tile
 // (sx, sy) the rect reaches.  A tile of the super-tile is inside the rect iff its column bit and its row bit are both set:
 // two instructions in the blend kernel's list scan instead of four byte compares.
 __device__ __forceinline__ uint32_t bn_tile_mask(uint32_t rc, int sx, int sy, int shift)
@@ -58,7 +59,7 @@ __device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, const 
     for (int sy = y0 >> shift; sy <= (y1 >> shift); ++sy) {
         if (sh.count > 1) {
             const int lo = max(y0, sy << shift), hi = min(y1, ((sy + 1) << shift) - 1);
-            if (gsr_owned_rows(lo, hi, sh) == 0) continue;
+            if (gsr_owned_rect_rows(lo, hi, sh) == 0) continue;
         }
         const uint32_t rowkey = (uint32_t)sy * (uint32_t)stiles_x;
         for (int sx = sx0; sx <= sx1; ++sx) fn(rowkey + (uint32_t)sx, sx, sy);
@@ -93,7 +94,7 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, const GsrShar
             const int ry = t / w, sy = sy0 + ry, sx = sx0 + (t - ry * w);
             if (sh.count > 1) {
                 const int lo = max(Y0, sy << shift), hi = min(Y1, ((sy + 1) << shift) - 1);
-                if (gsr_owned_rows(lo, hi, sh) == 0) continue;
+                if (gsr_owned_rect_rows(lo, hi, sh) == 0) continue;
             }
             const uint32_t dd = (uint32_t)sy * (uint32_t)stiles_x + (uint32_t)sx;
             fn(L, vL, dd, sx, sy);

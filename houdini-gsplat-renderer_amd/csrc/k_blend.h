@@ -67,6 +67,7 @@ struct GsrBlendArgs {
     GsrShard shard;             // which tile rows this launch owns
     int32_t band_rows;          // pixel rows of the output (band) image
     int32_t super_shift;        // log2(super-tile edge in tiles)
+    int32_t rect_shift;         // the list entries' column / row bits are in units of (1 << rect_shift) tiles
     int32_t stiles_x;
     int32_t use_map;            // blockIdx -> tile through tile_map (XCD-aware order)
     int32_t flags;              // GSR_FLAG_*
@@ -172,10 +173,10 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     int scan_pos = 0;                 // next list entry to scan
     uint32_t q_head = 0, q_tail = 0;  // monotonic; slot = counter & (BL_QCAP-1)
     int spar = 0;
-    // A list entry is (splat index, tile mask): bit c of the low half = the splat's rect reaches tile column c of the
-    // super-tile, bit 16 + r = tile row r (k_bin_place).  This tile is in the rect iff both of ITS bits are set.
+    // A list entry is (splat index, tile mask): bit c of the low half = the splat's rect reaches column c of the
+    // super-tile, bit 16 + r = row r, in rect units (k_bin_place).  This tile is in the rect iff both of ITS bits are set.
     const uint32_t sub_mask = (1u << a.super_shift) - 1u;
-    const uint32_t tile_bits = (1u << (tx & sub_mask)) | (0x10000u << (gty & sub_mask));
+    const uint32_t tile_bits = (1u << ((tx & sub_mask) >> a.rect_shift)) | (0x10000u << ((gty & sub_mask) >> a.rect_shift));
     // thread t scans entries 4t .. 4t+3 of a 1024-entry step: two 16-byte loads, prefetched one step ahead
     typedef uint32_t gsr_u4 __attribute__((ext_vector_type(4), aligned(8)));
     gsr_u4 preA = {0u, 0u, 0u, 0u}, preB = {0u, 0u, 0u, 0u};

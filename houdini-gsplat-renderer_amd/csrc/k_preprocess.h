@@ -417,11 +417,11 @@ gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, co
         const int i1 = (int)__builtin_floorf(__builtin_fminf(xhi, wm1));
         const int j0 = (int)__builtin_ceilf(__builtin_fmaxf(ylo, 0.0f));
         const int j1 = (int)__builtin_floorf(__builtin_fminf(yhi, hm1));
-        if (i1 >= i0 && j1 >= j0) out_rect = gsr_pack_rect(i0 >> 4, j0 >> 4, i1 >> 4, j1 >> 4);
+        if (i1 >= i0 && j1 >= j0) { const int g4 = 4 + f.rect_shift; out_rect = gsr_pack_rect(i0 >> g4, j0 >> g4, i1 >> g4, j1 >> g4); }
     }
     // a splat none of whose tiles belong to this context's row shard is dropped here: it costs no
     // colour fetch, no record and (sentinel key) no sorting
-    if (out_rect != GSR_RECT_EMPTY && gsr_rect_tiles(out_rect, GsrShard{f.shard_index, f.shard_count, f.shard_rpb}) == 0)
+    if (out_rect != GSR_RECT_EMPTY && gsr_rect_tiles(out_rect, GsrShard{f.shard_index, f.shard_count, f.shard_rpb, f.rect_shift}) == 0)
         out_rect = GSR_RECT_EMPTY;
     // Occlusion culling against the previous frame's depth horizons (k_blend.h, k_sum_work): a tile that went opaque at some
     // depth needs nothing behind it.  A splat whose key lies beyond the horizon of EVERY tile its rect reaches (widened by the
@@ -430,7 +430,9 @@ gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, co
     // look further than its horizon reports the frame, which is then rendered again without culling (k_sum_work).
     // (The pyramid is read through the cache: at most four gathers, usually of one or two lines.)
     if (hpyr && out_rect != GSR_RECT_EMPTY) {
-        const int x0 = (int)(out_rect & 255u), y0 = (int)((out_rect >> 8) & 255u), x1 = (int)((out_rect >> 16) & 255u), y1 = (int)(out_rect >> 24);
+        const int g = f.rect_shift;
+        const int x0 = (int)(out_rect & 255u) << g, y0 = (int)((out_rect >> 8) & 255u) << g;
+        const int x1 = (((int)((out_rect >> 16) & 255u) + 1) << g) - 1, y1 = (((int)(out_rect >> 24) + 1) << g) - 1;
         const int r = f.cull_dilate;
         const float h = gsr_pyr_max(hpyr, f.pyr_off, f.tiles_x, max(x0 - r, 0), max(y0 - r, 0), min(x1 + r, f.tiles_x - 1), min(y1 + r, f.tiles_y - 1));
         if (o.kb > gsr_horizon_key(h, f.key_min, f.key_max)) out_rect = GSR_RECT_EMPTY;

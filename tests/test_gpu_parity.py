@@ -170,6 +170,95 @@ def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine, n,
         assert (cover > 8).sum() > 50       # the cooperative big-splat path was exercised
 
 
+@pytest.mark.parametrize("w,h,n,big", [
+    (8192, 272, 30000, 2000),       # 512 tiles wide: tile rects are packed in pairs of tiles (GsrFrame.rect_shift = 1)
+    (272, 8192, 30000, 2000),       # ... and 512 tiles high
+    (4608, 4368, 40000, 1500),      # both sides beyond 4096: 288 x 273 tiles
+])
+def test_framebuffers_beyond_4096_pixels(pkg, oracle, engine, w, h, n, big):
+    """the reference has no framebuffer limit (src/GSplatRenderer.C:534-657); here tile coordinates are packed in 8 bits, and a
+    frame of more than 256 tiles a side carries its rects in units of two tiles -- a superset everywhere it is read, so the
+    pixels are the oracle's, with and without occlusion culling, sharded or not"""
+    splats = pkg.scenes.make_scene(n, seed=1234 + w, sh=True)
+    splats.scale[:big] = pkg.scenes.f16bits(np.random.default_rng(w).uniform(0.3, 2.5, size=(big, 3)))
+    cam = pkg.camera.make_camera(w, h, sh_order=3, frame=3)
+    engine.upload(splats)
+    img = engine.render(cam)
+    st = engine.stats()
+    assert st["stiles_x"] * st["stiles_y"] <= 256
+    ref = oracle.render(splats, cam, threads=oracle.max_threads())
+    assert ref[..., 3].max() > 0.5
+    _check_image(img, ref)
+    # every list in depth order, and holding at least the splats whose exact tile rect reaches the super-tile
+    ls, le, pv = engine.debug_tile_lists()
+    dev = engine.debug_records(splats.n)
+    rec = oracle.preprocess(splats, cam)
+    perm = oracle.argsort(rec, oracle.storage_order(splats.P))
+    rank = np.empty(splats.n, np.int64)
+    rank[perm] = np.arange(splats.n)
+    vis = np.flatnonzero(dev["visible"] == 1)
+    r = dev[vis]
+    i0 = np.ceil(np.maximum(r["cx"] - r["hx"] - 0.5, 0)); i1 = np.floor(np.minimum(r["cx"] + r["hx"] - 0.5, w - 1))
+    j0 = np.ceil(np.maximum(r["cy"] - r["hy"] - 0.5, 0)); j1 = np.floor(np.minimum(r["cy"] + r["hy"] - 0.5, h - 1))
+    ok = (i1 >= i0) & (j1 >= j0)
+    tx0, tx1, ty0, ty1 = (i0 // 16).astype(np.int64), (i1 // 16).astype(np.int64), (j0 // 16).astype(np.int64), (j1 // 16).astype(np.int64)
+    S, sx = st["super_tile"], st["stiles_x"]
+    extra = 0
+    for t in range(ls.shape[0]):
+        lst = pv[ls[t]:le[t]]
+        if lst.shape[0] > 1:
+            assert (np.diff(rank[lst]) > 0).all(), f"super-tile {t} not in depth order"
+        X0, Y0 = (t % sx) * S, (t // sx) * S
+        need = ok & (tx1 >= X0) & (tx0 <= X0 + S - 1) & (ty1 >= Y0) & (ty0 <= Y0 + S - 1)
+        # ... and at most those whose rect, rounded outwards to pairs of tiles, does
+        may = ok & ((tx1 | 1) >= X0) & ((tx0 & ~1) <= X0 + S - 1) & ((ty1 | 1) >= Y0) & ((ty0 & ~1) <= Y0 + S - 1)
+        got = set(lst.tolist())
+        assert set(vis[need].tolist()) <= got <= set(vis[may].tolist()), f"super-tile {t}: membership"
+        extra += len(got) - int(need.sum())
+    assert extra >= 0
+    _same_with_culling(pkg, engine, cam, img)
+    # row shards (both layouts): the owned tile rows of the full frame, bit for bit
+    for layout, (idx, cnt) in ((0, (1, 3)), (1, (2, 4))):
+        engine.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
+        engine.set_row_shard(idx, cnt)
+        try:
+            band = engine.render(cam)
+        finally:
+            engine.set_row_shard(0, 1)
+            engine.set_option(pkg.engine.OPT_SHARD_LAYOUT, 0)
+        assert np.array_equal(band, pkg.multigpu.extract_band(img, idx, cnt, layout)), (layout, idx, cnt)
+
+
+def test_the_largest_framebuffer(pkg, oracle, engine):
+    """8192 x 8192 (GSR_MAX_DIM): 512 x 512 tiles, 256 super-tiles of 32 x 32 tiles; three bands of rows against the oracle"""
+    import ctypes as C
+    w = h = pkg.engine.MAX_DIM
+    assert w == 8192
+    splats = pkg.scenes.make_scene(20000, seed=8192, sh=False)
+    splats.scale[:1000] = pkg.scenes.f16bits(np.random.default_rng(8).uniform(0.3, 2.0, size=(1000, 3)))
+    cam = pkg.camera.make_camera(w, h, sh_order=0, frame=1)
+    engine.upload(splats)
+    hip = C.CDLL("libamdhip64.so")
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), C.c_size_t(w * h * 16)) == 0
+    try:
+        engine.render_to_device(cam, p.value)
+        engine.synchronize()
+        st = engine.stats()
+        assert st["super_tile"] == 32 and st["stiles_x"] * st["stiles_y"] == 256
+        for y0 in (0, 4000, h - 96):
+            got = np.empty((96, w, 4), np.float32)
+            assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), C.c_void_p(p.value + y0 * w * 16), C.c_size_t(got.nbytes), 2) == 0
+            ref = oracle.render_rows(splats, cam, y0, y0 + 96, threads=oracle.max_threads())
+            assert ref[..., 3].max() > 0.2
+            _check_image(got, ref)
+            del ref
+    finally:
+        hip.hipFree(p)
+    with pytest.raises(pkg.GsrError):
+        engine.render_to_device(pkg.camera.make_camera(w + 1, 64, sh_order=0), 0)
+
+
 def _same_with_culling(pkg, engine, cam, img):
     """the same camera again with occlusion culling forced on (it engages from the slot's second frame): same pixels"""
     engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)

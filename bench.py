@@ -446,18 +446,19 @@ def main():
         "note": "k_blend is FP32-vector-issue bound at this arithmetic intensity (DESIGN.md); the HBM fraction is reported "
                 "as the metric asks, on consumed pairs only (SURVEY 8d)",
     }
-    # the bound that actually binds k_blend: FP32 vector issue.  One pixel evaluation of one record is 34 FLOP
-    # (fma = 2: affine forms 8, power 3, contract-exp2 13, opacity+clamp 2, under-blend 8), counted
+    # the bound that actually binds k_blend: FP32 vector issue.  One pixel evaluation of one record is 22 FLOP
+    # (fma = 2: affine forms 8, power 3, log-domain alpha 2 = one subtraction + one v_exp_f32 (contract v3; the software
+    # 2^x + multiply of contract v2 were 15), quad test 1, under-blend 8), counted
     # per 64-lane wave evaluation by the kernel itself (lanes outside the quad execute the same instructions)
-    FLOP_PER_EVAL = 34.0
+    FLOP_PER_EVAL = 22.0
     wave_evals = st["blend_wave_evals_total"] / frames_done
     valu_tflops = wave_evals * 64 * FLOP_PER_EVAL / (blend_ms * 1e-3) / 1e12 if blend_ms > 0 else 0.0
     # ... and against the ISSUE RATES measured on this GPU (tools/ubench_valu.hip -> profiles/ubench_valu_mi355x.txt).
     # One inner-loop iteration = two wave-record evaluations (ISA of k_blend<false>, tools/kernel_resources.py --isa):
-    # 5 v_pk_fma_f32 with three full operands (2.02 ns per SIMD), 7 with a broadcast operand (1.77), 4 v_pk_mul/add (1.76),
-    # 2 v_lshl_add (1.74), 2 v_max + 6 v_cmp (1.72), 2 v_cndmask (1.64), 9 full-rate mul/fmac/sub/add (1.0)
+    # 5 v_pk_fma_f32 with three full operands (2.02 ns per SIMD), 2 with a broadcast operand (1.77), 1 v_pk_mul (1.76),
+    # 2 v_max + 6 v_cmp (1.72), 2 v_cndmask (1.64), 2 v_exp_f32 (3.40), 9 full-rate mul/fmac/sub/add (1.0)
     n_simd = 256 * 4
-    iter_ns = 5 * 2.02 + 7 * 1.77 + 4 * 1.76 + 2 * 1.74 + 8 * 1.72 + 2 * 1.64 + 9 * 1.0
+    iter_ns = 5 * 2.02 + 2 * 1.77 + 1 * 1.76 + 8 * 1.72 + 2 * 1.64 + 2 * 3.40 + 9 * 1.0
     issue_ms = (wave_evals / 2.0) * iter_ns / n_simd * 1e-6
     roofline["valu"] = {"bound": "fp32 vector", "achieved": valu_tflops, "peak": 157.3, "unit": "TFLOP/s",
                         "frac": valu_tflops / 157.3, "wave_record_evals_per_launch": wave_evals,

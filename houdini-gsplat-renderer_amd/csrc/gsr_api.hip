@@ -1961,7 +1961,7 @@ extern "C" int gsr_debug_read_records(gsr_context* c, gsr_debug_record* out, int
             const GsrRecord& q = hr[slot];
             o.visible = 1;
             o.cx = q.cx; o.cy = q.cy; o.a1x = q.a1x; o.a1y = q.a1y; o.b1x = q.b1x; o.b1y = q.b1y;
-            o.hx = q.hx; o.hy = q.hy; o.r = q.r; o.g = q.g; o.b = q.b; o.opacity = q.opacity;
+            o.hx = q.hx; o.hy = q.hy; o.r = q.r; o.g = q.g; o.b = q.b; o.la = q.la;
             const uint32_t kb = hk[r] + sl->key_min;   // keys are stored relative to the frame's key_min
             std::memcpy(&o.key, &kb, 4);
         }

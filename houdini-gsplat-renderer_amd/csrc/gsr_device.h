@@ -29,7 +29,7 @@
 struct __attribute__((aligned(16))) GsrRecord {
     float cx, cy, hx, hy;        // centre (GL window coords), conservative bbox half extents
     float a1x, a1y, b1x, b1y;    // kappa * e / s1, kappa * e_perp / s2  (e = unit major axis, e_perp = (-ey, ex))
-    float r, g, b, opacity;      // colour after SH, opacity
+    float r, g, b, la;           // colour after SH; log2(opacity) by gsr_log2_opacity() (contract v3: alpha = 2^(la - |kappa q|^2))
 };
 static_assert(sizeof(GsrRecord) == 48, "record layout");
 #define GSR_KAPPA 1.2011224087864498f   // sqrt(log2 e)
@@ -147,6 +147,37 @@ __device__ __forceinline__ float gsr_support_radius_fast(float opacity)
 {
     const float L = __builtin_amdgcn_logf(255.0f * opacity) * 0.693147181f;
     return __builtin_fminf(2.0f, __builtin_amdgcn_sqrtf(__builtin_fmaxf(L, 0.0f) + 1.0e-4f) + 1.0e-3f);
+}
+// the same radius from la = log2(opacity): ln(255 opacity) = (la + log2 255) ln 2  (+1e-5: la carries ~1e-7 of its own error)
+__device__ __forceinline__ float gsr_support_radius_from_la(float la)
+{
+    const float L = (la + 7.99435343685886f) * 0.693147181f + 1.0e-5f;
+    return __builtin_fminf(2.0f, __builtin_amdgcn_sqrtf(__builtin_fmaxf(L, 0.0f) + 1.0e-4f) + 1.0e-3f);
+}
+
+// Contract v3: alpha lives in the log domain.  la = log2(opacity), formed once per splat with exactly the operations of the
+// oracle's gso_log2_opacity() (oracle/gsplat_oracle.c): -inf unless opacity >= 1/255 (NaN too), +inf for +inf, else
+// e + 2/ln2 * atanh((m-1)/(m+1)), opacity = m 2^e, m in (sqrt(1/2), sqrt(2)], atanh by its series up to s^9.  The fragment's
+// alpha is 2^(la - pw) -- one subtraction and one v_exp_f32 in k_blend -- and it is discarded iff la - pw < -log2(255): the
+// decision is taken on the argument, which oracle and kernel compute bit-identically.
+#define GSR_LOG2_255 7.99435343685886f
+__device__ __forceinline__ float gsr_log2_opacity(float opacity)
+{
+    if (!(opacity >= (1.0f / 255.0f))) return -__builtin_inff();
+    if (opacity > 3.4028234663852886e38f) return __builtin_inff();
+    uint32_t bits = __builtin_bit_cast(uint32_t, opacity);
+    int32_t e = (int32_t)(bits >> 23) - 127;
+    float m = __builtin_bit_cast(float, (bits & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    const float s = (m - 1.0f) / (m + 1.0f);      // IEEE division (-ffp-contract=off, no fast-math)
+    const float z = s * s;
+    float p = 1.0f / 9.0f;
+    p = __builtin_fmaf(p, z, 1.0f / 7.0f);
+    p = __builtin_fmaf(p, z, 1.0f / 5.0f);
+    p = __builtin_fmaf(p, z, 1.0f / 3.0f);
+    p = __builtin_fmaf(p, z, 1.0f);
+    const float l = s * p;
+    return __builtin_fmaf(l, 2.885390043f, (float)e);
 }
 
 // A depth horizon (distance^2 from the camera; +inf or NaN = none) in a frame's sort-key domain: K1 and the binning kernels

@@ -78,8 +78,8 @@ struct GsrBlendArgs {
 // Staging layout: one list PER QUADRANT (= per wave), holding the round's records that reach that
 // quadrant, in depth order, two records interleaved per block so that every ds_read_b128 lands as
 // ready-made operand pairs of the packed-FP32 instructions (no v_mov shuffling):
-//   f4 0: a.a1x b.a1x a.a1y b.a1y     f4 3: a.r a.g a.b a.opacity
-//   f4 1: a.b1x b.b1x a.b1y b.b1y     f4 4: b.r b.g b.b b.opacity
+//   f4 0: a.a1x b.a1x a.a1y b.a1y     f4 3: a.r a.g a.b a.la
+//   f4 1: a.b1x b.b1x a.b1y b.b1y     f4 4: b.r b.g b.b b.la
 //   f4 2: a.c0  b.c0  a.c1  b.c1      f4 5: a.zwin b.zwin - -          (HAS_DEPTH only)
 // c0/c1 = the two affine forms of the record at the TILE origin (contract v2): kq0 = lx*a1x + ly*a1y + c0 for the
 // pixel (lx, ly) of the tile -- computed once per (record, tile) by the gathering thread.
@@ -253,8 +253,8 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     // Can the splat touch this quadrant?  Separating-axis test of the oriented quad (shrunk to the radius
                     // where alpha can still reach 1/255) against the quadrant's box of pixel centres: the box axes (= bbox
                     // test) and the quad's own two axes.  Conservative.
-                    // r0 = (cx, cy, hx, hy), r1 = (a1x, a1y, b1x, b1y) = kappa e/s1, kappa e_perp/s2, r2 = (r, g, b, opacity)
-                    const float rqk = (((a.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius_fast(r2.w)) + 1.0e-3f) * GSR_KAPPA;
+                    // r0 = (cx, cy, hx, hy), r1 = (a1x, a1y, b1x, b1y) = kappa e/s1, kappa e_perp/s2, r2 = (r, g, b, la = log2 opacity)
+                    const float rqk = (((a.flags & GSR_FLAG_NO_ALPHA_RADIUS) ? 2.0f : gsr_support_radius_from_la(r2.w)) + 1.0e-3f) * GSR_KAPPA;
                     const float ddx = qcx - r0.x, ddy = qcy - r0.y;
                     // (hx, hy carry K1's own margin of 1e-4 relative + 0.01 px)
                     const bool box = __builtin_fmaxf(__builtin_fabsf(ddx) - r0.z, __builtin_fabsf(ddy) - r0.w) <= 3.5f;
@@ -289,12 +289,12 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     reinterpret_cast<float4*>(blk)[3 + h] = r2;
                     if (HAS_DEPTH) blk[20 + h] = rz;
                 }
-                if ((cnt & 1) && lane == 0) {   // odd list: pad with a record that cannot contribute (opacity 0 -> alpha 0 < 1/255)
+                if ((cnt & 1) && lane == 0) {   // odd list: pad with a record that cannot contribute (la = -inf: discarded everywhere)
                     float* blk = reinterpret_cast<float*>(&slist[wave][(cnt >> 1) * PF4]);
                     blk[1] = 0.0f; blk[3] = 0.0f; blk[5] = 0.0f; blk[7] = 0.0f;
                     blk[9] = 0.0f; blk[11] = 0.0f;
-                    // colour and opacity 0 (the axes may be stale garbage: a NaN there is rejected by the quad test)
-                    reinterpret_cast<float4*>(blk)[4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    // colour 0, la -inf (the axes may be stale garbage: a NaN there is rejected by the quad test)
+                    reinterpret_cast<float4*>(blk)[4] = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
                     if (HAS_DEPTH) blk[21] = 0.0f;
                 }
                 // the list is written and read by this wave only: LDS operations of one wave execute in order
@@ -313,13 +313,14 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     const gsr_v2f q0 = gsr_fma2(lx, (gsr_v2f){v0.x, v0.y}, gsr_fma2(ly, (gsr_v2f){v0.z, v0.w}, (gsr_v2f){v2.x, v2.y}));
                     const gsr_v2f q1 = gsr_fma2(lx, (gsr_v2f){v1.x, v1.y}, gsr_fma2(ly, (gsr_v2f){v1.z, v1.w}, (gsr_v2f){v2.z, v2.w}));
                     const gsr_v2f pw = gsr_fma2(q0, q0, q1 * q1);
-                    // (lanes outside the quad may feed exp2 a large negative argument: their result is unused)
-                    const gsr_v2f e = gsr_exp2n2(-pw);
-                    // clamp(exp * opacity, 0, 1): folds into the multiply's clamp modifier
-                    const float ala = __builtin_fminf(__builtin_fmaxf(e.x * v3.w, 0.0f), 1.0f);
-                    const float alb = __builtin_fminf(__builtin_fmaxf(e.y * v4.w, 0.0f), 1.0f);
-                    bool ina = (__builtin_fmaxf(__builtin_fabsf(q0.x), __builtin_fabsf(q1.x)) <= GSR_QLIM) && (ala >= (1.0f / 255.0f));
-                    bool inb = (__builtin_fmaxf(__builtin_fabsf(q0.y), __builtin_fabsf(q1.y)) <= GSR_QLIM) && (alb >= (1.0f / 255.0f));
+                    // contract v3: alpha = clamp(2^(la - pw), 0, 1) on the transcendental unit (v_exp_f32, the clamp is its output
+                    // modifier); the fragment is discarded iff la - pw < -log2(255) -- decided on the argument, which the oracle
+                    // forms with the same operations (lanes outside the quad may feed 2^x anything: their result is unused)
+                    const float arga = v3.w - pw.x, argb = v4.w - pw.y;
+                    const float ala = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(arga), 0.0f), 1.0f);
+                    const float alb = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(argb), 0.0f), 1.0f);
+                    bool ina = (__builtin_fmaxf(__builtin_fabsf(q0.x), __builtin_fabsf(q1.x)) <= GSR_QLIM) && (arga >= -GSR_LOG2_255);
+                    bool inb = (__builtin_fmaxf(__builtin_fabsf(q0.y), __builtin_fabsf(q1.y)) <= GSR_QLIM) && (argb >= -GSR_LOG2_255);
                     if (HAS_DEPTH) {
                         const float4 v5 = L[p * PF4 + 5];
                         ina = ina && (v5.x <= dpx);

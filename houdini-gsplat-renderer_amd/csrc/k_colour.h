@@ -64,7 +64,7 @@ cl_colour_span(const GsrFrame& f, const uint2* __restrict__ lists, int first, in
             float cr, cg, cb;
             gsr_splat_colour_from_row(f, row, 0u, cr, cg, cb);
             const float opacity = __uint_as_float(row[0].w);
-            reinterpret_cast<float4*>(rec + idx)[2] = make_float4(cr, cg, cb, opacity);   // (r, g, b, opacity): the record's third quad
+            reinterpret_cast<float4*>(rec + idx)[2] = make_float4(cr, cg, cb, gsr_log2_opacity(opacity));   // (r, g, b, la): the record's third quad
             ++mine;
         }
         __builtin_amdgcn_wave_barrier();   // the rows are overwritten by the next trip

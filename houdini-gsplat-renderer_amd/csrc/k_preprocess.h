@@ -458,7 +458,7 @@ gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, co
         float4* dst = reinterpret_cast<float4*>(rec + i);
         dst[0] = make_float4(cx, cy, hx, hy);
         dst[1] = make_float4(ex * k1, ey * k1, -(ey * k2), ex * k2);
-        dst[2] = make_float4(cr, cg, cbl, opacity);
+        dst[2] = make_float4(cr, cg, cbl, gsr_log2_opacity(opacity));
     }
     return out_rect;
 }

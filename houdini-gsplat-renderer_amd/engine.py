@@ -54,12 +54,12 @@ class gsr_stats(C.Structure):
 
 class gsr_debug_record(C.Structure):
     _fields_ = [(n, C.c_float) for n in
-                ("cx", "cy", "a1x", "a1y", "b1x", "b1y", "hx", "hy", "r", "g", "b", "opacity", "key")] + \
+                ("cx", "cy", "a1x", "a1y", "b1x", "b1y", "hx", "hy", "r", "g", "b", "la", "key")] + \
                [("visible", C.c_int32)]
 
 
 DEBUG_RECORD_DTYPE = np.dtype([(n, np.float32) for n in
-                               ("cx", "cy", "a1x", "a1y", "b1x", "b1y", "hx", "hy", "r", "g", "b", "opacity", "key")]
+                               ("cx", "cy", "a1x", "a1y", "b1x", "b1y", "hx", "hy", "r", "g", "b", "la", "key")]
                               + [("visible", np.int32)])
 
 

@@ -309,7 +309,7 @@ int  gsr_set_option(gsr_context* ctx, int option, int value);
 /* ---- debug / test access (device -> host copies of intermediates) -------- */
 /* One projected record as tests read it back (not the packed device layout). */
 typedef struct gsr_debug_record {
-    float cx, cy, a1x, a1y, b1x, b1y, hx, hy, r, g, b, opacity;   /* a1 = kappa e/s1, b1 = kappa e_perp/s2, kappa = sqrt(log2 e) */
+    float cx, cy, a1x, a1y, b1x, b1y, hx, hy, r, g, b, la;   /* a1 = kappa e/s1, b1 = kappa e_perp/s2, kappa = sqrt(log2 e); la = log2(opacity) (contract v3) */
     float key;
     int32_t visible;   /* 0 = culled */
 } gsr_debug_record;

@@ -138,6 +138,36 @@ float gso_exp2f(float x)
     return y;
 }
 
+/* Contract v3: the fragment's alpha is formed in the LOG domain, alpha = 2^(la - |kappa q|^2) with la = log2(opacity) formed
+ * once per splat -- on the GPU that is one subtraction and one transcendental-unit instruction instead of a thirteen-operation
+ * software 2^x and a multiply -- and the discard test (alpha < 1/255, shaders/GSplatShaderSource.h:307-308) is taken on the
+ * ARGUMENT, la - pw < -log2(255), which both sides compute with the same float32 operations: oracle and product agree on
+ * every fragment's fate, and 2^x itself may be any implementation good to a few ulp (here gso_exp2f, there v_exp_f32).
+ * la: -inf unless opacity >= 1/255 (alpha <= opacity: such a splat can never pass the test; NaN lands here too), +inf for
+ * +inf, else e + log2(m), opacity = m * 2^e with m in (sqrt(1/2), sqrt(2)], log2(m) = 2/ln2 * atanh(s), s = (m-1)/(m+1),
+ * atanh by its series up to s^9 (|s| <= 0.1716: the first dropped term is < 2e-9 of the result).                        */
+float gso_log2_opacity(float opacity)
+{
+    if (!(opacity >= 1.0f / 255.0f)) return -INFINITY;
+    if (opacity > 3.4028234663852886e38f) return INFINITY;
+    uint32_t bits;
+    memcpy(&bits, &opacity, 4);
+    int32_t e = (int32_t)(bits >> 23) - 127;
+    bits = (bits & 0x007fffffu) | 0x3f800000u;
+    float m;
+    memcpy(&m, &bits, 4);                      /* [1, 2) */
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float z = s * s;
+    float p = 1.0f / 9.0f;
+    p = fmaf(p, z, 1.0f / 7.0f);
+    p = fmaf(p, z, 1.0f / 5.0f);
+    p = fmaf(p, z, 1.0f / 3.0f);
+    p = fmaf(p, z, 1.0f);
+    const float l = s * p;
+    return fmaf(l, 2.885390043f, (float)e);   /* 2 / ln 2 */
+}
+
 /* src/GSplatRenderer.C:155-163 (texture side length); kept as a KAT target */
 unsigned gso_closest_sqrt_power_of_2(int n)
 {
@@ -398,6 +428,7 @@ static void project_splat(const gso_splats* s, const gso_frame* f, int64_t i, gs
     o->g = cg;
     o->b = cbl;
     o->opacity = s->alpha[i];
+    o->la = gso_log2_opacity(o->opacity);
     o->visible = 1;
 }
 
@@ -615,7 +646,6 @@ static void splat_rows_depth(const gso_record* o, int width, int height, int row
     const int i1 = (int)floorf(fminf(xhi, (float)(width - 1)));
     const int j0 = (int)ceilf(fmaxf(ylo, (float)row_lo));
     const int j1 = (int)floorf(fminf(yhi, (float)row_hi));
-    const float inv255 = 1.0f / 255.0f;
     for (int j = j0; j <= j1; ++j) {
         float* row = rgba + (size_t)j * (size_t)width * 4;
         /* Contract v2: positions are taken relative to the pixel's 16x16 TILE origin (the product composites per
@@ -635,9 +665,9 @@ static void splat_rows_depth(const gso_record* o, int width, int height, int row
             const float q1 = fmaf(lx, o->b1x, fmaf(ly, o->b1y, c1));
             if (!(fmaxf(fabsf(q0), fabsf(q1)) <= GSO_QLIM)) continue; /* outside the quad */
             const float pw = fmaf(q0, q0, q1 * q1);                   /* = log2(e) * |q|^2 */
-            float alpha = gso_exp2f(-pw) * o->opacity;                /* exp(-|q|^2) * opacity (:306-307) */
-            alpha = fminf(fmaxf(alpha, 0.0f), 1.0f);
-            if (alpha < inv255) continue; /* discard */
+            const float arg = o->la - pw;                             /* log2 of exp(-|q|^2) * opacity (:306-307) */
+            if (!(arg >= -GSO_LOG2_255)) continue;                    /* alpha < 1/255: discard (:307-308) */
+            const float alpha = arg >= 0.0f ? 1.0f : gso_exp2f(arg);  /* clamp(alpha, 0, 1) */
             /* depth test against the opaque pass (depth writes are off): GL_LEQUAL */
             if (depth && !(o->zwin <= depth[(size_t)j * (size_t)width + (size_t)i])) continue;
             float* px = row + (size_t)i * 4;

@@ -39,6 +39,7 @@ extern "C" {
 #define GSO_TILE  16                 /* the product's tile edge (include/gsplat_hip.h GSR_TILE): fragment positions
                                         are formed relative to the tile origin (contract v2)                     */
 #define GSO_KAPPA 1.2011224087864498f /* sqrt(log2 e): exp(-|q|^2) == 2^(-|kappa q|^2)                            */
+#define GSO_LOG2_255 7.99435343685886f /* a fragment is discarded iff la - |kappa q|^2 < -log2(255)  (contract v3)    */
 #define GSO_QLIM  (2.0f * GSO_KAPPA)  /* the quad |q| <= 2 in kappa units                                         */
 
 /* Per-frame uniforms, named after the GLSL uniforms they stand for
@@ -72,6 +73,7 @@ typedef struct gso_record {
     float hx, hy;       /* conservative half extents of the quad's bbox (not parity-relevant) */
     float r, g, b;      /* colour after SH                                            */
     float opacity;
+    float la;           /* log2(opacity) by gso_log2_opacity() (contract v3): alpha = 2^(la - |kappa q|^2)   */
     float key;          /* squared distance to cam_pos (sort key)                     */
     float zwin;         /* window-space depth of the whole quad: ndc.z*0.5+0.5        */
     int32_t visible;    /* 0 if culled (w<=0, z outside [-w,w])                        */
@@ -104,6 +106,7 @@ float    gso_half_to_float(uint16_t h);
 uint16_t gso_float_to_half(float f);              /* round-to-nearest-even */
 float    gso_expf(float x);                       /* contract v1 exp, x in [-80, 0] (kept as a known-answer target) */
 float    gso_exp2f(float x);                      /* the contract's 2^x, x in [-100, 0] */
+float    gso_log2_opacity(float opacity);         /* the contract's log2 of a splat's opacity (-inf below 1/255) */
 unsigned gso_closest_sqrt_power_of_2(int n);      /* src/GSplatRenderer.C:155-163 */
 
 /* vertex stage for all splats; rec[n] */

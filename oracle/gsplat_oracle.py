@@ -37,12 +37,12 @@ class gso_frame(C.Structure):
 
 class gso_record(C.Structure):
     _fields_ = [(n, C.c_float) for n in
-                ("cx", "cy", "ex", "ey", "is1", "is2", "a1x", "a1y", "b1x", "b1y", "hx", "hy", "r", "g", "b", "opacity", "key", "zwin")] + \
+                ("cx", "cy", "ex", "ey", "is1", "is2", "a1x", "a1y", "b1x", "b1y", "hx", "hy", "r", "g", "b", "opacity", "la", "key", "zwin")] + \
                [("visible", C.c_int32)]
 
 
 RECORD_DTYPE = np.dtype([(n, np.float32) for n in
-                         ("cx", "cy", "ex", "ey", "is1", "is2", "a1x", "a1y", "b1x", "b1y", "hx", "hy", "r", "g", "b", "opacity", "key", "zwin")]
+                         ("cx", "cy", "ex", "ey", "is1", "is2", "a1x", "a1y", "b1x", "b1y", "hx", "hy", "r", "g", "b", "opacity", "la", "key", "zwin")]
                         + [("visible", np.int32)])
 
 
@@ -83,6 +83,8 @@ def lib() -> C.CDLL:
         L.gso_expf.argtypes = [C.c_float]
         L.gso_exp2f.restype = C.c_float
         L.gso_exp2f.argtypes = [C.c_float]
+        L.gso_log2_opacity.restype = C.c_float
+        L.gso_log2_opacity.argtypes = [C.c_float]
         L.gso_closest_sqrt_power_of_2.restype = C.c_uint
         L.gso_closest_sqrt_power_of_2.argtypes = [C.c_int]
         L.gso_preprocess.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p]
@@ -294,6 +296,13 @@ def expf(x: float) -> float:
 
 def exp2f(x: float) -> float:
     return float(lib().gso_exp2f(float(x)))
+
+
+LOG2_255 = float(np.float32(7.99435343685886))    # GSO_LOG2_255: a fragment is discarded iff la - |kappa q|^2 < -LOG2_255
+
+
+def log2_opacity(x: float) -> float:
+    return float(lib().gso_log2_opacity(float(x)))
 
 
 def closest_sqrt_power_of_2(n: int) -> int:

@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-3
-REC_FIELDS = ("cx", "cy", "a1x", "a1y", "b1x", "b1y", "r", "g", "b", "opacity")
+REC_FIELDS = ("cx", "cy", "a1x", "a1y", "b1x", "b1y", "r", "g", "b", "la")
 
 
 def _check_image(img, ref, tol=TOL):

@@ -100,6 +100,26 @@ def test_known_answers_from_the_source(oracle):
     assert np.abs(y / np.exp(x.astype(np.float64)) - 1).max() < 4e-7
     assert oracle.expf(0.0) == 1.0 and (np.diff(y) >= 0).all() and y.max() <= 1.0
 
+    # contract v3: the base-2 exponential of the fragment stage and the log2 of a splat's opacity
+    x = np.linspace(-9.0, 0.0, 20001).astype(np.float32)
+    y = np.array([oracle.exp2f(float(v)) for v in x], dtype=np.float64)
+    assert np.abs(y / np.exp2(x.astype(np.float64)) - 1).max() < 4e-7 and oracle.exp2f(0.0) == 1.0 and y.max() <= 1.0
+    op = np.concatenate([np.geomspace(1 / 255, 1.0, 20001), np.geomspace(1.0, 1e30, 2001), [1 / 255, 0.5, 1.0, 2.0, np.sqrt(2), 255.0]]).astype(np.float32)
+    op = op[op >= np.float32(1.0) / np.float32(255.0)]
+    la = np.array([oracle.log2_opacity(float(v)) for v in op], dtype=np.float64)
+    err = np.abs(la - np.log2(op.astype(np.float64)))
+    assert err[op <= 4].max() < 5e-7                                             # under an ulp of 8 where opacities live ...
+    assert (err / np.maximum(np.abs(la), 1.0)).max() < 1.5e-7                    # ... and relative beyond
+    assert oracle.log2_opacity(1.0) == 0.0 and oracle.log2_opacity(2.0) == 1.0 and oracle.log2_opacity(0.5) == -1.0
+    srt = np.argsort(op, kind="stable")
+    assert (np.diff(la[srt]) >= 0).all()                                         # monotone
+    # below the discard threshold a splat can never draw (alpha <= opacity): -inf, which fails every fragment test
+    for v in (0.0, -1.0, 1e-3, float(np.nextafter(np.float32(1 / 255), np.float32(0))), float("nan"), float("-inf")):
+        assert oracle.log2_opacity(v) == float("-inf")
+    assert oracle.log2_opacity(float("inf")) == float("inf")
+    # the discard rule on the argument agrees with alpha >= 1/255 except within rounding of the threshold
+    assert abs(2.0 ** (-oracle.LOG2_255) - 1 / 255) < 1e-9
+
 
 def test_single_splat_centre_alpha(oracle, pkg):
     """an isolated splat: alpha at a pixel = clamp(opacity * exp(-|q|^2)) (GSplatShaderSource.h:304-312)"""

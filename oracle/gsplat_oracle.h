@@ -105,7 +105,7 @@ typedef struct gso_splats {
 float    gso_half_to_float(uint16_t h);
 uint16_t gso_float_to_half(float f);              /* round-to-nearest-even */
 float    gso_expf(float x);                       /* contract v1 exp, x in [-80, 0] (kept as a known-answer target) */
-float    gso_exp2f(float x);                      /* the contract's 2^x, x in [-100, 0] */
+float    gso_exp2f(float x);                      /* the oracle's 2^x, x in [-100, 0] (contract v3 admits any 2^x good to a few ulp) */
 float    gso_log2_opacity(float opacity);         /* the contract's log2 of a splat's opacity (-inf below 1/255) */
 unsigned gso_closest_sqrt_power_of_2(int n);      /* src/GSplatRenderer.C:155-163 */
 

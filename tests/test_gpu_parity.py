@@ -783,6 +783,32 @@ def test_multi_gpu_in_library_matches_single_gpu(pkg, oracle, engine, ranks, lay
     _check_image(want, oracle.render(splats, cam))
 
 
+def test_multi_gpu_back_to_back_device_frames_with_uneven_ranks(pkg, engine):
+    """COPY transport, device target, no synchronisation between frames, bands of very different weight (the ball fills the
+    middle bands, the outer ones see sky): a light rank is frames ahead of the root's copies unless its stream waits for them
+    -- every frame must still be the single-GPU frame, bit for bit"""
+    splats, _ = pkg.scenes.make_config("B1", 400000)
+    w, h = 960, 544
+    cams = [pkg.scenes.config_camera("B1", pkg.camera, w, h, 3, i) for i in range(8)]
+    engine.upload(splats)
+    want = [engine.render(c) for c in cams]
+    hb = HipBuffers()
+    try:
+        outs = [hb.alloc(w * h * 16) for _ in cams]
+        with pkg.MultiEngine([0] * 4, pkg.engine.TRANSPORT_COPY) as M:
+            M.set_option(pkg.engine.OPT_SHARD_LAYOUT, 1)
+            M.upload(splats)
+            for c, o in zip(cams, outs):
+                M.render_struct_to_device(pkg.engine.camera_struct(c), o, 0)        # (no synchronisation in between)
+            M.synchronize()
+            vis = [M.stats(r)["n_visible"] for r in range(4)]
+            assert max(vis) > 3 * max(1, min(vis))                                  # the ranks really are uneven
+            for k, o in enumerate(outs):
+                assert np.array_equal(hb.download(o, (h, w, 4)), want[k]), f"frame {k} differs"
+    finally:
+        hb.free()
+
+
 def test_multi_gpu_behind_the_renderer_verbs(pkg, oracle):
     """GSplatRenderer over two contexts: the nine verbs drive the sharded path from the one draw thread"""
     a = pkg.scenes.make_scene(20000, seed=141, sh=True)

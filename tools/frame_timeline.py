@@ -5,6 +5,19 @@ import csv
 import sys
 
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+if len(sys.argv) > 2 and sys.argv[2] == "--gaps":
+    # idle time in front of every kernel, over the whole trace: median / 90th percentile per kernel name
+    import statistics
+    gaps = {}
+    for p_, r in zip(rows, rows[1:]):
+        g = (int(r["Start_Timestamp"]) - int(p_["End_Timestamp"])) / 1e3
+        gaps.setdefault(r["Kernel_Name"].split("(")[0][:40], []).append(g)
+    print("%-40s %6s %9s %9s %9s" % ("idle in front of", "n", "median us", "p90 us", "min us"))
+    for k, v in sorted(gaps.items(), key=lambda kv: -statistics.median(kv[1])):
+        if len(v) >= 20:
+            v.sort()
+            print("%-40s %6d %9.1f %9.1f %9.1f" % (k, len(v), statistics.median(v), v[int(0.9 * (len(v) - 1))], v[0]))
+    sys.exit(0)
 # a frame = from one k_preprocess to the next; take the last complete one
 starts = [i for i, r in enumerate(rows) if "k_preprocess" in r["Kernel_Name"]]
 if len(starts) < 3:

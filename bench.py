@@ -334,8 +334,10 @@ def main():
             torch.cuda.synchronize()
             verified = bool(torch.equal(stitched, ref)) and bool(ref[..., 3].max() > 0)
             ref_eng.close()
-            if not verified:
-                raise SystemExit("sharded frame differs from the unsharded frame")
+            if not verified:   # reported in the JSON line (a number next to "false" is not a valid number); no exit here: the
+                               # other ranks are waiting at the barrier below
+                print("[bench] the sharded frame DIFFERS from the unsharded frame: max |diff| %.3e" %
+                      float((stitched - ref).abs().max()), file=sys.stderr)
         dist.barrier()
     st = eng.stats()
     # extra leg (untimed, informational): a few more frames with HIP events around EVERY stage -> per-stage breakdown and the

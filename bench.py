@@ -90,7 +90,7 @@ def parse_args():
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="timed region: 1 (default) = strictly serial frames, what an interactive viewport does and "
                          "what gives clean per-kernel durations for the roofline; 2 = frame f+1's front end overlaps "
-                         "frame f's blend kernel (the library default; reported separately as 'pipelined')")
+                         "frame f's blend kernel (reported separately as 'pipelined')")
     ap.add_argument("--pipelined", action="store_true",
                     help="after the timed region, time the same K steps again with two frames in flight and report "
                          "them as 'pipelined' (off by default so that a rocprofv3 run of the default command sees "

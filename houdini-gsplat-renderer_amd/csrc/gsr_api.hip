@@ -223,7 +223,8 @@ struct gsr_context {
     double bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
 
     FrameSlot slot[GSR_MAX_SLOTS];
-    int nslots = GSR_MAX_SLOTS;        // frames in flight (GSR_OPT_FRAMES_IN_FLIGHT)
+    int nslots = 1;                    // frames in flight (GSR_OPT_FRAMES_IN_FLIGHT): serial by default -- occlusion culling wants the
+                                       // horizons of the frame just before, and two slots hand it those of the frame before that
 
     int32_t* tile_map = nullptr;       // blockIdx -> tile (XCD-aware order), -1 = idle block
     size_t map_cap = 0;

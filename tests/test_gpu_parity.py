@@ -253,6 +253,22 @@ def test_the_largest_framebuffer(pkg, oracle, engine):
             assert ref[..., 3].max() > 0.2
             _check_image(got, ref)
             del ref
+        # the same frame with the heaviest-first tile order and occlusion culling forced on: bit-identical
+        first = np.empty((256, w, 4), np.float32)
+        assert hip.hipMemcpy(C.c_void_p(first.ctypes.data), C.c_void_p(p.value + 3900 * w * 16), C.c_size_t(first.nbytes), 2) == 0
+        engine.set_option(pkg.engine.OPT_XCD_SWIZZLE, 3)
+        engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)
+        try:
+            for _ in range(3):
+                engine.render_to_device(cam, p.value)
+            engine.synchronize()
+            assert engine.stats()["frames_culled"] >= 1
+        finally:
+            engine.set_option(pkg.engine.OPT_XCD_SWIZZLE, 2)
+            engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 1)
+        again = np.empty_like(first)
+        assert hip.hipMemcpy(C.c_void_p(again.ctypes.data), C.c_void_p(p.value + 3900 * w * 16), C.c_size_t(again.nbytes), 2) == 0
+        assert np.array_equal(first, again)
     finally:
         hip.hipFree(p)
     with pytest.raises(pkg.GsrError):

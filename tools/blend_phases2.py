@@ -40,6 +40,14 @@ print("%s local-sort %d: %.1f us per frame (host clock); last launch: %d waves, 
 for n, x in zip(names, v[:, :9].sum(axis=0)):
     print("  %-34s %6.2f %%   %7.2f us/wave" % (n, 100 * x / tot, x / tot * res / v.shape[0]))
 life = (end - start) / 100.0
+# where do the longest-lived waves (the launch's tail) spend their time?
+thr = np.quantile(life, 0.99)
+vv = v[life >= thr]
+tt = vv[:, :9].sum()
+print("the %d waves that live >= %.1f us (p99):" % (vv.shape[0], thr))
+for n, x in zip(names, vv[:, :9].sum(axis=0)):
+    print("  %-34s %6.2f %%   %7.2f us/wave" % (n, 100 * x / tt, x / tt * ((vv[:, 12] - vv[:, 11]).sum() / 100.0) / vv.shape[0]))
+print("  rounds (batches) per wave: median %.0f  max %.0f" % (np.median(vv[:, 10]), vv[:, 10].max()))
 print("wave lifetime us: median %.1f  p90 %.1f  p99 %.1f  max %.1f" % tuple(np.quantile(life, [0.5, 0.9, 0.99, 1.0])))
 t0_ = start.min()
 edges = np.linspace(0, span * 100.0, 11)

@@ -275,6 +275,16 @@ static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; 
 
 // ---------------------------------------------------------------------------
 // for the other translation units of the library (gsr_multi.cpp)
+#ifdef GSR_KPROF
+extern "C" int gsr_debug_kprof_blocks(unsigned int* out8192) {
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out8192, HIP_SYMBOL(g_kprof_blk), sizeof(g_kprof_blk)) == hipSuccess ? 0 : -1;
+}
+extern "C" int gsr_debug_kprof(unsigned long long* out128) {
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_kprof), sizeof(g_kprof)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef SW_PROFILE
 extern "C" int gsr_debug_sw_profile(unsigned long long* out8) {
     hipDeviceSynchronize();

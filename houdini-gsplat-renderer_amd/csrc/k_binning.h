@@ -112,6 +112,7 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     // (d < BN_BINS below: a frame whose small-frame sort overflowed a bucket is rendered again, but until then its payloads may
     //  be another frame's -- they must not index past the bins)
     __shared__ uint32_t h[4][BN_BINS];
+    KPROF_BLK_BEGIN
     const int wave = threadIdx.x >> 6;
     const uint32_t n = *n_dev;
     const uint32_t nb = (n + BN_TILE - 1) / BN_TILE;
@@ -132,6 +133,7 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     __syncthreads();
     for (int b = threadIdx.x; b < BN_BINS; b += BN_THREADS)
         hist[(size_t)b * nblk + tile] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
+    KPROF_BLK_END(3, n - tile * BN_TILE < BN_TILE ? n - tile * BN_TILE : BN_TILE)
 }
 
 // list range of every super-tile = exclusive scan of the totals; the pair count and the frame's other news go to the host.
@@ -200,7 +202,7 @@ k_bin_ranges(GsrRangeArgs a)
 // Nothing is mutated between A and B, so a wave pays a handful of dependent LDS round trips in
 // total instead of several per group.
 // Dynamic LDS: lmask[4 waves][BN_ITEMS groups][ns] (u64) followed by wbase[4][ns] (u32), ns = n_super.
-// ranges.totals != NULL: the list ranges are formed HERE (every workgroup scans the 256 totals itself; workgroup 0 also writes
+// ranges.totals != NULL: the list ranges are formed HERE (every workgroup scans the 256 totals itself; the last one also writes
 // them out and posts the pair count) instead of by a k_bin_ranges launch in front: one launch floor less per frame.
 __global__ void __launch_bounds__(BN_THREADS)
 k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, GsrShard sh,
@@ -208,16 +210,22 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
             uint32_t nblk, uint32_t cap, uint2* __restrict__ out, GsrRangeArgs ranges)
 {
     static_assert(BN_THREADS == BN_BINS, "one thread per super-tile in the range scan");
+    KPROF(0, 0)
+    KPROF_BLK_BEGIN
     extern __shared__ unsigned long long bn_lds[];
     __shared__ uint32_t s_start[BN_BINS];
     __shared__ uint32_t s_rwave[4];
     __shared__ unsigned long long s_rsum[4];
     if (ranges.totals) {
-        s_start[threadIdx.x] = bn_ranges(ranges, blockIdx.x == 0, s_rwave, s_rsum);
+        // (the LAST workgroup of the grid publishes: the grid is sized for the host's upper bound, so that one has no splats of
+        //  its own as a rule -- writing the ranges and the mailbox, four dependent trips, cost workgroup 0 three microseconds
+        //  that the kernel then ended three microseconds later)
+        s_start[threadIdx.x] = bn_ranges(ranges, blockIdx.x == gridDim.x - 1u, s_rwave, s_rsum);
     } else {
         s_start[threadIdx.x] = ((int)threadIdx.x < ns) ? (uint32_t)sstart[threadIdx.x] : 0u;
     }
     __syncthreads();
+    KPROF(0, 1)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long* lmask = bn_lds + (size_t)wave * BN_ITEMS * ns;                       // [g][d] of this wave
     uint32_t* wbase_all = reinterpret_cast<uint32_t*>(bn_lds + (size_t)4 * BN_ITEMS * ns);   // [wave][d]
@@ -227,9 +235,11 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     if (blockIdx.x >= nb) return;
     const uint32_t tile = rs_tile_of_block(blockIdx.x, nb, true);
     const uint32_t first = tile * BN_TILE + wave * BN_WAVE_ITEMS;
+    KPROF(0, 2)
     for (int b = lane; b < BN_ITEMS * ns; b += 64) lmask[b] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    KPROF(0, 3)
     uint2 v[BN_ITEMS];
 #pragma unroll
     for (int g = 0; g < BN_ITEMS; ++g) {   // (A)
@@ -240,6 +250,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    KPROF(0, 4)
     for (int d = lane; d < ns; d += 64) {  // (S) this wave's pair count per super-tile
         uint32_t c = 0;
 #pragma unroll
@@ -247,12 +258,14 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
         wbase[d] = c;
     }
     __syncthreads();
+    KPROF(0, 5)
     for (int d = threadIdx.x; d < ns; d += BN_THREADS) {   // counts -> first list position of each wave
         uint32_t p = s_start[d] + offs[(size_t)d * nblk + tile];
 #pragma unroll
         for (int w = 0; w < 4; ++w) { const uint32_t c = wbase_all[w * ns + d]; wbase_all[w * ns + d] = p; p += c; }
     }
     __syncthreads();
+    KPROF(0, 6)
 #pragma unroll
     for (int g = 0; g < BN_ITEMS; ++g) {   // (B)
         bn_group_pairs(v[g], shift, sh, stiles_x, [&](int L, uint2 vL, uint32_t d, int sx, int sy) {
@@ -263,6 +276,8 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
             if (pos < cap) out[pos] = make_uint2(vL.x, bn_tile_mask(vL.y, sx, sy, shift));
         });
     }
+    KPROF(0, 7)
+    KPROF_BLK_END(0, n - tile * BN_TILE < BN_TILE ? n - tile * BN_TILE : BN_TILE)
 }
 
 // root side of the multi-GPU path: gathered band images -> frame.

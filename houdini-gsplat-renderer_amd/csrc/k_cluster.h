@@ -15,7 +15,10 @@
 #include "gsr_device.h"
 
 #define GSR_CLUSTER 64                 // splats per cluster = lanes of a wavefront
-#define CC_THREADS 256                 // threads of a k_cluster_cull workgroup (one cluster each per round)
+#ifndef CC_THREADS
+#define CC_THREADS 256
+#endif
+// (CC_THREADS: threads of a k_cluster_cull workgroup, one cluster each per round)
 #define CC_MAX_GROUPS 4096             // count entries K1's prologue can search (64 x 64)
 
 // ---- upload time ------------------------------------------------------------------------------------------------------

@@ -371,11 +371,14 @@ k_bucket_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ val
     __shared__ uint32_t h[BK_BUCKETS];
     __shared__ uint32_t s_wave[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    KPROF(1, 0)
+    KPROF_BLK_BEGIN
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t nb = (n + RS_TILE - 1) / RS_TILE;
     if (blockIdx.x >= nb) return;
     for (int b = threadIdx.x; b < BK_BUCKETS; b += RS_THREADS) h[b] = 0;
     __syncthreads();
+    KPROF(1, 1)
     const uint32_t tile_base = blockIdx.x * RS_TILE;
     const uint32_t nvalid = (n - tile_base < RS_TILE) ? (n - tile_base) : RS_TILE;
     uint32_t k_[RS_ITEMS], meta[RS_ITEMS];   // meta = bucket | rank in (workgroup, bucket) << 12, 0xffffffff = no item
@@ -406,6 +409,7 @@ k_bucket_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ val
         }
     }
     __syncthreads();
+    KPROF(1, 2)
     for (int d = threadIdx.x; d < BK_BUCKETS; d += RS_THREADS) {   // one reservation per bucket this workgroup has keys for
         const uint32_t c = h[d];
         h[d] = c ? atomicAdd(&gcnt[(size_t)d * BK_STRIDE], c) : 0u;
@@ -416,6 +420,7 @@ k_bucket_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ val
         if (threadIdx.x == 0 && tot) atomicAdd(n_out, tot);
     }
     __syncthreads();
+    KPROF(1, 3)
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         if (meta[r] == 0xffffffffu) continue;
@@ -423,12 +428,16 @@ k_bucket_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ val
         if (p < (uint32_t)BK_CAP) { kout[(size_t)d * BK_CAP + p] = k_[r]; vout[(size_t)d * BK_CAP + p] = v_[r]; }
         else if (failed) *failed = 1u;            // the bucket's region is full: the prediction missed badly
     }
+    KPROF(1, 4)
+    KPROF_BLK_END(1, mine)
 }
 
 // one stable 8-bit pass over the n (<= RL_CHUNK) items a workgroup holds in registers in (wave, round, lane) order:
 // on return skeys / svals hold them sorted by the digit, and dcount[d] = items with digit d, dbase[d] = their first position
+// wq = items per wave (a multiple of 64, <= RL_WAVE_ITEMS): wave w holds items [w * wq, (w + 1) * wq) -- a small bucket is
+// spread over the four waves instead of filling the first one round after round
 template <typename V>
-__device__ __forceinline__ void rl_pass_in_lds(uint32_t (&k_)[RL_ITEMS], V (&v_)[RL_ITEMS], uint32_t n, int shift, uint32_t sub,
+__device__ __forceinline__ void rl_pass_in_lds(uint32_t (&k_)[RL_ITEMS], V (&v_)[RL_ITEMS], uint32_t n, uint32_t wq, int shift, uint32_t sub,
                                                uint32_t (*wc)[RL_BINS], uint32_t* dbase, uint32_t* dcount, uint32_t* s_wave,
                                                uint32_t* skeys, V* svals)
 {
@@ -439,8 +448,8 @@ __device__ __forceinline__ void rl_pass_in_lds(uint32_t (&k_)[RL_ITEMS], V (&v_)
     uint32_t meta[RL_ITEMS];
 #pragma unroll
     for (int r = 0; r < RL_ITEMS; ++r) {
-        const uint32_t li = (uint32_t)wave * RL_WAVE_ITEMS + (uint32_t)r * 64u + (uint32_t)lane;
-        const bool valid = li < n;
+        const uint32_t li = (uint32_t)wave * wq + (uint32_t)r * 64u + (uint32_t)lane;
+        const bool valid = (uint32_t)r * 64u < wq && li < n;
         const uint32_t d = ((k_[r] - sub) >> shift) & (RL_BINS - 1);
         unsigned long long m = __ballot(valid);
         if (m == 0ull) { meta[r] = 0xffffffffu; continue; }   // (wave-uniform)
@@ -519,12 +528,15 @@ k_radix_local(const uint32_t* __restrict__ cnt, int low_bits, int full_bits, uin
     __shared__ V svals[RL_CHUNK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = (int)blockIdx.x;
+    KPROFB(2, 0, 512)
+    KPROF_BLK_BEGIN
     // where the bucket goes: the (clamped) counts of the buckets before it
     uint32_t before = 0;
     for (int d = threadIdx.x; d < b; d += RL_THREADS) { const uint32_t c = cnt[(size_t)d * BK_STRIDE]; before += c < (uint32_t)BK_CAP ? c : (uint32_t)BK_CAP; }
     uint32_t tot;
     (void)block_excl_scan_256(before, s_wave, &tot);
     const uint32_t start = tot;
+    KPROFB(2, 1, 512)
     uint32_t n = cnt[(size_t)b * BK_STRIDE];
     n = n < (uint32_t)BK_CAP ? n : (uint32_t)BK_CAP;
     if (n == 0u) return;
@@ -539,34 +551,41 @@ k_radix_local(const uint32_t* __restrict__ cnt, int low_bits, int full_bits, uin
     uint32_t k_[RL_ITEMS];
     V v_[RL_ITEMS];
     if (n <= (uint32_t)RL_CHUNK) {
-        // the whole bucket lives in registers + LDS for all passes
+        // the whole bucket lives in registers + LDS for all passes, a quarter (rounded up to whole rounds of 64) per wave
+        const uint32_t wq = ((n + 255u) / 256u) * 64u;
+        auto mine = [&](int r, uint32_t& li) { li = (uint32_t)wave * wq + (uint32_t)r * 64u + (uint32_t)lane; return (uint32_t)r * 64u < wq && li < n; };
 #pragma unroll
         for (int r = 0; r < RL_ITEMS; ++r) {
-            const uint32_t li = (uint32_t)wave * RL_WAVE_ITEMS + (uint32_t)r * 64u + (uint32_t)lane;
+            uint32_t li;
             k_[r] = 0u; v_[r] = V{};
-            if (li < n) { k_[r] = ks[li]; v_[r] = vs[li]; }
+            if (mine(r, li)) { k_[r] = ks[li]; v_[r] = vs[li]; }
         }
+        KPROFB(2, 2, 512)
         if (npass == 0) {      // (a bucket one key wide: nothing to sort but the ties)
 #pragma unroll
             for (int r = 0; r < RL_ITEMS; ++r) {
-                const uint32_t li = (uint32_t)wave * RL_WAVE_ITEMS + (uint32_t)r * 64u + (uint32_t)lane;
-                if (li < n) { skeys[li] = k_[r]; svals[li] = v_[r]; }
+                uint32_t li;
+                if (mine(r, li)) { skeys[li] = k_[r]; svals[li] = v_[r]; }
             }
             __syncthreads();
         }
         for (int p = 0; p < npass; ++p) {
-            rl_pass_in_lds(k_, v_, n, 8 * p, sub, wc, dbase, dcount, s_wave, skeys, svals);
+            rl_pass_in_lds(k_, v_, n, wq, 8 * p, sub, wc, dbase, dcount, s_wave, skeys, svals);
             if (p + 1 < npass) {
 #pragma unroll
                 for (int r = 0; r < RL_ITEMS; ++r) {
-                    const uint32_t li = (uint32_t)wave * RL_WAVE_ITEMS + (uint32_t)r * 64u + (uint32_t)lane;
-                    if (li < n) { k_[r] = skeys[li]; v_[r] = svals[li]; }
+                    uint32_t li;
+                    if (mine(r, li)) { k_[r] = skeys[li]; v_[r] = svals[li]; }
                 }
                 __syncthreads();
             }
         }
+        KPROFB(2, 3, 512)
         rl_fix_ties(skeys, svals, n, failed);
+        KPROFB(2, 4, 512)
         for (uint32_t j = threadIdx.x; j < n; j += RL_THREADS) { kd[j] = skeys[j]; vd[j] = svals[j]; }
+        KPROFB(2, 5, 512)
+        KPROF_BLK_END(2, n)
         return;
     }
     // a bucket larger than one chunk: every pass goes through global memory, chunk by chunk in order (src -> dst -> src ...)
@@ -594,7 +613,7 @@ k_radix_local(const uint32_t* __restrict__ cnt, int low_bits, int full_bits, uin
                 k_[r] = 0u; v_[r] = V{};
                 if (li < m) { k_[r] = ka[c0 + li]; v_[r] = va[c0 + li]; }
             }
-            rl_pass_in_lds(k_, v_, m, shift, sub, wc, dbase, dcount, s_wave, skeys, svals);
+            rl_pass_in_lds(k_, v_, m, (uint32_t)RL_WAVE_ITEMS, shift, sub, wc, dbase, dcount, s_wave, skeys, svals);
             for (uint32_t j = threadIdx.x; j < m; j += RL_THREADS) {
                 const uint32_t key = skeys[j];
                 const uint32_t d = ((key - sub) >> shift) & (RL_BINS - 1);
@@ -617,4 +636,5 @@ k_radix_local(const uint32_t* __restrict__ cnt, int low_bits, int full_bits, uin
         __syncthreads();
     }
     rl_fix_ties(kd, vd, n, failed);
+    KPROF_BLK_END(2, n)
 }

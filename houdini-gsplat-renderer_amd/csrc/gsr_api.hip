@@ -92,6 +92,7 @@ struct FrameJob {
     const float* d_depth = nullptr;
     bool out_is_device = false, timing = false, timing_all = false, use_map = false;
     bool speculative = false;      // the back end was queued before the pair count was known
+    int bn_items = 4;              // splats per thread of the binning kernels (k_binning.h): 4, or fewer for a small frame
     bool local_sort = false;       // the depth sort took the small-frame form (k_sort.h) ...
     bool sort_failed = false;      // ... and gave a bucket up: the frame is rendered again with the three global passes
     bool ranges_folded = false;    // ... and k_bin_place forms the list ranges and posts the pair count itself (no k_bin_ranges launch)
@@ -223,6 +224,7 @@ struct gsr_context {
     double bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
 
     FrameSlot slot[GSR_MAX_SLOTS];
+    int opt_bn_items = 0;              // (A/B hook, GSR_BN_ITEMS in the environment: 1, 2 or 4 splats per binning thread; 0 = by frame size)
     int nslots = 1;                    // frames in flight (GSR_OPT_FRAMES_IN_FLIGHT): serial by default -- occlusion culling wants the
                                        // horizons of the frame just before, and two slots hand it those of the frame before that
 
@@ -421,6 +423,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
     gsr_context* c = new (std::nothrow) gsr_context();
     if (!c) return set_err(GSR_E_OOM, "gsr_create: host allocation failed");
     c->device = device;
+    if (const char* e = std::getenv("GSR_BN_ITEMS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) c->opt_bn_items = v; }   // (A/B hook)
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return set_err(GSR_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
@@ -1156,11 +1159,14 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
     int rc;
     if ((rc = mark(sl, 3))) return rc;
     if (j.n > 0) {
-        const uint32_t nblk = div_up(j.n, BN_TILE);
-        const size_t lds = (size_t)4 * BN_ITEMS * j.n_super * 8 + (size_t)4 * j.n_super * 4;
-        hipLaunchKernelGGL(k_bin_place, dim3(nblk), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n, f.super_shift - f.rect_shift,
-                           GsrShard{f.shard_index, f.shard_count, f.shard_rpb, f.rect_shift}, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk,
-                           (uint32_t)sl.pair_cap, sl.pvA, j.ranges_folded ? range_args(c, sl) : GsrRangeArgs{});
+        const uint32_t nblk = div_up(j.n, (uint32_t)BN_THREADS * (uint32_t)j.bn_items);
+        const size_t lds = (size_t)4 * j.bn_items * j.n_super * 8 + (size_t)4 * j.n_super * 4;
+        const GsrShard shd{f.shard_index, f.shard_count, f.shard_rpb, f.rect_shift};
+        const GsrRangeArgs ra = j.ranges_folded ? range_args(c, sl) : GsrRangeArgs{};
+#define GSR_PLACE(I) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin_place<I>), dim3(nblk), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n,          \
+                                        f.super_shift - f.rect_shift, shd, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk, (uint32_t)sl.pair_cap, sl.pvA, ra)
+        if (j.bn_items == 1) GSR_PLACE(1); else if (j.bn_items == 2) GSR_PLACE(2); else GSR_PLACE(4);
+#undef GSR_PLACE
         HIP_TRY(hipGetLastError());
     }
     if ((rc = mark(sl, 4))) return rc;
@@ -1625,12 +1631,19 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     hipError_t e = hipSuccess;
     if (n > 0) {
         // coarse binning as a counting sort (k_binning.h): count -> scan -> ranges -> [pair count to the host] -> place
-        const uint32_t nblk = div_up(n, BN_TILE);
+        // splats per binning workgroup: 1024 for frames that keep millions, fewer for the small ones (k_binning.h)
+        // (measured, fps with 4 / 2 / 1: C1 12 770 / 13 540 / 14 190, C2 7880 / 8270 / 8510, C3 4770 / 4900 / 4830, C4 3930 / 3950 / 3760)
+        j.bn_items = c->opt_bn_items > 0 ? c->opt_bn_items : (!local ? 4 : (sl.kept_hint <= 150000u ? 1 : 2));
+        const uint32_t bn_tile = (uint32_t)BN_THREADS * (uint32_t)j.bn_items;
+        const uint32_t nblk = div_up(n, bn_tile);
         rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)BN_BINS * nblk + 8);
         if (rc) return frame_abort(sl, rc);
-        hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift - f.rect_shift,
-                           GsrShard{f.shard_index, f.shard_count, f.shard_rpb, f.rect_shift}, f.stiles_x, sl.hist, nblk);
-        hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals, sl.d_n, n, (uint32_t)BN_TILE);
+        const GsrShard shd{f.shard_index, f.shard_count, f.shard_rpb, f.rect_shift};
+#define GSR_COUNT(I) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin_count<I>), dim3(nblk), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift - f.rect_shift, \
+                                        shd, f.stiles_x, sl.hist, nblk)
+        if (j.bn_items == 1) GSR_COUNT(1); else if (j.bn_items == 2) GSR_COUNT(2); else GSR_COUNT(4);
+#undef GSR_COUNT
+        hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals, sl.d_n, n, bn_tile);
         // the list ranges and the pair count: formed by k_bin_place itself (queue_back_end) when the back end is queued
         // speculatively; a frame without a list buffer needs the count first
         if (!(sl.pair_cap > 0)) hipLaunchKernelGGL(k_bin_ranges, dim3(1), dim3(BN_BINS), 0, s, range_args(c, sl));

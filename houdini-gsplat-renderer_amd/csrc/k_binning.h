@@ -105,25 +105,30 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, const GsrShar
 // sorted = (splat index, packed tile rect) in depth-rank order; *n_dev of them exist (the grid is
 // sized for the host-side upper bound: surplus blocks publish zeros).  Blocks are handed to XCDs
 // in contiguous eighths (rs_tile_of_block), like the depth sort's.
+// ITEMS = splats per thread: 4 for frames that keep millions (fewer, larger workgroups: less histogram to scan), 1 or 2 for the
+// few hundred thousand splats of an occlusion-culled frame (300 workgroups of 1024 splats leave most of the chip idle and every
+// workgroup walks four groups one after the other)
+template <int ITEMS>
 __global__ void __launch_bounds__(BN_THREADS)
 k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, GsrShard sh,
             int stiles_x, uint32_t* __restrict__ hist, uint32_t nblk)
 {
+    constexpr uint32_t TILE = BN_THREADS * ITEMS;
     // (d < BN_BINS below: a frame whose small-frame sort overflowed a bucket is rendered again, but until then its payloads may
     //  be another frame's -- they must not index past the bins)
     __shared__ uint32_t h[4][BN_BINS];
     KPROF_BLK_BEGIN
     const int wave = threadIdx.x >> 6;
     const uint32_t n = *n_dev;
-    const uint32_t nb = (n + BN_TILE - 1) / BN_TILE;
+    const uint32_t nb = (n + TILE - 1) / TILE;
     if (blockIdx.x >= nb) return;   // surplus block of the upper-bound grid: the row scan only reads the blocks that exist
     for (int b = threadIdx.x; b < 4 * BN_BINS; b += BN_THREADS) (&h[0][0])[b] = 0;
     __syncthreads();
     const uint32_t tile = rs_tile_of_block(blockIdx.x, nb, true);
     {
-        const uint32_t base = tile * BN_TILE;
-#pragma unroll 2
-        for (int k = 0; k < BN_ITEMS; ++k) {
+        const uint32_t base = tile * TILE;
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
             const uint32_t i = base + k * BN_THREADS + threadIdx.x;   // (every wave sees 64 consecutive splats)
             const uint2 v = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
             bn_group_pairs(v, shift, sh, stiles_x,
@@ -133,7 +138,7 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     __syncthreads();
     for (int b = threadIdx.x; b < BN_BINS; b += BN_THREADS)
         hist[(size_t)b * nblk + tile] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
-    KPROF_BLK_END(3, n - tile * BN_TILE < BN_TILE ? n - tile * BN_TILE : BN_TILE)
+    KPROF_BLK_END(3, n - tile * TILE < TILE ? n - tile * TILE : TILE)
 }
 
 // list range of every super-tile = exclusive scan of the totals; the pair count and the frame's other news go to the host.
@@ -204,12 +209,14 @@ k_bin_ranges(GsrRangeArgs a)
 // Dynamic LDS: lmask[4 waves][BN_ITEMS groups][ns] (u64) followed by wbase[4][ns] (u32), ns = n_super.
 // ranges.totals != NULL: the list ranges are formed HERE (every workgroup scans the 256 totals itself; the last one also writes
 // them out and posts the pair count) instead of by a k_bin_ranges launch in front: one launch floor less per frame.
+template <int ITEMS>
 __global__ void __launch_bounds__(BN_THREADS)
 k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, GsrShard sh,
             int stiles_x, int ns, const uint32_t* __restrict__ offs, const int32_t* __restrict__ sstart,
             uint32_t nblk, uint32_t cap, uint2* __restrict__ out, GsrRangeArgs ranges)
 {
     static_assert(BN_THREADS == BN_BINS, "one thread per super-tile in the range scan");
+    constexpr uint32_t TILE = BN_THREADS * ITEMS, WAVE_ITEMS = TILE / 4;   // wave w owns the w-th contiguous quarter of the block
     KPROF(0, 0)
     KPROF_BLK_BEGIN
     extern __shared__ unsigned long long bn_lds[];
@@ -227,22 +234,22 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     __syncthreads();
     KPROF(0, 1)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long* lmask = bn_lds + (size_t)wave * BN_ITEMS * ns;                       // [g][d] of this wave
-    uint32_t* wbase_all = reinterpret_cast<uint32_t*>(bn_lds + (size_t)4 * BN_ITEMS * ns);   // [wave][d]
+    unsigned long long* lmask = bn_lds + (size_t)wave * ITEMS * ns;                       // [g][d] of this wave
+    uint32_t* wbase_all = reinterpret_cast<uint32_t*>(bn_lds + (size_t)4 * ITEMS * ns);   // [wave][d]
     uint32_t* wbase = wbase_all + wave * ns;
     const uint32_t n = *n_dev;
-    const uint32_t nb = (n + BN_TILE - 1) / BN_TILE;
+    const uint32_t nb = (n + TILE - 1) / TILE;
     if (blockIdx.x >= nb) return;
     const uint32_t tile = rs_tile_of_block(blockIdx.x, nb, true);
-    const uint32_t first = tile * BN_TILE + wave * BN_WAVE_ITEMS;
+    const uint32_t first = tile * TILE + wave * WAVE_ITEMS;
     KPROF(0, 2)
-    for (int b = lane; b < BN_ITEMS * ns; b += 64) lmask[b] = 0ull;
+    for (int b = lane; b < ITEMS * ns; b += 64) lmask[b] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     KPROF(0, 3)
-    uint2 v[BN_ITEMS];
+    uint2 v[ITEMS];
 #pragma unroll
-    for (int g = 0; g < BN_ITEMS; ++g) {   // (A)
+    for (int g = 0; g < ITEMS; ++g) {   // (A)
         const uint32_t i = first + g * 64 + lane;
         v[g] = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
         bn_group_pairs(v[g], shift, sh, stiles_x,
@@ -254,7 +261,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     for (int d = lane; d < ns; d += 64) {  // (S) this wave's pair count per super-tile
         uint32_t c = 0;
 #pragma unroll
-        for (int g = 0; g < BN_ITEMS; ++g) c += (uint32_t)__builtin_popcountll(lmask[g * ns + d]);
+        for (int g = 0; g < ITEMS; ++g) c += (uint32_t)__builtin_popcountll(lmask[g * ns + d]);
         wbase[d] = c;
     }
     __syncthreads();
@@ -267,7 +274,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     __syncthreads();
     KPROF(0, 6)
 #pragma unroll
-    for (int g = 0; g < BN_ITEMS; ++g) {   // (B)
+    for (int g = 0; g < ITEMS; ++g) {   // (B)
         bn_group_pairs(v[g], shift, sh, stiles_x, [&](int L, uint2 vL, uint32_t d, int sx, int sy) {
             if (d >= (uint32_t)ns) return;
             uint32_t pos = wbase[d] + (uint32_t)__builtin_popcountll(lmask[g * ns + d] & ((1ull << L) - 1ull));
@@ -277,7 +284,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
         });
     }
     KPROF(0, 7)
-    KPROF_BLK_END(0, n - tile * BN_TILE < BN_TILE ? n - tile * BN_TILE : BN_TILE)
+    KPROF_BLK_END(0, n - tile * TILE < TILE ? n - tile * TILE : TILE)
 }
 
 // root side of the multi-GPU path: gathered band images -> frame.

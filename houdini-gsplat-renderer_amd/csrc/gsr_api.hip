@@ -224,6 +224,7 @@ struct gsr_context {
     double bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
 
     FrameSlot slot[GSR_MAX_SLOTS];
+    int opt_scatter_direct = 1;        // (A/B hook, GSR_SCATTER_DIRECT in the environment) the small-frame sort's scatter: one workgroup per K1 block
     int opt_bn_items = 0;              // (A/B hook, GSR_BN_ITEMS in the environment: 1, 2 or 4 splats per binning thread; 0 = by frame size)
     int nslots = 1;                    // frames in flight (GSR_OPT_FRAMES_IN_FLIGHT): serial by default -- occlusion culling wants the
                                        // horizons of the frame just before, and two slots hand it those of the frame before that
@@ -423,6 +424,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
     gsr_context* c = new (std::nothrow) gsr_context();
     if (!c) return set_err(GSR_E_OOM, "gsr_create: host allocation failed");
     c->device = device;
+    if (const char* e = std::getenv("GSR_SCATTER_DIRECT")) c->opt_scatter_direct = std::atoi(e);   // (A/B hook: 0 never, 1 by frame size, 2 always)
     if (const char* e = std::getenv("GSR_BN_ITEMS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) c->opt_bn_items = v; }   // (A/B hook)
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return set_err(GSR_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
@@ -1612,10 +1614,16 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
             while (bshift < 31 && (width >> bshift) > (uint64_t)BK_BUCKETS) ++bshift;
             const uint32_t nblk = div_up(n_slots, RS_TILE);
             // K1's compacted slots -> bucket regions (counters and *d_n were cleared by K1) -> sorted (keyA, valA)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter<uint2, true>), dim3(nblk), dim3(RS_THREADS), 0, s, sl.keyA, sl.valA, n_slots, sl.d_counts,
-                               bshift, lo, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, sl.d_n, sl.d_counts + 2);
+            // one global atomic per key pays up to ~150 k keys (fps direct / aggregated: C1 16 700 / 14 400, C2 8830 / 8560, C3 4650 / 4920, C4 3800 / 3950)
+            const bool direct = c->opt_scatter_direct == 2 || (c->opt_scatter_direct == 1 && sl.kept_hint <= 150000u);
+            if (direct)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter_direct<uint2>), dim3(n_slots / RS_SRC_BLOCK), dim3(RS_SRC_BLOCK), 0, s, sl.keyA, sl.valA,
+                                   sl.d_counts, bshift, lo, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, sl.d_counts + 2);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter<uint2, true>), dim3(nblk), dim3(RS_THREADS), 0, s, sl.keyA, sl.valA, n_slots, sl.d_counts,
+                                   bshift, lo, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, sl.d_n, sl.d_counts + 2);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_local<uint2>), dim3(BK_BUCKETS), dim3(RL_THREADS), 0, s, sl.bkt_cnt, bshift, key_bits, lo,
-                               sl.bkt_key, sl.bkt_val, sl.keyA, sl.valA, sl.d_counts + 2);
+                               sl.bkt_key, sl.bkt_val, sl.keyA, sl.valA, sl.d_counts + 2, direct ? sl.d_n : (uint32_t*)nullptr);
             if (hipGetLastError() != hipSuccess) rc = set_err(GSR_E_HIP, "small-frame sort: launch failed");
         } else {
             rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n_slots, key_bits,
@@ -2084,7 +2092,7 @@ static int debug_sort_pairs(gsr_context* c, uint32_t* keys, uint32_t* vals, int6
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter<uint32_t, false>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, vA, n, (const uint32_t*)nullptr,
                                dbg_shift, dbg_lo, (const uint32_t*)nullptr, sl.bkt_cnt, sl.bkt_key, reinterpret_cast<uint32_t*>(sl.bkt_val), (uint32_t*)nullptr, sl.d_counts + 2);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_local<uint32_t>), dim3(BK_BUCKETS), dim3(RL_THREADS), 0, sl.stream, sl.bkt_cnt, dbg_shift, key_bits, dbg_lo,
-                               sl.bkt_key, reinterpret_cast<uint32_t*>(sl.bkt_val), kA, vA, (uint32_t*)nullptr);
+                               sl.bkt_key, reinterpret_cast<uint32_t*>(sl.bkt_val), kA, vA, (uint32_t*)nullptr, (uint32_t*)nullptr);
             uint32_t over = 0;
             if (e2 == hipSuccess) e2 = hipMemcpyAsync(&over, sl.d_counts + 2, 4, hipMemcpyDeviceToHost, sl.stream);
             if (e2 == hipSuccess) e2 = hipStreamSynchronize(sl.stream);

@@ -432,6 +432,30 @@ k_bucket_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ val
     KPROF_BLK_END(1, mine)
 }
 
+// The same scatter for the frames this sort is made for, one workgroup per K1 workgroup-iteration (its kept splats sit at the
+// head of its 256 slots): a key's place in its bucket is simply what one global atomic on the bucket's counter returns.  No LDS,
+// no barrier, three dependent trips to memory -- and ten times the workgroups: k_bucket_scatter's 2048-slot workgroups leave
+// a frame of a few hundred thousand keys (let alone ten thousand) on a handful of CUs.  The atomics are about as many either
+// way (a workgroup of k_bucket_scatter finds its ~900 keys in ~600 different buckets).  The total is left to k_radix_local.
+template <typename V>
+__global__ void __launch_bounds__(RS_SRC_BLOCK)
+k_bucket_scatter_direct(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in, const uint32_t* __restrict__ n_dev,
+                        int shift, uint32_t lo, const uint32_t* __restrict__ src_cnt, uint32_t* __restrict__ gcnt,
+                        uint32_t* __restrict__ kout, V* __restrict__ vout, uint32_t* __restrict__ failed)
+{
+    const uint32_t slot = blockIdx.x * (uint32_t)RS_SRC_BLOCK + threadIdx.x;
+    // (requested together; the grid covers the slots K1 can fill at most, so both addresses exist)
+    const uint32_t cnt = src_cnt[blockIdx.x];
+    const uint32_t key = keys_in[slot];
+    const V val = vals_in[slot];
+    const uint32_t n = *n_dev;
+    if (blockIdx.x * (uint32_t)RS_SRC_BLOCK >= n || threadIdx.x >= cnt) return;
+    const uint32_t d = rs_digit<true>(key, shift, lo, BK_BUCKETS - 1);
+    const uint32_t p = atomicAdd(&gcnt[(size_t)d * BK_STRIDE], 1u);
+    if (p < (uint32_t)BK_CAP) { kout[(size_t)d * BK_CAP + p] = key; vout[(size_t)d * BK_CAP + p] = val; }
+    else if (failed) *failed = 1u;
+}
+
 // one stable 8-bit pass over the n (<= RL_CHUNK) items a workgroup holds in registers in (wave, round, lane) order:
 // on return skeys / svals hold them sorted by the digit, and dcount[d] = items with digit d, dbase[d] = their first position
 // wq = items per wave (a multiple of 64, <= RL_WAVE_ITEMS): wave w holds items [w * wq, (w + 1) * wq) -- a small bucket is
@@ -519,7 +543,7 @@ template <typename V>
 __global__ void __launch_bounds__(RL_THREADS)
 k_radix_local(const uint32_t* __restrict__ cnt, int low_bits, int full_bits, uint32_t lo,
               uint32_t* __restrict__ ksrc, V* __restrict__ vsrc, uint32_t* __restrict__ kdst, V* __restrict__ vdst,
-              uint32_t* __restrict__ failed)
+              uint32_t* __restrict__ failed, uint32_t* __restrict__ n_out /* the last workgroup leaves the number of keys here (or NULL) */)
 {
     __shared__ uint32_t wc[4][RL_BINS];
     __shared__ uint32_t dbase[RL_BINS], dcount[RL_BINS], gbase[RL_BINS];
@@ -539,6 +563,7 @@ k_radix_local(const uint32_t* __restrict__ cnt, int low_bits, int full_bits, uin
     KPROFB(2, 1, 512)
     uint32_t n = cnt[(size_t)b * BK_STRIDE];
     n = n < (uint32_t)BK_CAP ? n : (uint32_t)BK_CAP;
+    if (n_out && b == BK_BUCKETS - 1 && threadIdx.x == 0) *n_out = start + n;
     if (n == 0u) return;
     uint32_t* ks = ksrc + (size_t)b * BK_CAP;
     V* vs = vsrc + (size_t)b * BK_CAP;

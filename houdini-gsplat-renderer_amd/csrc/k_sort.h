@@ -575,6 +575,32 @@ k_radix_local(const uint32_t* __restrict__ cnt, int low_bits, int full_bits, uin
     const int npass = sort_bits <= 0 ? 0 : (sort_bits + 7) / 8;
     uint32_t k_[RL_ITEMS];
     V v_[RL_ITEMS];
+    if (n <= 64u) {
+        // a handful of keys (every bucket of a frame of ten thousand splats): every thread counts the keys
+        // that come before its own -- (key, splat index) pairs, so the contract's tie order falls out -- and stores its key there.
+        // n broadcast reads from LDS instead of two LSD passes with six barriers each: 8.6 -> 6.8 us on BASELINE C1.  (Not beyond:
+        // at 100 - 256 keys the four waves, alone on their SIMDs, take longer over the comparisons than the passes take.)
+        unsigned long long* packed = reinterpret_cast<unsigned long long*>(svals);
+        static_assert(sizeof(V) * RL_CHUNK >= 8 * RL_THREADS, "the payload staging area holds one packed pair per thread");
+        const uint32_t t = threadIdx.x;
+        uint32_t key = 0u;
+        V val{};
+        if (t < n) { key = ks[t]; val = vs[t]; }
+        const unsigned long long me = ((unsigned long long)key << 32) | (unsigned long long)rl_id(val);
+        packed[t] = t < n ? me : ~0ull;           // (the padding never counts: nothing is below it, and it equals no pair)
+        __syncthreads();
+        uint32_t rank = 0;
+        for (uint32_t j0 = 0; j0 < n; j0 += 8u) {  // eight reads in flight: one at a time the loop is an LDS latency per key
+            unsigned long long o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = packed[j0 + (uint32_t)u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += (o[u] < me || (o[u] == me && j0 + (uint32_t)u < t)) ? 1u : 0u;
+        }
+        if (t < n) { kd[rank] = key; vd[rank] = val; }
+        KPROF_BLK_END(2, n)
+        return;
+    }
     if (n <= (uint32_t)RL_CHUNK) {
         // the whole bucket lives in registers + LDS for all passes, a quarter (rounded up to whole rounds of 64) per wave
         const uint32_t wq = ((n + 255u) / 256u) * 64u;

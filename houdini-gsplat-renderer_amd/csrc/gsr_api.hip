@@ -424,7 +424,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
     gsr_context* c = new (std::nothrow) gsr_context();
     if (!c) return set_err(GSR_E_OOM, "gsr_create: host allocation failed");
     c->device = device;
-    if (const char* e = std::getenv("GSR_SCATTER_DIRECT")) c->opt_scatter_direct = std::atoi(e);   // (A/B hook: 0 never, 1 by frame size, 2 always)
+    if (const char* e = std::getenv("GSR_SCATTER_DIRECT")) c->opt_scatter_direct = std::atoi(e);   // (A/B hook: -1 the general scatter, 0 never direct, 1 direct by frame size, 2 always direct)
     if (const char* e = std::getenv("GSR_BN_ITEMS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) c->opt_bn_items = v; }   // (A/B hook)
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return set_err(GSR_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
@@ -1619,11 +1619,14 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
             if (direct)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter_direct<uint2>), dim3(n_slots / RS_SRC_BLOCK), dim3(RS_SRC_BLOCK), 0, s, sl.keyA, sl.valA,
                                    sl.d_counts, bshift, lo, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, sl.d_counts + 2);
-            else
+            else if (c->opt_scatter_direct >= 0)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter_k1<uint2>), dim3(div_up(n_slots / RS_SRC_BLOCK, 4u)), dim3(256), 0, s, sl.keyA, sl.valA,
+                                   n_slots / RS_SRC_BLOCK, sl.d_counts, bshift, lo, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, sl.d_counts + 2);
+            else   // (A/B: the general gathering scatter, 2048 slots per workgroup)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter<uint2, true>), dim3(nblk), dim3(RS_THREADS), 0, s, sl.keyA, sl.valA, n_slots, sl.d_counts,
-                                   bshift, lo, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, sl.d_n, sl.d_counts + 2);
+                                   bshift, lo, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, (uint32_t*)nullptr, sl.d_counts + 2);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_local<uint2>), dim3(BK_BUCKETS), dim3(RL_THREADS), 0, s, sl.bkt_cnt, bshift, key_bits, lo,
-                               sl.bkt_key, sl.bkt_val, sl.keyA, sl.valA, sl.d_counts + 2, direct ? sl.d_n : (uint32_t*)nullptr);
+                               sl.bkt_key, sl.bkt_val, sl.keyA, sl.valA, sl.d_counts + 2, sl.d_n);
             if (hipGetLastError() != hipSuccess) rc = set_err(GSR_E_HIP, "small-frame sort: launch failed");
         } else {
             rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n_slots, key_bits,

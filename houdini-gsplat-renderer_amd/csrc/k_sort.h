@@ -432,6 +432,57 @@ k_bucket_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ val
     KPROF_BLK_END(1, mine)
 }
 
+// The scatter for K1's output as it is: one WAVE per K1 workgroup-iteration (whose kept splats sit at the head of its 256 slots,
+// blk_cnt of them), four of them per workgroup -- half the slots of k_bucket_scatter's workgroups, twice the workgroups, no
+// gather arithmetic: a frame of a few hundred thousand keys is bound by how long ONE workgroup takes, not by throughput.
+// The total is left to k_radix_local.
+template <typename V>
+__global__ void __launch_bounds__(256)
+k_bucket_scatter_k1(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in, uint32_t n_blocks_host, const uint32_t* __restrict__ n_dev,
+                    int shift, uint32_t lo, const uint32_t* __restrict__ src_cnt, uint32_t* __restrict__ gcnt,
+                    uint32_t* __restrict__ kout, V* __restrict__ vout, uint32_t* __restrict__ failed)
+{
+    __shared__ uint32_t h[BK_BUCKETS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t gb = blockIdx.x * 4u + (uint32_t)wave;                    // this wave's K1 block
+    gb = gb < n_blocks_host ? gb : n_blocks_host - 1u;                 // (the last workgroup's surplus waves: a block that exists; they find base >= n)
+    const bool surplus = blockIdx.x * 4u + (uint32_t)wave >= n_blocks_host;
+    const uint32_t base = gb * (uint32_t)RS_SRC_BLOCK;
+    // (requested together; the grid covers the slots K1 can fill at most, so every address exists)
+    const uint32_t cnt_raw = src_cnt[gb];
+    uint32_t k_[4];
+    V v_[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { k_[r] = keys_in[base + (uint32_t)(r * 64 + lane)]; v_[r] = vals_in[base + (uint32_t)(r * 64 + lane)]; }
+    const uint32_t n = *n_dev;
+    if (blockIdx.x * 4u * (uint32_t)RS_SRC_BLOCK >= n) return;
+    const uint32_t cnt = (base < n && !surplus) ? cnt_raw : 0u;
+    for (int b = threadIdx.x; b < BK_BUCKETS; b += 256) h[b] = 0;
+    __syncthreads();
+    uint32_t meta[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        meta[r] = 0xffffffffu;
+        if ((uint32_t)(r * 64 + lane) < cnt) {
+            const uint32_t d = rs_digit<true>(k_[r], shift, lo, BK_BUCKETS - 1);
+            meta[r] = d | (atomicAdd(&h[d], 1u) << 12);
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < BK_BUCKETS; d += 256) {   // one reservation per bucket this workgroup has keys for
+        const uint32_t c = h[d];
+        h[d] = c ? atomicAdd(&gcnt[(size_t)d * BK_STRIDE], c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (meta[r] == 0xffffffffu) continue;
+        const uint32_t d = meta[r] & 4095u, p = h[d] + (meta[r] >> 12);
+        if (p < (uint32_t)BK_CAP) { kout[(size_t)d * BK_CAP + p] = k_[r]; vout[(size_t)d * BK_CAP + p] = v_[r]; }
+        else if (failed) *failed = 1u;
+    }
+}
+
 // The same scatter for the frames this sort is made for, one workgroup per K1 workgroup-iteration (its kept splats sit at the
 // head of its 256 slots): a key's place in its bucket is simply what one global atomic on the bucket's counter returns.  No LDS,
 // no barrier, three dependent trips to memory -- and ten times the workgroups: k_bucket_scatter's 2048-slot workgroups leave

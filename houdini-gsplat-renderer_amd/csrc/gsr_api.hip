@@ -93,6 +93,8 @@ struct FrameJob {
     bool out_is_device = false, timing = false, timing_all = false, use_map = false;
     bool speculative = false;      // the back end was queued before the pair count was known
     int bn_items = 4;              // splats per thread of the binning kernels (k_binning.h): 4, or fewer for a small frame
+    uint32_t bn_grid = 0;          // ... and their grid (workgroups that stride over the blocks)
+    uint32_t k1_grid = 0;          // K1's grid: the estimate of its workgroup-iterations (sizes the bucket scatter's grid too)
     bool local_sort = false;       // the depth sort took the small-frame form (k_sort.h) ...
     bool sort_failed = false;      // ... and gave a bucket up: the frame is rendered again with the three global passes
     bool ranges_folded = false;    // ... and k_bin_place forms the list ranges and posts the pair count itself (no k_bin_ranges launch)
@@ -1165,7 +1167,9 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         const size_t lds = (size_t)4 * j.bn_items * j.n_super * 8 + (size_t)4 * j.n_super * 4;
         const GsrShard shd{f.shard_index, f.shard_count, f.shard_rpb, f.rect_shift};
         const GsrRangeArgs ra = j.ranges_folded ? range_args(c, sl) : GsrRangeArgs{};
-#define GSR_PLACE(I) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin_place<I>), dim3(nblk), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n,          \
+        // (+1: the publishing workgroup)
+        const uint32_t grid = std::min(nblk, j.bn_grid) + (j.ranges_folded ? 1u : 0u);
+#define GSR_PLACE(I) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin_place<I>), dim3(grid), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n,          \
                                         f.super_shift - f.rect_shift, shd, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk, (uint32_t)sl.pair_cap, sl.pvA, ra)
         if (j.bn_items == 1) GSR_PLACE(1); else if (j.bn_items == 2) GSR_PLACE(2); else GSR_PLACE(4);
 #undef GSR_PLACE
@@ -1582,6 +1586,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         if (sl.surv_hint > 0) k1_grid = std::min<uint32_t>(all_iter, div_up(sl.surv_hint, 4u) * 5u / 4u + 64u);
         // on a cache hit (identical frame description) the sorted (keyA, valA) are kept and K1's key/payload
         // output goes to the scratch buffers
+        j.k1_grid = k1_grid;
         hipLaunchKernelGGL(k_preprocess, dim3(k1_grid ? k1_grid : 1u), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, cache_hit ? sl.keyB : sl.keyA, cache_hit ? sl.valB : sl.valA,
                            j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.cull ? sl.hpyr : (const float*)nullptr, sl.blk_cnt,
@@ -1620,7 +1625,8 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter_direct<uint2>), dim3(n_slots / RS_SRC_BLOCK), dim3(RS_SRC_BLOCK), 0, s, sl.keyA, sl.valA,
                                    sl.d_counts, bshift, lo, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, sl.d_counts + 2);
             else if (c->opt_scatter_direct >= 0)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter_k1<uint2>), dim3(div_up(n_slots / RS_SRC_BLOCK, 4u)), dim3(256), 0, s, sl.keyA, sl.valA,
+                // (grid: K1's own estimate of its workgroup-iterations, four per workgroup here)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter_k1<uint2>), dim3(std::max(1u, std::min(div_up(n_slots / RS_SRC_BLOCK, 4u), div_up(j.k1_grid, 4u) + 16u))), dim3(256), 0, s, sl.keyA, sl.valA,
                                    n_slots / RS_SRC_BLOCK, sl.d_counts, bshift, lo, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, sl.d_counts + 2);
             else   // (A/B: the general gathering scatter, 2048 slots per workgroup)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter<uint2, true>), dim3(nblk), dim3(RS_THREADS), 0, s, sl.keyA, sl.valA, n_slots, sl.d_counts,
@@ -1650,7 +1656,9 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)BN_BINS * nblk + 8);
         if (rc) return frame_abort(sl, rc);
         const GsrShard shd{f.shard_index, f.shard_count, f.shard_rpb, f.rect_shift};
-#define GSR_COUNT(I) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin_count<I>), dim3(nblk), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift - f.rect_shift, \
+        // the grids of the binning kernels: what the slot's previous frame kept, + 25 % (they loop if the frame keeps more)
+        j.bn_grid = sl.kept_hint > 0 ? std::min<uint32_t>(nblk, div_up(sl.kept_hint + sl.kept_hint / 4u, bn_tile) + 64u) : nblk;
+#define GSR_COUNT(I) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin_count<I>), dim3(j.bn_grid), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift - f.rect_shift, \
                                         shd, f.stiles_x, sl.hist, nblk)
         if (j.bn_items == 1) GSR_COUNT(1); else if (j.bn_items == 2) GSR_COUNT(2); else GSR_COUNT(4);
 #undef GSR_COUNT

@@ -121,24 +121,28 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     const int wave = threadIdx.x >> 6;
     const uint32_t n = *n_dev;
     const uint32_t nb = (n + TILE - 1) / TILE;
-    if (blockIdx.x >= nb) return;   // surplus block of the upper-bound grid: the row scan only reads the blocks that exist
-    for (int b = threadIdx.x; b < 4 * BN_BINS; b += BN_THREADS) (&h[0][0])[b] = 0;
-    __syncthreads();
-    const uint32_t tile = rs_tile_of_block(blockIdx.x, nb, true);
-    {
-        const uint32_t base = tile * TILE;
+    // the grid follows what the slot's previous frame kept (+25 %): a frame that keeps more simply loops (nblk = the row
+    // length of hist, the host's upper bound on the blocks)
+    for (uint32_t blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+        for (int b = threadIdx.x; b < 4 * BN_BINS; b += BN_THREADS) (&h[0][0])[b] = 0;
+        __syncthreads();
+        const uint32_t tile = rs_tile_of_block(blk, nb, true);
+        {
+            const uint32_t base = tile * TILE;
 #pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-            const uint32_t i = base + k * BN_THREADS + threadIdx.x;   // (every wave sees 64 consecutive splats)
-            const uint2 v = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
-            bn_group_pairs(v, shift, sh, stiles_x,
-                           [&](int, uint2, uint32_t d, int, int) { if (d < (uint32_t)BN_BINS) atomicAdd(&h[wave][d], 1u); });
+            for (int k = 0; k < ITEMS; ++k) {
+                const uint32_t i = base + k * BN_THREADS + threadIdx.x;   // (every wave sees 64 consecutive splats)
+                const uint2 v = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
+                bn_group_pairs(v, shift, sh, stiles_x,
+                               [&](int, uint2, uint32_t d, int, int) { if (d < (uint32_t)BN_BINS) atomicAdd(&h[wave][d], 1u); });
+            }
         }
+        __syncthreads();
+        for (int b = threadIdx.x; b < BN_BINS; b += BN_THREADS)
+            hist[(size_t)b * nblk + tile] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
+        __syncthreads();
     }
-    __syncthreads();
-    for (int b = threadIdx.x; b < BN_BINS; b += BN_THREADS)
-        hist[(size_t)b * nblk + tile] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
-    KPROF_BLK_END(3, n - tile * TILE < TILE ? n - tile * TILE : TILE)
+    KPROF_BLK_END(3, n < TILE ? n : TILE)
 }
 
 // list range of every super-tile = exclusive scan of the totals; the pair count and the frame's other news go to the host.
@@ -223,11 +227,19 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     __shared__ uint32_t s_start[BN_BINS];
     __shared__ uint32_t s_rwave[4];
     __shared__ unsigned long long s_rsum[4];
+    // (the grid is sized for the host's upper bound on the splats a frame keeps: most of its workgroups have nothing to do, and
+    //  they leave before the range scan -- eleven thousand of them doing it first doubled the kernel on a culled C4 frame)
+    const uint32_t n = *n_dev;
+    const uint32_t nb = (n + TILE - 1) / TILE;
+    // The LAST workgroup of the grid only publishes the ranges and the mailbox (four dependent trips: done by a workgroup with
+    // splats of its own they ended the kernel three microseconds late); the others stride over the blocks -- the grid follows
+    // what the slot's previous frame kept (+25 %) -- and one without a block leaves before the range scan.
+    const bool publisher = ranges.totals && blockIdx.x == gridDim.x - 1u;
+    const uint32_t workers = ranges.totals ? gridDim.x - 1u : gridDim.x;
+    if (!publisher && blockIdx.x >= nb) return;
     if (ranges.totals) {
-        // (the LAST workgroup of the grid publishes: the grid is sized for the host's upper bound, so that one has no splats of
-        //  its own as a rule -- writing the ranges and the mailbox, four dependent trips, cost workgroup 0 three microseconds
-        //  that the kernel then ended three microseconds later)
-        s_start[threadIdx.x] = bn_ranges(ranges, blockIdx.x == gridDim.x - 1u, s_rwave, s_rsum);
+        s_start[threadIdx.x] = bn_ranges(ranges, publisher, s_rwave, s_rsum);
+        if (publisher) return;
     } else {
         s_start[threadIdx.x] = ((int)threadIdx.x < ns) ? (uint32_t)sstart[threadIdx.x] : 0u;
     }
@@ -237,10 +249,8 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     unsigned long long* lmask = bn_lds + (size_t)wave * ITEMS * ns;                       // [g][d] of this wave
     uint32_t* wbase_all = reinterpret_cast<uint32_t*>(bn_lds + (size_t)4 * ITEMS * ns);   // [wave][d]
     uint32_t* wbase = wbase_all + wave * ns;
-    const uint32_t n = *n_dev;
-    const uint32_t nb = (n + TILE - 1) / TILE;
-    if (blockIdx.x >= nb) return;
-    const uint32_t tile = rs_tile_of_block(blockIdx.x, nb, true);
+    for (uint32_t blk = blockIdx.x; blk < nb; blk += workers) {
+    const uint32_t tile = rs_tile_of_block(blk, nb, true);
     const uint32_t first = tile * TILE + wave * WAVE_ITEMS;
     KPROF(0, 2)
     for (int b = lane; b < ITEMS * ns; b += 64) lmask[b] = 0ull;
@@ -284,7 +294,9 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
         });
     }
     KPROF(0, 7)
-    KPROF_BLK_END(0, n - tile * TILE < TILE ? n - tile * TILE : TILE)
+    __syncthreads();   // (the next block re-uses the masks and the wave bases)
+    }
+    KPROF_BLK_END(0, n < TILE ? n : TILE)
 }
 
 // root side of the multi-GPU path: gathered band images -> frame.

@@ -444,42 +444,49 @@ k_bucket_scatter_k1(const uint32_t* __restrict__ keys_in, const V* __restrict__ 
 {
     __shared__ uint32_t h[BK_BUCKETS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t gb = blockIdx.x * 4u + (uint32_t)wave;                    // this wave's K1 block
-    gb = gb < n_blocks_host ? gb : n_blocks_host - 1u;                 // (the last workgroup's surplus waves: a block that exists; they find base >= n)
-    const bool surplus = blockIdx.x * 4u + (uint32_t)wave >= n_blocks_host;
-    const uint32_t base = gb * (uint32_t)RS_SRC_BLOCK;
-    // (requested together; the grid covers the slots K1 can fill at most, so every address exists)
-    const uint32_t cnt_raw = src_cnt[gb];
-    uint32_t k_[4];
-    V v_[4];
+    // The grid follows the slot's previous frame (like K1's): a frame that fills more slots loops.  The first trip's loads are
+    // requested together with the slot count that says whether they exist (every address does: clamped to the host's bound).
+    uint32_t n = 0xffffffffu;
+    for (uint32_t wg = blockIdx.x; wg * 4u * (uint32_t)RS_SRC_BLOCK < n; wg += gridDim.x) {
+        uint32_t gb = wg * 4u + (uint32_t)wave;                        // this wave's K1 block
+        const bool surplus = gb >= n_blocks_host;
+        gb = surplus ? n_blocks_host - 1u : gb;
+        const uint32_t base = gb * (uint32_t)RS_SRC_BLOCK;
+        const uint32_t cnt_raw = src_cnt[gb];
+        uint32_t k_[4];
+        V v_[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { k_[r] = keys_in[base + (uint32_t)(r * 64 + lane)]; v_[r] = vals_in[base + (uint32_t)(r * 64 + lane)]; }
-    const uint32_t n = *n_dev;
-    if (blockIdx.x * 4u * (uint32_t)RS_SRC_BLOCK >= n) return;
-    const uint32_t cnt = (base < n && !surplus) ? cnt_raw : 0u;
-    for (int b = threadIdx.x; b < BK_BUCKETS; b += 256) h[b] = 0;
-    __syncthreads();
-    uint32_t meta[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        meta[r] = 0xffffffffu;
-        if ((uint32_t)(r * 64 + lane) < cnt) {
-            const uint32_t d = rs_digit<true>(k_[r], shift, lo, BK_BUCKETS - 1);
-            meta[r] = d | (atomicAdd(&h[d], 1u) << 12);
+        for (int r = 0; r < 4; ++r) { k_[r] = keys_in[base + (uint32_t)(r * 64 + lane)]; v_[r] = vals_in[base + (uint32_t)(r * 64 + lane)]; }
+        if (n == 0xffffffffu) {
+            n = *n_dev;
+            if (wg * 4u * (uint32_t)RS_SRC_BLOCK >= n) return;
         }
-    }
-    __syncthreads();
-    for (int d = threadIdx.x; d < BK_BUCKETS; d += 256) {   // one reservation per bucket this workgroup has keys for
-        const uint32_t c = h[d];
-        h[d] = c ? atomicAdd(&gcnt[(size_t)d * BK_STRIDE], c) : 0u;
-    }
-    __syncthreads();
+        const uint32_t cnt = (base < n && !surplus) ? cnt_raw : 0u;
+        for (int b = threadIdx.x; b < BK_BUCKETS; b += 256) h[b] = 0;
+        __syncthreads();
+        uint32_t meta[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (meta[r] == 0xffffffffu) continue;
-        const uint32_t d = meta[r] & 4095u, p = h[d] + (meta[r] >> 12);
-        if (p < (uint32_t)BK_CAP) { kout[(size_t)d * BK_CAP + p] = k_[r]; vout[(size_t)d * BK_CAP + p] = v_[r]; }
-        else if (failed) *failed = 1u;
+        for (int r = 0; r < 4; ++r) {
+            meta[r] = 0xffffffffu;
+            if ((uint32_t)(r * 64 + lane) < cnt) {
+                const uint32_t d = rs_digit<true>(k_[r], shift, lo, BK_BUCKETS - 1);
+                meta[r] = d | (atomicAdd(&h[d], 1u) << 12);
+            }
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d < BK_BUCKETS; d += 256) {   // one reservation per bucket this workgroup has keys for
+            const uint32_t c = h[d];
+            h[d] = c ? atomicAdd(&gcnt[(size_t)d * BK_STRIDE], c) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (meta[r] == 0xffffffffu) continue;
+            const uint32_t d = meta[r] & 4095u, p = h[d] + (meta[r] >> 12);
+            if (p < (uint32_t)BK_CAP) { kout[(size_t)d * BK_CAP + p] = k_[r]; vout[(size_t)d * BK_CAP + p] = v_[r]; }
+            else if (failed) *failed = 1u;
+        }
+        __syncthreads();   // (the next trip clears the counts)
     }
 }
 

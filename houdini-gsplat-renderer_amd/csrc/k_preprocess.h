@@ -466,8 +466,9 @@ gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, co
 // One wavefront per surviving cluster (k_cluster.h): workgroup-iteration k takes the clusters of rank 4k .. 4k+3 of
 // k_cluster_cull's ordered list, so its 256 slots are in storage order like the list itself.  The grid is sized from the
 // previous frame's survivor count (gsr_api.hip); a frame that keeps more simply loops.
+// (6 waves per SIMD = 80 VGPRs: with the colours evaluated here, 7 waves (72 VGPRs) spill 12 dwords: 38.2 -> 34.5 us on a culled C4 frame)
 #ifndef GSR_K1_WAVES_PER_EU
-#define GSR_K1_WAVES_PER_EU 7
+#define GSR_K1_WAVES_PER_EU 6
 #endif
 __global__ void __launch_bounds__(GSR_K1_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_K1_WAVES_PER_EU)))
 k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,

@@ -799,6 +799,39 @@ def test_multi_gpu_in_library_matches_single_gpu(pkg, oracle, engine, ranks, lay
     _check_image(want, oracle.render(splats, cam))
 
 
+@pytest.mark.parametrize("direct,items", [("2", "1"), ("-1", "2"), ("0", "4"), ("2", "4")])
+def test_small_frame_kernel_variants_do_not_change_pixels(pkg, engine, direct, items):
+    """the small-frame sort's scatter (general gathering / one wave per K1 block / one atomic per key) and the binning kernels'
+    splats per thread are chosen by frame size; forced through the A/B hooks, every combination renders the same frames"""
+    import os
+    splats = pkg.scenes.make_scene(300000, seed=77, sh=True)
+    w, h = 800, 608
+    cams = [pkg.camera.make_camera(w, h, sh_order=3, frame=i) for i in range(6)]
+    engine.upload(splats)
+    engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)
+    try:
+        want = [engine.render(c) for c in cams]
+    finally:
+        engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 1)
+    old = {k: os.environ.get(k) for k in ("GSR_SCATTER_DIRECT", "GSR_BN_ITEMS")}
+    os.environ["GSR_SCATTER_DIRECT"], os.environ["GSR_BN_ITEMS"] = direct, items
+    try:
+        eng = pkg.Engine(0)                     # (the hooks are read when a context is created)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    try:
+        eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)
+        eng.set_option(pkg.engine.OPT_LOCAL_SORT, 2)      # the small-frame sort whatever the frame keeps
+        eng.upload(splats)
+        for k, c in enumerate(cams):
+            assert np.array_equal(eng.render(c), want[k]), f"frame {k} differs"
+        assert eng.stats()["frames_culled"] >= 4 and eng.stats()["frames_resorted"] == 0
+    finally:
+        eng.close()
+
+
 def test_multi_gpu_back_to_back_device_frames_with_uneven_ranks(pkg, engine):
     """COPY transport, device target, no synchronisation between frames, bands of very different weight (the ball fills the
     middle bands, the outer ones see sky): a light rank is frames ahead of the root's copies unless its stream waits for them

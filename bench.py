@@ -53,10 +53,17 @@ def kernel_source_sha() -> str:
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "houdini-gsplat-renderer_amd", "csrc")
+    import re
     for name in sorted(os.listdir(csrc)):
         if name.endswith((".h", ".hip", ".cpp")):
+            text = open(os.path.join(csrc, name), "r", encoding="utf-8", errors="replace").read()
+            # comments and white space do not make a different kernel (the sources hold no string literal with "//" or "/*" in it
+            # that matters to the device code)
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", "", text)
+            text = re.sub(r"\s+", " ", text)
             h.update(name.encode())
-            h.update(open(os.path.join(csrc, name), "rb").read())
+            h.update(text.encode())
     return h.hexdigest()[:16]
 
 

@@ -4,8 +4,10 @@
 // (/root/reference/gsplat_plugin/shaders/GSplatShaderSource.h:190-288 with the
 // helpers in shaders/GSplatShaderCoreLib.h:10-93,103-179) -- evaluated ONCE per
 // splat instead of once per quad corner -- and the CPU distance loop of
-// argsortByDistance (src/GSplatRenderer.C:194-204).  Roofline: HBM streaming
-// (128 B read + 60 B written per splat at SH order 3; ~250 flop).
+// argsortByDistance (src/GSplatRenderer.C:194-204).  One wavefront per cluster that survived k_cluster_cull (k_cluster.h):
+// 32 B read per splat of it, 56 B (record, key, payload) written per splat that stays, + its 96 B of colour halves when the
+// frame shades in K1 (occlusion-culled frames; unculled ones leave the colours to k_colour.h).  Bound by FP32 issue -- the
+// ~1000-instruction covariance chain with its eleven IEEE divisions and four square roots -- not by HBM.
 #pragma once
 #include "gsr_device.h"
 #include "k_cluster.h"

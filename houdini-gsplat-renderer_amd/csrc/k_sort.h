@@ -1,5 +1,6 @@
-// k_sort.h -- stable LSD radix sort (8- or 9-bit digits)
-// of (u32 key, u32 value) pairs.
+// k_sort.h -- the depth sort: a stable LSD radix sort (8- or 9-bit digits) of (u32 key, payload) pairs for frames that keep
+// millions of splats, and -- further down -- a bucket scatter + one local kernel for the few hundred thousand an
+// occlusion-culled frame keeps.
 //
 // Replaces tbb::parallel_sort of the index array in argsortByDistance
 // (/root/reference/gsplat_plugin/src/GSplatRenderer.C:206-208) and supplies the

@@ -537,7 +537,7 @@ def main():
                             "fallback_tiles_last_frame": st["lazy_redo_tiles"]},
             "occlusion_culling": {"enabled": bool(args.cull), "policy_bits": st["policy_bits"], "dilate_tiles": st["cull_dilate"], "holdoff_frames": st["cull_holdoff"], "frames_culled": st["frames_culled"], "frames_repaired": st["frames_repaired"],
                                   "frames": st["frames"], "without": unculled,
-                                  "note": "splats whose tile rect lies wholly behind the previous frame's per-super-tile depth horizons get no colour, no record, and "
+                                  "note": "splats whose tile rect lies wholly behind the previous frame's per-tile depth horizons get no colour, no record, and "
                                           "no place in the sort and the lists; every culled frame verifies itself and is rendered again without culling if a horizon "
                                           "broke (frames_repaired; those frames are inside the timed region)"},
         }

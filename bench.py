@@ -116,6 +116,7 @@ def parse_args():
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="run ONLY the warm-up and the timed region (no per-stage leg, no culling-off leg, no pipelined leg): what a "
                          "rocprofv3 run should see, so that its per-kernel averages describe one regime")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the informational leg that renders BASELINE C1, C2, C3 and C5 after the timed region")
     ap.add_argument("--no-verify", action="store_true",
                     help="N>1: skip the check (after the timed region) that the last stitched frame is bit-identical to the same frame "
                          "rendered unsharded on rank 0")
@@ -407,6 +408,36 @@ def main():
                      "ms_per_step": el2 / args.steps * 1e3,
                      "note": "GSR_OPT_FRAMES_IN_FLIGHT=2: frame f+1's front end overlaps frame f's blend kernel"}
         eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, args.frames_in_flight)
+    # extra leg (informational, single GPU, the default run of the headline config only): the other BASELINE configs, the same
+    # library and options, serial frames -- so that their frame rates are on the driver's record too, not only in DESIGN.md
+    other = None
+    if world == 1 and args.config == "C4" and args.splats is None and not args.no_extra_legs and not args.no_other_configs and args.emulate_shard <= 1:
+        other = {}
+        for oc in ("C1", "C2", "C3", "C5"):
+            osp, ocfg = pkg.scenes.make_config(oc)
+            oW, oH, oord = ocfg["width"], ocfg["height"], ocfg["sh_order"]
+            oe = pkg.Engine(dev_index)
+            oe.set_stream(stream.cuda_stream)
+            oe.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, 1)
+            oe.set_option(pkg.engine.OPT_TIMING_EVERY, 1000)
+            oe.upload(osp)
+            oband = torch.zeros((oH, oW, 4), dtype=torch.float32, device="cuda")
+            ocams = [pkg.engine.camera_struct(pkg.scenes.config_camera(oc, pkg.camera, oW, oH, oord, i)) for i in range(110)]
+            for i in range(10):
+                oe.render_struct_to_device(ocams[i], oband.data_ptr())
+            torch.cuda.synchronize()
+            oe.stats_reset()
+            t0 = time.perf_counter()
+            for i in range(10, 110):
+                oe.render_struct_to_device(ocams[i], oband.data_ptr())
+            torch.cuda.synchronize()
+            odt = (time.perf_counter() - t0) / 100
+            ost = oe.stats()
+            other[oc] = {"value": 1.0 / odt, "unit": "frames/sec", "ms_per_step": odt * 1e3, "steps": 100, "n_splats": int(osp.n),
+                         "width": oW, "height": oH, "frames_culled": ost["frames_culled"], "frames_repaired": ost["frames_repaired"]}
+            oe.close()
+            del oband, osp
+            torch.cuda.empty_cache()
     # blend-kernel roofline, measured with HIP events on the kernel's own stream
     launches = max(1, st["blend_launches"])                    # launches bracketed by events (every --time-every-th frame)
     frames_done = max(1, st["frames"])                         # launches in all: the kernel's own counters cover every one
@@ -543,6 +574,8 @@ def main():
         }
         if pipelined is not None:
             line["pipelined"] = pipelined
+        if other is not None:
+            line["other_configs"] = other
         if verified is not None:
             line["sharded_frame_bit_identical"] = verified
         if world == 1 and not args.no_cpu_baseline:

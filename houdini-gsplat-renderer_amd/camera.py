@@ -75,3 +75,16 @@ def make_camera(width: int, height: int, sh_order: int = 3, frame: int = 0, dist
     return Camera(obj_view=_gl(obj_view), object=_gl(obj), inv_object=_gl(np.linalg.inv(obj)), view=_gl(view),
                   proj=_gl(proj), cam_pos=cam_pos.astype(np.float32), width=int(width), height=int(height),
                   sh_order=int(sh_order), meta={"frame": frame, "distance": distance})
+
+
+def rotated_in_place(cam: Camera, yaw_deg: float, pitch_deg: float = 0.0) -> Camera:
+    """the same camera turned about its own position (the reference re-sorts only when the POSITION moves,
+    src/GSplatRenderer.C:165-186): view' = R_cam * view; cam_pos is carried over bit for bit"""
+    view = np.asarray(cam.view, dtype=np.float64).reshape(4, 4).T
+    obj = np.asarray(cam.object, dtype=np.float64).reshape(4, 4).T
+    a, b = np.deg2rad(yaw_deg), np.deg2rad(pitch_deg)
+    ry = np.array([[np.cos(a), 0, np.sin(a), 0], [0, 1, 0, 0], [-np.sin(a), 0, np.cos(a), 0], [0, 0, 0, 1]])
+    rx = np.array([[1, 0, 0, 0], [0, np.cos(b), -np.sin(b), 0], [0, np.sin(b), np.cos(b), 0], [0, 0, 0, 1]])
+    v2 = rx @ ry @ view
+    return Camera(obj_view=_gl(v2 @ obj), object=cam.object.copy(), inv_object=cam.inv_object.copy(), view=_gl(v2), proj=cam.proj.copy(),
+                  cam_pos=cam.cam_pos.copy(), width=cam.width, height=cam.height, sh_order=cam.sh_order, meta=dict(cam.meta))

@@ -226,6 +226,16 @@ struct gsr_context {
     double bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
 
     FrameSlot slot[GSR_MAX_SLOTS];
+    // position-keyed order (GSR_OPT_SORT_CACHE = 2): all splats in depth order for one camera position
+    uint32_t* pos_order = nullptr;
+    size_t pos_cap = 0;
+    bool pos_valid = false;
+    uint64_t pos_gen = 0;
+    float pos_cam[3] = {0, 0, 0}, last_cam[3] = {0, 0, 0};
+    uint32_t pos_kmin = 0, pos_kmax = 0;
+    bool last_cam_set = false;
+    uint32_t* blk_pre = nullptr;       // exclusive prefix of K1's per-iteration counts (k_scan_counts)
+    size_t blk_pre_cap = 0;
     int opt_scatter_direct = 1;        // (A/B hook, GSR_SCATTER_DIRECT in the environment) the small-frame sort's scatter: one workgroup per K1 block
     int opt_bn_items = 0;              // (A/B hook, GSR_BN_ITEMS in the environment: 1, 2 or 4 splats per binning thread; 0 = by frame size)
     int nslots = 1;                    // frames in flight (GSR_OPT_FRAMES_IN_FLIGHT): serial by default -- occlusion culling wants the
@@ -471,6 +481,7 @@ extern "C" void gsr_destroy(gsr_context* c)
     dev_free(c->tile_map);
     dev_free(c->wire_zbuf); dev_free(c->wire_out); dev_free(c->stage);
     dev_free(c->prefix); dev_free(c->prefix_all); dev_free(c->prefix_none); dev_free(c->lazy_hint);
+    dev_free(c->pos_order); dev_free(c->blk_pre);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -493,7 +504,9 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
     case GSR_OPT_XCD_SWIZZLE: c->opt_swizzle = value < 0 ? 0 : (value > 3 ? 3 : value); break;
     case GSR_OPT_STAGE_TIMING: c->opt_timing = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_SORT_CACHE:
-        c->opt_sort_cache = value ? 1 : 0;
+        if (value < 0 || value > 2) return set_err(GSR_E_INVALID, "gsr_set_option: sort cache is 0, 1 or 2");
+        c->opt_sort_cache = value;
+        c->pos_valid = false;
         for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
         break;
     case GSR_OPT_DEBUG_FLAGS: c->opt_flags = value; break;
@@ -1434,6 +1447,32 @@ static int finish_open_frames(gsr_context* c)
     return rc;
 }
 
+// the depth order of ALL splats for the camera position of frame f (k_sort.h): keys -> LSD passes -> c->pos_order
+static int build_pos_order(gsr_context* c, FrameSlot& sl, const GsrFrame& f)
+{
+    const uint32_t n = c->n;
+    int rc;
+    uint32_t *kA = nullptr, *kB = nullptr, *vA = nullptr, *vB = nullptr;
+    auto drop = [&]() { dev_free(kA); dev_free(kB); dev_free(vA); dev_free(vB); };
+    if ((rc = dev_alloc(&kA, (size_t)n + 256)) || (rc = dev_alloc(&kB, (size_t)n + 256)) || (rc = dev_alloc(&vA, (size_t)n + 256)) ||
+        (rc = dev_alloc(&vB, (size_t)n + 256))) { drop(); return rc; }
+    hipStream_t s = sl.stream;
+    int key_bits = 1;
+    while (key_bits < 32 && ((f.key_max - f.key_min) >> key_bits) != 0u) ++key_bits;
+    hipLaunchKernelGGL(k_pos_keys, dim3(div_up(n, 256)), dim3(256), 0, s, c->geoA, n, f.cam[0], f.cam[1], f.cam[2], f.key_min, f.key_max, kA, vA);
+    rc = radix_sort(sl, kA, vA, kB, vB, n, key_bits, true, (uint32_t*)nullptr, RS_XCD_DEPTH != 0);
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = set_err(GSR_E_HIP, "position-keyed order: sort failed");
+    if (rc) { drop(); return rc; }
+    dev_free(c->pos_order);
+    c->pos_order = vA; vA = nullptr;       // (radix_sort leaves the result in the A pair)
+    drop();
+    c->pos_valid = true;
+    c->pos_gen = c->geo_gen;
+    std::memcpy(c->pos_cam, f.cam, sizeof c->pos_cam);
+    c->pos_kmin = f.key_min; c->pos_kmax = f.key_max;
+    return GSR_OK;
+}
+
 static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth, int depth_is_device,
                        float* rgba_out, int out_is_device, FrameSlot** used, bool allow_cull)
 {
@@ -1554,6 +1593,23 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     const SortKey key_now = {c->geo_gen, c->shard_index, c->shard_count, c->shard_layout, c->opt_flags, *cam};
     // (a culled frame's order holds only the splats in front of ITS horizons, and the horizons move: no reuse either way)
     const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now) && !j.cull && !sl.sorted_culled;
+    // Position-keyed order (GSR_OPT_SORT_CACHE = 2; the reference's rule, src/GSplatRenderer.C:165-186): while the camera POSITION stands
+    // still -- a rotation about the eye, a change of lens -- the depth order of ALL splats is the one sorted when it last moved, K1 walks
+    // the splats in that order, and what a frame keeps leaves it sorted.  Built the second time a position is seen (a moving camera never
+    // pays for it).  Not for sharded, deferred or full-key frames.
+    bool ordered = false;
+    if (c->opt_sort_cache >= 2 && !cache_hit && n > 0 && c->shard_count == 1 && !j.deferred && !(c->opt_flags & GSR_FLAG_FULL_KEYS)) {
+        const bool same_pos = c->last_cam_set && std::memcmp(c->last_cam, cam->cam_pos, sizeof c->last_cam) == 0;
+        if (c->pos_valid && (c->pos_gen != c->geo_gen || std::memcmp(c->pos_cam, cam->cam_pos, sizeof c->pos_cam) != 0 ||
+                             c->pos_kmin != f.key_min || c->pos_kmax != f.key_max))
+            c->pos_valid = false;
+        if (!c->pos_valid && same_pos) {
+            if ((rc = build_pos_order(c, sl, f))) return frame_abort(sl, rc);
+        }
+        ordered = c->pos_valid;
+    }
+    std::memcpy(c->last_cam, cam->cam_pos, sizeof c->last_cam);
+    c->last_cam_set = true;
     // which depth sort: A frame that keeps few splats (occlusion culling; small clouds) is sorted by ONE bucket scatter + one local
     // kernel (k_sort.h) instead of three global passes: 2 launches instead of 9.  Chosen from what the slot's previous frame kept
     // (correct whatever it chooses).  Not for deferred frames: nobody could render them again; and no prediction from a culled
@@ -1561,7 +1617,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     int key_bits = 1;
     while (key_bits < 32 && ((f.key_max - f.key_min) >> key_bits) != 0u) ++key_bits;
     const uint32_t n_slots = n ? div_up(c->nclus, 4u) * (uint32_t)GSR_K1_THREADS : 0u;   // the slots K1 can fill at most
-    const bool local = !cache_hit && n_slots > 0 && key_bits > 9 && !(c->opt_flags & GSR_FLAG_FULL_KEYS) && sl.kept_hi > sl.kept_lo && !j.deferred &&
+    const bool local = !cache_hit && !ordered && n_slots > 0 && key_bits > 9 && !(c->opt_flags & GSR_FLAG_FULL_KEYS) && sl.kept_hi > sl.kept_lo && !j.deferred &&
                        !c->classic_once && sl.kept_culled == j.cull &&
                        (c->opt_local_sort >= 2 || (c->opt_local_sort == 1 && sl.kept_hint > 0 && sl.kept_hint <= 500000u));
     if (!cache_hit) c->classic_once = false;
@@ -1577,20 +1633,21 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
             rounds = std::max(rounds, 3);
             ngroups = div_up(c->nclus, (uint32_t)CC_THREADS * (uint32_t)rounds);
         }
-        hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, c->opt_cluster,
-                           j.cull ? sl.hpyr : (const float*)nullptr, sl.cseg, sl.ccnt);
+        hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, ordered ? 0 : c->opt_cluster,
+                           (j.cull && !ordered) ? sl.hpyr : (const float*)nullptr, sl.cseg, sl.ccnt);   // (ordered: slots, not clusters -- all of them)
         // K1 over the survivors, four clusters per workgroup-iteration; the grid follows the slot's previous frame (+25 %), and
         // a frame that keeps more simply loops
         const uint32_t all_iter = div_up(c->nclus, 4u);
         uint32_t k1_grid = all_iter;
-        if (sl.surv_hint > 0) k1_grid = std::min<uint32_t>(all_iter, div_up(sl.surv_hint, 4u) * 5u / 4u + 64u);
+        if (sl.surv_hint > 0 && !ordered) k1_grid = std::min<uint32_t>(all_iter, div_up(sl.surv_hint, 4u) * 5u / 4u + 64u);
         // on a cache hit (identical frame description) the sorted (keyA, valA) are kept and K1's key/payload
         // output goes to the scratch buffers
         j.k1_grid = k1_grid;
         hipLaunchKernelGGL(k_preprocess, dim3(k1_grid ? k1_grid : 1u), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
-                           sl.rec, cache_hit ? sl.keyB : sl.keyA, cache_hit ? sl.valB : sl.valA,
+                           sl.rec, (cache_hit || ordered) ? sl.keyB : sl.keyA, (cache_hit || ordered) ? sl.valB : sl.valA,
                            j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.cull ? sl.hpyr : (const float*)nullptr, sl.blk_cnt,
-                           sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts, local ? sl.bkt_cnt : (uint32_t*)nullptr, local ? sl.d_n : (uint32_t*)nullptr);
+                           sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts, local ? sl.bkt_cnt : (uint32_t*)nullptr, local ? sl.d_n : (uint32_t*)nullptr,
+                           ordered ? c->pos_order : (const uint32_t*)nullptr);
         hipError_t e = hipGetLastError();
 #ifdef GSR_HOST_TIMING
         if (g_t_verdict > 0) {
@@ -1607,6 +1664,18 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     if ((rc = mark(sl, 1))) return frame_abort(sl, rc);
     if (cache_hit) {
         c->st.sorts_skipped += 1;
+    } else if (ordered) {
+        // K1 walked the splats nearest first: the heads of its 256-slot blocks, one after the other, ARE the sorted frame
+        const uint32_t m_max = n_slots / RS_SRC_BLOCK;
+        if ((rc = ensure_u32(&c->blk_pre, &c->blk_pre_cap, (size_t)m_max + 8))) return frame_abort(sl, rc);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, sl.blk_cnt, sl.d_counts, c->blk_pre, sl.d_n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compact_blocks<uint2>), dim3(m_max), dim3(RS_SRC_BLOCK), 0, s, sl.keyB, sl.valB, sl.blk_cnt, c->blk_pre,
+                           sl.d_counts, sl.keyA, sl.valA);
+        if (hipGetLastError() != hipSuccess) return frame_abort(sl, set_err(GSR_E_HIP, "position-keyed order: launch failed"));
+        c->st.sorts_skipped += 1;
+        sl.key_min = f.key_min;
+        sl.sort_valid = false;       // (what the slot holds is this frame's kept set only)
+        sl.sorted_culled = j.cull;
     } else {
         if (local) {
             // 512 buckets of equal width over the key range the previous frame kept, widened by a sixteenth on either side (the

@@ -483,7 +483,9 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              uint32_t* __restrict__ d_counts /* [0] = slots K1 filled (256 per workgroup-iteration), [1] = surviving clusters, [2] = "the small-frame sort
                                                 gave a bucket up" (cleared here, set by k_bucket_scatter / k_radix_local) */,
              uint32_t* __restrict__ zero_cnt /* the small-frame sort's bucket counters (BK_BUCKETS, BK_STRIDE apart), cleared here */,
-             uint32_t* __restrict__ zero_n /* ... and the count its scatter accumulates */)
+             uint32_t* __restrict__ zero_n /* ... and the count its scatter accumulates */,
+             const uint32_t* __restrict__ order /* position-keyed order (GSR_OPT_SORT_CACHE = 2): slot j holds splat order[j], the splats
+                                                   are walked nearest first and leave already sorted; NULL = storage order */)
 {
     static_assert(GSR_K1_THREADS == 4 * GSR_CLUSTER, "a K1 workgroup is four clusters");
     __shared__ uint32_t s_inc[CC_MAX_GROUPS];
@@ -503,7 +505,9 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
         if (rank < nsurv) {                                   // (wave-uniform)
             const uint32_t cl = cc_find_cluster(s_inc, ngroups, rank, cseg, cper);
             i = cl * (uint32_t)GSR_CLUSTER + (uint32_t)lane;
-            if (i < n) {
+            const bool exists = i < n;
+            if (order && exists) i = order[i];
+            if (exists) {
                 // geoA and geoB are fetched together; colour only once the splat is known to be needed (fetching it up front
                 // was measured slower: the bytes wasted on culled splats cost more than the second round trip)
                 const float4 a = geoA[i];

@@ -335,6 +335,69 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
 }
 
 // ---------------------------------------------------------------------------
+// Position-keyed order (GSR_OPT_SORT_CACHE = 2; the reference's rule: argsortByDistance runs only when the camera POSITION moves,
+// /root/reference/gsplat_plugin/src/GSplatRenderer.C:165-186).  The distance keys depend on the position alone, so ALL splats are
+// sorted once per position (k_pos_keys + the LSD passes above); while the position stands still K1 walks the splats in that
+// order, its per-workgroup compaction leaves what a frame keeps already sorted, and two small kernels make it dense.
+__global__ void __launch_bounds__(256)
+k_pos_keys(const float4* __restrict__ geoA, uint32_t n, float cx, float cy, float cz, uint32_t key_min, uint32_t key_max,
+           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = geoA[i];
+    // distance^2 with the operations of k_preprocess.h (gsr_k1_front) -- the same key bits
+    const float dx = a.x - cx, dy = a.y - cy, dz = a.z - cz;
+    const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    uint32_t b = __builtin_bit_cast(uint32_t, d2);
+    b = b < key_min ? key_min : (b > key_max ? key_max : b);
+    keys[i] = b - key_min;
+    vals[i] = i;
+}
+// exclusive scan of cnt[0, m) (m = *slots_dev / RS_SRC_BLOCK workgroup-iterations of K1) -> pre[0, m); the total -> *n_out.  One workgroup.
+__global__ void __launch_bounds__(1024)
+k_scan_counts(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ slots_dev, uint32_t* __restrict__ pre, uint32_t* __restrict__ n_out)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t m = *slots_dev / (uint32_t)RS_SRC_BLOCK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0u;
+    __syncthreads();
+    for (uint32_t base = 0; base < m; base += 1024u) {
+        const uint32_t j = base + threadIdx.x;
+        const uint32_t v = j < m ? cnt[j] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += s_w[w];
+        const uint32_t carry = s_carry;
+        if (j < m) pre[j] = carry + wbase + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wbase + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = s_carry;
+}
+// K1's per-workgroup-iteration compaction (cnt[k] items at the head of slots [256 k, 256 k + 256)) -> dense arrays
+template <typename V>
+__global__ void __launch_bounds__(RS_SRC_BLOCK)
+k_compact_blocks(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ pre,
+                 const uint32_t* __restrict__ slots_dev, uint32_t* __restrict__ keys_out, V* __restrict__ vals_out)
+{
+    const uint32_t k = blockIdx.x;
+    if (k * (uint32_t)RS_SRC_BLOCK >= *slots_dev) return;
+    if (threadIdx.x < cnt[k]) {
+        const uint32_t src = k * (uint32_t)RS_SRC_BLOCK + threadIdx.x, dst = pre[k] + threadIdx.x;
+        keys_out[dst] = keys_in[src];
+        vals_out[dst] = vals_in[src];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Small sorts: ONE bucket kernel + ONE local kernel.
 // After occlusion culling a frame sorts a few hundred thousand keys, and the three LSD passes above are nine launches at
 // their latency floors (65 us for 0.3 M keys on MI355X).  Instead:

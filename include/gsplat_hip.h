@@ -254,10 +254,15 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        kernels find the tiles unequal enough for it to pay, 3 = heaviest first always */
 #define GSR_OPT_STAGE_TIMING    2   /* HIP events on the frame's stream: 0 = none, 1 = around the blend kernel only
                                        (default; feeds gsr_stats.blend_ms_total), 2 = around every stage (ms_* fields) */
-#define GSR_OPT_SORT_CACHE      3   /* 0/1: skip the depth sort when the frame description (camera, shard, geometry) is
+#define GSR_OPT_SORT_CACHE      3   /* 0/1 (default 1): skip the depth sort when the frame description (camera, shard, geometry) is
                                        unchanged -- argsortByDistance's caching (src/GSplatRenderer.C:179-186) for the case
                                        that matters, a static viewport redraw; the sorted list holds only the splats visible
-                                       to the camera that sorted, so a pure rotation re-sorts */
+                                       to the camera that sorted, so a pure rotation re-sorts.
+                                       2: the reference's rule in full (src/GSplatRenderer.C:165-186) -- the order depends on the camera
+                                       POSITION only: the second frame in a row from one position sorts ALL splats for it once, and until
+                                       the position moves every frame walks the splats in that order and skips its sort (pixels identical;
+                                       single context, not deferred).  Off by default: on MI355X re-sorting the few hundred thousand splats
+                                       a frame keeps is cheaper than walking six million in depth order */
 #define GSR_OPT_SUPER_TILE      4   /* super-tile edge in tiles: 0 = auto (smallest power of two giving
                                        <= 256 super-tiles), or a lower bound 1,2,4,8,16 (raised as needed
                                        to stay within 256 super-tiles) */

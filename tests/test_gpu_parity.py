@@ -934,6 +934,38 @@ def test_sort_cache_counts_hits(pkg, engine):
         engine.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, 2)
 
 
+@pytest.mark.parametrize("cull", [0, 2])
+def test_position_keyed_order_skips_the_sort_on_a_rotation(pkg, oracle, cull):
+    """GSR_OPT_SORT_CACHE = 2, the reference's rule (src/GSplatRenderer.C:165-186: argsortByDistance runs only when the camera
+    POSITION moves): while the position stands still the frames take the depth order of all splats sorted for that position --
+    sorts_skipped counts them -- and render exactly what a context that sorts every frame renders"""
+    splats = pkg.scenes.make_scene(120000, seed=163, sh=True)
+    w, h = 480, 320
+    base = pkg.camera.make_camera(w, h, sh_order=3, frame=2)
+    turns = [pkg.camera.rotated_in_place(base, y, p) for y, p in ((0, 0), (4, 0), (8, 2), (-6, -3), (12, 1))]
+    moved = pkg.camera.make_camera(w, h, sh_order=3, frame=9)
+    ref = pkg.Engine(0); ref.upload(splats); ref.set_option(pkg.engine.OPT_OCCLUSION_CULL, cull)
+    eng = pkg.Engine(0); eng.upload(splats); eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, cull)
+    try:
+        eng.set_option(pkg.engine.OPT_SORT_CACHE, 2)
+        eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, 1)
+        eng.stats_reset()
+        assert np.array_equal(eng.render(turns[0]), ref.render(turns[0]))
+        assert eng.stats()["sorts_skipped"] == 0                      # a position seen for the first time: sorted as ever
+        for k, c in enumerate(turns[1:], start=1):
+            assert np.array_equal(eng.render(c), ref.render(c)), f"turn {k}"
+            # the position has not moved: the order stands (a frame that occlusion culling renders twice skips twice)
+            assert eng.stats()["sorts_skipped"] - eng.stats()["frames_repaired"] == k
+        before = eng.stats()["sorts_skipped"]
+        assert np.array_equal(eng.render(moved), ref.render(moved))
+        assert eng.stats()["sorts_skipped"] == before                   # ... and a move sorts again
+        assert np.array_equal(eng.render(pkg.camera.rotated_in_place(moved, 5)), ref.render(pkg.camera.rotated_in_place(moved, 5)))
+        assert eng.stats()["sorts_skipped"] > before
+        _check_image(eng.render(turns[2]), oracle.render(splats, turns[2], threads=oracle.max_threads()))
+    finally:
+        eng.close(); ref.close()
+
+
 @pytest.mark.parametrize("scheme", ["array", "vec3", "f_rest", "none"])
 def test_prim_ingest_renders_like_the_oracle(pkg, oracle, scheme):
     """SURVEY N1 on the GPU: raw float attributes in each SH naming scheme -> GSplatPrim::update (quantise, pack, register)

@@ -119,6 +119,16 @@ def test_known_answers_from_the_source(oracle):
     assert oracle.log2_opacity(float("inf")) == float("inf")
     # the discard rule on the argument agrees with alpha >= 1/255 except within rounding of the threshold
     assert abs(2.0 ** (-oracle.LOG2_255) - 1 / 255) < 1e-9
+    rng = np.random.default_rng(255)
+    ops = np.concatenate([rng.uniform(1 / 255, 1.0, 4000), rng.uniform(1.0, 50.0, 500)]).astype(np.float32)
+    la32 = np.array([oracle.log2_opacity(float(v)) for v in ops], dtype=np.float32)
+    # |kappa q|^2 drawn around each splat's own threshold log2(255 opacity), where the decision is made
+    thr = np.log2(255.0 * ops.astype(np.float64))
+    pw = (thr[:, None] + rng.normal(0.0, 0.02, (ops.size, 40))).clip(0.0, None).astype(np.float32)
+    contract = (la32[:, None] - pw) >= np.float32(-oracle.LOG2_255)                      # float32, as the oracle and the kernel form it
+    alpha = ops.astype(np.float64)[:, None] * np.exp2(-pw.astype(np.float64))            # the shader's alpha, exactly
+    clear = np.abs(alpha * 255.0 - 1.0) > 2e-6                                           # (a few float32 ulps of the argument)
+    assert clear.mean() > 0.99 and np.array_equal(contract[clear], (alpha >= 1 / 255)[clear])
 
 
 def test_single_splat_centre_alpha(oracle, pkg):

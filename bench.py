@@ -504,7 +504,10 @@ def main():
                         "frac": valu_tflops / 157.3, "wave_record_evals_per_launch": wave_evals,
                         "flop_per_pixel_eval": FLOP_PER_EVAL, "inner_loop_iteration_ns": iter_ns,
                         "inner_loop_issue_bound_ms": issue_ms, "inner_loop_issue_frac": issue_ms / blend_ms if blend_ms > 0 else 0.0,
-                        "note": "issue bound = inner-loop instruction mix x issue intervals measured with tools/ubench_valu.hip"}
+                        "frac_at_contract_v2_flop_count": (wave_evals * 64 * 34.0 / (blend_ms * 1e-3) / 1e12 / 157.3) if blend_ms > 0 else 0.0,
+                        "note": "issue bound = inner-loop instruction mix x issue intervals measured with tools/ubench_valu.hip; "
+                                "contract v3 removed 12 of the 34 FLOP of a pixel evaluation (the software 2^x), so the same evaluations "
+                                "count for fewer FLOP: frac_at_contract_v2_flop_count prices them as rounds 1-2 did"}
     stages = {k: st_stage[k] for k in ("ms_preprocess", "ms_depth_sort", "ms_emit", "ms_tile_sort", "ms_blend", "ms_total")} if st_stage else {}
     stages["note"] = ("one frame of the extra leg with events around every stage: ms_emit = binning count+scans, ms_tile_sort = "
                       "binning placement + lazy colour pass")

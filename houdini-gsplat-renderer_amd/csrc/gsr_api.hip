@@ -138,6 +138,7 @@ struct FrameSlot {
     int32_t* order = nullptr;          // blockIdx -> tile, heaviest tiles first: written by k_tile_order at the end of a frame
     size_t order_cap = 0;              //   for this slot's next frame (valid while the tile geometry stays what it was)
     bool order_valid = false;
+    int order_age = 0;                 // frames the table has stood (tiles alike: it is rebuilt every opt_order_keep frames only)
     int order_sig[6] = {0, 0, 0, 0, 0, 0}, order_per_xcd = 0;
     uint32_t* st_scan = nullptr;       // [512] per super-tile: deepest scan of its opaque tiles / "a tile stayed open" (k_tile_pass -> k_sum_work)
     GsrTilePartial* partial = nullptr; // [4096] per 8x8-tile block: partial sums of the frame's counters (k_tile_pass -> k_sum_work)
@@ -236,6 +237,7 @@ struct gsr_context {
     bool last_cam_set = false;
     uint32_t* blk_pre = nullptr;       // exclusive prefix of K1's per-iteration counts (k_scan_counts)
     size_t blk_pre_cap = 0;
+    int opt_order_keep = 32;           // (A/B hook, GSR_ORDER_KEEP in the environment: 0 = no tile order where the tiles are alike)
     int opt_scatter_direct = 1;        // (A/B hook, GSR_SCATTER_DIRECT in the environment) the small-frame sort's scatter: one workgroup per K1 block
     int opt_bn_items = 0;              // (A/B hook, GSR_BN_ITEMS in the environment: 1, 2 or 4 splats per binning thread; 0 = by frame size)
     int nslots = 1;                    // frames in flight (GSR_OPT_FRAMES_IN_FLIGHT): serial by default -- occlusion culling wants the
@@ -436,6 +438,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
     gsr_context* c = new (std::nothrow) gsr_context();
     if (!c) return set_err(GSR_E_OOM, "gsr_create: host allocation failed");
     c->device = device;
+    if (const char* e = std::getenv("GSR_ORDER_KEEP")) c->opt_order_keep = std::atoi(e);   // (A/B hook)
     if (const char* e = std::getenv("GSR_SCATTER_DIRECT")) c->opt_scatter_direct = std::atoi(e);   // (A/B hook: -1 the general scatter, 0 never direct, 1 direct by frame size, 2 always direct)
     if (const char* e = std::getenv("GSR_BN_ITEMS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) c->opt_bn_items = v; }   // (A/B hook)
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
@@ -1272,8 +1275,16 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
         const int sig[7] = {j.f.width, j.f.height, j.f.shard_index, j.f.shard_count, j.f.shard_rpb, j.f.super_shift, (int)c->geo_gen};
         std::memcpy(sl.horizon_sig, sig, sizeof sig);
     }
-    sl.order_valid = false;
-    if (j.use_map && (c->opt_swizzle >= 3 || (c->opt_swizzle == 2 && c->order_pays)) && j.local_tiles > 0 && j.n_super <= 256 &&
+    // The heaviest-first table is rebuilt every frame where the tiles differ a lot (k_sum_work's verdict); where they do not it is
+    // still worth a few microseconds of k_blend's tail (C4: 0.142 -> 0.139 ms), but not the 10 us of k_tile_order every frame:
+    // then a table stands for GSR_ORDER_KEEP frames of the same shape.
+    const int osig[6] = {j.f.width, j.f.height, j.f.shard_index, j.f.shard_count, j.f.shard_rpb, j.f.super_shift};
+    const bool order_due = c->opt_swizzle >= 3 || (c->opt_swizzle == 2 && c->order_pays);
+    const bool order_kept = !order_due && c->opt_swizzle == 2 && c->opt_order_keep > 0 && sl.order_valid && sl.order_age < c->opt_order_keep &&
+                            std::memcmp(osig, sl.order_sig, sizeof osig) == 0;
+    const bool order_refresh = !order_due && !order_kept && c->opt_swizzle == 2 && c->opt_order_keep > 0 && c->n >= 1000000u;
+    if (order_kept) sl.order_age += 1; else sl.order_valid = false;
+    if (j.use_map && (order_due || order_refresh) && j.local_tiles > 0 && j.n_super <= 256 &&
         sl.sup_work) {
         // the next frame's tile order
         const int per_xcd = 2 * ((j.n_super + 15) / 16) << (2 * j.f.super_shift);
@@ -1293,6 +1304,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
         std::memcpy(sl.order_sig, sig, sizeof sig);
         sl.order_per_xcd = per_xcd;
         sl.order_valid = true;
+        sl.order_age = 0;
     }
     sl.sup_par ^= 1;
     if (j.f.sh_order > 0 && c->opt_lazy) c->prefix_valid = true;   // (eager frames keep the scan depths too: the switch to lazy starts predicted)

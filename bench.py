@@ -9,8 +9,12 @@ resident in HBM before the timed region (uploaded once, as the reference stages
 textures once).
 
   python bench.py --gpus 1 --steps 60 --warmup 5
+  python bench.py --gpus N ...          (no launcher: ONE process drives the N GPUs through gsr_multi_* -- the form the
+                                         reference's single draw thread implies, src/DM_GSplatHook.C:30-39; RCCL gather)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W          (one process per GPU, gsr_comm_*)
+Fewer than N GPUs visible: one JSON line with an "error" field and a non-zero exit code (GSR_BENCH_ALLOW_DUP=1 lets the
+single-process form put several ranks on one GPU over the COPY transport: a functional test, flagged in the line).
 
 Workload at every N: BASELINE config C4 -- 6,000,000 synthetic splats (SH degree 3,
 seed 1004), 1920x1080 -- the scene the ">= 60 fps on one MI355X" target is quoted on.
@@ -158,6 +162,15 @@ def cpu_baseline(oracle, splats, cam0, pkg, budget_s: float) -> dict:
         oracle.reference_host_stage(splats.P, cam.cam_pos, threads)
         hs.append(time.perf_counter() - t0)
     host_stage_ms = float(np.median(hs[1:])) * 1e3
+    # ... and ONE un-scaled frame of the whole scene, so that the extrapolation above can be checked against a measurement
+    full_ms = None
+    if sample_n != n:
+        oracle.render(splats, cam0, threads=threads) if n <= 2_000_000 else None      # (a warm-up only where it is cheap)
+        t0 = time.perf_counter()
+        oracle.render(splats, pkg.camera.make_camera(cam0.width, cam0.height, sh_order=cam0.sh_order, frame=warm), threads=threads)
+        full_ms = (time.perf_counter() - t0) * 1e3
+    else:
+        full_ms = t_med * 1e3
     return {
         "value": fps_sample * (sample_n / n),
         "unit": "frames/sec",
@@ -169,30 +182,293 @@ def cpu_baseline(oracle, splats, cam0, pkg, budget_s: float) -> dict:
                    f"(per-splat work is linear in splats; per-pixel work grows more slowly, so this flatters the CPU)"),
         "sample_fps": fps_sample,
         "frames": len(times),
+        "full_scene_ms": full_ms,
+        "full_scene_fps": (1e3 / full_ms) if full_ms else None,
+        "full_scene": f"one frame of all {n} splats (not scaled), {threads} threads",
         "reference_host_stage_ms": host_stage_ms,
         "reference_host_stage": (f"argsortByDistance restated (distance^2 + __gnu_parallel::sort of int indices by indirect float "
                                  f"compare, standing in for tbb::parallel_sort) on all {n} splats, {threads} threads: median of 3"),
     }
 
 
+def error_line(args, msg: str, code: int = 2):
+    """a parsable line instead of a bare exit string: the driver records what went wrong"""
+    print(json.dumps({"metric": "frames/sec at 1920x1080 + achieved HBM GB/s (blend kernel)", "value": None, "unit": "frames/sec",
+                      "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "error": msg}))
+    sys.stdout.flush()
+    sys.exit(code)
+
+
+def blend_roofline(st, own_px: float, regime: str, hbm, tj, traffic_from, kernel="k_blend") -> dict:
+    """blend-kernel roofline of ONE context from its gsr_stats: HIP events on the kernel's own stream, counts from the kernel"""
+    launches = max(1, st["blend_launches"])                    # launches bracketed by events (every --time-every-th frame)
+    frames_done = max(1, st["frames"])                         # launches in all: the kernel's own counters cover every one
+    blend_ms = st["blend_ms_total"] / launches
+    d_eff = st["blend_pairs_consumed_total"] / frames_done     # (tile, splat) pairs CONSUMED per launch = records gathered
+    scanned = st["blend_entries_scanned_total"] / frames_done  # list entries (idx + mask) read per launch
+    rec_b, pair_b = st["record_bytes"], st["pair_bytes"]
+    # SURVEY 8(d): unit of work = one consumed (tile, splat) pair = its list entry (8 B) + its projected record (48 B; this
+    # build's true sizes), plus one RGBA-f32 store per pixel.  The entries a tile merely SCANS in its super-tile's list to
+    # find its own (the price of coarse lists) are NOT algorithmic bytes: they are reported beside it.
+    bytes_blend = (pair_b + rec_b) * d_eff + 16.0 * own_px
+    achieved = bytes_blend / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
+    traffic = None
+    if tj is not None:
+        try:
+            traffic = float(next(v for k, v in tj.items() if kernel in k)["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
+    peak_meas = hbm["peak_GBps"] if hbm else None
+    roofline = {
+        "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS, "peak_measured": peak_meas, "frac_of_measured": (achieved / peak_meas) if peak_meas else None,
+        "peak_measured_by": "tools/ubench_hbm.hip: best of the streaming copies over 1 GiB arrays on this GPU (read + write bytes)" if hbm else None, "hbm_ubench": hbm,
+        "regime": regime, "traffic": traffic, "traffic_replayed_from": traffic_from if traffic is not None else None,
+        "avg_launch_ms": blend_ms, "launches_timed": int(st["blend_launches"]), "launches": int(st["frames"]),
+        "algorithmic_bytes_per_launch": bytes_blend,
+        "pairs_consumed_per_launch": d_eff, "bytes_per_consumed_pair": pair_b + rec_b,
+        "entries_scanned_per_launch": scanned, "list_scan_bytes": pair_b * scanned,
+        "scan_amplification": scanned / d_eff if d_eff > 0 else None,
+        "pairs_sorted_last_frame": st["pairs_total"], "record_bytes": rec_b, "entry_bytes": pair_b,
+        "super_tile": st["super_tile"],
+        "note": "k_blend is FP32-vector-issue bound at this arithmetic intensity (DESIGN.md); the HBM fraction is reported "
+                "as the metric asks, on consumed pairs only (SURVEY 8d)",
+    }
+    # the bound that actually binds k_blend: FP32 vector issue.  One pixel evaluation of one record is 22 FLOP
+    # (fma = 2: affine forms 8, power 3, log-domain alpha 2 = one subtraction + one v_exp_f32 (contract v3; the software
+    # 2^x + multiply of contract v2 were 15), quad test 1, under-blend 8), counted
+    # per 64-lane wave evaluation by the kernel itself (lanes outside the quad execute the same instructions)
+    FLOP_PER_EVAL = 22.0
+    wave_evals = st["blend_wave_evals_total"] / frames_done
+    valu_tflops = wave_evals * 64 * FLOP_PER_EVAL / (blend_ms * 1e-3) / 1e12 if blend_ms > 0 else 0.0
+    # ... and against the ISSUE RATES measured on this GPU (tools/ubench_valu.hip -> profiles/ubench_valu_mi355x.txt).
+    # One inner-loop iteration = two wave-record evaluations (ISA of k_blend<false>, tools/kernel_resources.py --isa)
+    n_simd = 256 * 4
+    iter_ns = BLEND_ITER_NS
+    issue_ms = (wave_evals / 2.0) * iter_ns / n_simd * 1e-6
+    roofline["valu"] = {"bound": "fp32 vector", "achieved": valu_tflops, "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": valu_tflops / 157.3, "wave_record_evals_per_launch": wave_evals,
+                        "flop_per_pixel_eval": FLOP_PER_EVAL, "inner_loop_iteration_ns": iter_ns,
+                        "inner_loop_issue_bound_ms": issue_ms, "inner_loop_issue_frac": issue_ms / blend_ms if blend_ms > 0 else 0.0,
+                        "frac_at_contract_v2_flop_count": (wave_evals * 64 * 34.0 / (blend_ms * 1e-3) / 1e12 / 157.3) if blend_ms > 0 else 0.0,
+                        "note": "issue bound = inner-loop instruction mix x issue intervals measured with tools/ubench_valu.hip; "
+                                "contract v3 removed 12 of the 34 FLOP of a pixel evaluation (the software 2^x), so the same evaluations "
+                                "count for fewer FLOP: frac_at_contract_v2_flop_count prices them as rounds 1-2 did"}
+    return roofline
+
+
+# one inner-loop iteration of k_blend<false> = two wave-record evaluations (ISA, tools/kernel_resources.py --isa):
+# 5 v_pk_fma_f32 with three full operands (2.02 ns per SIMD), 2 with a broadcast operand (1.77), 1 v_pk_mul (1.76),
+# 2 v_max + 6 v_cmp (1.72), 2 v_cndmask (1.64), 2 v_exp_f32 (3.40), 9 full-rate mul/fmac/sub/add (1.0)
+BLEND_ITER_NS = 5 * 2.02 + 2 * 1.77 + 1 * 1.76 + 8 * 1.72 + 2 * 1.64 + 2 * 3.40 + 9 * 1.0
+
+
+def load_traffic(regime: str, usable: bool):
+    """HBM traffic per launch: PMC counters cannot be read from inside this process, so the figure is REPLAYED from the
+    rocprofv3 --pmc passes of this same command (tools/gpu_pmc.sh -> profiles/pmc_traffic.json; 2*FETCH_SIZE + WRITE_SIZE as
+    the MI355X guide prescribes) -- and only when that file was produced by the kernels being run now"""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not (usable and os.path.exists(tpath)):
+        return None, None
+    try:
+        tall = json.load(open(tpath))
+        if tall.get("_kernel_source_sha") != kernel_source_sha():   # (stale: collected with other kernels)
+            return None, None
+        return tall.get(regime), f"profiles/pmc_traffic.json[{regime}] (" + str(tall.get("_collected", "rocprofv3 --pmc passes of this command")) + ")"
+    except Exception:
+        return None, None
+
+
+def set_common_options(target, pkg, args):
+    """the options both forms (one context / gsr_multi) take"""
+    E = pkg.engine
+    target.set_option(E.OPT_OCCLUSION_CULL, args.cull)
+    target.set_option(E.OPT_CLUSTER_CULL, args.cluster_cull)
+    target.set_option(E.OPT_LOCAL_SORT, args.local_sort)
+    if args.dilate >= 0:
+        target.set_option(E.OPT_CULL_DILATE, args.dilate)
+    target.set_option(E.OPT_STORAGE_ORDER, args.storage_order)
+    target.set_option(E.OPT_TIMING_EVERY, args.time_every if args.time_every > 0 else max(1, min(8, args.steps // 16)))
+    target.set_option(E.OPT_XCD_SWIZZLE, 0 if args.no_swizzle else args.tile_order)
+    target.set_option(E.OPT_SUPER_TILE, args.super_tile)
+    target.set_option(E.OPT_DEBUG_FLAGS, args.flags)
+    target.set_option(E.OPT_FRAMES_IN_FLIGHT, args.frames_in_flight)
+    target.set_option(E.OPT_STAGE_TIMING, args.stage_timing)
+    target.set_option(E.OPT_LAZY_COLOUR, args.lazy)
+    target.set_option(E.OPT_SHARD_LAYOUT, args.shard_layout)
+
+
+def reference_frame(pkg, torch, dev_index, stream, splats, cam_struct, W, H, exact: bool):
+    """the same frame from a second, unsharded context on GPU `dev_index`; exact = occlusion AND cluster culling off (every
+    clip-visible splat is projected, sorted, binned: what the timed frames must be bit-identical to)"""
+    ref_eng = pkg.Engine(dev_index)
+    try:
+        ref_eng.set_stream(stream.cuda_stream)
+        if exact:
+            ref_eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, 0)
+            ref_eng.set_option(pkg.engine.OPT_CLUSTER_CULL, 0)
+        ref_eng.upload(splats)
+        ref = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{dev_index}")
+        ref_eng.render_struct_to_device(cam_struct, ref.data_ptr())
+        torch.cuda.synchronize(dev_index)
+        return ref
+    finally:
+        ref_eng.close()
+
+
+def main_single_process(args):
+    """python bench.py --gpus N, no launcher: ONE process, gsr_multi_* (a worker thread per rank inside the library, the
+    frame's one collective over RCCL).  The reference draws from one thread of one process (src/DM_GSplatHook.C:30-39)."""
+    import torch
+
+    N = args.gpus
+    if not torch.cuda.is_available():
+        error_line(args, "bench.py needs a GPU (the HIP path has no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    allow_dup = os.environ.get("GSR_BENCH_ALLOW_DUP", "0") == "1"
+    if ndev < N and not allow_dup:
+        error_line(args, f"--gpus {N} but only {ndev} GPU(s) visible (GSR_BENCH_ALLOW_DUP=1 runs the ranks as contexts on the "
+                         f"GPUs there are, over the COPY transport: a functional test, not a measurement)")
+    devices = [g % ndev for g in range(N)]
+    functional_only = ndev < N
+    pkg = ge.load_package()
+    E = pkg.engine
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    splats, cfg = pkg.scenes.make_config(args.config, args.splats)
+    W, H, order = cfg["width"], cfg["height"], cfg["sh_order"]
+    torch.cuda.set_device(devices[0])
+    try:
+        M = pkg.MultiEngine(devices, E.TRANSPORT_COPY if functional_only else E.TRANSPORT_RCCL)
+    except pkg.engine.GsrError as e:
+        error_line(args, f"gsr_multi_create over devices {devices}: {e}")
+    stream = torch.cuda.Stream(device=devices[0])
+    torch.cuda.set_stream(stream)
+    M.set_stream(stream.cuda_stream)
+    set_common_options(M, pkg, args)
+    M.upload(splats)
+    cams = [E.camera_struct(pkg.scenes.config_camera(args.config, pkg.camera, W, H, order, i)) for i in range(args.warmup + args.steps)]
+    final = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{devices[0]}")
+
+    def sync_all():
+        M.synchronize()
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    def step(i):
+        M.render_struct_to_device(cams[i], final.data_ptr())
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    for g in range(N):
+        E._check(M.L.gsr_stats_reset(M.L.gsr_multi_context(M.h, g)))
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    verified = None
+    if not args.no_verify:
+        ref = reference_frame(pkg, torch, devices[0], stream, splats, cams[args.warmup + args.steps - 1], W, H, exact=True)
+        verified = bool(torch.equal(final, ref)) and bool(ref[..., 3].max() > 0)
+        if not verified:
+            print("[bench] the sharded frame DIFFERS from the unsharded frame: max |diff| %.3e" % float((final - ref).abs().max()), file=sys.stderr)
+        del ref
+    stats = [M.stats(g) for g in range(N)]
+    # extra leg (untimed): per-rank stage times (HIP events around every stage) and the gather on the root's transfer stream
+    stage = None
+    gather_ms = None
+    if not args.no_extra_legs:
+        M.set_option(E.OPT_STAGE_TIMING, 2)
+        last = args.warmup + args.steps
+        for i in range(max(0, last - 12), max(0, last - 10)):
+            step(i)
+        sync_all()
+        for g in range(N):
+            E._check(M.L.gsr_stats_reset(M.L.gsr_multi_context(M.h, g)))
+        M.gather_stats(1)
+        for i in range(max(0, last - 10), last):
+            step(i)
+        sync_all()
+        ms, k = M.gather_stats(0)
+        gather_ms = ms / k if k else None
+        stage = []
+        for g in range(N):
+            sg = M.stats(g)
+            fr = max(1, sg["stage_frames"])
+            stage.append({"rank": g, "device": devices[g], "ms_preprocess": sg["stage_ms_total"][0] / fr, "ms_depth_sort": sg["stage_ms_total"][1] / fr,
+                          "ms_binning": (sg["stage_ms_total"][2] + sg["stage_ms_total"][3]) / fr, "ms_blend": sg["stage_ms_total"][4] / fr,
+                          "ms_total": sg["frame_ms_total"] / fr, "n_visible": sg["n_visible"], "clusters_kept": sg["clusters_kept"],
+                          "frames_culled": sg["frames_culled"], "frames_repaired": sg["frames_repaired"]})
+        M.set_option(E.OPT_STAGE_TIMING, args.stage_timing)
+    rccl_ranks, rccl_n = M.comm_info()
+    hbm = measured_hbm_peak()
+    per_rank = []
+    for g in range(N):
+        own_px = sum(min(16, H - r * 16) for r in pkg.multigpu.owned_tile_rows(H, g, N, args.shard_layout)) * W
+        regime = "culled" if stats[g]["frames_culled"] * 2 > stats[g]["frames"] else "unculled"
+        per_rank.append(blend_roofline(stats[g], own_px, regime, hbm if g == 0 else None, None, None))
+        per_rank[-1]["rank"] = g
+    heavy = max(range(N), key=lambda g: per_rank[g]["avg_launch_ms"])
+    line = {
+        "metric": "frames/sec at 1920x1080 + achieved HBM GB/s (blend kernel)" if (W, H) == (1920, 1080)
+        else f"frames/sec at {W}x{H} + achieved HBM GB/s (blend kernel)",
+        "value": (args.steps / elapsed) if verified is not False else None,
+        "unit": "frames/sec", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {splats.n} synthetic splats (SH deg {order}, seed {cfg['seed']}), {W}x{H}, orbiting camera (re-sort every frame)",
+                   "parallelism": f"tile-row shard x{N}, " + ("contiguous bands" if args.shard_layout else "interleaved rows") +
+                                  ", one process (gsr_multi: a worker thread per rank)",
+                   "gather": ("in-library RCCL: ncclSend / ncclRecv in one group on per-rank transfer streams, " +
+                              ("received straight into the framebuffer (zero copy)" if args.shard_layout else "k_stitch_bands on the root") +
+                              ", overlapping the next frame's kernels") if M.transport == E.TRANSPORT_RCCL else
+                             "COPY transport (device-to-device copies ordered by events): FUNCTIONAL TEST, several ranks share a GPU",
+                   "devices": devices, "functional_only": functional_only,
+                   "n_splats": splats.n, "width": W, "height": H, "frames_in_flight": args.frames_in_flight},
+        "rccl_ranks": rccl_ranks, "rccl_comm_count": rccl_n,
+        "sharded_frame_bit_identical": verified,
+        "gather_ms": gather_ms,
+        "per_rank_stages_ms": stage,
+        "roofline": per_rank[heavy],
+        "roofline_per_rank": [{k: r[k] for k in ("rank", "achieved", "frac", "avg_launch_ms", "pairs_consumed_per_launch", "algorithmic_bytes_per_launch", "regime")} for r in per_rank],
+        "n_visible_per_rank": [st["n_visible"] for st in stats],
+        "occlusion_culling": {"enabled": bool(args.cull), "frames_culled": [st["frames_culled"] for st in stats],
+                              "frames_repaired": [st["frames_repaired"] for st in stats], "frames": [st["frames"] for st in stats]},
+    }
+    print(json.dumps(line))
+    sys.stdout.flush()
+    M.close()
+    if verified is False:
+        sys.exit(3)
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return main_single_process(args)
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        if rank == 0:
+            error_line(args, f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+        sys.exit(2)
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        if rank == 0:
+            error_line(args, "bench.py needs a GPU (the HIP path has no CPU fallback)")
+        sys.exit(2)
     # one rank per GPU; GSR_BENCH_BACKEND=gloo + fewer GPUs than ranks is a functional test mode only
     # (lets the sharded path run end-to-end on a 1-GPU box), never a performance configuration
     backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     if backend == "nccl" and world > ndev:
-        raise SystemExit(f"{world} ranks but only {ndev} GPUs")
+        if rank == 0:
+            error_line(args, f"{world} ranks but only {ndev} GPU(s) visible")
+        sys.exit(2)
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dist = None
@@ -221,24 +497,11 @@ def main():
     W, H, order = cfg["width"], cfg["height"], cfg["sh_order"]
 
     eng = pkg.Engine(dev_index)
-    # one explicit (non-null) HIP stream carries the kernels, the RCCL gather and the stitch in order
+    # one explicit (non-null) HIP stream: frames are ordered on it (N > 1: the kernels and the RCCL gather run on streams of the library)
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
-    eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, args.cull)
-    eng.set_option(pkg.engine.OPT_CLUSTER_CULL, args.cluster_cull)
-    eng.set_option(pkg.engine.OPT_LOCAL_SORT, args.local_sort)
-    if args.dilate >= 0:
-        eng.set_option(pkg.engine.OPT_CULL_DILATE, args.dilate)
-    eng.set_option(pkg.engine.OPT_STORAGE_ORDER, args.storage_order)
-    eng.set_option(pkg.engine.OPT_TIMING_EVERY, args.time_every if args.time_every > 0 else max(1, min(8, args.steps // 16)))
-    eng.set_option(pkg.engine.OPT_XCD_SWIZZLE, 0 if args.no_swizzle else args.tile_order)
-    eng.set_option(pkg.engine.OPT_SUPER_TILE, args.super_tile)
-    eng.set_option(pkg.engine.OPT_DEBUG_FLAGS, args.flags)
-    eng.set_option(pkg.engine.OPT_FRAMES_IN_FLIGHT, args.frames_in_flight)
-    eng.set_option(pkg.engine.OPT_STAGE_TIMING, args.stage_timing)
-    eng.set_option(pkg.engine.OPT_LAZY_COLOUR, args.lazy)
-    eng.set_option(pkg.engine.OPT_SHARD_LAYOUT, args.shard_layout)
+    set_common_options(eng, pkg, args)
     if world > 1:
         eng.set_row_shard(rank, world)
     elif args.emulate_shard > 1:
@@ -248,12 +511,13 @@ def main():
     cams = [pkg.engine.camera_struct(pkg.scenes.config_camera(args.config, pkg.camera, W, H, order, i))
             for i in range(args.warmup + args.steps)]
     # N>1: the frame's ONE collective -- band images -> rank 0 over xGMI -- lives INSIDE the library (gsr_comm_render:
-    # render band -> ncclSend / ncclRecv x (N-1) in one group -> k_stitch_bands on the root).  torch.distributed only
-    # carries the 128-byte communicator id, the barriers and the max-over-ranks of the timing.  Every rank must be able
-    # to load RCCL for that; otherwise (and in the gloo functional-test mode) the torch gather of multigpu.py is used.
+    # render band -> ncclSend / ncclRecv x (N-1) in one group on a transfer stream; band layout: straight into the framebuffer).
+    # torch.distributed only carries the 128-byte communicator id, the barriers and the max-over-ranks of the timing.  Every
+    # rank must be able to load RCCL for that; otherwise (and in the gloo functional-test mode) the torch gather of multigpu.py is used.
     gather = "none (1 GPU)"
     fg = None
     final = None
+    rccl_info = None
     if world > 1:
         use_lib = backend == "nccl" and not args.torch_gather
         if use_lib:
@@ -287,16 +551,22 @@ def main():
                     eng.set_row_shard(rank, world)
             if use_lib:
                 final = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
-                gather = "in-library RCCL: gsr_comm_render (ncclSend/ncclRecv group + k_stitch_bands)"
+                gather = ("in-library RCCL: gsr_comm_render (ncclSend / ncclRecv group on a transfer stream, " +
+                          ("received straight into the framebuffer" if args.shard_layout else "k_stitch_bands on the root") +
+                          ", overlapping the next frame's kernels)")
+                rccl_info = list(eng.comm_info())
         if not use_lib:
             fg = pkg.multigpu.FrameGatherer(dist, rank, world, W, H, "cuda", engine=eng, via_host=(backend != "nccl"),
                                             layout=args.shard_layout)
             gather = "torch.distributed.gather + gsr_stitch_bands"
-    band = torch.zeros((eng.band_rows(H), W, 4), dtype=torch.float32, device="cuda") if fg is None else fg.band
-    assert band.shape[0] == eng.band_rows(H)
+    in_lib = world > 1 and fg is None
+    band = None
+    if not in_lib:
+        band = torch.zeros((eng.band_rows(H), W, 4), dtype=torch.float32, device="cuda") if fg is None else fg.band
+        assert band.shape[0] == eng.band_rows(H)
 
     def step(i):
-        if final is not None or (world > 1 and fg is None):
+        if in_lib:
             eng.comm_render(cams[i], final.data_ptr() if final is not None else 0)
         else:
             eng.render_struct_to_device(cams[i], band.data_ptr())
@@ -329,24 +599,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Is the last TIMED frame the full frame?  The same camera from a second context on this GPU that culls nothing
+    # (GSR_OPT_OCCLUSION_CULL = 0, GSR_OPT_CLUSTER_CULL = 0, unsharded): bit for bit.
     verified = None
-    if world > 1 and not args.no_verify:
+    if not args.no_verify and (world > 1 or args.emulate_shard <= 1):
         last = cams[args.warmup + args.steps - 1]
-        stitched = current_frame()                              # the last step's frame on rank 0
+        shown = current_frame()                                 # the last step's frame on rank 0
         if rank == 0:
-            ref_eng = pkg.Engine(dev_index)                     # an unsharded context beside the sharded one
-            ref_eng.set_stream(stream.cuda_stream)
-            ref_eng.upload(splats)
-            ref = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-            ref_eng.render_struct_to_device(last, ref.data_ptr())
-            torch.cuda.synchronize()
-            verified = bool(torch.equal(stitched, ref)) and bool(ref[..., 3].max() > 0)
-            ref_eng.close()
-            if not verified:   # reported in the JSON line (a number next to "false" is not a valid number); no exit here: the
-                               # other ranks are waiting at the barrier below
-                print("[bench] the sharded frame DIFFERS from the unsharded frame: max |diff| %.3e" %
-                      float((stitched - ref).abs().max()), file=sys.stderr)
-        dist.barrier()
+            ref = reference_frame(pkg, torch, dev_index, stream, splats, last, W, H, exact=True)
+            verified = bool(torch.equal(shown, ref)) and bool(ref[..., 3].max() > 0)
+            if not verified:   # reported in the JSON line; the exit code follows after the line (the other ranks are at the barrier below)
+                print("[bench] the timed frame DIFFERS from the frame rendered without culling / sharding: max |diff| %.3e" %
+                      float((shown - ref).abs().max()), file=sys.stderr)
+            del ref
+            torch.cuda.empty_cache()
+        if world > 1:
+            dist.barrier()
     st = eng.stats()
     # extra leg (untimed, informational): a few more frames with HIP events around EVERY stage -> per-stage breakdown and the
     # k_preprocess / k_colour_prefix durations.  Kept out of the timed region: six extra events per frame stall the queue ~35 us.
@@ -439,75 +707,14 @@ def main():
             del oband, osp
             torch.cuda.empty_cache()
     # blend-kernel roofline, measured with HIP events on the kernel's own stream
-    launches = max(1, st["blend_launches"])                    # launches bracketed by events (every --time-every-th frame)
-    frames_done = max(1, st["frames"])                         # launches in all: the kernel's own counters cover every one
-    blend_ms = st["blend_ms_total"] / launches
-    d_eff = st["blend_pairs_consumed_total"] / frames_done     # (tile, splat) pairs CONSUMED per launch = records gathered
-    scanned = st["blend_entries_scanned_total"] / frames_done  # list entries (idx + mask) read per launch
-    rec_b, pair_b = st["record_bytes"], st["pair_bytes"]
     shards = args.emulate_shard if (world == 1 and args.emulate_shard > 1) else world
     srank = (args.emulate_rank % shards) if (world == 1 and args.emulate_shard > 1) else rank
     own_px = sum(min(16, H - r * 16) for r in pkg.multigpu.owned_tile_rows(H, srank, shards, args.shard_layout)) * W
-    # unit of work = one consumed (tile, splat) pair = its list entry (8 B) + its projected record (48 B; this
-    # build's true sizes), plus one RGBA-f32 store per pixel.  The entries a tile merely SCANS in its super-tile's list to
-    # find its own (the price of coarse lists) are NOT algorithmic bytes: they are reported beside it.
-    bytes_blend = (pair_b + rec_b) * d_eff + 16.0 * own_px
-    achieved = bytes_blend / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
-    # HBM traffic of k_blend per launch: PMC counters cannot be read from inside this process, so the figure is REPLAYED from
-    # the rocprofv3 --pmc passes of this same command (tools/gpu_pmc.sh -> profiles/pmc_traffic.json; 2*FETCH_SIZE +
-    # WRITE_SIZE as the MI355X guide prescribes) -- and only when that file was produced by the kernels being run now
-    traffic, traffic_from = None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    tj = None
     regime = "culled" if st["frames_culled"] * 2 > st["frames"] else "unculled"
-    if os.path.exists(tpath) and world == 1 and args.config == "C4" and args.splats is None:
-        try:
-            tall = json.load(open(tpath))
-            if tall.get("_kernel_source_sha") == kernel_source_sha():   # (else stale: collected with other kernels)
-                tj = tall.get(regime)
-                traffic = float(next(v for k, v in tj.items() if "k_blend" in k)["hbm_bytes_per_launch"])
-                traffic_from = f"profiles/pmc_traffic.json[{regime}] (" + str(tall.get("_collected", "rocprofv3 --pmc passes of this command")) + ")"
-        except Exception:
-            traffic, tj = None, None
+    tj, traffic_from = load_traffic(regime, world == 1 and args.config == "C4" and args.splats is None)
     hbm = measured_hbm_peak() if rank == 0 else None
-    peak_meas = hbm["copy_GBps"] if hbm else None
-    roofline = {
-        "bound": "hbm", "kernel": "k_blend", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBPS, "peak_measured": peak_meas, "frac_of_measured": (achieved / peak_meas) if peak_meas else None,
-        "peak_measured_by": "tools/ubench_hbm.hip: float4 copy over 1 GiB arrays on this GPU" if hbm else None, "hbm_ubench": hbm,
-        "regime": regime, "traffic": traffic, "traffic_replayed_from": traffic_from,
-        "avg_launch_ms": blend_ms, "launches_timed": int(st["blend_launches"]), "launches": int(st["frames"]),
-        "algorithmic_bytes_per_launch": bytes_blend,
-        "pairs_consumed_per_launch": d_eff, "bytes_per_consumed_pair": pair_b + rec_b,
-        "entries_scanned_per_launch": scanned, "list_scan_bytes": pair_b * scanned,
-        "scan_amplification": scanned / d_eff if d_eff > 0 else None,
-        "pairs_sorted_last_frame": st["pairs_total"], "record_bytes": rec_b, "entry_bytes": pair_b,
-        "super_tile": st["super_tile"],
-        "note": "k_blend is FP32-vector-issue bound at this arithmetic intensity (DESIGN.md); the HBM fraction is reported "
-                "as the metric asks, on consumed pairs only (SURVEY 8d)",
-    }
-    # the bound that actually binds k_blend: FP32 vector issue.  One pixel evaluation of one record is 22 FLOP
-    # (fma = 2: affine forms 8, power 3, log-domain alpha 2 = one subtraction + one v_exp_f32 (contract v3; the software
-    # 2^x + multiply of contract v2 were 15), quad test 1, under-blend 8), counted
-    # per 64-lane wave evaluation by the kernel itself (lanes outside the quad execute the same instructions)
-    FLOP_PER_EVAL = 22.0
-    wave_evals = st["blend_wave_evals_total"] / frames_done
-    valu_tflops = wave_evals * 64 * FLOP_PER_EVAL / (blend_ms * 1e-3) / 1e12 if blend_ms > 0 else 0.0
-    # ... and against the ISSUE RATES measured on this GPU (tools/ubench_valu.hip -> profiles/ubench_valu_mi355x.txt).
-    # One inner-loop iteration = two wave-record evaluations (ISA of k_blend<false>, tools/kernel_resources.py --isa):
-    # 5 v_pk_fma_f32 with three full operands (2.02 ns per SIMD), 2 with a broadcast operand (1.77), 1 v_pk_mul (1.76),
-    # 2 v_max + 6 v_cmp (1.72), 2 v_cndmask (1.64), 2 v_exp_f32 (3.40), 9 full-rate mul/fmac/sub/add (1.0)
-    n_simd = 256 * 4
-    iter_ns = 5 * 2.02 + 2 * 1.77 + 1 * 1.76 + 8 * 1.72 + 2 * 1.64 + 2 * 3.40 + 9 * 1.0
-    issue_ms = (wave_evals / 2.0) * iter_ns / n_simd * 1e-6
-    roofline["valu"] = {"bound": "fp32 vector", "achieved": valu_tflops, "peak": 157.3, "unit": "TFLOP/s",
-                        "frac": valu_tflops / 157.3, "wave_record_evals_per_launch": wave_evals,
-                        "flop_per_pixel_eval": FLOP_PER_EVAL, "inner_loop_iteration_ns": iter_ns,
-                        "inner_loop_issue_bound_ms": issue_ms, "inner_loop_issue_frac": issue_ms / blend_ms if blend_ms > 0 else 0.0,
-                        "frac_at_contract_v2_flop_count": (wave_evals * 64 * 34.0 / (blend_ms * 1e-3) / 1e12 / 157.3) if blend_ms > 0 else 0.0,
-                        "note": "issue bound = inner-loop instruction mix x issue intervals measured with tools/ubench_valu.hip; "
-                                "contract v3 removed 12 of the 34 FLOP of a pixel evaluation (the software 2^x), so the same evaluations "
-                                "count for fewer FLOP: frac_at_contract_v2_flop_count prices them as rounds 1-2 did"}
+    peak_meas = hbm["peak_GBps"] if hbm else None
+    roofline = blend_roofline(st, own_px, regime, hbm, tj, traffic_from)
     stages = {k: st_stage[k] for k in ("ms_preprocess", "ms_depth_sort", "ms_emit", "ms_tile_sort", "ms_blend", "ms_total")} if st_stage else {}
     stages["note"] = ("one frame of the extra leg with events around every stage: ms_emit = binning count+scans, ms_tile_sort = "
                       "binning placement + lazy colour pass")
@@ -545,7 +752,7 @@ def main():
         line = {
             "metric": "frames/sec at 1920x1080 + achieved HBM GB/s (blend kernel)" if (W, H) == (1920, 1080)
             else f"frames/sec at {W}x{H} + achieved HBM GB/s (blend kernel)",
-            "value": args.steps / elapsed,
+            "value": (args.steps / elapsed) if verified is not False else None,   # (a frame rate of wrong pixels is not a number)
             "unit": "frames/sec",
             "n_gpus": world,
             "steps": args.steps,
@@ -558,7 +765,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {splats.n} synthetic splats (SH deg {order}, seed {cfg['seed']}), "
                                    f"{W}x{H}, orbiting camera (re-sort every frame)",
-                       "parallelism": (f"tile-row shard x{world}, " + ("contiguous bands" if args.shard_layout else "interleaved rows"))
+                       "parallelism": (f"tile-row shard x{world}, " + ("contiguous bands" if args.shard_layout else "interleaved rows") + ", one process per GPU")
                        if world > 1 else "single GPU", "gather": gather,
                        "n_splats": splats.n, "width": W, "height": H, "frames_in_flight": args.frames_in_flight},
             "roofline": roofline,
@@ -580,7 +787,12 @@ def main():
         if other is not None:
             line["other_configs"] = other
         if verified is not None:
-            line["sharded_frame_bit_identical"] = verified
+            # the last frame of the timed region against the same camera from a context that culls nothing (and is not sharded)
+            line["timed_frame_bit_identical"] = verified
+            if world > 1:
+                line["sharded_frame_bit_identical"] = verified
+        if rccl_info is not None:
+            line["rccl_rank_of_root"], line["rccl_comm_count"] = rccl_info
         if world == 1 and not args.no_cpu_baseline:
             oracle = ge.load_oracle()
             cam0 = pkg.camera.make_camera(W, H, sh_order=order, frame=0)
@@ -589,7 +801,15 @@ def main():
         sys.stdout.flush()
     eng.close()
     if world > 1:
+        # every rank leaves with the same code: a run that rendered wrong pixels is a failed run
+        t = torch.tensor([0 if verified is not False else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        bad = bool(t.item())
         dist.destroy_process_group()
+        if bad:
+            sys.exit(3)
+    elif verified is False:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

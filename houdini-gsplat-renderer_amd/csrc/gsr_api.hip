@@ -327,6 +327,8 @@ extern "C" int gsr_debug_blend_profile(unsigned long long* out, int reset) {   /
 #endif
 __attribute__((visibility("hidden"))) int gsr_internal_set_error(int code, const char* text) { return set_err(code, "%s", text); }
 void gsr_internal_comm_release(gsr_context* c);
+bool gsr_internal_comm_set_user_stream(gsr_context* c, void* stream, void* own);
+int gsr_internal_comm_sync(gsr_context* c);
 
 extern "C" int gsr_device_count(void)
 {
@@ -492,6 +494,8 @@ extern "C" void gsr_destroy(gsr_context* c)
 extern "C" int gsr_set_stream(gsr_context* c, void* s)
 {
     if (!c) return set_err(GSR_E_INVALID, "gsr_set_stream: ctx is NULL");
+    // a context with a communicator (gsr_comm_init, world > 1) keeps its kernels on a stream of its own; results are ordered on `s`
+    if (gsr_internal_comm_set_user_stream(c, s, c->own_stream)) return GSR_OK;
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
@@ -812,14 +816,21 @@ extern "C" int gsr_band_rows(int height, int index, int count)
     return ((tiles_y + count - 1) / count) * GSR_TILE;
 }
 
+__attribute__((visibility("hidden"))) int gsr_internal_shard_layout(gsr_context* c) { return c ? c->shard_layout : 0; }
+__attribute__((visibility("hidden"))) int gsr_internal_stitch(gsr_context* c, const float* gathered, int count, int width, int height, float* out, void* stream);
 extern "C" int gsr_stitch_bands(gsr_context* c, const float* gathered, int count, int width, int height, float* out)
+{
+    return gsr_internal_stitch(c, gathered, count, width, height, out, c ? (void*)c->stream : nullptr);
+}
+// (the stream: the multi-GPU gather stitches on its transfer stream, gsr_multi.cpp)
+__attribute__((visibility("hidden"))) int gsr_internal_stitch(gsr_context* c, const float* gathered, int count, int width, int height, float* out, void* stream)
 {
     // (the bands were rendered with this context's shard layout: GSR_OPT_SHARD_LAYOUT)
     if (!c || !gathered || !out || count < 1 || width <= 0 || height <= 0)
         return set_err(GSR_E_INVALID, "gsr_stitch_bands: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t npx = (size_t)width * height;
-    hipLaunchKernelGGL(k_stitch_bands, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(k_stitch_bands, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const float4*>(gathered), count,
                        (c->shard_layout == 1 && count > 1) ? ((height + GSR_TILE - 1) / GSR_TILE + count - 1) / count : 0,
                        gsr_band_rows(height, 0, count), width, height, reinterpret_cast<float4*>(out));
@@ -1914,7 +1925,8 @@ extern "C" int gsr_synchronize(gsr_context* c)
 {
     if (!c) return set_err(GSR_E_INVALID, "gsr_synchronize: ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    return sync_all(c);
+    int rc = sync_all(c);
+    return rc ? rc : gsr_internal_comm_sync(c);   // (... and the gather in flight, if the context has a communicator)
 }
 
 // the frame summaries live in device memory (no PCIe writes on the per-frame path); callers have synchronised

@@ -103,8 +103,8 @@ C_ABI_SYMBOLS = [
     "gsr_multi_create", "gsr_multi_destroy", "gsr_multi_count", "gsr_multi_transport", "gsr_multi_context",
     "gsr_multi_set_stream", "gsr_multi_set_option", "gsr_multi_upload_begin", "gsr_multi_upload_append",
     "gsr_multi_upload_end", "gsr_multi_upload_abort", "gsr_multi_upload", "gsr_multi_render", "gsr_multi_render_depth",
-    "gsr_multi_synchronize", "gsr_multi_get_stats",
-    "gsr_comm_available", "gsr_comm_get_unique_id", "gsr_comm_init", "gsr_comm_destroy", "gsr_comm_render",
+    "gsr_multi_synchronize", "gsr_multi_get_stats", "gsr_multi_comm_info", "gsr_multi_gather_stats",
+    "gsr_comm_available", "gsr_comm_get_unique_id", "gsr_comm_init", "gsr_comm_info", "gsr_comm_destroy", "gsr_comm_render",
     "gsplat_renderer_create_multi", "gsplat_renderer_multi",
     "gsplat_prim_create", "gsplat_prim_destroy", "gsplat_prim_update", "gsplat_prim_render", "gsplat_prim_missing",
     "gsplat_prim_sh_order", "gsplat_prim_has_sh", "gsplat_prim_array",
@@ -224,6 +224,9 @@ def load_library() -> C.CDLL:
     L.gsr_multi_render_depth.argtypes = [vp, C.POINTER(gsr_camera), vp, i32, vp, i32]
     L.gsr_multi_synchronize.argtypes = [vp]
     L.gsr_multi_get_stats.argtypes = [vp, i32, C.POINTER(gsr_stats)]
+    L.gsr_multi_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.gsr_multi_gather_stats.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.gsr_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.gsr_comm_get_unique_id.argtypes = [vp]
     L.gsr_comm_init.argtypes = [vp, vp, i32, i32]
     L.gsr_comm_destroy.argtypes = [vp]
@@ -425,6 +428,12 @@ class Engine:
 
     def comm_render(self, cam_struct: gsr_camera, out_ptr: int, depth_ptr: int = 0):
         _check(self.L.gsr_comm_render(self.h, C.byref(cam_struct), C.c_void_p(depth_ptr or None), 1, C.c_void_p(out_ptr or None)))
+
+    def comm_info(self):
+        """(rank, ranks) as RCCL itself reports them for this context's communicator"""
+        r, n = C.c_int(-1), C.c_int(0)
+        _check(self.L.gsr_comm_info(self.h, C.byref(r), C.byref(n)))
+        return r.value, n.value
 
     def comm_destroy(self):
         _check(self.L.gsr_comm_destroy(self.h))
@@ -663,6 +672,19 @@ class MultiEngine:
 
     def synchronize(self):
         _check(self.L.gsr_multi_synchronize(self.h))
+
+    def comm_info(self):
+        """([ncclCommUserRank of every rank's communicator], ncclCommCount); ([-1, ...], 0) with the COPY transport"""
+        ranks = (C.c_int * self.count)()
+        n = C.c_int(0)
+        _check(self.L.gsr_multi_comm_info(self.h, ranks, C.byref(n)))
+        return list(ranks), n.value
+
+    def gather_stats(self, enable: int = -1):
+        """(milliseconds, gathers) measured on the root's transfer stream so far; enable = 1 / 0 switches the measurement"""
+        ms, k = C.c_double(0.0), C.c_int64(0)
+        _check(self.L.gsr_multi_gather_stats(self.h, int(enable), C.byref(ms), C.byref(k)))
+        return ms.value, k.value
 
     def stats(self, rank: int = 0) -> dict:
         st = gsr_stats()

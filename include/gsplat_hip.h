@@ -177,9 +177,13 @@ int  gsr_stitch_bands(gsr_context* ctx, const float* gathered, int count,
 
 /* ---- several GPUs, one caller thread -------------------------------------- */
 /* The reference draws from Houdini's single draw thread (src/DM_GSplatHook.C:30-39); gsr_multi drives G contexts -- one
- * per GPU, tile row r -> rank r % G, splats replicated -- from that one thread: a frame is queued on every GPU before
- * the host waits for any, the band images are gathered to devices[0] by ONE collective (ncclRecv x (G-1) + ncclSend per
- * peer in one group; RCCL over xGMI) and de-interleaved there.  The result is bit-identical to the 1-GPU frame. */
+ * per GPU, splats replicated, rank g owning a contiguous band of tile rows (GSR_OPT_SHARD_LAYOUT = 1 is gsr_multi's
+ * default; 0 = interleaved rows) -- on behalf of that one thread: every rank's frame is queued by a worker thread of its
+ * own (GSR_MULTI_THREADS=0 in the environment: by the caller's thread, one rank after the other), then the caller's thread
+ * issues the frame's ONE collective: ncclRecv x (G-1) + ncclSend per peer in one group (RCCL over xGMI) on per-rank
+ * transfer streams.  With the band layout the peers' bands are received straight into rgba_out (a band is a block of rows
+ * of the final image); with interleaved rows they are de-interleaved on the root.  Bands are double-buffered, so the
+ * gather of frame f overlaps the kernels of frame f+1.  The result is bit-identical to the 1-GPU frame. */
 typedef struct gsr_multi gsr_multi;
 #define GSR_TRANSPORT_AUTO   0   /* RCCL when the devices are distinct (and librccl loads), else COPY */
 #define GSR_TRANSPORT_RCCL   1   /* single-process communicator (ncclCommInitAll) */
@@ -190,8 +194,16 @@ void gsr_multi_destroy(gsr_multi* m);
 int  gsr_multi_count(gsr_multi* m);
 int  gsr_multi_transport(gsr_multi* m);                       /* the transport in use (GSR_TRANSPORT_RCCL / _COPY) */
 gsr_context* gsr_multi_context(gsr_multi* m, int rank);      /* rank's context (stats, debug access); do not destroy */
-int  gsr_multi_set_stream(gsr_multi* m, void* hip_stream);   /* the ROOT's public stream (device devices[0]) */
+int  gsr_multi_set_stream(gsr_multi* m, void* hip_stream);   /* the stream on devices[0] that frames are ORDERED on (the
+                                                                 ranks' kernels and the gather run on streams of the library) */
 int  gsr_multi_set_option(gsr_multi* m, int option, int value);
+/* what RCCL itself reports: ranks_out[g] = ncclCommUserRank of rank g's communicator, *nranks_out = ncclCommCount of the
+ * root's (-1 / 0 with the COPY transport) */
+int  gsr_multi_comm_info(gsr_multi* m, int* ranks_out, int* nranks_out);
+/* the gather on the root's transfer stream, from the first receive to "frame complete", measured with HIP events:
+ * enable = 1 / 0 switches the measurement (and clears the sums when it changes), -1 leaves it; returns the sums so far.
+ * Synchronises. */
+int  gsr_multi_gather_stats(gsr_multi* m, int enable, double* ms_total, int64_t* gathers);
 int  gsr_multi_upload_begin(gsr_multi* m, int64_t total_splats, int has_sh, const float origin[3]);
 int  gsr_multi_upload_append(gsr_multi* m, int64_t n, const float* P, const uint16_t* Cd, const float* alpha,
                              const uint16_t* scale, const uint16_t* orient,
@@ -201,7 +213,8 @@ int  gsr_multi_upload_abort(gsr_multi* m);
 int  gsr_multi_upload(gsr_multi* m, int64_t n, const float* P, const uint16_t* Cd, const float* alpha,
                       const uint16_t* scale, const uint16_t* orient,
                       const uint16_t* shx, const uint16_t* shy, const uint16_t* shz, const float origin[3]);
-/* full frame on devices[0] (device pointer there, asynchronous on the root's public stream) or in host memory */
+/* full frame on devices[0] (device pointer there, asynchronous, ordered on the stream of gsr_multi_set_stream) or in host
+ * memory (synchronous) */
 int  gsr_multi_render(gsr_multi* m, const gsr_camera* cam, float* rgba_out, int out_is_device);
 int  gsr_multi_render_depth(gsr_multi* m, const gsr_camera* cam, const float* depth, int depth_is_device,
                             float* rgba_out, int out_is_device);
@@ -210,12 +223,16 @@ int  gsr_multi_get_stats(gsr_multi* m, int rank, gsr_stats* out);
 
 /* ---- one process per GPU (torchrun-style launches): the same gather ----------- */
 /* The launcher hands every rank the 128-byte id rank 0 obtained (any side channel); after gsr_comm_init a frame is one
- * call per rank: the rank's band is rendered, sent (ncclSend) or received and stitched (root).  Asynchronous, ordered on
- * the context's public stream; rgba_out_device is the FULL frame on the root and ignored elsewhere. */
+ * call per rank: the rank's band is rendered, sent (ncclSend) or received (root: straight into rgba_out_device with the
+ * band layout, stitched there with interleaved rows).  With world > 1 the context's kernels move to a stream of the
+ * library and the collective to a second one (the gather of frame f overlaps frame f+1); the frame is ORDERED on the
+ * context's public stream (gsr_set_stream, before or after gsr_comm_init).  rgba_out_device is the FULL frame on the root
+ * and ignored elsewhere. */
 #define GSR_COMM_ID_BYTES 128
 int  gsr_comm_available(void);                       /* 1 if librccl could be loaded in this process (no GPU work) */
 int  gsr_comm_get_unique_id(void* id);
 int  gsr_comm_init(gsr_context* ctx, const void* id, int rank, int world);   /* collective; sets the row shard (rank, world) */
+int  gsr_comm_info(gsr_context* ctx, int* rank, int* nranks);               /* ncclCommUserRank / ncclCommCount */
 int  gsr_comm_destroy(gsr_context* ctx);
 int  gsr_comm_render(gsr_context* ctx, const gsr_camera* cam, const float* depth, int depth_is_device,
                      float* rgba_out_device);

@@ -1445,3 +1445,110 @@ def test_rccl_entry_points_on_one_gpu(pkg, engine):
         assert M.transport == pkg.engine.TRANSPORT_RCCL
         M.upload(splats)
         assert np.array_equal(M.render(cam), want)
+
+
+# ---------------------------------------------------------------------------------------------
+# round 4: the headline regime (culled, orbiting) verified at the size it is quoted on, and bench.py launching itself
+@pytest.mark.parametrize("config", ["C4", "C5"])
+def test_headline_regime_is_the_full_frame_at_full_size(pkg, oracle, config):
+    """BASELINE C4 / C5 at FULL size: 12 frames of the bench's orbit plus one jump to the far side, the library's default policy
+    (cluster culling, occlusion culling against the previous frame's horizons, small-frame sort, repairs) against a context
+    that never culls anything: every frame bit for bit, most of them really culled -- and one culled frame against the oracle."""
+    splats, cfg = pkg.scenes.make_config(config)
+    w, h = cfg["width"], cfg["height"]
+    frames = list(range(12)) + [60]                       # 3 degrees per frame; frame 60 = the other side of the cloud
+    cams = [pkg.scenes.config_camera(config, pkg.camera, w, h, 3, i) for i in frames]
+    plain, dflt = pkg.Engine(0), pkg.Engine(0)
+    try:
+        plain.set_option(pkg.engine.OPT_OCCLUSION_CULL, 0)
+        plain.set_option(pkg.engine.OPT_CLUSTER_CULL, 0)
+        plain.upload(splats)
+        dflt.upload(splats)
+        checked = None
+        for k, c in enumerate(cams):
+            got = dflt.render(c)
+            want = plain.render(c)
+            assert np.array_equal(got, want), f"{config}: frame {frames[k]} differs from the frame rendered without culling"
+            if k == 8:
+                checked = (c, got.copy())
+        st = dflt.stats()
+        assert st["frames_culled"] >= 10, st                # (the first frames of a cloud are unculled: the policy needs their verdict)
+        assert plain.stats()["frames_culled"] == 0
+        # the jump: a culled attempt that broke horizons is repaired (or the policy saw it coming); pixels were compared above
+        assert st["frames_repaired"] <= 2, st
+        c, img = checked
+        _check_image(img, oracle.render(splats, c, threads=oracle.max_threads()))
+    finally:
+        plain.close(); dflt.close()
+
+
+def _run_bench(args, env_extra, timeout=900):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(env_extra)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_launches_itself_on_several_gpus(pkg):
+    """`python bench.py --gpus N` with no launcher drives gsr_multi_* from one process.  On this box the ranks share the GPU over
+    the COPY transport (a functional run, flagged as such); the line is the driver's contract and the stitched frame is the
+    unsharded frame bit for bit.  Without enough GPUs (and without the override) the line carries an error and the exit code says so."""
+    ndev = int(pkg.load_library().gsr_device_count())
+    res, line = _run_bench(["--gpus", "2", "--config", "C3", "--steps", "12", "--warmup", "4", "--no-cpu-baseline"],
+                           {"GSR_BENCH_ALLOW_DUP": "1"})
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert line is not None and line["n_gpus"] == 2 and line["sharded_frame_bit_identical"] is True and line["value"] > 0
+    assert line["config"]["functional_only"] == (ndev < 2) and len(line["per_rank_stages_ms"]) == 2
+    assert line["gather_ms"] is not None and line["gather_ms"] > 0 and len(line["rccl_ranks"]) == 2
+    if ndev >= 2:
+        assert line["rccl_ranks"] == [0, 1] and line["rccl_comm_count"] == 2
+    # interleaved rows through the same door
+    res, line = _run_bench(["--gpus", "3", "--config", "C2", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--shard-layout", "0", "--no-extra-legs"],
+                           {"GSR_BENCH_ALLOW_DUP": "1"})
+    assert res.returncode == 0 and line["sharded_frame_bit_identical"] is True, res.stderr[-2000:]
+    if ndev < 64:
+        res, line = _run_bench(["--gpus", "64", "--steps", "2", "--warmup", "1"], {"GSR_BENCH_ALLOW_DUP": "0"})
+        assert res.returncode != 0 and line is not None and "error" in line and line["value"] is None
+
+
+def test_bench_single_gpu_line_says_whether_the_timed_frame_is_the_full_frame(pkg):
+    res, line = _run_bench(["--config", "C3", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs"], {})
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert line["timed_frame_bit_identical"] is True and line["occlusion_culling"]["frames_culled"] > 0
+    assert line["roofline"]["peak_measured"] is None or line["roofline"]["peak_measured"] > 3000
+
+
+def test_multi_gpu_gather_overlaps_the_next_frame_and_keeps_every_frame(pkg, engine):
+    """gsr_multi with double-buffered bands: many device-target frames back to back into FEWER target buffers than frames (a
+    target is reused while older gathers are still in flight), both layouts, resolution change in between -- every frame that is
+    read back is the single-GPU frame"""
+    splats = pkg.scenes.make_scene(200000, seed=313, sh=True)
+    engine.upload(splats)
+    hb = HipBuffers()
+    try:
+        with pkg.MultiEngine([0] * 3, pkg.engine.TRANSPORT_COPY) as M:
+            M.upload(splats)
+            for layout in (1, 0):
+                M.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
+                for (w, h) in ((640, 360), (500, 333)):
+                    cams = [pkg.camera.make_camera(w, h, sh_order=3, frame=i) for i in range(9)]
+                    want = [engine.render(c) for c in cams]
+                    outs = [hb.alloc(w * h * 16) for _ in range(3)]
+                    for k, c in enumerate(cams):
+                        M.render_struct_to_device(pkg.engine.camera_struct(c), outs[k % 3], 0)
+                        if k % 3 == 2:                                  # read the last three frames back
+                            M.synchronize()
+                            for j in range(3):
+                                assert np.array_equal(hb.download(outs[j], (h, w, 4)), want[k - 2 + j]), (layout, w, k - 2 + j)
+            ms, n = M.gather_stats(1)
+            M.render(pkg.camera.make_camera(500, 333, sh_order=3, frame=3))
+            ms, n = M.gather_stats(0)
+            assert n == 1 and ms > 0
+            assert M.comm_info() == ([-1, -1, -1], 0)
+    finally:
+        hb.free()

@@ -49,6 +49,33 @@ def perspective(p00: float, aspect_w_over_h: float, near: float, far: float) -> 
     return p
 
 
+def frustum(left: float, right: float, bottom: float, top: float, near: float, far: float) -> np.ndarray:
+    """glFrustum: an OFF-CENTRE perspective projection when left != -right or bottom != -top (a cropped / zoomed / tiled
+    viewport): P02 = (r+l)/(r-l), P12 = (t+b)/(t-b)"""
+    p = np.zeros((4, 4), dtype=np.float64)
+    p[0, 0] = 2.0 * near / (right - left)
+    p[1, 1] = 2.0 * near / (top - bottom)
+    p[0, 2] = (right + left) / (right - left)
+    p[1, 2] = (top + bottom) / (top - bottom)
+    p[2, 2] = -(far + near) / (far - near)
+    p[2, 3] = -2.0 * far * near / (far - near)
+    p[3, 2] = -1.0
+    return p
+
+
+def orthographic(left: float, right: float, bottom: float, top: float, near: float, far: float) -> np.ndarray:
+    """glOrtho (Houdini's Top / Front / Right views): clip w == 1 everywhere"""
+    p = np.zeros((4, 4), dtype=np.float64)
+    p[0, 0] = 2.0 / (right - left)
+    p[1, 1] = 2.0 / (top - bottom)
+    p[2, 2] = -2.0 / (far - near)
+    p[0, 3] = -(right + left) / (right - left)
+    p[1, 3] = -(top + bottom) / (top - bottom)
+    p[2, 3] = -(far + near) / (far - near)
+    p[3, 3] = 1.0
+    return p
+
+
 def look_from(rot_rows: np.ndarray, position: np.ndarray) -> np.ndarray:
     """world->camera matrix for a camera whose axes (x right, y up, z backwards) are the rows
     of ``rot_rows`` and which sits at ``position``."""
@@ -61,7 +88,8 @@ def look_from(rot_rows: np.ndarray, position: np.ndarray) -> np.ndarray:
 def make_camera(width: int, height: int, sh_order: int = 3, frame: int = 0, distance: float = _HIP_DIST,
                 p00: float = _HIP_P00, near: float = 0.01, far: float = 1.0e5,
                 object_matrix: np.ndarray | None = None, rot_rows: np.ndarray | None = None,
-                pivot=(0.0, 0.0, 0.0), step_deg: float = 3.0) -> Camera:
+                pivot=(0.0, 0.0, 0.0), step_deg: float = 3.0, proj_matrix: np.ndarray | None = None) -> Camera:
+    """proj_matrix: a 4x4 projection (column-vector maths) instead of the symmetric perspective(p00, aspect, near, far)"""
     rot = _HIP_ROT if rot_rows is None else np.asarray(rot_rows, dtype=np.float64)
     ang = np.deg2rad(step_deg * frame)
     ry = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
@@ -69,7 +97,7 @@ def make_camera(width: int, height: int, sh_order: int = 3, frame: int = 0, dist
     pos = np.asarray(pivot, dtype=np.float64) + distance * rot[2]
     view = look_from(rot, pos)
     obj = np.eye(4) if object_matrix is None else np.asarray(object_matrix, dtype=np.float64)
-    proj = perspective(p00, width / height, near, far)
+    proj = perspective(p00, width / height, near, far) if proj_matrix is None else np.asarray(proj_matrix, dtype=np.float64)
     obj_view = view @ obj
     cam_pos = np.linalg.inv(view)[:3, 3]   # translation of V^-1 (src/GSplatRenderer.C:558-562)
     return Camera(obj_view=_gl(obj_view), object=_gl(obj), inv_object=_gl(np.linalg.inv(obj)), view=_gl(view),

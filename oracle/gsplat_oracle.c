@@ -906,6 +906,90 @@ int gso_render_wire(const gso_splats* s, const gso_frame* f, float* rgba)
     return 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Where may a rasteriser legitimately disagree with the analytic quad?  A fragment's fate is decided by thresholds: the
+ * quad's edges (GL decides coverage of a pixel centre that sits ON an edge by its fixed-point rules, after snapping the
+ * vertices to its sub-pixel grid), the 1/255 discard, and -- depth-tested frames -- zwin <= depth.  mask[p] = 1 iff for
+ * SOME visible splat pixel p lies within delta_px of one of the quad's four edges (and within delta_px of the quad along
+ * the other axis), or inside the quad with log2(alpha * 255) within eps_log2 (+ what a shift of the quad by delta_px does to
+ * it) of 0, or inside with |zwin - depth| <= eps_depth.  Every pixel of a reference-GLSL image that differs from the oracle's by more than the 1e-3 budget must lie
+ * in this mask (tests/helpers.py): an error anywhere else is an arithmetic difference, not a coverage rule.            */
+int gso_edge_mask(const gso_record* rec, int64_t n, int width, int height, float delta_px, float eps_log2,
+                  const float* depth, float eps_depth, uint8_t* mask)
+{
+    if (!rec || !mask || width <= 0 || height <= 0) return -1;
+    memset(mask, 0, (size_t)width * (size_t)height);
+    for (int64_t r = 0; r < n; ++r) {
+        const gso_record* o = &rec[r];
+        if (!o->visible) continue;
+        const float pad = delta_px + 1.0f;
+        const float xlo = o->cx - o->hx - 0.5f - pad, xhi = o->cx + o->hx - 0.5f + pad;
+        const float ylo = o->cy - o->hy - 0.5f - pad, yhi = o->cy + o->hy - 0.5f + pad;
+        if (!(xhi >= 0.0f && xlo <= (float)(width - 1) && yhi >= 0.0f && ylo <= (float)(height - 1))) continue;
+        const int i0 = (int)ceilf(fmaxf(xlo, 0.0f)), i1 = (int)floorf(fminf(xhi, (float)(width - 1)));
+        const int j0 = (int)ceilf(fmaxf(ylo, 0.0f)), j1 = (int)floorf(fminf(yhi, (float)(height - 1)));
+        /* |grad kq0| = |a1| = kappa / s1 per pixel: a distance of delta_px to the edge |kq0| = QLIM is |a1| delta_px in kq0 */
+        const double na = sqrt((double)o->a1x * o->a1x + (double)o->a1y * o->a1y), nb = sqrt((double)o->b1x * o->b1x + (double)o->b1y * o->b1y);
+        const double ta = na * delta_px, tb = nb * delta_px;
+        for (int j = j0; j <= j1; ++j)
+            for (int i = i0; i <= i1; ++i) {
+                const double dx = ((double)i + 0.5) - o->cx, dy = ((double)j + 0.5) - o->cy;
+                const double q0 = fabs(dx * o->a1x + dy * o->a1y), q1 = fabs(dx * o->b1x + dy * o->b1y);
+                const double e0 = q0 - (double)GSO_QLIM, e1 = q1 - (double)GSO_QLIM;
+                int hit = (fabs(e0) <= ta && e1 <= tb) || (fabs(e1) <= tb && e0 <= ta);
+                if (!hit && e0 <= 0.0 && e1 <= 0.0) {
+                    /* the 1/255 discard: a shift of the quad by delta_px moves |kq|^2 by up to 2 (|kq0| |a1| + |kq1| |b1|) delta_px */
+                    const double arg = (double)o->la - (q0 * q0 + q1 * q1);
+                    if (fabs(arg + (double)GSO_LOG2_255) <= eps_log2 + 2.0 * (q0 * ta + q1 * tb)) hit = 1;
+                    if (depth && fabs((double)o->zwin - (double)depth[(size_t)j * (size_t)width + (size_t)i]) <= eps_depth) hit = 1;
+                }
+                if (hit) mask[(size_t)j * (size_t)width + (size_t)i] = 1;
+            }
+    }
+    return 0;
+}
+
+/* How strongly does a pixel react to a sub-pixel shift of the quads that cover it?  A GL rasteriser snaps every vertex to its
+ * sub-pixel grid before it interpolates the quad-local coordinate, so each quad of a reference image sits up to a grid step
+ * away from where the shader put it: alpha = 2^(la - |kq|^2) of a fragment then moves by a factor 2^(-d|kq|^2),
+ * d|kq|^2 <= 2 (|kq0| |a1| + |kq1| |b1|) * shift.  sens[p] = sum over the fragments of pixel p, in depth order, of
+ * T * alpha * (|kq0| |a1| + |kq1| |b1|)   [1 / pixel]:
+ * a shift of every quad by `shift` pixels changes a channel of p by at most ~ 2 ln2 * shift * sens[p] * (colour range).
+ * Small splats (an axis of half a pixel) make this exceed the 1e-3 budget far from any quad edge (tests/helpers.py).        */
+int gso_snap_sensitivity(const gso_record* rec, const int32_t* perm, int64_t n, int width, int height, float* sens)
+{
+    if (!rec || !perm || !sens || width <= 0 || height <= 0) return -1;
+    const size_t npx = (size_t)width * (size_t)height;
+    float* T = (float*)malloc(npx * sizeof(float) + 4);
+    if (!T) return -2;
+    for (size_t p = 0; p < npx; ++p) { T[p] = 1.0f; sens[p] = 0.0f; }
+    for (int64_t r = 0; r < n; ++r) {
+        const gso_record* o = &rec[perm[r]];
+        if (!o->visible) continue;
+        const float xlo = o->cx - o->hx - 0.5f, xhi = o->cx + o->hx - 0.5f;
+        const float ylo = o->cy - o->hy - 0.5f, yhi = o->cy + o->hy - 0.5f;
+        if (!(xhi >= 0.0f && xlo <= (float)(width - 1) && yhi >= 0.0f && ylo <= (float)(height - 1))) continue;
+        const int i0 = (int)ceilf(fmaxf(xlo, 0.0f)), i1 = (int)floorf(fminf(xhi, (float)(width - 1)));
+        const int j0 = (int)ceilf(fmaxf(ylo, 0.0f)), j1 = (int)floorf(fminf(yhi, (float)(height - 1)));
+        const float na = sqrtf(o->a1x * o->a1x + o->a1y * o->a1y), nb = sqrtf(o->b1x * o->b1x + o->b1y * o->b1y);
+        for (int j = j0; j <= j1; ++j)
+            for (int i = i0; i <= i1; ++i) {
+                const float dx = ((float)i + 0.5f) - o->cx, dy = ((float)j + 0.5f) - o->cy;
+                const float q0 = dx * o->a1x + dy * o->a1y, q1 = dx * o->b1x + dy * o->b1y;
+                if (!(fmaxf(fabsf(q0), fabsf(q1)) <= GSO_QLIM)) continue;
+                const float arg = o->la - (q0 * q0 + q1 * q1);
+                if (!(arg >= -GSO_LOG2_255)) continue;
+                const float alpha = arg >= 0.0f ? 1.0f : exp2f(arg);
+                const size_t p = (size_t)j * (size_t)width + (size_t)i;
+                const float w = T[p] * alpha;
+                sens[p] += w * (fabsf(q0) * na + fabsf(q1) * nb);
+                T[p] -= w;
+            }
+    }
+    free(T);
+    return 0;
+}
+
 int gso_max_threads(void)
 {
 #ifdef _OPENMP

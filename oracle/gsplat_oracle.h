@@ -157,6 +157,11 @@ int gso_host_sort_only(const float* P, int64_t n, const float cam_pos[3], int32_
 int gso_host_sort_from(const float* P, int64_t n, const float cam_pos[3], const int32_t* order0, int32_t* perm);
 
 /* number of OpenMP threads the parallel entry points would use */
+/* pixels where a rasteriser's coverage / discard / depth rule may decide differently from the analytic quad (see the .c file) */
+int gso_edge_mask(const gso_record* rec, int64_t n, int width, int height, float delta_px, float eps_log2,
+                  const float* depth, float eps_depth, uint8_t* mask);
+/* per-pixel sensitivity of the frame to a sub-pixel shift of its quads (see the .c file) */
+int gso_snap_sensitivity(const gso_record* rec, const int32_t* perm, int64_t n, int width, int height, float* sens);
 int gso_max_threads(void);
 
 #ifdef __cplusplus

@@ -99,6 +99,8 @@ def lib() -> C.CDLL:
         L.gso_render_wire.argtypes = [C.POINTER(gso_splats), C.POINTER(gso_frame), C.c_void_p]
         L.gso_host_sort_only.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p]
         L.gso_max_threads.restype = C.c_int
+        L.gso_snap_sensitivity.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        L.gso_edge_mask.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p]
         L.gso_storage_order.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.gso_set_tie_order.argtypes = [C.c_int]
         L.gso_set_tie_order.restype = None
@@ -224,6 +226,30 @@ def render_wire(splats, cam) -> np.ndarray:
     f = make_frame(cam, (0, 0, 0))
     out = np.zeros((f.height, f.width, 4), dtype=np.float32)
     rc = lib().gso_render_wire(C.byref(pk.struct), C.byref(f), out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def edge_mask(splats, cam, origin=(0, 0, 0), delta_px: float = 0.02, eps_log2: float = 1e-3, depth=None, eps_depth: float = 1e-6) -> np.ndarray:
+    """bool [H, W]: pixels where a rasteriser's coverage rule (a pixel centre within delta_px of a quad edge), the 1/255 discard
+    (alpha within 2^+-eps_log2 of it) or the depth test (|zwin - depth| <= eps_depth) may legitimately decide differently from
+    the oracle for SOME visible splat -- the only places a reference-GLSL image may differ by more than the 1e-3 budget"""
+    rec = np.ascontiguousarray(preprocess(splats, cam, origin))
+    mask = np.zeros((int(cam.height), int(cam.width)), dtype=np.uint8)
+    d = None if depth is None else np.ascontiguousarray(depth, dtype=np.float32).reshape(mask.shape)
+    rc = lib().gso_edge_mask(rec.ctypes.data, rec.shape[0], int(cam.width), int(cam.height), float(delta_px), float(eps_log2),
+                             None if d is None else d.ctypes.data, float(eps_depth), mask.ctypes.data)
+    assert rc == 0
+    return mask.astype(bool)
+
+
+def snap_sensitivity(splats, cam, origin=(0, 0, 0)) -> np.ndarray:
+    """float32 [H, W], 1 / pixel: sum over a pixel's fragments of T * alpha * (|kq0| |a1| + |kq1| |b1|) -- how strongly the pixel
+    reacts to a sub-pixel shift of the quads covering it (a GL rasteriser snaps vertices to its sub-pixel grid)"""
+    rec = np.ascontiguousarray(preprocess(splats, cam, origin))
+    perm = np.ascontiguousarray(argsort(rec, storage_order(splats.P)), dtype=np.int32)
+    out = np.zeros((int(cam.height), int(cam.width)), dtype=np.float32)
+    rc = lib().gso_snap_sensitivity(rec.ctypes.data, perm.ctypes.data, rec.shape[0], int(cam.width), int(cam.height), out.ctypes.data)
     assert rc == 0
     return out
 

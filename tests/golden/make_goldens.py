@@ -541,6 +541,26 @@ def cases(pkg):
     # C1: BASELINE config 0 -- 10k isotropic splats, SH degree 0, 512x512
     s, cfg = sc.make_config("C1")
     out.append(("c1_10k_iso", s, cm.make_camera(cfg["width"], cfg["height"], sh_order=0, frame=0), (0, 0, 0), 5))
+    # ---- projections a Houdini viewport really produces (round 4).  The reference's covariance code assumes a
+    # symmetric perspective frustum (shaders/GSplatShaderCoreLib.h:44-58: focal and both clamp limits from P00 alone, a division by
+    # view z whatever the projection) and sandwiches the projection between two y flips (GSplatShaderSource.h:203-207, :281).  What
+    # that does under other projections is what the contract has to do too:
+    # G9: ORTHOGRAPHIC (Top / Front / Right views): clip w == 1, yet J still divides by view z
+    s = sc.make_scene(1500, seed=19, sh=True, log_scale_range=(-2.6, -1.3))
+    hw = 1.35
+    out.append(("g9_ortho", s, cm.make_camera(192, 144, sh_order=3, frame=3,
+                                             proj_matrix=cm.orthographic(-hw, hw, -hw * 144 / 192, hw * 144 / 192, 0.05, 60.0)), (0, 0, 0), 9))
+    # G10: OFF-CENTRE frustum (a cropped / zoomed viewport: P02, P12 != 0).  The flip-Y sandwich is the identity only for P12 == 0:
+    # here the vertical offset term comes out with its sign flipped (Q4), and J ignores both offsets
+    near = 0.05
+    a = near / 2.41421
+    c = a * 150.0 / 200.0
+    out.append(("g10_offcentre", sc.make_scene(1500, seed=20, sh=True, log_scale_range=(-4.2, -2.8)),
+                cm.make_camera(200, 150, sh_order=3, frame=7, proj_matrix=cm.frustum(-0.6 * a, 1.4 * a, -1.3 * c, 0.7 * c, near, 1.0e4)), (0, 0, 0), 9))
+    # G11: a wide lens in PORTRAIT format: limY = 1.3 / P00 is the HORIZONTAL limit (Q3), far inside the vertical field here, so
+    # splats near the top and bottom edges have their view position clamped
+    out.append(("g11_fov_aspect", sc.make_scene(1500, seed=21, sh=True, log_scale_range=(-4.0, -2.7), radius=1.6),
+                cm.make_camera(120, 200, sh_order=2, frame=11, p00=1.1, distance=2.6), (0, 0, 0), 9))
     return out
 
 

@@ -39,18 +39,39 @@ def load_golden(name):
     return d, s, c
 
 
-# Acceptance of an image against the reference-GLSL golden (SwiftShader, supersampled so that its
-# vertex snapping matches 8-bit sub-pixel hardware).  A rasteriser decides coverage of pixels that
-# sit exactly on a quad edge by its own fixed-point rules, so a small set of edge pixels differs by
-# up to opacity*exp(-4) ~ 0.018 no matter what; everything else must be inside
-# the north-star tolerance of 1e-3 per channel.
+# Acceptance of an image against the reference-GLSL golden (SwiftShader, rasterised at `supersample` times the nominal resolution
+# so that its vertex snapping -- 1/16 of ITS pixel -- shrinks to `grid` = 1/(16 * supersample) of a nominal pixel: ~8-bit sub-pixel
+# hardware).  Where may such an image differ from the analytic frame by more than the north-star tolerance of 1e-3 per channel?
+# Round 4 answers that per pixel instead of with a blanket "0.2 % of the pixels":
+#   * inside the oracle's EDGE MASK (gso_edge_mask): the pixel centre lies within 1.5 grid steps of an edge of some visible quad --
+#     there the rasteriser's fixed-point coverage rule decides -- or a covering fragment sits at the 1/255 discard threshold to
+#     within what a grid step of quad shift does to its alpha, or (depth-tested frames) at the depth test's threshold.  A flipped
+#     fragment moves a channel by at most opacity * exp(-4) * T (edge) or 1/255 (discard): bounded by GOLDEN_MAX_OUTLIER;
+#   * everywhere else the fragments are the same on both sides, and the only difference is that GL interpolates the quad-local
+#     coordinate from SNAPPED vertices: |err| <= 1e-3 + GOLDEN_SNAP_GAIN * grid * sens[p], sens = gso_snap_sensitivity (sum of
+#     T * alpha * |d|kq|^2 / d shift| over the pixel's fragments; half-pixel-wide splats make that term exceed 1e-3 by itself).
+# Measured on the twelve fixtures: no pixel outside the mask needs a gain above 0.22 (the bound is ~2 ln2 * shift / grid ~ 1);
+# the mask covers 1-13 % of a frame.  The old global figures stay as sanity bounds.
 GOLDEN_TOL = 1e-3
-GOLDEN_MIN_FRAC = 0.998      # >= 99.8 % of pixels within 1e-3 on every channel
+GOLDEN_MIN_FRAC = 0.997      # >= 99.7 % of pixels within 1e-3 on every channel (sanity; the per-pixel rule below is the test)
 GOLDEN_MAX_OUTLIER = 0.02    # edge-flip bound: exp(-4) * opacity * T
 GOLDEN_MEAN = 1e-4
+GOLDEN_EDGE_STEPS = 1.5      # half-width of the edge band, in sub-pixel grid steps
+GOLDEN_SNAP_GAIN = 1.0       # channel change per (grid step x sensitivity) outside the mask
 
 
-def check_against_golden(img, golden_img, max_bias=2e-5):
+def golden_uncertainty(oracle, d, s, c):
+    """(edge mask bool [H, W], allowed |err| outside the mask float [H, W]) for a fixture: see the rule above"""
+    grid = 1.0 / (16.0 * int(d["supersample"]))
+    depth = d["depth"] if "depth" in d.files else None
+    mask = oracle.edge_mask(s, c, d["origin"], delta_px=GOLDEN_EDGE_STEPS * grid, eps_log2=1e-5, depth=depth, eps_depth=1e-6)
+    sens = oracle.snap_sensitivity(s, c, d["origin"]).astype(np.float64)
+    return mask, GOLDEN_TOL + GOLDEN_SNAP_GAIN * grid * sens
+
+
+def check_against_golden(img, golden_img, max_bias=2e-5, uncertainty=None, extra_tol=0.0):
+    """uncertainty = golden_uncertainty(...): the per-pixel rule; extra_tol: what the image under test may add by construction
+    (the blend kernel's per-pixel early-out: 2^-14)"""
     err = np.abs(img.astype(np.float64) - golden_img.astype(np.float64))
     frac = float((err.max(axis=2) <= GOLDEN_TOL).mean())
     assert frac >= GOLDEN_MIN_FRAC, f"only {frac:.5f} of pixels within {GOLDEN_TOL}"
@@ -58,6 +79,13 @@ def check_against_golden(img, golden_img, max_bias=2e-5):
     assert err.mean() <= GOLDEN_MEAN, f"mean abs error {err.mean()}"
     signed = float((img.astype(np.float64) - golden_img).mean())
     assert abs(signed) <= max_bias, f"biased by {signed}"
+    if uncertainty is not None:
+        mask, allowed = uncertainty
+        e = err.max(axis=2)
+        bad = (~mask) & (e > allowed + extra_tol)
+        assert not bad.any(), (f"{int(bad.sum())} pixels differ by more than the 1e-3 budget away from every quad edge and discard threshold: "
+                               f"first at (x, y) = {np.argwhere(bad)[0][::-1].tolist()}, |err| = {e[bad].max():.5f}")
+        assert mask.mean() <= 0.25, f"the edge mask covers {mask.mean():.3f} of the frame: not a sharp rule any more"
     return frac, float(err.max()), float(err.mean())
 
 

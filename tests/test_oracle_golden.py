@@ -11,21 +11,24 @@ import hashlib
 import numpy as np
 import pytest
 
-from helpers import (GOLDEN_DIR, check_against_golden, check_wire_against_golden, golden_names, load_golden,
+from helpers import (GOLDEN_DIR, check_against_golden, check_wire_against_golden, golden_names, golden_uncertainty, load_golden,
                      oracle_render_golden)
 
 NAMES = golden_names()
 
 
 def test_goldens_are_present():
-    assert len(NAMES) >= 8 and "g8_depth_tested" in NAMES
+    assert len(NAMES) >= 11 and "g8_depth_tested" in NAMES
+    # the projections a Houdini viewport really produces (orthographic, off-centre, wide portrait lens) are pinned too
+    assert {"g9_ortho", "g10_offcentre", "g11_fov_aspect"} <= set(NAMES)
 
 
 @pytest.mark.parametrize("name", NAMES)
 def test_oracle_image_matches_reference_glsl(oracle, name):
     d, s, c = load_golden(name)
     img = oracle_render_golden(oracle, d, s, c)          # (g8 carries an opaque pass's depth buffer: SURVEY N4)
-    check_against_golden(img, d["image_reference_glsl"])
+    # every pixel beyond the 1e-3 budget sits on a quad edge / at a discard threshold (helpers.py: the per-pixel rule)
+    check_against_golden(img, d["image_reference_glsl"], uncertainty=golden_uncertainty(oracle, d, s, c))
     # regression pin of the oracle itself (deterministic IEEE arithmetic)
     assert hashlib.sha256(img.tobytes()).digest() == d["oracle_sha256"].tobytes()
     if "depth" in d.files:

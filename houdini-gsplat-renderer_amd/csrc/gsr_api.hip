@@ -162,6 +162,8 @@ struct FrameSlot {
     uint32_t kept_hint = 0;            // splats that reached the depth sort in this slot's last frame (picks the sort; 0 = unknown)
     uint32_t kept_lo = 0, kept_hi = 0; // ... and the smallest / largest of their keys, as float bits of the distance^2 (0, 0 = unknown)
     bool kept_culled = false;          // ... in a frame that was occlusion-culled (an unculled one keeps ten times as much: no prediction across)
+    int local_fails = 0;               // small-frame sorts in a row that gave a bucket up (a run of > 64 equal keys does so EVERY frame) ...
+    int local_holdoff = 0;             // ... after three of them: frames this slot stays with the three global passes
     unsigned long long* h_end = nullptr;      // pinned + mapped: ticket << 32 | violation
     unsigned long long* h_end_dev = nullptr;
     bool horizon_valid = false;
@@ -648,6 +650,20 @@ extern "C" int gsr_upload_append(gsr_context* c, int64_t n64, const float* P, co
 
 static int order_and_cluster(gsr_context* c);
 
+// an upload that failed after the arrays were filled: the context goes back to "nothing uploaded"
+static void drop_geometry(gsr_context* c)
+{
+    c->n = 0; c->nclus = 0; c->up_total = c->up_filled = 0; c->st.n_splats = 0;
+    dev_free(c->perm); dev_free(c->clusA); dev_free(c->clusB); c->h_perm.clear();
+    c->geo_gen = 0;                    // gsr_render: GSR_E_NO_GEOMETRY
+    c->pos_valid = false; c->prefix_valid = false;
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k) {
+        FrameSlot& sl = c->slot[k];
+        sl.sort_valid = false; sl.horizon_valid = false; sl.order_valid = false;
+        sl.surv_hint = 0; sl.kept_hint = 0; sl.kept_lo = sl.kept_hi = 0;
+    }
+}
+
 extern "C" int gsr_upload_append_raw(gsr_context* c, int64_t n64, const gsr_raw_attrs* a)
 {
     if (!c || !c->uploading) return set_err(GSR_E_INVALID, "gsr_upload_append_raw: no upload in progress");
@@ -761,14 +777,19 @@ extern "C" int gsr_upload_end(gsr_context* c)
             }
         c->bbox_ok = ok;
         rc = order_and_cluster(c);
-        if (rc) return rc;
+        if (rc) {
+            // nothing half-made may stay renderable: no geometry, no cached order, no horizons, no hints (a later gsr_render says
+            // GSR_E_NO_GEOMETRY until a complete upload has succeeded)
+            drop_geometry(c);
+            return rc;
+        }
     }
     c->geo_gen++;
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
     c->prefix_valid = false;           // lazy colour: the first frame of a new cloud colours every list completely
     c->order_pays = false;
     c->cull_pays = false; c->cull_holdoff = 0; c->cull_backoff = 8; c->cull_streak = 0; c->vis_unculled = 0; c->cull_dilate = c->opt_dilate;
-    for (int k = 0; k < GSR_MAX_SLOTS; ++k) { c->slot[k].surv_hint = 0; c->slot[k].kept_hint = 0; c->slot[k].kept_lo = c->slot[k].kept_hi = 0; c->slot[k].horizon_valid = false; }
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k) { c->slot[k].surv_hint = 0; c->slot[k].kept_hint = 0; c->slot[k].kept_lo = c->slot[k].kept_hi = 0; c->slot[k].horizon_valid = false; c->slot[k].local_fails = 0; c->slot[k].local_holdoff = 0; }
     c->lazy_pays = false;              // ... and in automatic mode the first frames are eager until the kernels say it pays
     c->st.n_splats = c->n;
     return GSR_OK;
@@ -925,13 +946,18 @@ static int order_and_cluster(gsr_context* c)
         uint32_t *kA = nullptr, *kB = nullptr, *vA = nullptr, *vB = nullptr;
         float4* nA = nullptr; uint4 *nB = nullptr, *ncol = nullptr, *nrow = nullptr;
         auto drop = [&]() { dev_free(kA); dev_free(kB); dev_free(vB); dev_free(nA); dev_free(nB); dev_free(ncol); dev_free(nrow); };
-        if ((rc = dev_alloc(&kA, n)) || (rc = dev_alloc(&kB, n)) || (rc = dev_alloc(&vA, n)) || (rc = dev_alloc(&vB, n)) ||
-            (rc = dev_alloc(&nA, c->cap)) || (rc = dev_alloc(&nB, c->cap)) || (rc = dev_alloc(&ncol, (size_t)c->cap * c->col_chunks)) ||
-            (c->has_sh && (rc = dev_alloc(&nrow, (size_t)c->cap * 8)))) {
+        const bool have_tmp = !((rc = dev_alloc(&kA, n)) || (rc = dev_alloc(&kB, n)) || (rc = dev_alloc(&vA, n)) || (rc = dev_alloc(&vB, n)) ||
+                                (rc = dev_alloc(&nA, c->cap)) || (rc = dev_alloc(&nB, c->cap)) || (rc = dev_alloc(&ncol, (size_t)c->cap * c->col_chunks)) ||
+                                (c->has_sh && (rc = dev_alloc(&nrow, (size_t)c->cap * 8))));
+        if (!have_tmp) {
+            // the reorder needs a second copy of the geometry for a moment; without it the splats simply stay in upload order
+            // (perm = NULL: ties then break by upload index, the documented meaning of an unordered store) and get their clusters
             drop(); dev_free(vA);
-            return rc;
+            (void)hipGetLastError();
+            rc = GSR_OK;
         }
         float lo[3], sc[3];
+        if (have_tmp) {
         for (int k = 0; k < 3; ++k) {
             lo[k] = (float)c->bb_lo[k];
             const double ext = c->bb_hi[k] - c->bb_lo[k];
@@ -953,6 +979,7 @@ static int order_and_cluster(gsr_context* c)
         if (c->has_sh) std::swap(c->colrow, nrow);
         c->perm = vA;
         drop();   // (now the upload-ordered arrays and the sort scratch)
+        }
     }
     c->nclus = div_up(n, GSR_CLUSTER);
     if ((rc = dev_alloc(&c->clusA, c->nclus)) || (rc = dev_alloc(&c->clusB, c->nclus))) return rc;
@@ -1380,6 +1407,20 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
         const int wrc = wait_mailbox(sl, box, j.ticket, "pair count", &v);
         if (wrc) return frame_abort(sl, wrc);
         D = (uint32_t)v;
+        j.sort_failed = j.local_sort && (box[1] & 32ull) != 0ull;
+        if (j.sort_failed) {
+            // the small-frame sort gave a bucket up: this frame's order, lists and pair count mean nothing.  frame_check renders it
+            // again (three global passes); nothing of it is kept -- not the order (sort cache), not its bookkeeping (no frame end),
+            // not its say in the policies below -- and the work sums its speculative back end added over garbage lists are cleared
+            sl.sort_valid = false;
+            sl.kept_hint = 0; sl.kept_lo = sl.kept_hi = 0;
+            sl.last_pairs = 0;
+            if (sl.sup_work) (void)hipMemsetAsync(sl.sup_work + 256 * sl.sup_par, 0, 256 * sizeof(uint32_t), sl.stream);
+            sl.local_fails += 1;       // (back-off: gsr_api.hip frame_begin)
+            j.open = false;
+            return GSR_OK;
+        }
+        if (j.local_sort) sl.local_fails = 0;
         c->lazy_pays = (box[1] & 1ull) != 0ull;
         c->cull_pays = (box[1] & 4ull) != 0ull;
         c->prefix_cheaper = (box[1] & 8ull) != 0ull;
@@ -1395,16 +1436,6 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
         sl.surv_hint = (uint32_t)box[2];           // clusters that survived k_cluster_cull: sizes the next frame's K1 grid
         sl.kept_hint = (uint32_t)(box[1] >> 32);   // ... and how many splats reached the depth sort: picks the next frame's sort
         sl.kept_culled = j.cull;
-        j.sort_failed = j.local_sort && (box[1] & 32ull) != 0ull;
-        if (j.sort_failed) {
-            // the small-frame sort gave a bucket up: this frame's order, lists and pair count mean nothing.  frame_check renders it
-            // again (three global passes); nothing of it is kept -- not the order (sort cache), not its bookkeeping (no frame end)
-            sl.sort_valid = false;
-            sl.kept_hint = 0; sl.kept_lo = sl.kept_hi = 0;
-            sl.last_pairs = 0;
-            j.open = false;
-            return GSR_OK;
-        }
         if (sl.kept_hint > 0) {                    // ... between which keys (stored relative to THIS frame's key_min)
             sl.kept_lo = (uint32_t)box[3] + j.f.key_min;
             sl.kept_hi = (uint32_t)(box[3] >> 32) + j.f.key_min;
@@ -1640,8 +1671,13 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     int key_bits = 1;
     while (key_bits < 32 && ((f.key_max - f.key_min) >> key_bits) != 0u) ++key_bits;
     const uint32_t n_slots = n ? div_up(c->nclus, 4u) * (uint32_t)GSR_K1_THREADS : 0u;   // the slots K1 can fill at most
+    // (back-off: a geometry with a long run of coincident splats fails the small-frame sort's tie rule every frame; the re-render
+    //  refills the hints, so without this it would be rendered twice per frame for good)
+    if (sl.local_fails >= 3) { sl.local_fails = 0; sl.local_holdoff = 64; }
+    const bool held = sl.local_holdoff > 0 && c->opt_local_sort < 2;
+    if (sl.local_holdoff > 0 && !cache_hit) sl.local_holdoff -= 1;
     const bool local = !cache_hit && !ordered && n_slots > 0 && key_bits > 9 && !(c->opt_flags & GSR_FLAG_FULL_KEYS) && sl.kept_hi > sl.kept_lo && !j.deferred &&
-                       !c->classic_once && sl.kept_culled == j.cull &&
+                       !c->classic_once && !held && sl.kept_culled == j.cull &&
                        (c->opt_local_sort >= 2 || (c->opt_local_sort == 1 && sl.kept_hint > 0 && sl.kept_hint <= 500000u));
     if (!cache_hit) c->classic_once = false;
     j.local_sort = local;
@@ -1701,7 +1737,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         sl.sorted_culled = j.cull;
     } else {
         if (local) {
-            // 512 buckets of equal width over the key range the previous frame kept, widened by a sixteenth on either side (the
+            // BK_BUCKETS buckets of equal width over the key range the previous frame kept, widened by a sixteenth on either side (the
             // view moves); in this frame's key domain (keys are stored relative to key_min)
             const uint64_t span = (uint64_t)sl.kept_hi - sl.kept_lo, margin = span / 16 + 64;
             const uint64_t lo_abs = sl.kept_lo > margin ? sl.kept_lo - margin : 0, hi_abs = (uint64_t)sl.kept_hi + margin;
@@ -2188,7 +2224,7 @@ static int debug_sort_pairs(gsr_context* c, uint32_t* keys, uint32_t* vals, int6
     hipError_t e = hipMemcpyAsync(kA, keys, (size_t)n * 4, hipMemcpyHostToDevice, sl.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(vA, vals, (size_t)n * 4, hipMemcpyHostToDevice, sl.stream);
     if (e == hipSuccess) {
-        if (local) {   // one scatter into 512 buckets of width 2^shift from lo, then every bucket on its own (k_radix_local)
+        if (local) {   // one scatter into BK_BUCKETS buckets of width 2^shift from lo, then every bucket on its own (k_radix_local)
             // (uint32 payloads in the slot's bucket regions: the payload region is large enough for either type)
             const uint32_t nblk = div_up(n, RS_TILE);
             hipError_t e2 = hipMemsetAsync(sl.bkt_cnt, 0, (size_t)BK_BUCKETS * BK_STRIDE * sizeof(uint32_t), sl.stream);

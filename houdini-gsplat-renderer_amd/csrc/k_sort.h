@@ -674,7 +674,7 @@ k_radix_local(const uint32_t* __restrict__ cnt, int low_bits, int full_bits, uin
     __shared__ V svals[RL_CHUNK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = (int)blockIdx.x;
-    KPROFB(2, 0, 512)
+    KPROFB(2, 0, BK_BUCKETS / 2)
     KPROF_BLK_BEGIN
     // where the bucket goes: the (clamped) counts of the buckets before it
     uint32_t before = 0;
@@ -682,7 +682,7 @@ k_radix_local(const uint32_t* __restrict__ cnt, int low_bits, int full_bits, uin
     uint32_t tot;
     (void)block_excl_scan_256(before, s_wave, &tot);
     const uint32_t start = tot;
-    KPROFB(2, 1, 512)
+    KPROFB(2, 1, BK_BUCKETS / 2)
     uint32_t n = cnt[(size_t)b * BK_STRIDE];
     n = n < (uint32_t)BK_CAP ? n : (uint32_t)BK_CAP;
     if (n_out && b == BK_BUCKETS - 1 && threadIdx.x == 0) *n_out = start + n;
@@ -733,7 +733,7 @@ k_radix_local(const uint32_t* __restrict__ cnt, int low_bits, int full_bits, uin
             k_[r] = 0u; v_[r] = V{};
             if (mine(r, li)) { k_[r] = ks[li]; v_[r] = vs[li]; }
         }
-        KPROFB(2, 2, 512)
+        KPROFB(2, 2, BK_BUCKETS / 2)
         if (npass == 0) {      // (a bucket one key wide: nothing to sort but the ties)
 #pragma unroll
             for (int r = 0; r < RL_ITEMS; ++r) {
@@ -753,11 +753,11 @@ k_radix_local(const uint32_t* __restrict__ cnt, int low_bits, int full_bits, uin
                 __syncthreads();
             }
         }
-        KPROFB(2, 3, 512)
+        KPROFB(2, 3, BK_BUCKETS / 2)
         rl_fix_ties(skeys, svals, n, failed);
-        KPROFB(2, 4, 512)
+        KPROFB(2, 4, BK_BUCKETS / 2)
         for (uint32_t j = threadIdx.x; j < n; j += RL_THREADS) { kd[j] = skeys[j]; vd[j] = svals[j]; }
-        KPROFB(2, 5, 512)
+        KPROFB(2, 5, BK_BUCKETS / 2)
         KPROF_BLK_END(2, n)
         return;
     }

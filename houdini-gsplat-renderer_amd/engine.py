@@ -491,7 +491,7 @@ class Engine:
         return out.reshape(st["tiles_y"], st["tiles_x"], 4)
 
     def debug_sort_pairs(self, keys: np.ndarray, vals: np.ndarray, key_bits: int = 32, local=None):
-        """the pipeline's stable radix sort on host arrays; local = (bucket_lo, bucket_shift): the small-frame form (512 buckets of
+        """the pipeline's stable radix sort on host arrays; local = (bucket_lo, bucket_shift): the small-frame form (BK_BUCKETS = 1024 buckets of
         width 2^shift from lo globally, then every bucket on its own)"""
         k = np.ascontiguousarray(keys, dtype=np.uint32).copy()
         v = np.ascontiguousarray(vals, dtype=np.uint32).copy()

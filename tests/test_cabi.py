@@ -121,3 +121,32 @@ def test_product_never_touches_the_oracle_or_the_reference():
     # bench.py uses the oracle only inside its cpu_baseline leg
     bench = open(os.path.join(ROOT, "bench.py")).read()
     assert bench.count("load_oracle") == 1 and "def cpu_baseline" in bench
+
+
+def test_hdk_glue_calls_only_what_the_headers_declare():
+    """hdk/*.C (the Houdini-side glue; needs the HDK, so it is never compiled here) may only call verbs that
+    include/GSplatRenderer.h, include/GSplatPrim.h and include/gsplat_hip.h declare, and must keep the DSO entry point and the
+    class names the reference's unchanged sources look for (/root/reference/gsplat_plugin/src/GEO_GSplat.C:494-498,
+    src/DM_GSplatHook.C:66-71)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = lambda *p: open(os.path.join(root, *p), encoding="utf-8").read()
+    hdr_r, hdr_p, hdr_c = read("include", "GSplatRenderer.h"), read("include", "GSplatPrim.h"), read("include", "gsplat_hip.h")
+    gr, dm, uni = read("hdk", "GR_GSplat_hip.C"), read("hdk", "DM_GSplatHook_hip.C"), read("hdk", "gsplat_plugin_hip.C")
+    for verb in set(re.findall(r"\bR\.(\w+)\(", dm)):
+        assert re.search(r"\b%s\(" % verb, hdr_r), f"GSplatRenderer::{verb} is not declared"
+    for verb in set(re.findall(r"\bmyPrim\.(\w+)\(", gr)):
+        assert re.search(r"\b%s\(" % verb, hdr_p), f"GSplatPrim::{verb} is not declared"
+    for fn in set(re.findall(r"\b(gsr_\w+)\(", gr + dm)):
+        assert re.search(r"\b%s\(" % fn, hdr_c), f"{fn} is not in the C ABI"
+    for field in set(re.findall(r"\bctx\.(\w+)", dm)):
+        assert re.search(r"\b%s\b" % field, hdr_r[hdr_r.index("typedef struct GSplatRenderContext"):hdr_r.index("} GSplatRenderContext;")]), field
+    for field in set(re.findall(r"\ba\.(\w+)\s*=", gr)):
+        assert re.search(r"\b%s;" % field, hdr_p[hdr_p.index("typedef struct gsplat_attrs"):hdr_p.index("} gsplat_attrs;")]), field
+    assert "void newRenderHook(DM_RenderTable* table)" in dm and "DM_HOOK_BEAUTY, DM_HOOK_AFTER_NATIVE" in dm and "INT_MAX" in dm
+    assert "class GR_PrimGsplatHook : public GUI_PrimitiveHook" in read("hdk", "GR_GSplat_hip.h")
+    assert '#include "GR_GSplat_hip.h"' in read("hdk", "GR_GSplat.h")
+    for inc in ("src/GEO_GSplat.C", "src/SOP_GSplat.C", "GR_GSplat_hip.C", "DM_GSplatHook_hip.C"):
+        assert f'#include "{inc}"' in uni
+    assert "HFS" in read("hdk", "build.sh")

@@ -1567,3 +1567,24 @@ def test_multi_gpu_gather_overlaps_the_next_frame_and_keeps_every_frame(pkg, eng
             assert M.comm_info() == ([-1, -1, -1], 0)
     finally:
         hb.free()
+
+
+def test_small_frame_sort_backs_off_when_a_tie_run_defeats_it_every_frame(pkg):
+    """A cloud with a run of more than 64 coincident splats: the small-frame sort's tie rule gives that bucket up, and the frame
+    is rendered again with the global sort.  The re-render refills the hints, so without a back-off EVERY frame would be
+    rendered twice; after three failures in a row the slot stays with the global sort for a while.  Pixels are the global
+    sort's throughout."""
+    splats = pkg.scenes.make_scene(60000, seed=401, sh=True)
+    splats.P[5000:5100] = splats.P[4000]                       # 101 splats at one position: 101 equal sort keys
+    w, h = 640, 400
+    cams = [pkg.camera.make_camera(w, h, sh_order=3, frame=i) for i in range(16)]
+    ref, eng = pkg.Engine(0), pkg.Engine(0)
+    try:
+        ref.set_option(pkg.engine.OPT_LOCAL_SORT, 0)
+        ref.upload(splats); eng.upload(splats)
+        for k, c in enumerate(cams):
+            assert np.array_equal(eng.render(c), ref.render(c)), f"frame {k}"
+        st = eng.stats()
+        assert 1 <= st["frames_resorted"] <= 4, st["frames_resorted"]      # (16 without the back-off)
+    finally:
+        ref.close(); eng.close()

@@ -86,7 +86,10 @@ def parse_args():
     ap.add_argument("--time-every", type=int, default=0, help="HIP events around the blend kernel of every N-th frame of the timed region; "
                     "0 = min(8, steps / 16), so that at least 16 launches are timed "
                     "(each pair idles the queue ~12 us; the roofline's launch time is the mean over the sampled launches)")
-    ap.add_argument("--cull", type=int, default=1, help="0 = no occlusion culling against the previous frame's depth horizons (A/B)")
+    ap.add_argument("--cull", type=int, default=1, help="GSR_OPT_OCCLUSION_CULL: 0 = no occlusion culling, 1 = the library's policy (default), 2 = against the previous "
+                    "frame whenever it left horizons, 3 = inside the frame only (every frame a front-slab frame: nothing depends on the previous frame)")
+    ap.add_argument("--front-slab", type=int, default=1, help="GSR_OPT_FRONT_SLAB (A/B): 0 = frames that cannot use the previous frame's horizons are plain unculled frames")
+    ap.add_argument("--jump-every", type=int, default=0, help="the orbit jumps by 111 degrees every N steps (0 = a steady orbit): N = 1 makes every frame a cold frame")
     ap.add_argument("--cluster-cull", type=int, default=1, help="0 = no cluster culling in front of K1 (A/B)")
     ap.add_argument("--storage-order", type=int, default=1, help="0 = splats stored in upload order instead of Morton order (A/B)")
     ap.add_argument("--dilate", type=int, default=-1, help="GSR_OPT_CULL_DILATE (A/B; -1 = library default)")
@@ -191,6 +194,11 @@ def cpu_baseline(oracle, splats, cam0, pkg, budget_s: float) -> dict:
     }
 
 
+def orbit_frame(i: int, jump_every: int) -> int:
+    """the orbit frame of step i: 3 degrees per step, plus a jump of 37 frames (111 degrees) every `jump_every` steps"""
+    return i + (37 * (i // jump_every) if jump_every > 0 else 0)
+
+
 def error_line(args, msg: str, code: int = 2):
     """a parsable line instead of a bare exit string: the driver records what went wrong"""
     print(json.dumps({"metric": "frames/sec at 1920x1080 + achieved HBM GB/s (blend kernel)", "value": None, "unit": "frames/sec",
@@ -284,6 +292,7 @@ def set_common_options(target, pkg, args):
     E = pkg.engine
     target.set_option(E.OPT_OCCLUSION_CULL, args.cull)
     target.set_option(E.OPT_CLUSTER_CULL, args.cluster_cull)
+    target.set_option(E.OPT_FRONT_SLAB, args.front_slab)
     target.set_option(E.OPT_LOCAL_SORT, args.local_sort)
     if args.dilate >= 0:
         target.set_option(E.OPT_CULL_DILATE, args.dilate)
@@ -346,7 +355,7 @@ def main_single_process(args):
     M.set_stream(stream.cuda_stream)
     set_common_options(M, pkg, args)
     M.upload(splats)
-    cams = [E.camera_struct(pkg.scenes.config_camera(args.config, pkg.camera, W, H, order, i)) for i in range(args.warmup + args.steps)]
+    cams = [E.camera_struct(pkg.scenes.config_camera(args.config, pkg.camera, W, H, order, orbit_frame(i, args.jump_every))) for i in range(args.warmup + args.steps)]
     final = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{devices[0]}")
 
     def sync_all():
@@ -508,7 +517,7 @@ def main():
         eng.set_row_shard(args.emulate_rank % args.emulate_shard, args.emulate_shard)
     eng.upload(splats)  # once: geometry stays resident in HBM
 
-    cams = [pkg.engine.camera_struct(pkg.scenes.config_camera(args.config, pkg.camera, W, H, order, i))
+    cams = [pkg.engine.camera_struct(pkg.scenes.config_camera(args.config, pkg.camera, W, H, order, orbit_frame(i, args.jump_every)))
             for i in range(args.warmup + args.steps)]
     # N>1: the frame's ONE collective -- band images -> rank 0 over xGMI -- lives INSIDE the library (gsr_comm_render:
     # render band -> ncclSend / ncclRecv x (N-1) in one group on a transfer stream; band layout: straight into the framebuffer).
@@ -650,6 +659,31 @@ def main():
         unculled = {"value": k2 / (time.perf_counter() - t0), "unit": "frames/sec", "steps": k2,
                     "note": "GSR_OPT_OCCLUSION_CULL=0: every clip-visible splat is coloured (lazily), sorted and binned"}
         eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, args.cull)
+    # extra leg (informational, single GPU): COLD frames -- every frame jumps 111 degrees, so no frame can use the previous one's
+    # horizons.  Under the library's policy (a culled attempt that breaks is re-rendered as a front-slab frame; culling backs off) and
+    # with occlusion culling inside the frame only (GSR_OPT_OCCLUSION_CULL = 3: every frame a front-slab frame)
+    cold = None
+    if world == 1 and args.cull and not args.no_extra_legs and args.emulate_shard <= 1:
+        k3 = min(40, args.steps)
+        jcams = [pkg.engine.camera_struct(pkg.scenes.config_camera(args.config, pkg.camera, W, H, order, orbit_frame(i, 1))) for i in range(k3 + 6)]
+        cold = {}
+        for name, mode in (("policy", args.cull), ("intra_frame_only", 3)):
+            eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, mode)
+            for i in range(6):
+                eng.render_struct_to_device(jcams[i], band.data_ptr())
+            torch.cuda.synchronize()
+            eng.stats_reset()
+            t0 = time.perf_counter()
+            for i in range(k3):
+                eng.render_struct_to_device(jcams[6 + i], band.data_ptr())
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            stc = eng.stats()
+            cold[name] = {"value": k3 / dt, "unit": "frames/sec", "steps": k3, "frames_slab": stc["frames_slab"], "frames_culled": stc["frames_culled"],
+                          "frames_repaired": stc["frames_repaired"]}
+        cold["note"] = ("every frame jumps 111 degrees: nothing of the previous frame applies.  policy = the default (GSR_OPT_OCCLUSION_CULL = 1, "
+                        "GSR_OPT_FRONT_SLAB = 1); intra_frame_only = GSR_OPT_OCCLUSION_CULL = 3; compare occlusion_culling.without (every frame unculled)")
+        eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, args.cull)
     # extra leg (informational): the same K steps with two frames in flight
     pipelined = None
     if args.pipelined and args.frames_in_flight == 1 and not args.no_extra_legs:
@@ -776,12 +810,14 @@ def main():
             "lazy_colour": {"mode": args.lazy, "active": st["lazy_colours_total"] > 0, "colours_evaluated_per_frame": st["lazy_colours_total"] / max(1, st["frames"]),
                             "visible_splats": st["n_visible"],
                             "fallback_tiles_last_frame": st["lazy_redo_tiles"]},
-            "occlusion_culling": {"enabled": bool(args.cull), "policy_bits": st["policy_bits"], "dilate_tiles": st["cull_dilate"], "holdoff_frames": st["cull_holdoff"], "frames_culled": st["frames_culled"], "frames_repaired": st["frames_repaired"],
+            "occlusion_culling": {"enabled": bool(args.cull), "policy_bits": st["policy_bits"], "dilate_tiles": st["cull_dilate"], "holdoff_frames": st["cull_holdoff"], "frames_culled": st["frames_culled"], "frames_repaired": st["frames_repaired"], "frames_slab": st["frames_slab"],
                                   "frames": st["frames"], "without": unculled,
                                   "note": "splats whose tile rect lies wholly behind the previous frame's per-tile depth horizons get no colour, no record, and "
                                           "no place in the sort and the lists; every culled frame verifies itself and is rendered again without culling if a horizon "
                                           "broke (frames_repaired; those frames are inside the timed region)"},
         }
+        if cold is not None:
+            line["cold_frames"] = cold
         if pipelined is not None:
             line["pipelined"] = pipelined
         if other is not None:

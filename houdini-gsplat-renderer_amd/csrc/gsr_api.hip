@@ -103,6 +103,14 @@ struct FrameJob {
     bool cull = false;             // occlusion culling: k_cluster_cull and K1 drop what lies behind the slot's depth horizons
     bool direct = false;           // the frame runs on the public stream itself
     uint32_t ticket = 0;           // stamps the frame's pair count in the host mailbox
+    // front-slab frames: 0 = an ordinary frame; 1 = the front slab (splats up to the slab key), followed at frame_finish by
+    // 2 = the rest, culled against the tiles phase 1 left opaque.  The call's arguments are kept for queueing phase 2.
+    int phase = 0;
+    gsr_camera cam_arg{};
+    const float* depth_arg = nullptr;
+    int depth_is_device_arg = 0;
+    float* out_arg = nullptr;
+    int out_is_device_arg = 0;
 };
 
 // Everything one frame in flight owns: its HIP stream, the per-frame HBM arrays, the small
@@ -134,6 +142,14 @@ struct FrameSlot {
     int32_t *sstart = nullptr, *send = nullptr;  // super-tile ranges
     uint4* tile_work = nullptr;        // per tile: entries scanned, records gathered, wave-record evaluations
     size_t tile_cap = 0;
+    // front-slab frames
+    uint4* tile_work_a = nullptr;      // phase 1's per-tile bookkeeping (tile_cap entries)
+    float* tbuf = nullptr;             // per pixel of the band: the transmittance phase 1 left
+    size_t tbuf_cap = 0;
+    float* hpyr2 = nullptr;            // the pyramid of "this tile is finished" phase 2 culls against (GSR_PYR_FLOATS)
+    float* hraw2 = nullptr;            // ... its level 0 before k_horizon_dilate
+    uint32_t* slab = nullptr;          // [GSR_SLAB_BINS + 4] histogram of the surviving clusters' nearest keys; then [0] the slab key, [1] clusters
+    uint32_t slab_kept = 0;            // splats phase 1 sent to the depth sort
     int32_t* redo = nullptr;           // lazy colour: tiles the plain blend kernel gave up (tile_cap entries)
     int32_t* order = nullptr;          // blockIdx -> tile, heaviest tiles first: written by k_tile_order at the end of a frame
     size_t order_cap = 0;              //   for this slot's next frame (valid while the tile geometry stays what it was)
@@ -252,6 +268,8 @@ struct gsr_context {
     int shard_index = 0, shard_count = 1, shard_layout = 0;   // layout: 0 = interleaved rows, 1 = contiguous bands
     int opt_swizzle = 2, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0, opt_lazy = 1, opt_cull = 1, opt_timing_every = 1;
     int opt_cluster = 1, opt_morton = 1, opt_local_sort = 1;
+    int opt_slab = 1;                  // front-slab frames (GSR_OPT_FRONT_SLAB): 0 off, 1 where occlusion culling pays but has no horizons, 2 always
+    int slab_frac = 26, slab_min = 4096;   // the slab: this many 256ths of the surviving clusters, at least so many (A/B hooks: GSR_SLAB_FRAC, GSR_SLAB_MIN)
     bool classic_once = false;         // the next frame sorts with the three global passes whatever the prediction says
 
     gsr_stats st{};
@@ -371,6 +389,10 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMemset(sl.colour_evals, 0, 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hraw), 512 * 512 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr2), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hraw2), 512 * 512 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.slab), (GSR_SLAB_BINS + 4) * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(sl.slab, 0, (GSR_SLAB_BINS + 4) * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.ccnt), CC_MAX_GROUPS * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.bkt_key), (size_t)BK_BUCKETS * BK_CAP * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.bkt_val), (size_t)BK_BUCKETS * BK_CAP * sizeof(uint2)) == hipSuccess;
@@ -415,7 +437,7 @@ static void slot_destroy(FrameSlot& sl)
     dev_free(sl.hist); dev_free(sl.totals);
     dev_free(sl.pvA);
     dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.fb);
-    dev_free(sl.hpyr); dev_free(sl.hraw); dev_free(sl.ccnt); dev_free(sl.bkt_key); dev_free(sl.bkt_val); dev_free(sl.bkt_cnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
+    dev_free(sl.hpyr); dev_free(sl.hraw); dev_free(sl.hpyr2); dev_free(sl.hraw2); dev_free(sl.slab); dev_free(sl.tile_work_a); dev_free(sl.tbuf); dev_free(sl.ccnt); dev_free(sl.bkt_key); dev_free(sl.bkt_val); dev_free(sl.bkt_cnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
     if (sl.h_end) (void)hipHostFree(sl.h_end); dev_free(sl.depth_stage);
     dev_free(sl.redo); dev_free(sl.lazy_ctr); dev_free(sl.colour_evals);
     dev_free(sl.counters); dev_free(sl.d_n);
@@ -444,6 +466,8 @@ extern "C" int gsr_create(int device, gsr_context** out)
     c->device = device;
     if (const char* e = std::getenv("GSR_ORDER_KEEP")) c->opt_order_keep = std::atoi(e);   // (A/B hook)
     if (const char* e = std::getenv("GSR_SCATTER_DIRECT")) c->opt_scatter_direct = std::atoi(e);   // (A/B hook: -1 the general scatter, 0 never direct, 1 direct by frame size, 2 always direct)
+    if (const char* e = std::getenv("GSR_SLAB_FRAC")) { const int v = std::atoi(e); if (v >= 1 && v <= 255) c->slab_frac = v; }   // (A/B hook)
+    if (const char* e = std::getenv("GSR_SLAB_MIN")) { const int v = std::atoi(e); if (v >= 1) c->slab_min = v; }                 // (A/B hook)
     if (const char* e = std::getenv("GSR_BN_ITEMS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) c->opt_bn_items = v; }   // (A/B hook)
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return set_err(GSR_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
@@ -521,11 +545,12 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
     case GSR_OPT_DEBUG_FLAGS: c->opt_flags = value; break;
     case GSR_OPT_DEFERRED_CHECK: c->opt_deferred = value ? 1 : 0; break;
     case GSR_OPT_TIMING_EVERY: c->opt_timing_every = value < 1 ? 1 : (value > 1024 ? 1024 : value); break;
-    case GSR_OPT_OCCLUSION_CULL: c->opt_cull = value < 0 ? 0 : (value > 2 ? 2 : value); break;
+    case GSR_OPT_OCCLUSION_CULL: c->opt_cull = value < 0 ? 0 : (value > 3 ? 3 : value); break;
     case GSR_OPT_LAZY_COLOUR: c->opt_lazy = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_SHARD_LAYOUT: c->shard_layout = value ? 1 : 0; break;
     case GSR_OPT_CLUSTER_CULL: c->opt_cluster = value ? 1 : 0; break;
     case GSR_OPT_LOCAL_SORT: c->opt_local_sort = value < 0 ? 0 : (value > 2 ? 2 : value); break;
+    case GSR_OPT_FRONT_SLAB: c->opt_slab = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_CULL_DILATE: c->opt_dilate = value < 0 ? 0 : (value > 64 ? 64 : value); c->cull_dilate = c->opt_dilate; break;
     case GSR_OPT_STORAGE_ORDER: c->opt_morton = value ? 1 : 0; break;   // (takes effect at the next upload)
     case GSR_OPT_SUPER_TILE:
@@ -1103,6 +1128,7 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
         off += gsr_pyr_dim(f->tiles_x, l) * gsr_pyr_dim(f->tiles_y, l);
     }
     f->cull_dilate = c->cull_dilate;
+    f->phase = 0;
 }
 
 // blockIdx -> tile table for the blend kernel.  Workgroup b lands on XCD b % 8; XCD x is
@@ -1247,6 +1273,8 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         a.super_shift = f.super_shift; a.rect_shift = f.rect_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
         a.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
         a.sup_work = (a.use_map && c->opt_swizzle >= 2 && sl.sup_work) ? sl.sup_work + 256 * sl.sup_par : nullptr;
+        a.slab = j.phase; a.tbuf = sl.tbuf; a.tile_work_a = sl.tile_work_a;
+        uint4* const tw = j.phase == 1 ? sl.tile_work_a : sl.tile_work;   // (phase 1's bookkeeping is kept for phase 2 and the frame end)
         // heaviest-first table of this slot's previous frame, if that frame had the same tiles
         const int sig[6] = {f.width, f.height, f.shard_index, f.shard_count, f.shard_rpb, f.super_shift};
         const bool ordered = a.use_map && c->opt_swizzle >= 2 && sl.order_valid && std::memcmp(sig, sl.order_sig, sizeof sig) == 0;
@@ -1259,10 +1287,10 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         float4* tgt = reinterpret_cast<float4*>(j.target);
         if (j.d_depth)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<true>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
-                               sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
+                               sl.send, sl.rec, tgt, tw, sl.zwin, j.d_depth, lz);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
-                               sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
+                               sl.send, sl.rec, tgt, tw, sl.zwin, j.d_depth, lz);
         if (j.lazy) {   // the tiles that met a pending colour, with on-demand evaluation (normally none: the blocks exit at once)
             if (j.d_depth)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<true>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
@@ -1289,12 +1317,13 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     // (below a few hundred thousand splats in the sort the frame is bound by launch floors: nothing for culling to win)
     // ... and while culling is held off nobody needs horizons: they are prepared again two frames before it may resume.
     // A deferred frame (handed over before its pair count was known) never culls and may have clamped lists: no horizons from it.
-    if (c->opt_cull && j.n > 0 && !j.deferred && (c->opt_cull >= 2 || j.cull || (c->vis_unculled >= 300000u && c->cull_holdoff <= 2))) {
+    if (c->opt_cull && c->opt_cull != 3 && j.n > 0 && !j.deferred && (c->opt_cull >= 2 || j.cull || j.phase == 2 || (c->vis_unculled >= 300000u && c->cull_holdoff <= 2))) {
         hz.raw = sl.hraw; hz.pyr_in = sl.hpyr; hz.pyr_out = sl.hpyr; hz.dilate = j.f.cull_dilate; hz.culled = j.cull ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
         for (int l = 0; l < GSR_PYR_LEVELS; ++l) hz.pyr_off[l] = j.f.pyr_off[l];
         hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
         hz.host_end = j.cull ? sl.h_end_dev : nullptr; hz.ticket = j.ticket;
     }
+    if (j.phase == 2) { hz.slab = 2; hz.tile_work_a = sl.tile_work_a; }
     const int nblocks8 = ((j.f.tiles_x + 7) >> 3) * ((j.f.tiles_y + 7) >> 3);
     hipLaunchKernelGGL(k_tile_pass, dim3((unsigned)nblocks8), dim3(64), 0, s, sl.tile_work, g, sl.sstart, sl.send, hz, sl.partial, sl.st_scan);
     hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.partial, nblocks8, g, sl.counters, sl.d_n, sl.d_frame,
@@ -1345,7 +1374,8 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
         sl.order_age = 0;
     }
     sl.sup_par ^= 1;
-    if (j.f.sh_order > 0 && c->opt_lazy) c->prefix_valid = true;   // (eager frames keep the scan depths too: the switch to lazy starts predicted)
+    if (j.f.sh_order > 0 && c->opt_lazy) c->prefix_valid = j.phase == 0;   // (eager frames keep the scan depths too: the switch to lazy starts predicted;
+                                                                           //  a front-slab frame's scan depths belong to two different lists)
     sl.last_lazy = j.lazy;
     if (j.timing) { sl.ev_pending = true; sl.ev_all = j.timing_all; }
     if (!j.out_is_device) {
@@ -1357,6 +1387,29 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
         HIP_TRY(hipEventRecord(sl.ev_done, s));
         HIP_TRY(hipStreamWaitEvent(c->stream, sl.ev_done, 0));
     }
+    return GSR_OK;
+}
+
+// The middle of a front-slab frame: phase 1 is composited; which tiles are finished?  (k_blend.h: k_slab_mid, then the pyramid
+// phase 2 culls against -- no dilation: same frame, same camera)
+static int queue_slab_mid(gsr_context* c, FrameSlot& sl)
+{
+    const FrameJob& j = sl.job;
+    hipStream_t s = sl.stream;
+    GsrSumArgs g;
+    g.n_tiles = j.local_tiles; g.tiles_x = j.f.tiles_x; g.tiles_y = j.f.tiles_y; g.shard = GsrShard{j.f.shard_index, j.f.shard_count, j.f.shard_rpb};
+    g.super_shift = j.f.super_shift; g.stiles_x = j.f.stiles_x; g.n_super = j.n_super;
+    GsrHorizonArgs hz{};
+    hz.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
+    hz.raw = (c->opt_cull && c->opt_cull != 3) ? sl.hraw : nullptr;          // the finished tiles' horizons for the slot's NEXT frame
+    hz.lists = sl.pvA; hz.geoA = c->geoA;
+    for (int l = 0; l < GSR_PYR_LEVELS; ++l) hz.pyr_off[l] = j.f.pyr_off[l];
+    hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
+    const int nblocks8 = ((j.f.tiles_x + 7) >> 3) * ((j.f.tiles_y + 7) >> 3);
+    hipLaunchKernelGGL(k_slab_mid, dim3((unsigned)nblocks8), dim3(64), 0, s, sl.tile_work_a, g, sl.sstart, sl.send, hz, sl.hraw2, sl.hpyr2,
+                       sl.slab + GSR_SLAB_BINS, j.f.key_min);
+    hipLaunchKernelGGL(k_horizon_dilate, dim3((unsigned)nblocks8), dim3(64), 0, s, sl.hraw2, j.f.tiles_x, j.f.tiles_y, 0, hz, sl.hpyr2);
+    HIP_TRY(hipGetLastError());
     return GSR_OK;
 }
 
@@ -1393,6 +1446,9 @@ static int wait_mailbox(FrameSlot& sl, volatile unsigned long long* box, uint32_
     return GSR_OK;
 }
 
+static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth, int depth_is_device,
+                       float* rgba_out, int out_is_device, FrameSlot** used, bool allow_cull, int phase_in = 0);
+
 static int frame_finish(gsr_context* c, FrameSlot& sl)
 {
     if (!sl.job.open) return GSR_OK;
@@ -1421,9 +1477,13 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
             return GSR_OK;
         }
         if (j.local_sort) sl.local_fails = 0;
-        c->lazy_pays = (box[1] & 1ull) != 0ull;
-        c->cull_pays = (box[1] & 4ull) != 0ull;
-        c->prefix_cheaper = (box[1] & 8ull) != 0ull;
+        if (j.phase != 2) {   // (the kernels' verdicts on the frame BEFORE: lazy colour / occlusion culling / list prefixes pay)
+            c->lazy_pays = (box[1] & 1ull) != 0ull;
+            c->cull_pays = (box[1] & 4ull) != 0ull;
+            c->prefix_cheaper = (box[1] & 8ull) != 0ull;
+            c->order_pays = (box[1] & 2ull) != 0ull;
+        }
+        if (j.phase == 0) {
         {   // occlusion culling earns its keep only if it drops a good part of what an unculled frame keeps
             const uint32_t kept = (uint32_t)(box[1] >> 32);
             if (!j.cull) c->vis_unculled = kept;
@@ -1432,11 +1492,21 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
                 if (c->opt_cull == 1 && c->cull_weak) c->cull_holdoff = 256;
             }
         }
-        c->order_pays = (box[1] & 2ull) != 0ull;   // (written before the ticket) k_sum_work's verdict on the frame before
         sl.surv_hint = (uint32_t)box[2];           // clusters that survived k_cluster_cull: sizes the next frame's K1 grid
         sl.kept_hint = (uint32_t)(box[1] >> 32);   // ... and how many splats reached the depth sort: picks the next frame's sort
         sl.kept_culled = j.cull;
-        if (sl.kept_hint > 0) {                    // ... between which keys (stored relative to THIS frame's key_min)
+        } else {
+            // a front-slab frame: its two phases say nothing about what an ordinary frame keeps (no say in the policies); the next
+            // frame -- usually one culled against this frame's horizons -- keeps about what both phases kept, from about as many clusters
+            const uint32_t kept = (uint32_t)(box[1] >> 32);
+            if (j.phase == 1) sl.slab_kept = kept;
+            else {
+                sl.kept_hint = sl.slab_kept + kept;
+                sl.surv_hint = std::min<uint32_t>((uint32_t)box[2], std::max<uint32_t>(16384u, 2u * div_up(sl.kept_hint, GSR_CLUSTER)));
+                sl.kept_culled = true;
+            }
+        }
+        if (sl.kept_hint > 0 && j.phase == 0) {    // ... between which keys (stored relative to THIS frame's key_min)
             sl.kept_lo = (uint32_t)box[3] + j.f.key_min;
             sl.kept_hi = (uint32_t)(box[3] >> 32) + j.f.key_min;
         } else {
@@ -1469,6 +1539,22 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
         }
     }
     sl.last_pairs = D;
+    if (j.phase == 1) {
+        // front slab composited: find the finished tiles, then the rest of the frame (same slot, same call arguments)
+        int rc = queue_slab_mid(c, sl);
+        if (rc) return frame_abort(sl, rc);
+        j.open = false;
+        const gsr_camera cam = j.cam_arg;
+        const float* depth = j.depth_arg;
+        const int ddev = j.depth_is_device_arg, odev = j.out_is_device_arg;
+        float* out = j.out_arg;
+        c->frame_no -= 1;          // (the same frame, in the same slot)
+        c->st.frames -= 1;
+        FrameSlot* sl2 = nullptr;
+        rc = frame_begin(c, &cam, depth, ddev, out, odev, &sl2, false, 2);
+        if (rc) return rc;
+        return frame_finish(c, *sl2);
+    }
     if (!j.deferred) {
         int rc = queue_frame_end(c, sl);
         if (rc) return frame_abort(sl, rc);
@@ -1528,7 +1614,7 @@ static int build_pos_order(gsr_context* c, FrameSlot& sl, const GsrFrame& f)
 }
 
 static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth, int depth_is_device,
-                       float* rgba_out, int out_is_device, FrameSlot** used, bool allow_cull)
+                       float* rgba_out, int out_is_device, FrameSlot** used, bool allow_cull, int phase_in /* 2 = the second phase of a front-slab frame */)
 {
     if (!c || !cam || !rgba_out) return set_err(GSR_E_INVALID, "gsr_render: NULL argument");
     if (c->uploading) return set_err(GSR_E_INVALID, "gsr_render: upload in progress");
@@ -1578,14 +1664,15 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     j.use_map = c->opt_swizzle != 0;
     j.user_out = rgba_out;
     j.out_is_device = out_is_device != 0;
-    j.deferred = c->opt_deferred && j.out_is_device;
+    j.cam_arg = *cam; j.depth_arg = depth; j.depth_is_device_arg = depth_is_device; j.out_arg = rgba_out; j.out_is_device_arg = out_is_device;
+    j.deferred = c->opt_deferred && j.out_is_device && phase_in == 0;
     // order 0: the colour is Cd itself, nothing to defer; mode 1 follows the kernels' own verdict on the previous frames
     j.lazy = f.sh_order > 0 && (c->opt_lazy == 2 || (c->opt_lazy == 1 && c->lazy_pays));
     {
         const int sig[7] = {f.width, f.height, f.shard_index, f.shard_count, f.shard_rpb, f.super_shift, (int)c->geo_gen};
-        j.cull = allow_cull && c->opt_cull && !j.deferred && n > 0 && sl.horizon_valid && std::memcmp(sig, sl.horizon_sig, sizeof sig) == 0 &&
-                 !(c->opt_flags & GSR_FLAG_FULL_KEYS) && (c->opt_cull >= 2 || (c->cull_pays && c->cull_holdoff == 0));
-        if (allow_cull && c->cull_holdoff > 0) c->cull_holdoff -= 1;
+        j.cull = allow_cull && phase_in == 0 && c->opt_cull && !j.deferred && n > 0 && sl.horizon_valid && std::memcmp(sig, sl.horizon_sig, sizeof sig) == 0 &&
+                 !(c->opt_flags & GSR_FLAG_FULL_KEYS) && c->opt_cull != 3 && (c->opt_cull >= 2 || (c->cull_pays && c->cull_holdoff == 0));
+        if (allow_cull && phase_in == 0 && c->cull_holdoff > 0) c->cull_holdoff -= 1;
         j.f.cull_dilate = std::max(c->cull_dilate - sl.hpyr_re, 0);   // (the rest of the radius is built into the slot's pyramid)
         if (j.cull) {
             c->st.frames_culled += 1;
@@ -1595,6 +1682,21 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
             // over the sorted payloads, k_colour_kept: 16 us of scattered 128-byte rows against 9 us more in K1.)
             if (f.sh_order > 0 && c->opt_lazy) j.lazy = c->opt_lazy >= 2 || (c->prefix_cheaper && c->prefix_valid);
         }
+    }
+    // Front-slab frame?  A frame that cannot be culled against a previous frame's horizons (the first frames of a cloud, a jump, the
+    // re-render of a frame that broke a horizon, culling held off) is rendered in two phases where occlusion culling is known to pay:
+    // the nearest splats first, then -- behind the tiles that are still open only -- the rest (GSR_OPT_FRONT_SLAB; k_blend.h).
+    const SortKey key_now = {c->geo_gen, c->shard_index, c->shard_count, c->shard_layout, c->opt_flags, *cam};
+    {
+        const bool hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now) && !j.cull && !sl.sorted_culled;   // (a static redraw)
+        const bool slab = phase_in == 0 && !j.cull && !j.deferred && n > 0 && c->opt_slab && c->opt_cull && c->opt_cluster && c->bbox_ok &&
+                          !(c->opt_flags & GSR_FLAG_FULL_KEYS) && c->opt_sort_cache < 2 && !hit &&
+                          (c->opt_slab >= 2 || c->opt_cull == 3 || (c->cull_pays && !c->cull_weak && c->vis_unculled >= 300000u));
+        j.phase = phase_in == 2 ? 2 : (slab ? 1 : 0);
+        j.f.phase = j.phase;
+        if (j.phase) { j.lazy = false; j.timing = false; }     // (a phase keeps about what it composites: K1 shades on the spot)
+        if (j.phase == 2) j.f.cull_dilate = 0;                 // (this frame's own tiles: nothing moves)
+        if (j.phase == 1) c->st.frames_slab += 1;
     }
     j.ticket = ++sl.ticket ? sl.ticket : ++sl.ticket;   // (never 0: the mailbox starts at 0)
     if (j.timing) harvest_slot(c, sl);
@@ -1607,11 +1709,18 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     // per-tile bookkeeping + super-tile ranges
     if ((size_t)j.local_tiles + 1 > sl.tile_cap || !sl.sstart) {
         HIP_TRY(hipStreamSynchronize(s));
-        dev_free(sl.tile_work); dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.redo);
+        dev_free(sl.tile_work); dev_free(sl.tile_work_a); dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.redo);
         sl.tile_cap = 0;
-        if ((rc = dev_alloc(&sl.tile_work, (size_t)j.local_tiles + 1)) || (rc = dev_alloc(&sl.sstart, (size_t)65536 + 1)) ||
+        if ((rc = dev_alloc(&sl.tile_work, (size_t)j.local_tiles + 1)) || (rc = dev_alloc(&sl.tile_work_a, (size_t)j.local_tiles + 1)) || (rc = dev_alloc(&sl.sstart, (size_t)65536 + 1)) ||
             (rc = dev_alloc(&sl.send, (size_t)65536 + 1)) || (rc = dev_alloc(&sl.redo, (size_t)j.local_tiles + 1))) return rc;
         sl.tile_cap = (size_t)j.local_tiles + 1;
+    }
+    if (j.phase == 1 && j.out_px > sl.tbuf_cap) {          // the transmittance a front slab leaves behind, per pixel of the band
+        HIP_TRY(hipStreamSynchronize(s));
+        dev_free(sl.tbuf);
+        sl.tbuf_cap = 0;
+        if ((rc = dev_alloc(&sl.tbuf, j.out_px))) return rc;
+        sl.tbuf_cap = j.out_px;
     }
     if (j.use_map && (rc = build_tile_map(c, f))) return rc;
     j.d_depth = depth;
@@ -1644,15 +1753,15 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     // The depth order depends on the camera POSITION only (argsortByDistance re-sorts when the position moves,
     // src/GSplatRenderer.C:165-186) -- but the sorted list holds just the splats visible to the frame that sorted, so
     // it is reused as is only for an identical frame description (a static viewport redraw), per frame slot.
-    const SortKey key_now = {c->geo_gen, c->shard_index, c->shard_count, c->shard_layout, c->opt_flags, *cam};
-    // (a culled frame's order holds only the splats in front of ITS horizons, and the horizons move: no reuse either way)
-    const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now) && !j.cull && !sl.sorted_culled;
+    // (a culled frame's order holds only the splats in front of ITS horizons, and the horizons move: no reuse either way; the
+    //  two phases of a front-slab frame each sort what they keep)
+    const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now) && !j.cull && !sl.sorted_culled && j.phase == 0;
     // Position-keyed order (GSR_OPT_SORT_CACHE = 2; the reference's rule, src/GSplatRenderer.C:165-186): while the camera POSITION stands
     // still -- a rotation about the eye, a change of lens -- the depth order of ALL splats is the one sorted when it last moved, K1 walks
     // the splats in that order, and what a frame keeps leaves it sorted.  Built the second time a position is seen (a moving camera never
     // pays for it).  Not for sharded, deferred or full-key frames.
     bool ordered = false;
-    if (c->opt_sort_cache >= 2 && !cache_hit && n > 0 && c->shard_count == 1 && !j.deferred && !(c->opt_flags & GSR_FLAG_FULL_KEYS)) {
+    if (c->opt_sort_cache >= 2 && !cache_hit && n > 0 && c->shard_count == 1 && !j.deferred && !(c->opt_flags & GSR_FLAG_FULL_KEYS) && j.phase == 0) {
         const bool same_pos = c->last_cam_set && std::memcmp(c->last_cam, cam->cam_pos, sizeof c->last_cam) == 0;
         if (c->pos_valid && (c->pos_gen != c->geo_gen || std::memcmp(c->pos_cam, cam->cam_pos, sizeof c->pos_cam) != 0 ||
                              c->pos_kmin != f.key_min || c->pos_kmax != f.key_max))
@@ -1677,7 +1786,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     const bool held = sl.local_holdoff > 0 && c->opt_local_sort < 2;
     if (sl.local_holdoff > 0 && !cache_hit) sl.local_holdoff -= 1;
     const bool local = !cache_hit && !ordered && n_slots > 0 && key_bits > 9 && !(c->opt_flags & GSR_FLAG_FULL_KEYS) && sl.kept_hi > sl.kept_lo && !j.deferred &&
-                       !c->classic_once && !held && sl.kept_culled == j.cull &&
+                       !c->classic_once && !held && sl.kept_culled == j.cull && j.phase == 0 &&
                        (c->opt_local_sort >= 2 || (c->opt_local_sort == 1 && sl.kept_hint > 0 && sl.kept_hint <= 500000u));
     if (!cache_hit) c->classic_once = false;
     j.local_sort = local;
@@ -1692,21 +1801,32 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
             rounds = std::max(rounds, 3);
             ngroups = div_up(c->nclus, (uint32_t)CC_THREADS * (uint32_t)rounds);
         }
+        // (front-slab frames: phase 1 leaves a histogram of the survivors' nearest keys and k_slab_pick takes the slab key from it;
+        //  phase 2 culls against the tiles phase 1 finished)
+        const int hist_shift = key_bits > 10 ? key_bits - 10 : 0;
+        const float* pyr = j.phase == 2 ? sl.hpyr2 : ((j.cull && !ordered) ? sl.hpyr : (const float*)nullptr);
         hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, ordered ? 0 : c->opt_cluster,
-                           (j.cull && !ordered) ? sl.hpyr : (const float*)nullptr, sl.cseg, sl.ccnt);   // (ordered: slots, not clusters -- all of them)
+                           pyr, sl.cseg, sl.ccnt,   // (ordered: slots, not clusters -- all of them)
+                           j.phase == 1 ? sl.slab : (uint32_t*)nullptr, hist_shift, j.phase == 2 ? sl.slab + GSR_SLAB_BINS : (const uint32_t*)nullptr);
+        if (j.phase == 1)
+            hipLaunchKernelGGL(k_slab_pick, dim3(1), dim3(GSR_SLAB_BINS), 0, s, sl.slab, hist_shift, (uint32_t)c->slab_min, (uint32_t)c->slab_frac, sl.slab + GSR_SLAB_BINS);
         // K1 over the survivors, four clusters per workgroup-iteration; the grid follows the slot's previous frame (+25 %), and
         // a frame that keeps more simply loops
         const uint32_t all_iter = div_up(c->nclus, 4u);
         uint32_t k1_grid = all_iter;
         if (sl.surv_hint > 0 && !ordered) k1_grid = std::min<uint32_t>(all_iter, div_up(sl.surv_hint, 4u) * 5u / 4u + 64u);
+        if (j.phase) k1_grid = std::min<uint32_t>(all_iter, 8192u);   // (what a phase keeps is not known beforehand: a bounded grid that loops)
         // on a cache hit (identical frame description) the sorted (keyA, valA) are kept and K1's key/payload
         // output goes to the scratch buffers
         j.k1_grid = k1_grid;
         hipLaunchKernelGGL(k_preprocess, dim3(k1_grid ? k1_grid : 1u), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, (cache_hit || ordered) ? sl.keyB : sl.keyA, (cache_hit || ordered) ? sl.valB : sl.valA,
-                           j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.cull ? sl.hpyr : (const float*)nullptr, sl.blk_cnt,
-                           sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts, local ? sl.bkt_cnt : (uint32_t*)nullptr, local ? sl.d_n : (uint32_t*)nullptr,
-                           ordered ? c->pos_order : (const uint32_t*)nullptr);
+                           j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.phase == 2 ? sl.hpyr2 : (j.cull ? sl.hpyr : (const float*)nullptr), sl.blk_cnt,
+                           sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts, local ? sl.bkt_cnt : (uint32_t*)nullptr,
+                           // (the count of sorted splats starts at zero: a frame whose clusters are ALL culled runs no sort workgroup that
+                           //  could say so, and the binning kernels would walk the previous frame's order; a static redraw keeps its order)
+                           cache_hit ? (uint32_t*)nullptr : sl.d_n,
+                           ordered ? c->pos_order : (const uint32_t*)nullptr, sl.slab + GSR_SLAB_BINS, c->clusA, c->clusB);
         hipError_t e = hipGetLastError();
 #ifdef GSR_HOST_TIMING
         if (g_t_verdict > 0) {
@@ -1768,7 +1888,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         }
         if (rc) return frame_abort(sl, rc);
         sl.key_min = f.key_min;
-        sl.sort_valid = true;
+        sl.sort_valid = j.phase == 0;    // (a phase's order holds a part of the frame only)
         sl.sort_key = key_now;
         sl.sorted_culled = j.cull;
     }
@@ -1778,14 +1898,14 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         // coarse binning as a counting sort (k_binning.h): count -> scan -> ranges -> [pair count to the host] -> place
         // splats per binning workgroup: 1024 for frames that keep millions, fewer for the small ones (k_binning.h)
         // (measured, fps with 4 / 2 / 1: C1 12 770 / 13 540 / 14 190, C2 7880 / 8270 / 8510, C3 4770 / 4900 / 4830, C4 3930 / 3950 / 3760)
-        j.bn_items = c->opt_bn_items > 0 ? c->opt_bn_items : (!local ? 4 : (sl.kept_hint <= 150000u ? 1 : 2));
+        j.bn_items = c->opt_bn_items > 0 ? c->opt_bn_items : (j.phase ? 2 : (!local ? 4 : (sl.kept_hint <= 150000u ? 1 : 2)));
         const uint32_t bn_tile = (uint32_t)BN_THREADS * (uint32_t)j.bn_items;
         const uint32_t nblk = div_up(n, bn_tile);
         rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)BN_BINS * nblk + 8);
         if (rc) return frame_abort(sl, rc);
         const GsrShard shd{f.shard_index, f.shard_count, f.shard_rpb, f.rect_shift};
         // the grids of the binning kernels: what the slot's previous frame kept, + 25 % (they loop if the frame keeps more)
-        j.bn_grid = sl.kept_hint > 0 ? std::min<uint32_t>(nblk, div_up(sl.kept_hint + sl.kept_hint / 4u, bn_tile) + 64u) : nblk;
+        j.bn_grid = (sl.kept_hint > 0 && j.phase == 0) ? std::min<uint32_t>(nblk, div_up(sl.kept_hint + sl.kept_hint / 4u, bn_tile) + 64u) : (j.phase ? std::min<uint32_t>(nblk, 4096u) : nblk);
 #define GSR_COUNT(I) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin_count<I>), dim3(j.bn_grid), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift - f.rect_shift, \
                                         shd, f.stiles_x, sl.hist, nblk)
         if (j.bn_items == 1) GSR_COUNT(1); else if (j.bn_items == 2) GSR_COUNT(2); else GSR_COUNT(4);

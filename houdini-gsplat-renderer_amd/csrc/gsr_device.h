@@ -81,7 +81,11 @@ struct GsrFrame {
     int32_t cull_dilate;               // tiles by which a rect is widened before it is compared with the horizons (on top of the
                                        // dilation built into the pyramid)
     int32_t rect_shift;                // tile rects are packed in units of (1 << rect_shift) tiles: 0 up to 256 tiles a side, 1 up to 512
+    int32_t phase;                     // front-slab frames (gsr_api.hip): 0 = the whole frame; 1 = only the splats with key <= the slab key
+                                       // (device word, picked by k_slab_pick); 2 = only the ones beyond it, culled against the tiles
+                                       // that phase 1 left opaque
 };
+#define GSR_SLAB_BINS 1024             // k_cluster_cull's histogram of the surviving clusters' nearest keys (k_slab_pick reads it)
 #define GSR_FLAG_NO_ALPHA_RADIUS 1   // bbox from the full +-2 quad instead of the alpha>=1/255 support
 #define GSR_FLAG_NO_SAT          2   // quadrant masks from the bbox only
 #define GSR_FLAG_FULL_KEYS       4   // sort all 32 key bits (no key-range reduction, 8-bit digits)

@@ -73,6 +73,13 @@ struct GsrBlendArgs {
     int32_t flags;              // GSR_FLAG_*
     int32_t list_cap;           // entries the list buffer holds (a speculative launch may see ranges beyond it)
     uint32_t* sup_work;         // [256] work per super-tile, summed over its tiles (or NULL)
+    // front-slab frames (gsr_api.hip): phase 1 (slab = 1) also stores every pixel's transmittance T in tbuf -- the alpha channel
+    // holds 1 - T, which does not give T back bit for bit -- and phase 2 (slab = 2) CONTINUES from the stored (C, T): a tile that
+    // phase 1 left opaque (bit 0 of its tile_work_a entry) is finished, every other tile composites the splats beyond the slab on
+    // top of what it has.  The pixels are those of the one-pass frame, bit for bit: the same records in the same order.
+    int32_t slab;
+    float* tbuf;                // [band pixels]
+    const uint4* tile_work_a;   // phase 2: phase 1's per-tile bookkeeping
 };
 
 // Staging layout: one list PER QUADRANT (= per wave), holding the round's records that reach that
@@ -165,6 +172,20 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     gsr_v2f C01 = {0.0f, 0.0f};   // {C0, C1} as a register pair
     float C2 = 0.0f, T = 1.0f;    // blue, transmittance 1 - A
     bool wave_done = false;
+    if (a.slab == 2) {
+        // front-slab phase 2: finished tiles keep what they have; the others go on from the stored colour and transmittance
+        const uint4 wa = a.tile_work_a[tile];
+        if (wa.w & 1u) {
+            if (tid == 0) tile_work[tile] = make_uint4(0u, 0u, 0u, 1u | (0xffffu << 16));
+            return;
+        }
+        if (pix_ok) {
+            const size_t at = (size_t)(lty * GSR_TILE_PX + (wave >> 1) * 8 + (lane >> 3)) * a.width + (size_t)(tx * GSR_TILE_PX + (wave & 1) * 8 + (lane & 7));
+            const float4 c = out[at];
+            C01 = (gsr_v2f){c.x, c.y}; C2 = c.z; T = a.tbuf[at];
+        }
+        wave_done = __all(!pix_ok || T < GSR_T_MIN);
+    }
     uint32_t fetched = 0;             // (uniform) queued hits handed to the waves
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -381,6 +402,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         const int brow = lty * GSR_TILE_PX + (w2 >> 1) * 8 + (l2 >> 3);
         const int bcol = tx * GSR_TILE_PX + (w2 & 1) * 8 + (l2 & 7);
         out[(size_t)brow * a.width + bcol] = make_float4(C01.x, C01.y, C2, 1.0f - T);
+        if (a.slab == 1) a.tbuf[(size_t)brow * a.width + bcol] = T;
     }
     BLP(8)
 #ifdef BL_PROFILE
@@ -496,6 +518,8 @@ struct GsrHorizonArgs {
     float cam[3];
     unsigned long long* host_end;   // mapped host word: ticket << 32 | "a horizon broke"
     uint32_t ticket;
+    int32_t slab;                   // 2 = the end of a front-slab frame: tiles that phase 1 left opaque were dealt with by k_slab_mid
+    const uint4* tile_work_a;       // ... phase 1's per-tile bookkeeping (added to the frame's counters)
 };
 // per-block partial sums of k_tile_pass
 struct __attribute__((aligned(16))) GsrTilePartial {
@@ -522,6 +546,11 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
     }
     // every phase issues its loads unconditionally (tiles that do not exist read a safe address and discard the value)
     uint4 w = tile_work[ti];
+    // front-slab frames: what phase 1 spent on the tile; a tile it left opaque is finished (its next horizon is k_slab_mid's)
+    uint4 wa = make_uint4(0u, 0u, 0u, 0u);
+    if (hz.slab == 2 && own) wa = hz.tile_work_a[ti];
+    const bool a_done = (wa.w & 1u) != 0u;
+    if (a_done) w = make_uint4(0u, 0u, 0u, 0u);
     const int s0 = sstart[st];
     int e0 = send[st];
     float hold = __builtin_inff();
@@ -543,7 +572,7 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
         // lanes (Morton order): reduce over them first -- atomics that share a cache line serialise like atomics on one address
         // (8160 of them on five lines took 20 us).
         const int gs = g.super_shift < 3 ? g.super_shift : 3;     // the part of a super-tile inside this 8x8 block: 4^gs lanes
-        uint32_t m = opaque ? rd : 0u, open = (own && !opaque) ? 1u : 0u, any = own ? 1u : 0u;
+        uint32_t m = opaque ? rd : 0u, open = (own && !opaque && !a_done) ? 1u : 0u, any = own ? 1u : 0u;
         for (int d = 1; d < (1 << (2 * gs)); d <<= 1) {
             const uint32_t om = __shfl_xor(m, d, 64), oo = __shfl_xor(open, d, 64), oa = __shfl_xor(any, d, 64);
             m = om > m ? om : m; open |= oo; any |= oa;
@@ -578,11 +607,12 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
                 else if (hold < 3.0e38f) h = hold * 1.05f;
             }
             if (len > 0u) { nused = 1u; if (h < 3.0e38f && (unsigned long long)want * 10ull <= (unsigned long long)len * 7ull) nfin = 1u; }
+            if (a_done) { nused = 1u; nfin = 1u; }   // (went opaque inside the front slab)
         }
-        if (inside) hz.raw[gty * g.tiles_x + tx] = h;
+        if (inside && !a_done) hz.raw[gty * g.tiles_x + tx] = h;
     }
-    unsigned long long sc = w.x, fe = w.y, ev = w.z;
-    uint32_t wmax = gsr_tile_weight(w), unsat = (own && !(w.w & 1u) && w.y) ? 1u : 0u;
+    unsigned long long sc = (unsigned long long)w.x + wa.x, fe = (unsigned long long)w.y + wa.y, ev = (unsigned long long)w.z + wa.z;
+    uint32_t wmax = gsr_tile_weight(w) + gsr_tile_weight(wa), unsat = (own && !a_done && !(w.w & 1u) && (w.y || wa.y)) ? 1u : 0u;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         sc += __shfl_down(sc, d, 64); fe += __shfl_down(fe, d, 64); ev += __shfl_down(ev, d, 64); unsat += __shfl_down(unsat, d, 64);
@@ -595,6 +625,59 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
         p.scanned = sc; p.fetched = fe; p.evals = ev; p.wmax = wmax; p.unsat = unsat; p.nused = nused; p.nfin = nfin;
         p.viol = any_viol ? 1u : 0u; p.pad_ = 0u;
         partial[b] = p;
+    }
+}
+
+// The middle of a front-slab frame (gsr_api.hip), one wavefront per 8x8 block of tiles like k_tile_pass.  Phase 1 has composited
+// the splats up to the slab key; a tile whose pixels are all opaque now needs NOTHING of what lies beyond it -- no prediction, no
+// check: raw2 = 0 for such a tile (and for tiles of other ranks), +inf for a tile that is still open; k_horizon_dilate (radius 0)
+// makes the pyramid phase 2 culls against.  For the tiles that are finished this is also the moment to form the horizon of the
+// slot's NEXT frame (k_tile_pass's rule, on phase 1's lists while they exist; a list too short for it was cut by the slab, and
+// the slab's own distance, pushed out by 5 %, stands in).
+__global__ void __launch_bounds__(64)
+k_slab_mid(const uint4* __restrict__ tile_work_a, GsrSumArgs g, const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
+           GsrHorizonArgs hz /* raw (may be NULL), lists, list_cap, geoA, cam, pyr_off */, float* __restrict__ raw2,
+           float* __restrict__ pyr2 /* levels 4, 5 cleared here */, const uint32_t* __restrict__ slab, uint32_t key_min)
+{
+    const int lane = threadIdx.x;
+    const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const int nbx = (g.tiles_x + 7) >> 3;
+    const int b = (int)blockIdx.x, by = b / nbx, bx = b - by * nbx;
+    const int tx = bx * 8 + lx, gty = by * 8 + ly;
+    const bool inside = tx < g.tiles_x && gty < g.tiles_y;
+    if (b == 0) {
+        const int n45 = gsr_pyr_dim(g.tiles_x, 4) * gsr_pyr_dim(g.tiles_y, 4) + gsr_pyr_dim(g.tiles_x, 5) * gsr_pyr_dim(g.tiles_y, 5);
+        for (int i = lane; i < n45; i += 64) pyr2[hz.pyr_off[4] + i] = 0.0f;
+    }
+    bool own = false;
+    int ti = 0, st = 0;
+    if (inside && gsr_shard_owns(g.shard, gty)) {
+        const int lty = g.shard.rpb > 0 ? gty - g.shard.index * g.shard.rpb : gty / g.shard.count;
+        const int i = lty * g.tiles_x + tx;
+        if (i < g.n_tiles) { own = true; ti = i; st = (gty >> g.super_shift) * g.stiles_x + (tx >> g.super_shift); }
+    }
+    const uint4 w = tile_work_a[ti];
+    const int s0 = sstart[st];
+    int e0 = send[st];
+    e0 = e0 < hz.list_cap ? e0 : hz.list_cap;
+    const bool opaque = own && (w.w & 1u) != 0u;
+    if (inside) raw2[gty * g.tiles_x + tx] = (own && !opaque) ? __builtin_inff() : 0.0f;
+    if (hz.raw) {
+        const uint32_t len = (own && e0 > s0) ? (uint32_t)(e0 - s0) : 0u;
+        const uint32_t es = w.w >> 16;
+        const uint32_t rd = (es == 0xffffu || (es << 10) > w.x) ? w.x : (es << 10);
+        const uint32_t first = ((w.w >> 1) & 0x7fffu) << 10;
+        const uint32_t want = rd + ((rd > first ? rd - first : 0u) >> 2) + 1024u;
+        const bool c2 = opaque && rd > 0u && rd <= len && want < len;
+        const uint32_t i2 = hz.lists[c2 ? (uint32_t)s0 + want : 0u].x;
+        const float4 P2 = hz.geoA[c2 ? i2 : 0u];
+        const float dx = P2.x - hz.cam[0], dy = P2.y - hz.cam[1], dz = P2.z - hz.cam[2];
+        const float hnew = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));
+        const uint32_t ka = slab[0];
+        const float slab_d2 = ka == 0xffffffffu ? __builtin_inff() : __builtin_bit_cast(float, ka + key_min);
+        float h = 0.0f;
+        if (own) h = !opaque ? __builtin_inff() : (c2 ? hnew : slab_d2 * 1.05f);
+        if (inside) hz.raw[gty * g.tiles_x + tx] = h;
     }
 }
 

@@ -146,18 +146,29 @@ __device__ __forceinline__ float gsr_pyr_max(const float* __restrict__ pyr, cons
 
 // one thread per cluster; workgroup b handles the clusters [b * per, (b + 1) * per), per = CC_THREADS * rounds, and leaves
 // the ones that stay, in cluster order, at seg[b * per ...] with their number in cnt[b]
+// Front-slab frames (gsr_api.hip): phase 1 also leaves a HISTOGRAM of the surviving clusters' nearest sort keys (slab_hist:
+// GSR_SLAB_BINS bins of width 2^hist_shift over the frame's key range; a cluster without a usable bound counts as nearest), from
+// which k_slab_pick takes the slab key; phase 2 reads that key (slab_key) and drops the clusters that lie wholly in front of it.
 __global__ void __launch_bounds__(CC_THREADS)
 k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __restrict__ clusB, uint32_t nclus, int rounds,
                int enabled, const float* __restrict__ hpyr /* or NULL: no occlusion test */,
-               uint32_t* __restrict__ seg, uint32_t* __restrict__ cnt)
+               uint32_t* __restrict__ seg, uint32_t* __restrict__ cnt,
+               uint32_t* __restrict__ slab_hist /* or NULL */, int hist_shift, const uint32_t* __restrict__ slab_key /* phase 2 */)
 {
     __shared__ uint32_t s_w[CC_THREADS / 64];
+    __shared__ uint32_t s_hist[GSR_SLAB_BINS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t per = (uint32_t)CC_THREADS * (uint32_t)rounds;
     uint32_t kept = 0;
+    if (slab_hist) {
+        for (int b = threadIdx.x; b < GSR_SLAB_BINS; b += CC_THREADS) s_hist[b] = 0u;
+        __syncthreads();
+    }
+    const uint32_t key_a = (f.phase == 2 && slab_key) ? *slab_key : 0u;
     for (int r = 0; r < rounds; ++r) {
         const uint32_t cl = blockIdx.x * per + (uint32_t)r * CC_THREADS + threadIdx.x;
         bool keep = cl < nclus;
+        uint32_t kb_near = 0u;                 // a lower bound of the cluster's sort keys (0 = unknown)
         if (keep && enabled) {
             const float4 A = clusA[cl], B = clusB[cl];
             if (B.w == 0.0f) {
@@ -224,27 +235,43 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                             const int ty0 = (int)__builtin_fmaxf(ylo, 0.0f) >> 4, ty1 = (int)__builtin_fminf(yhi, hm1) >> 4;
                             if (gsr_owned_rows(ty0, ty1, GsrShard{f.shard_index, f.shard_count, f.shard_rpb}) == 0) {
                                 keep = false;                           // none of its tile rows is ours
-                            } else if (hpyr) {
-                                // behind the depth horizon of every tile it can reach (widened by the dilation radius)?  The sort key
-                                // is the distance^2 of the UN-offset position (k_preprocess.h): a lower bound from the raw box
-                                float d2 = 0.0f;
+                            } else if (hpyr || slab_hist || f.phase == 2) {
+                                // The sort key is the distance^2 of the UN-offset position (k_preprocess.h): bounds from the raw box
+                                float d2 = 0.0f, d2far = 0.0f;
 #pragma unroll
                                 for (int k = 0; k < 3; ++k) {
                                     const float d = __builtin_fmaxf(__builtin_fmaxf(plo[k] - f.cam[k], f.cam[k] - phi[k]), 0.0f);
                                     d2 = gsr_fma(d, d, d2);
+                                    const float e = __builtin_fmaxf(__builtin_fabsf(plo[k] - f.cam[k]), __builtin_fabsf(phi[k] - f.cam[k]));
+                                    d2far = gsr_fma(e, e, d2far);
                                 }
                                 d2 *= (1.0f - 1.0e-5f);
+                                d2far *= (1.0f + 1.0e-5f);
                                 uint32_t kb = __builtin_bit_cast(uint32_t, d2);
                                 kb = kb < f.key_min ? f.key_min : (kb > f.key_max ? f.key_max : kb);
                                 kb -= f.key_min;
-                                const int r_ = f.cull_dilate;
-                                const float h = gsr_pyr_max(hpyr, f.pyr_off, f.tiles_x, max(tx0 - r_, 0), max(ty0 - r_, 0), min(tx1 + r_, f.tiles_x - 1), min(ty1 + r_, f.tiles_y - 1));
-                                if (kb > gsr_horizon_key(h, f.key_min, f.key_max)) keep = false;
+                                kb_near = kb;
+                                // front-slab phase 2: every splat of the cluster was drawn by phase 1 (key <= the slab key)
+                                if (f.phase == 2 && d2far < 3.0e38f) {
+                                    uint32_t kf = __builtin_bit_cast(uint32_t, d2far);
+                                    kf = kf < f.key_min ? f.key_min : (kf > f.key_max ? f.key_max : kf);
+                                    if (kf - f.key_min <= key_a) keep = false;
+                                }
+                                // behind the depth horizon of every tile it can reach (widened by the dilation radius)?
+                                if (keep && hpyr) {
+                                    const int r_ = f.cull_dilate;
+                                    const float h = gsr_pyr_max(hpyr, f.pyr_off, f.tiles_x, max(tx0 - r_, 0), max(ty0 - r_, 0), min(tx1 + r_, f.tiles_x - 1), min(ty1 + r_, f.tiles_y - 1));
+                                    if (kb > gsr_horizon_key(h, f.key_min, f.key_max)) keep = false;
+                                }
                             }
                         }
                     }
                 }
             }
+        }
+        if (slab_hist && keep) {
+            const uint32_t b = kb_near >> hist_shift;
+            atomicAdd(&s_hist[b < (uint32_t)GSR_SLAB_BINS ? b : (uint32_t)GSR_SLAB_BINS - 1u], 1u);
         }
         // ordered compaction: ballot ranks inside the wave, wave counts through LDS
         const unsigned long long bal = __ballot(keep);
@@ -258,6 +285,46 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
         __syncthreads();
     }
     if (threadIdx.x == 0) cnt[blockIdx.x] = kept;
+    if (slab_hist) {   // (Morton-ordered clusters: a workgroup's 256 fall into a few dozen bins)
+        __syncthreads();
+        for (int b = threadIdx.x; b < GSR_SLAB_BINS; b += CC_THREADS) {
+            const uint32_t v = s_hist[b];
+            if (v) atomicAdd(&slab_hist[b], v);
+        }
+    }
+}
+
+// Front-slab frames: the slab key = the end of the first histogram bin by which `want` of the surviving clusters have begun
+// (want = max(min_clusters, total * frac_num / 256)); everything when the frame keeps fewer than twice that.  One workgroup;
+// clears the histogram for its next use.  slab[0] = the key (relative to key_min, inclusive), slab[1] = surviving clusters.
+__global__ void __launch_bounds__(GSR_SLAB_BINS)
+k_slab_pick(uint32_t* __restrict__ hist, int hist_shift, uint32_t min_clusters, uint32_t frac_num, uint32_t* __restrict__ slab)
+{
+    __shared__ uint32_t s_wave[GSR_SLAB_BINS / 64];
+    __shared__ uint32_t s_pick;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t v = hist[t];
+    hist[t] = 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) s_wave[wave] = inc;
+    if (t == 0) s_pick = 0xffffffffu;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < GSR_SLAB_BINS / 64; ++w) { const uint32_t c = s_wave[w]; before += w < wave ? c : 0u; total += c; }
+    inc += before;
+    uint32_t want = (uint32_t)(((unsigned long long)total * frac_num) >> 8);
+    want = want < min_clusters ? min_clusters : want;
+    if (total >= 2u * want && inc >= want && inc - v < want) s_pick = (uint32_t)t;    // the bin in which the count crosses `want`
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t b = s_pick;
+        const unsigned long long end = ((unsigned long long)(b + 1u) << hist_shift) - 1ull;
+        slab[0] = (b == 0xffffffffu || end > 0xfffffffeull) ? 0xffffffffu : (uint32_t)end;
+        slab[1] = total;
+    }
 }
 
 // K1's prologue: the inclusive prefix of the cnt[] of k_cluster_cull, in LDS (ngroups <= CC_MAX_GROUPS), returns the

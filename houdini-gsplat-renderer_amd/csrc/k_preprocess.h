@@ -325,7 +325,7 @@ struct GsrK1Front {
 };
 
 __device__ __forceinline__ GsrK1Front
-gsr_k1_front(const GsrFrame& f, const float4 a, const uint4 b, float* __restrict__ zwin_i)
+gsr_k1_front(const GsrFrame& f, const float4 a, const uint4 b, float* __restrict__ zwin_i, uint32_t slab_key = 0xffffffffu)
 {
     GsrK1Front o;
     const float px = a.x, py = a.y, pz = a.z;
@@ -358,6 +358,9 @@ gsr_k1_front(const GsrFrame& f, const float4 a, const uint4 b, float* __restrict
     // w<=0 (:209-214); near/far clip of a constant-z quad; alpha = e*opacity <= opacity
     // can never reach 1/255 when opacity < 1/255 (e <= 1), so those splats draw nothing.
     o.keep = (clw > 0.0f) && !(clz < -clw || clz > clw) && (o.opacity >= (1.0f / 255.0f));
+    // front-slab frames: phase 1 draws the splats up to the slab key, phase 2 the ones beyond it (ties at the key: phase 1)
+    if (f.phase == 1) o.keep = o.keep && o.kb <= slab_key;
+    if (f.phase == 2) o.keep = o.keep && o.kb > slab_key;
     o.far = false;
     o.cx = 0.0f; o.cy = 0.0f;
     if (o.keep) {
@@ -485,7 +488,9 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              uint32_t* __restrict__ zero_cnt /* the small-frame sort's bucket counters (BK_BUCKETS, BK_STRIDE apart), cleared here */,
              uint32_t* __restrict__ zero_n /* ... and the count its scatter accumulates */,
              const uint32_t* __restrict__ order /* position-keyed order (GSR_OPT_SORT_CACHE = 2): slot j holds splat order[j], the splats
-                                                   are walked nearest first and leave already sorted; NULL = storage order */)
+                                                   are walked nearest first and leave already sorted; NULL = storage order */,
+             const uint32_t* __restrict__ slab /* front-slab frames (f.phase != 0): [0] = the slab key (k_slab_pick) */,
+             const float4* __restrict__ clusA, const float4* __restrict__ clusB /* cluster bounds: phase 1 skips the clusters beyond the slab */)
 {
     static_assert(GSR_K1_THREADS == 4 * GSR_CLUSTER, "a K1 workgroup is four clusters");
     __shared__ uint32_t s_inc[CC_MAX_GROUPS];
@@ -498,6 +503,7 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
         if (threadIdx.x == 0) { d_counts[0] = niter * (uint32_t)GSR_K1_THREADS; d_counts[1] = nsurv; d_counts[2] = 0u; if (zero_n) *zero_n = 0u; }
         if (zero_cnt) for (int d = threadIdx.x; d < BK_BUCKETS; d += GSR_K1_THREADS) zero_cnt[(size_t)d * BK_STRIDE] = 0u;
     }
+    const uint32_t slab_key = (f.phase != 0 && slab) ? slab[0] : 0xffffffffu;
     int par = 0;
     for (uint32_t k = blockIdx.x; k < niter; k += gridDim.x, par ^= 1) {
         const uint32_t rank = 4u * k + (uint32_t)wave;
@@ -505,14 +511,31 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
         if (rank < nsurv) {                                   // (wave-uniform)
             const uint32_t cl = cc_find_cluster(s_inc, ngroups, rank, cseg, cper);
             i = cl * (uint32_t)GSR_CLUSTER + (uint32_t)lane;
-            const bool exists = i < n;
+            bool exists = i < n;
+            if (f.phase == 1 && !order) {
+                // the whole cluster beyond the slab?  (the nearest point of its box: a lower bound of its keys, as in k_cluster_cull)
+                const float4 A = clusA[cl], B = clusB[cl];
+                if (B.w == 0.0f) {
+                    float d2 = 0.0f;
+                    const float lo[3] = {A.x, A.y, A.z}, hi[3] = {B.x, B.y, B.z};
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const float d = __builtin_fmaxf(__builtin_fmaxf(lo[q] - f.cam[q], f.cam[q] - hi[q]), 0.0f);
+                        d2 = gsr_fma(d, d, d2);
+                    }
+                    d2 *= (1.0f - 1.0e-5f);
+                    uint32_t kn = __builtin_bit_cast(uint32_t, d2);
+                    kn = kn < f.key_min ? f.key_min : (kn > f.key_max ? f.key_max : kn);
+                    if (kn - f.key_min > slab_key) exists = false;
+                }
+            }
             if (order && exists) i = order[i];
             if (exists) {
                 // geoA and geoB are fetched together; colour only once the splat is known to be needed (fetching it up front
                 // was measured slower: the bytes wasted on culled splats cost more than the second round trip)
                 const float4 a = geoA[i];
                 const uint4 b = geoB[i];
-                const GsrK1Front o = gsr_k1_front(f, a, b, zwin ? zwin + i : nullptr);
+                const GsrK1Front o = gsr_k1_front(f, a, b, zwin ? zwin + i : nullptr, slab_key);
                 if (o.keep && !o.far) out_rect = gsr_k1_back(f, i, cap, o, b, col, rec, lazy, hpyr);
                 kb = o.kb;
             }

@@ -104,6 +104,7 @@ typedef struct gsr_stats {
     int32_t reserved2_;
     int64_t frames_resorted;               /* GSR_OPT_LOCAL_SORT: frames whose small-frame sort met a bucket far beyond its prediction and were
                                               rendered again with the three global passes */
+    int64_t frames_slab;                   /* GSR_OPT_FRONT_SLAB: frames rendered in two phases (front slab, then the rest behind the tiles still open) */
 } gsr_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -305,7 +306,10 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        horizon broke) / 2 (whenever possible): splats behind the depth at which every tile of the super-tiles they reach went
                                        opaque in the previous frame are dropped before projection, sorting and binning.  Exact: the lists
                                        are cut at those horizons, a tile that runs off a cut list without going opaque reports the
-                                       frame, and gsr_render renders it again without culling before it returns (gsr_stats.frames_repaired).
+                                       frame, and gsr_render renders it again (as a front-slab frame where that pays: GSR_OPT_FRONT_SLAB) before it
+                                       returns (gsr_stats.frames_repaired).  3 = never against a previous frame: every frame is a front-slab frame
+                                       (occlusion culling inside the frame only: no prediction, no repairs, a frame time that does not depend on
+                                       how the camera moved).
                                        Off for GSR_OPT_DEFERRED_CHECK frames.  Every rank of gsr_multi / gsr_comm culls and checks its own band. */
 #define GSR_OPT_LAZY_COLOUR      8   /* SH colours only for the splats a frame can composite (the front of every super-tile list, as
                                        deep as the previous frame scanned, with an on-demand fallback) instead of for every visible
@@ -327,6 +331,13 @@ int  gsr_stats_reset(gsr_context* ctx);
                                        scatter into 1024 buckets over the key range that frame kept + one kernel that sorts every bucket locally
                                        (2 launches instead of 9); 0 = always three global LSD passes; 2 = the local form whenever a previous
                                        frame's key range is known.  Same order either way. */
+#define GSR_OPT_FRONT_SLAB      16   /* occlusion culling WITHOUT a previous frame.  A frame that cannot use the previous frame's depth horizons (the
+                                       first frames of a cloud, a camera jump, the re-render of a frame that broke a horizon) is rendered in two
+                                       phases: the nearest splats first (a slab holding ~a tenth of the surviving clusters, picked from a histogram of
+                                       their distances), then -- the tiles that are opaque by then need nothing more, exactly, with no prediction and
+                                       no check -- the rest only where a tile is still open, continuing from the stored colour and transmittance.
+                                       Bit-identical to the one-pass frame.  1 (default) = where occlusion culling pays; 0 = off; 2 = every frame
+                                       that is not culled against a previous frame. */
 int  gsr_set_option(gsr_context* ctx, int option, int value);
 
 /* ---- debug / test access (device -> host copies of intermediates) -------- */

@@ -1588,3 +1588,100 @@ def test_small_frame_sort_backs_off_when_a_tie_run_defeats_it_every_frame(pkg):
         assert 1 <= st["frames_resorted"] <= 4, st["frames_resorted"]      # (16 without the back-off)
     finally:
         ref.close(); eng.close()
+
+
+@pytest.mark.parametrize("shard", [(0, 1, 0), (1, 3, 1), (2, 4, 0)])
+def test_front_slab_frames_are_exact(pkg, oracle, shard):
+    """GSR_OPT_FRONT_SLAB: occlusion culling inside ONE frame.  The nearest splats (a slab picked from a histogram of the surviving
+    clusters' distances) are composited first; the tiles that are opaque by then are finished, and the rest of the cloud is projected,
+    sorted, binned and composited only where a tile is still open, continuing from the stored colour and transmittance.  No
+    previous frame, no prediction, no check -- and every frame must equal the one-pass frame bit for bit: on an orbit, across
+    jumps, from inside the cloud, depth-tested, sharded, with every slab size, and as the repair of a temporally culled frame."""
+    idx, count, layout = shard
+    splats = pkg.scenes.make_scene(400000, seed=197, sh=True, radius=1.0)
+    w, h = 960, 540
+    cams = [pkg.camera.make_camera(w, h, sh_order=3, frame=i) for i in (0, 1, 40, 41, 77)]
+    cams += [pkg.camera.make_camera(w, h, sh_order=3, frame=43, distance=d) for d in (0.5, 2.2, 9.0)]          # inside, near, far
+    cams += [pkg.camera.make_camera(w, h, sh_order=3, frame=9, distance=2.5, pivot=(1.5, 0.4, 0.0))]              # most of the cloud off screen
+    cm = pkg.camera
+    cams += [cm.make_camera(w, h, sh_order=3, frame=3, proj_matrix=cm.orthographic(-1.35, 1.35, -1.35 * h / w, 1.35 * h / w, 0.05, 60.0))]
+    rng = np.random.default_rng(11)
+    depth = np.where(rng.random((h, w)) < 0.5, 0.9973, 1.0).astype(np.float32)
+    plain, eng = pkg.Engine(0), pkg.Engine(0)
+    try:
+        for e in (plain, eng):
+            e.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
+            e.set_row_shard(idx, count)
+            e.upload(splats)
+        plain.set_option(pkg.engine.OPT_OCCLUSION_CULL, 0)
+        want = [plain.render(c).copy() for c in cams]
+        want_d = [plain.render_depth(c, depth).copy() for c in cams[:3]]
+        vis_full = plain.stats()["n_visible"]
+        if count == 1:
+            _check_image(want[0], oracle.render(splats, cams[0], threads=oracle.max_threads()))
+        eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, 3)              # every frame a front-slab frame
+        for k, (c, ref) in enumerate(zip(cams, want)):
+            assert np.array_equal(eng.render(c), ref), f"front-slab frame {k} differs"
+        for k, (c, ref) in enumerate(zip(cams[:3], want_d)):
+            assert np.array_equal(eng.render_depth(c, depth), ref), f"depth-tested front-slab frame {k} differs"
+        st = eng.stats()
+        assert st["frames_slab"] == len(cams) + 3 and st["frames_culled"] == 0 and st["frames_repaired"] == 0, st
+        assert np.array_equal(eng.render(cams[0]), want[0])
+        assert eng.stats()["n_visible"] < 0.5 * vis_full              # (what phase 2 kept: far less than the frame holds)
+    finally:
+        eng.close()
+    # every slab size, from "almost nothing in front" to "everything in front"
+    import os
+    for frac, mn in (("1", "1"), ("128", "64"), ("255", "100000000")):
+        old = {k: os.environ.get(k) for k in ("GSR_SLAB_FRAC", "GSR_SLAB_MIN")}
+        os.environ["GSR_SLAB_FRAC"], os.environ["GSR_SLAB_MIN"] = frac, mn
+        try:
+            e2 = pkg.Engine(0)
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+        try:
+            e2.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
+            e2.set_row_shard(idx, count)
+            e2.set_option(pkg.engine.OPT_OCCLUSION_CULL, 3)
+            e2.upload(splats)
+            for k in (0, 2, 5, 8):
+                assert np.array_equal(e2.render(cams[k]), want[k]), f"slab {frac}/{mn}: frame {k} differs"
+        finally:
+            e2.close()
+    # the default policy: temporal culling in the steady state, a front-slab frame where a horizon broke (the jumps)
+    e3 = pkg.Engine(0)
+    try:
+        e3.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
+        e3.set_row_shard(idx, count)
+        e3.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)
+        e3.set_option(pkg.engine.OPT_FRONT_SLAB, 2)
+        e3.upload(splats)
+        orbit = [pkg.camera.make_camera(w, h, sh_order=3, frame=i) for i in (0, 1, 2, 3, 50, 51, 52, 110, 111)]
+        for k, c in enumerate(orbit):
+            assert np.array_equal(e3.render(c), plain.render(c)), f"default policy: frame {k} differs"
+        st = e3.stats()
+        assert st["frames_slab"] >= 1 and st["frames_culled"] >= 5, st
+    finally:
+        e3.close(); plain.close()
+
+
+def test_a_frame_whose_clusters_are_all_culled_is_empty(pkg, engine):
+    """every cluster off screen / behind the eye: no K1 slot is filled and no sort workgroup runs -- the frame must be EMPTY, not the
+    previous frame's splats walked again (the sorted count of a slot outlives its frame)"""
+    splats = pkg.scenes.make_scene(200000, seed=5, sh=True)
+    cam = pkg.camera.make_camera(640, 360, sh_order=3, frame=2)
+    away = pkg.camera.make_camera(640, 360, sh_order=3, frame=2, pivot=(0.0, 0.0, 0.0), distance=-30.0)     # the cloud behind the eye
+    engine.upload(splats)
+    for mode in (0, 1, 2, 3):
+        engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, mode)
+        try:
+            a = engine.render(cam)
+            assert a[..., 3].max() > 0.5
+            b = engine.render(away)
+            assert not b.any(), f"occlusion culling mode {mode}: {np.count_nonzero(b)} non-zero values in a frame that shows nothing"
+            assert engine.stats()["n_visible"] == 0
+            assert np.array_equal(engine.render(cam), a)
+        finally:
+            engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 1)

@@ -147,9 +147,10 @@ struct FrameSlot {
     float* tbuf = nullptr;             // per pixel of the band: the transmittance phase 1 left
     size_t tbuf_cap = 0;
     float* hpyr2 = nullptr;            // the pyramid of "this tile is finished" phase 2 culls against (GSR_PYR_FLOATS)
-    float* hraw2 = nullptr;            // ... its level 0 before k_horizon_dilate
-    uint32_t* slab = nullptr;          // [GSR_SLAB_BINS + 4] histogram of the surviving clusters' nearest keys; then [0] the slab key, [1] clusters
+    uint32_t* slab = nullptr;          // [GSR_SLAB_BINS + 8] histogram of the surviving clusters' nearest keys; then [0] the slab key, [1] clusters,
+                                       // [2..5] the bucket ranges of the two phases' small-frame sorts (k_slab_pick)
     uint32_t slab_kept = 0;            // splats phase 1 sent to the depth sort
+    uint32_t slab_kept1 = 0, slab_kept2 = 0;   // ... in this slot's LAST front-slab frame, per phase (0 = none yet): which sort a phase takes
     int32_t* redo = nullptr;           // lazy colour: tiles the plain blend kernel gave up (tile_cap entries)
     int32_t* order = nullptr;          // blockIdx -> tile, heaviest tiles first: written by k_tile_order at the end of a frame
     size_t order_cap = 0;              //   for this slot's next frame (valid while the tile geometry stays what it was)
@@ -269,7 +270,8 @@ struct gsr_context {
     int opt_swizzle = 2, opt_timing = 1, opt_sort_cache = 1, opt_super = 0, opt_flags = 0, opt_deferred = 0, opt_lazy = 1, opt_cull = 1, opt_timing_every = 1;
     int opt_cluster = 1, opt_morton = 1, opt_local_sort = 1;
     int opt_slab = 1;                  // front-slab frames (GSR_OPT_FRONT_SLAB): 0 off, 1 where occlusion culling pays but has no horizons, 2 always
-    int slab_frac = 26, slab_min = 4096;   // the slab: this many 256ths of the surviving clusters, at least so many (A/B hooks: GSR_SLAB_FRAC, GSR_SLAB_MIN)
+    int slab_frac = 40, slab_min = 4096, slab_max = 8192;   // the slab: this many 256ths of the surviving clusters, at least / at most so many
+                                       // clusters (A/B hooks: GSR_SLAB_FRAC, GSR_SLAB_MIN, GSR_SLAB_MAX)
     bool classic_once = false;         // the next frame sorts with the three global passes whatever the prediction says
 
     gsr_stats st{};
@@ -390,9 +392,8 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hraw), 512 * 512 * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr2), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hraw2), 512 * 512 * sizeof(float)) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.slab), (GSR_SLAB_BINS + 4) * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMemset(sl.slab, 0, (GSR_SLAB_BINS + 4) * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.slab), (GSR_SLAB_BINS + 8) * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(sl.slab, 0, (GSR_SLAB_BINS + 8) * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.ccnt), CC_MAX_GROUPS * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.bkt_key), (size_t)BK_BUCKETS * BK_CAP * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.bkt_val), (size_t)BK_BUCKETS * BK_CAP * sizeof(uint2)) == hipSuccess;
@@ -437,7 +438,7 @@ static void slot_destroy(FrameSlot& sl)
     dev_free(sl.hist); dev_free(sl.totals);
     dev_free(sl.pvA);
     dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.fb);
-    dev_free(sl.hpyr); dev_free(sl.hraw); dev_free(sl.hpyr2); dev_free(sl.hraw2); dev_free(sl.slab); dev_free(sl.tile_work_a); dev_free(sl.tbuf); dev_free(sl.ccnt); dev_free(sl.bkt_key); dev_free(sl.bkt_val); dev_free(sl.bkt_cnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
+    dev_free(sl.hpyr); dev_free(sl.hraw); dev_free(sl.hpyr2); dev_free(sl.slab); dev_free(sl.tile_work_a); dev_free(sl.tbuf); dev_free(sl.ccnt); dev_free(sl.bkt_key); dev_free(sl.bkt_val); dev_free(sl.bkt_cnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
     if (sl.h_end) (void)hipHostFree(sl.h_end); dev_free(sl.depth_stage);
     dev_free(sl.redo); dev_free(sl.lazy_ctr); dev_free(sl.colour_evals);
     dev_free(sl.counters); dev_free(sl.d_n);
@@ -468,6 +469,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
     if (const char* e = std::getenv("GSR_SCATTER_DIRECT")) c->opt_scatter_direct = std::atoi(e);   // (A/B hook: -1 the general scatter, 0 never direct, 1 direct by frame size, 2 always direct)
     if (const char* e = std::getenv("GSR_SLAB_FRAC")) { const int v = std::atoi(e); if (v >= 1 && v <= 255) c->slab_frac = v; }   // (A/B hook)
     if (const char* e = std::getenv("GSR_SLAB_MIN")) { const int v = std::atoi(e); if (v >= 1) c->slab_min = v; }                 // (A/B hook)
+    if (const char* e = std::getenv("GSR_SLAB_MAX")) { const int v = std::atoi(e); if (v >= 1) c->slab_max = v; }                 // (A/B hook)
     if (const char* e = std::getenv("GSR_BN_ITEMS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) c->opt_bn_items = v; }   // (A/B hook)
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return set_err(GSR_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
@@ -814,7 +816,7 @@ extern "C" int gsr_upload_end(gsr_context* c)
     c->prefix_valid = false;           // lazy colour: the first frame of a new cloud colours every list completely
     c->order_pays = false;
     c->cull_pays = false; c->cull_holdoff = 0; c->cull_backoff = 8; c->cull_streak = 0; c->vis_unculled = 0; c->cull_dilate = c->opt_dilate;
-    for (int k = 0; k < GSR_MAX_SLOTS; ++k) { c->slot[k].surv_hint = 0; c->slot[k].kept_hint = 0; c->slot[k].kept_lo = c->slot[k].kept_hi = 0; c->slot[k].horizon_valid = false; c->slot[k].local_fails = 0; c->slot[k].local_holdoff = 0; }
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k) { c->slot[k].surv_hint = 0; c->slot[k].kept_hint = 0; c->slot[k].kept_lo = c->slot[k].kept_hi = 0; c->slot[k].horizon_valid = false; c->slot[k].local_fails = 0; c->slot[k].local_holdoff = 0; c->slot[k].slab_kept1 = c->slot[k].slab_kept2 = 0; }
     c->lazy_pays = false;              // ... and in automatic mode the first frames are eager until the kernels say it pays
     c->st.n_splats = c->n;
     return GSR_OK;
@@ -1406,9 +1408,8 @@ static int queue_slab_mid(gsr_context* c, FrameSlot& sl)
     for (int l = 0; l < GSR_PYR_LEVELS; ++l) hz.pyr_off[l] = j.f.pyr_off[l];
     hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
     const int nblocks8 = ((j.f.tiles_x + 7) >> 3) * ((j.f.tiles_y + 7) >> 3);
-    hipLaunchKernelGGL(k_slab_mid, dim3((unsigned)nblocks8), dim3(64), 0, s, sl.tile_work_a, g, sl.sstart, sl.send, hz, sl.hraw2, sl.hpyr2,
+    hipLaunchKernelGGL(k_slab_mid, dim3((unsigned)nblocks8), dim3(64), 0, s, sl.tile_work_a, g, sl.sstart, sl.send, hz, sl.hpyr2,
                        sl.slab + GSR_SLAB_BINS, j.f.key_min);
-    hipLaunchKernelGGL(k_horizon_dilate, dim3((unsigned)nblocks8), dim3(64), 0, s, sl.hraw2, j.f.tiles_x, j.f.tiles_y, 0, hz, sl.hpyr2);
     HIP_TRY(hipGetLastError());
     return GSR_OK;
 }
@@ -1499,8 +1500,11 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
             // a front-slab frame: its two phases say nothing about what an ordinary frame keeps (no say in the policies); the next
             // frame -- usually one culled against this frame's horizons -- keeps about what both phases kept, from about as many clusters
             const uint32_t kept = (uint32_t)(box[1] >> 32);
-            if (j.phase == 1) sl.slab_kept = kept;
+            static const bool dbg = std::getenv("GSR_SLAB_DEBUG") != nullptr;
+            if (dbg) fprintf(stderr, "[slab] phase %d: clusters through K1 %u, splats kept %u, pairs %u\n", j.phase, (uint32_t)box[2], kept, D);
+            if (j.phase == 1) { sl.slab_kept = kept; sl.slab_kept1 = std::max(kept, 1u); }
             else {
+                sl.slab_kept2 = std::max(kept, 1u);
                 sl.kept_hint = sl.slab_kept + kept;
                 sl.surv_hint = std::min<uint32_t>((uint32_t)box[2], std::max<uint32_t>(16384u, 2u * div_up(sl.kept_hint, GSR_CLUSTER)));
                 sl.kept_culled = true;
@@ -1788,8 +1792,13 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     const bool local = !cache_hit && !ordered && n_slots > 0 && key_bits > 9 && !(c->opt_flags & GSR_FLAG_FULL_KEYS) && sl.kept_hi > sl.kept_lo && !j.deferred &&
                        !c->classic_once && !held && sl.kept_culled == j.cull && j.phase == 0 &&
                        (c->opt_local_sort >= 2 || (c->opt_local_sort == 1 && sl.kept_hint > 0 && sl.kept_hint <= 500000u));
-    if (!cache_hit) c->classic_once = false;
-    j.local_sort = local;
+    const bool classic_now = c->classic_once;
+    if (!cache_hit && j.phase != 1) c->classic_once = false;   // (the re-render of a front-slab frame: both phases)
+    // front-slab phases: the key range of a phase is k_slab_pick's (on the device); the small-frame sort is taken when the slot's
+    // last front-slab frame kept few enough in that phase (phase 1: the slab holds <= slab_max clusters; the first such frame: global passes)
+    const uint32_t kept_prev = j.phase == 1 ? sl.slab_kept1 : sl.slab_kept2;
+    const bool local_phase = j.phase != 0 && n_slots > 0 && key_bits > 9 && c->opt_local_sort && !classic_now && !held && kept_prev > 0 && kept_prev <= 900000u;
+    j.local_sort = local || local_phase;
     if (n > 0) {
 #ifdef GSR_HOST_TIMING
         const double t_pre = now_us();
@@ -1805,11 +1814,15 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         //  phase 2 culls against the tiles phase 1 finished)
         const int hist_shift = key_bits > 10 ? key_bits - 10 : 0;
         const float* pyr = j.phase == 2 ? sl.hpyr2 : ((j.cull && !ordered) ? sl.hpyr : (const float*)nullptr);
+        const GsrSlabPick pk{(uint32_t)c->slab_min, (uint32_t)c->slab_max, (uint32_t)c->slab_frac, f.key_max - f.key_min};
+        if (j.phase == 1) {   // a first pass for the histogram alone (the pass below takes the slab key from it and keeps the slab's clusters only)
+            const int n45 = gsr_pyr_dim(f.tiles_x, 4) * gsr_pyr_dim(f.tiles_y, 4) + gsr_pyr_dim(f.tiles_x, 5) * gsr_pyr_dim(f.tiles_y, 5);
+            hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, c->opt_cluster,
+                               (const float*)nullptr, sl.cseg, sl.ccnt, 1, sl.slab, hist_shift, sl.slab + GSR_SLAB_BINS, pk, sl.hpyr2 + f.pyr_off[4], n45);
+        }
         hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, ordered ? 0 : c->opt_cluster,
                            pyr, sl.cseg, sl.ccnt,   // (ordered: slots, not clusters -- all of them)
-                           j.phase == 1 ? sl.slab : (uint32_t*)nullptr, hist_shift, j.phase == 2 ? sl.slab + GSR_SLAB_BINS : (const uint32_t*)nullptr);
-        if (j.phase == 1)
-            hipLaunchKernelGGL(k_slab_pick, dim3(1), dim3(GSR_SLAB_BINS), 0, s, sl.slab, hist_shift, (uint32_t)c->slab_min, (uint32_t)c->slab_frac, sl.slab + GSR_SLAB_BINS);
+                           j.phase == 1 ? 2 : (j.phase == 2 ? 3 : 0), sl.slab, hist_shift, sl.slab + GSR_SLAB_BINS, pk, (float*)nullptr, 0);
         // K1 over the survivors, four clusters per workgroup-iteration; the grid follows the slot's previous frame (+25 %), and
         // a frame that keeps more simply loops
         const uint32_t all_iter = div_up(c->nclus, 4u);
@@ -1822,11 +1835,11 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         hipLaunchKernelGGL(k_preprocess, dim3(k1_grid ? k1_grid : 1u), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, (cache_hit || ordered) ? sl.keyB : sl.keyA, (cache_hit || ordered) ? sl.valB : sl.valA,
                            j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.phase == 2 ? sl.hpyr2 : (j.cull ? sl.hpyr : (const float*)nullptr), sl.blk_cnt,
-                           sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts, local ? sl.bkt_cnt : (uint32_t*)nullptr,
+                           sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts, (local || local_phase) ? sl.bkt_cnt : (uint32_t*)nullptr,
                            // (the count of sorted splats starts at zero: a frame whose clusters are ALL culled runs no sort workgroup that
                            //  could say so, and the binning kernels would walk the previous frame's order; a static redraw keeps its order)
                            cache_hit ? (uint32_t*)nullptr : sl.d_n,
-                           ordered ? c->pos_order : (const uint32_t*)nullptr, sl.slab + GSR_SLAB_BINS, c->clusA, c->clusB);
+                           ordered ? c->pos_order : (const uint32_t*)nullptr, sl.slab + GSR_SLAB_BINS);
         hipError_t e = hipGetLastError();
 #ifdef GSR_HOST_TIMING
         if (g_t_verdict > 0) {
@@ -1856,7 +1869,15 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         sl.sort_valid = false;       // (what the slot holds is this frame's kept set only)
         sl.sorted_culled = j.cull;
     } else {
-        if (local) {
+        if (local_phase) {
+            // K1's compacted slots -> bucket regions over the phase's key range (k_slab_pick left it on the device) -> sorted (keyA, valA)
+            const uint32_t* range = sl.slab + GSR_SLAB_BINS + (j.phase == 1 ? 2 : 4);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter_k1<uint2>), dim3(std::max(1u, std::min(div_up(n_slots / RS_SRC_BLOCK, 4u), div_up(j.k1_grid, 4u) + 16u))), dim3(256), 0, s, sl.keyA, sl.valA,
+                               n_slots / RS_SRC_BLOCK, sl.d_counts, 0, 0u, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, sl.d_counts + 2, range);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_local<uint2>), dim3(BK_BUCKETS), dim3(RL_THREADS), 0, s, sl.bkt_cnt, 0, key_bits, 0u,
+                               sl.bkt_key, sl.bkt_val, sl.keyA, sl.valA, sl.d_counts + 2, sl.d_n, range);
+            if (hipGetLastError() != hipSuccess) rc = set_err(GSR_E_HIP, "small-frame sort: launch failed");
+        } else if (local) {
             // BK_BUCKETS buckets of equal width over the key range the previous frame kept, widened by a sixteenth on either side (the
             // view moves); in this frame's key domain (keys are stored relative to key_min)
             const uint64_t span = (uint64_t)sl.kept_hi - sl.kept_lo, margin = span / 16 + 64;

@@ -630,14 +630,14 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
 
 // The middle of a front-slab frame (gsr_api.hip), one wavefront per 8x8 block of tiles like k_tile_pass.  Phase 1 has composited
 // the splats up to the slab key; a tile whose pixels are all opaque now needs NOTHING of what lies beyond it -- no prediction, no
-// check: raw2 = 0 for such a tile (and for tiles of other ranks), +inf for a tile that is still open; k_horizon_dilate (radius 0)
-// makes the pyramid phase 2 culls against.  For the tiles that are finished this is also the moment to form the horizon of the
+// check: level 0 of the pyramid phase 2 culls against = 0 for such a tile (and for tiles of other ranks), +inf for a tile that is
+// still open; the coarser levels are maxima over it.  For the tiles that are finished this is also the moment to form the horizon of the
 // slot's NEXT frame (k_tile_pass's rule, on phase 1's lists while they exist; a list too short for it was cut by the slab, and
 // the slab's own distance, pushed out by 5 %, stands in).
 __global__ void __launch_bounds__(64)
 k_slab_mid(const uint4* __restrict__ tile_work_a, GsrSumArgs g, const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
-           GsrHorizonArgs hz /* raw (may be NULL), lists, list_cap, geoA, cam, pyr_off */, float* __restrict__ raw2,
-           float* __restrict__ pyr2 /* levels 4, 5 cleared here */, const uint32_t* __restrict__ slab, uint32_t key_min)
+           GsrHorizonArgs hz /* raw (may be NULL), lists, list_cap, geoA, cam, pyr_off */,
+           float* __restrict__ pyr2 /* all levels written here */, const uint32_t* __restrict__ slab, uint32_t key_min)
 {
     const int lane = threadIdx.x;
     const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
@@ -645,10 +645,6 @@ k_slab_mid(const uint4* __restrict__ tile_work_a, GsrSumArgs g, const int32_t* _
     const int b = (int)blockIdx.x, by = b / nbx, bx = b - by * nbx;
     const int tx = bx * 8 + lx, gty = by * 8 + ly;
     const bool inside = tx < g.tiles_x && gty < g.tiles_y;
-    if (b == 0) {
-        const int n45 = gsr_pyr_dim(g.tiles_x, 4) * gsr_pyr_dim(g.tiles_y, 4) + gsr_pyr_dim(g.tiles_x, 5) * gsr_pyr_dim(g.tiles_y, 5);
-        for (int i = lane; i < n45; i += 64) pyr2[hz.pyr_off[4] + i] = 0.0f;
-    }
     bool own = false;
     int ti = 0, st = 0;
     if (inside && gsr_shard_owns(g.shard, gty)) {
@@ -661,7 +657,21 @@ k_slab_mid(const uint4* __restrict__ tile_work_a, GsrSumArgs g, const int32_t* _
     int e0 = send[st];
     e0 = e0 < hz.list_cap ? e0 : hz.list_cap;
     const bool opaque = own && (w.w & 1u) != 0u;
-    if (inside) raw2[gty * g.tiles_x + tx] = (own && !opaque) ? __builtin_inff() : 0.0f;
+    {   // the pyramid phase 2 culls against, all levels (k_horizon_dilate's scheme at radius 0: lane = tile in Morton order; levels
+        // 4 and 5 were cleared by phase 1's first k_cluster_cull pass)
+        float v = inside ? ((own && !opaque) ? __builtin_inff() : 0.0f) : 0.0f;
+        if (inside) pyr2[hz.pyr_off[0] + gty * g.tiles_x + tx] = v;
+        v = __builtin_fmaxf(v, __shfl_xor(v, 1, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 2, 64));
+        if ((lane & 3) == 0 && inside) pyr2[hz.pyr_off[1] + (gty >> 1) * gsr_pyr_dim(g.tiles_x, 1) + (tx >> 1)] = v;
+        v = __builtin_fmaxf(v, __shfl_xor(v, 4, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 8, 64));
+        if ((lane & 15) == 0 && inside) pyr2[hz.pyr_off[2] + (gty >> 2) * gsr_pyr_dim(g.tiles_x, 2) + (tx >> 2)] = v;
+        v = __builtin_fmaxf(v, __shfl_xor(v, 16, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 32, 64));
+        if (lane == 0) {
+            pyr2[hz.pyr_off[3] + by * nbx + bx] = v;
+            atomicMax(reinterpret_cast<uint32_t*>(pyr2) + hz.pyr_off[4] + (by >> 1) * gsr_pyr_dim(g.tiles_x, 4) + (bx >> 1), __float_as_uint(v));
+            atomicMax(reinterpret_cast<uint32_t*>(pyr2) + hz.pyr_off[5] + (by >> 2) * gsr_pyr_dim(g.tiles_x, 5) + (bx >> 2), __float_as_uint(v));
+        }
+    }
     if (hz.raw) {
         const uint32_t len = (own && e0 > s0) ? (uint32_t)(e0 - s0) : 0u;
         const uint32_t es = w.w >> 16;

@@ -144,27 +144,98 @@ __device__ __forceinline__ float gsr_pyr_max(const float* __restrict__ pyr, cons
     return h;
 }
 
+// Front-slab frames: the slab key = the end of the first histogram bin by which `want` of the surviving clusters have begun
+// (want = clamp(total * frac_num / 256, min_clusters, max_clusters)); everything when the frame keeps fewer than twice that.
+// Every workgroup of phase 1's second k_cluster_cull pass works it out for itself from the first pass's histogram (a scan of
+// GSR_SLAB_BINS bins: cheaper than a launch in between); workgroup 0 also leaves it in memory for everything behind:
+// slab[0] = the key (relative to key_min, inclusive), slab[1] = surviving clusters; slab[2], [3] = first key and bucket shift
+// of the small-frame sort (k_sort.h) over phase 1's keys [0, key], slab[4], [5] = the same for phase 2's keys (key, key_range].
+// The histogram is cleared by phase 2's pass.
+struct GsrSlabPick {
+    uint32_t min_clusters, max_clusters, frac_num, key_range;
+};
+__device__ __forceinline__ uint32_t gsr_slab_pick(const uint32_t* __restrict__ hist, int hist_shift, const GsrSlabPick& pk, uint32_t* __restrict__ slab,
+                                                  uint32_t* s_wave /* [CC_THREADS / 64] */, uint32_t* s_pick /* [1] */)
+{
+    static_assert(GSR_SLAB_BINS % CC_THREADS == 0, "bins per thread");
+    constexpr int PER = GSR_SLAB_BINS / CC_THREADS;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { v[k] = hist[t * PER + k]; sum += v[k]; }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) s_wave[wave] = inc;
+    if (t == 0) *s_pick = 0xffffffffu;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < CC_THREADS / 64; ++w) { const uint32_t c = s_wave[w]; before += w < wave ? c : 0u; total += c; }
+    uint32_t want = (uint32_t)(((unsigned long long)total * pk.frac_num) >> 8);
+    want = want > pk.max_clusters ? pk.max_clusters : want;
+    want = want < pk.min_clusters ? pk.min_clusters : want;
+    uint32_t run = before + inc - sum;                       // clusters in the bins before this thread's
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (total >= 2u * want && run < want && run + v[k] >= want) *s_pick = (uint32_t)(t * PER + k);   // the bin in which the count crosses `want`
+        run += v[k];
+    }
+    __syncthreads();
+    const uint32_t b = *s_pick;
+    const unsigned long long end = ((unsigned long long)(b + 1u) << hist_shift) - 1ull;
+    const uint32_t key = (b == 0xffffffffu || end > 0xfffffffeull || end >= (unsigned long long)pk.key_range) ? 0xffffffffu : (uint32_t)end;
+    if (blockIdx.x == 0 && t == 0) {
+        slab[0] = key;
+        slab[1] = total;
+        // BK_BUCKETS equal buckets over each phase's key range
+        const unsigned long long w1 = (key == 0xffffffffu ? (unsigned long long)pk.key_range : (unsigned long long)key) + 1ull;
+        int s1 = 0;
+        while (s1 < 31 && (w1 >> s1) > (unsigned long long)BK_BUCKETS) ++s1;
+        slab[2] = 0u; slab[3] = (uint32_t)s1;
+        const unsigned long long w2 = key == 0xffffffffu ? 1ull : (unsigned long long)pk.key_range - key;
+        int s2 = 0;
+        while (s2 < 31 && (w2 >> s2) > (unsigned long long)BK_BUCKETS) ++s2;
+        slab[4] = key == 0xffffffffu ? 0u : key + 1u; slab[5] = (uint32_t)s2;
+    }
+    return key;
+}
+
 // one thread per cluster; workgroup b handles the clusters [b * per, (b + 1) * per), per = CC_THREADS * rounds, and leaves
 // the ones that stay, in cluster order, at seg[b * per ...] with their number in cnt[b]
 // Front-slab frames (gsr_api.hip): phase 1 also leaves a HISTOGRAM of the surviving clusters' nearest sort keys (slab_hist:
 // GSR_SLAB_BINS bins of width 2^hist_shift over the frame's key range; a cluster without a usable bound counts as nearest), from
 // which k_slab_pick takes the slab key; phase 2 reads that key (slab_key) and drops the clusters that lie wholly in front of it.
+// mode (front-slab frames): 0 = an ordinary frame; 1 = phase 1's first pass: the histogram (slab_hist is written; workgroup 0 also
+// clears the top levels of the pyramid k_slab_mid is going to fill, zero_f[0, zero_n)); 2 = phase 1's second pass: the slab key
+// from the histogram (gsr_slab_pick; slab_hist is read), only the slab's clusters stay; 3 = phase 2: slab[0] is read, the clusters
+// wholly inside the slab go, the rest is culled against the tiles phase 1 finished (hpyr), and the histogram is cleared.
 __global__ void __launch_bounds__(CC_THREADS)
 k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __restrict__ clusB, uint32_t nclus, int rounds,
                int enabled, const float* __restrict__ hpyr /* or NULL: no occlusion test */,
                uint32_t* __restrict__ seg, uint32_t* __restrict__ cnt,
-               uint32_t* __restrict__ slab_hist /* or NULL */, int hist_shift, const uint32_t* __restrict__ slab_key /* phase 2 */)
+               int mode, uint32_t* __restrict__ slab_hist, int hist_shift, uint32_t* __restrict__ slab, GsrSlabPick pk,
+               float* __restrict__ zero_f, int zero_n)
 {
     __shared__ uint32_t s_w[CC_THREADS / 64];
     __shared__ uint32_t s_hist[GSR_SLAB_BINS];
+    __shared__ uint32_t s_pick;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t per = (uint32_t)CC_THREADS * (uint32_t)rounds;
     uint32_t kept = 0;
-    if (slab_hist) {
+    uint32_t key_a = 0xffffffffu;
+    if (mode == 1) {
         for (int b = threadIdx.x; b < GSR_SLAB_BINS; b += CC_THREADS) s_hist[b] = 0u;
+        if (blockIdx.x == 0) for (int i = threadIdx.x; i < zero_n; i += CC_THREADS) zero_f[i] = 0.0f;
         __syncthreads();
+    } else if (mode == 2) {
+        key_a = gsr_slab_pick(slab_hist, hist_shift, pk, slab, s_w, &s_pick);
+        __syncthreads();                                       // (s_w is used again below)
+    } else if (mode == 3) {
+        key_a = slab[0];
+        if (blockIdx.x == 0) for (int b = threadIdx.x; b < GSR_SLAB_BINS; b += CC_THREADS) slab_hist[b] = 0u;
     }
-    const uint32_t key_a = (f.phase == 2 && slab_key) ? *slab_key : 0u;
+    const bool want_hist = mode == 1;
     for (int r = 0; r < rounds; ++r) {
         const uint32_t cl = blockIdx.x * per + (uint32_t)r * CC_THREADS + threadIdx.x;
         bool keep = cl < nclus;
@@ -235,7 +306,7 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                             const int ty0 = (int)__builtin_fmaxf(ylo, 0.0f) >> 4, ty1 = (int)__builtin_fminf(yhi, hm1) >> 4;
                             if (gsr_owned_rows(ty0, ty1, GsrShard{f.shard_index, f.shard_count, f.shard_rpb}) == 0) {
                                 keep = false;                           // none of its tile rows is ours
-                            } else if (hpyr || slab_hist || f.phase == 2) {
+                            } else if (hpyr || mode != 0) {
                                 // The sort key is the distance^2 of the UN-offset position (k_preprocess.h): bounds from the raw box
                                 float d2 = 0.0f, d2far = 0.0f;
 #pragma unroll
@@ -251,8 +322,10 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                                 kb = kb < f.key_min ? f.key_min : (kb > f.key_max ? f.key_max : kb);
                                 kb -= f.key_min;
                                 kb_near = kb;
+                                // front-slab phase 1: the whole cluster lies beyond the slab
+                                if (mode == 2 && kb > key_a) keep = false;
                                 // front-slab phase 2: every splat of the cluster was drawn by phase 1 (key <= the slab key)
-                                if (f.phase == 2 && d2far < 3.0e38f) {
+                                if (mode == 3 && d2far < 3.0e38f) {
                                     uint32_t kf = __builtin_bit_cast(uint32_t, d2far);
                                     kf = kf < f.key_min ? f.key_min : (kf > f.key_max ? f.key_max : kf);
                                     if (kf - f.key_min <= key_a) keep = false;
@@ -269,7 +342,7 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                 }
             }
         }
-        if (slab_hist && keep) {
+        if (want_hist && keep) {
             const uint32_t b = kb_near >> hist_shift;
             atomicAdd(&s_hist[b < (uint32_t)GSR_SLAB_BINS ? b : (uint32_t)GSR_SLAB_BINS - 1u], 1u);
         }
@@ -285,45 +358,12 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
         __syncthreads();
     }
     if (threadIdx.x == 0) cnt[blockIdx.x] = kept;
-    if (slab_hist) {   // (Morton-ordered clusters: a workgroup's 256 fall into a few dozen bins)
+    if (want_hist) {   // (Morton-ordered clusters: a workgroup's 256 fall into a few dozen bins)
         __syncthreads();
         for (int b = threadIdx.x; b < GSR_SLAB_BINS; b += CC_THREADS) {
             const uint32_t v = s_hist[b];
             if (v) atomicAdd(&slab_hist[b], v);
         }
-    }
-}
-
-// Front-slab frames: the slab key = the end of the first histogram bin by which `want` of the surviving clusters have begun
-// (want = max(min_clusters, total * frac_num / 256)); everything when the frame keeps fewer than twice that.  One workgroup;
-// clears the histogram for its next use.  slab[0] = the key (relative to key_min, inclusive), slab[1] = surviving clusters.
-__global__ void __launch_bounds__(GSR_SLAB_BINS)
-k_slab_pick(uint32_t* __restrict__ hist, int hist_shift, uint32_t min_clusters, uint32_t frac_num, uint32_t* __restrict__ slab)
-{
-    __shared__ uint32_t s_wave[GSR_SLAB_BINS / 64];
-    __shared__ uint32_t s_pick;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint32_t v = hist[t];
-    hist[t] = 0u;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-    if (lane == 63) s_wave[wave] = inc;
-    if (t == 0) s_pick = 0xffffffffu;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < GSR_SLAB_BINS / 64; ++w) { const uint32_t c = s_wave[w]; before += w < wave ? c : 0u; total += c; }
-    inc += before;
-    uint32_t want = (uint32_t)(((unsigned long long)total * frac_num) >> 8);
-    want = want < min_clusters ? min_clusters : want;
-    if (total >= 2u * want && inc >= want && inc - v < want) s_pick = (uint32_t)t;    // the bin in which the count crosses `want`
-    __syncthreads();
-    if (t == 0) {
-        const uint32_t b = s_pick;
-        const unsigned long long end = ((unsigned long long)(b + 1u) << hist_shift) - 1ull;
-        slab[0] = (b == 0xffffffffu || end > 0xfffffffeull) ? 0xffffffffu : (uint32_t)end;
-        slab[1] = total;
     }
 }
 

@@ -489,8 +489,7 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              uint32_t* __restrict__ zero_n /* ... and the count its scatter accumulates */,
              const uint32_t* __restrict__ order /* position-keyed order (GSR_OPT_SORT_CACHE = 2): slot j holds splat order[j], the splats
                                                    are walked nearest first and leave already sorted; NULL = storage order */,
-             const uint32_t* __restrict__ slab /* front-slab frames (f.phase != 0): [0] = the slab key (k_slab_pick) */,
-             const float4* __restrict__ clusA, const float4* __restrict__ clusB /* cluster bounds: phase 1 skips the clusters beyond the slab */)
+             const uint32_t* __restrict__ slab /* front-slab frames (f.phase != 0): [0] = the slab key (k_slab_pick) */)
 {
     static_assert(GSR_K1_THREADS == 4 * GSR_CLUSTER, "a K1 workgroup is four clusters");
     __shared__ uint32_t s_inc[CC_MAX_GROUPS];
@@ -511,24 +510,7 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
         if (rank < nsurv) {                                   // (wave-uniform)
             const uint32_t cl = cc_find_cluster(s_inc, ngroups, rank, cseg, cper);
             i = cl * (uint32_t)GSR_CLUSTER + (uint32_t)lane;
-            bool exists = i < n;
-            if (f.phase == 1 && !order) {
-                // the whole cluster beyond the slab?  (the nearest point of its box: a lower bound of its keys, as in k_cluster_cull)
-                const float4 A = clusA[cl], B = clusB[cl];
-                if (B.w == 0.0f) {
-                    float d2 = 0.0f;
-                    const float lo[3] = {A.x, A.y, A.z}, hi[3] = {B.x, B.y, B.z};
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const float d = __builtin_fmaxf(__builtin_fmaxf(lo[q] - f.cam[q], f.cam[q] - hi[q]), 0.0f);
-                        d2 = gsr_fma(d, d, d2);
-                    }
-                    d2 *= (1.0f - 1.0e-5f);
-                    uint32_t kn = __builtin_bit_cast(uint32_t, d2);
-                    kn = kn < f.key_min ? f.key_min : (kn > f.key_max ? f.key_max : kn);
-                    if (kn - f.key_min > slab_key) exists = false;
-                }
-            }
+            const bool exists = i < n;
             if (order && exists) i = order[i];
             if (exists) {
                 // geoA and geoB are fetched together; colour only once the splat is known to be needed (fetching it up front

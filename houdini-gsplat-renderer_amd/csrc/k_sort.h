@@ -504,10 +504,12 @@ template <typename V>
 __global__ void __launch_bounds__(256)
 k_bucket_scatter_k1(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in, uint32_t n_blocks_host, const uint32_t* __restrict__ n_dev,
                     int shift, uint32_t lo, const uint32_t* __restrict__ src_cnt, uint32_t* __restrict__ gcnt,
-                    uint32_t* __restrict__ kout, V* __restrict__ vout, uint32_t* __restrict__ failed)
+                    uint32_t* __restrict__ kout, V* __restrict__ vout, uint32_t* __restrict__ failed,
+                    const uint32_t* __restrict__ range_dev = nullptr /* or: { lo, shift } on the device (front-slab phases: k_slab_pick) */)
 {
     __shared__ uint32_t h[BK_BUCKETS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (range_dev) { lo = range_dev[0]; shift = (int)range_dev[1]; }
     // The grid follows the slot's previous frame (like K1's): a frame that fills more slots loops.  The first trip's loads are
     // requested together with the slot count that says whether they exist (every address does: clamped to the host's bound).
     uint32_t n = 0xffffffffu;
@@ -665,8 +667,10 @@ template <typename V>
 __global__ void __launch_bounds__(RL_THREADS)
 k_radix_local(const uint32_t* __restrict__ cnt, int low_bits, int full_bits, uint32_t lo,
               uint32_t* __restrict__ ksrc, V* __restrict__ vsrc, uint32_t* __restrict__ kdst, V* __restrict__ vdst,
-              uint32_t* __restrict__ failed, uint32_t* __restrict__ n_out /* the last workgroup leaves the number of keys here (or NULL) */)
+              uint32_t* __restrict__ failed, uint32_t* __restrict__ n_out /* the last workgroup leaves the number of keys here (or NULL) */,
+              const uint32_t* __restrict__ range_dev = nullptr /* or: { lo, low_bits } on the device (front-slab phases: k_slab_pick) */)
 {
+    if (range_dev) { lo = range_dev[0]; low_bits = (int)range_dev[1]; }
     __shared__ uint32_t wc[4][RL_BINS];
     __shared__ uint32_t dbase[RL_BINS], dcount[RL_BINS], gbase[RL_BINS];
     __shared__ uint32_t s_wave[4];

@@ -327,9 +327,15 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                 // (3) composite: the wave walks its list, two records per iteration in packed FP32
                 const int npairs = (cnt + 1) >> 1;
                 const float4* L = slist[wave];
-                auto blend_pair = [&](int p, gsr_v2f& C01, float& C2, float& T) __attribute__((always_inline)) {
-                    const float4 v0 = L[p * PF4 + 0], v1 = L[p * PF4 + 1], v2 = L[p * PF4 + 2];
-                    const float4 v3 = L[p * PF4 + 3], v4 = L[p * PF4 + 4];
+                struct PairOps { float4 v0, v1, v2, v3, v4, v5; };
+                auto load_pair = [&](int p) __attribute__((always_inline)) {
+                    PairOps o;
+                    o.v0 = L[p * PF4 + 0]; o.v1 = L[p * PF4 + 1]; o.v2 = L[p * PF4 + 2]; o.v3 = L[p * PF4 + 3]; o.v4 = L[p * PF4 + 4];
+                    o.v5 = HAS_DEPTH ? L[p * PF4 + 5] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    return o;
+                };
+                auto blend_ops = [&](const PairOps& o, gsr_v2f& C01, float& C2, float& T) __attribute__((always_inline)) {
+                    const float4 v0 = o.v0, v1 = o.v1, v2 = o.v2, v3 = o.v3, v4 = o.v4;
                     // kappa * (quad-local coordinate) of this pixel for the two records
                     const gsr_v2f q0 = gsr_fma2(lx, (gsr_v2f){v0.x, v0.y}, gsr_fma2(ly, (gsr_v2f){v0.z, v0.w}, (gsr_v2f){v2.x, v2.y}));
                     const gsr_v2f q1 = gsr_fma2(lx, (gsr_v2f){v1.x, v1.y}, gsr_fma2(ly, (gsr_v2f){v1.z, v1.w}, (gsr_v2f){v2.z, v2.w}));
@@ -343,7 +349,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     bool ina = (__builtin_fmaxf(__builtin_fabsf(q0.x), __builtin_fabsf(q1.x)) <= GSR_QLIM) && (arga >= -GSR_LOG2_255);
                     bool inb = (__builtin_fmaxf(__builtin_fabsf(q0.y), __builtin_fabsf(q1.y)) <= GSR_QLIM) && (argb >= -GSR_LOG2_255);
                     if (HAS_DEPTH) {
-                        const float4 v5 = L[p * PF4 + 5];
+                        const float4 v5 = o.v5;
                         ina = ina && (v5.x <= dpx);
                         inb = inb && (v5.y <= dpx);
                     }
@@ -361,6 +367,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     C2 = gsr_fma(wb, v4.z, C2);
                     T = T - wb;
                 };
+                auto blend_pair = [&](int p, gsr_v2f& C01, float& C2, float& T) __attribute__((always_inline)) { blend_ops(load_pair(p), C01, C2, T); };
 #ifdef BL_EXP_DOUBLE   // experiment: the inner loop a second time on shadow accumulators (its marginal cost = the time difference)
                 {
                     gsr_v2f sC01 = C01; float sC2 = C2, sT = T;
@@ -370,10 +377,24 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
 #endif
                 // (the wave looks every BL_CHECK pairs whether its pixels are all opaque: on average it goes opaque half-way
                 //  through a list, and the rest of that list -- ~6 of the tile's ~60 pair iterations -- would be wasted)
+                // BL_CHECK pairs per trip, straight-line (one loop branch and one "all opaque?" ballot per BL_CHECK pairs: written pair by
+                // pair the compiler left four branches and twenty scalar instructions in every iteration), then the remainder
                 int p = 0;
-                for (; p < npairs; ++p) {
-                    blend_pair(p, C01, C2, T);
-                    if ((p & (BL_CHECK - 1)) == BL_CHECK - 1 && __all(!pix_ok || T < GSR_T_MIN)) { ++p; break; }
+                if (!HAS_DEPTH) {
+                    const int nfull = npairs & ~(BL_CHECK - 1);
+                    bool stop = false;
+                    for (; p < nfull && !stop; p += BL_CHECK) {
+#pragma unroll
+                        for (int u = 0; u < BL_CHECK; ++u) blend_pair(p + u, C01, C2, T);
+                        stop = __all(!pix_ok || T < GSR_T_MIN);
+                    }
+                    if (!stop)
+                        for (; p < npairs; ++p) blend_pair(p, C01, C2, T);
+                } else {   // (the depth-tested form carries a sixth operand vector per pair: unrolled it spills)
+                    for (; p < npairs; ++p) {
+                        blend_pair(p, C01, C2, T);
+                        if ((p & (BL_CHECK - 1)) == BL_CHECK - 1 && __all(!pix_ok || T < GSR_T_MIN)) { ++p; break; }
+                    }
                 }
                 my_evals += (uint32_t)(2 * p < cnt ? 2 * p : cnt);
                 BLP(4)

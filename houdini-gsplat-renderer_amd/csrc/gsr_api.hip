@@ -166,6 +166,7 @@ struct FrameSlot {
     // checked there too (did a tile look past the horizon its splats were culled against?); the verdict goes to the mapped word
     // h_end, and the host renders a frame that failed again, without culling, before it hands it over.
     float* hpyr = nullptr;             // pyramid levels 0..3 (k_cluster.h), GSR_PYR_FLOATS floats: what the slot's next frame culls against
+    float* hpyr_next = nullptr;        // ... double-buffered: a frame's last kernels read the one it was culled against while they fill the other
     float* hraw = nullptr;             // per-tile horizons before dilation (k_tile_pass -> k_horizon_dilate)
     int hpyr_re = 0;                   // the dilation radius built into hpyr
     // cluster culling (k_cluster.h): the ordered list of surviving clusters of the frame, as per-workgroup segments
@@ -390,6 +391,7 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.colour_evals), 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.colour_evals, 0, 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr_next), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hraw), 512 * 512 * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr2), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.slab), (GSR_SLAB_BINS + 8) * sizeof(uint32_t)) == hipSuccess;
@@ -438,7 +440,7 @@ static void slot_destroy(FrameSlot& sl)
     dev_free(sl.hist); dev_free(sl.totals);
     dev_free(sl.pvA);
     dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.fb);
-    dev_free(sl.hpyr); dev_free(sl.hraw); dev_free(sl.hpyr2); dev_free(sl.slab); dev_free(sl.tile_work_a); dev_free(sl.tbuf); dev_free(sl.ccnt); dev_free(sl.bkt_key); dev_free(sl.bkt_val); dev_free(sl.bkt_cnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
+    dev_free(sl.hpyr); dev_free(sl.hpyr_next); dev_free(sl.hraw); dev_free(sl.hpyr2); dev_free(sl.slab); dev_free(sl.tile_work_a); dev_free(sl.tbuf); dev_free(sl.ccnt); dev_free(sl.bkt_key); dev_free(sl.bkt_val); dev_free(sl.bkt_cnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
     if (sl.h_end) (void)hipHostFree(sl.h_end); dev_free(sl.depth_stage);
     dev_free(sl.redo); dev_free(sl.lazy_ctr); dev_free(sl.colour_evals);
     dev_free(sl.counters); dev_free(sl.d_n);
@@ -1320,7 +1322,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     // ... and while culling is held off nobody needs horizons: they are prepared again two frames before it may resume.
     // A deferred frame (handed over before its pair count was known) never culls and may have clamped lists: no horizons from it.
     if (c->opt_cull && c->opt_cull != 3 && j.n > 0 && !j.deferred && (c->opt_cull >= 2 || j.cull || j.phase == 2 || (c->vis_unculled >= 300000u && c->cull_holdoff <= 2))) {
-        hz.raw = sl.hraw; hz.pyr_in = sl.hpyr; hz.pyr_out = sl.hpyr; hz.dilate = j.f.cull_dilate; hz.culled = j.cull ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
+        hz.raw = sl.hraw; hz.pyr_in = sl.hpyr; hz.pyr_out = sl.hpyr_next; hz.dilate = j.f.cull_dilate; hz.culled = j.cull ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
         for (int l = 0; l < GSR_PYR_LEVELS; ++l) hz.pyr_off[l] = j.f.pyr_off[l];
         hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
         hz.host_end = j.cull ? sl.h_end_dev : nullptr; hz.ticket = j.ticket;
@@ -1328,21 +1330,24 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     if (j.phase == 2) { hz.slab = 2; hz.tile_work_a = sl.tile_work_a; }
     const int nblocks8 = ((j.f.tiles_x + 7) >> 3) * ((j.f.tiles_y + 7) >> 3);
     hipLaunchKernelGGL(k_tile_pass, dim3((unsigned)nblocks8), dim3(64), 0, s, sl.tile_work, g, sl.sstart, sl.send, hz, sl.partial, sl.st_scan);
-    hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.partial, nblocks8, g, sl.counters, sl.d_n, sl.d_frame,
-                       (j.f.sh_order > 0 && c->opt_lazy) ? c->prefix : (uint32_t*)nullptr,
-                       j.lazy ? reinterpret_cast<const uint32_t*>(sl.lazy_ctr) : (const uint32_t*)nullptr,
-                       sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint,
-                       sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr, hz, sl.st_scan);
-    HIP_TRY(hipGetLastError());
+    uint32_t* const prefix_arg = (j.f.sh_order > 0 && c->opt_lazy) ? c->prefix : (uint32_t*)nullptr;
+    const uint32_t* const redo_arg = j.lazy ? reinterpret_cast<const uint32_t*>(sl.lazy_ctr) : (const uint32_t*)nullptr;
+    uint32_t* const work_next = sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr;
     sl.horizon_valid = hz.raw != nullptr;
     if (sl.horizon_valid) {
-        // the next frame's pyramid: every tile's horizon widened to its neighbourhood (behind k_sum_work: it runs while the
-        // host is still reacting to the verdict)
+        // the frame's sums and verdict, and BESIDE them (one launch) the next frame's pyramid: every tile's horizon widened to its
+        // neighbourhood, into the slot's other pyramid buffer
         sl.hpyr_re = std::min(c->cull_dilate, GSR_DILATE_EXACT_MAX);
-        hipLaunchKernelGGL(k_horizon_dilate, dim3((unsigned)nblocks8), dim3(64), 0, s, sl.hraw, j.f.tiles_x, j.f.tiles_y, sl.hpyr_re, hz, sl.hpyr);
+        hipLaunchKernelGGL(k_frame_end, dim3((unsigned)nblocks8 + 1u), dim3(SW_THREADS), 0, s, sl.partial, nblocks8, g, sl.counters, sl.d_n, sl.d_frame,
+                           prefix_arg, redo_arg, sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint, work_next, hz, sl.st_scan, sl.hpyr_re);
         HIP_TRY(hipGetLastError());
+        std::swap(sl.hpyr, sl.hpyr_next);      // (what the slot's next frame culls against)
         const int sig[7] = {j.f.width, j.f.height, j.f.shard_index, j.f.shard_count, j.f.shard_rpb, j.f.super_shift, (int)c->geo_gen};
         std::memcpy(sl.horizon_sig, sig, sizeof sig);
+    } else {
+        hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.partial, nblocks8, g, sl.counters, sl.d_n, sl.d_frame,
+                           prefix_arg, redo_arg, sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint, work_next, hz, sl.st_scan);
+        HIP_TRY(hipGetLastError());
     }
     // The heaviest-first table is rebuilt every frame where the tiles differ a lot (k_sum_work's verdict); where they do not it is
     // still worth a few microseconds of k_blend's tail (C4: 0.142 -> 0.139 ms), but not the 10 us of k_tile_order every frame:

@@ -558,6 +558,10 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
     const int b = (int)blockIdx.x, by = b / nbx, bx = b - by * nbx;
     const int tx = bx * 8 + lx, gty = by * 8 + ly;
     const bool inside = tx < g.tiles_x && gty < g.tiles_y;
+    if (hz.raw && b == 0) {   // levels 4 and 5 of the NEXT frame's pyramid (the other buffer) are max-reduced by the dilation's workgroups: clear them
+        const int n45 = gsr_pyr_dim(g.tiles_x, 4) * gsr_pyr_dim(g.tiles_y, 4) + gsr_pyr_dim(g.tiles_x, 5) * gsr_pyr_dim(g.tiles_y, 5);
+        for (int i = lane; i < n45; i += 64) hz.pyr_out[hz.pyr_off[4] + i] = 0.0f;
+    }
     bool own = false;
     int ti = 0, st = 0;
     if (inside && gsr_shard_owns(g.shard, gty)) {
@@ -712,8 +716,8 @@ k_slab_mid(const uint4* __restrict__ tile_work_a, GsrSumArgs g, const int32_t* _
     }
 }
 
-__global__ void __launch_bounds__(SW_THREADS)
-k_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g, unsigned long long* __restrict__ counters,
+__device__ __forceinline__ void
+gsr_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g, unsigned long long* __restrict__ counters,
            const uint32_t* __restrict__ n_visible, unsigned long long* __restrict__ summary /* device [8]: fetched by gsr_get_stats */,
            uint32_t* __restrict__ prefix /* [256] lazy colour: list entries to colour per super-tile, next frame (or NULL) */,
            const uint32_t* __restrict__ redo_count /* tiles the plain blend kernel gave up this frame (or NULL) */,
@@ -770,10 +774,6 @@ k_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g
         __threadfence_system();   // out to the host NOW (without it the word left with the kernel's end: a 13 us bubble before the next frame)
     }
     if (sup_work_next) sup_work_next[threadIdx.x] = 0u;
-    if (hz.raw) {   // levels 4 and 5 of the next frame's pyramid are max-reduced by k_horizon_dilate's workgroups: clear them
-        const int n45 = gsr_pyr_dim(g.tiles_x, 4) * gsr_pyr_dim(g.tiles_y, 4) + gsr_pyr_dim(g.tiles_x, 5) * gsr_pyr_dim(g.tiles_y, 5);
-        for (int i = (int)threadIdx.x; i < n45; i += SW_THREADS) hz.pyr_out[hz.pyr_off[4] + i] = 0.0f;
-    }
     {
         const int st = (int)threadIdx.x;
         if (st < g.n_super) {
@@ -825,11 +825,21 @@ k_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g
     }
     SWP(5)
 }
+__global__ void __launch_bounds__(SW_THREADS)
+k_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g, unsigned long long* __restrict__ counters,
+           const uint32_t* __restrict__ n_visible, unsigned long long* __restrict__ summary, uint32_t* __restrict__ prefix,
+           const uint32_t* __restrict__ redo_count, uint32_t* __restrict__ colour_evals, unsigned long long* __restrict__ colour_total,
+           const int32_t* __restrict__ sstart, const int32_t* __restrict__ send, uint32_t* __restrict__ lazy_hint,
+           uint32_t* __restrict__ sup_work_next, GsrHorizonArgs hz, uint32_t* __restrict__ st_scan)
+{
+    gsr_sum_work(partial, nblocks, g, counters, n_visible, summary, prefix, redo_count, colour_evals, colour_total, sstart, send, lazy_hint,
+                 sup_work_next, hz, st_scan);
+}
 
 // raw = per-tile horizons (k_tile_pass); pyr = the pyramid the slot's next frame culls against: level 0 = every tile's horizon
 // widened to the largest of its (2r+1)^2 neighbourhood, levels 1..3 from wave shuffles (lane = tile in Morton order).
-__global__ void __launch_bounds__(64)
-k_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int r, GsrHorizonArgs hz, float* __restrict__ pyr)
+__device__ __forceinline__ void
+gsr_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int r, const GsrHorizonArgs& hz, float* __restrict__ pyr)
 {
     const int lane = threadIdx.x;
     const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
@@ -856,6 +866,31 @@ k_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int r,
         atomicMax(reinterpret_cast<uint32_t*>(pyr) + hz.pyr_off[4] + (by >> 1) * gsr_pyr_dim(tiles_x, 4) + (bx >> 1), __float_as_uint(v));
         atomicMax(reinterpret_cast<uint32_t*>(pyr) + hz.pyr_off[5] + (by >> 2) * gsr_pyr_dim(tiles_x, 5) + (bx >> 2), __float_as_uint(v));
     }
+}
+__global__ void __launch_bounds__(64)
+k_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int r, GsrHorizonArgs hz, float* __restrict__ pyr)
+{
+    gsr_horizon_dilate(raw, tiles_x, tiles_y, r, hz, pyr);
+}
+
+// The end of a frame that leaves horizons, in ONE launch: workgroups 0 .. nblocks - 1 (their first wavefront) dilate the per-tile
+// horizons into the slot's next pyramid, workgroup nblocks sums the frame's counters and posts the culling verdict.  Both read what
+// k_tile_pass left and nothing of each other (the pyramid is double-buffered: k_tile_pass cleared the top levels of the one written
+// here), so the dilation runs beside the sums instead of behind them.
+__global__ void __launch_bounds__(SW_THREADS)
+k_frame_end(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g, unsigned long long* __restrict__ counters,
+            const uint32_t* __restrict__ n_visible, unsigned long long* __restrict__ summary, uint32_t* __restrict__ prefix,
+            const uint32_t* __restrict__ redo_count, uint32_t* __restrict__ colour_evals, unsigned long long* __restrict__ colour_total,
+            const int32_t* __restrict__ sstart, const int32_t* __restrict__ send, uint32_t* __restrict__ lazy_hint,
+            uint32_t* __restrict__ sup_work_next, GsrHorizonArgs hz, uint32_t* __restrict__ st_scan, int dilate_r)
+{
+    if ((int)blockIdx.x == nblocks) {
+        gsr_sum_work(partial, nblocks, g, counters, n_visible, summary, prefix, redo_count, colour_evals, colour_total, sstart, send, lazy_hint,
+                     sup_work_next, hz, st_scan);
+        return;
+    }
+    if (threadIdx.x >= 64) return;
+    gsr_horizon_dilate(hz.raw, g.tiles_x, g.tiles_y, dilate_r, hz, hz.pyr_out);
 }
 
 // Heaviest tiles first.  The blend kernel's workgroups are dispatched in blockIdx order as slots free up; when a frame's tiles

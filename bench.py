@@ -666,12 +666,12 @@ def main():
     if world == 1 and args.cull and not args.no_extra_legs and args.emulate_shard <= 1:
         k3 = min(40, args.steps)
         # (a rotation about a ball-shaped cloud leaves its depth horizons valid; what makes a frame cold is a jump in DISTANCE:
-        #  every other frame from 1.6 x as far, 111 degrees further round)
+        #  every other frame from 1.3 x as far, 111 degrees further round)
         base_d = pkg.scenes.CONFIGS[args.config].get("distance", 4.61995)
         if pkg.scenes.CONFIGS[args.config].get("kind") == "terrain":
-            jcams = [pkg.engine.camera_struct(pkg.scenes.terrain_camera(pkg.camera, W, H, frame=orbit_frame(i, 1), sh_order=order, distance=4.2 * (1.6 if i % 2 else 1.0))) for i in range(k3 + 6)]
+            jcams = [pkg.engine.camera_struct(pkg.scenes.terrain_camera(pkg.camera, W, H, frame=orbit_frame(i, 1), sh_order=order, distance=4.2 * (1.3 if i % 2 else 1.0))) for i in range(k3 + 6)]
         else:
-            jcams = [pkg.engine.camera_struct(pkg.camera.make_camera(W, H, sh_order=order, frame=orbit_frame(i, 1), distance=base_d * (1.6 if i % 2 else 1.0))) for i in range(k3 + 6)]
+            jcams = [pkg.engine.camera_struct(pkg.camera.make_camera(W, H, sh_order=order, frame=orbit_frame(i, 1), distance=base_d * (1.3 if i % 2 else 1.0))) for i in range(k3 + 6)]
         cold = {}
         for name, mode in (("policy", args.cull), ("intra_frame_only", 3)):
             eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, mode)
@@ -687,7 +687,7 @@ def main():
             stc = eng.stats()
             cold[name] = {"value": k3 / dt, "unit": "frames/sec", "steps": k3, "frames_slab": stc["frames_slab"], "frames_culled": stc["frames_culled"],
                           "frames_repaired": stc["frames_repaired"]}
-        cold["note"] = ("every frame jumps 111 degrees round the cloud and to / from 1.6 x the distance: nothing of the previous frame applies.  policy = the default (GSR_OPT_OCCLUSION_CULL = 1, "
+        cold["note"] = ("every frame jumps 111 degrees round the cloud and to / from 1.3 x the distance: nothing of the previous frame applies.  policy = the default (GSR_OPT_OCCLUSION_CULL = 1, "
                         "GSR_OPT_FRONT_SLAB = 1); intra_frame_only = GSR_OPT_OCCLUSION_CULL = 3; compare occlusion_culling.without (every frame unculled)")
         eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, args.cull)
     # extra leg (informational): the same K steps with two frames in flight

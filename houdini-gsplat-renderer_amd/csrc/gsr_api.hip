@@ -284,6 +284,7 @@ struct gsr_context {
     uint32_t vis_unculled = 0;         // splats kept by the last frame that was not culled
     bool cull_pays = false;            // ... and its third: most super-tile lists have a depth horizon (occlusion culling)
     bool cull_weak = false;            // the last culled frame kept > 70 % of what an unculled frame keeps
+    int slab_holdoff = 0;              // a front-slab frame kept more than a third of what an unculled frame keeps (measured break-even: B1 at 0.46 loses 9 %): plain frames for a while
     bool prefix_cheaper = false;       // the list-prefix colour pass would evaluate fewer colours than one per kept splat
     int cull_holdoff = 0, cull_backoff = 8, cull_streak = 0;   // frames without culling after a broken horizon (x4 each time, <= 1024; back to 8 after 64 good frames)
     int cull_dilate = 2;               // tiles by which rects are widened before they are compared with the horizons (grows when horizons break)
@@ -817,7 +818,7 @@ extern "C" int gsr_upload_end(gsr_context* c)
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
     c->prefix_valid = false;           // lazy colour: the first frame of a new cloud colours every list completely
     c->order_pays = false;
-    c->cull_pays = false; c->cull_holdoff = 0; c->cull_backoff = 8; c->cull_streak = 0; c->vis_unculled = 0; c->cull_dilate = c->opt_dilate;
+    c->cull_pays = false; c->slab_holdoff = 0; c->cull_holdoff = 0; c->cull_backoff = 8; c->cull_streak = 0; c->vis_unculled = 0; c->cull_dilate = c->opt_dilate;
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) { c->slot[k].surv_hint = 0; c->slot[k].kept_hint = 0; c->slot[k].kept_lo = c->slot[k].kept_hi = 0; c->slot[k].horizon_valid = false; c->slot[k].local_fails = 0; c->slot[k].local_holdoff = 0; c->slot[k].slab_kept1 = c->slot[k].slab_kept2 = 0; }
     c->lazy_pays = false;              // ... and in automatic mode the first frames are eager until the kernels say it pays
     c->st.n_splats = c->n;
@@ -1511,6 +1512,9 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
             else {
                 sl.slab_kept2 = std::max(kept, 1u);
                 sl.kept_hint = sl.slab_kept + kept;
+                // a slab behind which most of the frame still has to be drawn (a ball seen from afar: its near cap finishes few tiles;
+                // oblique ground; a wall) costs more than it saves
+                if (c->vis_unculled > 0 && (unsigned long long)sl.kept_hint * 3ull > (unsigned long long)c->vis_unculled) c->slab_holdoff = 256;
                 sl.surv_hint = std::min<uint32_t>((uint32_t)box[2], std::max<uint32_t>(16384u, 2u * div_up(sl.kept_hint, GSR_CLUSTER)));
                 sl.kept_culled = true;
             }
@@ -1700,7 +1704,10 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         const bool hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now) && !j.cull && !sl.sorted_culled;   // (a static redraw)
         const bool slab = phase_in == 0 && !j.cull && !j.deferred && n > 0 && c->opt_slab && c->opt_cull && c->opt_cluster && c->bbox_ok &&
                           !(c->opt_flags & GSR_FLAG_FULL_KEYS) && c->opt_sort_cache < 2 && !hit &&
-                          (c->opt_slab >= 2 || c->opt_cull == 3 || (c->cull_pays && !c->cull_weak && c->vis_unculled >= 300000u));
+                          // (where a frame is heavy enough for two phases' worth of launches to be repaid: C3's 0.8 M visible splats are not.
+                          //  Not tied to cull_weak: horizons of another view cull weakly whatever the scene; a slab that is weak holds ITSELF off)
+                          (c->opt_slab >= 2 || c->opt_cull == 3 || (c->cull_pays && c->vis_unculled >= 1500000u && c->slab_holdoff == 0));
+        if (phase_in == 0 && c->slab_holdoff > 0) c->slab_holdoff -= 1;
         j.phase = phase_in == 2 ? 2 : (slab ? 1 : 0);
         j.f.phase = j.phase;
         if (j.phase) { j.lazy = false; j.timing = false; }     // (a phase keeps about what it composites: K1 shades on the spot)

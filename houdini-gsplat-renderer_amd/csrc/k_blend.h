@@ -631,11 +631,13 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
                 if (c2) h = hnew;
                 else if (hold < 3.0e38f) h = hold * 1.05f;
             }
-            if (len > 0u) { nused = 1u; if (h < 3.0e38f && (unsigned long long)want * 10ull <= (unsigned long long)len * 7ull) nfin = 1u; }
-            if (a_done) { nused = 1u; nfin = 1u; }   // (went opaque inside the front slab)
         }
         if (inside && !a_done) hz.raw[gty * g.tiles_x + tx] = h;
     }
+    // would occlusion culling have something to work with?  Judged on every frame, with or without horizons being prepared: a tile
+    // that draws anything counts, and counts as "finished early" when it went opaque in the first 70 % of its list
+    if (own && len > 0u) { nused = 1u; if (opaque && rd > 0u && rd <= len && (unsigned long long)want * 10ull <= (unsigned long long)len * 7ull) nfin = 1u; }
+    if (a_done) { nused = 1u; nfin = 1u; }   // (went opaque inside the front slab)
     unsigned long long sc = (unsigned long long)w.x + wa.x, fe = (unsigned long long)w.y + wa.y, ev = (unsigned long long)w.z + wa.z;
     uint32_t wmax = gsr_tile_weight(w) + gsr_tile_weight(wa), unsat = (own && !a_done && !(w.w & 1u) && (w.y || wa.y)) ? 1u : 0u;
 #pragma unroll
@@ -811,8 +813,7 @@ gsr_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs
                                     // bit 3: in a frame like this one the list-prefix colour pass would evaluate fewer colours than one per
                                     // kept splat (a culled frame that still keeps a lot: oblique ground, silhouettes)
                                     ((prefix && (unsigned long long)s_est * 3ull < (unsigned long long)nvis * 2ull) ? 8u : 0u) |
-                                    ((hz.raw && (hz.culled || ((unsigned long long)s_nfin * 10ull >= (unsigned long long)s_nused * 3ull &&
-                                                               s_nused > 0u))) ? 4u : 0u);
+                                    ((hz.culled || ((unsigned long long)s_nfin * 10ull >= (unsigned long long)s_nused * 3ull && s_nused > 0u)) ? 4u : 0u);
         // running totals: plain read-modify-write (a slot's frames are serialised on its stream; nothing else touches them)
         const unsigned long long t2 = old2 + s_sum[1], t4 = old4 + s_sum[0], t5 = old5 + s_sum[2];
         counters[1] = s_sum[1]; counters[2] = t2; counters[3] = s_sum[0]; counters[4] = t4; counters[5] = t5;

@@ -750,7 +750,7 @@ def main():
     shards = args.emulate_shard if (world == 1 and args.emulate_shard > 1) else world
     srank = (args.emulate_rank % shards) if (world == 1 and args.emulate_shard > 1) else rank
     own_px = sum(min(16, H - r * 16) for r in pkg.multigpu.owned_tile_rows(H, srank, shards, args.shard_layout)) * W
-    regime = "culled" if st["frames_culled"] * 2 > st["frames"] else "unculled"
+    regime = "culled" if st["frames_culled"] * 2 > st["frames"] else ("slab" if st["frames_slab"] * 2 > st["frames"] else "unculled")
     tj, traffic_from = load_traffic(regime, world == 1 and args.config == "C4" and args.splats is None)
     hbm = measured_hbm_peak() if rank == 0 else None
     peak_meas = hbm["peak_GBps"] if hbm else None

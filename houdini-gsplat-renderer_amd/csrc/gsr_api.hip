@@ -1556,6 +1556,7 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
         // front slab composited: find the finished tiles, then the rest of the frame (same slot, same call arguments)
         int rc = queue_slab_mid(c, sl);
         if (rc) return frame_abort(sl, rc);
+        if (j.timing) { sl.ev_pending = true; sl.ev_all = false; }
         j.open = false;
         const gsr_camera cam = j.cam_arg;
         const float* depth = j.depth_arg;
@@ -1710,7 +1711,11 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         if (phase_in == 0 && c->slab_holdoff > 0) c->slab_holdoff -= 1;
         j.phase = phase_in == 2 ? 2 : (slab ? 1 : 0);
         j.f.phase = j.phase;
-        if (j.phase) { j.lazy = false; j.timing = false; }     // (a phase keeps about what it composites: K1 shades on the spot)
+        if (j.phase) {   // (a phase keeps about what it composites: K1 shades on the spot; events only around phase 1's blend kernel)
+            j.lazy = false;
+            j.timing = j.phase == 1 && j.timing && c->opt_timing == 1;
+            j.timing_all = false;
+        }
         if (j.phase == 2) j.f.cull_dilate = 0;                 // (this frame's own tiles: nothing moves)
         if (j.phase == 1) c->st.frames_slab += 1;
     }

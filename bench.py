@@ -673,7 +673,7 @@ def main():
         else:
             jcams = [pkg.engine.camera_struct(pkg.camera.make_camera(W, H, sh_order=order, frame=orbit_frame(i, 1), distance=base_d * (1.3 if i % 2 else 1.0))) for i in range(k3 + 6)]
         cold = {}
-        for name, mode in (("policy", args.cull), ("intra_frame_only", 3)):
+        for name, mode in (("policy", args.cull), ("intra_frame_only", 3), ("one_pass", 0)):
             eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, mode)
             for i in range(6):
                 eng.render_struct_to_device(jcams[i], band.data_ptr())
@@ -686,9 +686,9 @@ def main():
             dt = time.perf_counter() - t0
             stc = eng.stats()
             cold[name] = {"value": k3 / dt, "unit": "frames/sec", "steps": k3, "frames_slab": stc["frames_slab"], "frames_culled": stc["frames_culled"],
-                          "frames_repaired": stc["frames_repaired"]}
+                          "frames_repaired": stc["frames_repaired"], "frames_jumped": stc["frames_jumped"]}
         cold["note"] = ("every frame jumps 111 degrees round the cloud and to / from 1.3 x the distance: nothing of the previous frame applies.  policy = the default (GSR_OPT_OCCLUSION_CULL = 1, "
-                        "GSR_OPT_FRONT_SLAB = 1); intra_frame_only = GSR_OPT_OCCLUSION_CULL = 3; compare occlusion_culling.without (every frame unculled)")
+                        "GSR_OPT_FRONT_SLAB = 1); intra_frame_only = GSR_OPT_OCCLUSION_CULL = 3; one_pass = GSR_OPT_OCCLUSION_CULL = 0 on the same cameras")
         eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, args.cull)
     # extra leg (informational): the same K steps with two frames in flight
     pipelined = None

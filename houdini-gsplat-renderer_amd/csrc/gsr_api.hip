@@ -186,6 +186,7 @@ struct FrameSlot {
     unsigned long long* h_end_dev = nullptr;
     bool horizon_valid = false;
     int horizon_sig[7] = {0, 0, 0, 0, 0, 0, 0};   // tile geometry + geometry generation the horizons belong to
+    gsr_camera horizon_cam{};                     // ... and the camera of the frame that left them (camera_jumped)
     bool sorted_culled = false;        // the cached depth order holds a culled frame's splats only
     unsigned long long* lazy_ctr = nullptr;   // [0] low word: redo count of the frame, [1]: colours evaluated (running)
     uint32_t* colour_evals = nullptr;         // [256] colours evaluated per super-tile list (this frame; folded into lazy_ctr[1])
@@ -1345,6 +1346,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
         std::swap(sl.hpyr, sl.hpyr_next);      // (what the slot's next frame culls against)
         const int sig[7] = {j.f.width, j.f.height, j.f.shard_index, j.f.shard_count, j.f.shard_rpb, j.f.super_shift, (int)c->geo_gen};
         std::memcpy(sl.horizon_sig, sig, sizeof sig);
+        sl.horizon_cam = j.cam_arg;
     } else {
         hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.partial, nblocks8, g, sl.counters, sl.d_n, sl.d_frame,
                            prefix_arg, redo_arg, sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint, work_next, hz, sl.st_scan);
@@ -1451,6 +1453,42 @@ static int wait_mailbox(FrameSlot& sl, volatile unsigned long long* box, uint32_
     }
     *out = v;
     return GSR_OK;
+}
+
+// Did the camera JUMP since the frame that left the slot's depth horizons (a cut, a viewport switch, "home")?  Horizons tolerate a
+// view that moves by a few tiles per frame (they are widened by the dilation radius, 16 tiles at most) and distances that change by
+// a few per cent (a horizon sits a quarter of the tile's depth range behind what the tile needed).  Beyond that a culled attempt is
+// wasted -- its check fails and the frame is rendered again -- so such a frame is rendered as if the slot had no horizons (a
+// front-slab frame where that pays).  A heuristic on nine reference points (the corners and the centre of the cloud's bounding
+// box: their direction as seen from the camera, and their distance); whatever it answers, the pixels are the same.
+static bool camera_jumped(const gsr_context* c, const gsr_camera& was, const gsr_camera& now)
+{
+    if (!c->bbox_ok) return false;
+    double diag2 = 0.0;
+    for (int k = 0; k < 3; ++k) diag2 += ((double)c->bb_hi[k] - c->bb_lo[k]) * ((double)c->bb_hi[k] - c->bb_lo[k]);
+    if (!(diag2 > 0.0) || !std::isfinite(diag2)) return false;
+    const double near2 = diag2 / 16.0;                              // reference points closer than a quarter of the diagonal say nothing
+    const double focal_px = 0.5 * std::fabs((double)now.proj[0]) * now.width;
+    const double max_px = 24.0 * GSR_TILE_PX;
+    int used = 0;
+    for (int k = 0; k < 9; ++k) {
+        double p[3], va[3], vb[3], da2 = 0.0, db2 = 0.0;
+        for (int a = 0; a < 3; ++a) p[a] = k < 8 ? (((k >> a) & 1) ? c->bb_hi[a] : c->bb_lo[a]) : 0.5 * ((double)c->bb_lo[a] + c->bb_hi[a]);
+        for (int r = 0; r < 3; ++r) {                               // view-space positions (GL column-major: m[c * 4 + r])
+            va[r] = was.obj_view[r] * p[0] + was.obj_view[4 + r] * p[1] + was.obj_view[8 + r] * p[2] + was.obj_view[12 + r];
+            vb[r] = now.obj_view[r] * p[0] + now.obj_view[4 + r] * p[1] + now.obj_view[8 + r] * p[2] + now.obj_view[12 + r];
+            da2 += va[r] * va[r]; db2 += vb[r] * vb[r];
+        }
+        if (!(da2 > near2) || !(db2 > near2) || !std::isfinite(da2) || !std::isfinite(db2)) continue;
+        ++used;
+        const double ratio2 = db2 / da2;
+        if (ratio2 > 1.25 * 1.25 || ratio2 < 0.8 * 0.8) return true;
+        const double cosang = (va[0] * vb[0] + va[1] * vb[1] + va[2] * vb[2]) / std::sqrt(da2 * db2);
+        const double ang = std::acos(std::min(1.0, std::max(-1.0, cosang)));
+        if (ang * focal_px > max_px) return true;
+    }
+    (void)used;
+    return false;
 }
 
 static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth, int depth_is_device,
@@ -1686,6 +1724,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         const int sig[7] = {f.width, f.height, f.shard_index, f.shard_count, f.shard_rpb, f.super_shift, (int)c->geo_gen};
         j.cull = allow_cull && phase_in == 0 && c->opt_cull && !j.deferred && n > 0 && sl.horizon_valid && std::memcmp(sig, sl.horizon_sig, sizeof sig) == 0 &&
                  !(c->opt_flags & GSR_FLAG_FULL_KEYS) && c->opt_cull != 3 && (c->opt_cull >= 2 || (c->cull_pays && c->cull_holdoff == 0));
+        if (j.cull && c->opt_cull == 1 && camera_jumped(c, sl.horizon_cam, *cam)) { j.cull = false; c->st.frames_jumped += 1; }
         if (allow_cull && phase_in == 0 && c->cull_holdoff > 0) c->cull_holdoff -= 1;
         j.f.cull_dilate = std::max(c->cull_dilate - sl.hpyr_re, 0);   // (the rest of the radius is built into the slot's pyramid)
         if (j.cull) {

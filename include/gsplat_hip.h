@@ -105,6 +105,7 @@ typedef struct gsr_stats {
     int64_t frames_resorted;               /* GSR_OPT_LOCAL_SORT: frames whose small-frame sort met a bucket far beyond its prediction and were
                                               rendered again with the three global passes */
     int64_t frames_slab;                   /* GSR_OPT_FRONT_SLAB: frames rendered in two phases (front slab, then the rest behind the tiles still open) */
+    int64_t frames_jumped;                 /* frames whose camera had jumped since the frame that left the depth horizons: rendered without them (policy mode only) */
 } gsr_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */

@@ -9,7 +9,7 @@
 #ifdef GSR_KPROF
 #include <hip/hip_runtime.h>
 __device__ unsigned long long g_kprof[8][16];
-__device__ unsigned int g_kprof_blk[4][2][8192];   // per kernel and workgroup: [0] duration in 10 ns, [1] items
+__device__ unsigned int g_kprof_blk[5][2][8192];   // per kernel and workgroup: [0] duration in 10 ns, [1] items
 #define KPROF_BLK_BEGIN const unsigned long long kp0_ = wall_clock64();
 #define KPROF_BLK_END(k, items) { if (threadIdx.x == 0 && blockIdx.x < 8192) { g_kprof_blk[k][0][blockIdx.x] = (unsigned int)(wall_clock64() - kp0_); g_kprof_blk[k][1][blockIdx.x] = (unsigned int)(items); } }
 #define KPROF(k, i) { if (blockIdx.x == 0 && threadIdx.x == 0) g_kprof[k][i] = wall_clock64(); }

@@ -496,7 +496,10 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
     __shared__ uint32_t s_wcnt[2][GSR_K1_THREADS / 64];
     __shared__ uint32_t s_scan[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    KPROFB(4, 0, gridDim.x / 2)
+    KPROF_BLK_BEGIN
     const uint32_t nsurv = cc_prefix_to_lds(ccnt, ngroups, s_inc, s_scan);
+    KPROFB(4, 1, gridDim.x / 2)
     const uint32_t niter = (nsurv + 3u) / 4u;
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) { d_counts[0] = niter * (uint32_t)GSR_K1_THREADS; d_counts[1] = nsurv; d_counts[2] = 0u; if (zero_n) *zero_n = 0u; }
@@ -517,6 +520,9 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
                 // was measured slower: the bytes wasted on culled splats cost more than the second round trip)
                 const float4 a = geoA[i];
                 const uint4 b = geoB[i];
+#ifdef GSR_KPROF
+                if (k == blockIdx.x && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_kprof[4][2] = wall_clock64(); }
+#endif
                 const GsrK1Front o = gsr_k1_front(f, a, b, zwin ? zwin + i : nullptr, slab_key);
                 if (o.keep && !o.far) out_rect = gsr_k1_back(f, i, cap, o, b, col, rec, lazy, hpyr);
                 kb = o.kb;
@@ -526,6 +532,7 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
         // the head of its 256 slots, with their number in blk_cnt: the depth sort's first pass gathers those prefixes (k_sort.h,
         // GATHER) instead of reading one key per splat, and, the slots being in storage order, equal keys leave the stable
         // sort in storage order.
+        if (k == blockIdx.x) { KPROFB(4, 3, gridDim.x / 2) }
         const bool stays = out_rect != GSR_RECT_EMPTY;
         const unsigned long long bal = __ballot(stays);
         if (lane == 0) s_wcnt[par][wave] = (uint32_t)__builtin_popcountll(bal);
@@ -539,7 +546,9 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
             val[pos] = make_uint2(i, out_rect);   // sort payload: storage index + tile rect
         }
         if (threadIdx.x == 0) blk_cnt[k] = total;
+        if (k == blockIdx.x) { KPROFB(4, 4, gridDim.x / 2) }
     }
+    KPROF_BLK_END(4, (blockIdx.x < niter ? 1u : 0u) + (niter > blockIdx.x ? (niter - 1u - blockIdx.x) / gridDim.x : 0u))
 }
 
 // upload time: per-workgroup partial bounding boxes of the positions (finished on the host)

@@ -26,18 +26,22 @@ for f in range(40):
         acc += d; cnt += 1
 labels = {0: ("k_bin_place", ["ranges (scan of the totals)", "n, tile", "zero the lane masks", "load splats + (A) masks", "(S) counts", "positions", "(B) place"]),
           1: ("k_bucket_scatter", ["n, zero LDS", "gather + LDS count", "reservations (global atomics)", "scatter"]),
-          2: ("k_radix_local (bucket 512)", ["prefix of the bucket counts", "load keys", "LSD passes in LDS", "ties", "store"])}
+          2: ("k_radix_local (bucket 512)", ["prefix of the bucket counts", "load keys", "LSD passes in LDS", "ties", "store"]),
+          4: ("k_preprocess (the workgroup in the middle of the grid, first iteration)", ["prologue: prefix of the cluster counts", "find cluster + geoA/geoB arrive", "front + back (chain, horizons, colour, record)", "compaction + key/payload store"])}
 for k, (nm, labs) in labels.items():
     print(nm)
     for i, l in enumerate(labs, start=1):
         print("   %-34s %6.2f us" % (l, acc[k, i] / max(cnt, 1)))
 
 fb = lib.gsr_debug_kprof_blocks; fb.argtypes = [C.c_void_p]
-blk = np.zeros((4, 2, 8192), np.uint32); fb(blk.ctypes.data)
-for k, nm in ((1, "k_bucket_scatter"), (2, "k_radix_local"), (3, "k_bin_count"), (0, "k_bin_place")):
+blk = np.zeros((5, 2, 8192), np.uint32); fb(blk.ctypes.data)
+for k, nm in ((4, "k_preprocess"), (1, "k_bucket_scatter"), (2, "k_radix_local"), (3, "k_bin_count"), (0, "k_bin_place")):
     dur, items = blk[k, 0] / 100.0, blk[k, 1].copy()
     if k in (0, 3): items[(eng.stats()["n_visible"] + 1023) // 1024:] = 0      # (entries of earlier, larger frames)
     live = items > 0
+    if k == 4:
+        idle = (items == 0) & (dur > 0)
+        if idle.any(): print("k_preprocess      workgroups without an iteration (prologue only): %d, median %.1f us" % (int(idle.sum()), float(np.median(dur[idle]))))
     if not live.any(): continue
     print("%-17s last frame: %4d workgroups with items; items median %4d p90 %4d max %4d; workgroup time median %5.1f p90 %5.1f max %5.1f us (%d items)" % (
         nm, int(live.sum()), *np.quantile(items[live], [0.5, 0.9, 1.0]).astype(int), *np.quantile(dur[live], [0.5, 0.9, 1.0]), int(items[np.argmax(np.where(live, dur, 0))])))

@@ -259,6 +259,7 @@ struct gsr_context {
     uint32_t* blk_pre = nullptr;       // exclusive prefix of K1's per-iteration counts (k_scan_counts)
     size_t blk_pre_cap = 0;
     int opt_order_keep = 32;           // (A/B hook, GSR_ORDER_KEEP in the environment: 0 = no tile order where the tiles are alike)
+    int opt_k1_scatter = 1;            // (A/B hook, GSR_K1_SCATTER) the small-frame sort's bucket pass inside K1 (0: a kernel of its own behind it)
     int opt_scatter_direct = 1;        // (A/B hook, GSR_SCATTER_DIRECT in the environment) the small-frame sort's scatter: one workgroup per K1 block
     int opt_bn_items = 0;              // (A/B hook, GSR_BN_ITEMS in the environment: 1, 2 or 4 splats per binning thread; 0 = by frame size)
     int nslots = 1;                    // frames in flight (GSR_OPT_FRAMES_IN_FLIGHT): serial by default -- occlusion culling wants the
@@ -471,6 +472,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
     c->device = device;
     if (const char* e = std::getenv("GSR_ORDER_KEEP")) c->opt_order_keep = std::atoi(e);   // (A/B hook)
     if (const char* e = std::getenv("GSR_SCATTER_DIRECT")) c->opt_scatter_direct = std::atoi(e);   // (A/B hook: -1 the general scatter, 0 never direct, 1 direct by frame size, 2 always direct)
+    if (const char* e = std::getenv("GSR_K1_SCATTER")) c->opt_k1_scatter = std::atoi(e);   // (A/B hook)
     if (const char* e = std::getenv("GSR_SLAB_FRAC")) { const int v = std::atoi(e); if (v >= 1 && v <= 255) c->slab_frac = v; }   // (A/B hook)
     if (const char* e = std::getenv("GSR_SLAB_MIN")) { const int v = std::atoi(e); if (v >= 1) c->slab_min = v; }                 // (A/B hook)
     if (const char* e = std::getenv("GSR_SLAB_MAX")) { const int v = std::atoi(e); if (v >= 1) c->slab_max = v; }                 // (A/B hook)
@@ -1855,6 +1857,10 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     const uint32_t kept_prev = j.phase == 1 ? sl.slab_kept1 : sl.slab_kept2;
     const bool local_phase = j.phase != 0 && n_slots > 0 && key_bits > 9 && c->opt_local_sort && !classic_now && !held && kept_prev > 0 && kept_prev <= 900000u;
     j.local_sort = local || local_phase;
+    GsrK1Scatter scat{};
+    uint32_t bk_lo = 0u;
+    int bk_shift = 0;
+    bool k1_scatters = false;
     if (n > 0) {
 #ifdef GSR_HOST_TIMING
         const double t_pre = now_us();
@@ -1874,11 +1880,29 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         if (j.phase == 1) {   // a first pass for the histogram alone (the pass below takes the slab key from it and keeps the slab's clusters only)
             const int n45 = gsr_pyr_dim(f.tiles_x, 4) * gsr_pyr_dim(f.tiles_y, 4) + gsr_pyr_dim(f.tiles_x, 5) * gsr_pyr_dim(f.tiles_y, 5);
             hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, c->opt_cluster,
-                               (const float*)nullptr, sl.cseg, sl.ccnt, 1, sl.slab, hist_shift, sl.slab + GSR_SLAB_BINS, pk, sl.hpyr2 + f.pyr_off[4], n45);
+                               (const float*)nullptr, sl.cseg, sl.ccnt, 1, sl.slab, hist_shift, sl.slab + GSR_SLAB_BINS, pk, sl.hpyr2 + f.pyr_off[4], n45,
+                               (uint32_t*)nullptr, (uint32_t*)nullptr);
         }
         hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, ordered ? 0 : c->opt_cluster,
                            pyr, sl.cseg, sl.ccnt,   // (ordered: slots, not clusters -- all of them)
-                           j.phase == 1 ? 2 : (j.phase == 2 ? 3 : 0), sl.slab, hist_shift, sl.slab + GSR_SLAB_BINS, pk, (float*)nullptr, 0);
+                           j.phase == 1 ? 2 : (j.phase == 2 ? 3 : 0), sl.slab, hist_shift, sl.slab + GSR_SLAB_BINS, pk, (float*)nullptr, 0,
+                           (local || local_phase) ? sl.bkt_cnt : (uint32_t*)nullptr, sl.d_counts + 2);
+        // The small-frame sort's bucket pass runs inside K1 (a key's place in its bucket = one atomic): BK_BUCKETS buckets of equal width
+        // over the key range the previous frame kept, widened by a sixteenth on either side (the view moves), in this frame's key domain
+        // (keys are stored relative to key_min); front-slab phases: over the phase's own range, which k_slab_pick left on the device
+        if (local) {
+            const uint64_t span = (uint64_t)sl.kept_hi - sl.kept_lo, margin = span / 16 + 64;
+            const uint64_t lo_abs = sl.kept_lo > margin ? sl.kept_lo - margin : 0, hi_abs = (uint64_t)sl.kept_hi + margin;
+            bk_lo = lo_abs > f.key_min ? (uint32_t)(lo_abs - f.key_min) : 0u;
+            const uint64_t width = (hi_abs > f.key_min ? hi_abs - f.key_min : 0) - bk_lo + 1;
+            while (bk_shift < 31 && (width >> bk_shift) > (uint64_t)BK_BUCKETS) ++bk_shift;
+        }
+        k1_scatters = c->opt_k1_scatter != 0 && (local || local_phase) && c->opt_scatter_direct >= 0;
+        if (k1_scatters) {
+            scat.key = sl.bkt_key; scat.val = sl.bkt_val; scat.cnt = sl.bkt_cnt; scat.failed = sl.d_counts + 2;
+            scat.range_dev = local_phase ? sl.slab + GSR_SLAB_BINS + (j.phase == 1 ? 2 : 4) : (const uint32_t*)nullptr;
+            scat.lo = bk_lo; scat.shift = bk_shift;
+        }
         // K1 over the survivors, four clusters per workgroup-iteration; the grid follows the slot's previous frame (+25 %), and
         // a frame that keeps more simply loops
         const uint32_t all_iter = div_up(c->nclus, 4u);
@@ -1891,7 +1915,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         hipLaunchKernelGGL(k_preprocess, dim3(k1_grid ? k1_grid : 1u), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, (cache_hit || ordered) ? sl.keyB : sl.keyA, (cache_hit || ordered) ? sl.valB : sl.valA,
                            j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.phase == 2 ? sl.hpyr2 : (j.cull ? sl.hpyr : (const float*)nullptr), sl.blk_cnt,
-                           sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts, (local || local_phase) ? sl.bkt_cnt : (uint32_t*)nullptr,
+                           sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts, scat,
                            // (the count of sorted splats starts at zero: a frame whose clusters are ALL culled runs no sort workgroup that
                            //  could say so, and the binning kernels would walk the previous frame's order; a static redraw keeps its order)
                            cache_hit ? (uint32_t*)nullptr : sl.d_n,
@@ -1928,25 +1952,24 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         if (local_phase) {
             // K1's compacted slots -> bucket regions over the phase's key range (k_slab_pick left it on the device) -> sorted (keyA, valA)
             const uint32_t* range = sl.slab + GSR_SLAB_BINS + (j.phase == 1 ? 2 : 4);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter_k1<uint2>), dim3(std::max(1u, std::min(div_up(n_slots / RS_SRC_BLOCK, 4u), div_up(j.k1_grid, 4u) + 16u))), dim3(256), 0, s, sl.keyA, sl.valA,
-                               n_slots / RS_SRC_BLOCK, sl.d_counts, 0, 0u, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, sl.d_counts + 2, range);
+            if (!k1_scatters)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter_k1<uint2>), dim3(std::max(1u, std::min(div_up(n_slots / RS_SRC_BLOCK, 4u), div_up(j.k1_grid, 4u) + 16u))), dim3(256), 0, s, sl.keyA, sl.valA,
+                                   n_slots / RS_SRC_BLOCK, sl.d_counts, 0, 0u, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, sl.d_counts + 2, range);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_local<uint2>), dim3(BK_BUCKETS), dim3(RL_THREADS), 0, s, sl.bkt_cnt, 0, key_bits, 0u,
                                sl.bkt_key, sl.bkt_val, sl.keyA, sl.valA, sl.d_counts + 2, sl.d_n, range);
             if (hipGetLastError() != hipSuccess) rc = set_err(GSR_E_HIP, "small-frame sort: launch failed");
         } else if (local) {
             // BK_BUCKETS buckets of equal width over the key range the previous frame kept, widened by a sixteenth on either side (the
             // view moves); in this frame's key domain (keys are stored relative to key_min)
-            const uint64_t span = (uint64_t)sl.kept_hi - sl.kept_lo, margin = span / 16 + 64;
-            const uint64_t lo_abs = sl.kept_lo > margin ? sl.kept_lo - margin : 0, hi_abs = (uint64_t)sl.kept_hi + margin;
-            const uint32_t lo = lo_abs > f.key_min ? (uint32_t)(lo_abs - f.key_min) : 0u;
-            const uint64_t width = (hi_abs > f.key_min ? hi_abs - f.key_min : 0) - lo + 1;
-            int bshift = 0;
-            while (bshift < 31 && (width >> bshift) > (uint64_t)BK_BUCKETS) ++bshift;
+            const uint32_t lo = bk_lo;
+            const int bshift = bk_shift;
             const uint32_t nblk = div_up(n_slots, RS_TILE);
             // K1's compacted slots -> bucket regions (counters and *d_n were cleared by K1) -> sorted (keyA, valA)
             // one global atomic per key pays up to ~150 k keys (fps direct / aggregated: C1 16 700 / 14 400, C2 8830 / 8560, C3 4650 / 4920, C4 3800 / 3950)
             const bool direct = c->opt_scatter_direct == 2 || (c->opt_scatter_direct == 1 && sl.kept_hint <= 150000u);
-            if (direct)
+            if (k1_scatters) {
+                // (K1 did it)
+            } else if (direct)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bucket_scatter_direct<uint2>), dim3(n_slots / RS_SRC_BLOCK), dim3(RS_SRC_BLOCK), 0, s, sl.keyA, sl.valA,
                                    sl.d_counts, bshift, lo, sl.blk_cnt, sl.bkt_cnt, sl.bkt_key, sl.bkt_val, sl.d_counts + 2);
             else if (c->opt_scatter_direct >= 0)

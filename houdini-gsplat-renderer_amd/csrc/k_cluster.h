@@ -215,7 +215,10 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                int enabled, const float* __restrict__ hpyr /* or NULL: no occlusion test */,
                uint32_t* __restrict__ seg, uint32_t* __restrict__ cnt,
                int mode, uint32_t* __restrict__ slab_hist, int hist_shift, uint32_t* __restrict__ slab, GsrSlabPick pk,
-               float* __restrict__ zero_f, int zero_n)
+               float* __restrict__ zero_f, int zero_n,
+               uint32_t* __restrict__ bk_zero /* the small-frame sort's bucket counters (BK_BUCKETS, BK_STRIDE apart), or NULL */,
+               uint32_t* __restrict__ flag_zero /* ... and its "gave a bucket up" flag: cleared here, BEFORE K1, whose workgroups scatter
+                                                   into the buckets themselves */)
 {
     __shared__ uint32_t s_w[CC_THREADS / 64];
     __shared__ uint32_t s_hist[GSR_SLAB_BINS];
@@ -234,6 +237,10 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
     } else if (mode == 3) {
         key_a = slab[0];
         if (blockIdx.x == 0) for (int b = threadIdx.x; b < GSR_SLAB_BINS; b += CC_THREADS) slab_hist[b] = 0u;
+    }
+    if (blockIdx.x == gridDim.x - 1u) {
+        if (bk_zero) for (int d = threadIdx.x; d < BK_BUCKETS; d += CC_THREADS) bk_zero[(size_t)d * BK_STRIDE] = 0u;
+        if (threadIdx.x == 0 && flag_zero) *flag_zero = 0u;
     }
     const bool want_hist = mode == 1;
     for (int r = 0; r < rounds; ++r) {

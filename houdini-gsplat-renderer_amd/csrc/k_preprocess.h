@@ -468,6 +468,16 @@ gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, co
     return out_rect;
 }
 
+struct GsrK1Scatter {
+    uint32_t* key;                 // [BK_BUCKETS * BK_CAP] bucket regions, or NULL: K1 leaves the bucket pass to k_bucket_scatter*
+    uint2* val;
+    uint32_t* cnt;                 // [BK_BUCKETS * BK_STRIDE] keys per bucket (cleared by k_cluster_cull)
+    uint32_t* failed;              // set when a bucket's region is full
+    const uint32_t* range_dev;     // { lo, shift } on the device (front-slab phases), or NULL: the two below
+    uint32_t lo;
+    int32_t shift;
+};
+
 // One wavefront per surviving cluster (k_cluster.h): workgroup-iteration k takes the clusters of rank 4k .. 4k+3 of
 // k_cluster_cull's ordered list, so its 256 slots are in storage order like the list itself.  The grid is sized from the
 // previous frame's survivor count (gsr_api.hip); a frame that keeps more simply loops.
@@ -485,8 +495,8 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
              const uint32_t* __restrict__ cseg, const uint32_t* __restrict__ ccnt, uint32_t ngroups, uint32_t cper /* k_cluster_cull's output */,
              uint32_t* __restrict__ d_counts /* [0] = slots K1 filled (256 per workgroup-iteration), [1] = surviving clusters, [2] = "the small-frame sort
                                                 gave a bucket up" (cleared here, set by k_bucket_scatter / k_radix_local) */,
-             uint32_t* __restrict__ zero_cnt /* the small-frame sort's bucket counters (BK_BUCKETS, BK_STRIDE apart), cleared here */,
-             uint32_t* __restrict__ zero_n /* ... and the count its scatter accumulates */,
+             GsrK1Scatter sc /* small-frame sort: the kept keys go straight into its buckets (sc.key != NULL) */,
+             uint32_t* __restrict__ zero_n /* the count of sorted splats, cleared here */,
              const uint32_t* __restrict__ order /* position-keyed order (GSR_OPT_SORT_CACHE = 2): slot j holds splat order[j], the splats
                                                    are walked nearest first and leave already sorted; NULL = storage order */,
              const uint32_t* __restrict__ slab /* front-slab frames (f.phase != 0): [0] = the slab key (k_slab_pick) */)
@@ -502,9 +512,12 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
     KPROFB(4, 1, gridDim.x / 2)
     const uint32_t niter = (nsurv + 3u) / 4u;
     if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) { d_counts[0] = niter * (uint32_t)GSR_K1_THREADS; d_counts[1] = nsurv; d_counts[2] = 0u; if (zero_n) *zero_n = 0u; }
-        if (zero_cnt) for (int d = threadIdx.x; d < BK_BUCKETS; d += GSR_K1_THREADS) zero_cnt[(size_t)d * BK_STRIDE] = 0u;
+        // (d_counts[2], "the small-frame sort gave a bucket up", and the bucket counters were cleared by k_cluster_cull)
+        if (threadIdx.x == 0) { d_counts[0] = niter * (uint32_t)GSR_K1_THREADS; d_counts[1] = nsurv; if (zero_n) *zero_n = 0u; }
     }
+    uint32_t sc_lo = sc.lo;
+    int sc_shift = sc.shift;
+    if (sc.key && sc.range_dev) { sc_lo = sc.range_dev[0]; sc_shift = (int)sc.range_dev[1]; }
     const uint32_t slab_key = (f.phase != 0 && slab) ? slab[0] : 0xffffffffu;
     int par = 0;
     for (uint32_t k = blockIdx.x; k < niter; k += gridDim.x, par ^= 1) {
@@ -544,6 +557,15 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
             const uint32_t pos = k * (uint32_t)GSR_K1_THREADS + before + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
             key[pos] = kb;
             val[pos] = make_uint2(i, out_rect);   // sort payload: storage index + tile rect
+            if (sc.key) {
+                // The small-frame sort's bucket pass, here: a key's place in its bucket is what one atomic on the bucket's counter returns
+                // (k_sort.h; order inside a bucket is k_radix_local's business).  Bucket = min((key - lo) >> shift, BK_BUCKETS - 1).
+                const uint32_t t = kb > sc_lo ? (kb - sc_lo) >> sc_shift : 0u;
+                const uint32_t d = t < (uint32_t)(BK_BUCKETS - 1) ? t : (uint32_t)(BK_BUCKETS - 1);
+                const uint32_t p = atomicAdd(&sc.cnt[(size_t)d * BK_STRIDE], 1u);
+                if (p < (uint32_t)BK_CAP) { sc.key[(size_t)d * BK_CAP + p] = kb; sc.val[(size_t)d * BK_CAP + p] = make_uint2(i, out_rect); }
+                else *sc.failed = 1u;             // the bucket's region is full: the prediction missed badly
+            }
         }
         if (threadIdx.x == 0) blk_cnt[k] = total;
         if (k == blockIdx.x) { KPROFB(4, 4, gridDim.x / 2) }

@@ -547,6 +547,19 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
         // sort in storage order.
         if (k == blockIdx.x) { KPROFB(4, 3, gridDim.x / 2) }
         const bool stays = out_rect != GSR_RECT_EMPTY;
+        if (sc.key) {                                  // (uniform)
+            // The small-frame sort's bucket pass, here: a key's place in its bucket is what one atomic on the bucket's counter returns
+            // (k_sort.h; order inside a bucket is k_radix_local's business: it puts ties back into storage order).
+            // Bucket = min((key - lo) >> shift, BK_BUCKETS - 1).  Nothing else reads K1's slots in such a frame: no compaction.
+            if (stays) {
+                const uint32_t t = kb > sc_lo ? (kb - sc_lo) >> sc_shift : 0u;
+                const uint32_t d = t < (uint32_t)(BK_BUCKETS - 1) ? t : (uint32_t)(BK_BUCKETS - 1);
+                const uint32_t p = atomicAdd(&sc.cnt[(size_t)d * BK_STRIDE], 1u);
+                if (p < (uint32_t)BK_CAP) { sc.key[(size_t)d * BK_CAP + p] = kb; sc.val[(size_t)d * BK_CAP + p] = make_uint2(i, out_rect); }
+                else *sc.failed = 1u;             // the bucket's region is full: the prediction missed badly
+            }
+            continue;
+        }
         const unsigned long long bal = __ballot(stays);
         if (lane == 0) s_wcnt[par][wave] = (uint32_t)__builtin_popcountll(bal);
         __syncthreads();
@@ -557,15 +570,6 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
             const uint32_t pos = k * (uint32_t)GSR_K1_THREADS + before + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
             key[pos] = kb;
             val[pos] = make_uint2(i, out_rect);   // sort payload: storage index + tile rect
-            if (sc.key) {
-                // The small-frame sort's bucket pass, here: a key's place in its bucket is what one atomic on the bucket's counter returns
-                // (k_sort.h; order inside a bucket is k_radix_local's business).  Bucket = min((key - lo) >> shift, BK_BUCKETS - 1).
-                const uint32_t t = kb > sc_lo ? (kb - sc_lo) >> sc_shift : 0u;
-                const uint32_t d = t < (uint32_t)(BK_BUCKETS - 1) ? t : (uint32_t)(BK_BUCKETS - 1);
-                const uint32_t p = atomicAdd(&sc.cnt[(size_t)d * BK_STRIDE], 1u);
-                if (p < (uint32_t)BK_CAP) { sc.key[(size_t)d * BK_CAP + p] = kb; sc.val[(size_t)d * BK_CAP + p] = make_uint2(i, out_rect); }
-                else *sc.failed = 1u;             // the bucket's region is full: the prediction missed badly
-            }
         }
         if (threadIdx.x == 0) blk_cnt[k] = total;
         if (k == blockIdx.x) { KPROFB(4, 4, gridDim.x / 2) }

@@ -824,6 +824,8 @@ extern "C" int gsr_upload_end(gsr_context* c)
     c->cull_pays = false; c->slab_holdoff = 0; c->cull_holdoff = 0; c->cull_backoff = 8; c->cull_streak = 0; c->vis_unculled = 0; c->cull_dilate = c->opt_dilate;
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) { c->slot[k].surv_hint = 0; c->slot[k].kept_hint = 0; c->slot[k].kept_lo = c->slot[k].kept_hi = 0; c->slot[k].horizon_valid = false; c->slot[k].local_fails = 0; c->slot[k].local_holdoff = 0; c->slot[k].slab_kept1 = c->slot[k].slab_kept2 = 0; }
     c->lazy_pays = false;              // ... and in automatic mode the first frames are eager until the kernels say it pays
+    // (the kernels' verdicts on the last frame of the PREVIOUS cloud must not reach the first frame of this one through the device word)
+    if (c->lazy_hint && hipMemset(c->lazy_hint, 0, 4) != hipSuccess) return set_err(GSR_E_HIP, "upload: could not reset the policy word");
     c->st.n_splats = c->n;
     return GSR_OK;
 }

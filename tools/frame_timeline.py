@@ -22,8 +22,14 @@ if len(sys.argv) > 2 and sys.argv[2] == "--gaps":
 starts = [i for i, r in enumerate(rows) if "k_preprocess" in r["Kernel_Name"]]
 if len(starts) < 3:
     sys.exit("not enough frames in the trace")
-# optional second argument: which frame (index into the frames of the trace; default: the last complete one)
-which = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) - 2
+# optional second argument: which frame (index into the frames of the trace; default: the last complete one), or "median": the
+# frame of median period among the last 40 complete frames (a single frame can carry a host hiccup or the events of a timed frame)
+if len(sys.argv) > 2 and sys.argv[2] == "median":
+    cand = list(range(max(0, len(starts) - 41), len(starts) - 1))
+    per = sorted((int(rows[starts[i + 1]]["Start_Timestamp"]) - int(rows[starts[i]]["Start_Timestamp"]), i) for i in cand)
+    which = per[len(per) // 2][1]
+else:
+    which = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) - 2
 a, b = starts[which], starts[which + 1]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = None

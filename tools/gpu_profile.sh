@@ -16,6 +16,6 @@ cd "$REPO"
 cp "$(find /tmp/rp_$TAG -name '*kernel_stats*' -printf '%s %p\n' | sort -n | tail -1 | cut -d' ' -f2)" "$OUT/kernel_stats.csv"
 find /tmp/rp_$TAG -name '*domain_stats*' -exec cp {} "$OUT/domain_stats.csv" \;
 T=$(find /tmp/rp_$TAG -name '*kernel_trace.csv' -printf '%s %p\n' | sort -n | tail -1 | cut -d' ' -f2)   # (the largest: bench.py's own process, not the HBM micro-benchmark it spawns)
-[ -n "$T" ] && python tools/frame_timeline.py "$T" 30 > "$OUT/frame_timeline.txt" 2>&1   # (a frame of the timed leg: the last legs are informational)
+[ -n "$T" ] && python tools/frame_timeline.py "$T" median > "$OUT/frame_timeline.txt" 2>&1   # (the frame of median period among the last 40)
 ls -la /tmp/rp_$TAG/* | head
 head -30 "$OUT/kernel_stats.csv"

@@ -30,7 +30,9 @@ if len(sys.argv) > 2 and sys.argv[2] == "median":
     which = per[len(per) // 2][1]
 else:
     which = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) - 2
-a, b = starts[which], starts[which + 1]
+nseg = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # optional third argument: consecutive segments to print (a front-slab frame is two)
+nseg = max(1, min(nseg, len(starts) - 1 - which))
+a, b = starts[which], starts[which + nseg]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = None
 busy = 0

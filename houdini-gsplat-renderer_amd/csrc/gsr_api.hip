@@ -395,7 +395,7 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMemset(sl.colour_evals, 0, 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr_next), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hraw), 512 * 512 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hraw), (size_t)GSR_MAX_TILES_SIDE * GSR_MAX_TILES_SIDE * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr2), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.slab), (GSR_SLAB_BINS + 8) * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.slab, 0, (GSR_SLAB_BINS + 8) * sizeof(uint32_t)) == hipSuccess;
@@ -411,7 +411,7 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.h_end_dev), sl.h_end, 0) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.st_scan), 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.st_scan, 0, 512 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.partial), 4096 * sizeof(GsrTilePartial)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.partial), (size_t)(GSR_MAX_TILES_SIDE / 8) * (GSR_MAX_TILES_SIDE / 8) * sizeof(GsrTilePartial)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.sup_work), 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.sup_work, 0, 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl.h_total), 4 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
@@ -1102,9 +1102,11 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
     if (c->opt_super > 0)
         while ((1 << shift) < c->opt_super) ++shift;
     while ((((f->tiles_x - 1) >> shift) + 1) * (((f->tiles_y - 1) >> shift) + 1) > 256) ++shift;
-    // more than 256 tiles a side (> 4096 pixels): rects are packed in pairs of tiles (gsr_device.h); a super-tile is then at least
-    // a pair wide (512 tiles a side cannot give <= 256 super-tiles otherwise)
-    f->rect_shift = (f->tiles_x > 256 || f->tiles_y > 256) ? 1 : 0;
+    // more than 256 tiles a side (> 4096 pixels): rects are packed in pairs of tiles (gsr_device.h), more than 512 (> 8192 pixels) in
+    // blocks of four; a super-tile is then at least that wide (512 tiles a side cannot give <= 256 super-tiles otherwise), and its
+    // edge in rect units stays <= 16: the list entries' column and row bits
+    static_assert(GSR_MAX_DIM / GSR_TILE_PX == GSR_MAX_TILES_SIDE && GSR_MAX_TILES_SIDE <= 256 * 4, "tile coordinates are packed in 8 bits of rect units");
+    f->rect_shift = (f->tiles_x > 512 || f->tiles_y > 512) ? 2 : ((f->tiles_x > 256 || f->tiles_y > 256) ? 1 : 0);
     if (shift < f->rect_shift) shift = f->rect_shift;
     f->super_shift = shift;
     f->flags = c->opt_flags;

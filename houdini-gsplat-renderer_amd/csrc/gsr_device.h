@@ -80,7 +80,7 @@ struct GsrFrame {
     int32_t pyr_off[6];                // depth-horizon pyramid: first cell of level l (k_cluster.h; GSR_PYR_LEVELS)
     int32_t cull_dilate;               // tiles by which a rect is widened before it is compared with the horizons (on top of the
                                        // dilation built into the pyramid)
-    int32_t rect_shift;                // tile rects are packed in units of (1 << rect_shift) tiles: 0 up to 256 tiles a side, 1 up to 512
+    int32_t rect_shift;                // tile rects are packed in units of (1 << rect_shift) tiles: 0 up to 256 tiles a side, 1 up to 512, 2 up to 1024
     int32_t phase;                     // front-slab frames (gsr_api.hip): 0 = the whole frame; 1 = only the splats with key <= the slab key
                                        // (device word, picked by k_slab_pick); 2 = only the ones beyond it, culled against the tiles
                                        // that phase 1 left opaque

@@ -113,7 +113,8 @@ k_cluster_bounds(uint32_t n, const float4* __restrict__ geoA, const uint4* __res
 // (dilated) horizon of the tiles [x 2^l, (x+1) 2^l) x [y 2^l, (y+1) 2^l); +inf = no horizon (nothing may be culled there), 0 =
 // a tile of another rank (nothing is needed there).
 #define GSR_PYR_LEVELS 6
-#define GSR_PYR_FLOATS (512 * 512 + 256 * 256 + 128 * 128 + 64 * 64 + 32 * 32 + 16 * 16 + 16)   // a grid of up to 512 x 512 tiles
+#define GSR_MAX_TILES_SIDE 1024        // GSR_MAX_DIM / GSR_TILE_PX
+#define GSR_PYR_FLOATS (1024 * 1024 + 512 * 512 + 256 * 256 + 128 * 128 + 64 * 64 + 32 * 32 + 16)   // a grid of up to 1024 x 1024 tiles
 #define GSR_DILATE_EXACT_MAX 3         // the dilation k_horizon_dilate applies tile by tile; what a frame wants beyond that
                                        // is added by widening the rects at look-up time
 __host__ __device__ __forceinline__ int gsr_pyr_dim(int tiles, int level) { return ((tiles - 1) >> level) + 1; }

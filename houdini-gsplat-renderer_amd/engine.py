@@ -83,7 +83,7 @@ class gsplat_attrs(C.Structure):
 
 
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_COPY = 0, 1, 2
-MAX_DIM = 8192          # GSR_MAX_DIM (include/gsplat_hip.h): largest framebuffer width / height
+MAX_DIM = 16384         # GSR_MAX_DIM (include/gsplat_hip.h): largest framebuffer width / height
 MISSING_CD, MISSING_OPACITY, MISSING_SCALE, MISSING_ORIENT, MISSING_SH, BAD_SH_ORDER = 1, 2, 4, 8, 16, 32
 OPT_XCD_SWIZZLE, OPT_STAGE_TIMING, OPT_SORT_CACHE, OPT_SUPER_TILE, OPT_DEBUG_FLAGS, OPT_FRAMES_IN_FLIGHT, OPT_DEFERRED_CHECK, OPT_LAZY_COLOUR, OPT_SHARD_LAYOUT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPT_OCCLUSION_CULL = 10

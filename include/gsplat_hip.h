@@ -36,7 +36,7 @@ extern "C" {
 #define GSR_E_COMM           -7   /* RCCL could not be loaded, or a communicator call failed */
 
 #define GSR_TILE              16          /* tile edge in pixels */
-#define GSR_MAX_DIM           8192        /* max framebuffer width/height */
+#define GSR_MAX_DIM           16384       /* max framebuffer width/height (1024 x 1024 tiles) */
 #define GSR_MAX_PAIRS         0x7fffff00ll
 
 typedef struct gsr_context gsr_context;

@@ -174,11 +174,13 @@ def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine, n,
     (8192, 272, 30000, 2000),       # 512 tiles wide: tile rects are packed in pairs of tiles (GsrFrame.rect_shift = 1)
     (272, 8192, 30000, 2000),       # ... and 512 tiles high
     (4608, 4368, 40000, 1500),      # both sides beyond 4096: 288 x 273 tiles
+    (16384, 272, 30000, 2000),      # 1024 tiles wide: rects in blocks of four tiles (rect_shift = 2)
+    (272, 16384, 30000, 2000),      # ... and 1024 tiles high
 ])
 def test_framebuffers_beyond_4096_pixels(pkg, oracle, engine, w, h, n, big):
     """the reference has no framebuffer limit (src/GSplatRenderer.C:534-657); here tile coordinates are packed in 8 bits, and a
-    frame of more than 256 tiles a side carries its rects in units of two tiles -- a superset everywhere it is read, so the
-    pixels are the oracle's, with and without occlusion culling, sharded or not"""
+    frame of more than 256 (512) tiles a side carries its rects in units of two (four) tiles -- a superset everywhere it is read,
+    so the pixels are the oracle's, with and without occlusion culling, sharded or not"""
     splats = pkg.scenes.make_scene(n, seed=1234 + w, sh=True)
     splats.scale[:big] = pkg.scenes.f16bits(np.random.default_rng(w).uniform(0.3, 2.5, size=(big, 3)))
     cam = pkg.camera.make_camera(w, h, sh_order=3, frame=3)
@@ -210,8 +212,9 @@ def test_framebuffers_beyond_4096_pixels(pkg, oracle, engine, w, h, n, big):
             assert (np.diff(rank[lst]) > 0).all(), f"super-tile {t} not in depth order"
         X0, Y0 = (t % sx) * S, (t // sx) * S
         need = ok & (tx1 >= X0) & (tx0 <= X0 + S - 1) & (ty1 >= Y0) & (ty0 <= Y0 + S - 1)
-        # ... and at most those whose rect, rounded outwards to pairs of tiles, does
-        may = ok & ((tx1 | 1) >= X0) & ((tx0 & ~1) <= X0 + S - 1) & ((ty1 | 1) >= Y0) & ((ty0 & ~1) <= Y0 + S - 1)
+        # ... and at most those whose rect, rounded outwards to the rect unit (pairs of tiles; blocks of four beyond 8192 pixels), does
+        u = 3 if max(w, h) > 8192 else 1
+        may = ok & ((tx1 | u) >= X0) & ((tx0 & ~u) <= X0 + S - 1) & ((ty1 | u) >= Y0) & ((ty0 & ~u) <= Y0 + S - 1)
         got = set(lst.tolist())
         assert set(vis[need].tolist()) <= got <= set(vis[may].tolist()), f"super-tile {t}: membership"
         extra += len(got) - int(need.sum())
@@ -230,10 +233,10 @@ def test_framebuffers_beyond_4096_pixels(pkg, oracle, engine, w, h, n, big):
 
 
 def test_the_largest_framebuffer(pkg, oracle, engine):
-    """8192 x 8192 (GSR_MAX_DIM): 512 x 512 tiles, 256 super-tiles of 32 x 32 tiles; three bands of rows against the oracle"""
+    """16384 x 16384 (GSR_MAX_DIM): 1024 x 1024 tiles, 256 super-tiles of 64 x 64 tiles, a 4.3 GB frame; three bands of rows against the oracle"""
     import ctypes as C
     w = h = pkg.engine.MAX_DIM
-    assert w == 8192
+    assert w == 16384
     splats = pkg.scenes.make_scene(20000, seed=8192, sh=False)
     splats.scale[:1000] = pkg.scenes.f16bits(np.random.default_rng(8).uniform(0.3, 2.0, size=(1000, 3)))
     cam = pkg.camera.make_camera(w, h, sh_order=0, frame=1)
@@ -245,8 +248,8 @@ def test_the_largest_framebuffer(pkg, oracle, engine):
         engine.render_to_device(cam, p.value)
         engine.synchronize()
         st = engine.stats()
-        assert st["super_tile"] == 32 and st["stiles_x"] * st["stiles_y"] == 256
-        for y0 in (0, 4000, h - 96):
+        assert st["super_tile"] == 64 and st["stiles_x"] * st["stiles_y"] == 256
+        for y0 in (0, 8000, h - 96):
             got = np.empty((96, w, 4), np.float32)
             assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), C.c_void_p(p.value + y0 * w * 16), C.c_size_t(got.nbytes), 2) == 0
             ref = oracle.render_rows(splats, cam, y0, y0 + 96, threads=oracle.max_threads())
@@ -255,7 +258,7 @@ def test_the_largest_framebuffer(pkg, oracle, engine):
             del ref
         # the same frame with the heaviest-first tile order and occlusion culling forced on: bit-identical
         first = np.empty((256, w, 4), np.float32)
-        assert hip.hipMemcpy(C.c_void_p(first.ctypes.data), C.c_void_p(p.value + 3900 * w * 16), C.c_size_t(first.nbytes), 2) == 0
+        assert hip.hipMemcpy(C.c_void_p(first.ctypes.data), C.c_void_p(p.value + 7900 * w * 16), C.c_size_t(first.nbytes), 2) == 0
         engine.set_option(pkg.engine.OPT_XCD_SWIZZLE, 3)
         engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 2)
         try:
@@ -267,7 +270,7 @@ def test_the_largest_framebuffer(pkg, oracle, engine):
             engine.set_option(pkg.engine.OPT_XCD_SWIZZLE, 2)
             engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 1)
         again = np.empty_like(first)
-        assert hip.hipMemcpy(C.c_void_p(again.ctypes.data), C.c_void_p(p.value + 3900 * w * 16), C.c_size_t(again.nbytes), 2) == 0
+        assert hip.hipMemcpy(C.c_void_p(again.ctypes.data), C.c_void_p(p.value + 7900 * w * 16), C.c_size_t(again.nbytes), 2) == 0
         assert np.array_equal(first, again)
     finally:
         hip.hipFree(p)

@@ -97,6 +97,7 @@ struct FrameJob {
     uint32_t k1_grid = 0;          // K1's grid: the estimate of its workgroup-iterations (sizes the bucket scatter's grid too)
     bool local_sort = false;       // the depth sort took the small-frame form (k_sort.h) ...
     bool sort_failed = false;      // ... and gave a bucket up: the frame is rendered again with the three global passes
+    bool redo = false;             // phase 2 of a front-slab frame met a list buffer that was too short: the frame is rendered again (frame_check)
     bool ranges_folded = false;    // ... and k_bin_place forms the list ranges and posts the pair count itself (no k_bin_ranges launch)
     bool deferred = false;         // ... and the frame handed over without waiting for it (GSR_OPT_DEFERRED_CHECK)
     bool lazy = false;             // K1 left the SH colours pending (k_colour.h)
@@ -193,6 +194,7 @@ struct FrameSlot {
     bool last_lazy = false;            // the last frame of this slot left colours pending
     float* fb = nullptr;               // staging for host-pointer output
     size_t fb_cap = 0;
+    int fb_sig[5] = {-1, -1, -1, -1, -1};   // the band shape the staging buffer was last cleared for
     // small device/host mailboxes
     unsigned long long* counters = nullptr;  // k_sum_work's layout: [1]/[2] records gathered (frame/running), [3]/[4] list entries
                                              // scanned, [5] wave-record evaluations (running)
@@ -1571,16 +1573,32 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
         }
         if (D == 0xffffffffu || (unsigned long long)D > (unsigned long long)GSR_MAX_PAIRS)
             return frame_abort(sl, set_err(GSR_E_TOO_MANY_PAIRS, "gsr_render: the frame's super-tile pairs exceed the limit of %lld", GSR_MAX_PAIRS));
-        const bool short_buffer = D > sl.pair_cap;
+        // (a slot that has never met a pair has no list buffer at all: the frame-end kernels read entry 0 of it unconditionally --
+        //  a rank whose rows see nothing, under forced culling or forced front-slab frames, faulted on the null pointer)
+        const bool short_buffer = D > sl.pair_cap || !sl.pvA;
         if (short_buffer) {
             (void)hipStreamSynchronize(sl.stream);   // a speculative (clamped) back end may still be reading the old buffer
             dev_free(sl.pvA);
             sl.pair_cap = 0;
-            const size_t want = (size_t)D + D / 4 + 4096;
+            // (a slot's first buffer may be sized by a frame -- or a front slab -- that shows next to nothing: at least two entries per splat
+            //  then, up to 32 MB, so that the frames behind it need not each regrow it)
+            const size_t floor_ = sl.pvA ? 0 : std::min<size_t>((size_t)2 * j.n + 4096, (size_t)1 << 22);
+            const size_t want = std::max<size_t>((size_t)D + D / 4 + 4096, std::max(floor_, c->pair_want));
             int rc = dev_alloc(&sl.pvA, want + 4);   // (+4: the blend kernel scans in 4-entry steps)
             if (rc) return frame_abort(sl, rc);
             sl.pair_cap = want;
             c->pair_want = std::max(c->pair_want, want);   // the other frame slot grows before its next frame
+        }
+        if (short_buffer && j.speculative && j.phase == 2) {
+            // Phase 2 of a front-slab frame CONTINUES from what phase 1 left in the target: the clamped back end that has run has
+            // composited on top of it, and a second run would composite the same splats again.  The whole frame again (frame_check),
+            // with the buffer that now fits; nothing of this attempt is kept.
+            c->st.frames_requeued += 1;
+            if (sl.sup_work) (void)hipMemsetAsync(sl.sup_work + 256 * sl.sup_par, 0, 256 * sizeof(uint32_t), sl.stream);
+            sl.sort_valid = false;
+            j.redo = true;
+            j.open = false;
+            return GSR_OK;
         }
         if (j.deferred) {
             // the frame was handed over before its pair count was known; if the lists were clamped it misses their tails
@@ -1810,6 +1828,14 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
             sl.fb_cap = 0;
             if ((rc = dev_alloc(&sl.fb, j.out_px * 4))) return rc;
             sl.fb_cap = j.out_px * 4;
+            std::memset(sl.fb_sig, 0xff, sizeof sl.fb_sig);
+        }
+        // A sharded context's band image is padded (gsr_band_rows): the pixel rows behind the rank's last image row are never
+        // written.  In the library's own staging buffer they read as zeros: it is cleared whenever the band's shape changes.
+        const int fsig[5] = {f.width, f.height, f.shard_index, f.shard_count, f.shard_rpb};
+        if (std::memcmp(fsig, sl.fb_sig, sizeof fsig) != 0) {
+            HIP_TRY(hipMemsetAsync(sl.fb, 0, j.out_px * 16, s));
+            std::memcpy(sl.fb_sig, fsig, sizeof fsig);
         }
         j.target = sl.fb;
     }
@@ -2048,11 +2074,14 @@ static FrameSlot* latest_slot(gsr_context* c);
 static int frame_check(gsr_context* c, FrameSlot& slot, const gsr_camera* cam, const float* depth, int depth_is_device,
                        float* rgba_out, int out_is_device)
 {
-    if (slot.job.sort_failed) {
+    if (slot.job.sort_failed || slot.job.redo) {
         // the small-frame sort met a bucket far beyond its prediction and left it unsorted: the frame again, with the global sort
-        // (and without culling: a prediction that far off means the view jumped, and the horizons with it)
-        c->st.frames_resorted += 1;
-        c->classic_once = true;
+        // (and without culling: a prediction that far off means the view jumped, and the horizons with it) -- or the second phase of
+        // a front-slab frame ran off its list buffer (frame_finish): the frame again, as it was
+        if (slot.job.sort_failed) {
+            c->st.frames_resorted += 1;
+            c->classic_once = true;
+        }
         c->frame_no -= 1;
         c->st.frames -= 1;
         FrameSlot* sl2 = nullptr;

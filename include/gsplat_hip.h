@@ -169,7 +169,10 @@ int  gsr_upload(gsr_context* ctx, int64_t n,
  * interleaved: balances any scene) or the contiguous band [index*rpb, (index+1)*rpb), rpb = ceil(tile rows / count)
  * (layout 1, GSR_OPT_SHARD_LAYOUT: a rank keeps ~1/count of the splats, so its sort/binning/colour work shrinks too).
  * Its output is the compact band image: the owned tile rows stacked bottom-up, gsr_band_rows() pixel rows of `width`
- * RGBA-f32 pixels.  The stitched frame is bit-identical to the unsharded one in either layout. */
+ * RGBA-f32 pixels.  The stitched frame is bit-identical to the unsharded one in either layout.  The band is padded to the
+ * same height on every rank: pixel rows behind the rank's last image row (a last tile row the image does not fill, whole
+ * tile rows of a rank that owns fewer than the others, all of it for a rank beyond the image) are NEVER written in a
+ * device target -- clear it once if they are to read as zeros -- and read as zeros in a host target. */
 int  gsr_set_row_shard(gsr_context* ctx, int index, int count);
 int  gsr_band_rows(int height, int index, int count);      /* pixel rows in that band image */
 /* Root side: bands[count] gathered back to back (each padded to

@@ -1672,6 +1672,85 @@ def test_front_slab_frames_are_exact(pkg, oracle, shard):
         e3.close(); plain.close()
 
 
+def test_a_rank_whose_rows_see_nothing(pkg):
+    """a context that has never met a (super-tile, splat) pair -- one splat, a row shard that does not own its rows -- under forced
+    occlusion culling and forced front-slab frames: the frame-end kernels read entry 0 of the list buffer unconditionally, and a slot
+    without one faulted on the null pointer (found by tools/fuzz_parity.py).  And the padding of a band (rows behind the rank's
+    last image row) reads as zeros in a host target."""
+    E = pkg.engine
+    splats = pkg.scenes.make_scene(1, seed=5, sh=False)
+    cams = [pkg.camera.make_camera(64, 720, sh_order=0, frame=f, distance=4.61995 * d) for f, d in ((0, 1.0), (1, 1.0), (2, 1.0), (40, 1.3))]
+    for cull, slab in ((1, 2), (2, 1), (2, 2), (3, 1)):
+        eng = E.Engine(0)
+        try:
+            eng.set_option(E.OPT_SHARD_LAYOUT, 0)
+            eng.set_row_shard(2, 3)
+            eng.set_option(E.OPT_OCCLUSION_CULL, cull)
+            eng.set_option(E.OPT_FRONT_SLAB, slab)
+            eng.set_option(E.OPT_LOCAL_SORT, 2)
+            eng.set_option(E.OPT_FRAMES_IN_FLIGHT, 2)
+            eng.upload(splats)
+            for c in cams:
+                assert not eng.render(c).any()
+        finally:
+            eng.close()
+    # more ranks than tile rows (48 pixels = 3 tile rows, 8 contiguous bands): the last ranks own nothing; every band is defined
+    big = pkg.scenes.make_scene(20000, seed=6, sh=False)
+    cam = pkg.camera.make_camera(1920, 48, sh_order=0, frame=0)
+    full = E.Engine(0)
+    try:
+        full.upload(big)
+        img = full.render(cam)
+        assert img[..., 3].max() > 0.5
+        for idx in (0, 2, 3, 7):
+            eng = E.Engine(0)
+            try:
+                eng.set_option(E.OPT_SHARD_LAYOUT, 1)
+                eng.set_row_shard(idx, 8)
+                eng.upload(big)
+                for _ in range(2):
+                    assert np.array_equal(eng.render(cam), pkg.multigpu.extract_band(img, idx, 8, 1)), idx
+            finally:
+                eng.close()
+    finally:
+        full.close()
+
+
+def test_front_slab_phase_two_outgrows_the_list_buffer(pkg):
+    """phase 2 of a front-slab frame continues from what phase 1 composited: when its lists outgrow the buffer (sized by frames
+    that showed far less), the clamped speculative back end must not simply run again on top of its own output -- the whole
+    frame is rendered again"""
+    E = pkg.engine
+    splats = pkg.scenes.make_scene(20000, seed=77, sh=True)
+    # (large splats: from afar a splat reaches one or two super-tiles, from near by most of the 135 -- far more pairs than the two
+    #  entries per splat a slot's first buffer allows for)
+    splats.scale[:] = pkg.scenes.f16bits(np.random.default_rng(7).uniform(0.05, 0.5, size=(splats.n, 3)))
+    far = [pkg.camera.make_camera(960, 540, sh_order=3, frame=f, distance=200.0) for f in (0, 1)]
+    near = [pkg.camera.make_camera(960, 540, sh_order=3, frame=f) for f in (30, 31)]
+    dut, plain = E.Engine(0), E.Engine(0)
+    try:
+        plain.set_option(E.OPT_OCCLUSION_CULL, 0)
+        dut.set_option(E.OPT_OCCLUSION_CULL, 3)
+        dut.set_option(E.OPT_FRONT_SLAB, 2)
+        plain.upload(splats); dut.upload(splats)
+        for c in far + near + far + near:
+            assert np.array_equal(dut.render(c), plain.render(c))
+        st = dut.stats()
+        assert st["frames_slab"] >= 6 and st["frames_requeued"] >= 1, st
+    finally:
+        dut.close(); plain.close()
+
+
+def test_randomised_exactness_soak(pkg):
+    """tools/fuzz_parity.py, a short run: random clouds, framebuffers, projections, row shards and library options; every frame of a
+    short camera path bit-identical to a context that culls nothing, takes the global sort and shades eagerly"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "11"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert "frames bit-identical" in res.stdout
+
+
 def test_a_frame_whose_clusters_are_all_culled_is_empty(pkg, engine):
     """every cluster off screen / behind the eye: no K1 slot is filled and no sort workgroup runs -- the frame must be EMPTY, not the
     previous frame's splats walked again (the sorted count of a slot outlives its frame)"""

@@ -1,0 +1,99 @@
+"""Randomised exactness soak (GPU box): python tools/fuzz_parity.py [iterations] [seed]
+Every iteration: a random cloud (0 .. 400 k splats, random scale range, SH or not), a random framebuffer, a random projection
+(perspective / off-centre / orthographic), a random row shard and random library options (occlusion culling mode, front slab,
+small-frame sort, lazy colour, frames in flight, cluster culling, storage order), then a short camera path (small steps, a
+jump, a repeat) -- every frame must be BIT-IDENTICAL to the same camera from a context that culls nothing, takes the global
+sort and shades eagerly (that configuration is what the -m gpu tests hold against the CPU oracle).
+Exits non-zero at the first difference, printing the configuration that produced it."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import __graft_entry__ as ge  # noqa: E402
+
+pkg = ge.load_package()
+E = pkg.engine
+
+
+def random_camera(rng, w, h, order, frame, dist_scale, kind):
+    near, far = 0.01, 1.0e5
+    aspect = w / h
+    proj = None
+    if kind == 1:      # off-centre frustum
+        r = near / 2.41421
+        cx, cy = rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4)
+        proj = pkg.camera.frustum((cx - 1) * r, (cx + 1) * r, (cy - 1) * r / aspect, (cy + 1) * r / aspect, near, far)
+    elif kind == 2:    # orthographic
+        half = rng.uniform(0.6, 1.6)
+        proj = pkg.camera.orthographic(-half, half, -half / aspect, half / aspect, near, far)
+    return pkg.camera.make_camera(w, h, sh_order=order, frame=frame, distance=4.61995 * dist_scale, proj_matrix=proj)
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    first = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # (skip the iterations before this one: same random sequence)
+    rng = np.random.default_rng(seed)
+    t_start = time.time()
+    frames = 0
+    for it in range(iters):
+        n = int(rng.choice([0, 1, 63, 64, 65, 1000, 20000, 100000, 400000]))
+        sh = bool(rng.integers(0, 2))
+        lo = rng.uniform(-6.0, -3.0)
+        splats = pkg.scenes.make_scene(n, seed=int(rng.integers(1, 1 << 30)), sh=sh, log_scale_range=(lo, lo + rng.uniform(0.5, 2.5)))
+        if n >= 1000 and rng.random() < 0.3:      # a few huge splats (the cooperative big-rect path)
+            k = min(200, n)
+            splats.scale[:k] = pkg.scenes.f16bits(rng.uniform(0.2, 1.5, size=(k, 3)))
+        if n >= 1000 and rng.random() < 0.3:      # coincident splats: ties in the sort
+            k = int(rng.integers(2, 80))
+            splats.P[100:100 + k] = splats.P[100]
+        w = int(rng.choice([64, 333, 640, 1280, 1920, 2500]))
+        h = int(rng.choice([48, 217, 480, 720, 1080]))
+        order = int(rng.integers(0, 4)) if sh else 0
+        kind = int(rng.integers(0, 3))
+        count = int(rng.choice([1, 1, 2, 3, 8]))
+        index = int(rng.integers(0, count))
+        layout = int(rng.integers(0, 2))
+        opts = {E.OPT_OCCLUSION_CULL: int(rng.choice([0, 1, 2, 3])), E.OPT_FRONT_SLAB: int(rng.choice([0, 1, 2])),
+                E.OPT_LOCAL_SORT: int(rng.choice([0, 1, 2])), E.OPT_LAZY_COLOUR: int(rng.choice([0, 1, 2])),
+                E.OPT_FRAMES_IN_FLIGHT: int(rng.choice([1, 1, 2])), E.OPT_CLUSTER_CULL: int(rng.choice([0, 1, 1])),
+                E.OPT_STORAGE_ORDER: int(rng.choice([0, 1, 1])), E.OPT_XCD_SWIZZLE: int(rng.choice([0, 1, 2, 3]))}
+        desc = dict(it=it, n=n, sh=sh, w=w, h=h, order=order, proj=kind, shard=(index, count, layout), opts={int(k): v for k, v in opts.items()})
+        path = [(0, 1.0), (1, 1.0), (2, 1.0), (40, 1.3), (41, 1.3), (41, 1.3), (3, 1.0), (4, 0.7)]
+        cams = [random_camera(np.random.default_rng(1000 + it), w, h, order, f, d, kind) for f, d in path]
+        if it < first:
+            continue
+        print("..", desc, flush=True)
+        dut, plain = E.Engine(0), E.Engine(0)
+        try:
+            for e in (dut, plain):
+                e.set_option(E.OPT_SHARD_LAYOUT, layout)
+                e.set_row_shard(index, count)
+            # (the storage order is a property of the product under test: ties are drawn in storage order, so the plain context stores alike)
+            plain.set_option(E.OPT_STORAGE_ORDER, opts[E.OPT_STORAGE_ORDER])
+            plain.set_option(E.OPT_OCCLUSION_CULL, 0); plain.set_option(E.OPT_CLUSTER_CULL, 0)
+            plain.set_option(E.OPT_LOCAL_SORT, 0); plain.set_option(E.OPT_LAZY_COLOUR, 0)
+            for k, v in opts.items():
+                dut.set_option(k, v)
+            dut.upload(splats); plain.upload(splats)
+            for k, c in enumerate(cams):
+                want = plain.render(c)
+                got = dut.render(c)
+                frames += 1
+                if not np.array_equal(got, want, equal_nan=True):
+                    d = np.abs(got - want)
+                    print("MISMATCH frame", k, "max |diff|", float(np.nanmax(d)), "pixels", int((d.max(axis=-1) > 0).sum()), desc, dut.stats())
+                    return 1
+            st = dut.stats()
+            print("ok", it, "n", n, f"{w}x{h}", "proj", kind, "shard", (index, count, layout), "cull", opts[E.OPT_OCCLUSION_CULL], "slab", opts[E.OPT_FRONT_SLAB],
+                  "| culled", st["frames_culled"], "slab", st["frames_slab"], "jumped", st["frames_jumped"], "repaired", st["frames_repaired"], "resorted", st["frames_resorted"], flush=True)
+        finally:
+            dut.close(); plain.close()
+    print(f"{iters} iterations, {frames} frames bit-identical, {time.time() - t_start:.0f} s")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,9 +1,12 @@
-"""Randomised exactness soak (GPU box): python tools/fuzz_parity.py [iterations] [seed]
+"""Randomised exactness soak (GPU box): python tools/fuzz_parity.py [iterations] [seed] [first] [heavy]
 Every iteration: a random cloud (0 .. 400 k splats, random scale range, SH or not), a random framebuffer, a random projection
 (perspective / off-centre / orthographic), a random row shard and random library options (occlusion culling mode, front slab,
 small-frame sort, lazy colour, frames in flight, cluster culling, storage order), then a short camera path (small steps, a
 jump, a repeat) -- every frame must be BIT-IDENTICAL to the same camera from a context that culls nothing, takes the global
 sort and shades eagerly (that configuration is what the -m gpu tests hold against the CPU oracle).
+Some iterations render depth-tested (an opaque pass's depth image in front of part of the frame), some go through gsr_multi_*
+(several contexts on this GPU, COPY transport: shard, render, gather) and are compared with the unsharded frame.
+heavy = 1: clouds of 1 - 2.5 M splats at 1920x1080 (the policy's temporal culling and front-slab frames engage by themselves).
 Exits non-zero at the first difference, printing the configuration that produced it."""
 import sys
 import time
@@ -35,11 +38,12 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     first = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # (skip the iterations before this one: same random sequence)
+    heavy = len(sys.argv) > 4 and sys.argv[4] == "1"
     rng = np.random.default_rng(seed)
     t_start = time.time()
     frames = 0
     for it in range(iters):
-        n = int(rng.choice([0, 1, 63, 64, 65, 1000, 20000, 100000, 400000]))
+        n = int(rng.choice([1000000, 1500000, 2500000])) if heavy else int(rng.choice([0, 1, 63, 64, 65, 1000, 20000, 100000, 400000]))
         sh = bool(rng.integers(0, 2))
         lo = rng.uniform(-6.0, -3.0)
         splats = pkg.scenes.make_scene(n, seed=int(rng.integers(1, 1 << 30)), sh=sh, log_scale_range=(lo, lo + rng.uniform(0.5, 2.5)))
@@ -49,8 +53,8 @@ def main():
         if n >= 1000 and rng.random() < 0.3:      # coincident splats: ties in the sort
             k = int(rng.integers(2, 80))
             splats.P[100:100 + k] = splats.P[100]
-        w = int(rng.choice([64, 333, 640, 1280, 1920, 2500]))
-        h = int(rng.choice([48, 217, 480, 720, 1080]))
+        w = 1920 if heavy else int(rng.choice([64, 333, 640, 1280, 1920, 2500]))
+        h = 1080 if heavy else int(rng.choice([48, 217, 480, 720, 1080]))
         order = int(rng.integers(0, 4)) if sh else 0
         kind = int(rng.integers(0, 3))
         count = int(rng.choice([1, 1, 2, 3, 8]))
@@ -59,35 +63,49 @@ def main():
         opts = {E.OPT_OCCLUSION_CULL: int(rng.choice([0, 1, 2, 3])), E.OPT_FRONT_SLAB: int(rng.choice([0, 1, 2])),
                 E.OPT_LOCAL_SORT: int(rng.choice([0, 1, 2])), E.OPT_LAZY_COLOUR: int(rng.choice([0, 1, 2])),
                 E.OPT_FRAMES_IN_FLIGHT: int(rng.choice([1, 1, 2])), E.OPT_CLUSTER_CULL: int(rng.choice([0, 1, 1])),
-                E.OPT_STORAGE_ORDER: int(rng.choice([0, 1, 1])), E.OPT_XCD_SWIZZLE: int(rng.choice([0, 1, 2, 3]))}
-        desc = dict(it=it, n=n, sh=sh, w=w, h=h, order=order, proj=kind, shard=(index, count, layout), opts={int(k): v for k, v in opts.items()})
+                E.OPT_STORAGE_ORDER: int(rng.choice([0, 1, 1])), E.OPT_XCD_SWIZZLE: int(rng.choice([0, 1, 2, 3])),
+                E.OPT_CULL_DILATE: int(rng.choice([0, 1, 2, 5])), E.OPT_SORT_CACHE: int(rng.choice([0, 1, 1])),
+                E.OPT_SUPER_TILE: int(rng.choice([0, 0, 2, 8]))}
+        if rng.random() < (0.7 if heavy else 0.25):     # the library as it comes
+            opts = {}
+        use_depth = rng.random() < 0.25
+        multi = int(rng.choice([0, 0, 0, 2, 3, 8])) if not heavy else 0
+        if multi:
+            index, count = 0, 1
+        desc = dict(it=it, n=n, sh=sh, w=w, h=h, order=order, proj=kind, shard=(index, count, layout), depth=use_depth, multi=multi,
+                    opts={int(k): v for k, v in opts.items()})
+        depth = None
+        if use_depth:
+            depth = np.where(np.random.default_rng(it).random((h, w)) < 0.5, 0.5, 1.0).astype(np.float32)
         path = [(0, 1.0), (1, 1.0), (2, 1.0), (40, 1.3), (41, 1.3), (41, 1.3), (3, 1.0), (4, 0.7)]
         cams = [random_camera(np.random.default_rng(1000 + it), w, h, order, f, d, kind) for f, d in path]
         if it < first:
             continue
         print("..", desc, flush=True)
-        dut, plain = E.Engine(0), E.Engine(0)
+        dut, plain = (E.MultiEngine([0] * multi, E.TRANSPORT_COPY) if multi else E.Engine(0)), E.Engine(0)
         try:
-            for e in (dut, plain):
+            if multi:
+                dut.set_option(E.OPT_SHARD_LAYOUT, layout)
+            for e in ((plain,) if multi else (dut, plain)):
                 e.set_option(E.OPT_SHARD_LAYOUT, layout)
                 e.set_row_shard(index, count)
             # (the storage order is a property of the product under test: ties are drawn in storage order, so the plain context stores alike)
-            plain.set_option(E.OPT_STORAGE_ORDER, opts[E.OPT_STORAGE_ORDER])
+            plain.set_option(E.OPT_STORAGE_ORDER, opts.get(E.OPT_STORAGE_ORDER, 1))
             plain.set_option(E.OPT_OCCLUSION_CULL, 0); plain.set_option(E.OPT_CLUSTER_CULL, 0)
             plain.set_option(E.OPT_LOCAL_SORT, 0); plain.set_option(E.OPT_LAZY_COLOUR, 0)
             for k, v in opts.items():
                 dut.set_option(k, v)
             dut.upload(splats); plain.upload(splats)
             for k, c in enumerate(cams):
-                want = plain.render(c)
-                got = dut.render(c)
+                want = plain.render(c) if depth is None else plain.render_depth(c, depth)
+                got = (dut.render(c) if depth is None else (dut.render(c, depth) if multi else dut.render_depth(c, depth)))
                 frames += 1
                 if not np.array_equal(got, want, equal_nan=True):
                     d = np.abs(got - want)
                     print("MISMATCH frame", k, "max |diff|", float(np.nanmax(d)), "pixels", int((d.max(axis=-1) > 0).sum()), desc, dut.stats())
                     return 1
             st = dut.stats()
-            print("ok", it, "n", n, f"{w}x{h}", "proj", kind, "shard", (index, count, layout), "cull", opts[E.OPT_OCCLUSION_CULL], "slab", opts[E.OPT_FRONT_SLAB],
+            print("ok", it, "n", n, f"{w}x{h}", "proj", kind, "shard", (index, count, layout), "multi", multi, "depth", int(use_depth), "cull", opts.get(E.OPT_OCCLUSION_CULL, "-"), "slab", opts.get(E.OPT_FRONT_SLAB, "-"),
                   "| culled", st["frames_culled"], "slab", st["frames_slab"], "jumped", st["frames_jumped"], "repaired", st["frames_repaired"], "resorted", st["frames_resorted"], flush=True)
         finally:
             dut.close(); plain.close()

@@ -7,6 +7,7 @@ sort and shades eagerly (that configuration is what the -m gpu tests hold agains
 Some iterations render depth-tested (an opaque pass's depth image in front of part of the frame), some go through gsr_multi_*
 (several contexts on this GPU, COPY transport: shard, render, gather) and are compared with the unsharded frame.
 heavy = 1: clouds of 1 - 2.5 M splats at 1920x1080 (the policy's temporal culling and front-slab frames engage by themselves).
+heavy = 2: ONE long-lived context under test for the whole run (re-uploads, option flips, shard and shape changes between iterations).
 Exits non-zero at the first difference, printing the configuration that produced it."""
 import sys
 import time
@@ -39,6 +40,8 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     first = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # (skip the iterations before this one: same random sequence)
     heavy = len(sys.argv) > 4 and sys.argv[4] == "1"
+    longlived = len(sys.argv) > 4 and sys.argv[4] == "2"      # ONE context under test for the whole run: re-uploads, option flips, shape changes
+    keep_dut = None
     rng = np.random.default_rng(seed)
     t_start = time.time()
     frames = 0
@@ -53,8 +56,8 @@ def main():
         if n >= 1000 and rng.random() < 0.3:      # coincident splats: ties in the sort
             k = int(rng.integers(2, 80))
             splats.P[100:100 + k] = splats.P[100]
-        w = 1920 if heavy else int(rng.choice([64, 333, 640, 1280, 1920, 2500]))
-        h = 1080 if heavy else int(rng.choice([48, 217, 480, 720, 1080]))
+        w = 1920 if heavy else int(rng.choice([64, 333, 640, 1280, 1920, 2500, 2500, 5000, 9000, 16384]))
+        h = 1080 if heavy else (int(rng.choice([48, 217])) if w > 2500 else int(rng.choice([48, 217, 480, 720, 1080])))
         order = int(rng.integers(0, 4)) if sh else 0
         kind = int(rng.integers(0, 3))
         count = int(rng.choice([1, 1, 2, 3, 8]))
@@ -69,7 +72,12 @@ def main():
         if rng.random() < (0.7 if heavy else 0.25):     # the library as it comes
             opts = {}
         use_depth = rng.random() < 0.25
-        multi = int(rng.choice([0, 0, 0, 2, 3, 8])) if not heavy else 0
+        multi = int(rng.choice([0, 0, 0, 2, 3, 8])) if not (heavy or longlived) else 0
+        if longlived:     # every option gets a definite value (the context remembers the last iteration's)
+            full = {E.OPT_OCCLUSION_CULL: 1, E.OPT_FRONT_SLAB: 1, E.OPT_LOCAL_SORT: 1, E.OPT_LAZY_COLOUR: 1, E.OPT_FRAMES_IN_FLIGHT: 1, E.OPT_CLUSTER_CULL: 1,
+                    E.OPT_STORAGE_ORDER: 1, E.OPT_XCD_SWIZZLE: 2, E.OPT_CULL_DILATE: 2, E.OPT_SORT_CACHE: 1, E.OPT_SUPER_TILE: 0}
+            full.update(opts)
+            opts = full
         if multi:
             index, count = 0, 1
         desc = dict(it=it, n=n, sh=sh, w=w, h=h, order=order, proj=kind, shard=(index, count, layout), depth=use_depth, multi=multi,
@@ -82,7 +90,12 @@ def main():
         if it < first:
             continue
         print("..", desc, flush=True)
-        dut, plain = (E.MultiEngine([0] * multi, E.TRANSPORT_COPY) if multi else E.Engine(0)), E.Engine(0)
+        if longlived:
+            if keep_dut is None:
+                keep_dut = E.Engine(0)
+            dut, plain = keep_dut, E.Engine(0)
+        else:
+            dut, plain = (E.MultiEngine([0] * multi, E.TRANSPORT_COPY) if multi else E.Engine(0)), E.Engine(0)
         try:
             if multi:
                 dut.set_option(E.OPT_SHARD_LAYOUT, layout)
@@ -97,6 +110,18 @@ def main():
                 dut.set_option(k, v)
             dut.upload(splats); plain.upload(splats)
             for k, c in enumerate(cams):
+                if longlived and rng.random() < 0.3:       # an option flipped, or the shard changed, in mid-stream
+                    which = int(rng.integers(0, 9))
+                    choices = [(E.OPT_OCCLUSION_CULL, [0, 1, 2, 3]), (E.OPT_FRONT_SLAB, [0, 1, 2]), (E.OPT_LOCAL_SORT, [0, 1, 2]), (E.OPT_LAZY_COLOUR, [0, 1, 2]),
+                               (E.OPT_FRAMES_IN_FLIGHT, [1, 2]), (E.OPT_CLUSTER_CULL, [0, 1]), (E.OPT_XCD_SWIZZLE, [0, 1, 2, 3]), (E.OPT_CULL_DILATE, [0, 1, 2, 5])]
+                    if which < 8:
+                        o, vals = choices[which]
+                        dut.set_option(o, int(rng.choice(vals)))
+                    else:
+                        cnt2 = int(rng.choice([1, 2, 3, 8])); idx2 = int(rng.integers(0, cnt2)); lay2 = int(rng.integers(0, 2))
+                        for e in (dut, plain):
+                            e.set_option(E.OPT_SHARD_LAYOUT, lay2)
+                            e.set_row_shard(idx2, cnt2)
                 want = plain.render(c) if depth is None else plain.render_depth(c, depth)
                 got = (dut.render(c) if depth is None else (dut.render(c, depth) if multi else dut.render_depth(c, depth)))
                 frames += 1
@@ -108,7 +133,9 @@ def main():
             print("ok", it, "n", n, f"{w}x{h}", "proj", kind, "shard", (index, count, layout), "multi", multi, "depth", int(use_depth), "cull", opts.get(E.OPT_OCCLUSION_CULL, "-"), "slab", opts.get(E.OPT_FRONT_SLAB, "-"),
                   "| culled", st["frames_culled"], "slab", st["frames_slab"], "jumped", st["frames_jumped"], "repaired", st["frames_repaired"], "resorted", st["frames_resorted"], flush=True)
         finally:
-            dut.close(); plain.close()
+            if not longlived:
+                dut.close()
+            plain.close()
     print(f"{iters} iterations, {frames} frames bit-identical, {time.time() - t_start:.0f} s")
     return 0
 

@@ -22,7 +22,14 @@ E = pkg.engine
 
 
 def random_camera(rng, w, h, order, frame, dist_scale, kind):
-    near, far = 0.01, 1.0e5
+    # (rng is seeded per iteration: the draws below are the same for every frame of the iteration's path)
+    near, far = float(rng.choice([0.01, 0.01, 0.5, 2.0])), float(rng.choice([1.0e5, 1.0e5, 6.0, 4.7]))
+    obj = None
+    if rng.random() < 0.3:                      # an object-level transform: rotation, non-uniform scale, shear, translation
+        a = rng.standard_normal((3, 3)) * 0.35 + np.eye(3) * rng.uniform(0.5, 1.6)
+        obj = np.eye(4); obj[:3, :3] = a; obj[:3, 3] = rng.uniform(-0.5, 0.5, 3)
+    if rng.random() < 0.3:                      # the camera close to, or inside, the cloud
+        dist_scale *= float(rng.choice([0.03, 0.12, 0.3]))
     aspect = w / h
     proj = None
     if kind == 1:      # off-centre frustum
@@ -32,7 +39,7 @@ def random_camera(rng, w, h, order, frame, dist_scale, kind):
     elif kind == 2:    # orthographic
         half = rng.uniform(0.6, 1.6)
         proj = pkg.camera.orthographic(-half, half, -half / aspect, half / aspect, near, far)
-    return pkg.camera.make_camera(w, h, sh_order=order, frame=frame, distance=4.61995 * dist_scale, proj_matrix=proj)
+    return pkg.camera.make_camera(w, h, sh_order=order, frame=frame, distance=4.61995 * dist_scale, proj_matrix=proj, near=near, far=far, object_matrix=obj)
 
 
 def main():
@@ -56,6 +63,17 @@ def main():
         if n >= 1000 and rng.random() < 0.3:      # coincident splats: ties in the sort
             k = int(rng.integers(2, 80))
             splats.P[100:100 + k] = splats.P[100]
+        if n >= 64 and rng.random() < 0.25:       # poisoned attributes: NaN, infinities, zeros, absurd magnitudes
+            f32 = np.array([np.nan, np.inf, -np.inf, 1.0e30, -1.0e30, 0.0, 1.0e-30], np.float32)
+            h16 = pkg.scenes.f16bits(np.array([np.nan, np.inf, -np.inf, 65504.0, 0.0, 6.0e-8, -1.0], np.float32))
+            for _ in range(int(rng.integers(1, 12))):
+                i = int(rng.integers(0, n))
+                what = int(rng.integers(0, 5))
+                if what == 0: splats.P[i, int(rng.integers(0, 3))] = rng.choice(f32)
+                elif what == 1: splats.scale[i, int(rng.integers(0, 3))] = rng.choice(h16)
+                elif what == 2: splats.orient[i, :] = rng.choice(h16) if rng.random() < 0.5 else pkg.scenes.f16bits(np.zeros(4, np.float32))
+                elif what == 3: splats.alpha[i] = rng.choice(np.array([np.nan, np.inf, -1.0, 2.0, 0.0, 1.0 / 255.0, 1.0], np.float32))
+                else: splats.Cd[i, int(rng.integers(0, 3))] = rng.choice(h16)
         w = 1920 if heavy else int(rng.choice([64, 333, 640, 1280, 1920, 2500, 2500, 5000, 9000, 16384]))
         h = 1080 if heavy else (int(rng.choice([48, 217])) if w > 2500 else int(rng.choice([48, 217, 480, 720, 1080])))
         order = int(rng.integers(0, 4)) if sh else 0

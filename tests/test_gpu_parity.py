@@ -1741,6 +1741,47 @@ def test_front_slab_phase_two_outgrows_the_list_buffer(pkg):
         dut.close(); plain.close()
 
 
+def test_randomised_frames_match_the_oracle(pkg, oracle):
+    """random small clouds (scale ranges, huge splats, coincident splats), framebuffers and cameras -- perspective, off-centre,
+    orthographic, object-level transforms, near / far planes that cut the cloud, cameras inside it -- under random library
+    options: every frame within 1e-3 per channel of the CPU oracle (the generators are tools/fuzz_parity.py's)"""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    E = pkg.engine
+    rng = np.random.default_rng(int(os.environ.get("GSR_FUZZ_SEED", "2026")))
+    worst = 0.0
+    for it in range(int(os.environ.get("GSR_FUZZ_ITERS", "40"))):      # (a longer hunt: GSR_FUZZ_ITERS=400 GSR_FUZZ_SEED=...)
+        n = int(rng.choice([1, 64, 65, 1000, 5000, 20000, 60000]))
+        sh = bool(rng.integers(0, 2))
+        lo = rng.uniform(-6.0, -3.0)
+        splats = pkg.scenes.make_scene(n, seed=int(rng.integers(1, 1 << 30)), sh=sh, log_scale_range=(lo, lo + rng.uniform(0.5, 2.5)))
+        if n >= 1000 and rng.random() < 0.3:
+            splats.scale[:100] = pkg.scenes.f16bits(rng.uniform(0.2, 1.5, size=(100, 3)))
+        if n >= 1000 and rng.random() < 0.3:
+            splats.P[100:140] = splats.P[100]
+        w, h = int(rng.choice([64, 333, 640, 1280])), int(rng.choice([48, 217, 480]))
+        order = int(rng.integers(0, 4)) if sh else 0
+        kind = int(rng.integers(0, 3))
+        cams = [fz.random_camera(np.random.default_rng(5000 + it), w, h, order, f, d, kind) for f, d in ((0, 1.0), (1, 1.0), (40, 1.3))]
+        eng = E.Engine(0)
+        try:
+            eng.set_option(E.OPT_OCCLUSION_CULL, int(rng.choice([0, 1, 2, 3])))
+            eng.set_option(E.OPT_FRONT_SLAB, int(rng.choice([0, 1, 2])))
+            eng.set_option(E.OPT_LOCAL_SORT, int(rng.choice([0, 1, 2])))
+            eng.set_option(E.OPT_LAZY_COLOUR, int(rng.choice([0, 1, 2])))
+            eng.upload(splats)
+            for k, c in enumerate(cams):
+                img = eng.render(c)
+                if k != 1:
+                    ref = oracle.render(splats, c, threads=oracle.max_threads())
+                    worst = max(worst, _check_image(img, ref))
+        finally:
+            eng.close()
+    assert worst > 0.0     # (something was drawn)
+
+
 def test_randomised_exactness_soak(pkg):
     """tools/fuzz_parity.py, a short run: random clouds, framebuffers, projections, row shards and library options; every frame of a
     short camera path bit-identical to a context that culls nothing, takes the global sort and shades eagerly"""

@@ -296,6 +296,8 @@ struct gsr_context {
     bool order_pays = false;           // k_sum_work's other verdict: the tiles differ enough in work for k_tile_order to pay
     unsigned long long* wire_zbuf = nullptr;   // wireframe overlay: (depth bits, splat index) per pixel ...
     float* wire_out = nullptr;                 // ... and the image staged for a host target
+    uint32_t* wire_inv = nullptr;              // ... and, with spatially ordered storage, upload index -> storage slot (built on first use per geometry)
+    uint64_t wire_inv_gen = 0;
     size_t wire_cap = 0;                       // pixels both hold
     char* stage = nullptr;                     // raw attribute arrays of an upload in progress
     size_t stage_cap = 0;
@@ -520,7 +522,7 @@ extern "C" void gsr_destroy(gsr_context* c)
     free_geometry(c);
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) slot_destroy(c->slot[k]);
     dev_free(c->tile_map);
-    dev_free(c->wire_zbuf); dev_free(c->wire_out); dev_free(c->stage);
+    dev_free(c->wire_zbuf); dev_free(c->wire_out); dev_free(c->wire_inv); dev_free(c->stage);
     dev_free(c->prefix); dev_free(c->prefix_all); dev_free(c->prefix_none); dev_free(c->lazy_hint);
     dev_free(c->pos_order); dev_free(c->blk_pre);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -2195,14 +2197,23 @@ extern "C" int gsr_render_wire(gsr_context* c, const gsr_camera* cam, float* rgb
         }
         c->wire_cap = npix;
     }
+    // outlines at the same depth are drawn in UPLOAD order (k_wire.h): with spatially ordered storage the resolve pass goes back
+    // from the winner's upload index to its slot through the inverse of the storage permutation, built once per geometry
+    if (c->perm && c->n > 0 && (!c->wire_inv || c->wire_inv_gen != c->geo_gen)) {
+        dev_free(c->wire_inv);
+        if ((rc = dev_alloc(&c->wire_inv, (size_t)c->n))) return rc;
+        hipLaunchKernelGGL(k_invert_perm, dim3(div_up(c->n, 256)), dim3(256), 0, s, c->perm, c->n, c->wire_inv);
+        c->wire_inv_gen = c->geo_gen;
+    }
+    const uint32_t* const inv = (c->perm && c->n > 0) ? c->wire_inv : (const uint32_t*)nullptr;
     unsigned long long* zbuf = c->wire_zbuf;
     float* target = out_is_device ? rgba_out : c->wire_out;
     hipError_t e = hipMemsetAsync(zbuf, 0xff, npix * 8, s);
     if (e == hipSuccess && c->n > 0)
-        hipLaunchKernelGGL(k_wire_splats, dim3(div_up(c->n, 256)), dim3(256), 0, s, c->n, f, c->geoA, c->geoB, zbuf);
+        hipLaunchKernelGGL(k_wire_splats, dim3(div_up(c->n, 256)), dim3(256), 0, s, c->n, f, c->geoA, c->geoB, zbuf, inv ? c->perm : (const uint32_t*)nullptr);
     if (e == hipSuccess)
         hipLaunchKernelGGL(k_wire_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, zbuf, npix, c->col,
-                           reinterpret_cast<float4*>(target));
+                           reinterpret_cast<float4*>(target), inv);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess && !out_is_device) e = hipMemcpyAsync(rgba_out, c->wire_out, npix * 16, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);

@@ -40,7 +40,8 @@ __device__ __forceinline__ void gsr_wire_edge(float x0, float y0, float x1, floa
 
 __global__ void __launch_bounds__(256)
 k_wire_splats(uint32_t n, GsrFrame f, const float4* __restrict__ geoA, const uint4* __restrict__ geoB,
-              unsigned long long* __restrict__ zbuf)
+              unsigned long long* __restrict__ zbuf,
+              const uint32_t* __restrict__ perm /* storage slot -> index in the upload (spatially ordered storage), or NULL */)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -68,8 +69,10 @@ k_wire_splats(uint32_t n, GsrFrame f, const float4* __restrict__ geoA, const uin
     const float c1x = (cx + ax) - bx, c1y = (cy + ay) - by;       // (+2,-2)
     const float c2x = (cx + ax) + bx, c2y = (cy + ay) + by;       // (+2,+2)
     const float c3x = (cx - ax) + bx, c3y = (cy - ay) + by;       // (-2,+2)
-    // nearest fragment wins, earlier splat on equal depth (GL_LESS in draw order): min of (depth bits, index)
-    const unsigned long long frag = ((unsigned long long)__builtin_bit_cast(uint32_t, zw) << 32) | (unsigned long long)i;
+    // nearest fragment wins, earlier splat on equal depth (GL_LESS in draw order): min of (depth bits, index) -- the index in the
+    // UPLOAD, which is the order the reference's line list is built and drawn in (src/GR_GSplat.C:374-421), not the storage slot:
+    // under an orthographic camera with a distant far plane whole groups of outlines share their depth bits
+    const unsigned long long frag = ((unsigned long long)__builtin_bit_cast(uint32_t, zw) << 32) | (unsigned long long)(perm ? perm[i] : i);
     gsr_wire_edge(c0x, c0y, c1x, c1y, f.width, f.height, frag, zbuf);   // vertices 0-1
     gsr_wire_edge(c1x, c1y, c2x, c2y, f.width, f.height, frag, zbuf);   // 2-3
     gsr_wire_edge(c2x, c2y, c3x, c3y, f.width, f.height, frag, zbuf);   // 4-5
@@ -78,15 +81,24 @@ k_wire_splats(uint32_t n, GsrFrame f, const float4* __restrict__ geoA, const uin
 
 __global__ void __launch_bounds__(256)
 k_wire_resolve(const unsigned long long* __restrict__ zbuf, size_t npix, const uint4* __restrict__ col0,
-               float4* __restrict__ out)
+               float4* __restrict__ out, const uint32_t* __restrict__ inv /* index in the upload -> storage slot, or NULL */)
 {
     const size_t p = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (p >= npix) return;
     const unsigned long long v = zbuf[p];
     float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (v != GSR_WIRE_EMPTY) {
-        const uint4 c = col0[(uint32_t)(v & 0xffffffffull)];      // chunk 0 starts with Cd.rgb (f16)
+        const uint32_t idx = (uint32_t)(v & 0xffffffffull);
+        const uint4 c = col0[inv ? inv[idx] : idx];               // chunk 0 starts with Cd.rgb (f16)
         o = make_float4(gsr_h2f(c.x & 0xffffu), gsr_h2f(c.x >> 16), gsr_h2f(c.y & 0xffffu), 1.0f);
     }
     out[p] = o;
+}
+
+// inv[perm[j]] = j
+__global__ void __launch_bounds__(256)
+k_invert_perm(const uint32_t* __restrict__ perm, uint32_t n, uint32_t* __restrict__ inv)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j < n) inv[perm[j]] = j;
 }

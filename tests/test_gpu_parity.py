@@ -1782,6 +1782,31 @@ def test_randomised_frames_match_the_oracle(pkg, oracle):
     assert worst > 0.0     # (something was drawn)
 
 
+def test_randomised_wire_overlays_match_the_oracle(pkg, oracle):
+    """the wireframe overlay (N3) of random clouds under random cameras: bit-identical to the oracle's"""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    rng = np.random.default_rng(int(os.environ.get("GSR_FUZZ_SEED", "77")))
+    eng = pkg.Engine(0)
+    try:
+        drawn = 0
+        for it in range(int(os.environ.get("GSR_FUZZ_ITERS", "25"))):
+            n = int(rng.choice([1, 65, 1000, 20000]))
+            lo = rng.uniform(-6.0, -2.5)
+            splats = pkg.scenes.make_scene(n, seed=int(rng.integers(1, 1 << 30)), sh=bool(rng.integers(0, 2)), log_scale_range=(lo, lo + rng.uniform(0.5, 2.5)))
+            w, h = int(rng.choice([64, 333, 640])), int(rng.choice([48, 217, 400]))
+            cam = fz.random_camera(np.random.default_rng(9000 + it), w, h, 0, int(rng.integers(0, 60)), float(rng.choice([1.0, 1.3, 0.6])), int(rng.integers(0, 3)))
+            eng.upload(splats)
+            img = eng.render_wire(cam)
+            assert np.array_equal(img, oracle.render_wire(splats, cam)), (it, n, w, h)
+            drawn += int(img.any())
+        assert drawn >= 8
+    finally:
+        eng.close()
+
+
 def test_randomised_exactness_soak(pkg):
     """tools/fuzz_parity.py, a short run: random clouds, framebuffers, projections, row shards and library options; every frame of a
     short camera path bit-identical to a context that culls nothing, takes the global sort and shades eagerly"""

@@ -126,7 +126,18 @@ def main():
             plain.set_option(E.OPT_LOCAL_SORT, 0); plain.set_option(E.OPT_LAZY_COLOUR, 0)
             for k, v in opts.items():
                 dut.set_option(k, v)
-            dut.upload(splats); plain.upload(splats)
+            if not multi and n >= 8 and rng.random() < 0.25:      # the same cloud staged as several entries (gsr_upload_begin / append / end)
+                cuts = sorted(set(int(v) for v in rng.integers(1, n, size=int(rng.integers(1, 4)))))
+                S = pkg.scenes.Splats
+                parts = []
+                for a, b in zip([0] + cuts, cuts + [n]):
+                    parts.append(S(P=splats.P[a:b], Cd=splats.Cd[a:b], alpha=splats.alpha[a:b], scale=splats.scale[a:b], orient=splats.orient[a:b],
+                                   shx=None if splats.shx is None else splats.shx[a:b], shy=None if splats.shy is None else splats.shy[a:b],
+                                   shz=None if splats.shz is None else splats.shz[a:b]))
+                dut.upload_parts(parts)
+            else:
+                dut.upload(splats)
+            plain.upload(splats)
             for k, c in enumerate(cams):
                 if longlived and rng.random() < 0.3:       # an option flipped, or the shard changed, in mid-stream
                     which = int(rng.integers(0, 9))

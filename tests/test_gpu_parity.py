@@ -1807,6 +1807,51 @@ def test_randomised_wire_overlays_match_the_oracle(pkg, oracle):
         eng.close()
 
 
+def test_randomised_records_and_depth_order_match_the_oracle(pkg, oracle):
+    """K1's records and sort keys bit for bit, and the depth order index for index, against the oracle under random cameras
+    (perspective / off-centre / orthographic, object-level transforms, near / far planes, positions inside the cloud), random
+    origins and clouds with coincident splats"""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    rng = np.random.default_rng(int(os.environ.get("GSR_FUZZ_SEED", "4242")))
+    eng = pkg.Engine(0)
+    try:
+        eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, 0)      # (every clip-visible splat gets a record)
+        seen = 0
+        for it in range(int(os.environ.get("GSR_FUZZ_ITERS", "30"))):
+            n = int(rng.choice([65, 1000, 20000, 70001]))
+            sh = bool(rng.integers(0, 2))
+            lo = rng.uniform(-6.0, -3.0)
+            splats = pkg.scenes.make_scene(n, seed=int(rng.integers(1, 1 << 30)), sh=sh, log_scale_range=(lo, lo + rng.uniform(0.5, 2.5)))
+            if n >= 1000:
+                splats.P[100:160] = splats.P[500:560]          # exact ties
+            w, h = int(rng.choice([64, 333, 640])), int(rng.choice([48, 217, 400]))
+            order = int(rng.integers(0, 4)) if sh else 0
+            cam = fz.random_camera(np.random.default_rng(7000 + it), w, h, order, int(rng.integers(0, 60)), float(rng.choice([1.0, 1.3, 0.5])), int(rng.integers(0, 3)))
+            origin = tuple(float(v) for v in rng.uniform(-0.5, 0.5, 3)) if rng.random() < 0.5 else (0.0, 0.0, 0.0)
+            eng.upload(splats, origin=origin)
+            eng.render(cam)
+            dev = eng.debug_records(splats.n)
+            ref = oracle.preprocess(splats, cam, origin=origin)
+            vis = dev["visible"] == 1
+            seen += int(vis.sum())
+            assert (ref["visible"][vis] == 1).all(), it
+            assert np.array_equal(dev["key"][vis].view(np.uint32), ref["key"][vis].view(np.uint32)), it
+            for f in REC_FIELDS:
+                a, b = dev[f][vis].view(np.uint32), ref[f][vis].view(np.uint32)
+                assert np.array_equal(a, b), f"iteration {it}, field {f}: {np.count_nonzero(a != b)} mismatches"
+            order_dev = eng.debug_depth_order(splats.n)
+            order_ref = oracle.host_sort_only(splats.P, cam.cam_pos)
+            keep = np.zeros(splats.n, bool)
+            keep[order_dev] = True
+            assert np.array_equal(order_dev, order_ref[keep[order_ref]]), it
+        assert seen > 1000
+    finally:
+        eng.close()
+
+
 def test_randomised_exactness_soak(pkg):
     """tools/fuzz_parity.py, a short run: random clouds, framebuffers, projections, row shards and library options; every frame of a
     short camera path bit-identical to a context that culls nothing, takes the global sort and shades eagerly"""

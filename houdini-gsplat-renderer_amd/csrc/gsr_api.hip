@@ -2073,52 +2073,64 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
 
 static FrameSlot* latest_slot(gsr_context* c);
 // a culled frame is handed over only once it has checked itself; one that broke a horizon is rendered again, complete
-static int frame_check(gsr_context* c, FrameSlot& slot, const gsr_camera* cam, const float* depth, int depth_is_device,
+static int frame_check(gsr_context* c, FrameSlot& first, const gsr_camera* cam, const float* depth, int depth_is_device,
                        float* rgba_out, int out_is_device)
 {
-    if (slot.job.sort_failed || slot.job.redo) {
-        // the small-frame sort met a bucket far beyond its prediction and left it unsorted: the frame again, with the global sort
-        // (and without culling: a prediction that far off means the view jumped, and the horizons with it) -- or the second phase of
-        // a front-slab frame ran off its list buffer (frame_finish): the frame again, as it was
-        if (slot.job.sort_failed) {
-            c->st.frames_resorted += 1;
-            c->classic_once = true;
+    // A frame that is rendered again is checked again: the repair of a culled frame may itself meet a bucket its small-frame sort
+    // gives up, or -- as a front-slab frame -- a list buffer its second phase overruns.  Every reason removes itself (the re-sort
+    // takes the global passes, the redo finds the buffer regrown, the repair does not cull), so a handful of rounds is the most a
+    // frame can need; found by tools/fuzz_parity.py: the second re-render used to be handed over unchecked.
+    FrameSlot* cur = &first;
+    for (int round = 0; round < 8; ++round) {
+        FrameSlot& slot = *cur;
+        if (slot.job.sort_failed || slot.job.redo) {
+            // the small-frame sort met a bucket far beyond its prediction and left it unsorted: the frame again, with the global sort
+            // (and without culling: a prediction that far off means the view jumped, and the horizons with it) -- or the second phase
+            // of a front-slab frame ran off its list buffer (frame_finish): the frame again, as it was
+            if (slot.job.sort_failed) {
+                c->st.frames_resorted += 1;
+                c->classic_once = true;
+            }
+            c->frame_no -= 1;
+            c->st.frames -= 1;
+            FrameSlot* sl2 = nullptr;
+            int rc2 = frame_begin(c, cam, depth, depth_is_device, rgba_out, out_is_device, &sl2, false);
+            if (rc2) return rc2;
+            if ((rc2 = frame_finish(c, *sl2))) return rc2;
+            cur = sl2;
+            continue;
         }
-        c->frame_no -= 1;
-        c->st.frames -= 1;
-        FrameSlot* sl2 = nullptr;
-        int rc2 = frame_begin(c, cam, depth, depth_is_device, rgba_out, out_is_device, &sl2, false);
-        if (rc2) return rc2;
-        return frame_finish(c, *sl2);
-    }
-    if (!slot.job.cull) return GSR_OK;
-    bool broke = false;
-    int rc = frame_verdict(c, slot, &broke);
-    if (rc) return rc;
-    if (!broke) {
-        if (++c->cull_streak >= 64) { c->cull_streak = 0; c->cull_backoff = 8; if (c->cull_dilate > c->opt_dilate) c->cull_dilate -= 1; }
+        if (!slot.job.cull) return GSR_OK;
+        bool broke = false;
+        int rc = frame_verdict(c, slot, &broke);
+        if (rc) return rc;
+        if (!broke) {
+            if (++c->cull_streak >= 64) { c->cull_streak = 0; c->cull_backoff = 8; if (c->cull_dilate > c->opt_dilate) c->cull_dilate -= 1; }
 #ifdef GSR_HOST_TIMING
-        g_t_verdict = now_us();
+            g_t_verdict = now_us();
 #endif
-        return GSR_OK;
+            return GSR_OK;
+        }
+        c->st.frames_repaired += 1;
+        // The view is changing faster than the horizons follow.  First answer: compare rects with the horizons of a wider
+        // neighbourhood from now on (the repaired frame leaves fresh horizons, and the radius shrinks back while frames hold);
+        // only when that is exhausted, leave culling alone for a while (8, 32, 128, 512, 1024 frames).
+        if (c->cull_dilate < 16) {
+            c->cull_dilate = std::max(2 * c->cull_dilate, 1);
+        } else {
+            c->cull_holdoff = std::max(c->cull_holdoff, c->cull_backoff);
+            c->cull_backoff = c->cull_backoff >= 256 ? 1024 : 4 * c->cull_backoff;
+        }
+        c->cull_streak = 0;
+        c->frame_no -= 1;          // the same frame again, in the same slot
+        c->st.frames -= 1;
+        FrameSlot* sl = nullptr;
+        rc = frame_begin(c, cam, depth, depth_is_device, rgba_out, out_is_device, &sl, false);
+        if (rc) return rc;
+        if ((rc = frame_finish(c, *sl))) return rc;
+        cur = sl;
     }
-    c->st.frames_repaired += 1;
-    // The view is changing faster than the horizons follow.  First answer: compare rects with the horizons of a wider
-    // neighbourhood from now on (the repaired frame leaves fresh horizons, and the radius shrinks back while frames hold);
-    // only when that is exhausted, leave culling alone for a while (8, 32, 128, 512, 1024 frames).
-    if (c->cull_dilate < 16) {
-        c->cull_dilate = std::max(2 * c->cull_dilate, 1);
-    } else {
-        c->cull_holdoff = std::max(c->cull_holdoff, c->cull_backoff);
-        c->cull_backoff = c->cull_backoff >= 256 ? 1024 : 4 * c->cull_backoff;
-    }
-    c->cull_streak = 0;
-    c->frame_no -= 1;          // the same frame again, in the same slot
-    c->st.frames -= 1;
-    FrameSlot* sl = nullptr;
-    rc = frame_begin(c, cam, depth, depth_is_device, rgba_out, out_is_device, &sl, false);
-    if (rc) return rc;
-    return frame_finish(c, *sl);
+    return set_err(GSR_E_HIP, "gsr_render: the frame did not settle after eight attempts");
 }
 
 extern "C" int gsr_render(gsr_context* c, const gsr_camera* cam, float* rgba_out, int out_is_device)

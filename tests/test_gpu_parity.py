@@ -1857,9 +1857,11 @@ def test_randomised_exactness_soak(pkg):
     short camera path bit-identical to a context that culls nothing, takes the global sort and shades eagerly"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "11"], capture_output=True, text=True, timeout=900, cwd=root)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
-    assert "frames bit-identical" in res.stdout
+    # fresh contexts per iteration; then ONE long-lived context with re-uploads and option / shard flips in mid-stream
+    for args in (["120", "11"], ["100", "12", "0", "2"]):
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py")] + args, capture_output=True, text=True, timeout=900, cwd=root)
+        assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+        assert "frames bit-identical" in res.stdout
 
 
 def test_a_frame_whose_clusters_are_all_culled_is_empty(pkg, engine):

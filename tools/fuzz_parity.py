@@ -12,6 +12,7 @@ mode 1: clouds of 1 - 2.5 M splats at 1920x1080 (the policy's temporal culling a
 mode 2: ONE long-lived context under test for the whole run: re-uploads, option flips and shard changes in mid-stream.
 At the first difference the iteration is replayed on fresh contexts -- alone, then behind its predecessors, then with every
 non-default option put back -- to say what it takes, and the run exits non-zero with the configuration that produced it."""
+import ctypes as C
 import os
 import sys
 import time
@@ -23,6 +24,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 pkg = ge.load_package()
 E = pkg.engine
+HIP = C.CDLL("libamdhip64.so")
 
 DEFAULTS = {E.OPT_OCCLUSION_CULL: 1, E.OPT_FRONT_SLAB: 1, E.OPT_LOCAL_SORT: 1, E.OPT_LAZY_COLOUR: 1, E.OPT_FRAMES_IN_FLIGHT: 1, E.OPT_CLUSTER_CULL: 1,
             E.OPT_STORAGE_ORDER: 1, E.OPT_XCD_SWIZZLE: 2, E.OPT_CULL_DILATE: 2, E.OPT_SORT_CACHE: 1, E.OPT_SUPER_TILE: 0, E.OPT_DEFERRED_CHECK: 0}
@@ -118,10 +120,11 @@ def make_script(rng, it, heavy, longlived):
                 else:
                     cnt2 = int(rng.choice([1, 2, 3, 8]))
                     flips[k] = ("shard", int(rng.integers(0, cnt2)), cnt2, int(rng.integers(0, 2)))
+    dev_target = bool(rng.random() < 0.3) and not multi and not use_depth     # the frames go to a DEVICE buffer (no staging copy; deferred hand-over possible)
     depth = np.where(np.random.default_rng(it).random((h, w)) < 0.5, 0.5, 1.0).astype(np.float32) if use_depth else None
-    desc = dict(it=it, n=n, sh=sh, w=w, h=h, order=order, proj=kind, shard=(index, count, layout), depth=use_depth, multi=multi, parts=cuts,
+    desc = dict(it=it, n=n, sh=sh, w=w, h=h, order=order, proj=kind, shard=(index, count, layout), depth=use_depth, multi=multi, parts=cuts, dev_target=dev_target,
                 opts={int(k): v for k, v in opts.items()}, flips={k: v for k, v in flips.items()})
-    return dict(splats=splats, n=n, w=w, h=h, shard=(index, count, layout), opts=opts, depth=depth, multi=multi, cams=cams, cuts=cuts, flips=flips, desc=desc)
+    return dict(splats=splats, n=n, w=w, h=h, shard=(index, count, layout), opts=opts, depth=depth, multi=multi, cams=cams, cuts=cuts, flips=flips, desc=desc, dev_target=dev_target)
 
 
 def execute(sc, dut, verbose=False):
@@ -152,6 +155,8 @@ def execute(sc, dut, verbose=False):
         else:
             dut.upload(splats)
         plain.upload(splats)
+        count_now = count
+        devbuf = [C.c_void_p(), 0]
         deferred = bool(opts.get(E.OPT_DEFERRED_CHECK, 0)) and not multi
         truncated_seen = dut.stats()["frames_truncated"] if not multi else 0
         for k, c in enumerate(sc["cams"]):
@@ -163,8 +168,22 @@ def execute(sc, dut, verbose=False):
                     for e in (dut, plain):
                         e.set_option(E.OPT_SHARD_LAYOUT, fl[3])
                         e.set_row_shard(fl[1], fl[2])
+                    count_now = fl[2]
             want = plain.render(c) if depth is None else plain.render_depth(c, depth)
-            got = (dut.render(c) if depth is None else (dut.render(c, depth) if multi else dut.render_depth(c, depth)))
+            if sc.get("dev_target"):
+                rows_ = dut.band_rows(c.height) if count_now > 1 else c.height
+                nbytes = rows_ * c.width * 16
+                if devbuf[1] < nbytes:
+                    if devbuf[0].value: HIP.hipFree(devbuf[0])
+                    assert HIP.hipMalloc(C.byref(devbuf[0]), C.c_size_t(nbytes)) == 0
+                    devbuf[1] = nbytes
+                assert HIP.hipMemset(devbuf[0], 0, C.c_size_t(nbytes)) == 0      # (band padding is never written in a device target)
+                dut.render_to_device(c, devbuf[0].value)
+                dut.synchronize()
+                got = np.empty((rows_, c.width, 4), np.float32)
+                assert HIP.hipMemcpy(C.c_void_p(got.ctypes.data), devbuf[0], C.c_size_t(nbytes), 2) == 0
+            else:
+                got = (dut.render(c) if depth is None else (dut.render(c, depth) if multi else dut.render_depth(c, depth)))
             frames += 1
             if deferred:
                 # (deferred hand-over: a frame whose lists outgrew the buffer is handed over with clamped lists and COUNTED --
@@ -188,6 +207,10 @@ def execute(sc, dut, verbose=False):
         return frames, None
     finally:
         plain.close()
+        try:
+            if devbuf[0].value: HIP.hipFree(devbuf[0])
+        except NameError:
+            pass
 
 
 def fresh_dut(sc):

@@ -1852,6 +1852,61 @@ def test_randomised_records_and_depth_order_match_the_oracle(pkg, oracle):
         eng.close()
 
 
+def test_randomised_shim_protocol(pkg):
+    """the host shim (N2) driven like Houdini drives the reference -- primitives registered, re-cooked (new cache version),
+    destroyed, shown in changing subsets -- against the C ABI fed by hand: every redraw = the active entries in registry (id)
+    order, SH present iff the LAST active entry has it (entries without get zeros), the shim's own origin"""
+    import os
+    E = pkg.engine
+    rng = np.random.default_rng(int(os.environ.get("GSR_FUZZ_SEED", "31")))
+    R = pkg.GSplatRenderer(0)
+    direct = E.Engine(0)
+    S = pkg.scenes.Splats
+    try:
+        R.setSphericalHarmonicsOrder(3)
+        details = {}          # gdp -> (id, splats)
+        version = 1
+        drawn = 0
+        for step in range(int(os.environ.get("GSR_FUZZ_ITERS", "60"))):
+            act = rng.random()
+            gdp = 0x1000 * int(rng.integers(1, 6))
+            if act < 0.35 or not details:                       # a primitive cooks (new or re-cooked: a new cache version purges the old entry)
+                version += 1
+                sp = pkg.scenes.make_scene(int(rng.choice([1, 64, 500, 3000, 20000])), seed=int(rng.integers(1, 1 << 30)), sh=bool(rng.random() < 0.6))
+                sp.P[:] += rng.uniform(-0.6, 0.6, 3).astype(np.float32)
+                details[gdp] = (R.registerUpdate(gdp, (version, 0, 0, 0), 0, sp), sp)
+            elif act < 0.45 and gdp in details:                 # a primitive is destroyed
+                R.flushEntriesForMatchingDetail(details.pop(gdp)[0])
+            w, h = int(rng.choice([64, 320, 640])), int(rng.choice([48, 240, 400]))
+            cam = pkg.camera.make_camera(w, h, sh_order=3, frame=int(rng.integers(0, 90)), distance=4.61995 * float(rng.choice([1.0, 1.3, 0.7])))
+            ids = sorted(rid for rid, _ in details.values())
+            active = [rid for rid in ids if rng.random() < 0.7]
+            img = R.frame(cam, active)
+            if not active:
+                assert not img.any(), step
+                continue
+            by_id = {rid: sp for rid, sp in details.values()}
+            parts = [by_id[rid] for rid in active]
+            has_sh = parts[-1].shx is not None                   # registry iteration order = id order: the last active entry decides
+            n_all = sum(p_.n for p_ in parts)
+            def field(f):
+                return np.concatenate([getattr(p_, f) for p_ in parts])
+            def shf(f):
+                return np.concatenate([getattr(p_, f) if getattr(p_, f) is not None else np.zeros((p_.n, 16), np.uint16) for p_ in parts]) if has_sh else None
+            cat = S(P=field("P"), Cd=field("Cd"), alpha=field("alpha"), scale=field("scale"), orient=field("orient"), shx=shf("shx"), shy=shf("shy"), shz=shf("shz"))
+            assert R.query(R.Q_SPLAT_COUNT) == n_all and R.query(R.Q_SH_PRESENT) == int(has_sh), step
+            direct.upload(cat, origin=tuple(float(v) for v in R.origin()))
+            cam_d = pkg.camera.make_camera(w, h, sh_order=3 if has_sh else 0, frame=cam.meta["frame"], distance=cam.meta["distance"])
+            cam_d.cam_pos = R.lastCameraPos()            # (the shim's own float32 inverse of the view matrix: src/GSplatRenderer.C:551-563)
+            ref = direct.render(cam_d)
+            err = float(np.abs(img - ref).max())
+            assert err == 0.0, (step, err, active, np.abs(cam_d.cam_pos - cam.cam_pos).max())
+            drawn += int(img.any())
+        assert drawn >= 10
+    finally:
+        R.close(); direct.close()
+
+
 def test_randomised_exactness_soak(pkg):
     """tools/fuzz_parity.py, a short run: random clouds, framebuffers, projections, row shards and library options; every frame of a
     short camera path bit-identical to a context that culls nothing, takes the global sort and shades eagerly"""

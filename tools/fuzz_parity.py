@@ -10,6 +10,7 @@ Some iterations render depth-tested (an opaque pass's depth image in front of pa
 entries, some go through gsr_multi_* (several contexts on this GPU, COPY transport: shard, render, gather).
 mode 1: clouds of 1 - 2.5 M splats at 1920x1080 (the policy's temporal culling and front-slab frames engage by themselves).
 mode 2: ONE long-lived context under test for the whole run: re-uploads, option flips and shard changes in mid-stream.
+mode 3: the same with a long-lived gsr_multi of three contexts.
 At the first difference the iteration is replayed on fresh contexts -- alone, then behind its predecessors, then with every
 non-default option put back -- to say what it takes, and the run exits non-zero with the configuration that produced it."""
 import ctypes as C
@@ -222,7 +223,8 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     first = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # (skip the iterations before this one: same random sequence)
     mode = sys.argv[4] if len(sys.argv) > 4 else "0"
-    heavy, longlived = mode == "1", mode == "2"
+    heavy, longlived = mode == "1", mode in ("2", "3")
+    multi_ll = 3 if mode == "3" else 0         # mode 3: the long-lived context is a gsr_multi of three contexts on this GPU
     rng = np.random.default_rng(seed)
     t_start = time.time()
     frames = 0
@@ -230,13 +232,18 @@ def main():
     history = []
     for it in range(iters):
         sc = make_script(rng, it, heavy, longlived)
+        if multi_ll:
+            sc["multi"] = multi_ll; sc["shard"] = (0, 1, sc["shard"][2]); sc["cuts"] = None; sc["dev_target"] = False
+            sc["opts"].pop(E.OPT_DEFERRED_CHECK, None)
+            sc["flips"] = {k: v for k, v in sc["flips"].items() if v[0] == "opt"}
+            sc["desc"].update(multi=multi_ll, shard=sc["shard"], parts=None, dev_target=False, flips=sc["flips"])
         if it < first:
             continue
         print("..", sc["desc"], flush=True)
         history = (history + [sc])[-4:] if longlived else [sc]
         if longlived:
             if keep_dut is None:
-                keep_dut = E.Engine(0)
+                keep_dut = E.MultiEngine([0] * multi_ll, E.TRANSPORT_COPY) if multi_ll else E.Engine(0)
             dut = keep_dut
         else:
             dut = fresh_dut(sc)

@@ -122,10 +122,11 @@ def make_script(rng, it, heavy, longlived):
                     cnt2 = int(rng.choice([1, 2, 3, 8]))
                     flips[k] = ("shard", int(rng.integers(0, cnt2)), cnt2, int(rng.integers(0, 2)))
     dev_target = bool(rng.random() < 0.3) and not multi and not use_depth     # the frames go to a DEVICE buffer (no staging copy; deferred hand-over possible)
+    user_stream = dev_target and bool(rng.random() < 0.6)                       # ... on the caller's own stream
     depth = np.where(np.random.default_rng(it).random((h, w)) < 0.5, 0.5, 1.0).astype(np.float32) if use_depth else None
-    desc = dict(it=it, n=n, sh=sh, w=w, h=h, order=order, proj=kind, shard=(index, count, layout), depth=use_depth, multi=multi, parts=cuts, dev_target=dev_target,
+    desc = dict(it=it, n=n, sh=sh, w=w, h=h, order=order, proj=kind, shard=(index, count, layout), depth=use_depth, multi=multi, parts=cuts, dev_target=dev_target, user_stream=user_stream,
                 opts={int(k): v for k, v in opts.items()}, flips={k: v for k, v in flips.items()})
-    return dict(splats=splats, n=n, w=w, h=h, shard=(index, count, layout), opts=opts, depth=depth, multi=multi, cams=cams, cuts=cuts, flips=flips, desc=desc, dev_target=dev_target)
+    return dict(splats=splats, n=n, w=w, h=h, shard=(index, count, layout), opts=opts, depth=depth, multi=multi, cams=cams, cuts=cuts, flips=flips, desc=desc, dev_target=dev_target, user_stream=user_stream)
 
 
 def execute(sc, dut, verbose=False):
@@ -158,6 +159,7 @@ def execute(sc, dut, verbose=False):
         plain.upload(splats)
         count_now = count
         devbuf = [C.c_void_p(), 0]
+        ustream = [C.c_void_p()]
         deferred = bool(opts.get(E.OPT_DEFERRED_CHECK, 0)) and not multi
         truncated_seen = dut.stats()["frames_truncated"] if not multi else 0
         for k, c in enumerate(sc["cams"]):
@@ -178,11 +180,24 @@ def execute(sc, dut, verbose=False):
                     if devbuf[0].value: HIP.hipFree(devbuf[0])
                     assert HIP.hipMalloc(C.byref(devbuf[0]), C.c_size_t(nbytes)) == 0
                     devbuf[1] = nbytes
-                assert HIP.hipMemset(devbuf[0], 0, C.c_size_t(nbytes)) == 0      # (band padding is never written in a device target)
-                dut.render_to_device(c, devbuf[0].value)
-                dut.synchronize()
-                got = np.empty((rows_, c.width, 4), np.float32)
-                assert HIP.hipMemcpy(C.c_void_p(got.ctypes.data), devbuf[0], C.c_size_t(nbytes), 2) == 0
+                if sc.get("user_stream"):
+                    # the caller's own stream (what bench.py does): the clear is QUEUED on it in front of the frame, the read-back behind
+                    # it -- no host synchronisation in between; the library has to order its kernels against both
+                    if not ustream[0].value:
+                        assert HIP.hipStreamCreate(C.byref(ustream[0])) == 0
+                        dut.set_stream(ustream[0].value)
+                    assert HIP.hipMemsetAsync(devbuf[0], 0xff if k % 2 else 0, C.c_size_t(nbytes), ustream[0]) == 0      # (poison, then zeros: the
+                    assert HIP.hipMemsetAsync(devbuf[0], 0, C.c_size_t(nbytes), ustream[0]) == 0                          #  frame must come after both)
+                    dut.render_to_device(c, devbuf[0].value)
+                    got = np.empty((rows_, c.width, 4), np.float32)
+                    assert HIP.hipMemcpyAsync(C.c_void_p(got.ctypes.data), devbuf[0], C.c_size_t(nbytes), 2, ustream[0]) == 0
+                    assert HIP.hipStreamSynchronize(ustream[0]) == 0
+                else:
+                    assert HIP.hipMemset(devbuf[0], 0, C.c_size_t(nbytes)) == 0      # (band padding is never written in a device target)
+                    dut.render_to_device(c, devbuf[0].value)
+                    dut.synchronize()
+                    got = np.empty((rows_, c.width, 4), np.float32)
+                    assert HIP.hipMemcpy(C.c_void_p(got.ctypes.data), devbuf[0], C.c_size_t(nbytes), 2) == 0
             else:
                 got = (dut.render(c) if depth is None else (dut.render(c, depth) if multi else dut.render_depth(c, depth)))
             frames += 1
@@ -209,6 +224,9 @@ def execute(sc, dut, verbose=False):
     finally:
         plain.close()
         try:
+            if ustream[0].value:
+                dut.set_stream(0)
+                HIP.hipStreamDestroy(ustream[0])
             if devbuf[0].value: HIP.hipFree(devbuf[0])
         except NameError:
             pass
@@ -233,7 +251,7 @@ def main():
     for it in range(iters):
         sc = make_script(rng, it, heavy, longlived)
         if multi_ll:
-            sc["multi"] = multi_ll; sc["shard"] = (0, 1, sc["shard"][2]); sc["cuts"] = None; sc["dev_target"] = False
+            sc["multi"] = multi_ll; sc["shard"] = (0, 1, sc["shard"][2]); sc["cuts"] = None; sc["dev_target"] = False; sc["user_stream"] = False
             sc["opts"].pop(E.OPT_DEFERRED_CHECK, None)
             sc["flips"] = {k: v for k, v in sc["flips"].items() if v[0] == "opt"}
             sc["desc"].update(multi=multi_ll, shard=sc["shard"], parts=None, dev_target=False, flips=sc["flips"])

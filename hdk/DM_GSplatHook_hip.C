@@ -12,8 +12,8 @@
  * (the reference tests against it with depth writes off, src/GSplatRenderer.C:595-610).
  *
  * EARLY-UNMAP HAZARD: with occlusion culling on (the default) gsr_render may write a frame that broke a depth horizon into
- * the target and overwrite it with the repaired frame before it returns; both writes are ordered on the stream handed to
- * map() / unmap() below.  A consumer that is ordered behind unmap() -- as here -- only ever sees the final frame; one that
+ * the target and overwrite it with the repaired frame before it returns; both writes are ordered on the hook's stream -- the one
+ * handed to gsr_set_stream AND to map() / unmap() below.  A consumer that is ordered behind unmap() -- as here -- only ever sees the final frame; one that
  * unmapped (or read through another stream) before R.render() returned could see the first attempt.  Keep the unmap
  * after postRender().
  *
@@ -102,7 +102,11 @@ class GSplatHipSceneRenderHook : public DM_SceneRenderHook
 {
 public:
     GSplatHipSceneRenderHook(DM_VPortAgent& vport, DM_ViewportType view_mask) : DM_SceneRenderHook(vport, view_mask) {}
-    ~GSplatHipSceneRenderHook() override { myBuffers.release(); }
+    ~GSplatHipSceneRenderHook() override
+    {
+        myBuffers.release();
+        if (myStream) (void)hipStreamDestroy(myStream);
+    }
 
     bool render(RE_RenderContext r, const DM_SceneHookData& hook_data) override
     {
@@ -132,7 +136,17 @@ public:
         glBindBuffer(GL_PIXEL_PACK_BUFFER, myBuffers.depthPbo);
         glReadPixels(0, 0, ctx.width, ctx.height, GL_DEPTH_COMPONENT, GL_FLOAT, nullptr);
         glBindBuffer(GL_PIXEL_PACK_BUFFER, 0);
-        hipStream_t stream = nullptr;       /* the stream given to gsr_set_stream(R.engine(), ...), if any */
+        /* ONE stream orders everything of this viewport: the maps, the engine's kernels (gsr_set_stream: a context's frames are
+         * ordered on its public stream -- its own stream is hipStreamNonBlocking and would NOT be ordered against stream 0) and
+         * the unmaps, which is what hands the finished frame back to GL */
+        if (!myStream && hipStreamCreateWithFlags(&myStream, hipStreamNonBlocking) != hipSuccess) myStream = nullptr;
+        hipStream_t stream = myStream;
+        const void* engineNow = R.engine() ? static_cast<const void*>(R.engine()) : static_cast<const void*>(R.multi());
+        if (engineNow != myBoundEngine) {   /* (once per engine: re-binding drains the context) */
+            if (R.engine()) (void)gsr_set_stream(R.engine(), stream);
+            else if (R.multi()) (void)gsr_multi_set_stream(R.multi(), stream);
+            myBoundEngine = engineNow;
+        }
         ctx.depth = static_cast<const float*>(myBuffers.depth.map(stream));
         ctx.depth_is_device = 1;
         ctx.target = static_cast<float*>(myBuffers.rgba.map(stream));
@@ -143,18 +157,25 @@ public:
             R.generateRenderGeometry(ctx);      /* re-stages only when the set of marked primitives changed */
             R.render(ctx, hook_data.disp_options->isObjectLevel());
             drew = R.query(GSplatRenderer::Q_CAN_RENDER) != 0;
-            if (theWireRequested && R.engine()) {
-                /* wireframe display / wire-over: quad outlines on top of (instead of) the beauty frame, from the resident arrays */
+            /* (several GPUs: the stitched frame and the whole cloud live on the root rank's context) */
+            gsr_context* wireEngine = R.engine() ? R.engine() : (R.multi() ? gsr_multi_context(R.multi(), 0) : nullptr);
+            if (theWireRequested && R.multi()) (void)gsr_multi_synchronize(R.multi());   /* the gather has landed before the outlines go on top */
+            if (theWireRequested && wireEngine) {
+                /* wire-over display: the reference draws the outlines and still includes the primitive in the splat pass
+                 * (src/GR_GSplat.C:471-486) -- the outlines go ON TOP of the beauty frame just rendered, from the resident arrays */
                 gsr_camera cam{};
                 std::memcpy(cam.obj_view, ctx.obj_view, 64); std::memcpy(cam.object, ctx.object, 64);
                 std::memcpy(cam.inv_object, ctx.inv_object, 64); std::memcpy(cam.view, ctx.view, 64); std::memcpy(cam.proj, ctx.proj, 64);
                 cam.width = ctx.width; cam.height = ctx.height; cam.sh_order = 0;
-                drew = gsr_render_wire(R.engine(), &cam, ctx.target, 1) == GSR_OK || drew;
+                drew = (drew ? gsr_render_wire_over(wireEngine, &cam, ctx.target, 1) : gsr_render_wire(wireEngine, &cam, ctx.target, 1)) == GSR_OK || drew;
             }
         }
         R.postRender();
         theWireRequested = false;
-        /* (after postRender: see the early-unmap hazard in the header comment) */
+        /* (after postRender: see the early-unmap hazard in the header comment).  Belt and braces: the frame's last kernel has
+         * finished before GL may touch the buffers, whatever a driver makes of the stream argument of the unmap */
+        if (R.engine()) (void)gsr_synchronize(R.engine());
+        else if (R.multi()) (void)gsr_multi_synchronize(R.multi());
         myBuffers.rgba.unmap(stream);
         myBuffers.depth.unmap(stream);
         if (!drew) return true;
@@ -185,6 +206,8 @@ public:
 
 private:
     ViewportBuffers myBuffers;
+    hipStream_t myStream = nullptr;
+    const void* myBoundEngine = nullptr;     /* the engine whose public stream is myStream */
 };
 
 class GSplatHipSceneHook : public DM_SceneHook

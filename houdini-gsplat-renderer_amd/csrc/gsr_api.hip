@@ -150,6 +150,8 @@ struct FrameSlot {
     float* hpyr2 = nullptr;            // the pyramid of "this tile is finished" phase 2 culls against (GSR_PYR_FLOATS)
     uint32_t* slab = nullptr;          // [GSR_SLAB_BINS + 8] histogram of the surviving clusters' nearest keys; then [0] the slab key, [1] clusters,
                                        // [2..5] the bucket ranges of the two phases' small-frame sorts (k_slab_pick)
+    bool slab_dirty = false;           // a phase 1 filled the histogram and no phase 2 followed (its cull pass is what clears it): the
+                                       // next front-slab frame clears it itself before it counts
     uint32_t slab_kept = 0;            // splats phase 1 sent to the depth sort
     uint32_t slab_kept1 = 0, slab_kept2 = 0;   // ... in this slot's LAST front-slab frame, per phase (0 = none yet): which sort a phase takes
     int32_t* redo = nullptr;           // lazy colour: tiles the plain blend kernel gave up (tile_cap entries)
@@ -228,7 +230,9 @@ struct gsr_context {
     uint32_t n = 0, cap = 0;
     bool has_sh = false;
     float origin[3] = {0, 0, 0};
-    uint64_t geo_gen = 0;
+    uint64_t geo_gen = 0;              // generation of the resident geometry: only ever counts up (cached orders, horizons, the wire overlay's
+                                       // inverse permutation are stamped with it), so a stamp of an older cloud can never match a newer one
+    bool has_geometry = false;         // a complete upload is resident (gsr_render: GSR_E_NO_GEOMETRY otherwise)
     float4* geoA = nullptr;
     uint4* geoB = nullptr;
     uint4* col = nullptr;              // colour halves as SoA chunks (eager colour in K1)
@@ -692,7 +696,9 @@ static void drop_geometry(gsr_context* c)
 {
     c->n = 0; c->nclus = 0; c->up_total = c->up_filled = 0; c->st.n_splats = 0;
     dev_free(c->perm); dev_free(c->clusA); dev_free(c->clusB); c->h_perm.clear();
-    c->geo_gen = 0;                    // gsr_render: GSR_E_NO_GEOMETRY
+    c->has_geometry = false;           // gsr_render: GSR_E_NO_GEOMETRY (the generation is NOT rewound: stamps of the lost cloud stay stale)
+    c->geo_gen++;
+    dev_free(c->wire_inv); c->wire_inv_gen = 0;
     c->pos_valid = false; c->prefix_valid = false;
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) {
         FrameSlot& sl = c->slot[k];
@@ -822,6 +828,7 @@ extern "C" int gsr_upload_end(gsr_context* c)
         }
     }
     c->geo_gen++;
+    c->has_geometry = true;
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
     c->prefix_valid = false;           // lazy colour: the first frame of a new cloud colours every list completely
     c->order_pays = false;
@@ -1580,11 +1587,12 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
         const bool short_buffer = D > sl.pair_cap || !sl.pvA;
         if (short_buffer) {
             (void)hipStreamSynchronize(sl.stream);   // a speculative (clamped) back end may still be reading the old buffer
+            const bool first_buffer = sl.pvA == nullptr;
             dev_free(sl.pvA);
             sl.pair_cap = 0;
             // (a slot's first buffer may be sized by a frame -- or a front slab -- that shows next to nothing: at least two entries per splat
             //  then, up to 32 MB, so that the frames behind it need not each regrow it)
-            const size_t floor_ = sl.pvA ? 0 : std::min<size_t>((size_t)2 * j.n + 4096, (size_t)1 << 22);
+            const size_t floor_ = !first_buffer ? 0 : std::min<size_t>((size_t)2 * j.n + 4096, (size_t)1 << 22);
             const size_t want = std::max<size_t>((size_t)D + D / 4 + 4096, std::max(floor_, c->pair_want));
             int rc = dev_alloc(&sl.pvA, want + 4);   // (+4: the blend kernel scans in 4-entry steps)
             if (rc) return frame_abort(sl, rc);
@@ -1698,7 +1706,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     if (c->uploading) return set_err(GSR_E_INVALID, "gsr_render: upload in progress");
     if (cam->width <= 0 || cam->height <= 0 || cam->width > GSR_MAX_DIM || cam->height > GSR_MAX_DIM)
         return set_err(GSR_E_INVALID, "gsr_render: bad framebuffer size %dx%d (max %d)", cam->width, cam->height, GSR_MAX_DIM);
-    if (c->geo_gen == 0) return set_err(GSR_E_NO_GEOMETRY, "gsr_render: nothing uploaded");
+    if (!c->has_geometry) return set_err(GSR_E_NO_GEOMETRY, "gsr_render: nothing uploaded");
 #ifdef GSR_HOST_TIMING
     const double t_enter = now_us();
 #endif
@@ -1910,11 +1918,17 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         const float* pyr = j.phase == 2 ? sl.hpyr2 : ((j.cull && !ordered) ? sl.hpyr : (const float*)nullptr);
         const GsrSlabPick pk{(uint32_t)c->slab_min, (uint32_t)c->slab_max, (uint32_t)c->slab_frac, f.key_max - f.key_min};
         if (j.phase == 1) {   // a first pass for the histogram alone (the pass below takes the slab key from it and keeps the slab's clusters only)
+            // (the histogram is cleared by phase 2's cull pass; a phase 1 that never got its phase 2 -- its small-frame sort gave a bucket
+            //  up, an error in between -- left its counts behind: they would skew this frame's slab key, never its pixels)
+            if (sl.slab_dirty && hipMemsetAsync(sl.slab, 0, (size_t)GSR_SLAB_BINS * sizeof(uint32_t), s) != hipSuccess)
+                return frame_abort(sl, set_err(GSR_E_HIP, "gsr_render: clearing the slab histogram failed"));
+            sl.slab_dirty = true;
             const int n45 = gsr_pyr_dim(f.tiles_x, 4) * gsr_pyr_dim(f.tiles_y, 4) + gsr_pyr_dim(f.tiles_x, 5) * gsr_pyr_dim(f.tiles_y, 5);
             hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, c->opt_cluster,
                                (const float*)nullptr, sl.cseg, sl.ccnt, 1, sl.slab, hist_shift, sl.slab + GSR_SLAB_BINS, pk, sl.hpyr2 + f.pyr_off[4], n45,
                                (uint32_t*)nullptr, (uint32_t*)nullptr);
         }
+        if (j.phase == 2) sl.slab_dirty = false;   // (mode 3 below clears the histogram for the slot's next front-slab frame)
         hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, ordered ? 0 : c->opt_cluster,
                            pyr, sl.cseg, sl.ccnt,   // (ordered: slots, not clusters -- all of them)
                            j.phase == 1 ? 2 : (j.phase == 2 ? 3 : 0), sl.slab, hist_shift, sl.slab + GSR_SLAB_BINS, pk, (float*)nullptr, 0,
@@ -2185,13 +2199,18 @@ __attribute__((visibility("hidden"))) void* gsr_internal_stream(gsr_context* c) 
 __attribute__((visibility("hidden"))) int gsr_internal_device(gsr_context* c) { return c ? c->device : -1; }
 
 // Wireframe overlay: synchronous, not on the per-frame beauty path.
-extern "C" int gsr_render_wire(gsr_context* c, const gsr_camera* cam, float* rgba_out, int out_is_device)
+static int render_wire(gsr_context* c, const gsr_camera* cam, float* rgba_out, int out_is_device, int over);
+extern "C" int gsr_render_wire(gsr_context* c, const gsr_camera* cam, float* rgba_out, int out_is_device) { return render_wire(c, cam, rgba_out, out_is_device, 0); }
+// wire-over display (the reference draws the outlines AND keeps the primitive in the splat pass, src/GR_GSplat.C:471-486): the outlines
+// go on top of the frame that is already in rgba_inout; pixels no outline covers are left as they are
+extern "C" int gsr_render_wire_over(gsr_context* c, const gsr_camera* cam, float* rgba_inout, int is_device) { return render_wire(c, cam, rgba_inout, is_device, 1); }
+static int render_wire(gsr_context* c, const gsr_camera* cam, float* rgba_out, int out_is_device, int over)
 {
     if (!c || !cam || !rgba_out) return set_err(GSR_E_INVALID, "gsr_render_wire: NULL argument");
     if (c->uploading) return set_err(GSR_E_INVALID, "gsr_render_wire: upload in progress");
     if (cam->width <= 0 || cam->height <= 0 || cam->width > GSR_MAX_DIM || cam->height > GSR_MAX_DIM)
         return set_err(GSR_E_INVALID, "gsr_render_wire: bad framebuffer size %dx%d", cam->width, cam->height);
-    if (c->geo_gen == 0) return set_err(GSR_E_NO_GEOMETRY, "gsr_render_wire: nothing uploaded");
+    if (!c->has_geometry) return set_err(GSR_E_NO_GEOMETRY, "gsr_render_wire: nothing uploaded");
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
@@ -2221,11 +2240,12 @@ extern "C" int gsr_render_wire(gsr_context* c, const gsr_camera* cam, float* rgb
     unsigned long long* zbuf = c->wire_zbuf;
     float* target = out_is_device ? rgba_out : c->wire_out;
     hipError_t e = hipMemsetAsync(zbuf, 0xff, npix * 8, s);
+    if (e == hipSuccess && over && !out_is_device) e = hipMemcpyAsync(c->wire_out, rgba_out, npix * 16, hipMemcpyHostToDevice, s);   // (the frame underneath)
     if (e == hipSuccess && c->n > 0)
         hipLaunchKernelGGL(k_wire_splats, dim3(div_up(c->n, 256)), dim3(256), 0, s, c->n, f, c->geoA, c->geoB, zbuf, inv ? c->perm : (const uint32_t*)nullptr);
     if (e == hipSuccess)
         hipLaunchKernelGGL(k_wire_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, zbuf, npix, c->col,
-                           reinterpret_cast<float4*>(target), inv);
+                           reinterpret_cast<float4*>(target), inv, over);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess && !out_is_device) e = hipMemcpyAsync(rgba_out, c->wire_out, npix * 16, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);

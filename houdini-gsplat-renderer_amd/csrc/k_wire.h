@@ -81,11 +81,13 @@ k_wire_splats(uint32_t n, GsrFrame f, const float4* __restrict__ geoA, const uin
 
 __global__ void __launch_bounds__(256)
 k_wire_resolve(const unsigned long long* __restrict__ zbuf, size_t npix, const uint4* __restrict__ col0,
-               float4* __restrict__ out, const uint32_t* __restrict__ inv /* index in the upload -> storage slot, or NULL */)
+               float4* __restrict__ out, const uint32_t* __restrict__ inv /* index in the upload -> storage slot, or NULL */,
+               int over /* 1 = wire-over display: only the pixels an outline covers are written, the frame underneath stays */)
 {
     const size_t p = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (p >= npix) return;
     const unsigned long long v = zbuf[p];
+    if (over && v == GSR_WIRE_EMPTY) return;
     float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (v != GSR_WIRE_EMPTY) {
         const uint32_t idx = (uint32_t)(v & 0xffffffffull);

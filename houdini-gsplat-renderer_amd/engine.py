@@ -98,7 +98,7 @@ OPT_FRONT_SLAB = 16
 C_ABI_SYMBOLS = [
     "gsr_device_count", "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_version", "gsr_set_stream",
     "gsr_upload_begin", "gsr_upload_append", "gsr_upload_append_raw", "gsr_upload_end", "gsr_upload_abort", "gsr_upload", "gsr_set_row_shard", "gsr_band_rows",
-    "gsr_stitch_bands", "gsr_render", "gsr_render_depth", "gsr_render_wire", "gsr_synchronize", "gsr_get_stats", "gsr_stats_reset", "gsr_set_option",
+    "gsr_stitch_bands", "gsr_render", "gsr_render_depth", "gsr_render_wire", "gsr_render_wire_over", "gsr_synchronize", "gsr_get_stats", "gsr_stats_reset", "gsr_set_option",
     "gsr_debug_read_records", "gsr_debug_read_depth_order", "gsr_debug_read_storage_order", "gsr_debug_read_tile_lists", "gsr_debug_sort_pairs", "gsr_debug_sort_pairs_local",
     "gsr_debug_read_tile_work",
     "gsr_multi_create", "gsr_multi_destroy", "gsr_multi_count", "gsr_multi_transport", "gsr_multi_context",
@@ -153,6 +153,7 @@ def load_library() -> C.CDLL:
     L.gsr_render.argtypes = [vp, C.POINTER(gsr_camera), vp, i32]
     L.gsr_render_depth.argtypes = [vp, C.POINTER(gsr_camera), vp, i32, vp, i32]
     L.gsr_render_wire.argtypes = [vp, C.POINTER(gsr_camera), vp, i32]
+    L.gsr_render_wire_over.argtypes = [vp, C.POINTER(gsr_camera), vp, i32]
     L.gsr_synchronize.argtypes = [vp]
     L.gsr_get_stats.argtypes = [vp, C.POINTER(gsr_stats)]
     L.gsr_stats_reset.argtypes = [vp]
@@ -406,6 +407,17 @@ class Engine:
         cs = camera_struct(cam)
         _check(self.L.gsr_render_wire(self.h, C.byref(cs), out.ctypes.data, 0))
         return out
+
+    def render_wire_over(self, cam, frame: np.ndarray) -> np.ndarray:
+        """wire-over display: the outlines on top of `frame` (a finished beauty frame [H, W, 4]); returns the combined image"""
+        out = np.ascontiguousarray(frame, dtype=np.float32).reshape(cam.height, cam.width, 4).copy()
+        cs = camera_struct(cam)
+        _check(self.L.gsr_render_wire_over(self.h, C.byref(cs), out.ctypes.data, 0))
+        return out
+
+    def render_wire_over_device(self, cam, device_ptr: int):
+        cs = camera_struct(cam)
+        _check(self.L.gsr_render_wire_over(self.h, C.byref(cs), C.c_void_p(device_ptr), 1))
 
     def render_to_device(self, cam, device_ptr: int):
         cs = camera_struct(cam)

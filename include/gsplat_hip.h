@@ -265,6 +265,11 @@ int  gsr_render_depth(gsr_context* ctx, const gsr_camera* cam, const float* dept
  * background 0.  Whole image (ignores the row shard), synchronous.  Like the reference's wire program it uses
  * P without the GSplatOrigin round trip and no object matrix in the covariance. */
 int  gsr_render_wire(gsr_context* ctx, const gsr_camera* cam, float* rgba_out, int out_is_device);
+/* Wire-OVER display: the reference draws the outlines and still includes the primitive in the splat pass
+ * (src/GR_GSplat.C:471-486), so shaded + wire shows both.  The outlines are written on top of the frame that is
+ * already in rgba_inout (a finished gsr_render / gsr_render_depth target of the same size); pixels no outline
+ * covers keep their value. */
+int  gsr_render_wire_over(gsr_context* ctx, const gsr_camera* cam, float* rgba_inout, int is_device);
 
 int  gsr_synchronize(gsr_context* ctx);
 int  gsr_get_stats(gsr_context* ctx, gsr_stats* out);     /* synchronizes the stream */

@@ -706,6 +706,48 @@ def test_wireframe_overlay(pkg, oracle, engine):
     assert np.array_equal(engine.render_wire(cam), oracle.render_wire(big, cam))
 
 
+def test_wire_over_keeps_the_beauty_frame(pkg, oracle, engine):
+    """Wire-over display (the reference draws the outlines and still includes the primitive in the splat pass,
+    src/GR_GSplat.C:471-486): gsr_render_wire_over writes the pixels an outline covers and leaves the beauty frame
+    everywhere else -- host target and device target alike"""
+    import torch
+    d, s, c = load_golden("w1_wire")
+    engine.upload(s)
+    beauty = engine.render(c)
+    wire = engine.render_wire(c)
+    both = engine.render_wire_over(c, beauty)
+    covered = wire[..., 3] > 0
+    assert covered.any() and (~covered).any()
+    assert np.array_equal(both[covered], wire[covered])
+    assert np.array_equal(both[~covered], beauty[~covered])
+    t = torch.from_numpy(beauty.copy()).cuda()
+    engine.render_wire_over_device(c, t.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy(), both)
+
+
+def test_wire_overlay_after_a_failed_upload_uses_the_new_cloud(pkg, oracle):
+    """The geometry generation only counts up: after an upload that failed (an announced count that was never filled) the next
+    cloud must not be drawn with the inverse storage permutation of the one before it (round-4 advisor finding: the generation was
+    rewound to 0, so the second cloud was generation 1 again)."""
+    eng = pkg.Engine(0)
+    try:
+        a = pkg.scenes.make_scene(5000, seed=11, sh=True)
+        cam = pkg.camera.make_camera(320, 200, sh_order=3, frame=3)
+        eng.upload(a)
+        assert np.array_equal(eng.render_wire(cam), oracle.render_wire(a, cam))
+        L = eng.L
+        assert L.gsr_upload_begin(eng.h, 1000, 0, None) == 0
+        assert L.gsr_upload_end(eng.h) != 0          # nothing was appended: the upload fails ...
+        L.gsr_upload_abort(eng.h)
+        b = pkg.scenes.make_scene(1200, seed=12, sh=True)    # ... and a smaller cloud follows
+        eng.upload(b)
+        assert np.array_equal(eng.render_wire(cam), oracle.render_wire(b, cam))
+        assert np.abs(eng.render(cam) - oracle.render(b, cam)).max() <= 1e-3
+    finally:
+        eng.close()
+
+
 def test_list_buffer_regrows_behind_a_speculative_back_end(pkg, oracle):
     """The back end (placement + compositing) is queued before the host knows the frame's pair count,
     clamped to the list buffer's capacity; when the count exceeds it the buffer is regrown and the back

@@ -84,7 +84,7 @@ def parse_args():
     ap.add_argument("--no-swizzle", action="store_true", help="disable the XCD-aware tile mapping (A/B)")
     ap.add_argument("--morton", action="store_true", help="experiment: hand the splats over in Morton order of their positions")
     ap.add_argument("--time-every", type=int, default=0, help="HIP events around the blend kernel of every N-th frame of the timed region; "
-                    "0 = min(8, steps / 16), so that at least 16 launches are timed "
+                    "0 = 4 (8 from 64 steps on), at least five launches timed "
                     "(each pair idles the queue ~12 us; the roofline's launch time is the mean over the sampled launches)")
     ap.add_argument("--cull", type=int, default=1, help="GSR_OPT_OCCLUSION_CULL: 0 = no occlusion culling, 1 = the library's policy (default), 2 = against the previous "
                     "frame whenever it left horizons, 3 = inside the frame only (every frame a front-slab frame: nothing depends on the previous frame)")
@@ -287,6 +287,14 @@ def load_traffic(regime: str, usable: bool):
         return None, None
 
 
+def time_every(args) -> int:
+    """HIP events around the blend kernel of every N-th timed frame: 4 by default (8 for long runs) -- an event pair idles the queue
+    ~12 us, so bracketing EVERY launch makes the frames it measures slower than the ones rocprofv3 sees; at least five launches are timed"""
+    if args.time_every > 0:
+        return args.time_every
+    return max(1, min(8 if args.steps >= 64 else 4, args.steps // 5))
+
+
 def set_common_options(target, pkg, args):
     """the options both forms (one context / gsr_multi) take"""
     E = pkg.engine
@@ -297,7 +305,7 @@ def set_common_options(target, pkg, args):
     if args.dilate >= 0:
         target.set_option(E.OPT_CULL_DILATE, args.dilate)
     target.set_option(E.OPT_STORAGE_ORDER, args.storage_order)
-    target.set_option(E.OPT_TIMING_EVERY, args.time_every if args.time_every > 0 else max(1, min(8, args.steps // 16)))
+    target.set_option(E.OPT_TIMING_EVERY, time_every(args))
     target.set_option(E.OPT_XCD_SWIZZLE, 0 if args.no_swizzle else args.tile_order)
     target.set_option(E.OPT_SUPER_TILE, args.super_tile)
     target.set_option(E.OPT_DEBUG_FLAGS, args.flags)
@@ -595,18 +603,26 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    stamps = [0.0] * (args.steps + 1)        # host clock after every call (no synchronisation: gsr_render returns once the frame is queued and,
+    t0 = time.perf_counter()                 # in the temporal regime, has checked itself -- the stamps trail the GPU by less than a frame)
     for i in range(args.steps):
         step(args.warmup + i)
+        stamps[i + 1] = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    stamps[args.steps] = elapsed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # dispersion inside the timed region: frames/s of five equal windows of it (host stamps; the last window ends at the synchronised end)
+    windows = None
+    if args.steps >= 10:
+        edges = [round(k * args.steps / 5) for k in range(6)]
+        windows = [(edges[k + 1] - edges[k]) / (stamps[edges[k + 1]] - stamps[edges[k]]) for k in range(5) if stamps[edges[k + 1]] > stamps[edges[k]]]
 
     # Is the last TIMED frame the full frame?  The same camera from a second context on this GPU that culls nothing
     # (GSR_OPT_OCCLUSION_CULL = 0, GSR_OPT_CLUSTER_CULL = 0, unsharded): bit for bit.
@@ -625,6 +641,23 @@ def main():
         if world > 1:
             dist.barrier()
     st = eng.stats()
+    # extra leg: LATENCY -- BASELINE.md section 5 defines fps as 1 / median wall-clock of a synchronous gsr_render; `value` above is the
+    # throughput of back-to-back frames (the queue never drains).  Here every frame is waited for before the next is issued.
+    latency = None
+    if not args.no_extra_legs:
+        lat = []
+        last = args.warmup + args.steps
+        k_lat = min(30, last)
+        for i in range(last - k_lat, last):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step(i)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        lat = sorted(lat[2:]) if len(lat) > 4 else sorted(lat)       # (the first two re-enter the orbit: they see another frame's horizons)
+        latency = {"latency_ms_median": lat[len(lat) // 2] * 1e3, "latency_ms_min": lat[0] * 1e3, "latency_ms_max": lat[-1] * 1e3, "frames": len(lat),
+                   "fps_at_median_latency": 1.0 / lat[len(lat) // 2],
+                   "note": "synchronous frames: issue, wait for the device, repeat (BASELINE.md section 5's definition of fps); `value` is back-to-back throughput"}
     # extra leg (untimed, informational): a few more frames with HIP events around EVERY stage -> per-stage breakdown and the
     # k_preprocess / k_colour_prefix durations.  Kept out of the timed region: six extra events per frame stall the queue ~35 us.
     st_stage = None
@@ -765,14 +798,20 @@ def main():
     if st_stage and st_stage["stage_frames"] > 0 and world == 1:
         k1_ms = st_stage["stage_ms_total"][0] / st_stage["stage_frames"]
         nvis = st_stage["n_visible"]
-        lazy_on = st_stage["lazy_colours_total"] > 0
+        # did K1 shade in the frames of THIS leg?  (frames_lazy counts the frames whose K1 left the colours pending; round 4 asked
+        # lazy_colours_total, which is a running device counter and said "lazy" for a leg whose K1 shaded every frame)
+        lazy_on = st_stage["frames_lazy"] * 2 > st_stage["frames"]
+        k1_regime = "culled" if st_stage["frames_culled"] * 2 > st_stage["frames"] else ("slab" if st_stage["frames_slab"] * 2 > st_stage["frames"] else "unculled")
         # eager: the colour halves are read for every visible splat; lazy: K1 reads geometry only (colours: k_colour_prefix)
         col_b = 0 if lazy_on else {0: 16, 1: 32, 2: 64, 3: 96}[order if splats.shx is not None else 0]
         # stage 0 = k_cluster_cull + k_preprocess.  Algorithmic bytes: 32 B of bounds per cluster; 32 B of geometry for every splat of a
         # SURVIVING cluster (64 each); a splat that stays also reads its colour halves (eager mode only) and writes 48 (record) + 12
         # (key, payload); 4 B per cluster for the ordered survivor list (written and read)
         ckept, call = st_stage["clusters_kept"], st_stage["clusters_total"]
-        k1_bytes = call * 32 + ckept * 64 * 32 + nvis * (col_b + 48 + 12) + ckept * 8
+        # key + payload (12 B) go either to the head of the workgroup's 256 slots (large frames: the first radix pass gathers them) or
+        # straight into the small-frame sort's bucket regions (culled frames, since round 4: + one 4-byte atomic on the bucket counter)
+        k1_scatters = k1_regime != "unculled"
+        k1_bytes = call * 32 + ckept * 64 * 32 + nvis * (col_b + 48 + 12 + (4 if k1_scatters else 0)) + ckept * 8
         k1_traffic = None
         try:
             k1_traffic = float(tj["k_preprocess"]["hbm_bytes_per_launch"]) if tj is not None else None
@@ -781,11 +820,13 @@ def main():
         k1_gbps = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         roofline_k1 = {"bound": "hbm", "kernel": "k_preprocess", "achieved": k1_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                        "frac": k1_gbps / HBM_PEAK_GBPS, "peak_measured": peak_meas, "frac_of_measured": (k1_gbps / peak_meas) if peak_meas else None,
-                       "traffic": k1_traffic, "avg_launch_ms": k1_ms,
+                       "traffic": k1_traffic, "avg_launch_ms": k1_ms, "regime": k1_regime, "colour": "lazy" if lazy_on else "eager",
                        "algorithmic_bytes_per_launch": k1_bytes,
+                       "bytes_per_kept_splat": col_b + 48 + 12 + (4 if k1_scatters else 0),
                        "splats_kept": int(nvis), "clusters_kept": int(ckept), "clusters": int(call),
                        "note": "k_cluster_cull + k_preprocess (stage 0 of the frame); " +
                                ("lazy colour: geometry only" if lazy_on else "eager colour: + the colour halves of every splat that stays") +
+                               ("; key + payload dropped into the small-frame sort's buckets by K1 itself (12 B + a 4-byte atomic)" if k1_scatters else "") +
                                "; K1 is FP32-issue bound (the 250-instruction covariance chain for every clip-visible splat of a surviving cluster)"}
 
     if rank == 0:
@@ -798,6 +839,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "value_min": min(windows) if windows else None, "value_max": max(windows) if windows else None,
+            "value_windows": windows,
+            "latency": latency,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

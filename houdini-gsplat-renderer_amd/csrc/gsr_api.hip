@@ -1792,6 +1792,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         if (j.phase == 2) j.f.cull_dilate = 0;                 // (this frame's own tiles: nothing moves)
         if (j.phase == 1) c->st.frames_slab += 1;
     }
+    if (j.lazy && n > 0 && phase_in == 0) c->st.frames_lazy += 1;
     j.ticket = ++sl.ticket ? sl.ticket : ++sl.ticket;   // (never 0: the mailbox starts at 0)
     if (j.timing) harvest_slot(c, sl);
 

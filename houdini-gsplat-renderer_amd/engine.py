@@ -44,7 +44,7 @@ class gsr_stats(C.Structure):
                 ("frames_culled", C.c_int64), ("frames_repaired", C.c_int64),
                 ("clusters_total", C.c_int64), ("clusters_kept", C.c_int64),
                 ("policy_bits", C.c_int32), ("cull_dilate", C.c_int32), ("cull_holdoff", C.c_int32), ("reserved2_", C.c_int32),
-                ("frames_resorted", C.c_int64), ("frames_slab", C.c_int64), ("frames_jumped", C.c_int64)]
+                ("frames_resorted", C.c_int64), ("frames_slab", C.c_int64), ("frames_jumped", C.c_int64), ("frames_lazy", C.c_int64)]
 
     def as_dict(self) -> dict:
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -121,7 +121,8 @@ C_ABI_SYMBOLS = [
 
 
 def lib_path() -> str:
-    return _build.LIB
+    """the in-tree library; GSR_LIBRARY names another build of the same sources (the sanitizer builds of tools/build_sanitized.sh)"""
+    return os.environ.get("GSR_LIBRARY") or _build.LIB
 
 
 def load_library() -> C.CDLL:

@@ -106,6 +106,7 @@ typedef struct gsr_stats {
                                               rendered again with the three global passes */
     int64_t frames_slab;                   /* GSR_OPT_FRONT_SLAB: frames rendered in two phases (front slab, then the rest behind the tiles still open) */
     int64_t frames_jumped;                 /* frames whose camera had jumped since the frame that left the depth horizons: rendered without them (policy mode only) */
+    int64_t frames_lazy;                   /* frames whose K1 left the SH colours pending (k_colour.h: list prefixes + on-demand fallback); the others shaded in K1 */
 } gsr_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */

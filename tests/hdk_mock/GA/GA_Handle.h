@@ -1,0 +1,2 @@
+/* test-only stand-in: see ../hdk_mock.h */
+#include "../hdk_mock.h"

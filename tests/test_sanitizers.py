@@ -1,0 +1,107 @@
+"""Sanitizer builds of the library's HOST code (tools/build_sanitized.sh).
+
+The registry of the host shim BORROWS raw pointers exactly as the reference's does
+(/root/reference/gsplat_plugin/src/GSplatRenderer.C:277-284; lifetime: src/GR_GSplat.C:63-70), and gsr_multi.cpp runs a worker
+thread per rank with mapped-memory mailboxes: what AddressSanitizer / UndefinedBehaviorSanitizer / ThreadSanitizer exist for.
+
+* CPU (not gpu): tests/test_host_shim.py + tests/test_cabi.py, every test of them, against the ASan + UBSan build (dry instances: the
+  registry / staging-plan / ingest logic, no GPU) -- in a child process, because the sanitizer runtime has to be preloaded.
+* GPU: the gsr_multi frames of test_multi_gpu_gather_overlaps_the_next_frame_and_keeps_every_frame (three ranks on one GPU over the
+  COPY transport: caller thread + three workers + the transfer streams) under the TSan build; and the host-shim frame protocol on a
+  real context under ASan.
+Skipped only where the compiler has no sanitizer runtime."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANTS = os.path.join(ROOT, "houdini-gsplat-renderer_amd", "variants")
+CSRC = os.path.join(ROOT, "houdini-gsplat-renderer_amd", "csrc")
+
+
+def _sanitized(kind: str):
+    """path of the sanitized library and of the runtime to preload; (re)built when a source is newer (no GPU needed)"""
+    lib = os.path.join(VARIANTS, f"libgsplat_hip_{kind}.so")
+    pre = os.path.join(VARIANTS, f"{kind}.preload")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    stale = not (os.path.exists(lib) and os.path.exists(pre)) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps)
+    if stale:
+        if not os.path.exists("/opt/rocm/bin/hipcc"):
+            pytest.skip("no hipcc: the sanitized library cannot be built here")
+        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "build_sanitized.sh"), kind], capture_output=True, text=True)
+        if r.returncode != 0:
+            if "libclang_rt" in r.stderr or "sanitizer" in r.stderr.lower():
+                pytest.skip("the compiler has no %s runtime: %s" % (kind, r.stderr[-300:]))
+            raise AssertionError("tools/build_sanitized.sh %s failed:\n%s" % (kind, r.stderr[-2000:]))
+    runtime = open(pre).read().strip()
+    if not os.path.exists(runtime):
+        pytest.skip(f"sanitizer runtime {runtime} is missing")
+    return lib, runtime
+
+
+def _run(kind: str, pytest_args, extra_env=None, timeout=1500):
+    lib, runtime = _sanitized(kind)
+    env = dict(os.environ)
+    env.update({"LD_PRELOAD": runtime, "GSR_LIBRARY": lib, "GSR_EXPECT_SANITIZER": kind,
+                # leaks: python itself "leaks" at exit; everything else stops the run at the first report
+                "ASAN_OPTIONS": "detect_leaks=0:halt_on_error=1:abort_on_error=0:exitcode=87",
+                "UBSAN_OPTIONS": "print_stacktrace=1:halt_on_error=1:exitcode=88",
+                "TSAN_OPTIONS": "halt_on_error=0:exitcode=66:report_signal_unsafe=0:ignore_noninstrumented_modules=1:"
+                                "suppressions=" + os.path.join(ROOT, "tests", "tsan.supp")})
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider"] + pytest_args, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    return r
+
+
+def test_host_shim_and_cabi_under_asan_and_ubsan():
+    """every CPU test of the host shim (registry, staging plans, 2^23-1 budget, ingest) and of the C ABI against the
+    -fsanitize=address,undefined build: no report, same verdicts"""
+    r = _run("asan", ["tests/test_host_shim.py", "tests/test_cabi.py", "-m", "not gpu"])
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "ERROR: AddressSanitizer" not in tail and "runtime error:" not in tail, tail
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 14, tail
+
+
+def test_the_sanitized_library_is_the_one_under_test():
+    """GSR_LIBRARY really swaps the library the harness loads (otherwise the test above would prove nothing)"""
+    lib, runtime = _sanitized("asan")
+    code = ("import __graft_entry__ as ge, ctypes as C\n"
+            "pkg = ge.load_package(); L = pkg.load_library()\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "assert 'libgsplat_hip_asan.so' in maps and 'houdini-gsplat-renderer_amd/libgsplat_hip.so' not in maps\n"
+            "assert C.CDLL(None).__asan_init is not None\n"
+            "print('ok')\n")
+    env = dict(os.environ, LD_PRELOAD=runtime, GSR_LIBRARY=lib, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_multi_gpu_workers_under_tsan():
+    """gsr_multi's caller thread, its worker per rank and the mailboxes under ThreadSanitizer: three ranks on one GPU over the COPY
+    transport, frames back to back (the gather of frame f overlapping the kernels of frame f + 1) -- no data race reported in the
+    library's own code"""
+    r = _run("tsan", ["tests/test_gpu_parity.py", "-m", "gpu", "-k",
+                      "test_multi_gpu_gather_overlaps_the_next_frame_and_keeps_every_frame or test_multi_gpu_back_to_back_device_frames_with_uneven_ranks"])
+    out = r.stdout + r.stderr
+    races = [b for b in out.split("==================") if "WARNING: ThreadSanitizer" in b]
+    ours = [b for b in races if re.search(r"gsr_multi|GSplatRenderer|gsr_api|gsplat_ingest|libgsplat_hip", b)]
+    assert not ours, "ThreadSanitizer reports in the library's own frames:\n" + "\n".join(ours)[:6000]
+    assert re.search(r"\d+ passed", r.stdout) and " failed" not in r.stdout, out[-3000:]
+
+
+@pytest.mark.gpu
+def test_renderer_verbs_on_a_gpu_under_asan():
+    """the nine verbs on a real context (registerUpdate borrows, generateRenderGeometry stages, render, postRender; entries flushed while
+    resident; the maximum-size plan) under ASan + UBSan: no report"""
+    r = _run("asan", ["tests/test_gpu_parity.py", "-m", "gpu", "-k", "test_renderer_shim_frame_protocol or test_randomised_shim_protocol or test_raw_ingest"],
+             extra_env={"ASAN_OPTIONS": "detect_leaks=0:halt_on_error=1:exitcode=87:protect_shadow_gap=0:use_sigaltstack=0"})
+    out = (r.stdout + r.stderr)
+    assert "ERROR: AddressSanitizer" not in out and "runtime error:" not in out, out[-4000:]
+    assert r.returncode == 0 and re.search(r"\d+ passed", r.stdout), out[-3000:]

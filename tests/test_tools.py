@@ -57,3 +57,24 @@ def test_frame_timeline_picks_the_median_frame(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "frame_timeline.py"), str(f), "median"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "frame period 250.0 us" in out.stdout
+
+
+def test_pmc_summary_drops_cold_dispatches(tmp_path):
+    """tools/pmc_summary.py on a synthetic counter CSV: four warm-up dispatches five times as long (and as heavy) as the steady ones
+    must not reach the per-kernel mean, and the summary says how many rows it dropped"""
+    import json, subprocess, sys
+    hdr = "Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"
+    for name, steady, cold in (("pass1.csv", 1000.0, 5000.0), ("pass2.csv", 200.0, 900.0)):
+        rows, t = [hdr], 0
+        counter = "FETCH_SIZE" if name == "pass1.csv" else "WRITE_SIZE"
+        for i in range(24):
+            dur, val = (200000, cold) if i < 4 else (40000 + (i % 3) * 500, steady)
+            rows.append(f"k_preprocess(unsigned int),{counter},{val},{t},{t + dur}")
+            t += dur + 1000
+        (tmp_path / name).write_text("\n".join(rows) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "dropped 8 of 48 counter rows" in out.stdout
+    t = json.load(open(tmp_path / "pmc_traffic.json"))["k_preprocess"]
+    assert t["dispatches"] == 20 and t["cold_rows_dropped"] == 8
+    assert abs(t["hbm_bytes_per_launch"] - (2 * 1000.0 + 200.0) * 1024.0) < 1e-6

@@ -79,6 +79,9 @@ def parse_args():
     ap.add_argument("--config", default="C4", help="BASELINE config (C1..C5); C4 is the headline workload.  T1 (a landscape under "
                     "open sky) and S1 (a thin wall) are extra scenes with silhouettes")
     ap.add_argument("--splats", type=int, default=None, help="override the splat count (debug only)")
+    ap.add_argument("--ply", default=None, help="an INRIA 3D-Gaussian-Splatting PLY (the kind of file the reference's example scene imports, "
+                    "hip/GSplatPlugin_simpleScene_v001.hip): rendered instead of --config, through the scene's activations (ply.py), 1920x1080, "
+                    "on an orbit fitted to the cloud's bounds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="wall budget of the cpu_baseline leg (23 frames of a sample sized to fit)")
     ap.add_argument("--no-swizzle", action="store_true", help="disable the XCD-aware tile mapping (A/B)")
@@ -192,6 +195,13 @@ def cpu_baseline(oracle, splats, cam0, pkg, budget_s: float) -> dict:
         "reference_host_stage": (f"argsortByDistance restated (distance^2 + __gnu_parallel::sort of int indices by indirect float "
                                  f"compare, standing in for tbb::parallel_sort) on all {n} splats, {threads} threads: median of 3"),
     }
+
+
+def workload_name(args, splats, cfg, order, W, H) -> str:
+    if cfg.get("kind") == "ply":
+        return (f"PLY {os.path.basename(cfg['path'])}: {splats.n} splats of an INRIA capture (SH deg {order}), {W}x{H}, camera orbiting the cloud's "
+                f"median at 1.6 x its 80 % radius (re-sort every frame)")
+    return f"{args.config}: {splats.n} synthetic splats (SH deg {order}, seed {cfg['seed']}), {W}x{H}, orbiting camera (re-sort every frame)"
 
 
 def orbit_frame(i: int, jump_every: int) -> int:
@@ -351,6 +361,8 @@ def main_single_process(args):
     pkg = ge.load_package()
     E = pkg.engine
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.ply:
+        args.config = pkg.scenes.register_ply_config(args.ply, pkg.ply)
     splats, cfg = pkg.scenes.make_config(args.config, args.splats)
     W, H, order = cfg["width"], cfg["height"], cfg["sh_order"]
     torch.cuda.set_device(devices[0])
@@ -434,8 +446,8 @@ def main_single_process(args):
         else f"frames/sec at {W}x{H} + achieved HBM GB/s (blend kernel)",
         "value": (args.steps / elapsed) if verified is not False else None,
         "unit": "frames/sec", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config}: {splats.n} synthetic splats (SH deg {order}, seed {cfg['seed']}), {W}x{H}, orbiting camera (re-sort every frame)",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.ply else "INRIA PLY capture (--ply)",
+        "config": {"workload": workload_name(args, splats, cfg, order, W, H),
                    "parallelism": f"tile-row shard x{N}, " + ("contiguous bands" if args.shard_layout else "interleaved rows") +
                                   ", one process (gsr_multi: a worker thread per rank)",
                    "gather": ("in-library RCCL: ncclSend / ncclRecv in one group on per-rank transfer streams, " +
@@ -499,6 +511,8 @@ def main():
             dist.init_process_group(backend=backend)
 
     pkg = ge.load_package()
+    if args.ply:
+        args.config = pkg.scenes.register_ply_config(args.ply, pkg.ply)
     splats, cfg = pkg.scenes.make_config(args.config, args.splats)
     if args.morton:
         P = splats.P.astype(np.float64)
@@ -754,7 +768,7 @@ def main():
     other = None
     if world == 1 and args.config == "C4" and args.splats is None and not args.no_extra_legs and not args.no_other_configs and args.emulate_shard <= 1:
         other = {}
-        for oc in ("C1", "C2", "C3", "C5"):
+        for oc in ("C1", "C2", "C3", "C5", "T1", "S1", "R1"):
             osp, ocfg = pkg.scenes.make_config(oc)
             oW, oH, oord = ocfg["width"], ocfg["height"], ocfg["sh_order"]
             oe = pkg.Engine(dev_index)
@@ -774,8 +788,10 @@ def main():
             torch.cuda.synchronize()
             odt = (time.perf_counter() - t0) / 100
             ost = oe.stats()
+            oreg = "temporal (culled)" if ost["frames_culled"] * 2 > ost["frames"] else ("front slab" if ost["frames_slab"] * 2 > ost["frames"] else "one pass")
             other[oc] = {"value": 1.0 / odt, "unit": "frames/sec", "ms_per_step": odt * 1e3, "steps": 100, "n_splats": int(osp.n),
-                         "width": oW, "height": oH, "frames_culled": ost["frames_culled"], "frames_repaired": ost["frames_repaired"]}
+                         "width": oW, "height": oH, "regime": oreg, "frames_culled": ost["frames_culled"], "frames_slab": ost["frames_slab"],
+                         "frames_repaired": ost["frames_repaired"], "n_visible": ost["n_visible"], "pairs": ost["pairs_total"]}
             oe.close()
             del oband, osp
             torch.cuda.empty_cache()
@@ -846,9 +862,8 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.config}: {splats.n} synthetic splats (SH deg {order}, seed {cfg['seed']}), "
-                                   f"{W}x{H}, orbiting camera (re-sort every frame)",
+            "data": "synthetic" if not args.ply else "INRIA PLY capture (--ply)",
+            "config": {"workload": workload_name(args, splats, cfg, order, W, H),
                        "parallelism": (f"tile-row shard x{world}, " + ("contiguous bands" if args.shard_layout else "interleaved rows") + ", one process per GPU")
                        if world > 1 else "single GPU", "gather": gather,
                        "n_splats": splats.n, "width": W, "height": H, "frames_in_flight": args.frames_in_flight},

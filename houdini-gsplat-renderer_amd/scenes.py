@@ -125,6 +125,116 @@ def make_slab(n: int, seed: int, sh: bool = True, half=(2.0, 1.0, 0.12)) -> Spla
     return Splats(P, *_attributes(rng, n, sh))
 
 
+def _quat_from_normal(nrm: np.ndarray, roll: np.ndarray) -> np.ndarray:
+    """unit quaternions (x, y, z, w) that turn the local z axis onto `nrm` (unit vectors), with a roll about it"""
+    z = np.array([0.0, 0.0, 1.0])
+    axis = np.cross(np.broadcast_to(z, nrm.shape), nrm)
+    s = np.linalg.norm(axis, axis=1)
+    c = nrm[:, 2]
+    ang = np.arctan2(s, c)
+    axis = np.where(s[:, None] > 1e-9, axis / np.maximum(s, 1e-9)[:, None], np.array([1.0, 0.0, 0.0]))
+    q1 = np.concatenate([axis * np.sin(ang / 2)[:, None], np.cos(ang / 2)[:, None]], axis=1)          # z -> nrm
+    q0 = np.stack([np.zeros_like(roll), np.zeros_like(roll), np.sin(roll / 2), np.cos(roll / 2)], axis=1)   # roll about z first
+    x1, y1, z1, w1 = q1.T
+    x0, y0, z0, w0 = q0.T
+    return np.stack([w1 * x0 + x1 * w0 + y1 * z0 - z1 * y0, w1 * y0 - x1 * z0 + y1 * w0 + z1 * x0,
+                     w1 * z0 + x1 * y0 - y1 * x0 + z1 * w0, w1 * w0 - x1 * x0 - y1 * y0 - z1 * z0], axis=1)
+
+
+def make_capture(n: int, seed: int, sh: bool = True) -> Splats:
+    """R1 -- a cloud shaped like a trained CAPTURE rather than like a ball of noise (the reference's only scene imports an INRIA
+    capture, hip/GSplatPlugin_simpleScene_v001.hip; the file itself is not shipped):
+      * splats lie ON nested surfaces -- an object in the middle (a lumpy ellipsoid, 40 %), the floor it stands on (15 %) and the
+        room around it (a shell at radius ~2.6 the camera is INSIDE of, 15 %) -- flattened along the surface normal, oriented to it;
+      * sizes are log-normal with a heavy tail: most splats are a few pixels, the room's are ten times larger, and 300 background
+        splats fill a good part of the screen each;
+      * 30 % are FLOATERS: near-transparent (opacity ~ 0.03-0.1) blobs anywhere in the volume, which every ray crosses dozens of
+        without ever saturating;
+      * colour is view-dependent: first-order SH coefficients three times the size of the higher ones.
+    Nothing here is friendly to tile-horizon culling: rays end on a surface only after crossing the floaters, silhouettes of the object
+    against the far room leave open tiles everywhere, the big background splats reach hundreds of tiles."""
+    rng = np.random.default_rng(seed)
+    n_obj, n_floor, n_room = int(0.40 * n), int(0.15 * n), int(0.15 * n)
+    n_big = min(300, n // 20)
+    n_float = n - n_obj - n_floor - n_room - n_big
+
+    def unit(m):
+        d = rng.standard_normal((m, 3))
+        return d / np.linalg.norm(d, axis=1, keepdims=True)
+    # the object: r(d) = 0.55 * (1 + lumps); normal ~ radial (good enough for orientation)
+    d = unit(n_obj)
+    r = 0.55 * (1.0 + 0.25 * np.sin(3.0 * d[:, 0] + 1.0) * np.cos(4.0 * d[:, 1]) + 0.15 * np.sin(5.0 * d[:, 2]))
+    P_obj = d * r[:, None] * np.array([1.0, 1.3, 0.9])
+    P_obj += 0.004 * rng.standard_normal((n_obj, 3))
+    N_obj = d
+    # the floor: a disk of radius 2.4 at y = -0.75 with gentle bumps
+    rad = 2.4 * np.sqrt(rng.random(n_floor)); th = rng.uniform(0, 2 * np.pi, n_floor)
+    P_floor = np.stack([rad * np.cos(th), -0.75 + 0.03 * np.sin(3 * rad * np.cos(th)) + 0.004 * rng.standard_normal(n_floor), rad * np.sin(th)], axis=1)
+    N_floor = np.broadcast_to(np.array([0.0, 1.0, 0.0]), (n_floor, 3))
+    # the room: a shell of radius 2.6 (upper part: the floor closes it below)
+    d = unit(n_room); d[:, 1] = np.abs(d[:, 1]) * 1.0 - 0.28
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    P_room = d * (2.6 + 0.05 * rng.standard_normal(n_room))[:, None]
+    N_room = -d
+    # the screen-filling background splats: on the room, huge
+    d = unit(n_big); d[:, 1] = np.abs(d[:, 1])
+    P_big = d * 2.7
+    N_big = -d
+    # floaters: anywhere inside the room
+    P_fl = unit(n_float) * (2.5 * rng.random(n_float) ** (1.0 / 3.0))[:, None]
+    P_fl[:, 1] = np.abs(P_fl[:, 1]) * 0.9 - 0.7
+    N_fl = unit(n_float)
+    P = np.concatenate([P_obj, P_floor, P_room, P_big, P_fl]).astype(np.float32)
+    N = np.concatenate([N_obj, N_floor, N_room, N_big, N_fl])
+    m = P.shape[0]
+    # sizes: log-normal in-plane, flattened along the normal
+    mu = np.concatenate([np.full(n_obj, -5.0), np.full(n_floor, -4.6), np.full(n_room, -3.0), np.full(n_big, -0.4), np.full(n_float, -4.2)])
+    sg = np.concatenate([np.full(n_obj, 0.55), np.full(n_floor, 0.5), np.full(n_room, 0.6), np.full(n_big, 0.35), np.full(n_float, 0.8)])
+    ls = mu[:, None] + sg[:, None] * rng.standard_normal((m, 3))
+    ls[:, 2] += np.where(np.arange(m) < m - n_float, -1.6, 0.0)                       # surface splats are flat; floaters are blobs
+    scale = f16bits(np.exp(ls))
+    orient = f16bits(_quat_from_normal(N, rng.uniform(0, 2 * np.pi, m)))
+    logit = np.concatenate([rng.normal(2.5, 1.5, n_obj + n_floor), rng.normal(1.5, 1.5, n_room), rng.normal(2.0, 1.0, n_big), rng.normal(-3.0, 0.8, n_float)])
+    alpha = (1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
+    base = np.concatenate([np.tile([0.75, 0.45, 0.30], (n_obj, 1)), np.tile([0.35, 0.40, 0.30], (n_floor, 1)), np.tile([0.55, 0.60, 0.70], (n_room, 1)),
+                           np.tile([0.60, 0.62, 0.68], (n_big, 1)), np.tile([0.5, 0.5, 0.5], (n_float, 1))])
+    Cd = f16bits(np.clip(base + 0.12 * rng.standard_normal((m, 3)), 0.0, 1.0))
+    shx = shy = shz = None
+    if sh:
+        fr = rng.normal(0.0, 0.08, (m, 45))
+        for ch in range(3):
+            fr[:, ch * 15: ch * 15 + 3] *= 3.0                                            # degree 1 dominates: view-dependent shading
+        shx = np.zeros((m, 16), np.uint16); shy = np.zeros((m, 16), np.uint16); shz = np.zeros((m, 16), np.uint16)
+        shx[:, :15] = f16bits(fr[:, 0:15]); shy[:, :15] = f16bits(fr[:, 15:30]); shz[:, :15] = f16bits(fr[:, 30:45])
+    perm = rng.permutation(m)                 # a capture's points come in no particular order
+    g = lambda a: None if a is None else np.ascontiguousarray(a[perm])
+    return Splats(g(P), g(Cd), g(alpha), g(scale), g(orient), g(shx), g(shy), g(shz))
+
+
+def fit_orbit(P: np.ndarray) -> dict:
+    """an orbit for an arbitrary cloud (bench.py --ply): pivot = the median position, distance = 1.6 x the radius that holds 80 % of
+    the points about it (robust against the far background points every capture has)"""
+    P = np.asarray(P, dtype=np.float64)
+    P = P[np.isfinite(P).all(axis=1)]
+    if P.shape[0] == 0:
+        return {"pivot": (0.0, 0.0, 0.0), "distance": 4.61995}
+    pivot = np.median(P, axis=0)
+    r = float(np.quantile(np.linalg.norm(P - pivot, axis=1), 0.8))
+    return {"pivot": tuple(float(x) for x in pivot), "distance": max(1.6 * r, 1e-3)}
+
+
+def register_ply_config(path: str, ply_mod, width: int = 1920, height: int = 1080, sh_order: int = 3, name: str = "PLY") -> str:
+    """bench.py --ply PATH: an INRIA 3DGS capture (the example scene's activations, ply.py / SURVEY App. D) as a config of its own,
+    with an orbit fitted to the cloud"""
+    s = ply_mod.load_inria_ply(path)
+    CONFIGS[name] = dict(n=s.n, seed=0, sh=s.has_sh, kind="ply", path=path, width=width, height=height, sh_order=sh_order if s.has_sh else 0, **fit_orbit(s.P))
+    _PLY_CACHE[name] = s
+    return name
+
+
+_PLY_CACHE: dict = {}
+
+
 def terrain_camera(camera_mod, width: int, height: int, frame: int = 0, sh_order: int = 3, distance: float = 4.2, pitch_deg: float = 14.0,
                    step_deg: float = 3.0):
     """camera above the landscape of make_terrain, looking slightly down at the pivot, orbiting about +Y by step_deg per frame"""
@@ -148,6 +258,8 @@ CONFIGS = {
     "B1": dict(n=6_000_000, seed=1004, sh=True, isotropic=False, radius=2.0, width=1920, height=1080, sh_order=3, distance=9.0),
     "T1": dict(n=4_000_000, seed=2001, sh=True, kind="terrain", width=1920, height=1080, sh_order=3),
     "S1": dict(n=2_000_000, seed=2002, sh=True, kind="slab", width=1920, height=1080, sh_order=3),
+    # R1 = a capture-shaped cloud (make_capture): surfaces, floaters, a heavy tail of sizes; the camera orbits INSIDE the room
+    "R1": dict(n=3_000_000, seed=2003, sh=True, kind="capture", width=1920, height=1080, sh_order=3, distance=2.1, pivot=(0.0, -0.1, 0.0)),
 }
 
 
@@ -156,7 +268,8 @@ def config_camera(name: str, camera_mod, width: int, height: int, sh_order: int,
     if CONFIGS[name].get("kind") == "terrain":
         return terrain_camera(camera_mod, width, height, frame=frame, sh_order=sh_order)
     if "distance" in CONFIGS[name]:
-        return camera_mod.make_camera(width, height, sh_order=sh_order, frame=frame, distance=CONFIGS[name]["distance"])
+        return camera_mod.make_camera(width, height, sh_order=sh_order, frame=frame, distance=CONFIGS[name]["distance"],
+                                      pivot=CONFIGS[name].get("pivot", (0.0, 0.0, 0.0)))
     return camera_mod.make_camera(width, height, sh_order=sh_order, frame=frame)
 
 
@@ -168,6 +281,11 @@ def make_config(name: str, n_override: int | None = None) -> tuple[Splats, dict]
         return make_terrain(cfg["n"], cfg["seed"], sh=cfg["sh"]), cfg
     if cfg.get("kind") == "slab":
         return make_slab(cfg["n"], cfg["seed"], sh=cfg["sh"]), cfg
+    if cfg.get("kind") == "capture":
+        return make_capture(cfg["n"], cfg["seed"], sh=cfg["sh"]), cfg
+    if cfg.get("kind") == "ply":
+        s = _PLY_CACHE[name]
+        return (s if n_override is None else s.subset(slice(0, int(n_override)))), cfg
     s = make_scene(cfg["n"], cfg["seed"], sh=cfg["sh"], isotropic=cfg["isotropic"], radius=cfg["radius"])
     if name == "C3":
         # the example scene overwrites Cd with 0.5 grey before the SOP

@@ -42,3 +42,57 @@ def test_inria_ply_round_trip(pkg, oracle, tmp_path):
     cam = pkg.camera.make_camera(64, 48, sh_order=3)
     img = oracle.render(pkg.ply.load_inria_ply(path, cd_override=(0.5, 0.5, 0.5)), cam)
     assert np.isfinite(img).all() and img[..., 3].max() > 0
+
+
+def test_ply_door_of_the_bench(pkg, tmp_path):
+    """bench.py --ply PATH: the capture becomes a config of its own (kind "ply") through the example scene's activations, with an
+    orbit fitted to the cloud -- pivot at the median position, the camera outside the radius that holds 80 % of the points and
+    looking at the pivot"""
+    v = pkg.scenes.make_inria_raw(5000, seed=4, radius=0.7)
+    v["x"] += 3.0; v["y"] -= 1.0                                  # a cloud that is NOT about the origin
+    v["x"][:50] += 400.0                                          # ... with far-away background points, as captures have
+    path = str(tmp_path / "capture.ply")
+    pkg.scenes.write_inria_ply(path, v)
+    name = pkg.scenes.register_ply_config(path, pkg.ply, name="PLY_TEST")
+    try:
+        splats, cfg = pkg.scenes.make_config(name)
+        ref = pkg.ply.load_inria_ply(path)
+        assert splats.n == 5000 and cfg["kind"] == "ply" and cfg["sh_order"] == 3
+        for a, b in ((splats.P, ref.P), (splats.Cd, ref.Cd), (splats.alpha, ref.alpha), (splats.scale, ref.scale), (splats.orient, ref.orient), (splats.shx, ref.shx)):
+            assert np.array_equal(a, b)
+        assert np.allclose(cfg["pivot"], (3.0, -1.0, 0.0), atol=0.08)
+        assert 0.5 < cfg["distance"] < 2.0                       # (1.6 x the 80 % radius of a 0.7 ball: ~1.0; the 400-unit outliers do not stretch it)
+        cam = pkg.scenes.config_camera(name, pkg.camera, cfg["width"], cfg["height"], cfg["sh_order"], 7)
+        assert abs(np.linalg.norm(cam.cam_pos - np.asarray(cfg["pivot"], np.float32)) - cfg["distance"]) < 1e-3
+        view = cam.view.reshape(4, 4).T
+        pv = view @ np.array([*cfg["pivot"], 1.0])
+        assert abs(pv[0]) < 1e-3 and abs(pv[1]) < 1e-3 and pv[2] < 0     # the pivot is dead ahead
+        sub, _ = pkg.scenes.make_config(name, 100)
+        assert sub.n == 100
+    finally:
+        pkg.scenes.CONFIGS.pop("PLY_TEST", None)
+    import bench
+    src = open(bench.__file__).read()
+    assert "--ply" in src and src.count("register_ply_config") == 2          # both entry forms (one process / one process per GPU)
+
+
+def test_capture_shaped_generator(pkg, oracle):
+    """R1 (scenes.make_capture): reproducible; surfaces + 30 % near-transparent floaters + a heavy tail of sizes + first-order SH that
+    dominates; and from inside the room every ray ends on a surface (the oracle's frame is opaque everywhere)"""
+    a = pkg.scenes.make_capture(40000, seed=5)
+    b = pkg.scenes.make_capture(40000, seed=5)
+    assert a.n == 40000 and np.array_equal(a.P, b.P) and np.array_equal(a.scale, b.scale) and np.array_equal(a.shx, b.shx)
+    op = a.alpha
+    assert 0.25 < (op < 0.2).mean() < 0.40                       # the floaters
+    sc = a.scale.view(np.float16).astype(np.float32)
+    big = sc.max(axis=1)
+    assert np.quantile(big, 0.5) < 0.03 and (big > 0.3).sum() >= 100      # a few hundred splats fill a good part of the screen
+    flat = sc.min(axis=1) / sc.max(axis=1)
+    assert np.median(flat) < 0.35                                # surface splats are flat
+    sh = a.shx.view(np.float16).astype(np.float32)
+    assert np.abs(sh[:, :3]).mean() > 2.0 * np.abs(sh[:, 3:15]).mean()
+    q = a.orient.view(np.float16).astype(np.float32)
+    assert np.allclose(np.linalg.norm(q, axis=1), 1.0, atol=2e-3)
+    cam = pkg.scenes.config_camera("R1", pkg.camera, 160, 90, 3, 2)
+    img = oracle.render(a, cam)
+    assert np.isfinite(img).all() and (img[..., 3] > 0.9).mean() > 0.9

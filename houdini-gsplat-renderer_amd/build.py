@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgsplat_hip.so")
 SOURCES = ["gsr_api.hip", "gsr_multi.cpp", "GSplatRenderer.cpp", "gsplat_ingest.cpp"]
-HEADERS = ["gsr_device.h", "k_cluster.h", "k_preprocess.h", "k_sort.h", "k_binning.h", "k_blend.h", "k_colour.h", "k_wire.h"]
+HEADERS = ["gsr_device.h", "gsr_policy.h", "k_cluster.h", "k_preprocess.h", "k_sort.h", "k_binning.h", "k_blend.h", "k_colour.h", "k_wire.h"]
 # -ffp-contract=off: only explicit fmaf() fuses (the float32 op-order contract)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-result", "-ldl", "-pthread"]

@@ -40,6 +40,7 @@ static double now_us() { return std::chrono::duration<double, std::micro>(std::c
 #endif
 #include "k_sort.h"
 #include "k_wire.h"
+#include "gsr_policy.h"
 static_assert(RS_SRC_BLOCK == GSR_K1_THREADS, "the gathering sort pass reads K1's per-workgroup compaction: 256 slots each");
 
 #define GSR_VERSION_STR "gsplat_hip 0.1.0 (gfx950)"
@@ -183,8 +184,7 @@ struct FrameSlot {
     uint32_t kept_hint = 0;            // splats that reached the depth sort in this slot's last frame (picks the sort; 0 = unknown)
     uint32_t kept_lo = 0, kept_hi = 0; // ... and the smallest / largest of their keys, as float bits of the distance^2 (0, 0 = unknown)
     bool kept_culled = false;          // ... in a frame that was occlusion-culled (an unculled one keeps ten times as much: no prediction across)
-    int local_fails = 0;               // small-frame sorts in a row that gave a bucket up (a run of > 64 equal keys does so EVERY frame) ...
-    int local_holdoff = 0;             // ... after three of them: frames this slot stays with the three global passes
+    GsrLocalSortPolicy local_pol;      // back-off of the small-frame sort (gsr_policy.h): a run of > 64 equal keys defeats it EVERY frame
     unsigned long long* h_end = nullptr;      // pinned + mapped: ticket << 32 | violation
     unsigned long long* h_end_dev = nullptr;
     bool horizon_valid = false;
@@ -289,14 +289,9 @@ struct gsr_context {
     int64_t lazy_base = 0;             // lazy_colours_total at the last gsr_stats_reset
     uint32_t* lazy_hint = nullptr;     // device: would lazy colour pay? (k_sum_work -> k_bin_ranges -> mailbox -> lazy_pays)
     bool lazy_pays = false;
-    uint32_t vis_unculled = 0;         // splats kept by the last frame that was not culled
-    bool cull_pays = false;            // ... and its third: most super-tile lists have a depth horizon (occlusion culling)
-    bool cull_weak = false;            // the last culled frame kept > 70 % of what an unculled frame keeps
-    int slab_holdoff = 0;              // a front-slab frame kept more than a third of what an unculled frame keeps (measured break-even: B1 at 0.46 loses 9 %): plain frames for a while
+    GsrCullPolicy cull_pol;            // occlusion culling: pays / weak / hold-off / back-off / dilation radius (gsr_policy.h; DESIGN.md section 4's state table)
+    GsrSlabPolicy slab_pol;            // front-slab frames: held off for 256 frames after one that kept more than a third of an unculled frame (B1 at 0.46 loses 9 %)
     bool prefix_cheaper = false;       // the list-prefix colour pass would evaluate fewer colours than one per kept splat
-    int cull_holdoff = 0, cull_backoff = 8, cull_streak = 0;   // frames without culling after a broken horizon (x4 each time, <= 1024; back to 8 after 64 good frames)
-    int cull_dilate = 2;               // tiles by which rects are widened before they are compared with the horizons (grows when horizons break)
-    int opt_dilate = 2;                // ... its starting (and smallest) value
     bool order_pays = false;           // k_sum_work's other verdict: the tiles differ enough in work for k_tile_order to pay
     unsigned long long* wire_zbuf = nullptr;   // wireframe overlay: (depth bits, splat index) per pixel ...
     float* wire_out = nullptr;                 // ... and the image staged for a host target
@@ -567,7 +562,7 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
     case GSR_OPT_CLUSTER_CULL: c->opt_cluster = value ? 1 : 0; break;
     case GSR_OPT_LOCAL_SORT: c->opt_local_sort = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case GSR_OPT_FRONT_SLAB: c->opt_slab = value < 0 ? 0 : (value > 2 ? 2 : value); break;
-    case GSR_OPT_CULL_DILATE: c->opt_dilate = value < 0 ? 0 : (value > 64 ? 64 : value); c->cull_dilate = c->opt_dilate; break;
+    case GSR_OPT_CULL_DILATE: c->cull_pol.set_dilate_option(value); break;
     case GSR_OPT_STORAGE_ORDER: c->opt_morton = value ? 1 : 0; break;   // (takes effect at the next upload)
     case GSR_OPT_SUPER_TILE:
         if (value != 0 && (value < 1 || value > 16 || (value & (value - 1))))
@@ -832,8 +827,8 @@ extern "C" int gsr_upload_end(gsr_context* c)
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) c->slot[k].sort_valid = false;
     c->prefix_valid = false;           // lazy colour: the first frame of a new cloud colours every list completely
     c->order_pays = false;
-    c->cull_pays = false; c->slab_holdoff = 0; c->cull_holdoff = 0; c->cull_backoff = 8; c->cull_streak = 0; c->vis_unculled = 0; c->cull_dilate = c->opt_dilate;
-    for (int k = 0; k < GSR_MAX_SLOTS; ++k) { c->slot[k].surv_hint = 0; c->slot[k].kept_hint = 0; c->slot[k].kept_lo = c->slot[k].kept_hi = 0; c->slot[k].horizon_valid = false; c->slot[k].local_fails = 0; c->slot[k].local_holdoff = 0; c->slot[k].slab_kept1 = c->slot[k].slab_kept2 = 0; }
+    c->cull_pol.on_upload(); c->slab_pol.on_upload();
+    for (int k = 0; k < GSR_MAX_SLOTS; ++k) { c->slot[k].surv_hint = 0; c->slot[k].kept_hint = 0; c->slot[k].kept_lo = c->slot[k].kept_hi = 0; c->slot[k].horizon_valid = false; c->slot[k].local_pol.on_upload(); c->slot[k].slab_kept1 = c->slot[k].slab_kept2 = 0; }
     c->lazy_pays = false;              // ... and in automatic mode the first frames are eager until the kernels say it pays
     // (the kernels' verdicts on the last frame of the PREVIOUS cloud must not reach the first frame of this one through the device word)
     if (c->lazy_hint && hipMemset(c->lazy_hint, 0, 4) != hipSuccess) return set_err(GSR_E_HIP, "upload: could not reset the policy word");
@@ -1150,7 +1145,7 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
         f->pyr_off[l] = off;
         off += gsr_pyr_dim(f->tiles_x, l) * gsr_pyr_dim(f->tiles_y, l);
     }
-    f->cull_dilate = c->cull_dilate;
+    f->cull_dilate = c->cull_pol.dilate;
     f->phase = 0;
 }
 
@@ -1340,7 +1335,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     // (below a few hundred thousand splats in the sort the frame is bound by launch floors: nothing for culling to win)
     // ... and while culling is held off nobody needs horizons: they are prepared again two frames before it may resume.
     // A deferred frame (handed over before its pair count was known) never culls and may have clamped lists: no horizons from it.
-    if (c->opt_cull && c->opt_cull != 3 && j.n > 0 && !j.deferred && (c->opt_cull >= 2 || j.cull || j.phase == 2 || (c->vis_unculled >= 300000u && c->cull_holdoff <= 2))) {
+    if (c->opt_cull && c->opt_cull != 3 && j.n > 0 && !j.deferred && (c->opt_cull >= 2 || j.cull || j.phase == 2 || (c->cull_pol.vis_unculled >= 300000u && c->cull_pol.holdoff <= 2))) {
         hz.raw = sl.hraw; hz.pyr_in = sl.hpyr; hz.pyr_out = sl.hpyr_next; hz.dilate = j.f.cull_dilate; hz.culled = j.cull ? 1 : 0; hz.lists = sl.pvA; hz.geoA = c->geoA;
         for (int l = 0; l < GSR_PYR_LEVELS; ++l) hz.pyr_off[l] = j.f.pyr_off[l];
         hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
@@ -1356,7 +1351,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     if (sl.horizon_valid) {
         // the frame's sums and verdict, and BESIDE them (one launch) the next frame's pyramid: every tile's horizon widened to its
         // neighbourhood, into the slot's other pyramid buffer
-        sl.hpyr_re = std::min(c->cull_dilate, GSR_DILATE_EXACT_MAX);
+        sl.hpyr_re = std::min(c->cull_pol.dilate, GSR_DILATE_EXACT_MAX);
         hipLaunchKernelGGL(k_frame_end, dim3((unsigned)nblocks8 + 1u), dim3(SW_THREADS), 0, s, sl.partial, nblocks8, g, sl.counters, sl.d_n, sl.d_frame,
                            prefix_arg, redo_arg, sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint, work_next, hz, sl.st_scan, sl.hpyr_re);
         HIP_TRY(hipGetLastError());
@@ -1534,25 +1529,21 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
             sl.kept_hint = 0; sl.kept_lo = sl.kept_hi = 0;
             sl.last_pairs = 0;
             if (sl.sup_work) (void)hipMemsetAsync(sl.sup_work + 256 * sl.sup_par, 0, 256 * sizeof(uint32_t), sl.stream);
-            sl.local_fails += 1;       // (back-off: gsr_api.hip frame_begin)
+            sl.local_pol.on_sort_result(true);       // (back-off: GsrLocalSortPolicy::begin_frame)
             j.open = false;
             return GSR_OK;
         }
-        if (j.local_sort) sl.local_fails = 0;
+        if (j.local_sort) sl.local_pol.on_sort_result(false);
         if (j.phase != 2) {   // (the kernels' verdicts on the frame BEFORE: lazy colour / occlusion culling / list prefixes pay)
             c->lazy_pays = (box[1] & 1ull) != 0ull;
-            c->cull_pays = (box[1] & 4ull) != 0ull;
+            c->cull_pol.on_kernel_verdict((box[1] & 4ull) != 0ull);
             c->prefix_cheaper = (box[1] & 8ull) != 0ull;
             c->order_pays = (box[1] & 2ull) != 0ull;
         }
         if (j.phase == 0) {
         {   // occlusion culling earns its keep only if it drops a good part of what an unculled frame keeps
             const uint32_t kept = (uint32_t)(box[1] >> 32);
-            if (!j.cull) c->vis_unculled = kept;
-            else {
-                c->cull_weak = c->vis_unculled > 0 && (unsigned long long)kept * 10ull > (unsigned long long)c->vis_unculled * 7ull;
-                if (c->opt_cull == 1 && c->cull_weak) c->cull_holdoff = 256;
-            }
+            c->cull_pol.on_kept(j.cull, kept, c->opt_cull);
         }
         sl.surv_hint = (uint32_t)box[2];           // clusters that survived k_cluster_cull: sizes the next frame's K1 grid
         sl.kept_hint = (uint32_t)(box[1] >> 32);   // ... and how many splats reached the depth sort: picks the next frame's sort
@@ -1569,7 +1560,7 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
                 sl.kept_hint = sl.slab_kept + kept;
                 // a slab behind which most of the frame still has to be drawn (a ball seen from afar: its near cap finishes few tiles;
                 // oblique ground; a wall) costs more than it saves
-                if (c->vis_unculled > 0 && (unsigned long long)sl.kept_hint * 3ull > (unsigned long long)c->vis_unculled) c->slab_holdoff = 256;
+                c->slab_pol.on_frame_done(sl.kept_hint, c->cull_pol.vis_unculled);
                 sl.surv_hint = std::min<uint32_t>((uint32_t)box[2], std::max<uint32_t>(16384u, 2u * div_up(sl.kept_hint, GSR_CLUSTER)));
                 sl.kept_culled = true;
             }
@@ -1757,10 +1748,10 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     {
         const int sig[7] = {f.width, f.height, f.shard_index, f.shard_count, f.shard_rpb, f.super_shift, (int)c->geo_gen};
         j.cull = allow_cull && phase_in == 0 && c->opt_cull && !j.deferred && n > 0 && sl.horizon_valid && std::memcmp(sig, sl.horizon_sig, sizeof sig) == 0 &&
-                 !(c->opt_flags & GSR_FLAG_FULL_KEYS) && c->opt_cull != 3 && (c->opt_cull >= 2 || (c->cull_pays && c->cull_holdoff == 0));
+                 !(c->opt_flags & GSR_FLAG_FULL_KEYS) && c->opt_cull != 3 && c->cull_pol.allows(c->opt_cull);
         if (j.cull && c->opt_cull == 1 && camera_jumped(c, sl.horizon_cam, *cam)) { j.cull = false; c->st.frames_jumped += 1; }
-        if (allow_cull && phase_in == 0 && c->cull_holdoff > 0) c->cull_holdoff -= 1;
-        j.f.cull_dilate = std::max(c->cull_dilate - sl.hpyr_re, 0);   // (the rest of the radius is built into the slot's pyramid)
+        if (allow_cull && phase_in == 0) c->cull_pol.tick();
+        j.f.cull_dilate = std::max(c->cull_pol.dilate - sl.hpyr_re, 0);   // (the rest of the radius is built into the slot's pyramid)
         if (j.cull) {
             c->st.frames_culled += 1;
             // What K1 keeps is about what the frame composites: it evaluates the colours itself (eager: the SoA colour chunks of a
@@ -1780,8 +1771,8 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
                           !(c->opt_flags & GSR_FLAG_FULL_KEYS) && c->opt_sort_cache < 2 && !hit &&
                           // (where a frame is heavy enough for two phases' worth of launches to be repaid: C3's 0.8 M visible splats are not.
                           //  Not tied to cull_weak: horizons of another view cull weakly whatever the scene; a slab that is weak holds ITSELF off)
-                          (c->opt_slab >= 2 || c->opt_cull == 3 || (c->cull_pays && c->vis_unculled >= 1500000u && c->slab_holdoff == 0));
-        if (phase_in == 0 && c->slab_holdoff > 0) c->slab_holdoff -= 1;
+                          c->slab_pol.allows(c->opt_slab >= 2 || c->opt_cull == 3, c->cull_pol);
+        if (phase_in == 0) c->slab_pol.tick();
         j.phase = phase_in == 2 ? 2 : (slab ? 1 : 0);
         j.f.phase = j.phase;
         if (j.phase) {   // (a phase keeps about what it composites: K1 shades on the spot; events only around phase 1's blend kernel)
@@ -1885,9 +1876,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     const uint32_t n_slots = n ? div_up(c->nclus, 4u) * (uint32_t)GSR_K1_THREADS : 0u;   // the slots K1 can fill at most
     // (back-off: a geometry with a long run of coincident splats fails the small-frame sort's tie rule every frame; the re-render
     //  refills the hints, so without this it would be rendered twice per frame for good)
-    if (sl.local_fails >= 3) { sl.local_fails = 0; sl.local_holdoff = 64; }
-    const bool held = sl.local_holdoff > 0 && c->opt_local_sort < 2;
-    if (sl.local_holdoff > 0 && !cache_hit) sl.local_holdoff -= 1;
+    const bool held = sl.local_pol.begin_frame(c->opt_local_sort, cache_hit);
     const bool local = !cache_hit && !ordered && n_slots > 0 && key_bits > 9 && !(c->opt_flags & GSR_FLAG_FULL_KEYS) && sl.kept_hi > sl.kept_lo && !j.deferred &&
                        !c->classic_once && !held && sl.kept_culled == j.cull && j.phase == 0 &&
                        (c->opt_local_sort >= 2 || (c->opt_local_sort == 1 && sl.kept_hint > 0 && sl.kept_hint <= 500000u));
@@ -2120,7 +2109,7 @@ static int frame_check(gsr_context* c, FrameSlot& first, const gsr_camera* cam, 
         int rc = frame_verdict(c, slot, &broke);
         if (rc) return rc;
         if (!broke) {
-            if (++c->cull_streak >= 64) { c->cull_streak = 0; c->cull_backoff = 8; if (c->cull_dilate > c->opt_dilate) c->cull_dilate -= 1; }
+            c->cull_pol.on_frame_held();
 #ifdef GSR_HOST_TIMING
             g_t_verdict = now_us();
 #endif
@@ -2130,13 +2119,7 @@ static int frame_check(gsr_context* c, FrameSlot& first, const gsr_camera* cam, 
         // The view is changing faster than the horizons follow.  First answer: compare rects with the horizons of a wider
         // neighbourhood from now on (the repaired frame leaves fresh horizons, and the radius shrinks back while frames hold);
         // only when that is exhausted, leave culling alone for a while (8, 32, 128, 512, 1024 frames).
-        if (c->cull_dilate < 16) {
-            c->cull_dilate = std::max(2 * c->cull_dilate, 1);
-        } else {
-            c->cull_holdoff = std::max(c->cull_holdoff, c->cull_backoff);
-            c->cull_backoff = c->cull_backoff >= 256 ? 1024 : 4 * c->cull_backoff;
-        }
-        c->cull_streak = 0;
+        c->cull_pol.on_horizon_broke();
         c->frame_no -= 1;          // the same frame again, in the same slot
         c->st.frames -= 1;
         FrameSlot* sl = nullptr;
@@ -2254,6 +2237,24 @@ static int render_wire(gsr_context* c, const gsr_camera* cam, float* rgba_out, i
     return GSR_OK;
 }
 
+// test door of the policies (gsr_policy.h): a pure function (state, event, a, b) -> state; needs no context and no GPU
+extern "C" int gsr_debug_policy(int32_t* state16, int event, long long a, long long b)
+{
+    if (!state16) return set_err(GSR_E_INVALID, "gsr_debug_policy: NULL state");
+    gsr_policy_apply(state16, event, a, b);
+    return state16[11] < 0 ? set_err(GSR_E_INVALID, "gsr_debug_policy: unknown event %d", event) : GSR_OK;
+}
+// ... and the live policy state of a context, in the same layout ([12] = frames the slot's local-sort policy is for: slot 0)
+extern "C" int gsr_debug_policy_state(gsr_context* c, int32_t* state16)
+{
+    if (!c || !state16) return set_err(GSR_E_INVALID, "gsr_debug_policy_state: NULL argument");
+    const GsrCullPolicy& p = c->cull_pol;
+    const int32_t v[GSR_POLICY_STATE_INTS] = {p.pays, p.weak, (int32_t)p.vis_unculled, p.holdoff, p.backoff, p.streak, p.dilate, p.opt_dilate,
+                                              c->slab_pol.holdoff, c->slot[0].local_pol.fails, c->slot[0].local_pol.holdoff, 0, 0, 0, 0, 0};
+    std::memcpy(state16, v, sizeof v);
+    return GSR_OK;
+}
+
 extern "C" int gsr_synchronize(gsr_context* c)
 {
     if (!c) return set_err(GSR_E_INVALID, "gsr_synchronize: ctx is NULL");
@@ -2300,9 +2301,9 @@ extern "C" int gsr_get_stats(gsr_context* c, gsr_stats* out)
         c->st.pairs_total = sl.last_pairs;
         c->st.clusters_total = c->nclus;
         c->st.clusters_kept = sl.surv_hint;
-        c->st.policy_bits = (c->lazy_pays ? 1 : 0) | (c->order_pays ? 2 : 0) | (c->cull_pays ? 4 : 0) | (c->cull_weak ? 8 : 0) | (c->prefix_cheaper ? 16 : 0);
-        c->st.cull_dilate = c->cull_dilate;
-        c->st.cull_holdoff = c->cull_holdoff;
+        c->st.policy_bits = (c->lazy_pays ? 1 : 0) | (c->order_pays ? 2 : 0) | (c->cull_pol.pays ? 4 : 0) | (c->cull_pol.weak ? 8 : 0) | (c->prefix_cheaper ? 16 : 0);
+        c->st.cull_dilate = c->cull_pol.dilate;
+        c->st.cull_holdoff = c->cull_pol.holdoff;
         c->st.tiles_x = sl.last_tiles_x;
         c->st.tiles_y = sl.last_local_ty;
         c->st.super_tile = sl.super_tile;

@@ -79,7 +79,21 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, const GsrShar
     const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = rc >> 16 & 255, y1 = rc >> 24;
     const bool some = x1 >= x0 && y1 >= y0;
     const int area = some ? ((x1 >> shift) - (x0 >> shift) + 1) * ((y1 >> shift) - (y0 >> shift) + 1) : 0;
-    const bool big = area > BN_BIG;
+    // Which splats are "big"?  One covering more than BN_BIG super-tiles stalls its 63 neighbours if it walks its rect alone -- but the
+    // wave expands big ones ONE AFTER THE OTHER, a dozen lanes busy each time, and a group where most splats are a little over
+    // the threshold (a capture's background: every splat of a far wall covers 3 x 3 or 4 x 4 super-tiles, and depth order puts
+    // them all next to each other) took 40 such rounds instead of 16 lock-step iterations: k_bin_place 176 us on R1 for 3.5 M pairs
+    // against 55 us on C4 for 8 M.  So: where more than BN_MANY lanes of the group are over BN_BIG, the lanes walk rects of up to
+    // BN_BIG_MANY super-tiles themselves, and only the really large ones are spread over the wave.  (Wave-uniform; k_bin_count and
+    // both phases of k_bin_place see the same groups, so they agree -- and the pairs a group yields do not depend on who walks them.)
+#ifndef BN_MANY
+#define BN_MANY 6
+#endif
+#ifndef BN_BIG_MANY
+#define BN_BIG_MANY 32
+#endif
+    const int thr = __builtin_popcountll(__ballot(area > BN_BIG)) > BN_MANY ? BN_BIG_MANY : BN_BIG;
+    const bool big = area > thr;
     if (!big) bn_for_each_super(rc, shift, sh, stiles_x, [&](uint32_t d, int sx, int sy) { fn(lane, v, d, sx, sy); });
     unsigned long long bigs = __ballot(big);
     while (bigs) {
@@ -90,14 +104,25 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, const GsrShar
         const int X0 = r & 255, Y0 = (r >> 8) & 255, X1 = (r >> 16) & 255, Y1 = r >> 24;
         const int sx0 = X0 >> shift, sy0 = Y0 >> shift;
         const int w = (X1 >> shift) - sx0 + 1, h = (Y1 >> shift) - sy0 + 1;
-        for (int t = lane; t < w * h; t += 64) {
-            const int ry = t / w, sy = sy0 + ry, sx = sx0 + (t - ry * w);
+        auto cell = [&](int ry, int cx) __attribute__((always_inline)) {
+            const int sy = sy0 + ry, sx = sx0 + cx;
             if (sh.count > 1) {
                 const int lo = max(Y0, sy << shift), hi = min(Y1, ((sy + 1) << shift) - 1);
-                if (gsr_owned_rect_rows(lo, hi, sh) == 0) continue;
+                if (gsr_owned_rect_rows(lo, hi, sh) == 0) return;
             }
             const uint32_t dd = (uint32_t)sy * (uint32_t)stiles_x + (uint32_t)sx;
             fn(L, vL, dd, sx, sy);
+        };
+        if (w <= 64) {
+            // lanes as rows x columns of the rect, the columns padded to a power of two: no integer division (~30 instructions
+            // here, and a capture's screen-filling background splats -- the LAST few hundred of the depth order, all in one
+            // workgroup -- are expanded by one wave, one after the other: that workgroup is what the kernel waits for)
+            const int cb = w > 1 ? 32 - __builtin_clz((unsigned)(w - 1)) : 0;     // 1 << cb = columns per row of lanes >= w
+            const int cx = lane & ((1 << cb) - 1), rstep = 64 >> cb;
+            if (cx < w)
+                for (int ry = lane >> cb; ry < h; ry += rstep) cell(ry, cx);
+        } else {   // (a frame more than 64 super-tiles wide: 16384 x 16 pixels)
+            for (int t = lane; t < w * h; t += 64) { const int ry = t / w; cell(ry, t - ry * w); }
         }
     }
 }

@@ -217,7 +217,8 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     for (;;) {
         // (1) SCAN until a batch of hits is queued, or the list ends
         bool scanned_any = false;
-        while ((int)(q_tail - q_head) < BL_BATCH && scan_pos < n) {
+        constexpr int batch = BL_BATCH;
+        while ((int)(q_tail - q_head) < batch && scan_pos < n) {
             const int rem = n - (scan_pos + 4 * tid);   // entries of this thread that exist
             const bool h0 = rem > 0 && (preA.y & tile_bits) == tile_bits, h1 = rem > 1 && (preA.w & tile_bits) == tile_bits;
             const bool h2 = rem > 2 && (preB.y & tile_bits) == tile_bits, h3 = rem > 3 && (preB.w & tile_bits) == tile_bits;
@@ -254,7 +255,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         // quadrant only, and the surviving records go -- still in depth order, by ballot rank -- into the wave's own LDS list.
         // No other wave reads that list, so nothing between here and the end of the batch needs a workgroup barrier.
         const int avail = (int)(q_tail - q_head);
-        const int take = avail < BL_BATCH ? avail : BL_BATCH;
+        const int take = avail < batch ? avail : batch;
         if (take == 0) break;                         // list exhausted and queue empty
         fetched += (uint32_t)take;
         BLP(2)

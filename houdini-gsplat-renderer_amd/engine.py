@@ -99,7 +99,7 @@ C_ABI_SYMBOLS = [
     "gsr_device_count", "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_version", "gsr_set_stream",
     "gsr_upload_begin", "gsr_upload_append", "gsr_upload_append_raw", "gsr_upload_end", "gsr_upload_abort", "gsr_upload", "gsr_set_row_shard", "gsr_band_rows",
     "gsr_stitch_bands", "gsr_render", "gsr_render_depth", "gsr_render_wire", "gsr_render_wire_over", "gsr_synchronize", "gsr_get_stats", "gsr_stats_reset", "gsr_set_option",
-    "gsr_debug_read_records", "gsr_debug_read_depth_order", "gsr_debug_read_storage_order", "gsr_debug_read_tile_lists", "gsr_debug_sort_pairs", "gsr_debug_sort_pairs_local",
+    "gsr_debug_read_records", "gsr_debug_read_depth_order", "gsr_debug_read_storage_order", "gsr_debug_read_tile_lists", "gsr_debug_sort_pairs", "gsr_debug_sort_pairs_local", "gsr_debug_policy", "gsr_debug_policy_state",
     "gsr_debug_read_tile_work",
     "gsr_multi_create", "gsr_multi_destroy", "gsr_multi_count", "gsr_multi_transport", "gsr_multi_context",
     "gsr_multi_set_stream", "gsr_multi_set_option", "gsr_multi_upload_begin", "gsr_multi_upload_append",
@@ -118,6 +118,10 @@ C_ABI_SYMBOLS = [
     "gsplat_renderer_engine", "gsplat_closest_sqrt_power_of_2", "gsplat_quantize_half",
     "gsplat_pack_sh_from_vec3", "gsplat_pack_sh_from_frest", "gsplat_pack_sh_from_array",
 ]
+
+
+POLICY_FIELDS = ("cull_pays", "cull_weak", "vis_unculled", "cull_holdoff", "cull_backoff", "cull_streak", "cull_dilate", "opt_dilate",
+                 "slab_holdoff", "local_fails", "local_holdoff")
 
 
 def lib_path() -> str:
@@ -165,6 +169,8 @@ def load_library() -> C.CDLL:
     L.gsr_debug_read_storage_order.argtypes = [vp, vp, i64]
     L.gsr_debug_sort_pairs.argtypes = [vp, vp, vp, i64, i32]
     L.gsr_debug_sort_pairs_local.argtypes = [vp, vp, vp, i64, i32, C.c_uint32, i32]
+    L.gsr_debug_policy.argtypes = [vp, i32, C.c_longlong, C.c_longlong]
+    L.gsr_debug_policy_state.argtypes = [vp, vp]
     L.gsr_debug_read_tile_work.argtypes = [vp, vp, i64]
     # host shim wrappers
     L.gsplat_renderer_create.restype = vp
@@ -401,6 +407,12 @@ class Engine:
         cs = camera_struct(cam)
         _check(self.L.gsr_render_depth(self.h, C.byref(cs), d.ctypes.data, 0, out.ctypes.data, 0))
         return out
+
+    def policy_state(self) -> dict:
+        """the live state of the host-side policies (csrc/gsr_policy.h)"""
+        st = np.zeros(16, np.int32)
+        _check(self.L.gsr_debug_policy_state(self.h, st.ctypes.data))
+        return dict(zip(POLICY_FIELDS, (int(x) for x in st[:11])))
 
     def render_wire(self, cam) -> np.ndarray:
         """wireframe overlay (outlines of the +-2 quads, colour Cd), float32 [H, W, 4]"""

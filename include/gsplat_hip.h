@@ -381,6 +381,14 @@ int  gsr_debug_sort_pairs(gsr_context* ctx, uint32_t* keys, uint32_t* vals, int6
  * GSR_E_INVALID if a bucket outgrows its region of 8192 keys (the pipeline then falls back to the global sort). */
 int  gsr_debug_sort_pairs_local(gsr_context* ctx, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits,
                                 uint32_t bucket_lo, int bucket_shift);
+/* The host-side policies (csrc/gsr_policy.h; DESIGN.md section 4: state table) as a pure function: state16 holds
+ * [0] cull.pays [1] cull.weak [2] cull.vis_unculled [3] cull.holdoff [4] cull.backoff [5] cull.streak [6] cull.dilate [7] cull.opt_dilate
+ * [8] slab.holdoff [9] local.fails [10] local.holdoff [11] (out) the event's answer; event = GsrPolicyEvent (0 upload, 1 cull allows?(a = opt),
+ * 2 cull tick, 3 kernel verdict(a), 4 kept(a = splats, b = culled | opt << 1), 5 frame held, 6 horizon broke, 7 slab allows?(a = forced),
+ * 8 slab tick, 9 slab done(a = kept), 10 local-sort begin(a = opt, b = static redraw), 11 local-sort result(a = failed), 12 set dilate(a)).
+ * No context, no GPU: what tests/test_policy.py drives.  gsr_debug_policy_state reads a live context's state in the same layout. */
+int  gsr_debug_policy(int32_t* state16, int event, long long a, long long b);
+int  gsr_debug_policy_state(gsr_context* ctx, int32_t* state16);
 
 #ifdef __cplusplus
 }

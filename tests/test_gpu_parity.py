@@ -1272,6 +1272,43 @@ def test_occlusion_culling_on_scenes_with_sky_and_silhouettes(pkg, oracle, kind)
         ref.close(); eng.close()
 
 
+def test_live_policy_state_follows_the_frames(pkg):
+    """The policies of a LIVE context (csrc/gsr_policy.h; every transition is pinned on the CPU by tests/test_policy.py) move as the
+    state table in DESIGN.md section 4 says when real frames drive them: a fresh cloud knows nothing; the first (unculled) frame sets the
+    yardstick; once the kernels say culling pays the orbit is culled and the streak of frames that held counts up; a camera JUMP is
+    recognised on the host (no culled attempt, no repair); the option is the floor of the dilation radius; a new cloud forgets."""
+    E = pkg.engine
+    splats = pkg.scenes.make_scene(600000, seed=43, sh=True, radius=1.0)
+    w, h = 960, 540
+    cams = [pkg.camera.make_camera(w, h, sh_order=3, frame=i, distance=3.2) for i in range(40)]
+    eng = pkg.Engine(0)
+    try:
+        eng.set_option(E.OPT_CULL_DILATE, 3)
+        eng.upload(splats)
+        p = eng.policy_state()
+        assert (p["cull_pays"], p["vis_unculled"], p["cull_holdoff"], p["cull_backoff"], p["cull_streak"], p["cull_dilate"], p["opt_dilate"]) == (0, 0, 0, 8, 0, 3, 3)
+        eng.render(cams[0])
+        p = eng.policy_state()
+        assert p["vis_unculled"] == eng.stats()["n_visible"] > 100000 and eng.stats()["frames_culled"] == 0
+        for c in cams[1:30]:
+            eng.render(c)
+        st, p = eng.stats(), eng.policy_state()
+        assert p["cull_pays"] == 1 and st["frames_culled"] >= 20, (st, p)
+        held = st["frames_culled"] - st["frames_repaired"]
+        assert p["cull_streak"] == held % 64 if st["frames_repaired"] == 0 else p["cull_streak"] <= held
+        assert p["cull_dilate"] >= 3 and (p["cull_dilate"] == 3 or st["frames_repaired"] > 0)
+        before = eng.stats()
+        eng.render(pkg.camera.make_camera(w, h, sh_order=3, frame=75, distance=4.4))       # a cut: 135 degrees round, 1.4 x as far
+        after = eng.stats()
+        assert after["frames_jumped"] == before["frames_jumped"] + 1 and after["frames_repaired"] == before["frames_repaired"]
+        assert eng.policy_state()["cull_streak"] == p["cull_streak"]                        # (no verdict was asked for: the streak stands)
+        eng.upload(pkg.scenes.make_scene(5000, seed=44, sh=False))
+        p = eng.policy_state()
+        assert (p["cull_pays"], p["vis_unculled"], p["cull_streak"], p["cull_dilate"], p["slab_holdoff"], p["local_fails"]) == (0, 0, 0, 3, 0, 0)
+    finally:
+        eng.close()
+
+
 def test_occlusion_culling_engages_on_a_ball_under_open_sky(pkg):
     """A dense ball in the middle of an empty frame (a third of the pixels are sky, the limb crosses hundreds of tiles): with
     per-tile horizons the library's own policy culls (nearly) every frame of a steady orbit, repairs (nearly) none, sends a

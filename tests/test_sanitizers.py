@@ -7,8 +7,9 @@ thread per rank with mapped-memory mailboxes: what AddressSanitizer / UndefinedB
 * CPU (not gpu): tests/test_host_shim.py + tests/test_cabi.py, every test of them, against the ASan + UBSan build (dry instances: the
   registry / staging-plan / ingest logic, no GPU) -- in a child process, because the sanitizer runtime has to be preloaded.
 * GPU: the gsr_multi frames of test_multi_gpu_gather_overlaps_the_next_frame_and_keeps_every_frame (three ranks on one GPU over the
-  COPY transport: caller thread + three workers + the transfer streams) under the TSan build; and the host-shim frame protocol on a
-  real context under ASan.
+  COPY transport: caller thread + three workers + the transfer streams) under the TSan build.  (ASan with a LIVE GPU was tried and
+  is not part of the suite: with the ASan runtime preloaded the ROCm runtime of this image does not initialise -- the process leaves at
+  hipInit without a report, protect_shadow_gap=0 or not -- so the address checks stay on the dry instances, which run the same host code.)
 Skipped only where the compiler has no sanitizer runtime."""
 import os
 import re
@@ -94,14 +95,3 @@ def test_multi_gpu_workers_under_tsan():
     ours = [b for b in races if re.search(r"gsr_multi|GSplatRenderer|gsr_api|gsplat_ingest|libgsplat_hip", b)]
     assert not ours, "ThreadSanitizer reports in the library's own frames:\n" + "\n".join(ours)[:6000]
     assert re.search(r"\d+ passed", r.stdout) and " failed" not in r.stdout, out[-3000:]
-
-
-@pytest.mark.gpu
-def test_renderer_verbs_on_a_gpu_under_asan():
-    """the nine verbs on a real context (registerUpdate borrows, generateRenderGeometry stages, render, postRender; entries flushed while
-    resident; the maximum-size plan) under ASan + UBSan: no report"""
-    r = _run("asan", ["tests/test_gpu_parity.py", "-m", "gpu", "-k", "test_renderer_shim_frame_protocol or test_randomised_shim_protocol or test_raw_ingest"],
-             extra_env={"ASAN_OPTIONS": "detect_leaks=0:halt_on_error=1:exitcode=87:protect_shadow_gap=0:use_sigaltstack=0"})
-    out = (r.stdout + r.stderr)
-    assert "ERROR: AddressSanitizer" not in out and "runtime error:" not in out, out[-4000:]
-    assert r.returncode == 0 and re.search(r"\d+ passed", r.stdout), out[-3000:]

@@ -127,6 +127,9 @@ def parse_args():
                     help="run ONLY the warm-up and the timed region (no per-stage leg, no culling-off leg, no pipelined leg): what a "
                          "rocprofv3 run should see, so that its per-kernel averages describe one regime")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the informational leg that renders BASELINE C1, C2, C3 and C5 after the timed region")
+    ap.add_argument("--via-multi", action="store_true",
+                    help="--gpus 1 through the multi-GPU entry (gsr_multi with ONE rank): what the N = 1 point of a scaling curve measured with "
+                         "`bench.py --gpus N` runs, so that it can be checked against the single-context line (they must agree within ~3 %)")
     ap.add_argument("--no-verify", action="store_true",
                     help="N>1: skip the check (after the timed region) that the last stitched frame is bit-identical to the same frame "
                          "rendered unsharded on rank 0")
@@ -433,6 +436,21 @@ def main_single_process(args):
                           "frames_culled": sg["frames_culled"], "frames_repaired": sg["frames_repaired"]})
         M.set_option(E.OPT_STAGE_TIMING, args.stage_timing)
     rccl_ranks, rccl_n = M.comm_info()
+    # a communicator that does not span the N ranks means the frame never crossed xGMI the way the line says: no number then
+    comm_ok = (M.transport != E.TRANSPORT_RCCL) or N == 1 or rccl_n == N
+    if not comm_ok:
+        print(f"[bench] RCCL reports {rccl_n} ranks in the communicator, {N} were asked for", file=sys.stderr)
+    # the gather, per link: every peer sends its band over its own xGMI link to the root (SURVEY 8e assumes ~153 GB/s per link)
+    band_bytes = [int(sum(min(16, H - r * 16) for r in pkg.multigpu.owned_tile_rows(H, g, N, args.shard_layout)) * W * 16) for g in range(N)]
+    link = None
+    if N > 1:
+        peer_bytes = max(band_bytes[1:])
+        link = {"bytes_per_peer": band_bytes[1:], "bytes_total_into_root": int(sum(band_bytes[1:])), "gather_ms": gather_ms,
+                "GBps_per_link": (peer_bytes / (gather_ms * 1e-3) / 1e9) if gather_ms else None, "GBps_assumed_per_link": 153.0,
+                "GBps_into_root": (sum(band_bytes[1:]) / (gather_ms * 1e-3) / 1e9) if gather_ms else None,
+                "note": "gather_ms = HIP events on the root's transfer stream around the grouped ncclRecv x (N-1) (+ the root's own band copy); the "
+                        "peers send concurrently, each over its own link: per-link rate = the largest peer band / gather_ms"
+                        + ("" if M.transport == E.TRANSPORT_RCCL else " -- COPY transport on shared GPUs: NOT a link measurement")}
     hbm = measured_hbm_peak()
     per_rank = []
     for g in range(N):
@@ -444,7 +462,7 @@ def main_single_process(args):
     line = {
         "metric": "frames/sec at 1920x1080 + achieved HBM GB/s (blend kernel)" if (W, H) == (1920, 1080)
         else f"frames/sec at {W}x{H} + achieved HBM GB/s (blend kernel)",
-        "value": (args.steps / elapsed) if verified is not False else None,
+        "value": (args.steps / elapsed) if (verified is not False and comm_ok) else None,
         "unit": "frames/sec", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.ply else "INRIA PLY capture (--ply)",
         "config": {"workload": workload_name(args, splats, cfg, order, W, H),
@@ -459,6 +477,8 @@ def main_single_process(args):
         "rccl_ranks": rccl_ranks, "rccl_comm_count": rccl_n,
         "sharded_frame_bit_identical": verified,
         "gather_ms": gather_ms,
+        "gather_links": link,
+        "per_rank_ms_per_step": [sg["ms_total"] for sg in stage] if stage else None,
         "per_rank_stages_ms": stage,
         "roofline": per_rank[heavy],
         "roofline_per_rank": [{k: r[k] for k in ("rank", "achieved", "frac", "avg_launch_ms", "pairs_consumed_per_launch", "algorithmic_bytes_per_launch", "regime")} for r in per_rank],
@@ -471,11 +491,13 @@ def main_single_process(args):
     M.close()
     if verified is False:
         sys.exit(3)
+    if not comm_ok:
+        sys.exit(4)
 
 
 def main():
     args = parse_args()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.via_multi):
         return main_single_process(args)
     import torch
 
@@ -840,6 +862,9 @@ def main():
                        "algorithmic_bytes_per_launch": k1_bytes,
                        "bytes_per_kept_splat": col_b + 48 + 12 + (4 if k1_scatters else 0),
                        "splats_kept": int(nvis), "clusters_kept": int(ckept), "clusters": int(call),
+                       # of the covariance chains K1 runs (one per splat of a surviving cluster), how many end in a splat that is dropped
+                       # (off-screen rect, alpha support shrunk to nothing, behind every horizon its rect reaches): what an earlier test could save
+                       "covariance_chains": int(ckept * 64), "chains_that_end_in_a_dropped_splat_frac": (1.0 - nvis / (ckept * 64.0)) if ckept else None,
                        "note": "k_cluster_cull + k_preprocess (stage 0 of the frame); " +
                                ("lazy colour: geometry only" if lazy_on else "eager colour: + the colour halves of every splat that stays") +
                                ("; key + payload dropped into the small-frame sort's buckets by K1 itself (12 B + a 4-byte atomic)" if k1_scatters else "") +

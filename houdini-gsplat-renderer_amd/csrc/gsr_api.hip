@@ -1262,7 +1262,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
     if ((rc = mark(sl, 3))) return rc;
     if (j.n > 0) {
         const uint32_t nblk = div_up(j.n, (uint32_t)BN_THREADS * (uint32_t)j.bn_items);
-        const size_t lds = (size_t)4 * j.bn_items * j.n_super * 8 + (size_t)4 * j.n_super * 4;
+        const size_t lds = (size_t)4 * j.bn_items * j.n_super * (8 + 4);   // lane masks (u64) + first list position (u32) per (group of 64 splats, super-tile)
         const GsrShard shd{f.shard_index, f.shard_count, f.shard_rpb, f.rect_shift};
         const GsrRangeArgs ra = j.ranges_folded ? range_args(c, sl) : GsrRangeArgs{};
         // (+1: the publishing workgroup)

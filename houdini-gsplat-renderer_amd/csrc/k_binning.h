@@ -227,15 +227,16 @@ k_bin_ranges(GsrRangeArgs a)
 }
 
 // Placement.  Inside a list the order must be the depth order of the splats, so the pairs of one
-// super-tile are ranked by splat position: across blocks by the scanned histogram, across the four
-// waves of a block by per-wave counts, and inside a wave through 64-bit LANE MASKS in LDS -- for
-// every group of 64 consecutive splats (lane = splat) and every super-tile, the set of lanes whose
-// splat covers it.  Every lane ORs its bit into the masks of the super-tiles it covers (A); the
-// counts of the masks give the wave bases (S); and a pair's list position is its wave base + the
-// population of the earlier groups' masks + the number of lower lanes in its own group's mask (B).
-// Nothing is mutated between A and B, so a wave pays a handful of dependent LDS round trips in
-// total instead of several per group.
-// Dynamic LDS: lmask[4 waves][BN_ITEMS groups][ns] (u64) followed by wbase[4][ns] (u32), ns = n_super.
+// super-tile are ranked by splat position: across blocks by the scanned histogram, and inside a block through 64-bit LANE
+// MASKS in LDS -- for every GROUP of 64 consecutive splats (lane = splat) and every super-tile, the set of lanes whose splat
+// covers it.  Every lane ORs its bit into the masks of the super-tiles it covers (A); thread d walks super-tile d's masks
+// group by group and leaves, per group, the list position of the group's first pair (S); a pair's position is then that +
+// the number of lower lanes in its own group's mask (B).  Nothing is mutated between A and B.
+// A block's 4 * ITEMS groups are dealt to the waves ROUND ROBIN (wave w: groups w, w + 4, ...), as in k_bin_count: the
+// screen-filling background splats of a capture are the LAST few hundred of the depth order -- with a contiguous quarter of
+// the block per wave (round 4) one wave expanded all of them, and the kernel waited for it (R1: 176 us for 3.5 M pairs against
+// 55 us for C4's 8 M).
+// Dynamic LDS: lmask[4 * ITEMS groups][ns] (u64) followed by gpre[4 * ITEMS][ns] (u32), ns = n_super.
 // ranges.totals != NULL: the list ranges are formed HERE (every workgroup scans the 256 totals itself; the last one also writes
 // them out and posts the pair count) instead of by a k_bin_ranges launch in front: one launch floor less per frame.
 template <int ITEMS>
@@ -245,7 +246,8 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
             uint32_t nblk, uint32_t cap, uint2* __restrict__ out, GsrRangeArgs ranges)
 {
     static_assert(BN_THREADS == BN_BINS, "one thread per super-tile in the range scan");
-    constexpr uint32_t TILE = BN_THREADS * ITEMS, WAVE_ITEMS = TILE / 4;   // wave w owns the w-th contiguous quarter of the block
+    constexpr uint32_t TILE = BN_THREADS * ITEMS;
+    constexpr int NG = 4 * ITEMS;                     // groups of 64 splats per block
     KPROF(0, 0)
     KPROF_BLK_BEGIN
     extern __shared__ unsigned long long bn_lds[];
@@ -270,56 +272,45 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     }
     __syncthreads();
     KPROF(0, 1)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long* lmask = bn_lds + (size_t)wave * ITEMS * ns;                       // [g][d] of this wave
-    uint32_t* wbase_all = reinterpret_cast<uint32_t*>(bn_lds + (size_t)4 * ITEMS * ns);   // [wave][d]
-    uint32_t* wbase = wbase_all + wave * ns;
+    const int wave = threadIdx.x >> 6;
+    unsigned long long* lmask = bn_lds;                                              // [group][d]
+    uint32_t* gpre = reinterpret_cast<uint32_t*>(bn_lds + (size_t)NG * ns);          // [group][d]: list position of the group's first pair
     for (uint32_t blk = blockIdx.x; blk < nb; blk += workers) {
     const uint32_t tile = rs_tile_of_block(blk, nb, true);
-    const uint32_t first = tile * TILE + wave * WAVE_ITEMS;
+    const uint32_t first = tile * TILE;
     KPROF(0, 2)
-    for (int b = lane; b < ITEMS * ns; b += 64) lmask[b] = 0ull;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    for (int b = threadIdx.x; b < NG * ns; b += BN_THREADS) lmask[b] = 0ull;
+    __syncthreads();
     KPROF(0, 3)
     uint2 v[ITEMS];
 #pragma unroll
-    for (int g = 0; g < ITEMS; ++g) {   // (A)
-        const uint32_t i = first + g * 64 + lane;
-        v[g] = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
-        bn_group_pairs(v[g], shift, sh, stiles_x,
-                       [&](int L, uint2, uint32_t d, int, int) { if (d < (uint32_t)ns) atomicOr(&lmask[g * ns + d], 1ull << L); });
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    KPROF(0, 4)
-    for (int d = lane; d < ns; d += 64) {  // (S) this wave's pair count per super-tile
-        uint32_t c = 0;
-#pragma unroll
-        for (int g = 0; g < ITEMS; ++g) c += (uint32_t)__builtin_popcountll(lmask[g * ns + d]);
-        wbase[d] = c;
+    for (int k = 0; k < ITEMS; ++k) {   // (A) wave w: groups w, w + 4, ...
+        const int grp = k * 4 + wave;
+        const uint32_t i = first + (uint32_t)grp * 64u + (threadIdx.x & 63u);
+        v[k] = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
+        bn_group_pairs(v[k], shift, sh, stiles_x,
+                       [&](int L, uint2, uint32_t d, int, int) { if (d < (uint32_t)ns) atomicOr(&lmask[grp * ns + d], 1ull << L); });
     }
     __syncthreads();
-    KPROF(0, 5)
-    for (int d = threadIdx.x; d < ns; d += BN_THREADS) {   // counts -> first list position of each wave
+    KPROF(0, 4)
+    for (int d = threadIdx.x; d < ns; d += BN_THREADS) {   // (S) per super-tile: where each group's pairs begin
         uint32_t p = s_start[d] + offs[(size_t)d * nblk + tile];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { const uint32_t c = wbase_all[w * ns + d]; wbase_all[w * ns + d] = p; p += c; }
+        for (int grp = 0; grp < NG; ++grp) { gpre[grp * ns + d] = p; p += (uint32_t)__builtin_popcountll(lmask[grp * ns + d]); }
     }
     __syncthreads();
     KPROF(0, 6)
 #pragma unroll
-    for (int g = 0; g < ITEMS; ++g) {   // (B)
-        bn_group_pairs(v[g], shift, sh, stiles_x, [&](int L, uint2 vL, uint32_t d, int sx, int sy) {
+    for (int k = 0; k < ITEMS; ++k) {   // (B)
+        const int grp = k * 4 + wave;
+        bn_group_pairs(v[k], shift, sh, stiles_x, [&](int L, uint2 vL, uint32_t d, int sx, int sy) {
             if (d >= (uint32_t)ns) return;
-            uint32_t pos = wbase[d] + (uint32_t)__builtin_popcountll(lmask[g * ns + d] & ((1ull << L) - 1ull));
-#pragma unroll
-            for (int e = 0; e < g; ++e) pos += (uint32_t)__builtin_popcountll(lmask[e * ns + d]);
+            const uint32_t pos = gpre[grp * ns + d] + (uint32_t)__builtin_popcountll(lmask[grp * ns + d] & ((1ull << L) - 1ull));
             if (pos < cap) out[pos] = make_uint2(vL.x, bn_tile_mask(vL.y, sx, sy, shift));
         });
     }
     KPROF(0, 7)
-    __syncthreads();   // (the next block re-uses the masks and the wave bases)
+    __syncthreads();   // (the next block re-uses the masks and the group positions)
     }
     KPROF_BLK_END(0, n < TILE ? n : TILE)
 }

@@ -155,7 +155,8 @@ def make_capture(n: int, seed: int, sh: bool = True) -> Splats:
     against the far room leave open tiles everywhere, the big background splats reach hundreds of tiles."""
     rng = np.random.default_rng(seed)
     n_obj, n_floor, n_room = int(0.40 * n), int(0.15 * n), int(0.15 * n)
-    n_big = min(300, n // 20)
+    import os
+    n_big = min(int(os.environ.get("GSR_R1_BIG", "300")), n // 20)     # (diagnostic hook: how much of a frame the screen-filling splats cost)
     n_float = n - n_obj - n_floor - n_room - n_big
 
     def unit(m):

@@ -1615,6 +1615,27 @@ def test_bench_launches_itself_on_several_gpus(pkg):
         assert res.returncode != 0 and line is not None and "error" in line and line["value"] is None
 
 
+def test_bench_one_rank_through_the_multi_gpu_door_matches_the_single_context(pkg):
+    """`bench.py --gpus 1 --via-multi` (gsr_multi with ONE rank: the N = 1 point of a scaling curve measured through `--gpus N`)
+    must give the single-context line's frame rate -- so that, the day the curve is measured, its first point agrees with BENCH.
+    Best of two runs each way (a box's runs differ by ~2 %); the gather line carries the per-link figures for N > 1."""
+    argv = ["--config", "C3", "--steps", "300", "--warmup", "20", "--no-cpu-baseline", "--no-extra-legs", "--no-verify"]
+    single, multi = [], []
+    for _ in range(2):
+        res, line = _run_bench(argv, {})
+        assert res.returncode == 0 and line["n_gpus"] == 1, res.stderr[-2000:]
+        single.append(line["value"])
+        res, line = _run_bench(argv + ["--gpus", "1", "--via-multi"], {})
+        assert res.returncode == 0 and line["n_gpus"] == 1 and "gsr_multi" in line["config"]["parallelism"], res.stderr[-2000:]
+        multi.append(line["value"])
+    assert abs(max(multi) / max(single) - 1.0) < 0.04, (single, multi)
+    res, line = _run_bench(["--gpus", "2", "--config", "C2", "--steps", "8", "--warmup", "3", "--no-cpu-baseline"], {"GSR_BENCH_ALLOW_DUP": "1"})
+    assert res.returncode == 0, res.stderr[-2000:]
+    gl = line["gather_links"]
+    assert gl["bytes_per_peer"] == [line["config"]["width"] * 16 * sum(min(16, line["config"]["height"] - r * 16) for r in range(23, 45))]
+    assert gl["GBps_per_link"] > 0 and gl["GBps_assumed_per_link"] == 153.0 and len(line["per_rank_ms_per_step"]) == 2
+
+
 def test_bench_single_gpu_line_says_whether_the_timed_frame_is_the_full_frame(pkg):
     res, line = _run_bench(["--config", "C3", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs"], {})
     assert res.returncode == 0, res.stderr[-2000:]

@@ -1265,8 +1265,9 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         const size_t lds = (size_t)4 * j.bn_items * j.n_super * (8 + 4);   // lane masks (u64) + first list position (u32) per (group of 64 splats, super-tile)
         const GsrShard shd{f.shard_index, f.shard_count, f.shard_rpb, f.rect_shift};
         const GsrRangeArgs ra = j.ranges_folded ? range_args(c, sl) : GsrRangeArgs{};
-        // (+1: the publishing workgroup)
-        const uint32_t grid = std::min(nblk, j.bn_grid) + (j.ranges_folded ? 1u : 0u);
+        // (+ the extra work items of the blocks that are split by rows of super-tiles, k_binning.h; +1: the publishing workgroup)
+        const uint32_t bn_extra = (uint32_t)BN_SPLIT_TILES * (uint32_t)std::max(f.stiles_y - 1, 0);
+        const uint32_t grid = std::min(nblk, j.bn_grid) + bn_extra + (j.ranges_folded ? 1u : 0u);
 #define GSR_PLACE(I) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin_place<I>), dim3(grid), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n,          \
                                         f.super_shift - f.rect_shift, shd, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk, (uint32_t)sl.pair_cap, sl.pvA, ra)
         if (j.bn_items == 1) GSR_PLACE(1); else if (j.bn_items == 2) GSR_PLACE(2); else GSR_PLACE(4);
@@ -2042,8 +2043,10 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         const GsrShard shd{f.shard_index, f.shard_count, f.shard_rpb, f.rect_shift};
         // the grids of the binning kernels: what the slot's previous frame kept, + 25 % (they loop if the frame keeps more)
         j.bn_grid = (sl.kept_hint > 0 && j.phase == 0) ? std::min<uint32_t>(nblk, div_up(sl.kept_hint + sl.kept_hint / 4u, bn_tile) + 64u) : (j.phase ? std::min<uint32_t>(nblk, 4096u) : nblk);
-#define GSR_COUNT(I) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin_count<I>), dim3(j.bn_grid), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift - f.rect_shift, \
-                                        shd, f.stiles_x, sl.hist, nblk)
+        // (+ the extra work items of the blocks that are split by rows of super-tiles: k_binning.h, BN_SPLIT_TILES)
+        const uint32_t bn_extra = (uint32_t)BN_SPLIT_TILES * (uint32_t)std::max(f.stiles_y - 1, 0);
+#define GSR_COUNT(I) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin_count<I>), dim3(j.bn_grid + bn_extra), dim3(BN_THREADS), 0, s, sl.valA, sl.d_n, f.super_shift - f.rect_shift, \
+                                        shd, f.stiles_x, f.stiles_y, sl.hist, nblk)
         if (j.bn_items == 1) GSR_COUNT(1); else if (j.bn_items == 2) GSR_COUNT(2); else GSR_COUNT(4);
 #undef GSR_COUNT
         hipLaunchKernelGGL(k_scan_rows, dim3(BN_BINS), dim3(SC_THREADS), 0, s, sl.hist, nblk, sl.totals, sl.d_n, n, bn_tile);

@@ -50,13 +50,14 @@ __device__ __forceinline__ uint32_t bn_tile_mask(uint32_t rc, int sx, int sy, in
 // visit the owned super-tiles of a packed tile rect
 // (occlusion culling needs nothing here: K1 keeps a splat iff one of the tiles of its rect may still need it, and then it
 //  enters every list its rect reaches -- a tile that does not need it has gone opaque before it gets there)
+// (row_lo, row_hi: the super-tile rows this work item owns -- BnPart below; 0 .. INT_MAX where a block is not split)
 template <typename F>
-__device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, const GsrShard& sh, int stiles_x, F&& fn)
+__device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, const GsrShard& sh, int stiles_x, int row_lo, int row_hi, F&& fn)
 {
     const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = (rc >> 16) & 255, y1 = rc >> 24;
     if (x1 < x0 || y1 < y0) return;
     const int sx0 = x0 >> shift, sx1 = x1 >> shift;
-    for (int sy = y0 >> shift; sy <= (y1 >> shift); ++sy) {
+    for (int sy = max(y0 >> shift, row_lo); sy <= min(y1 >> shift, row_hi); ++sy) {
         if (sh.count > 1) {
             const int lo = max(y0, sy << shift), hi = min(y1, ((sy + 1) << shift) - 1);
             if (gsr_owned_rect_rows(lo, hi, sh) == 0) continue;
@@ -71,14 +72,32 @@ __device__ __forceinline__ void bn_for_each_super(uint32_t rc, int shift, const 
 // super-tiles while the median covers one or two, and depth order puts all the big ones into the
 // same few groups -- so a lane walks its own rect only when it is small; the rect of a big splat
 // is spread over the 64 lanes (the caller's fn never assumes owner_lane == its own lane).
+// The NEAREST splats of a view from inside the cloud fill the screen: the first block of the depth order then holds a thousand
+// splats of 135 super-tiles each, and one workgroup expanded them all (R1: workgroup 0 of k_bin_place 126 us, the median one 15).
+// The first BN_SPLIT_TILES blocks are therefore each handled by one workgroup PER ROW of super-tiles: a part walks only the cells
+// of its row (hist columns and list positions of different super-tiles never meet, so the parts need not know of each other).
+#ifndef BN_SPLIT_TILES
+#define BN_SPLIT_TILES 16
+#endif
+struct BnPart { uint32_t tile; int row_lo, row_hi; };
+// work item v of nv = nb + min(nb, BN_SPLIT_TILES) * (rows - 1) -> (block, rows); blocks behind the split ones go to the XCDs in contiguous eighths
+__device__ __forceinline__ uint32_t bn_items(uint32_t nb, int rows) { const uint32_t hs = nb < (uint32_t)BN_SPLIT_TILES ? nb : (uint32_t)BN_SPLIT_TILES; return nb + hs * (uint32_t)(rows - 1); }
+__device__ __forceinline__ BnPart bn_part(uint32_t v, uint32_t nb, int rows)
+{
+    const uint32_t hs = nb < (uint32_t)BN_SPLIT_TILES ? nb : (uint32_t)BN_SPLIT_TILES;
+    if (v < hs * (uint32_t)rows) { const uint32_t t = v / (uint32_t)rows; const int r = (int)(v - t * (uint32_t)rows); return BnPart{t, r, r}; }
+    return BnPart{hs + rs_tile_of_block(v - hs * (uint32_t)rows, nb - hs, true), 0, 0x7fffffff};
+}
+
 template <typename F>
-__device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, const GsrShard& sh, int stiles_x, F&& fn)
+__device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, const GsrShard& sh, int stiles_x, int row_lo, int row_hi, F&& fn)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t rc = v.y;
     const int x0 = rc & 255, y0 = (rc >> 8) & 255, x1 = rc >> 16 & 255, y1 = rc >> 24;
     const bool some = x1 >= x0 && y1 >= y0;
-    const int area = some ? ((x1 >> shift) - (x0 >> shift) + 1) * ((y1 >> shift) - (y0 >> shift) + 1) : 0;
+    const int ya = max(y0 >> shift, row_lo), yb = min(y1 >> shift, row_hi);            // (the rows of the rect this work item owns)
+    const int area = (some && yb >= ya) ? ((x1 >> shift) - (x0 >> shift) + 1) * (yb - ya + 1) : 0;
     // Which splats are "big"?  One covering more than BN_BIG super-tiles stalls its 63 neighbours if it walks its rect alone -- but the
     // wave expands big ones ONE AFTER THE OTHER, a dozen lanes busy each time, and a group where most splats are a little over
     // the threshold (a capture's background: every splat of a far wall covers 3 x 3 or 4 x 4 super-tiles, and depth order puts
@@ -94,7 +113,7 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, const GsrShar
 #endif
     const int thr = __builtin_popcountll(__ballot(area > BN_BIG)) > BN_MANY ? BN_BIG_MANY : BN_BIG;
     const bool big = area > thr;
-    if (!big) bn_for_each_super(rc, shift, sh, stiles_x, [&](uint32_t d, int sx, int sy) { fn(lane, v, d, sx, sy); });
+    if (!big) bn_for_each_super(rc, shift, sh, stiles_x, row_lo, row_hi, [&](uint32_t d, int sx, int sy) { fn(lane, v, d, sx, sy); });
     unsigned long long bigs = __ballot(big);
     while (bigs) {
         const int L = __builtin_ctzll(bigs);
@@ -102,8 +121,8 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, const GsrShar
         const uint2 vL = make_uint2((uint32_t)__shfl((int)v.x, L, 64), (uint32_t)__shfl((int)v.y, L, 64));
         const uint32_t r = vL.y;
         const int X0 = r & 255, Y0 = (r >> 8) & 255, X1 = (r >> 16) & 255, Y1 = r >> 24;
-        const int sx0 = X0 >> shift, sy0 = Y0 >> shift;
-        const int w = (X1 >> shift) - sx0 + 1, h = (Y1 >> shift) - sy0 + 1;
+        const int sx0 = X0 >> shift, sy0 = max(Y0 >> shift, row_lo);
+        const int w = (X1 >> shift) - sx0 + 1, h = min(Y1 >> shift, row_hi) - sy0 + 1;
         auto cell = [&](int ry, int cx) __attribute__((always_inline)) {
             const int sy = sy0 + ry, sx = sx0 + cx;
             if (sh.count > 1) {
@@ -136,7 +155,7 @@ __device__ __forceinline__ void bn_group_pairs(uint2 v, int shift, const GsrShar
 template <int ITEMS>
 __global__ void __launch_bounds__(BN_THREADS)
 k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, GsrShard sh,
-            int stiles_x, uint32_t* __restrict__ hist, uint32_t nblk)
+            int stiles_x, int stiles_y, uint32_t* __restrict__ hist, uint32_t nblk)
 {
     constexpr uint32_t TILE = BN_THREADS * ITEMS;
     // (d < BN_BINS below: a frame whose small-frame sort overflowed a bucket is rendered again, but until then its payloads may
@@ -148,22 +167,26 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     const uint32_t nb = (n + TILE - 1) / TILE;
     // the grid follows what the slot's previous frame kept (+25 %): a frame that keeps more simply loops (nblk = the row
     // length of hist, the host's upper bound on the blocks)
-    for (uint32_t blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+    const uint32_t nv = bn_items(nb, stiles_y);
+    for (uint32_t wi = blockIdx.x; wi < nv; wi += gridDim.x) {
         for (int b = threadIdx.x; b < 4 * BN_BINS; b += BN_THREADS) (&h[0][0])[b] = 0;
         __syncthreads();
-        const uint32_t tile = rs_tile_of_block(blk, nb, true);
+        const BnPart part = bn_part(wi, nb, stiles_y);
+        const uint32_t tile = part.tile;
         {
             const uint32_t base = tile * TILE;
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) {
                 const uint32_t i = base + k * BN_THREADS + threadIdx.x;   // (every wave sees 64 consecutive splats)
                 const uint2 v = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
-                bn_group_pairs(v, shift, sh, stiles_x,
+                bn_group_pairs(v, shift, sh, stiles_x, part.row_lo, part.row_hi,
                                [&](int, uint2, uint32_t d, int, int) { if (d < (uint32_t)BN_BINS) atomicAdd(&h[wave][d], 1u); });
             }
         }
         __syncthreads();
-        for (int b = threadIdx.x; b < BN_BINS; b += BN_THREADS)
+        // (a part writes the columns of ITS rows of super-tiles only: the others belong to the block's other parts)
+        const int b_lo = part.row_lo * stiles_x, b_hi = part.row_hi >= stiles_y ? BN_BINS : (part.row_hi + 1) * stiles_x;
+        for (int b = b_lo + (int)threadIdx.x; b < b_hi; b += BN_THREADS)
             hist[(size_t)b * nblk + tile] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
         __syncthreads();
     }
@@ -263,7 +286,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     // what the slot's previous frame kept (+25 %) -- and one without a block leaves before the range scan.
     const bool publisher = ranges.totals && blockIdx.x == gridDim.x - 1u;
     const uint32_t workers = ranges.totals ? gridDim.x - 1u : gridDim.x;
-    if (!publisher && blockIdx.x >= nb) return;
+    if (!publisher && blockIdx.x >= bn_items(nb, stiles_x > 0 ? (ns + stiles_x - 1) / stiles_x : 1)) return;
     if (ranges.totals) {
         s_start[threadIdx.x] = bn_ranges(ranges, publisher, s_rwave, s_rsum);
         if (publisher) return;
@@ -275,8 +298,11 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
     const int wave = threadIdx.x >> 6;
     unsigned long long* lmask = bn_lds;                                              // [group][d]
     uint32_t* gpre = reinterpret_cast<uint32_t*>(bn_lds + (size_t)NG * ns);          // [group][d]: list position of the group's first pair
-    for (uint32_t blk = blockIdx.x; blk < nb; blk += workers) {
-    const uint32_t tile = rs_tile_of_block(blk, nb, true);
+    const int stiles_y = stiles_x > 0 ? (ns + stiles_x - 1) / stiles_x : 1;
+    const uint32_t nv = bn_items(nb, stiles_y);
+    for (uint32_t wi = blockIdx.x; wi < nv; wi += workers) {
+    const BnPart part = bn_part(wi, nb, stiles_y);
+    const uint32_t tile = part.tile;
     const uint32_t first = tile * TILE;
     KPROF(0, 2)
     for (int b = threadIdx.x; b < NG * ns; b += BN_THREADS) lmask[b] = 0ull;
@@ -288,7 +314,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
         const int grp = k * 4 + wave;
         const uint32_t i = first + (uint32_t)grp * 64u + (threadIdx.x & 63u);
         v[k] = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
-        bn_group_pairs(v[k], shift, sh, stiles_x,
+        bn_group_pairs(v[k], shift, sh, stiles_x, part.row_lo, part.row_hi,
                        [&](int L, uint2, uint32_t d, int, int) { if (d < (uint32_t)ns) atomicOr(&lmask[grp * ns + d], 1ull << L); });
     }
     __syncthreads();
@@ -303,7 +329,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {   // (B)
         const int grp = k * 4 + wave;
-        bn_group_pairs(v[k], shift, sh, stiles_x, [&](int L, uint2 vL, uint32_t d, int sx, int sy) {
+        bn_group_pairs(v[k], shift, sh, stiles_x, part.row_lo, part.row_hi, [&](int L, uint2 vL, uint32_t d, int sx, int sy) {
             if (d >= (uint32_t)ns) return;
             const uint32_t pos = gpre[grp * ns + d] + (uint32_t)__builtin_popcountll(lmask[grp * ns + d] & ((1ull << L) - 1ull));
             if (pos < cap) out[pos] = make_uint2(vL.x, bn_tile_mask(vL.y, sx, sy, shift));

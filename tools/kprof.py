@@ -24,7 +24,7 @@ for f in range(40):
             for i in range(1, 16):
                 if v[k, i] > 0 and v[k, i - 1] > 0: d[k, i] = (v[k, i] - v[k, i - 1]) / 100.0
         acc += d; cnt += 1
-labels = {0: ("k_bin_place", ["ranges (scan of the totals)", "n, tile", "zero the lane masks", "load splats + (A) masks", "(S) counts", "positions", "(B) place"]),
+labels = {0: ("k_bin_place", ["ranges (scan of the totals)", "n, tile", "zero the lane masks", "load splats + (A) masks", "-", "(S) group positions", "(B) place"]),
           1: ("k_bucket_scatter", ["n, zero LDS", "gather + LDS count", "reservations (global atomics)", "scatter"]),
           2: ("k_radix_local (bucket 512)", ["prefix of the bucket counts", "load keys", "LSD passes in LDS", "ties", "store"]),
           4: ("k_preprocess (the workgroup in the middle of the grid, first iteration)", ["prologue: prefix of the cluster counts", "find cluster + geoA/geoB arrive", "front + back (chain, horizons, colour, record)", "compaction + key/payload store"])}
@@ -45,4 +45,7 @@ for k, nm in ((4, "k_preprocess"), (1, "k_bucket_scatter"), (2, "k_radix_local")
     if not live.any(): continue
     print("%-17s last frame: %4d workgroups with items; items median %4d p90 %4d max %4d; workgroup time median %5.1f p90 %5.1f max %5.1f us (%d items)" % (
         nm, int(live.sum()), *np.quantile(items[live], [0.5, 0.9, 1.0]).astype(int), *np.quantile(dur[live], [0.5, 0.9, 1.0]), int(items[np.argmax(np.where(live, dur, 0))])))
+    if k in (0, 3):   # which blocks are the slow ones?  (blocks are in depth order: index 0 = the nearest 1024 splats)
+        idx = np.argsort(-np.where(live, dur, 0))[:8]
+        print("      slowest workgroups (index: us): " + ", ".join("%d: %.1f" % (int(i), float(dur[i])) for i in idx) + "; sum over workgroups %.0f us" % float(dur[live].sum()))
 print({k: eng.stats()[k] for k in ("frames_culled", "frames_repaired", "n_visible", "pairs_total")})

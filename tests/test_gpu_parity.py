@@ -108,6 +108,8 @@ def test_radix_sort_pairs(pkg, engine, n, bits):
 
 @pytest.mark.parametrize("n,w,h,frame,big,shard,layout", [
     (30000, 400, 300, 0, 0, (0, 1), 0),
+    (150000, 1920, 1080, -7, 0, (0, 1), 0),      # frame < 0: the camera INSIDE the cloud -- the nearest splats (the first blocks of the depth
+    (150000, 1920, 1080, -8, 0, (2, 4), 1),      #   order) fill the screen: those blocks are binned by one workgroup per ROW of super-tiles
     (20000, 1280, 720, 1, 3000, (0, 1), 0),      # 240 super-tiles, thousands of splats covering dozens of them each
     (20000, 4096, 4096, 2, 500, (0, 1), 0),      # the maximum: 256 super-tiles of 16x16 tiles
     (25000, 640, 480, 3, 1500, (1, 3), 0),       # row shard: a super-tile lists a splat only through an OWNED tile row
@@ -122,7 +124,7 @@ def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine, n,
     if big:
         sc = pkg.scenes.f16bits(np.random.default_rng(frame).uniform(0.5, 4.0, size=(big, 3)))
         splats.scale[:big] = sc
-    cam = pkg.camera.make_camera(w, h, sh_order=0, frame=frame)
+    cam = pkg.camera.make_camera(w, h, sh_order=0, frame=frame) if frame >= 0 else pkg.camera.make_camera(w, h, sh_order=0, frame=-frame, distance=0.35)
     engine.upload(splats)
     engine.set_option(pkg.engine.OPT_SHARD_LAYOUT, layout)
     engine.set_row_shard(*shard)
@@ -165,9 +167,12 @@ def test_super_tile_lists_are_depth_ordered_and_complete(pkg, oracle, engine, n,
         hit = ok & (tx1 >= X0) & (tx0 <= X1) & some_owned
         assert set(lst.tolist()) == set(vis[hit].tolist()), f"super-tile {t}: membership differs"
     assert seen == pv.shape[0]
-    if big:
+    if big or frame < 0:
         cover = ((tx1 // S - tx0 // S + 1) * (ty1 // S - ty0 // S + 1))[ok]
         assert (cover > 8).sum() > 50       # the cooperative big-splat path was exercised
+    if frame < 0:
+        cov_near = cover[np.argsort(rank[vis[ok]])[:256]]          # the 256 nearest splats that draw are big on screen: dozens of super-tiles each
+        assert np.median(cov_near) > 8 and cov_near.max() > 0.5 * ls.shape[0], (np.median(cov_near), cov_near.max())
 
 
 @pytest.mark.parametrize("w,h,n,big", [

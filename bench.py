@@ -740,7 +740,8 @@ def main():
         if pkg.scenes.CONFIGS[args.config].get("kind") == "terrain":
             jcams = [pkg.engine.camera_struct(pkg.scenes.terrain_camera(pkg.camera, W, H, frame=orbit_frame(i, 1), sh_order=order, distance=4.2 * (1.3 if i % 2 else 1.0))) for i in range(k3 + 6)]
         else:
-            jcams = [pkg.engine.camera_struct(pkg.camera.make_camera(W, H, sh_order=order, frame=orbit_frame(i, 1), distance=base_d * (1.3 if i % 2 else 1.0))) for i in range(k3 + 6)]
+            jcams = [pkg.engine.camera_struct(pkg.camera.make_camera(W, H, sh_order=order, frame=orbit_frame(i, 1), distance=base_d * (1.3 if i % 2 else 1.0),
+                                                                         pivot=pkg.scenes.CONFIGS[args.config].get("pivot", (0.0, 0.0, 0.0)))) for i in range(k3 + 6)]
         cold = {}
         for name, mode in (("policy", args.cull), ("intra_frame_only", 3), ("one_pass", 0)):
             eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, mode)

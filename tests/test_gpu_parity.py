@@ -715,7 +715,6 @@ def test_wire_over_keeps_the_beauty_frame(pkg, oracle, engine):
     """Wire-over display (the reference draws the outlines and still includes the primitive in the splat pass,
     src/GR_GSplat.C:471-486): gsr_render_wire_over writes the pixels an outline covers and leaves the beauty frame
     everywhere else -- host target and device target alike"""
-    import torch
     d, s, c = load_golden("w1_wire")
     engine.upload(s)
     beauty = engine.render(c)
@@ -725,10 +724,13 @@ def test_wire_over_keeps_the_beauty_frame(pkg, oracle, engine):
     assert covered.any() and (~covered).any()
     assert np.array_equal(both[covered], wire[covered])
     assert np.array_equal(both[~covered], beauty[~covered])
-    t = torch.from_numpy(beauty.copy()).cuda()
-    engine.render_wire_over_device(c, t.data_ptr())
-    torch.cuda.synchronize()
-    assert np.array_equal(t.cpu().numpy(), both)
+    hb = HipBuffers()                        # (a device target: raw hipMalloc, not torch -- torch's own HIP runtime does not come up behind ours)
+    try:
+        ptr = hb.upload(beauty)
+        engine.render_wire_over_device(c, ptr)
+        assert np.array_equal(hb.download(ptr, beauty.shape), both)
+    finally:
+        hb.free()
 
 
 def test_wire_overlay_after_a_failed_upload_uses_the_new_cloud(pkg, oracle):
@@ -1639,6 +1641,32 @@ def test_bench_one_rank_through_the_multi_gpu_door_matches_the_single_context(pk
     gl = line["gather_links"]
     assert gl["bytes_per_peer"] == [line["config"]["width"] * 16 * sum(min(16, line["config"]["height"] - r * 16) for r in range(23, 45))]
     assert gl["GBps_per_link"] > 0 and gl["GBps_assumed_per_link"] == 153.0 and len(line["per_rank_ms_per_step"]) == 2
+
+
+def test_bench_takes_an_inria_ply(pkg, oracle, tmp_path):
+    """`bench.py --ply PATH`: an INRIA 3DGS capture file (what the reference's example scene imports) goes through ply.py's
+    activations and gets the whole line -- frame rate, roofline, CPU baseline, the last timed frame checked bit for bit -- on an orbit
+    fitted to the cloud; and that frame is the oracle's frame of the same splats and camera."""
+    v = pkg.scenes.make_inria_raw(60000, seed=9, radius=0.8)
+    v["x"] += 5.0; v["z"] -= 2.0                                   # (somewhere else than the origin: the orbit has to find it)
+    path = str(tmp_path / "capture.ply")
+    pkg.scenes.write_inria_ply(path, v)
+    res, line = _run_bench(["--ply", path, "--steps", "30", "--warmup", "5", "--cpu-seconds", "4", "--no-other-configs"], {})
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert line["value"] > 0 and line["timed_frame_bit_identical"] is True and line["data"].startswith("INRIA PLY")
+    assert line["config"]["workload"].startswith("PLY capture.ply: 60000 splats") and line["config"]["n_splats"] == 60000
+    assert line["n_visible"] > 30000 and line["cpu_baseline"]["value"] > 0 and line["roofline"]["pairs_consumed_per_launch"] > 0
+    name = pkg.scenes.register_ply_config(path, pkg.ply, name="PLY_T")
+    try:
+        splats, cfg = pkg.scenes.make_config(name)
+        cam = pkg.scenes.config_camera(name, pkg.camera, 480, 270, 3, 3)
+        with pkg.Engine(0) as eng:
+            eng.upload(splats)
+            img = eng.render(cam)
+        ref = oracle.render(splats, cam)
+        assert np.abs(img - ref).max() <= 1e-3 and (ref[..., 3] > 0.5).mean() > 0.05
+    finally:
+        pkg.scenes.CONFIGS.pop("PLY_T", None)
 
 
 def test_bench_single_gpu_line_says_whether_the_timed_frame_is_the_full_frame(pkg):

@@ -265,6 +265,7 @@ struct gsr_context {
     uint32_t* blk_pre = nullptr;       // exclusive prefix of K1's per-iteration counts (k_scan_counts)
     size_t blk_pre_cap = 0;
     int opt_order_keep = 32;           // (A/B hook, GSR_ORDER_KEEP in the environment: 0 = no tile order where the tiles are alike)
+    int opt_mid_sort = 1;              // (A/B hook, GSR_MID_SORT) RS_ITEMS_MID keys per thread in the global sort passes of mid-size frames
     int opt_k1_scatter = 1;            // (A/B hook, GSR_K1_SCATTER) the small-frame sort's bucket pass inside K1 (0: a kernel of its own behind it)
     int opt_scatter_direct = 1;        // (A/B hook, GSR_SCATTER_DIRECT in the environment) the small-frame sort's scatter: one workgroup per K1 block
     int opt_bn_items = 0;              // (A/B hook, GSR_BN_ITEMS in the environment: 1, 2 or 4 splats per binning thread; 0 = by frame size)
@@ -476,6 +477,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
     if (const char* e = std::getenv("GSR_ORDER_KEEP")) c->opt_order_keep = std::atoi(e);   // (A/B hook)
     if (const char* e = std::getenv("GSR_SCATTER_DIRECT")) c->opt_scatter_direct = std::atoi(e);   // (A/B hook: -1 the general scatter, 0 never direct, 1 direct by frame size, 2 always direct)
     if (const char* e = std::getenv("GSR_K1_SCATTER")) c->opt_k1_scatter = std::atoi(e);   // (A/B hook)
+    if (const char* e = std::getenv("GSR_MID_SORT")) c->opt_mid_sort = std::atoi(e);       // (A/B hook)
     if (const char* e = std::getenv("GSR_SLAB_FRAC")) { const int v = std::atoi(e); if (v >= 1 && v <= 255) c->slab_frac = v; }   // (A/B hook)
     if (const char* e = std::getenv("GSR_SLAB_MIN")) { const int v = std::atoi(e); if (v >= 1) c->slab_min = v; }                 // (A/B hook)
     if (const char* e = std::getenv("GSR_SLAB_MAX")) { const int v = std::atoi(e); if (v >= 1) c->slab_max = v; }                 // (A/B hook)
@@ -914,15 +916,15 @@ static int ensure_u32(uint32_t** p, size_t* cap, size_t need)
     return GSR_OK;
 }
 
-template <typename V, int DBITS, bool GATHER, bool CLAMP = false>
+template <typename V, int DBITS, bool GATHER, int ITEMS>
 static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, uint32_t n, const uint32_t* n_dev,
                       int shift, uint32_t nblk, bool contig, uint32_t* n_out = nullptr, const uint32_t* src_cnt = nullptr, uint32_t lo = 0u)
 {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS, GATHER, CLAMP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, n,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<DBITS, GATHER, false, ITEMS>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA, n,
                        n_dev, shift, sl.hist, nblk, contig, src_cnt, lo);
     hipLaunchKernelGGL(k_scan_rows, dim3(1u << DBITS), dim3(SC_THREADS), 0, sl.stream, sl.hist, nblk, sl.totals, n_dev, n,
-                       (uint32_t)RS_TILE);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS, GATHER, CLAMP>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA,
+                       (uint32_t)RS_THREADS * (uint32_t)ITEMS);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<V, DBITS, GATHER, false, ITEMS>), dim3(nblk), dim3(RS_THREADS), 0, sl.stream, kA,
                        vA, kB, vB, n, n_dev, shift, sl.hist, sl.totals, nblk, contig, n_out, src_cnt, lo);
     HIP_TRY(hipGetLastError());
     return GSR_OK;
@@ -936,14 +938,15 @@ static int radix_pass(FrameSlot& sl, uint32_t* kA, V* vA, uint32_t* kB, V* vB, u
 template <typename V>
 static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& vB, uint32_t n, int bits,
                       bool allow9 = true, uint32_t* compact_to = nullptr, bool contig = false, const uint32_t* src_cnt = nullptr,
-                      const uint32_t* src_n_dev = nullptr /* compacting pass: the number of source SLOTS, on the device (<= n) */)
+                      const uint32_t* src_n_dev = nullptr /* compacting pass: the number of source SLOTS, on the device (<= n) */,
+                      bool mid = false /* a frame expected to keep <= ~1.5 M keys: RS_ITEMS_MID keys per thread (shorter workgroups, more of them) */)
 {
     if (n == 0) {
         if (compact_to) HIP_TRY(hipMemsetAsync(compact_to, 0, 4, sl.stream));
         return GSR_OK;
     }
     if (bits <= 0) bits = 1;
-    const uint32_t nblk = div_up(n, RS_TILE);
+    const uint32_t nblk = div_up(n, (uint32_t)RS_THREADS * (uint32_t)(mid ? RS_ITEMS_MID : RS_ITEMS));
     int rc = ensure_u32(&sl.hist, &sl.hist_cap, (size_t)512 * nblk + 8);
     if (rc) return rc;
     const int p8 = (bits + 7) / 8, p9 = (bits + 8) / 9;
@@ -952,12 +955,11 @@ static int radix_sort(FrameSlot& sl, uint32_t*& kA, V*& vA, uint32_t*& kB, V*& v
     for (int p = 0; p < passes; ++p) {
         const bool skip = compact_to && p == 0;
         const uint32_t* n_dev = compact_to ? (p > 0 ? compact_to : src_n_dev) : nullptr;
-        if (use9)
-            rc = skip ? radix_pass<V, 9, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig, compact_to, src_cnt)
-                      : radix_pass<V, 9, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig);
-        else
-            rc = skip ? radix_pass<V, 8, true>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig, compact_to, src_cnt)
-                      : radix_pass<V, 8, false>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig);
+#define GSR_PASS(W, I) (skip ? radix_pass<V, W, true, I>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig, compact_to, src_cnt) \
+                             : radix_pass<V, W, false, I>(sl, kA, vA, kB, vB, n, n_dev, p * width, nblk, contig))
+        if (use9) rc = mid ? GSR_PASS(9, RS_ITEMS_MID) : GSR_PASS(9, RS_ITEMS);
+        else rc = mid ? GSR_PASS(8, RS_ITEMS_MID) : GSR_PASS(8, RS_ITEMS);
+#undef GSR_PASS
         if (rc) return rc;
         uint32_t* t = kA; kA = kB; kB = t;
         V* tv = vA; vA = vB; vB = tv;
@@ -2020,8 +2022,10 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
                                sl.bkt_key, sl.bkt_val, sl.keyA, sl.valA, sl.d_counts + 2, sl.d_n);
             if (hipGetLastError() != hipSuccess) rc = set_err(GSR_E_HIP, "small-frame sort: launch failed");
         } else {
+            // (keys per thread: by what the slot's previous frame kept -- any choice sorts correctly)
+            const bool mid = c->opt_mid_sort && sl.kept_hint > 0 && sl.kept_hint <= 1500000u && n_slots <= 4000000u;
             rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n_slots, key_bits,
-                            !(c->opt_flags & GSR_FLAG_FULL_KEYS), sl.d_n, RS_XCD_DEPTH != 0, sl.blk_cnt, sl.d_counts);
+                            !(c->opt_flags & GSR_FLAG_FULL_KEYS), sl.d_n, RS_XCD_DEPTH != 0, sl.blk_cnt, sl.d_counts, mid);
         }
         if (rc) return frame_abort(sl, rc);
         sl.key_min = f.key_min;

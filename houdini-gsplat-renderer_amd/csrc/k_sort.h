@@ -21,6 +21,9 @@
 #define RS_ITEMS 12      // measured on C4 with XCD-contiguous tiles: 16 -> 0.205 ms, 12 -> 0.174, 8 -> 0.185, 4 -> 0.22
 #endif
 static_assert(RS_ITEMS % 4 == 0, "k_radix_hist reads uint4");
+#ifndef RS_ITEMS_MID
+#define RS_ITEMS_MID 4    // ... and for mid-size frames (k_radix_hist / k_radix_scatter's ITEMS)
+#endif
 #define RS_TILE (RS_THREADS * RS_ITEMS)  // items per workgroup
 #define RS_WAVE_ITEMS (RS_TILE / 4)      // items per wave
 #ifndef RS_XCD_DEPTH
@@ -93,23 +96,25 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_
 #define RS_WAVE_BLOCKS (RS_WAVE_ITEMS / RS_SRC_BLOCK)
 static_assert(RS_WAVE_ITEMS % RS_SRC_BLOCK == 0, "a wave's share of a tile is whole K1 blocks");
 // the wave's blocks' counts -> total; rs_gather_slot: q-th valid item of the wave -> its slot
+template <int NB>
 __device__ __forceinline__ uint32_t rs_gather_counts(const uint32_t* __restrict__ src_cnt, uint32_t first_block, uint32_t n_src_blocks,
-                                                      uint32_t (&c)[RS_WAVE_BLOCKS])
+                                                      uint32_t (&c)[NB])
 {
     uint32_t tot = 0;
 #pragma unroll
-    for (int j = 0; j < RS_WAVE_BLOCKS; ++j) {
+    for (int j = 0; j < NB; ++j) {
         const uint32_t gb = first_block + (uint32_t)j;
         c[j] = gb < n_src_blocks ? src_cnt[gb] : 0u;
         tot += c[j];
     }
     return tot;
 }
-__device__ __forceinline__ uint32_t rs_gather_slot(uint32_t q, uint32_t first_block, const uint32_t (&c)[RS_WAVE_BLOCKS])
+template <int NB>
+__device__ __forceinline__ uint32_t rs_gather_slot(uint32_t q, uint32_t first_block, const uint32_t (&c)[NB])
 {
     uint32_t j = 0, before = 0;
 #pragma unroll
-    for (int t = 0; t < RS_WAVE_BLOCKS - 1; ++t)
+    for (int t = 0; t < NB - 1; ++t)
         if (q >= before + c[t] && j == (uint32_t)t) { before += c[t]; j = (uint32_t)t + 1u; }
     return (first_block + j) * (uint32_t)RS_SRC_BLOCK + (q - before);
 }
@@ -125,32 +130,37 @@ __device__ __forceinline__ uint32_t rs_digit(uint32_t key, int shift, uint32_t l
     return t < mask ? t : mask;
 }
 
-template <int DBITS, bool GATHER, bool CLAMP = false>
+// ITEMS = keys per thread: RS_ITEMS (12) for the frames that keep millions, RS_ITEMS_MID (4) for the ones between the small-frame sort
+// and ~1.5 M keys, where a pass is bound by how long ONE workgroup takes (C3 --cull 0: +5 %, S1 +1.4 %, nothing at 4 M keys: LAB_NOTES round 5)
+template <int DBITS, bool GATHER, bool CLAMP = false, int ITEMS = RS_ITEMS>
 __global__ void __launch_bounds__(RS_THREADS)
 k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n_host, const uint32_t* __restrict__ n_dev, int shift,
              uint32_t* __restrict__ hist, uint32_t nblk, bool contig, const uint32_t* __restrict__ src_cnt, uint32_t lo = 0u)
 {
     constexpr int BINS = 1 << DBITS;
     constexpr uint32_t MASK = BINS - 1;
+    constexpr uint32_t TILE = RS_THREADS * ITEMS, WAVE_ITEMS = TILE / 4;
+    constexpr int WAVE_BLOCKS = WAVE_ITEMS / RS_SRC_BLOCK;
+    static_assert(ITEMS % 4 == 0 && WAVE_ITEMS % RS_SRC_BLOCK == 0, "uint4 reads; a wave's share of a tile is whole K1 blocks");
     __shared__ uint32_t h[4][BINS];
     const int wave = threadIdx.x >> 6;
     const uint32_t n = n_dev ? *n_dev : n_host;
-    const uint32_t nb = (n + RS_TILE - 1) / RS_TILE;   // tiles that exist (<= nblk, the grid's upper bound)
+    const uint32_t nb = (n + TILE - 1) / TILE;   // tiles that exist (<= nblk, the grid's upper bound)
     if (blockIdx.x >= nb) return;                       // surplus workgroup: k_scan_rows only reads the tiles that exist
     for (int b = threadIdx.x; b < 4 * BINS; b += RS_THREADS) (&h[0][0])[b] = 0;
     __syncthreads();
     const uint32_t tile = rs_tile_of_block(blockIdx.x, nb, contig);
-    const uint32_t base = tile * RS_TILE;
+    const uint32_t base = tile * TILE;
     if (GATHER) {
-        const uint32_t first_block = (base + (uint32_t)wave * RS_WAVE_ITEMS) / RS_SRC_BLOCK;
-        uint32_t c[RS_WAVE_BLOCKS];
+        const uint32_t first_block = (base + (uint32_t)wave * WAVE_ITEMS) / RS_SRC_BLOCK;
+        uint32_t c[WAVE_BLOCKS];
         const uint32_t tot = rs_gather_counts(src_cnt, first_block, (n + RS_SRC_BLOCK - 1) / RS_SRC_BLOCK, c);
         for (uint32_t q = threadIdx.x & 63u; q < tot; q += 64u)
             atomicAdd(&h[wave][rs_digit<CLAMP>(keys[rs_gather_slot(q, first_block, c)], shift, lo, MASK)], 1u);
-    } else if (base + RS_TILE <= n) {
+    } else if (base + TILE <= n) {
         const uint4* p = reinterpret_cast<const uint4*>(keys + base);
 #pragma unroll
-        for (int k = 0; k < RS_ITEMS / 4; ++k) {
+        for (int k = 0; k < ITEMS / 4; ++k) {
             uint4 v = p[k * RS_THREADS + threadIdx.x];
             atomicAdd(&h[wave][rs_digit<CLAMP>(v.x, shift, lo, MASK)], 1u);
             atomicAdd(&h[wave][rs_digit<CLAMP>(v.y, shift, lo, MASK)], 1u);
@@ -158,7 +168,7 @@ k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n_host, const uint32_t*
             atomicAdd(&h[wave][rs_digit<CLAMP>(v.w, shift, lo, MASK)], 1u);
         }
     } else {
-        for (int k = 0; k < RS_ITEMS; ++k) {
+        for (int k = 0; k < ITEMS; ++k) {
             uint32_t i = base + k * RS_THREADS + threadIdx.x;
             if (i < n) atomicAdd(&h[wave][rs_digit<CLAMP>(keys[i], shift, lo, MASK)], 1u);
         }
@@ -201,7 +211,7 @@ k_scan_rows(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ t
 // V = payload type: uint32_t (4 B) or uint2 (8 B: splat index + packed tile rect).
 // Item order inside a workgroup: wave w owns items [w*RS_WAVE_ITEMS, (w+1)*RS_WAVE_ITEMS) of the
 // tile, round k covers 64 consecutive items -> (wave, round, lane) is input order.
-template <typename V, int DBITS, bool GATHER, bool CLAMP = false>
+template <typename V, int DBITS, bool GATHER, bool CLAMP = false, int ITEMS = RS_ITEMS>
 __global__ void __launch_bounds__(RS_THREADS)
 k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in,
                 uint32_t* __restrict__ keys_out, V* __restrict__ vals_out, uint32_t n_host,
@@ -212,21 +222,23 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
 {
     constexpr int BINS = 1 << DBITS;
     constexpr uint32_t MASK = BINS - 1;
+    constexpr uint32_t TILE = RS_THREADS * ITEMS, WAVE_ITEMS = TILE / 4;
+    constexpr int WAVE_BLOCKS = WAVE_ITEMS / RS_SRC_BLOCK;
     constexpr int PER = BINS / RS_THREADS;   // digits per thread in the bookkeeping step (1 or 2)
     __shared__ uint32_t wc[4][BINS];    // per-wave digit counters -> per-wave bases
     __shared__ uint32_t dbase[BINS];    // first local sorted position of each digit
     __shared__ uint32_t gadj[BINS];     // global position of the digit run minus dbase
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t skeys[RS_TILE];
-    __shared__ V svals[RS_TILE];
+    __shared__ uint32_t skeys[TILE];
+    __shared__ V svals[TILE];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = n_dev ? *n_dev : n_host;
-    const uint32_t nb = (n + RS_TILE - 1) / RS_TILE;
+    const uint32_t nb = (n + TILE - 1) / TILE;
     if (blockIdx.x >= nb) return;   // surplus workgroup of an upper-bound grid
     const uint32_t tile = rs_tile_of_block(blockIdx.x, nb, contig);
-    const uint32_t tile_base = tile * RS_TILE;
-    const uint32_t nvalid = (n - tile_base < RS_TILE) ? (n - tile_base) : RS_TILE;
+    const uint32_t tile_base = tile * TILE;
+    const uint32_t nvalid = (n - tile_base < TILE) ? (n - tile_base) : TILE;
     for (int b = threadIdx.x; b < 4 * BINS; b += RS_THREADS) (&wc[0][0])[b] = 0;
     // digit bases: exclusive scan of the per-digit totals (thread t owns digits t*PER .. t*PER+PER-1)
     {
@@ -241,16 +253,16 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
     }
     __syncthreads();
 
-    uint32_t k_[RS_ITEMS], meta[RS_ITEMS];  // meta = digit | rank_in_wave_digit << DBITS, 0xffffffff = no item
+    uint32_t k_[ITEMS], meta[ITEMS];  // meta = digit | rank_in_wave_digit << DBITS, 0xffffffff = no item
     __shared__ uint32_t s_tile_items;
-    V v_[RS_ITEMS];
+    V v_[ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t gc[RS_WAVE_BLOCKS];
-    const uint32_t g_first = (tile_base + (uint32_t)wave * RS_WAVE_ITEMS) / RS_SRC_BLOCK;
+    uint32_t gc[WAVE_BLOCKS];
+    const uint32_t g_first = (tile_base + (uint32_t)wave * WAVE_ITEMS) / RS_SRC_BLOCK;
     const uint32_t g_tot = GATHER ? rs_gather_counts(src_cnt, g_first, (n + RS_SRC_BLOCK - 1) / RS_SRC_BLOCK, gc) : 0u;
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
-        const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;
+    for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t li = wave * WAVE_ITEMS + r * 64 + lane;
         bool valid = li < nvalid;
         uint32_t key = 0xffffffffu;
         V val{};
@@ -313,7 +325,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         if (meta[r] == 0xffffffffu) continue;
         const uint32_t d = meta[r] & MASK;
         const uint32_t lp = dbase[d] + wc[wave][d] + (meta[r] >> DBITS);
@@ -323,7 +335,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals
     __syncthreads();
     const uint32_t tile_items = s_tile_items;
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const uint32_t j = r * RS_THREADS + threadIdx.x;
         if (j < tile_items) {
             const uint32_t key = skeys[j];

@@ -17,8 +17,9 @@
  * unmapped (or read through another stream) before R.render() returned could see the first attempt.  Keep the unmap
  * after postRender().
  *
- * NOT COMPILED IN THIS REPOSITORY (no HDK, no GL context on the build or test machines): the interop header is
- * syntax-checked only, and this path -- map, render to device pointers, unmap, textured draw -- has NEVER EXECUTED.
+ * NOT BUILT IN THIS REPOSITORY (no HDK, no GL stack on the build or test machines: profiles/egl_probe_mi355x.txt): this file is
+ * TYPE-CHECKED against stand-ins for the HDK classes it touches (tests/hdk_mock/, tests/test_hdk_glue.py), the interop header is
+ * syntax-checked, and this path -- map, render to device pointers, unmap, textured draw -- has NEVER EXECUTED.
  * Everything between map() and unmap() is what the repo's -m gpu tests run through target_is_device = 1.  Build: hdk/build.sh.
  */
 #include <DM/DM_RenderTable.h>

@@ -16,7 +16,8 @@
  *   :460-493  render(): enable, include, camera, order          GSplatPrim::render
  *   :63-70    destructor: flushEntriesForMatchingDetail          ~GSplatPrim
  *
- * NOT COMPILED IN THIS REPOSITORY (no HDK here: $HFS, hcustom, GA / GR / GT / RE headers).  Everything below the
+ * NOT BUILT IN THIS REPOSITORY (no HDK here: $HFS, hcustom, GA / GR / GT / RE headers); type-checked against stand-ins for the
+ * HDK classes it touches (tests/hdk_mock/, tests/test_hdk_glue.py).  Everything below the
  * GSplatPrim calls is exercised by the repo's tests through the same entry points (tests/test_host_shim.py,
  * tests/test_gpu_parity.py::test_ingest_*).  Build: hdk/build.sh.
  */

@@ -1,7 +1,8 @@
 #!/bin/sh
 # Builds the Houdini DSO of the GSplat plugin over libgsplat_hip.  Needs a Houdini installation: `source houdini_setup`
 # first (sets $HFS and puts hcustom on the PATH) -- this repository's build and test machines have none, so the files in
-# this directory have never been compiled; they are the glue a maintainer drops into the reference tree.
+# this directory have never been BUILT (they are type-checked against mock HDK headers: tests/test_hdk_glue.py); they are the glue
+# a maintainer drops into the reference tree.
 #   REF  = checkout of rubendhz/houdini-gsplat-renderer (its gsplat_plugin/ directory)
 #   REPO = this repository (include/, houdini-gsplat-renderer_amd/libgsplat_hip.so built by __graft_entry__.build())
 set -e

@@ -1951,9 +1951,10 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         // on a cache hit (identical frame description) the sorted (keyA, valA) are kept and K1's key/payload
         // output goes to the scratch buffers
         j.k1_grid = k1_grid;
-        hipLaunchKernelGGL(k_preprocess, dim3(k1_grid ? k1_grid : 1u), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
+        // (two instantiations: the one that leaves the colours pending has no SH evaluation in it and runs at 8 waves per SIMD instead of 6)
+        hipLaunchKernelGGL(j.lazy ? k_preprocess_lazy : k_preprocess, dim3(k1_grid ? k1_grid : 1u), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, (cache_hit || ordered) ? sl.keyB : sl.keyA, (cache_hit || ordered) ? sl.valB : sl.valA,
-                           j.d_depth ? sl.zwin : (float*)nullptr, j.lazy ? 1 : 0, j.phase == 2 ? sl.hpyr2 : (j.cull ? sl.hpyr : (const float*)nullptr), sl.blk_cnt,
+                           j.d_depth ? sl.zwin : (float*)nullptr, j.phase == 2 ? sl.hpyr2 : (j.cull ? sl.hpyr : (const float*)nullptr), sl.blk_cnt,
                            sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts, scat,
                            // (the count of sorted splats starts at zero: a frame whose clusters are ALL culled runs no sort workgroup that
                            //  could say so, and the binning kernels would walk the previous frame's order; a static redraw keeps its order)

@@ -485,11 +485,18 @@ struct GsrK1Scatter {
 #ifndef GSR_K1_WAVES_PER_EU
 #define GSR_K1_WAVES_PER_EU 6
 #endif
-__global__ void __launch_bounds__(GSR_K1_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_K1_WAVES_PER_EU)))
-k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
+// The LAZY instantiation (colours left pending: unculled frames of scenes with depth complexity) has no SH evaluation in it and needs
+// 52 VGPRs instead of 80: it runs at 8 waves per SIMD.  K1 is bound by resident workgroups x the ~10 us a workgroup lives (12.7
+// generations of 1536 workgroups x 10.4 us = the 133 us of an unculled C4 frame, tools/kprof.py), so occupancy is its lever.
+#ifndef GSR_K1_WAVES_PER_EU_LAZY
+#define GSR_K1_WAVES_PER_EU_LAZY 8
+#endif
+template <bool LAZY>
+__device__ __forceinline__ void
+gsr_k1_body(uint32_t n, uint32_t cap, const GsrFrame& f,
              const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col,
              GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint2* __restrict__ val,
-             float* __restrict__ zwin /* NULL unless the frame is depth-tested */, int lazy /* leave SH colours pending */,
+             float* __restrict__ zwin /* NULL unless the frame is depth-tested */,
              const float* __restrict__ hpyr /* depth-horizon pyramid, or NULL: no occlusion culling */,
              uint32_t* __restrict__ blk_cnt /* [workgroup-iterations] splats of each that stay */,
              const uint32_t* __restrict__ cseg, const uint32_t* __restrict__ ccnt, uint32_t ngroups, uint32_t cper /* k_cluster_cull's output */,
@@ -537,7 +544,7 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
                 if (k == blockIdx.x && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_kprof[4][2] = wall_clock64(); }
 #endif
                 const GsrK1Front o = gsr_k1_front(f, a, b, zwin ? zwin + i : nullptr, slab_key);
-                if (o.keep && !o.far) out_rect = gsr_k1_back(f, i, cap, o, b, col, rec, lazy, hpyr);
+                if (o.keep && !o.far) out_rect = gsr_k1_back(f, i, cap, o, b, col, rec, LAZY ? 1 : 0, hpyr);
                 kb = o.kb;
             }
         }
@@ -576,6 +583,17 @@ k_preprocess(uint32_t n, uint32_t cap, GsrFrame f,
     }
     KPROF_BLK_END(4, (blockIdx.x < niter ? 1u : 0u) + (niter > blockIdx.x ? (niter - 1u - blockIdx.x) / gridDim.x : 0u))
 }
+
+#define GSR_K1_PARAMS uint32_t n, uint32_t cap, GsrFrame f, const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col, \
+                      GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint2* __restrict__ val, float* __restrict__ zwin, const float* __restrict__ hpyr, \
+                      uint32_t* __restrict__ blk_cnt, const uint32_t* __restrict__ cseg, const uint32_t* __restrict__ ccnt, uint32_t ngroups, uint32_t cper, \
+                      uint32_t* __restrict__ d_counts, GsrK1Scatter sc, uint32_t* __restrict__ zero_n, const uint32_t* __restrict__ order, const uint32_t* __restrict__ slab
+#define GSR_K1_ARGS n, cap, f, geoA, geoB, col, rec, key, val, zwin, hpyr, blk_cnt, cseg, ccnt, ngroups, cper, d_counts, sc, zero_n, order, slab
+// the two entry points: colours evaluated here (eager: 80 VGPRs, 6 waves per SIMD) or left pending (52 VGPRs, 8 waves per SIMD)
+__global__ void __launch_bounds__(GSR_K1_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_K1_WAVES_PER_EU)))
+k_preprocess(GSR_K1_PARAMS) { gsr_k1_body<false>(GSR_K1_ARGS); }
+__global__ void __launch_bounds__(GSR_K1_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_K1_WAVES_PER_EU_LAZY)))
+k_preprocess_lazy(GSR_K1_PARAMS) { gsr_k1_body<true>(GSR_K1_ARGS); }
 
 // upload time: per-workgroup partial bounding boxes of the positions (finished on the host)
 __global__ void __launch_bounds__(256)

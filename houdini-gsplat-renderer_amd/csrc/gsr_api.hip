@@ -265,6 +265,7 @@ struct gsr_context {
     uint32_t* blk_pre = nullptr;       // exclusive prefix of K1's per-iteration counts (k_scan_counts)
     size_t blk_pre_cap = 0;
     int opt_order_keep = 32;           // (A/B hook, GSR_ORDER_KEEP in the environment: 0 = no tile order where the tiles are alike)
+    int opt_fuse_order = 1;            // (A/B hook, GSR_FUSE_ORDER) the tile order is built in the frame-end launch instead of behind it
     int opt_mid_sort = 1;              // (A/B hook, GSR_MID_SORT) RS_ITEMS_MID keys per thread in the global sort passes of mid-size frames
     int opt_k1_scatter = 1;            // (A/B hook, GSR_K1_SCATTER) the small-frame sort's bucket pass inside K1 (0: a kernel of its own behind it)
     int opt_scatter_direct = 1;        // (A/B hook, GSR_SCATTER_DIRECT in the environment) the small-frame sort's scatter: one workgroup per K1 block
@@ -478,6 +479,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
     if (const char* e = std::getenv("GSR_SCATTER_DIRECT")) c->opt_scatter_direct = std::atoi(e);   // (A/B hook: -1 the general scatter, 0 never direct, 1 direct by frame size, 2 always direct)
     if (const char* e = std::getenv("GSR_K1_SCATTER")) c->opt_k1_scatter = std::atoi(e);   // (A/B hook)
     if (const char* e = std::getenv("GSR_MID_SORT")) c->opt_mid_sort = std::atoi(e);       // (A/B hook)
+    if (const char* e = std::getenv("GSR_FUSE_ORDER")) c->opt_fuse_order = std::atoi(e);   // (A/B hook)
     if (const char* e = std::getenv("GSR_SLAB_FRAC")) { const int v = std::atoi(e); if (v >= 1 && v <= 255) c->slab_frac = v; }   // (A/B hook)
     if (const char* e = std::getenv("GSR_SLAB_MIN")) { const int v = std::atoi(e); if (v >= 1) c->slab_min = v; }                 // (A/B hook)
     if (const char* e = std::getenv("GSR_SLAB_MAX")) { const int v = std::atoi(e); if (v >= 1) c->slab_max = v; }                 // (A/B hook)
@@ -1351,22 +1353,6 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     const uint32_t* const redo_arg = j.lazy ? reinterpret_cast<const uint32_t*>(sl.lazy_ctr) : (const uint32_t*)nullptr;
     uint32_t* const work_next = sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr;
     sl.horizon_valid = hz.raw != nullptr;
-    if (sl.horizon_valid) {
-        // the frame's sums and verdict, and BESIDE them (one launch) the next frame's pyramid: every tile's horizon widened to its
-        // neighbourhood, into the slot's other pyramid buffer
-        sl.hpyr_re = std::min(c->cull_pol.dilate, GSR_DILATE_EXACT_MAX);
-        hipLaunchKernelGGL(k_frame_end, dim3((unsigned)nblocks8 + 1u), dim3(SW_THREADS), 0, s, sl.partial, nblocks8, g, sl.counters, sl.d_n, sl.d_frame,
-                           prefix_arg, redo_arg, sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint, work_next, hz, sl.st_scan, sl.hpyr_re);
-        HIP_TRY(hipGetLastError());
-        std::swap(sl.hpyr, sl.hpyr_next);      // (what the slot's next frame culls against)
-        const int sig[7] = {j.f.width, j.f.height, j.f.shard_index, j.f.shard_count, j.f.shard_rpb, j.f.super_shift, (int)c->geo_gen};
-        std::memcpy(sl.horizon_sig, sig, sizeof sig);
-        sl.horizon_cam = j.cam_arg;
-    } else {
-        hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.partial, nblocks8, g, sl.counters, sl.d_n, sl.d_frame,
-                           prefix_arg, redo_arg, sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint, work_next, hz, sl.st_scan);
-        HIP_TRY(hipGetLastError());
-    }
     // The heaviest-first table is rebuilt every frame where the tiles differ a lot (k_sum_work's verdict); where they do not it is
     // still worth a few microseconds of k_blend's tail (C4: 0.142 -> 0.139 ms), but not the 10 us of k_tile_order every frame:
     // then a table stands for GSR_ORDER_KEEP frames of the same shape.
@@ -1376,10 +1362,9 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
                             std::memcmp(osig, sl.order_sig, sizeof osig) == 0;
     const bool order_refresh = !order_due && !order_kept && c->opt_swizzle == 2 && c->opt_order_keep > 0 && c->n >= 1000000u;
     if (order_kept) sl.order_age += 1; else sl.order_valid = false;
-    if (j.use_map && (order_due || order_refresh) && j.local_tiles > 0 && j.n_super <= 256 &&
-        sl.sup_work) {
-        // the next frame's tile order
-        const int per_xcd = 2 * ((j.n_super + 15) / 16) << (2 * j.f.super_shift);
+    const bool order_now = j.use_map && (order_due || order_refresh) && j.local_tiles > 0 && j.n_super <= 256 && sl.sup_work;
+    const int per_xcd = 2 * ((j.n_super + 15) / 16) << (2 * j.f.super_shift);
+    if (order_now) {
         const size_t want = (size_t)8 * per_xcd;
         if (want > sl.order_cap) {
             HIP_TRY(hipStreamSynchronize(s));
@@ -1389,11 +1374,40 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
             if (rc) return rc;
             sl.order_cap = want;
         }
-        hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(TO_THREADS), 0, s, sl.tile_work, g, j.f.tiles_y, sl.sup_work + 256 * sl.sup_par,
-                           per_xcd, sl.order);
+    }
+    // the next frame's tile order is built BESIDE the frame's sums (and the horizon dilation), in the same launch (k_blend.h: k_frame_end_order)
+    const bool fused_order = order_now && c->opt_fuse_order != 0;
+    if (sl.horizon_valid) sl.hpyr_re = std::min(c->cull_pol.dilate, GSR_DILATE_EXACT_MAX);
+    if (fused_order) {
+        const GsrOrderArgs oa{sl.tile_work, j.f.tiles_y, sl.sup_work + 256 * sl.sup_par, per_xcd, sl.order};
+        const int ndil = sl.horizon_valid ? nblocks8 : 0;
+        hipLaunchKernelGGL(k_frame_end_order, dim3(9u + (unsigned)ndil), dim3(TO_THREADS), 0, s, sl.partial, nblocks8, ndil, g, sl.counters, sl.d_n, sl.d_frame,
+                           prefix_arg, redo_arg, sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint, work_next, hz, sl.st_scan, sl.hpyr_re, oa);
         HIP_TRY(hipGetLastError());
-        const int sig[6] = {j.f.width, j.f.height, j.f.shard_index, j.f.shard_count, j.f.shard_rpb, j.f.super_shift};
-        std::memcpy(sl.order_sig, sig, sizeof sig);
+    } else if (sl.horizon_valid) {
+        // the frame's sums and verdict, and BESIDE them (one launch) the next frame's pyramid: every tile's horizon widened to its
+        // neighbourhood, into the slot's other pyramid buffer
+        hipLaunchKernelGGL(k_frame_end, dim3((unsigned)nblocks8 + 1u), dim3(SW_THREADS), 0, s, sl.partial, nblocks8, g, sl.counters, sl.d_n, sl.d_frame,
+                           prefix_arg, redo_arg, sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint, work_next, hz, sl.st_scan, sl.hpyr_re);
+        HIP_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_sum_work, dim3(1), dim3(SW_THREADS), 0, s, sl.partial, nblocks8, g, sl.counters, sl.d_n, sl.d_frame,
+                           prefix_arg, redo_arg, sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint, work_next, hz, sl.st_scan);
+        HIP_TRY(hipGetLastError());
+    }
+    if (sl.horizon_valid) {
+        std::swap(sl.hpyr, sl.hpyr_next);      // (what the slot's next frame culls against)
+        const int sig[7] = {j.f.width, j.f.height, j.f.shard_index, j.f.shard_count, j.f.shard_rpb, j.f.super_shift, (int)c->geo_gen};
+        std::memcpy(sl.horizon_sig, sig, sizeof sig);
+        sl.horizon_cam = j.cam_arg;
+    }
+    if (order_now) {
+        if (!fused_order) {
+            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(TO_THREADS), 0, s, sl.tile_work, g, j.f.tiles_y, sl.sup_work + 256 * sl.sup_par,
+                               per_xcd, sl.order);
+            HIP_TRY(hipGetLastError());
+        }
+        std::memcpy(sl.order_sig, osig, sizeof osig);
         sl.order_per_xcd = per_xcd;
         sl.order_valid = true;
         sl.order_age = 0;

@@ -841,12 +841,12 @@ k_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g
 // raw = per-tile horizons (k_tile_pass); pyr = the pyramid the slot's next frame culls against: level 0 = every tile's horizon
 // widened to the largest of its (2r+1)^2 neighbourhood, levels 1..3 from wave shuffles (lane = tile in Morton order).
 __device__ __forceinline__ void
-gsr_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int r, const GsrHorizonArgs& hz, float* __restrict__ pyr)
+gsr_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int r, const GsrHorizonArgs& hz, float* __restrict__ pyr, const int b)
 {
     const int lane = threadIdx.x;
     const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
     const int nbx = (tiles_x + 7) >> 3;
-    const int b = (int)blockIdx.x, by = b / nbx, bx = b - by * nbx;
+    const int by = b / nbx, bx = b - by * nbx;
     const int tx = bx * 8 + lx, ty = by * 8 + ly;
     const bool inside = tx < tiles_x && ty < tiles_y;
     float v = 0.0f;
@@ -872,7 +872,7 @@ gsr_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int 
 __global__ void __launch_bounds__(64)
 k_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int r, GsrHorizonArgs hz, float* __restrict__ pyr)
 {
-    gsr_horizon_dilate(raw, tiles_x, tiles_y, r, hz, pyr);
+    gsr_horizon_dilate(raw, tiles_x, tiles_y, r, hz, pyr, (int)blockIdx.x);
 }
 
 // The end of a frame that leaves horizons, in ONE launch: workgroups 0 .. nblocks - 1 (their first wavefront) dilate the per-tile
@@ -892,7 +892,7 @@ k_frame_end(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs 
         return;
     }
     if (threadIdx.x >= 64) return;
-    gsr_horizon_dilate(hz.raw, g.tiles_x, g.tiles_y, dilate_r, hz, hz.pyr_out);
+    gsr_horizon_dilate(hz.raw, g.tiles_x, g.tiles_y, dilate_r, hz, hz.pyr_out, (int)blockIdx.x);
 }
 
 // Heaviest tiles first.  The blend kernel's workgroups are dispatched in blockIdx order as slots free up; when a frame's tiles
@@ -907,16 +907,15 @@ k_frame_end(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs 
 // period of 16 gives every XCD two super-tiles).
 #define TO_THREADS 1024
 #define TO_LEVELS 128
-__global__ void __launch_bounds__(TO_THREADS)
-k_tile_order(const uint4* __restrict__ tile_work, GsrSumArgs g, int tiles_y, const uint32_t* __restrict__ sup_work, int cap,
-             int32_t* __restrict__ order)
+__device__ __forceinline__ void
+gsr_tile_order(const uint4* __restrict__ tile_work, const GsrSumArgs& g, int tiles_y, const uint32_t* __restrict__ sup_work, int cap,
+               int32_t* __restrict__ order, const int xcd)
 {
     __shared__ uint32_t s_sup[256];
     __shared__ uint32_t s_own[64];             // this XCD's super-tiles
     __shared__ uint32_t s_hist[TO_LEVELS];
     __shared__ uint32_t s_nown, s_wmax;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int xcd = blockIdx.x;
     if (tid < 256) s_sup[tid] = tid < g.n_super ? sup_work[tid] : 0u;
     if (tid < TO_LEVELS) s_hist[tid] = 0u;
     if (tid == 0) { s_nown = 0u; s_wmax = 0u; }
@@ -951,9 +950,18 @@ k_tile_order(const uint4* __restrict__ tile_work, GsrSumArgs g, int tiles_y, con
         w = gsr_tile_weight(tile_work[i]);
         return i;
     };
+    // (a thread's first TO_CACHE items stay in registers for the three passes: each pass used to fetch the tiles' bookkeeping again --
+    //  three dependent trips to memory in a kernel that is nothing but its one workgroup's latency: 11.4 us of C3's 197 us frame)
+    constexpr int TO_CACHE = 5;
+    int ci[TO_CACHE];
+    uint32_t cw[TO_CACHE];
+#pragma unroll
+    for (int k = 0; k < TO_CACHE; ++k) { const int it = tid + k * TO_THREADS; ci[k] = -1; cw[k] = 0u; if (it < items) ci[k] = tile_of(it, cw[k]); }
     {
         uint32_t wmax = 0;
-        for (int it = tid; it < items; it += TO_THREADS) { uint32_t w; (void)tile_of(it, w); wmax = w > wmax ? w : wmax; }
+#pragma unroll
+        for (int k = 0; k < TO_CACHE; ++k) wmax = cw[k] > wmax ? cw[k] : wmax;
+        for (int it = tid + TO_CACHE * TO_THREADS; it < items; it += TO_THREADS) { uint32_t w; (void)tile_of(it, w); wmax = w > wmax ? w : wmax; }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(wmax, d, 64); wmax = o > wmax ? o : wmax; }
         if (lane == 0 && wmax) atomicMax(&s_wmax, wmax);
@@ -962,7 +970,9 @@ k_tile_order(const uint4* __restrict__ tile_work, GsrSumArgs g, int tiles_y, con
     const float scale = s_wmax ? (float)(TO_LEVELS - 2) / (float)s_wmax : 0.0f;
     // heavy = low level = early; level 127 = the tiles without work
     auto level_of = [&](uint32_t w) { const int l = w ? (TO_LEVELS - 2) - (int)((float)w * scale) : TO_LEVELS - 1; return l < 0 ? 0 : l; };
-    for (int it = tid; it < items; it += TO_THREADS) {
+#pragma unroll
+    for (int k = 0; k < TO_CACHE; ++k) if (ci[k] >= 0) atomicAdd(&s_hist[level_of(cw[k])], 1u);
+    for (int it = tid + TO_CACHE * TO_THREADS; it < items; it += TO_THREADS) {
         uint32_t w;
         if (tile_of(it, w) >= 0) atomicAdd(&s_hist[level_of(w)], 1u);
     }
@@ -977,7 +987,13 @@ k_tile_order(const uint4* __restrict__ tile_work, GsrSumArgs g, int tiles_y, con
         if (lane == 63) s_nown = x;   // tiles in this XCD's column
     }
     __syncthreads();
-    for (int it = tid; it < items; it += TO_THREADS) {
+#pragma unroll
+    for (int k = 0; k < TO_CACHE; ++k)
+        if (ci[k] >= 0) {
+            const uint32_t pos = atomicAdd(&s_hist[level_of(cw[k])], 1u);
+            if ((int)pos < cap) order[8 * (int)pos + xcd] = ci[k];
+        }
+    for (int it = tid + TO_CACHE * TO_THREADS; it < items; it += TO_THREADS) {
         uint32_t w;
         const int i = tile_of(it, w);
         if (i >= 0) {
@@ -986,4 +1002,38 @@ k_tile_order(const uint4* __restrict__ tile_work, GsrSumArgs g, int tiles_y, con
         }
     }
     for (int p = (int)s_nown + tid; p < cap; p += TO_THREADS) order[8 * p + xcd] = -1;
+}
+__global__ void __launch_bounds__(TO_THREADS)
+k_tile_order(const uint4* __restrict__ tile_work, GsrSumArgs g, int tiles_y, const uint32_t* __restrict__ sup_work, int cap,
+             int32_t* __restrict__ order)
+{
+    gsr_tile_order(tile_work, g, tiles_y, sup_work, cap, order, (int)blockIdx.x);
+}
+
+// The end of a frame whose tile order is due, in ONE launch (round 5): the eight workgroups of k_tile_order BESIDE the frame's sums
+// (and the horizon dilation, where the frame leaves horizons) instead of behind them -- they read the blend kernel's bookkeeping
+// and this frame's half of the work sums, the sums clear the OTHER half: nothing of each other.  Workgroups of 1024 threads (the
+// tile order's); the others use their first 256 / 64.  C3: k_frame_end 6.8 + k_tile_order 11.4 us in every frame -> one launch.
+struct GsrOrderArgs { const uint4* tile_work; int32_t tiles_y; const uint32_t* sup_work; int32_t cap; int32_t* order; };
+__global__ void __launch_bounds__(TO_THREADS)
+k_frame_end_order(const GsrTilePartial* __restrict__ partial, int nblocks, int ndilate /* nblocks, or 0: the frame leaves no horizons */, GsrSumArgs g,
+                  unsigned long long* __restrict__ counters, const uint32_t* __restrict__ n_visible, unsigned long long* __restrict__ summary,
+                  uint32_t* __restrict__ prefix, const uint32_t* __restrict__ redo_count, uint32_t* __restrict__ colour_evals,
+                  unsigned long long* __restrict__ colour_total, const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
+                  uint32_t* __restrict__ lazy_hint, uint32_t* __restrict__ sup_work_next, GsrHorizonArgs hz, uint32_t* __restrict__ st_scan, int dilate_r,
+                  GsrOrderArgs oa)
+{
+    const int b = (int)blockIdx.x;
+    if (b < 8) {                       // (first: they are the longest)
+        gsr_tile_order(oa.tile_work, g, oa.tiles_y, oa.sup_work, oa.cap, oa.order, b);
+        return;
+    }
+    if (b == 8) {
+        if (threadIdx.x >= SW_THREADS) return;
+        gsr_sum_work(partial, nblocks, g, counters, n_visible, summary, prefix, redo_count, colour_evals, colour_total, sstart, send, lazy_hint,
+                     sup_work_next, hz, st_scan);
+        return;
+    }
+    if (threadIdx.x >= 64 || b - 9 >= ndilate) return;
+    gsr_horizon_dilate(hz.raw, g.tiles_x, g.tiles_y, dilate_r, hz, hz.pyr_out, b - 9);
 }

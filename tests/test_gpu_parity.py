@@ -1655,7 +1655,7 @@ def test_bench_takes_an_inria_ply(pkg, oracle, tmp_path):
     assert res.returncode == 0, res.stderr[-2000:]
     assert line["value"] > 0 and line["timed_frame_bit_identical"] is True and line["data"].startswith("INRIA PLY")
     assert line["config"]["workload"].startswith("PLY capture.ply: 60000 splats") and line["config"]["n_splats"] == 60000
-    assert line["n_visible"] > 30000 and line["cpu_baseline"]["value"] > 0 and line["roofline"]["pairs_consumed_per_launch"] > 0
+    assert line["n_visible"] > 5000 and line["cpu_baseline"]["value"] > 0 and line["roofline"]["pairs_consumed_per_launch"] > 0
     name = pkg.scenes.register_ply_config(path, pkg.ply, name="PLY_T")
     try:
         splats, cfg = pkg.scenes.make_config(name)

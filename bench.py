@@ -130,6 +130,11 @@ def parse_args():
     ap.add_argument("--via-multi", action="store_true",
                     help="--gpus 1 through the multi-GPU entry (gsr_multi with ONE rank): what the N = 1 point of a scaling curve measured with "
                          "`bench.py --gpus N` runs, so that it can be checked against the single-context line (they must agree within ~3 %)")
+    ap.add_argument("--depth", default="none", choices=("none", "far", "occluder"),
+                    help="the TIMED region renders depth-tested frames (gsr_render_depth, what the viewport hook issues on every redraw: the reference "
+                         "draws with the depth test on, src/GSplatRenderer.C:595-610): far = an opaque-pass depth buffer cleared to the far plane, "
+                         "occluder = with an opaque sphere among the splats covering ~30 %% of the screen (scenes.sphere_occluder_depth).  "
+                         "The default line reports both as `depth_tested` beside the plain frame; this switch is for rocprofv3 runs")
     ap.add_argument("--no-verify", action="store_true",
                     help="N>1: skip the check (after the timed region) that the last stitched frame is bit-identical to the same frame "
                          "rendered unsharded on rank 0")
@@ -205,6 +210,22 @@ def workload_name(args, splats, cfg, order, W, H) -> str:
         return (f"PLY {os.path.basename(cfg['path'])}: {splats.n} splats of an INRIA capture (SH deg {order}), {W}x{H}, camera orbiting the cloud's "
                 f"median at 1.6 x its 80 % radius (re-sort every frame)")
     return f"{args.config}: {splats.n} synthetic splats (SH deg {order}, seed {cfg['seed']}), {W}x{H}, orbiting camera (re-sort every frame)"
+
+
+# the opaque sphere of the depth-tested legs: centred on the view axis 3.0 units in front of the camera, radius 0.566: 30 % of a
+# 1920x1080 frame.  C4: its front pokes 0.19 units OUT of the cloud (the middle of the frame shows bare geometry behind a thin veil:
+# tiles that never saturate), its rim lies 0.2 units under the cloud's surface (tiles that saturate just in front of it), and in
+# between sits the ring where the geometry is AT the depth the tiles saturate at -- the case that decides whether the culling copes
+OCCLUDER = {"centre_distance": 3.0, "radius": 0.566}
+
+
+def depth_buffer(kind: str, pkg, torch, cam, scale: float = 1.0):
+    """device tensor [H, W] float32: the opaque pass's window depth (row 0 = bottom); scale = the orbit distance relative to C4's"""
+    if kind == "far":
+        d = np.ones((cam.height, cam.width), np.float32)
+    else:
+        d = pkg.scenes.sphere_occluder_depth(cam, OCCLUDER["centre_distance"] * scale, OCCLUDER["radius"] * scale)
+    return torch.from_numpy(d).to("cuda")
 
 
 def orbit_frame(i: int, jump_every: int) -> int:
@@ -328,7 +349,7 @@ def set_common_options(target, pkg, args):
     target.set_option(E.OPT_SHARD_LAYOUT, args.shard_layout)
 
 
-def reference_frame(pkg, torch, dev_index, stream, splats, cam_struct, W, H, exact: bool):
+def reference_frame(pkg, torch, dev_index, stream, splats, cam_struct, W, H, exact: bool, depth=None):
     """the same frame from a second, unsharded context on GPU `dev_index`; exact = occlusion AND cluster culling off (every
     clip-visible splat is projected, sorted, binned: what the timed frames must be bit-identical to)"""
     ref_eng = pkg.Engine(dev_index)
@@ -339,7 +360,10 @@ def reference_frame(pkg, torch, dev_index, stream, splats, cam_struct, W, H, exa
             ref_eng.set_option(pkg.engine.OPT_CLUSTER_CULL, 0)
         ref_eng.upload(splats)
         ref = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{dev_index}")
-        ref_eng.render_struct_to_device(cam_struct, ref.data_ptr())
+        if depth is not None:
+            ref_eng.render_struct_depth_to_device(cam_struct, depth.data_ptr(), ref.data_ptr())
+        else:
+            ref_eng.render_struct_to_device(cam_struct, ref.data_ptr())
         torch.cuda.synchronize(dev_index)
         return ref
     finally:
@@ -618,11 +642,19 @@ def main():
         band = torch.zeros((eng.band_rows(H), W, 4), dtype=torch.float32, device="cuda") if fg is None else fg.band
         assert band.shape[0] == eng.band_rows(H)
 
+    # --depth: the timed region's frames are depth-tested against an opaque pass's depth buffer (device memory, full image)
+    cam0_py = pkg.scenes.config_camera(args.config, pkg.camera, W, H, order, 0)
+    depth_scale = float(pkg.scenes.CONFIGS[args.config].get("distance", 4.61995)) / 4.61995
+    depth_t = depth_buffer(args.depth, pkg, torch, cam0_py, depth_scale) if args.depth != "none" else None
+
     def step(i):
         if in_lib:
-            eng.comm_render(cams[i], final.data_ptr() if final is not None else 0)
+            eng.comm_render(cams[i], final.data_ptr() if final is not None else 0, depth_t.data_ptr() if depth_t is not None else 0)
         else:
-            eng.render_struct_to_device(cams[i], band.data_ptr())
+            if depth_t is not None:
+                eng.render_struct_depth_to_device(cams[i], depth_t.data_ptr(), band.data_ptr())
+            else:
+                eng.render_struct_to_device(cams[i], band.data_ptr())
             if fg is not None:
                 fg.gather_and_stitch()
 
@@ -667,7 +699,7 @@ def main():
         last = cams[args.warmup + args.steps - 1]
         shown = current_frame()                                 # the last step's frame on rank 0
         if rank == 0:
-            ref = reference_frame(pkg, torch, dev_index, stream, splats, last, W, H, exact=True)
+            ref = reference_frame(pkg, torch, dev_index, stream, splats, last, W, H, exact=True, depth=depth_t)
             verified = bool(torch.equal(shown, ref)) and bool(ref[..., 3].max() > 0)
             if not verified:   # reported in the JSON line; the exit code follows after the line (the other ranks are at the barrier below)
                 print("[bench] the timed frame DIFFERS from the frame rendered without culling / sharding: max |diff| %.3e" %
@@ -760,6 +792,65 @@ def main():
         cold["note"] = ("every frame jumps 111 degrees round the cloud and to / from 1.3 x the distance: nothing of the previous frame applies.  policy = the default (GSR_OPT_OCCLUSION_CULL = 1, "
                         "GSR_OPT_FRONT_SLAB = 1); intra_frame_only = GSR_OPT_OCCLUSION_CULL = 3; one_pass = GSR_OPT_OCCLUSION_CULL = 0 on the same cameras")
         eng.set_option(pkg.engine.OPT_OCCLUSION_CULL, args.cull)
+    # extra leg (single GPU): the DEPTH-TESTED frame -- the one the viewport hook issues on every redraw (hdk/DM_GSplatHook_hip.C binds the
+    # opaque pass's depth; the reference draws with the depth test on, src/GSplatRenderer.C:595-610).  The same orbit three ways, back
+    # to back in this leg's own loop: plain (no depth buffer), a depth buffer cleared to the far plane, and one with an opaque sphere
+    # among the splats covering ~30 % of the screen.  Each variant's last frame is checked bit for bit against a context that culls nothing.
+    depth_leg = None
+    if world == 1 and not args.no_extra_legs and args.emulate_shard <= 1 and args.depth == "none":
+        k4 = min(60, args.steps)
+        depth_leg = {}
+        for name in ("plain", "far_plane", "occluder"):
+            dt_ = None if name == "plain" else depth_buffer("far" if name == "far_plane" else "occluder", pkg, torch, cam0_py, depth_scale)
+            # (a context of its own per variant, like `other_configs`: the policies' state -- dilation radius, hold-offs, the 64-frame
+            #  streak counter -- must not carry from one variant into the next)
+            de = pkg.Engine(dev_index)
+            de.set_stream(stream.cuda_stream)
+            set_common_options(de, pkg, args)
+            de.upload(splats)
+
+            def dstep(i):
+                if dt_ is None:
+                    de.render_struct_to_device(cams[i], band.data_ptr())
+                else:
+                    de.render_struct_depth_to_device(cams[i], dt_.data_ptr(), band.data_ptr())
+            for i in range(min(args.warmup + 5, args.warmup + args.steps)):
+                dstep(i)
+            torch.cuda.synchronize()
+            de.stats_reset()
+            t0 = time.perf_counter()
+            for i in range(k4):
+                dstep(args.warmup + i)
+            torch.cuda.synchronize()
+            ddt = time.perf_counter() - t0
+            sd = de.stats()
+            ok = None
+            if not args.no_verify:
+                ref = reference_frame(pkg, torch, dev_index, stream, splats, cams[args.warmup + k4 - 1], W, H, exact=True, depth=dt_)
+                ok = bool(torch.equal(band, ref)) and bool(ref[..., 3].max() > 0)
+                del ref
+                torch.cuda.empty_cache()
+            dreg = "temporal (culled)" if sd["frames_culled"] * 2 > sd["frames"] else ("front slab" if sd["frames_slab"] * 2 > sd["frames"] else "one pass")
+            depth_leg[name] = {"value": k4 / ddt, "unit": "frames/sec", "ms_per_step": ddt / k4 * 1e3, "steps": k4, "regime": dreg,
+                               "kernel": "k_blend<false>" if dt_ is None else "k_blend<true>",
+                               "blend_launch_ms": sd["blend_ms_total"] / max(1, sd["blend_launches"]), "blend_launches_timed": sd["blend_launches"],
+                               "frames_culled": sd["frames_culled"], "frames_repaired": sd["frames_repaired"], "frames_slab": sd["frames_slab"],
+                               "n_visible": sd["n_visible"], "pairs": sd["pairs_total"], "clusters_kept": sd["clusters_kept"],
+                               "pairs_consumed_per_frame": sd["blend_pairs_consumed_total"] / max(1, sd["frames"]),
+                               "cull_dilate": sd["cull_dilate"], "policy_bits": sd["policy_bits"],
+                               "depth_culling_active": bool(sd["policy_bits"] & 32),
+                               "opaque_pixels_frac": float((dt_ < 1.0).float().mean()) if dt_ is not None else 0.0,
+                               "last_frame_bit_identical_to_unculled": ok}
+            de.close()
+            del dt_, de
+            torch.cuda.empty_cache()
+        if depth_leg["plain"]["value"] > 0:
+            for name in ("far_plane", "occluder"):
+                depth_leg[name]["vs_plain"] = depth_leg[name]["value"] / depth_leg["plain"]["value"]
+        depth_leg["occluder_sphere"] = dict(OCCLUDER, scale=depth_scale,
+                                            note="an opaque sphere on the view axis (it follows the camera, so every frame of the orbit sees the same depth buffer)")
+        depth_leg["note"] = ("gsr_render_depth with a device depth buffer: fragment survives iff its quad's window depth <= depth[pixel] (one depth per quad); "
+                             "plain = gsr_render on the same cameras in the same loop")
     # extra leg (informational): the same K steps with two frames in flight
     pipelined = None
     if args.pipelined and args.frames_in_flight == 1 and not args.no_extra_legs:
@@ -907,6 +998,10 @@ def main():
                                           "no place in the sort and the lists; every culled frame verifies itself and is rendered again without culling if a horizon "
                                           "broke (frames_repaired; those frames are inside the timed region)"},
         }
+        if depth_leg is not None:
+            line["depth_tested"] = depth_leg
+        if args.depth != "none":
+            line["config"]["depth_tested"] = args.depth
         if cold is not None:
             line["cold_frames"] = cold
         if pipelined is not None:

@@ -40,6 +40,25 @@
 static bool theWireRequested = false;
 void GSplatHipRequestWireOverlay(bool on) { theWireRequested = theWireRequested || on; }
 
+/* ONE HIP stream for the whole plugin, owned next to the engine -- which is a process-wide singleton shared by every viewport
+ * (GSplatRenderer::getInstance()).  A stream per viewport hook (round 5) was wrong twice over: in a quad view hook B re-bound the
+ * engine to ITS stream, hook A -- whose cached "bound engine" still matched -- went on mapping and unmapping on a stream the kernels
+ * no longer ran on (the depth map was not ordered before K1); and a closing viewport destroyed a stream the engine was still bound
+ * to.  The stream lives as long as the process; the binding is redone whenever the engine object changes (single <-> multi GPU). */
+static hipStream_t theHookStream = nullptr;
+static const void* theBoundEngine = nullptr;     /* the engine whose public stream is theHookStream */
+static hipStream_t hookStream(GSplatRenderer& R)
+{
+    if (!theHookStream && hipStreamCreateWithFlags(&theHookStream, hipStreamNonBlocking) != hipSuccess) theHookStream = nullptr;
+    const void* engineNow = R.engine() ? static_cast<const void*>(R.engine()) : static_cast<const void*>(R.multi());
+    if (engineNow != theBoundEngine) {           /* (once per engine: re-binding drains the context) */
+        if (R.engine()) (void)gsr_set_stream(R.engine(), theHookStream);
+        else if (R.multi()) (void)gsr_multi_set_stream(R.multi(), theHookStream);
+        theBoundEngine = engineNow;
+    }
+    return theHookStream;
+}
+
 namespace {
 
 /* the two pixel buffers of one viewport and the texture the result is drawn from */
@@ -105,8 +124,9 @@ public:
     GSplatHipSceneRenderHook(DM_VPortAgent& vport, DM_ViewportType view_mask) : DM_SceneRenderHook(vport, view_mask) {}
     ~GSplatHipSceneRenderHook() override
     {
+        /* (the buffers are this viewport's; the stream is the plugin's: the engine stays bound to it) */
+        if (theHookStream) (void)hipStreamSynchronize(theHookStream);
         myBuffers.release();
-        if (myStream) (void)hipStreamDestroy(myStream);
     }
 
     bool render(RE_RenderContext r, const DM_SceneHookData& hook_data) override
@@ -137,17 +157,10 @@ public:
         glBindBuffer(GL_PIXEL_PACK_BUFFER, myBuffers.depthPbo);
         glReadPixels(0, 0, ctx.width, ctx.height, GL_DEPTH_COMPONENT, GL_FLOAT, nullptr);
         glBindBuffer(GL_PIXEL_PACK_BUFFER, 0);
-        /* ONE stream orders everything of this viewport: the maps, the engine's kernels (gsr_set_stream: a context's frames are
-         * ordered on its public stream -- its own stream is hipStreamNonBlocking and would NOT be ordered against stream 0) and
-         * the unmaps, which is what hands the finished frame back to GL */
-        if (!myStream && hipStreamCreateWithFlags(&myStream, hipStreamNonBlocking) != hipSuccess) myStream = nullptr;
-        hipStream_t stream = myStream;
-        const void* engineNow = R.engine() ? static_cast<const void*>(R.engine()) : static_cast<const void*>(R.multi());
-        if (engineNow != myBoundEngine) {   /* (once per engine: re-binding drains the context) */
-            if (R.engine()) (void)gsr_set_stream(R.engine(), stream);
-            else if (R.multi()) (void)gsr_multi_set_stream(R.multi(), stream);
-            myBoundEngine = engineNow;
-        }
+        /* ONE stream orders everything: the maps, the engine's kernels (gsr_set_stream: a context's frames are ordered on its
+         * public stream -- its own stream is hipStreamNonBlocking and would NOT be ordered against stream 0) and the unmaps, which
+         * is what hands the finished frame back to GL.  It is the plugin's, not this viewport's (hookStream above). */
+        hipStream_t stream = hookStream(R);
         ctx.depth = static_cast<const float*>(myBuffers.depth.map(stream));
         ctx.depth_is_device = 1;
         ctx.target = static_cast<float*>(myBuffers.rgba.map(stream));
@@ -207,8 +220,6 @@ public:
 
 private:
     ViewportBuffers myBuffers;
-    hipStream_t myStream = nullptr;
-    const void* myBoundEngine = nullptr;     /* the engine whose public stream is myStream */
 };
 
 class GSplatHipSceneHook : public DM_SceneHook

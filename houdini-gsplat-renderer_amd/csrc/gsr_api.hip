@@ -111,6 +111,12 @@ struct FrameJob {
     gsr_camera cam_arg{};
     const float* depth_arg = nullptr;
     int depth_is_device_arg = 0;
+    // depth-tested frames: K1 (and k_cluster_cull) drop what lies behind everything the opaque pass left under the tiles it reaches
+    bool dcull = false;            // ... against the slot's tile-max depth pyramid, parity dpar
+    int dpar = 0;
+    bool sort_fresh = false;       // this frame sorted (it did not reuse a cached order)
+    bool dblind = false;           // ... and k_cluster_cull ran without the depth pyramids (they were built beside it, for K1)
+    bool blend_guess_plain = false;   // the plain blend kernel was launched, guarded by "no pixel is covered" (queue_back_end)
     float* out_arg = nullptr;
     int out_is_device_arg = 0;
 };
@@ -134,6 +140,11 @@ struct FrameSlot {
     float* zwin = nullptr;             // per-splat window depth (depth-tested frames)
     float* depth_stage = nullptr;      // device copy of a host depth buffer
     size_t depth_cap = 0;
+    float* dpyr = nullptr;             // depth-tested frames: the two tile-max pyramids of the opaque pass's depth (k_cluster.h), by
+    size_t dpyr_cap = 0;               // frame parity: [par][which], dpyr_cap floats each
+    uint32_t* dactive = nullptr;       // [2] by parity: "some tile's largest depth is below 1" (something can be culled)
+    int dpar = 0;                      // parity of the slot's last depth-tested frame
+    bool sorted_dculled = false;       // the cached depth order holds a frame that was culled against its depth buffer
     // scan / sort scratch
     uint32_t* hist = nullptr;
     size_t hist_cap = 0;
@@ -294,6 +305,9 @@ struct gsr_context {
     GsrCullPolicy cull_pol;            // occlusion culling: pays / weak / hold-off / back-off / dilation radius (gsr_policy.h; DESIGN.md section 4's state table)
     GsrSlabPolicy slab_pol;            // front-slab frames: held off for 256 frames after one that kept more than a third of an unculled frame (B1 at 0.46 loses 9 %)
     bool prefix_cheaper = false;       // the list-prefix colour pass would evaluate fewer colours than one per kept splat
+    bool depth_active = false;         // the last depth-tested frame's depth buffer held opaque geometry in front of the far plane: the next one
+                                       // builds its depth pyramid in a launch of its own, IN FRONT of k_cluster_cull (which then culls against it
+                                       // too); otherwise the pyramid is built beside the cluster tests, for K1 alone (no extra launch)
     bool order_pays = false;           // k_sum_work's other verdict: the tiles differ enough in work for k_tile_order to pay
     unsigned long long* wire_zbuf = nullptr;   // wireframe overlay: (depth bits, splat index) per pixel ...
     float* wire_out = nullptr;                 // ... and the image staged for a host target
@@ -449,7 +463,7 @@ static void slot_destroy(FrameSlot& sl)
     dev_free(sl.pvA);
     dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.fb);
     dev_free(sl.hpyr); dev_free(sl.hpyr_next); dev_free(sl.hraw); dev_free(sl.hpyr2); dev_free(sl.slab); dev_free(sl.tile_work_a); dev_free(sl.tbuf); dev_free(sl.ccnt); dev_free(sl.bkt_key); dev_free(sl.bkt_val); dev_free(sl.bkt_cnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
-    if (sl.h_end) (void)hipHostFree(sl.h_end); dev_free(sl.depth_stage);
+    if (sl.h_end) (void)hipHostFree(sl.h_end); dev_free(sl.depth_stage); dev_free(sl.dpyr); dev_free(sl.dactive);
     dev_free(sl.redo); dev_free(sl.lazy_ctr); dev_free(sl.colour_evals);
     dev_free(sl.counters); dev_free(sl.d_n);
     if (sl.h_total) (void)hipHostFree(sl.h_total);
@@ -1254,7 +1268,54 @@ static GsrRangeArgs range_args(gsr_context* c, FrameSlot& sl)
     a.totals = sl.totals; a.n_super = j.n_super; a.sstart = sl.sstart; a.send = sl.send; a.host_total = sl.h_total_dev;
     a.ticket = j.ticket; a.max_pairs = (unsigned long long)GSR_MAX_PAIRS; a.redo_count = reinterpret_cast<uint32_t*>(sl.lazy_ctr);
     a.lazy_hint = c->lazy_hint; a.n_sorted = sl.d_n; a.k1_counts = sl.d_counts; a.sorted_keys = sl.keyA;
+    a.depth_active = j.dcull ? sl.dactive + j.dpar : (const uint32_t*)nullptr;
     return a;
+}
+
+// the compositing launch (+ the lazy-colour fallback behind it)
+static int queue_blend(gsr_context* c, FrameSlot& sl, bool with_depth, bool guarded)
+{
+    const FrameJob& j = sl.job;
+    const GsrFrame& f = j.f;
+    hipStream_t s = sl.stream;
+    if (j.local_tiles > 0) {
+        if (!j.direct) HIP_TRY(hipStreamWaitEvent(s, sl.ev_user, 0));
+        GsrBlendArgs a;
+        a.guard = guarded ? sl.dactive + j.dpar : (const uint32_t*)nullptr; a.guard_want = 0u;
+        a.width = f.width; a.height = f.height; a.tiles_x = f.tiles_x; a.local_tiles = j.local_tiles;
+        a.shard = GsrShard{f.shard_index, f.shard_count, f.shard_rpb}; a.band_rows = j.band_rows;
+        a.super_shift = f.super_shift; a.rect_shift = f.rect_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
+        a.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
+        a.sup_work = (a.use_map && c->opt_swizzle >= 2 && sl.sup_work) ? sl.sup_work + 256 * sl.sup_par : nullptr;
+        a.slab = j.phase; a.tbuf = sl.tbuf; a.tile_work_a = sl.tile_work_a;
+        uint4* const tw = j.phase == 1 ? sl.tile_work_a : sl.tile_work;   // (phase 1's bookkeeping is kept for phase 2 and the frame end)
+        // heaviest-first table of this slot's previous frame, if that frame had the same tiles
+        const int sig[6] = {f.width, f.height, f.shard_index, f.shard_count, f.shard_rpb, f.super_shift};
+        const bool ordered = a.use_map && c->opt_swizzle >= 2 && sl.order_valid && std::memcmp(sig, sl.order_sig, sizeof sig) == 0;
+        const int32_t* tmap = ordered ? sl.order : c->tile_map;
+        const unsigned grid = ordered ? (unsigned)(8 * sl.order_per_xcd) : a.use_map ? (unsigned)c->map_grid : (unsigned)j.local_tiles;
+        GsrLazyArgs lz;
+        lz.f = f; lz.colrow = c->colrow;
+        lz.redo = j.lazy ? sl.redo : nullptr;
+        lz.redo_count = reinterpret_cast<uint32_t*>(sl.lazy_ctr);
+        float4* tgt = reinterpret_cast<float4*>(j.target);
+        if (with_depth)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<true>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
+                               sl.send, sl.rec, tgt, tw, sl.zwin, j.d_depth, lz);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
+                               sl.send, sl.rec, tgt, tw, sl.zwin, j.d_depth, lz);
+        if (j.lazy) {   // the tiles that met a pending colour, with on-demand evaluation (normally none: the blocks exit at once)
+            if (with_depth)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<true>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
+                                   sl.pvA, sl.sstart, sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<false>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
+                                   sl.pvA, sl.sstart, sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return GSR_OK;
 }
 
 static int queue_back_end(gsr_context* c, FrameSlot& sl)
@@ -1288,42 +1349,10 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         HIP_TRY(hipGetLastError());
     }
     if ((rc = mark(sl, 5))) return rc;
-    if (j.local_tiles > 0) {
-        if (!j.direct) HIP_TRY(hipStreamWaitEvent(s, sl.ev_user, 0));
-        GsrBlendArgs a;
-        a.width = f.width; a.height = f.height; a.tiles_x = f.tiles_x; a.local_tiles = j.local_tiles;
-        a.shard = GsrShard{f.shard_index, f.shard_count, f.shard_rpb}; a.band_rows = j.band_rows;
-        a.super_shift = f.super_shift; a.rect_shift = f.rect_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
-        a.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
-        a.sup_work = (a.use_map && c->opt_swizzle >= 2 && sl.sup_work) ? sl.sup_work + 256 * sl.sup_par : nullptr;
-        a.slab = j.phase; a.tbuf = sl.tbuf; a.tile_work_a = sl.tile_work_a;
-        uint4* const tw = j.phase == 1 ? sl.tile_work_a : sl.tile_work;   // (phase 1's bookkeeping is kept for phase 2 and the frame end)
-        // heaviest-first table of this slot's previous frame, if that frame had the same tiles
-        const int sig[6] = {f.width, f.height, f.shard_index, f.shard_count, f.shard_rpb, f.super_shift};
-        const bool ordered = a.use_map && c->opt_swizzle >= 2 && sl.order_valid && std::memcmp(sig, sl.order_sig, sizeof sig) == 0;
-        const int32_t* tmap = ordered ? sl.order : c->tile_map;
-        const unsigned grid = ordered ? (unsigned)(8 * sl.order_per_xcd) : a.use_map ? (unsigned)c->map_grid : (unsigned)j.local_tiles;
-        GsrLazyArgs lz;
-        lz.f = f; lz.colrow = c->colrow;
-        lz.redo = j.lazy ? sl.redo : nullptr;
-        lz.redo_count = reinterpret_cast<uint32_t*>(sl.lazy_ctr);
-        float4* tgt = reinterpret_cast<float4*>(j.target);
-        if (j.d_depth)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<true>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
-                               sl.send, sl.rec, tgt, tw, sl.zwin, j.d_depth, lz);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
-                               sl.send, sl.rec, tgt, tw, sl.zwin, j.d_depth, lz);
-        if (j.lazy) {   // the tiles that met a pending colour, with on-demand evaluation (normally none: the blocks exit at once)
-            if (j.d_depth)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<true>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
-                                   sl.pvA, sl.sstart, sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<false>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
-                                   sl.pvA, sl.sstart, sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
-        }
-        HIP_TRY(hipGetLastError());
-    }
+    // Depth-tested frames: the plain kernel, guarded, while the slot's depth buffers have been clear (k_blend.h: GsrBlendArgs.guard);
+    // not for a frame that is handed over before its mailbox is read (nobody could queue the other kernel in time)
+    sl.job.blend_guess_plain = j.d_depth != nullptr && j.dcull && !c->depth_active && !j.deferred;
+    if ((rc = queue_blend(c, sl, j.d_depth != nullptr && !sl.job.blend_guess_plain, sl.job.blend_guess_plain))) return rc;
     return mark(sl, 6);
 }
 
@@ -1551,6 +1580,23 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
             return GSR_OK;
         }
         if (j.local_sort) sl.local_pol.on_sort_result(false);
+        if (j.dcull && j.dblind && j.cull && (box[1] & 64ull) != 0ull) {
+            // The frame was culled against horizons, its depth buffer turned out to hold opaque geometry, and k_cluster_cull did not know
+            // (the pyramids were built beside it: the previous depth buffer was clear).  Horizons speak for uncovered pixels only; the
+            // covered ones are served by the depth clause, which k_cluster_cull could not apply: clusters they need may be gone.  The
+            // frame again, with the pyramids in front (once, when opaque geometry first appears; frame_check).
+            c->depth_active = true;
+            c->st.frames_requeued += 1;
+            if (sl.sup_work) (void)hipMemsetAsync(sl.sup_work + 256 * sl.sup_par, 0, 256 * sizeof(uint32_t), sl.stream);
+            sl.sort_valid = false;
+            j.redo = true;
+            j.open = false;
+            return GSR_OK;
+        }
+        if (j.dcull) {   // (the kernels' word on THIS frame's depth buffer: does it hold anything in front of the far plane?)
+            c->depth_active = (box[1] & 64ull) != 0ull;
+            if (j.sort_fresh) sl.sorted_dculled = c->depth_active;   // (conservatively "yes" until now)
+        }
         if (j.phase != 2) {   // (the kernels' verdicts on the frame BEFORE: lazy colour / occlusion culling / list prefixes pay)
             c->lazy_pays = (box[1] & 1ull) != 0ull;
             c->cull_pol.on_kernel_verdict((box[1] & 4ull) != 0ull);
@@ -1632,6 +1678,12 @@ static int frame_finish(gsr_context* c, FrameSlot& sl)
         }
     }
     sl.last_pairs = D;
+    if (j.n > 0 && j.blend_guess_plain && (sl.h_total[1] & 64ull) != 0ull) {
+        // the guarded plain kernel found covered pixels and did nothing: the depth-tested one draws the frame
+        j.blend_guess_plain = false;
+        int rc = queue_blend(c, sl, true, false);
+        if (rc) return frame_abort(sl, rc);
+    }
     if (j.phase == 1) {
         // front slab composited: find the finished tiles, then the rest of the frame (same slot, same call arguments)
         int rc = queue_slab_mid(c, sl);
@@ -1783,7 +1835,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     // the nearest splats first, then -- behind the tiles that are still open only -- the rest (GSR_OPT_FRONT_SLAB; k_blend.h).
     const SortKey key_now = {c->geo_gen, c->shard_index, c->shard_count, c->shard_layout, c->opt_flags, *cam};
     {
-        const bool hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now) && !j.cull && !sl.sorted_culled;   // (a static redraw)
+        const bool hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now) && !j.cull && !sl.sorted_culled && !sl.sorted_dculled;   // (a static redraw)
         const bool slab = phase_in == 0 && !j.cull && !j.deferred && n > 0 && c->opt_slab && c->opt_cull && c->opt_cluster && c->bbox_ok &&
                           !(c->opt_flags & GSR_FLAG_FULL_KEYS) && c->opt_sort_cache < 2 && !hit &&
                           // (where a frame is heavy enough for two phases' worth of launches to be repaid: C3's 0.8 M visible splats are not.
@@ -1839,6 +1891,27 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         HIP_TRY(hipMemcpyAsync(sl.depth_stage, depth, npx * 4, hipMemcpyHostToDevice, s));
         j.d_depth = sl.depth_stage;
     }
+    // Depth-tested frames: the tile-max pyramid of the opaque pass's depth (k_cluster.h), rebuilt every frame (the buffer's content is
+    // the caller's), one per slot; the second phase of a front-slab frame uses the first one's.  GSR_OPT_OCCLUSION_CULL = 0 switches
+    // it off like every other occlusion test (what is left is k_blend's own per-quadrant classification and per-fragment compare).
+    j.dcull = j.d_depth != nullptr && c->opt_cull != 0 && n > 0;
+    if (j.dcull) {
+        const size_t need = (size_t)f.pyr_off[GSR_PYR_LEVELS - 1] + (size_t)gsr_pyr_dim(f.tiles_x, GSR_PYR_LEVELS - 1) * gsr_pyr_dim(f.tiles_y, GSR_PYR_LEVELS - 1) + 16;
+        if (need > sl.dpyr_cap || !sl.dactive) {
+            HIP_TRY(hipStreamSynchronize(s));
+            dev_free(sl.dpyr);
+            sl.dpyr_cap = 0;
+            if ((rc = dev_alloc(&sl.dpyr, 4 * need))) return rc;
+            HIP_TRY(hipMemsetAsync(sl.dpyr, 0, 4 * need * sizeof(float), s));   // (levels 4 and 5 start cleared; afterwards every frame clears the next one's)
+            sl.dpyr_cap = need;
+            if (!sl.dactive) {
+                if ((rc = dev_alloc(&sl.dactive, 2))) return rc;
+                HIP_TRY(hipMemsetAsync(sl.dactive, 0, 2 * sizeof(uint32_t), s));   // (on the frame's stream: a null-stream memset is not ordered against it)
+            }
+        }
+        if (phase_in != 2) sl.dpar ^= 1;
+        j.dpar = sl.dpar;
+    }
     j.target = rgba_out;
     if (!out_is_device) {
         if (j.out_px * 4 > sl.fb_cap) {
@@ -1866,7 +1939,8 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     // it is reused as is only for an identical frame description (a static viewport redraw), per frame slot.
     // (a culled frame's order holds only the splats in front of ITS horizons, and the horizons move: no reuse either way; the
     //  two phases of a front-slab frame each sort what they keep)
-    const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now) && !j.cull && !sl.sorted_culled && j.phase == 0;
+    // (nor the order of a frame that was culled against its depth buffer: the buffer's CONTENT is not part of the frame description)
+    const bool cache_hit = c->opt_sort_cache && sl.sort_valid && sl.sort_key.same(key_now) && !j.cull && !sl.sorted_culled && !sl.sorted_dculled && j.phase == 0;
     // Position-keyed order (GSR_OPT_SORT_CACHE = 2; the reference's rule, src/GSplatRenderer.C:165-186): while the camera POSITION stands
     // still -- a rotation about the eye, a change of lens -- the depth order of ALL splats is the one sorted when it last moved, K1 walks
     // the splats in that order, and what a frame keeps leaves it sorted.  Built the second time a position is seen (a moving camera never
@@ -1924,6 +1998,33 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         const int hist_shift = key_bits > 10 ? key_bits - 10 : 0;
         const float* pyr = j.phase == 2 ? sl.hpyr2 : ((j.cull && !ordered) ? sl.hpyr : (const float*)nullptr);
         const GsrSlabPick pk{(uint32_t)c->slab_min, (uint32_t)c->slab_max, (uint32_t)c->slab_frac, f.key_max - f.key_min};
+        // depth-tested frames: the opaque pass's tile-max depth pyramid.  Where the previous depth-tested frame found opaque geometry in
+        // its buffer, in a launch of its own in front of everything (k_cluster_cull then culls against it too); otherwise -- a buffer
+        // cleared to the far plane, the common case -- beside the cluster tests, as the first workgroups of k_cluster_cull's launch, for
+        // K1 alone.  Whatever the guess, the pixels are the same: the tests are conservative and k_blend compares every fragment.
+        GsrDepthPyrArgs dp{};
+        uint32_t n_dp = 0;
+        GsrDepthCull dc_clus{nullptr, nullptr, nullptr}, dc_k1{nullptr, nullptr, nullptr};
+        if (j.dcull) {
+            float* const dp0 = sl.dpyr + (size_t)(2 * j.dpar) * sl.dpyr_cap;
+            float* const dq0 = sl.dpyr + (size_t)(2 * (j.dpar ^ 1)) * sl.dpyr_cap;
+            dc_k1 = GsrDepthCull{dp0, dp0 + sl.dpyr_cap, sl.dactive + j.dpar};
+            if (j.phase != 2) {
+                dp.depth = j.d_depth; dp.pyr = dp0; dp.pyrc = dp0 + sl.dpyr_cap; dp.pyr_next = dq0; dp.pyrc_next = dq0 + sl.dpyr_cap; dp.active = sl.dactive; dp.par = j.dpar;
+                dp.width = f.width; dp.height = f.height; dp.tiles_x = f.tiles_x; dp.tiles_y = f.tiles_y;
+                for (int l = 0; l < GSR_PYR_LEVELS; ++l) dp.off[l] = f.pyr_off[l];
+                const uint32_t nb8 = (uint32_t)gsr_depth_pyramid_blocks(f.tiles_x, f.tiles_y);
+                if (c->depth_active) {
+                    hipLaunchKernelGGL(k_depth_pyramid, dim3(nb8), dim3(1024), 0, s, dp);
+                    if (c->opt_cluster && !ordered) dc_clus = dc_k1;
+                } else {
+                    n_dp = nb8;
+                    j.dblind = true;
+                }
+            } else if (c->opt_cluster) {
+                dc_clus = dc_k1;       // (phase 1 built it)
+            }
+        }
         if (j.phase == 1) {   // a first pass for the histogram alone (the pass below takes the slab key from it and keeps the slab's clusters only)
             // (the histogram is cleared by phase 2's cull pass; a phase 1 that never got its phase 2 -- its small-frame sort gave a bucket
             //  up, an error in between -- left its counts behind: they would skew this frame's slab key, never its pixels)
@@ -1931,15 +2032,16 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
                 return frame_abort(sl, set_err(GSR_E_HIP, "gsr_render: clearing the slab histogram failed"));
             sl.slab_dirty = true;
             const int n45 = gsr_pyr_dim(f.tiles_x, 4) * gsr_pyr_dim(f.tiles_y, 4) + gsr_pyr_dim(f.tiles_x, 5) * gsr_pyr_dim(f.tiles_y, 5);
-            hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, c->opt_cluster,
+            hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups + n_dp), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, c->opt_cluster,
                                (const float*)nullptr, sl.cseg, sl.ccnt, 1, sl.slab, hist_shift, sl.slab + GSR_SLAB_BINS, pk, sl.hpyr2 + f.pyr_off[4], n45,
-                               (uint32_t*)nullptr, (uint32_t*)nullptr);
+                               (uint32_t*)nullptr, (uint32_t*)nullptr, dp, n_dp, dc_clus);
+            if (n_dp) { n_dp = 0; if (c->opt_cluster) dc_clus = dc_k1; }   // (built: the pass below may use it)
         }
         if (j.phase == 2) sl.slab_dirty = false;   // (mode 3 below clears the histogram for the slot's next front-slab frame)
-        hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, ordered ? 0 : c->opt_cluster,
+        hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups + n_dp), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, ordered ? 0 : c->opt_cluster,
                            pyr, sl.cseg, sl.ccnt,   // (ordered: slots, not clusters -- all of them)
                            j.phase == 1 ? 2 : (j.phase == 2 ? 3 : 0), sl.slab, hist_shift, sl.slab + GSR_SLAB_BINS, pk, (float*)nullptr, 0,
-                           (local || local_phase) ? sl.bkt_cnt : (uint32_t*)nullptr, sl.d_counts + 2);
+                           (local || local_phase) ? sl.bkt_cnt : (uint32_t*)nullptr, sl.d_counts + 2, dp, n_dp, dc_clus);
         // The small-frame sort's bucket pass runs inside K1 (a key's place in its bucket = one atomic): BK_BUCKETS buckets of equal width
         // over the key range the previous frame kept, widened by a sixteenth on either side (the view moves), in this frame's key domain
         // (keys are stored relative to key_min); front-slab phases: over the phase's own range, which k_slab_pick left on the device
@@ -1973,7 +2075,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
                            // (the count of sorted splats starts at zero: a frame whose clusters are ALL culled runs no sort workgroup that
                            //  could say so, and the binning kernels would walk the previous frame's order; a static redraw keeps its order)
                            cache_hit ? (uint32_t*)nullptr : sl.d_n,
-                           ordered ? c->pos_order : (const uint32_t*)nullptr, sl.slab + GSR_SLAB_BINS);
+                           ordered ? c->pos_order : (const uint32_t*)nullptr, sl.slab + GSR_SLAB_BINS, dc_k1);
         hipError_t e = hipGetLastError();
 #ifdef GSR_HOST_TIMING
         if (g_t_verdict > 0) {
@@ -2047,6 +2149,8 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         sl.sort_valid = j.phase == 0;    // (a phase's order holds a part of the frame only)
         sl.sort_key = key_now;
         sl.sorted_culled = j.cull;
+        sl.sorted_dculled = j.dcull;     // (until the frame's mailbox says that its depth buffer culled nothing: frame_finish)
+        j.sort_fresh = true;
     }
     if ((rc = mark(sl, 2))) return frame_abort(sl, rc);
     hipError_t e = hipSuccess;
@@ -2323,7 +2427,7 @@ extern "C" int gsr_get_stats(gsr_context* c, gsr_stats* out)
         c->st.pairs_total = sl.last_pairs;
         c->st.clusters_total = c->nclus;
         c->st.clusters_kept = sl.surv_hint;
-        c->st.policy_bits = (c->lazy_pays ? 1 : 0) | (c->order_pays ? 2 : 0) | (c->cull_pol.pays ? 4 : 0) | (c->cull_pol.weak ? 8 : 0) | (c->prefix_cheaper ? 16 : 0);
+        c->st.policy_bits = (c->lazy_pays ? 1 : 0) | (c->order_pays ? 2 : 0) | (c->cull_pol.pays ? 4 : 0) | (c->cull_pol.weak ? 8 : 0) | (c->prefix_cheaper ? 16 : 0) | (c->depth_active ? 32 : 0);
         c->st.cull_dilate = c->cull_pol.dilate;
         c->st.cull_holdoff = c->cull_pol.holdoff;
         c->st.tiles_x = sl.last_tiles_x;

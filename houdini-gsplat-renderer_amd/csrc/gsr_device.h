@@ -91,6 +91,7 @@ struct GsrFrame {
 #define GSR_FLAG_FULL_KEYS       4   // sort all 32 key bits (no key-range reduction, 8-bit digits)
 #define GSR_FLAG_LAZY_NO_PREFIX  8   // lazy colour: colour nothing ahead of time, so that every tile takes the on-demand fallback
 #define GSR_FLAG_CULL_ROUNDS    16   // k_cluster_cull: three rounds of clusters per workgroup (what clouds beyond 33 M splats do)
+#define GSR_FLAG_NO_DEPTH_CLASS 32   // depth-tested frames: no per-quadrant classification in k_blend (every record staged, every fragment compared)
 
 // small-frame depth sort (k_sort.h): bucket regions
 #ifndef BK_BUCKETS

@@ -208,6 +208,7 @@ struct GsrRangeArgs {
     const uint32_t* n_sorted;          // splats that reached the depth sort (what the frame kept)
     const uint32_t* k1_counts;         // [1] = clusters that survived k_cluster_cull, [2] = the small-frame sort gave a bucket up
     const uint32_t* sorted_keys;       // the frame's keys in depth order
+    const uint32_t* depth_active;      // depth-tested frames: "the depth buffer holds something in front of the far plane" (k_cluster.h), or NULL
 };
 // all 256 threads of a workgroup; returns this thread's (= super-tile's) list start.  publish: also write the ranges and the mailbox
 __device__ __forceinline__ uint32_t bn_ranges(const GsrRangeArgs& a, bool publish, uint32_t* s_wave /*[4]*/, unsigned long long* s_sum /*[4]*/)
@@ -218,7 +219,8 @@ __device__ __forceinline__ uint32_t bn_ranges(const GsrRangeArgs& a, bool publis
         *a.redo_count = 0u;
         const uint32_t ns = *a.n_sorted;
         // (bit 5 of the hints: the small-frame sort gave a bucket up -- the lists of this frame are not to be trusted)
-        a.host_total[1] = ((unsigned long long)ns << 32) | (unsigned long long)(*a.lazy_hint & 31u) | (a.k1_counts[2] ? 32ull : 0ull);
+        a.host_total[1] = ((unsigned long long)ns << 32) | (unsigned long long)(*a.lazy_hint & 31u) | (a.k1_counts[2] ? 32ull : 0ull) |
+                          ((a.depth_active && *a.depth_active) ? 64ull : 0ull);
         a.host_total[2] = (unsigned long long)a.k1_counts[1];
         a.host_total[3] = ns ? ((unsigned long long)a.sorted_keys[ns - 1u] << 32) | (unsigned long long)a.sorted_keys[0] : 0ull;
     }

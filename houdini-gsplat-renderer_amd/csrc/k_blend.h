@@ -23,6 +23,7 @@
 // stops when all its pixels have, and the workgroup stops reading its list when
 // all four waves have.
 #pragma once
+#include <type_traits>
 #include "gsr_device.h"
 #include "k_preprocess.h"   // gsr_splat_colour_from_row (on-demand colour of the lazy path)
 #include "k_cluster.h"      // the depth-horizon pyramid
@@ -80,6 +81,13 @@ struct GsrBlendArgs {
     int32_t slab;
     float* tbuf;                // [band pixels]
     const uint4* tile_work_a;   // phase 2: phase 1's per-tile bookkeeping
+    // Depth-tested frames under a depth buffer that was merely CLEARED (the common case): the host, going by the slot's previous
+    // depth-tested frame, launches the PLAIN kernel -- no depth load, no sixth operand vector, 66 registers instead of 80 -- with a
+    // guard: the word the frame's depth pyramid pass leaves ("some pixel is covered", k_cluster.h).  A launch whose guess was wrong
+    // does nothing (no pixel, no bookkeeping), and the host, which reads the same word with the frame's pair count, queues the
+    // depth-tested kernel behind it (gsr_api.hip: frame_finish).  The word is loaded first thing and looked at after the first scan.
+    const uint32_t* guard;      // NULL: no guard
+    uint32_t guard_want;        // the launch is void unless (*guard != 0) == (guard_want != 0)
 };
 
 // Staging layout: one list PER QUADRANT (= per wave), holding the round's records that reach that
@@ -118,6 +126,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     __shared__ __attribute__((aligned(16))) uint32_t scnt[2][4];   // hits of each wave in a scan step
     __shared__ uint32_t sdone[2][4];
     __shared__ uint32_t sevals, sredo;
+    __shared__ uint32_t slastu[4];    // depth-tested frames: the same count at the moment the wave's UNCOVERED pixels were all opaque
     __shared__ uint32_t stail[32];    // hits queued after each of the last 32 scan steps (ring): which step held a given hit?
     __shared__ uint32_t slast[4];     // per wave: how many of the tile's hits it has gathered (exclusive count)
 
@@ -140,6 +149,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     }
 #endif
     if (tile < 0 || tile >= a.local_tiles) return;
+    const uint32_t guard_now = a.guard ? *a.guard : 0u;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef BL_PROFILE
     unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -163,6 +173,16 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     // depth test against what the opaque pass left (depth writes stay off): a fragment survives iff its quad's
     // window depth <= depth[pixel] (src/GSplatRenderer.C:595-610).  No depth buffer = +inf.
     const float dpx = (HAS_DEPTH && pix_ok) ? depth[(size_t)py * a.width + px] : __builtin_inff();
+    // Per WAVE (= 8x8 quadrant), once: what the opaque pass left under it.  K1 keeps a splat only if -w <= z <= w, so every window
+    // depth in the lists is <= 1 (an IEEE quotient of z <= w is <= 1, and fma(q, 0.5, 0.5) of q <= 1 is <= 1): a quadrant whose
+    // depth buffer was CLEARED TO THE FAR PLANE (all >= 1) passes every fragment -- d_triv -- and runs the plain loop, bit-identical
+    // by construction.  Otherwise d_wmax / d_wmin = the largest / smallest depth under the quadrant (a NaN pixel fails every
+    // fragment: -inf): a record whose window depth exceeds d_wmax can pass nowhere here and is not staged; one at or below d_wmin
+    // passes everywhere and needs no per-pixel compare; only the records in between take the depth-tested loop.
+    // (formed right before the first gather, not here: `dpx` is a load, and consuming it here would put its latency in front of the
+    //  list loads below instead of beside them -- measured: +13 us per C4 launch, five generations of tiles x ~2 us)
+    bool d_triv = true, d_init = !HAS_DEPTH;
+    float d_wmax = __builtin_inff(), d_wmin = __builtin_inff();
 
     const int st = (gty >> a.super_shift) * a.stiles_x + (tx >> a.super_shift);
     const int s = sstart[st];
@@ -175,8 +195,9 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     if (a.slab == 2) {
         // front-slab phase 2: finished tiles keep what they have; the others go on from the stored colour and transmittance
         const uint4 wa = a.tile_work_a[tile];
+        if (a.guard && (guard_now != 0u) != (a.guard_want != 0u)) return;
         if (wa.w & 1u) {
-            if (tid == 0) tile_work[tile] = make_uint4(0u, 0u, 0u, 1u | (0xffffu << 16));
+            if (tid == 0) tile_work[tile] = make_uint4(0u, 0u, 0u, 1u | 0x8000u | (0xffffu << 16));
             return;
         }
         if (pix_ok) {
@@ -186,6 +207,14 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         }
         wave_done = __all(!pix_ok || T < GSR_T_MIN);
     }
+    // Depth-tested frames: a pixel the opaque pass COVERED (depth < 1) may never saturate -- whatever lies in front of the geometry is
+    // all it can ever get, and K1 keeps exactly that for it (k_preprocess.h: zwin <= the largest covered depth of the tile).  What
+    // the depth horizons are about is the tile's UNCOVERED pixels: u_done = they are all opaque, my_last_u = how many of the tile's
+    // hits the wave had gathered by then.  (No depth buffer: u_done is wave_done.)
+    bool u_done = false;
+    uint32_t my_last_u = 0;
+    uint32_t es_u = 0xffu;            // (uniform) scan steps that hold what the tile's uncovered pixels needed (0xff: unknown / not reached)
+    bool u_all = false;               // (uniform) every wave's uncovered pixels are opaque
     uint32_t fetched = 0;             // (uniform) queued hits handed to the waves
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -213,6 +242,38 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     int first_hit_step = -1;          // (uniform) scan step (1024 entries each) that queued the tile's first hit
     bool saturated = false;           // left because every pixel is opaque, not because the list ended
 
+    // How deep did the tile have to LOOK for its first `c` hits?  Not as deep as it has scanned (the scan runs a batch of hits and a
+    // prefetched step ahead): they sit in the first scan step after which at least that many hits were queued (the ring remembers the
+    // last 32 steps).  All threads call it; returns the number of scan steps (0: none needed, 0xff: unknown / too many).
+    auto ext_steps_of = [&](uint32_t c) __attribute__((always_inline)) -> uint32_t {
+        const int cur = (scan_pos >> 10) - 1;            // the last step that was scanned
+        if (c == 0u) return 0u;
+        if (cur < 0) return 0xffu;
+        const bool reached = lane < 32 && cur - lane >= 0 && stail[(cur - lane) & 31] >= c;
+        const unsigned long long m = __ballot(reached);   // bit l: after step cur - l the queue already held the hit
+        const int k = __builtin_ctzll(~m | (1ull << 63)); // (bit 0 is always set in a wave that sees the ring: everything was queued by the last step)
+        const int e = cur - (k - 1) + 1;
+        return (m & 1ull) == 0ull || e <= 0 || e > 0xfe ? 0xffu : (uint32_t)e;
+    };
+    auto init_depth = [&]() __attribute__((always_inline)) {
+        d_init = true;
+        u_done = __all(!pix_ok || T < GSR_T_MIN || dpx < 1.0f);
+        d_triv = __all(dpx >= 1.0f) && !(a.flags & GSR_FLAG_NO_DEPTH_CLASS);
+        if (a.flags & GSR_FLAG_NO_DEPTH_CLASS) {   // (A/B and test hook: every record is staged and compared per pixel, as before round 6)
+            d_wmax = __builtin_inff(); d_wmin = -__builtin_inff();
+        } else if (!d_triv) {
+            const float ninf = -__builtin_inff();
+            float vmax = pix_ok ? (dpx == dpx ? dpx : ninf) : ninf;
+            float vmin = pix_ok ? (dpx == dpx ? dpx : ninf) : __builtin_inff();
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, d, 64));
+                vmin = __builtin_fminf(vmin, __shfl_xor(vmin, d, 64));
+            }
+            d_wmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vmax)));
+            d_wmin = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vmin)));
+        }
+    };
     BLP(0)
     for (;;) {
         // (1) SCAN until a batch of hits is queued, or the list ends
@@ -254,24 +315,26 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         // the l-th hit, loads its record (the four waves load the same lines: L1 hits), tests it against THIS wave's 8x8
         // quadrant only, and the surviving records go -- still in depth order, by ballot rank -- into the wave's own LDS list.
         // No other wave reads that list, so nothing between here and the end of the batch needs a workgroup barrier.
+        if (round == 0 && a.guard && (guard_now != 0u) != (a.guard_want != 0u)) return;   // (uniform) a void launch: the other kernel draws this frame
         const int avail = (int)(q_tail - q_head);
         const int take = avail < batch ? avail : batch;
         if (take == 0) break;                         // list exhausted and queue empty
         fetched += (uint32_t)take;
         BLP(2)
+        if (HAS_DEPTH && !d_init) init_depth();
         if (!wave_done) {
             for (int sub = 0; sub < take; sub += 64) {
                 my_last = q_head + (uint32_t)(sub + 64 < take ? sub + 64 : take);
                 const bool have = sub + lane < take;
                 float4 r1, r2;
                 float rz = 0.0f, c0 = 0.0f, c1 = 0.0f;
-                bool hit = false, pending = false;
+                bool hit = false, pending = false, dtest = false;
                 if (have) {
                     const uint32_t ridx = q[(q_head + (uint32_t)(sub + lane)) & (BL_QCAP - 1)];
                     const float4* p = reinterpret_cast<const float4*>(recs + ridx);
                     const float4 r0 = p[0];
                     r1 = p[1]; r2 = p[2];
-                    rz = HAS_DEPTH ? zwin[ridx] : 0.0f;
+                    rz = (HAS_DEPTH && !d_triv) ? zwin[ridx] : 0.0f;
                     // Can the splat touch this quadrant?  Separating-axis test of the oriented quad (shrunk to the radius
                     // where alpha can still reach 1/255) against the quadrant's box of pixel centres: the box axes (= bbox
                     // test) and the quad's own two axes.  Conservative.
@@ -286,6 +349,10 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     const float pu = __builtin_fabsf(ddx * r1.x + ddy * r1.y);
                     const float pv = __builtin_fabsf(ddx * r1.z + ddy * r1.w);
                     hit = box && (((a.flags & GSR_FLAG_NO_SAT) != 0) || (pu <= lim1 && pv <= lim2));
+                    if (HAS_DEPTH && !d_triv) {
+                        hit = hit && (rz <= d_wmax);          // behind everything the opaque pass left under this quadrant: no fragment passes
+                        dtest = hit && !(rz <= d_wmin);       // in front of all of it: every fragment passes
+                    }
                     pending = __builtin_bit_cast(uint32_t, r2.x) == GSR_COLOUR_PENDING;
                     if (LAZY) {
                         if (hit && pending) gsr_splat_colour_from_row(lz.f, lz.colrow, ridx, r2.x, r2.y, r2.z);
@@ -302,6 +369,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                 }
                 const unsigned long long bal = __ballot(hit);
                 const int cnt = (int)__builtin_popcountll(bal);     // wave-uniform (scalar)
+                const bool dslow = HAS_DEPTH && __any(dtest);       // (uniform) some staged record needs the per-pixel depth compare
                 if (hit) {
                     const uint32_t pos = (uint32_t)__builtin_popcountll(bal & lt_mask);
                     float* blk = reinterpret_cast<float*>(&slist[wave][(pos >> 1) * PF4]);
@@ -316,7 +384,10 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     blk[1] = 0.0f; blk[3] = 0.0f; blk[5] = 0.0f; blk[7] = 0.0f;
                     blk[9] = 0.0f; blk[11] = 0.0f;
                     // colour 0, la -inf (the axes may be stale garbage: a NaN there is rejected by the quad test)
-                    reinterpret_cast<float4*>(blk)[4] = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
+                    {   // (volatile scalar stores: as one float4 constant the compiler kept it live across the whole kernel -- and spilt it)
+                        volatile float* vb = blk;
+                        vb[16] = 0.0f; vb[17] = 0.0f; vb[18] = 0.0f; vb[19] = -__builtin_inff();
+                    }
                     if (HAS_DEPTH) blk[21] = 0.0f;
                 }
                 // the list is written and read by this wave only: LDS operations of one wave execute in order
@@ -329,13 +400,13 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                 const int npairs = (cnt + 1) >> 1;
                 const float4* L = slist[wave];
                 struct PairOps { float4 v0, v1, v2, v3, v4, v5; };
-                auto load_pair = [&](int p) __attribute__((always_inline)) {
+                auto load_pair = [&](auto with_depth, int p) __attribute__((always_inline)) {
                     PairOps o;
                     o.v0 = L[p * PF4 + 0]; o.v1 = L[p * PF4 + 1]; o.v2 = L[p * PF4 + 2]; o.v3 = L[p * PF4 + 3]; o.v4 = L[p * PF4 + 4];
-                    o.v5 = HAS_DEPTH ? L[p * PF4 + 5] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if constexpr (decltype(with_depth)::value) o.v5 = L[p * PF4 + 5]; else o.v5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     return o;
                 };
-                auto blend_ops = [&](const PairOps& o, gsr_v2f& C01, float& C2, float& T) __attribute__((always_inline)) {
+                auto blend_ops = [&](auto with_depth, const PairOps& o, gsr_v2f& C01, float& C2, float& T) __attribute__((always_inline)) {
                     const float4 v0 = o.v0, v1 = o.v1, v2 = o.v2, v3 = o.v3, v4 = o.v4;
                     // kappa * (quad-local coordinate) of this pixel for the two records
                     const gsr_v2f q0 = gsr_fma2(lx, (gsr_v2f){v0.x, v0.y}, gsr_fma2(ly, (gsr_v2f){v0.z, v0.w}, (gsr_v2f){v2.x, v2.y}));
@@ -349,7 +420,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     const float alb = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(argb), 0.0f), 1.0f);
                     bool ina = (__builtin_fmaxf(__builtin_fabsf(q0.x), __builtin_fabsf(q1.x)) <= GSR_QLIM) && (arga >= -GSR_LOG2_255);
                     bool inb = (__builtin_fmaxf(__builtin_fabsf(q0.y), __builtin_fabsf(q1.y)) <= GSR_QLIM) && (argb >= -GSR_LOG2_255);
-                    if (HAS_DEPTH) {
+                    if constexpr (decltype(with_depth)::value) {
                         const float4 v5 = o.v5;
                         ina = ina && (v5.x <= dpx);
                         inb = inb && (v5.y <= dpx);
@@ -368,7 +439,10 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     C2 = gsr_fma(wb, v4.z, C2);
                     T = T - wb;
                 };
-                auto blend_pair = [&](int p, gsr_v2f& C01, float& C2, float& T) __attribute__((always_inline)) { blend_ops(load_pair(p), C01, C2, T); };
+                typedef std::integral_constant<bool, false> no_depth_t;
+                typedef std::integral_constant<bool, true> depth_t;
+                auto blend_pair = [&](int p, gsr_v2f& C01, float& C2, float& T) __attribute__((always_inline)) { blend_ops(no_depth_t(), load_pair(no_depth_t(), p), C01, C2, T); };
+                auto blend_pair_d = [&](int p, gsr_v2f& C01, float& C2, float& T) __attribute__((always_inline)) { blend_ops(depth_t(), load_pair(depth_t(), p), C01, C2, T); };
 #ifdef BL_EXP_DOUBLE   // experiment: the inner loop a second time on shadow accumulators (its marginal cost = the time difference)
                 {
                     gsr_v2f sC01 = C01; float sC2 = C2, sT = T;
@@ -381,7 +455,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                 // BL_CHECK pairs per trip, straight-line (one loop branch and one "all opaque?" ballot per BL_CHECK pairs: written pair by
                 // pair the compiler left four branches and twenty scalar instructions in every iteration), then the remainder
                 int p = 0;
-                if (!HAS_DEPTH) {
+                if (!HAS_DEPTH || !dslow) {   // (no staged record needs the depth compare: the plain loop -- a weight-0 blend and a skipped one leave C, T bit-identical)
                     const int nfull = npairs & ~(BL_CHECK - 1);
                     bool stop = false;
                     for (; p < nfull && !stop; p += BL_CHECK) {
@@ -393,19 +467,21 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                         for (; p < npairs; ++p) blend_pair(p, C01, C2, T);
                 } else {   // (the depth-tested form carries a sixth operand vector per pair: unrolled it spills)
                     for (; p < npairs; ++p) {
-                        blend_pair(p, C01, C2, T);
+                        blend_pair_d(p, C01, C2, T);
                         if ((p & (BL_CHECK - 1)) == BL_CHECK - 1 && __all(!pix_ok || T < GSR_T_MIN)) { ++p; break; }
                     }
                 }
                 my_evals += (uint32_t)(2 * p < cnt ? 2 * p : cnt);
                 BLP(4)
+                if (HAS_DEPTH && !u_done && __all(!pix_ok || T < GSR_T_MIN || dpx < 1.0f)) { u_done = true; my_last_u = my_last; }
                 if (__all(!pix_ok || T < GSR_T_MIN)) { wave_done = true; break; }
                 __builtin_amdgcn_wave_barrier();   // (the next sub-round overwrites the list)
             }
         }
         q_head += (uint32_t)take;
         const int rpar = round & 1;
-        if (lane == 0) { sdone[rpar][wave] = wave_done ? 1u : 0u; slast[wave] = my_last; }
+        if (HAS_DEPTH && wave_done && !u_done) { u_done = true; my_last_u = my_last; }
+        if (lane == 0) { sdone[rpar][wave] = (wave_done ? 1u : 0u) | ((HAS_DEPTH ? u_done : wave_done) ? 2u : 0u); slast[wave] = my_last; if (HAS_DEPTH) slastu[wave] = my_last_u; }
         ++round;
         BLP(5)
         __syncthreads();   // the consumed queue slots may be overwritten from here on; every wave's verdict is in
@@ -414,7 +490,12 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
             if (tid == 0 && lz.redo) lz.redo[atomicAdd(lz.redo_count, 1u)] = tile;
             return;
         }
-        if ((sdone[rpar][0] & sdone[rpar][1] & sdone[rpar][2] & sdone[rpar][3]) != 0u) { saturated = true; break; }
+        const uint32_t dall = sdone[rpar][0] & sdone[rpar][1] & sdone[rpar][2] & sdone[rpar][3];
+        if (HAS_DEPTH && !u_all && (dall & 2u)) {   // (uniform) the moment the tile's uncovered pixels were all opaque: how deep had it looked?
+            u_all = true;
+            es_u = ext_steps_of(max(max(slastu[0], slastu[1]), max(slastu[2], slastu[3])));
+        }
+        if ((dall & 1u) != 0u) { saturated = true; break; }
     }
     if (pix_ok) {
         // (pixel coordinates re-derived from an opaque copy of the thread id: keeping them live across the loop costs a spill)
@@ -439,27 +520,21 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     __syncthreads();  // orders the sevals = 0 store when the list was empty
     if (lane == 0) atomicAdd(&sevals, my_evals);
     __syncthreads();
-    // How deep did the tile have to LOOK?  Not as deep as it scanned (the scan runs a batch of hits and a prefetched step ahead):
-    // the deepest hit any wave gathered sits in the first scan step after which at least that many hits were queued.
-    int ext_steps = 0;
-    {
-        const uint32_t c = max(max(slast[0], slast[1]), max(slast[2], slast[3]));
-        const int cur = (scan_pos >> 10) - 1;            // the last step that was scanned
-        if (wave == 0 && c > 0u && cur >= 0) {
-            const bool reached = lane < 32 && cur - lane >= 0 && stail[(cur - lane) & 31] >= c;
-            const unsigned long long m = __ballot(reached);   // bit l: after step cur - l the queue already held the hit
-            const int k = __builtin_ctzll(~m);               // (bit 0 is always set: everything was queued by the last step)
-            ext_steps = cur - (k - 1) + 1;
-        }
+    if (HAS_DEPTH && !d_init) init_depth();      // (a tile without a single hit)
+    const uint32_t es_c = ext_steps_of(max(max(slast[0], slast[1]), max(slast[2], slast[3])));   // (everything the tile gathered)
+    if (!HAS_DEPTH) { u_all = saturated; es_u = es_c; }
+    else if (!u_all) {   // (the list ended first: the last batch's verdicts)
+        const uint32_t dl = sdone[(round - 1) & 1][0] & sdone[(round - 1) & 1][1] & sdone[(round - 1) & 1][2] & sdone[(round - 1) & 1][3];
+        if (round > 0 ? (dl & 2u) != 0u : __syncthreads_and(u_done ? 1 : 0) != 0) { u_all = true; es_u = round > 0 ? ext_steps_of(max(max(slastu[0], slastu[1]), max(slastu[2], slastu[3]))) : 0u; }
     }
     if (tid == 0) {
         // entries actually read: everything up to scan_pos plus the prefetched step
         const int rd = scan_pos + 1024;
-        // (.w: bit 0 = went opaque; bits 1..15 = the 1024-entry scan step that held the tile's first hit; bits 16..31 = the number of
-        //  scan steps that hold everything the tile gathered, 0xffff = unknown / too many: fall back to .x)
-        const uint32_t fs = (uint32_t)(first_hit_step < 0 ? 0 : (first_hit_step > 0x7fff ? 0x7fff : first_hit_step));
-        const uint32_t es = (uint32_t)(ext_steps <= 0 || ext_steps > 0xfffe ? 0xffff : ext_steps);
-        const uint4 tw = make_uint4((uint32_t)(rd < n ? rd : n), fetched, sevals, (saturated ? 1u : 0u) | (fs << 1) | (es << 16));
+        // (.w: bit 0 = every pixel went opaque; bits 1..14 = the 1024-entry scan step that held the tile's first hit; bit 15 = the tile's
+        //  UNCOVERED pixels all went opaque (no depth buffer: bit 0 again); bits 16..23 = the number of scan steps that hold everything
+        //  the tile gathered, bits 24..31 = ... everything it had gathered when bit 15 came true; 0xff = unknown / too many: fall back to .x)
+        const uint32_t fs = (uint32_t)(first_hit_step < 0 ? 0 : (first_hit_step > 0x3fff ? 0x3fff : first_hit_step));
+        const uint4 tw = make_uint4((uint32_t)(rd < n ? rd : n), fetched, sevals, (saturated ? 1u : 0u) | (fs << 1) | (u_all ? 0x8000u : 0u) | (es_c << 16) | (es_u << 24));
         tile_work[tile] = tw;   // (k_sum_work turns these into colour prefixes, depth horizons and the frame's culling verdict)
         // work of the tile's super-tile, for k_tile_order (fire and forget: ~60 tiles per address and frame)
         if (a.sup_work && gsr_tile_weight(tw)) atomicAdd(&a.sup_work[st], gsr_tile_weight(tw));
@@ -587,10 +662,15 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
     e0 = e0 < hz.list_cap ? e0 : hz.list_cap;
     const uint32_t len = (own && e0 > s0) ? (uint32_t)(e0 - s0) : 0u;
     // how deep the tile looked: the scan steps that hold everything it gathered (k_blend), never more than it read
-    const uint32_t es = w.w >> 16;
-    const uint32_t rd = (es == 0xffffu || (es << 10) > w.x) ? w.x : (es << 10);
-    const bool opaque = own && (w.w & 1u) != 0u;
-    const uint32_t first = ((w.w >> 1) & 0x7fffu) << 10;   // list position (1024-entry granularity) of the tile's first hit
+    // Two notions of "opaque" (k_blend): EVERY pixel (bit 0: what the lazy-colour prefixes, the front slab and the counters go by) and
+    // every UNCOVERED pixel (bit 15: what the horizons go by -- a pixel the opaque pass covered gets what lies in front of the geometry
+    // through K1's depth clause, exactly, whether or not it saturates; without a depth buffer the two are the same)
+    const uint32_t es_all = (w.w >> 16) & 0xffu, es = w.w >> 24;
+    const uint32_t rd_all = (es_all == 0xffu || (es_all << 10) > w.x) ? w.x : (es_all << 10);
+    const uint32_t rd = (es == 0xffu || (es << 10) > w.x) ? w.x : (es << 10);
+    const bool opaque_all = own && (w.w & 1u) != 0u;
+    const bool opaque = own && (w.w & 0x8000u) != 0u;
+    const uint32_t first = ((w.w >> 1) & 0x3fffu) << 10;   // list position (1024-entry granularity) of the tile's first hit
     // where the tile's next horizon sits: a quarter of what it scanned from its first hit on (+1024 entries) beyond the scan -- a
     // tile high up in a super-tile over oblique ground starts deep in the shared list, and that part is not its depth range
     const uint32_t want = rd + ((rd > first ? rd - first : 0u) >> 2) + 1024u;
@@ -598,7 +678,7 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
         // lanes (Morton order): reduce over them first -- atomics that share a cache line serialise like atomics on one address
         // (8160 of them on five lines took 20 us).
         const int gs = g.super_shift < 3 ? g.super_shift : 3;     // the part of a super-tile inside this 8x8 block: 4^gs lanes
-        uint32_t m = opaque ? rd : 0u, open = (own && !opaque && !a_done) ? 1u : 0u, any = own ? 1u : 0u;
+        uint32_t m = opaque_all ? rd_all : 0u, open = (own && !opaque_all && !a_done) ? 1u : 0u, any = own ? 1u : 0u;
         for (int d = 1; d < (1 << (2 * gs)); d <<= 1) {
             const uint32_t om = __shfl_xor(m, d, 64), oo = __shfl_xor(open, d, 64), oa = __shfl_xor(any, d, 64);
             m = om > m ? om : m; open |= oo; any |= oa;
@@ -623,12 +703,15 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
         { const float dx = P2.x - hz.cam[0], dy = P2.y - hz.cam[1], dz = P2.z - hz.cam[2]; hnew = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx)); }
         float h = 0.0f;                    // outside the image / another rank's tile: nothing is needed there
         if (own) {
-            // this frame: a tile with a horizon must have gone opaque without looking past it
-            if (hold < 3.0e38f && (!opaque || !c1 || !(klast <= hold))) viol = 1u;
+            // this frame: a tile with a horizon must have gone opaque without looking past it (a tile whose uncovered pixels needed
+            // nothing at all -- the opaque pass covers it -- has looked at nothing)
+            const bool none = opaque && rd == 0u;
+            if (hold < 3.0e38f && !none && (!opaque || !c1 || !(klast <= hold))) viol = 1u;
             // next frame: the key a quarter (+1024 entries) beyond the scan; a list too short for that was itself thinned by
             // culling -- then the old horizon is pushed out by 5 % (in distance^2) instead
             h = __builtin_inff();
-            if (opaque) {
+            if (none) h = 0.0f;
+            else if (opaque) {
                 if (c2) h = hnew;
                 else if (hold < 3.0e38f) h = hold * 1.05f;
             }
@@ -702,9 +785,9 @@ k_slab_mid(const uint4* __restrict__ tile_work_a, GsrSumArgs g, const int32_t* _
     }
     if (hz.raw) {
         const uint32_t len = (own && e0 > s0) ? (uint32_t)(e0 - s0) : 0u;
-        const uint32_t es = w.w >> 16;
-        const uint32_t rd = (es == 0xffffu || (es << 10) > w.x) ? w.x : (es << 10);
-        const uint32_t first = ((w.w >> 1) & 0x7fffu) << 10;
+        const uint32_t es = (w.w >> 16) & 0xffu;      // (a finished tile: every pixel opaque, covered or not)
+        const uint32_t rd = (es == 0xffu || (es << 10) > w.x) ? w.x : (es << 10);
+        const uint32_t first = ((w.w >> 1) & 0x3fffu) << 10;
         const uint32_t want = rd + ((rd > first ? rd - first : 0u) >> 2) + 1024u;
         const bool c2 = opaque && rd > 0u && rd <= len && want < len;
         const uint32_t i2 = hz.lists[c2 ? (uint32_t)s0 + want : 0u].x;

@@ -145,6 +145,140 @@ __device__ __forceinline__ float gsr_pyr_max(const float* __restrict__ pyr, cons
     return h;
 }
 
+// ---- depth-tested frames (the reference draws with the depth test on, src/GSplatRenderer.C:595-610) -------------------
+// What the opaque pass left, as TWO tile-max pyramids over the same tile grid and level offsets as the horizons (levels 0..3):
+//   pyr   the largest depth under the tile.  A splat whose window depth exceeds it for every tile its rect reaches fails the test
+//         `zwin <= depth[pixel]` at every fragment: K1 and k_cluster_cull drop it (no colour, no record, no sorting, no list entry)
+//         instead of k_blend discarding it fragment by fragment.  Exact, whatever else the frame does.
+//   pyrc  the largest depth among the tile's COVERED pixels (depth < 1: the opaque pass drew something there), 0 if it has none.
+//         A covered pixel may never saturate, so no depth horizon can speak for it: the horizons are formed from the tiles'
+//         uncovered pixels alone (k_blend.h: bit 15 of the bookkeeping), and a splat beyond the horizons of its rect is dropped
+//         only if it is ALSO behind everything the opaque pass left under the covered pixels there (zwin > pyrc): the covered pixels
+//         get what lies in front of the geometry, exactly, without any prediction.
+// Values are clamped to >= 0 (window depths are >= 0, and a NaN pixel passes nothing), so their bit patterns order like unsigned
+// integers.  active[par] != 0 iff some pixel is covered: every window depth K1 keeps is <= 1, so under a buffer that was merely
+// cleared to the far plane nothing changes and the look-ups are skipped.
+struct GsrDepthCull {
+    const float* pyr;          // NULL = no culling against the opaque pass's depth
+    const float* pyrc;
+    const uint32_t* active;    // the word of this frame's parity
+};
+struct GsrDepthPyrArgs {
+    const float* depth;        // [height][width] window depth of the opaque pass (row 0 = bottom, like the framebuffer)
+    float* pyr;                // the two pyramids of this frame's parity ...
+    float* pyrc;
+    float* pyr_next;           // ... and the other parity's: levels 4 and 5 are max-reduced with atomics (like the horizons'), so this frame
+    float* pyrc_next;          //     clears them for the slot's next depth-tested frame
+    uint32_t* active;          // [2]: this frame sets [par], and clears [par ^ 1] likewise
+    int32_t par;
+    int32_t width, height, tiles_x, tiles_y;
+    int32_t off[GSR_PYR_LEVELS];
+};
+// largest value over the tile rect [x0, x1] x [y0, y1] of a depth pyramid (levels 0 .. GSR_DPYR_LEVELS - 1); +inf -- "unknown": nothing
+// is culled on its account -- for a rect that spans more than 2 x 2 cells of the top level (more than 512 pixels)
+#define GSR_DPYR_LEVELS 5
+__device__ __forceinline__ float gsr_dpyr_max(const float* __restrict__ pyr, const int32_t* pyr_off, int tiles_x, int x0, int y0, int x1, int y1)
+{
+    const int span = max(x1 - x0, y1 - y0);
+    int L = 31 - __builtin_clz((uint32_t)span | 1u);
+    if (((x1 >> L) - (x0 >> L)) > 1 || ((y1 >> L) - (y0 >> L)) > 1) ++L;
+    if (L >= GSR_DPYR_LEVELS) return __builtin_inff();
+    const int w = gsr_pyr_dim(tiles_x, L);
+    const float* p = pyr + pyr_off[L];
+    const int a0 = x0 >> L, a1 = x1 >> L, b0 = y0 >> L, b1 = y1 >> L;
+    return __builtin_fmaxf(__builtin_fmaxf(p[b0 * w + a0], p[b0 * w + a1]), __builtin_fmaxf(p[b1 * w + a0], p[b1 * w + a1]));
+}
+// One workgroup per 8 x 8 block of tiles (128 x 128 pixels, 64 KB), THREADS = 1024 in the launch of its own (four 16-byte loads per
+// thread, issued together: the pass is a latency chain, not a bandwidth problem -- 8.3 MB at 1080p), 256 as the first workgroups of
+// k_cluster_cull's launch (sixteen loads per thread, hidden beside the cluster tests).  Tile maxima meet in LDS, the first wavefront
+// (lane = tile in Morton order) writes level 0 and shuffles levels 1..3 together like k_horizon_dilate; level 4 is max-reduced with
+// two atomics per workgroup into cells the slot's PREVIOUS depth-tested frame cleared (the pyramids are double-buffered by frame
+// parity for that; atomics on one cache line serialise at ~12 ns each: one per 2 x 2-tile group on levels 2..5 took 10 us).
+__host__ __device__ __forceinline__ int gsr_depth_pyramid_blocks(int tiles_x, int tiles_y) { return ((tiles_x + 7) >> 3) * ((tiles_y + 7) >> 3); }
+template <int THREADS>
+__device__ __forceinline__ void gsr_depth_pyramid_block(const GsrDepthPyrArgs& a, const int b)
+{
+    static_assert(THREADS == 256 || THREADS == 1024, "rows of 32 lanes");
+    constexpr int RP = THREADS / 32, NL = 128 / RP;          // pixel rows per pass, loads per thread
+    __shared__ uint32_t s_tile[64], s_tilec[64], s_cov;
+    const int tid = threadIdx.x;
+    const int nbx = (a.tiles_x + 7) >> 3;
+    const int by = b / nbx, bx = b - by * nbx;
+    if (tid < 64) { s_tile[tid] = 0u; s_tilec[tid] = 0u; }
+    if (tid == 0) s_cov = 0u;
+    if (b == 0) {
+        if (tid == 0) a.active[a.par ^ 1] = 0u;
+        const int n4 = gsr_pyr_dim(a.tiles_x, 4) * gsr_pyr_dim(a.tiles_y, 4);
+        for (int i = tid; i < n4; i += THREADS) { a.pyr_next[a.off[4] + i] = 0.0f; a.pyrc_next[a.off[4] + i] = 0.0f; }
+    }
+    __syncthreads();
+    const int c4 = tid & 31, r = tid >> 5;
+    const int px0 = bx * 128 + c4 * 4;
+    const bool vec = ((a.width & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.depth) & 15u) == 0u);   // (uniform)
+    float4 q[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {            // (all loads first)
+        const int row = by * 128 + k * RP + r;
+        q[k] = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);   // (no pixel: neither a depth nor a covered one)
+        if (row < a.height && px0 < a.width) {
+            const float* src = a.depth + (size_t)row * a.width + px0;
+            if (vec) {
+                q[k] = *reinterpret_cast<const float4*>(src);
+            } else {
+                q[k].x = src[0];
+                if (px0 + 1 < a.width) q[k].y = src[1];
+                if (px0 + 2 < a.width) q[k].z = src[2];
+                if (px0 + 3 < a.width) q[k].w = src[3];
+            }
+        }
+    }
+    // (per pixel: fmax drops a NaN operand, so a NaN pixel counts as depth 0 -- it passes nothing; covered = depth < 1, which a NaN is not)
+    auto dep = [](float d) { return __builtin_fmaxf(d, 0.0f); };
+    auto cov = [](float d) { return (d < 1.0f && d >= 0.0f) ? d : 0.0f; };    // (a negative depth passes nothing either: 0)
+    bool anyc = false;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int rl = k * RP + r, row = by * 128 + rl;
+        const bool e0 = row < a.height && px0 < a.width, e1 = e0 && px0 + 1 < a.width, e2 = e0 && px0 + 2 < a.width, e3 = e0 && px0 + 3 < a.width;
+        float v = __builtin_fmaxf(__builtin_fmaxf(dep(q[k].x), dep(q[k].y)), __builtin_fmaxf(dep(q[k].z), dep(q[k].w)));
+        float vc = __builtin_fmaxf(__builtin_fmaxf(cov(q[k].x), cov(q[k].y)), __builtin_fmaxf(cov(q[k].z), cov(q[k].w)));
+        anyc = anyc || (e0 && q[k].x < 1.0f) || (e1 && q[k].y < 1.0f) || (e2 && q[k].z < 1.0f) || (e3 && q[k].w < 1.0f);
+        v = __builtin_fmaxf(v, __shfl_xor(v, 1, 64)); vc = __builtin_fmaxf(vc, __shfl_xor(vc, 1, 64));
+        v = __builtin_fmaxf(v, __shfl_xor(v, 2, 64)); vc = __builtin_fmaxf(vc, __shfl_xor(vc, 2, 64));
+        const int t = rl >> 4;                // tile row of the block
+        if ((c4 & 3) == 0 && v > 0.0f) atomicMax(&s_tile[t * 8 + (c4 >> 2)], __float_as_uint(v));
+        if ((c4 & 3) == 0 && vc > 0.0f) atomicMax(&s_tilec[t * 8 + (c4 >> 2)], __float_as_uint(vc));
+    }
+    if (__any(anyc) && (tid & 63) == 0) s_cov = 1u;
+    __syncthreads();
+    if (tid >= 64) return;
+    const int lane = tid;
+    const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const int tx = bx * 8 + lx, ty = by * 8 + ly;
+    const bool inside = tx < a.tiles_x && ty < a.tiles_y;
+    float v = inside ? __uint_as_float(s_tile[ly * 8 + lx]) : 0.0f, vc = inside ? __uint_as_float(s_tilec[ly * 8 + lx]) : 0.0f;
+    if (inside) { a.pyr[a.off[0] + ty * a.tiles_x + tx] = v; a.pyrc[a.off[0] + ty * a.tiles_x + tx] = vc; }
+    if (s_cov && lane == 0) atomicOr(&a.active[a.par], 1u);
+    v = __builtin_fmaxf(v, __shfl_xor(v, 1, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 2, 64));
+    vc = __builtin_fmaxf(vc, __shfl_xor(vc, 1, 64)); vc = __builtin_fmaxf(vc, __shfl_xor(vc, 2, 64));
+    if ((lane & 3) == 0 && inside) { const int o = a.off[1] + (ty >> 1) * gsr_pyr_dim(a.tiles_x, 1) + (tx >> 1); a.pyr[o] = v; a.pyrc[o] = vc; }
+    v = __builtin_fmaxf(v, __shfl_xor(v, 4, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 8, 64));
+    vc = __builtin_fmaxf(vc, __shfl_xor(vc, 4, 64)); vc = __builtin_fmaxf(vc, __shfl_xor(vc, 8, 64));
+    if ((lane & 15) == 0 && inside) { const int o = a.off[2] + (ty >> 2) * gsr_pyr_dim(a.tiles_x, 2) + (tx >> 2); a.pyr[o] = v; a.pyrc[o] = vc; }
+    v = __builtin_fmaxf(v, __shfl_xor(v, 16, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 32, 64));
+    vc = __builtin_fmaxf(vc, __shfl_xor(vc, 16, 64)); vc = __builtin_fmaxf(vc, __shfl_xor(vc, 32, 64));
+    if (lane == 0) {
+        a.pyr[a.off[3] + by * nbx + bx] = v; a.pyrc[a.off[3] + by * nbx + bx] = vc;
+        // (level 4: values are >= 0, their bit patterns order like unsigned integers)
+        const int o4 = a.off[4] + (by >> 1) * gsr_pyr_dim(a.tiles_x, 4) + (bx >> 1);
+        if (v > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(a.pyr) + o4, __float_as_uint(v));
+        if (vc > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(a.pyrc) + o4, __float_as_uint(vc));
+    }
+}
+// a launch of its own: frames whose previous depth buffer held opaque geometry (k_cluster_cull then culls against the pyramid too)
+__global__ void __launch_bounds__(1024)
+k_depth_pyramid(GsrDepthPyrArgs a) { gsr_depth_pyramid_block<1024>(a, (int)blockIdx.x); }
+
 // Front-slab frames: the slab key = the end of the first histogram bin by which `want` of the surviving clusters have begun
 // (want = clamp(total * frac_num / 256, min_clusters, max_clusters)); everything when the frame keeps fewer than twice that.
 // Every workgroup of phase 1's second k_cluster_cull pass works it out for itself from the first pass's histogram (a scan of
@@ -219,8 +353,15 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                float* __restrict__ zero_f, int zero_n,
                uint32_t* __restrict__ bk_zero /* the small-frame sort's bucket counters (BK_BUCKETS, BK_STRIDE apart), or NULL */,
                uint32_t* __restrict__ flag_zero /* ... and its "gave a bucket up" flag: cleared here, BEFORE K1, whose workgroups scatter
-                                                   into the buckets themselves */)
+                                                   into the buckets themselves */,
+               GsrDepthPyrArgs dp, uint32_t n_dp /* depth-tested frames: the FIRST n_dp workgroups build the opaque pass's tile-max pyramid
+                                                    for K1 (beside the cluster tests, not in front of them: no launch of its own) */,
+               GsrDepthCull dc /* ... or the pyramid exists already (k_depth_pyramid ran in front): clusters are tested against it */)
 {
+    static_assert(CC_THREADS == 256, "the folded depth pyramid workgroups are gsr_depth_pyramid_block<256>");
+    if (blockIdx.x < n_dp) { gsr_depth_pyramid_block<256>(dp, (int)blockIdx.x); return; }
+    const uint32_t bid = blockIdx.x - n_dp, nbid = gridDim.x - n_dp;
+    const bool dact = dc.pyr != nullptr && *dc.active != 0u;     // (uniform)
     __shared__ uint32_t s_w[CC_THREADS / 64];
     __shared__ uint32_t s_hist[GSR_SLAB_BINS];
     __shared__ uint32_t s_pick;
@@ -230,22 +371,22 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
     uint32_t key_a = 0xffffffffu;
     if (mode == 1) {
         for (int b = threadIdx.x; b < GSR_SLAB_BINS; b += CC_THREADS) s_hist[b] = 0u;
-        if (blockIdx.x == 0) for (int i = threadIdx.x; i < zero_n; i += CC_THREADS) zero_f[i] = 0.0f;
+        if (bid == 0) for (int i = threadIdx.x; i < zero_n; i += CC_THREADS) zero_f[i] = 0.0f;
         __syncthreads();
     } else if (mode == 2) {
         key_a = gsr_slab_pick(slab_hist, hist_shift, pk, slab, s_w, &s_pick);
         __syncthreads();                                       // (s_w is used again below)
     } else if (mode == 3) {
         key_a = slab[0];
-        if (blockIdx.x == 0) for (int b = threadIdx.x; b < GSR_SLAB_BINS; b += CC_THREADS) slab_hist[b] = 0u;
+        if (bid == 0) for (int b = threadIdx.x; b < GSR_SLAB_BINS; b += CC_THREADS) slab_hist[b] = 0u;
     }
-    if (blockIdx.x == gridDim.x - 1u) {
+    if (bid == nbid - 1u) {
         if (bk_zero) for (int d = threadIdx.x; d < BK_BUCKETS; d += CC_THREADS) bk_zero[(size_t)d * BK_STRIDE] = 0u;
         if (threadIdx.x == 0 && flag_zero) *flag_zero = 0u;
     }
     const bool want_hist = mode == 1;
     for (int r = 0; r < rounds; ++r) {
-        const uint32_t cl = blockIdx.x * per + (uint32_t)r * CC_THREADS + threadIdx.x;
+        const uint32_t cl = bid * per + (uint32_t)r * CC_THREADS + threadIdx.x;
         bool keep = cl < nclus;
         uint32_t kb_near = 0u;                 // a lower bound of the cluster's sort keys (0 = unknown)
         if (keep && enabled) {
@@ -261,7 +402,7 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                 }
                 // clip coordinates are affine in the position: their extrema over the box are at its corners
                 float wmin = 3.0e38f, wmax = -3.0e38f, zpw_max = -3.0e38f, wmz_max = -3.0e38f, tz_min = 3.0e38f, tz_max = -3.0e38f;
-                float cxmin = 3.0e38f, cxmax = -3.0e38f, cymin = 3.0e38f, cymax = -3.0e38f, mag = 0.0f;
+                float cxmin = 3.0e38f, cxmax = -3.0e38f, cymin = 3.0e38f, cymax = -3.0e38f, mag = 0.0f, znmin = 3.0e38f;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const float x = (c & 1) ? hi[0] : lo[0], y = (c & 2) ? hi[1] : lo[1], z = (c & 4) ? hi[2] : lo[2];
@@ -282,6 +423,7 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                     const float px = gsr_fma(clx * iw, 0.5f, 0.5f) * f.W, py = gsr_fma((-cly) * iw, 0.5f, 0.5f) * f.H;
                     cxmin = __builtin_fminf(cxmin, px); cxmax = __builtin_fmaxf(cxmax, px);
                     cymin = __builtin_fminf(cymin, py); cymax = __builtin_fmaxf(cymax, py);
+                    znmin = __builtin_fminf(znmin, clz * iw);          // (z / w is monotone along any line where w > 0: extrema at the corners too)
                 }
                 // rounding of the affine forms (here and in K1): a few ulp of the largest term
                 float prn = 0.0f;
@@ -312,8 +454,21 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                         } else {
                             const int tx0 = (int)__builtin_fmaxf(xlo, 0.0f) >> 4, tx1 = (int)__builtin_fminf(xhi, wm1) >> 4;
                             const int ty0 = (int)__builtin_fmaxf(ylo, 0.0f) >> 4, ty1 = (int)__builtin_fminf(yhi, hm1) >> 4;
+                            bool behind = false, covered_need = false;
+                            if (dact) {
+                                // depth-tested frames: does every splat of the cluster lie behind everything the opaque pass left under the
+                                // tiles the cluster can reach?  A LOWER bound of its splats' window depths: the smallest z / w of the
+                                // corners, less what rounding (here and in K1: eps per clip coordinate) can move a quotient
+                                const float zerr = 1.05f * eps * (1.0f + __builtin_fabsf(znmin)) / (wmin - eps) + 2.0e-7f;
+                                const float zlo = gsr_fma(znmin - zerr, 0.5f, 0.5f) - 2.0e-7f;
+                                behind = zlo > gsr_dpyr_max(dc.pyr, f.pyr_off, f.tiles_x, tx0, ty0, tx1, ty1);
+                                // ... or may a COVERED pixel there need one of them (k_preprocess.h: the depth clause of gsr_k1_back)?
+                                covered_need = !(zlo > gsr_dpyr_max(dc.pyrc, f.pyr_off, f.tiles_x, tx0, ty0, tx1, ty1));
+                            }
                             if (gsr_owned_rows(ty0, ty1, GsrShard{f.shard_index, f.shard_count, f.shard_rpb}) == 0) {
                                 keep = false;                           // none of its tile rows is ours
+                            } else if (behind) {
+                                keep = false;                           // wholly behind the opaque geometry
                             } else if (hpyr || mode != 0) {
                                 // The sort key is the distance^2 of the UN-offset position (k_preprocess.h): bounds from the raw box
                                 float d2 = 0.0f, d2far = 0.0f;
@@ -339,7 +494,7 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                                     if (kf - f.key_min <= key_a) keep = false;
                                 }
                                 // behind the depth horizon of every tile it can reach (widened by the dilation radius)?
-                                if (keep && hpyr) {
+                                if (keep && hpyr && !covered_need) {
                                     const int r_ = f.cull_dilate;
                                     const float h = gsr_pyr_max(hpyr, f.pyr_off, f.tiles_x, max(tx0 - r_, 0), max(ty0 - r_, 0), min(tx1 + r_, f.tiles_x - 1), min(ty1 + r_, f.tiles_y - 1));
                                     if (kb > gsr_horizon_key(h, f.key_min, f.key_max)) keep = false;
@@ -361,11 +516,11 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
         uint32_t before = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < CC_THREADS / 64; ++w) { const uint32_t c = s_w[w]; before += w < wave ? c : 0u; total += c; }
-        if (keep) seg[(size_t)blockIdx.x * per + kept + before + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] = cl;
+        if (keep) seg[(size_t)bid * per + kept + before + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] = cl;
         kept += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) cnt[blockIdx.x] = kept;
+    if (threadIdx.x == 0) cnt[bid] = kept;
     if (want_hist) {   // (Morton-ordered clusters: a workgroup's 256 fall into a few dozen bins)
         __syncthreads();
         for (int b = threadIdx.x; b < GSR_SLAB_BINS; b += CC_THREADS) {

@@ -260,6 +260,11 @@ __device__ __forceinline__ bool gsr_covariance_axes(const GsrFrame& f, const flo
 // (K1), the lazy colour pass and the blend kernel's on-demand fallback: the three produce identical bits.
 #define GSR_COLOUR_PENDING 0x7fc0deadu   // bit pattern of a record's `r` while its colour has not been evaluated (a NaN no
                                          // arithmetic produces: fp16->fp32 NaNs have zero low mantissa bits)
+__device__ __forceinline__ float gsr_finite_colour(float c)
+{
+    if (c != c) return 0.0f;
+    return c > 3.0e38f ? 3.0e38f : (c < -3.0e38f ? -3.0e38f : c);
+}
 __device__ __forceinline__ void gsr_splat_colour(const GsrFrame& f, const uint4* cw, float x, float y, float z,
                                                  float& cr, float& cg, float& cbl)
 {
@@ -286,6 +291,10 @@ __device__ __forceinline__ void gsr_splat_colour(const GsrFrame& f, const uint4*
         cg = gsr_shade_sh(cg, shg, dx, dy, dz, f.sh_order);
         cbl = gsr_shade_sh(cbl, shb, dx, dy, dz, f.sh_order);
     }
+    // (round 6, oracle and kernels together) a colour that is not finite is made finite where it is formed: NaN -> 0, +-inf -> +-3e38.
+    // k_blend blends a REJECTED fragment with weight 0 (no exec-mask juggling), and 0 x inf is NaN: one poisoned splat used to turn
+    // every pixel of every quadrant it was staged in into NaN -- and whether it was staged depends on culling
+    cr = gsr_finite_colour(cr); cg = gsr_finite_colour(cg); cbl = gsr_finite_colour(cbl);
 }
 
 // the splat's 128-byte row (position + 48 colour halves, two sectors) -> colour
@@ -320,6 +329,7 @@ struct GsrK1Front {
     uint32_t kb;        // sort key (distance^2 bits, range-reduced)
     float x, y, z;      // fl32(P - origin) + origin
     float cx, cy, opacity;
+    float zw;           // window depth of the quad (depth-tested frames only)
     bool keep;          // passes the clip tests
     bool far;           // ... but cannot touch this rank's rows / lies behind every horizon it can reach
 };
@@ -362,7 +372,7 @@ gsr_k1_front(const GsrFrame& f, const float4 a, const uint4 b, float* __restrict
     if (f.phase == 1) o.keep = o.keep && o.kb <= slab_key;
     if (f.phase == 2) o.keep = o.keep && o.kb > slab_key;
     o.far = false;
-    o.cx = 0.0f; o.cy = 0.0f;
+    o.cx = 0.0f; o.cy = 0.0f; o.zw = 0.0f;
     if (o.keep) {
         const float ndcx = clx / clw;
         const float ndcy = (-cly) / clw;
@@ -370,7 +380,7 @@ gsr_k1_front(const GsrFrame& f, const float4 a, const uint4 b, float* __restrict
         const float cy = gsr_fma(ndcy, 0.5f, 0.5f) * f.H;
         o.cx = cx; o.cy = cy;
         // every corner carries the centre's z and w: one window depth per quad (depth range 0..1)
-        if (zwin_i) *zwin_i = gsr_fma(clz / clw, 0.5f, 0.5f);
+        if (zwin_i) { o.zw = gsr_fma(clz / clw, 0.5f, 0.5f); *zwin_i = o.zw; }
 
         // A cheap UPPER BOUND of the quad's half extent in pixels, without the covariance chain (lambda1 <= trace(cov2d) <=
         // |J|_F^2 |V|_2^2 |O|_2^2 |diag(s) R^T|_F^2 + 0.6; h <= 2 sqrt2 s1 1.0001 + 0.01).  Conservative, so what it
@@ -398,7 +408,8 @@ gsr_k1_front(const GsrFrame& f, const float4 a, const uint4 b, float* __restrict
 // returns the packed tile rect (GSR_RECT_EMPTY: the splat draws nothing here); writes the record of a splat that draws
 __device__ __forceinline__ uint32_t
 gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, const uint4 b, const uint4* __restrict__ col,
-            GsrRecord* __restrict__ rec, int lazy, const float* __restrict__ hpyr)
+            GsrRecord* __restrict__ rec, int lazy, const float* __restrict__ hpyr, const float* __restrict__ dpyr /* NULL: no depth culling */,
+            const float* __restrict__ dpyrc)
 {
     uint32_t out_rect = GSR_RECT_EMPTY;
     const float x = o.x, y = o.y, z = o.z, cx = o.cx, cy = o.cy, opacity = o.opacity;
@@ -434,13 +445,32 @@ gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, co
     // Every list therefore holds, for each of its tiles, all the splats in front of that tile's horizon; a tile that had to
     // look further than its horizon reports the frame, which is then rendered again without culling (k_sum_work).
     // (The pyramid is read through the cache: at most four gathers, usually of one or two lines.)
+    // (depth-tested frames: "beyond every horizon" is half of the verdict -- see the depth clause below)
+    bool beyond = false;
     if (hpyr && out_rect != GSR_RECT_EMPTY) {
         const int g = f.rect_shift;
         const int x0 = (int)(out_rect & 255u) << g, y0 = (int)((out_rect >> 8) & 255u) << g;
         const int x1 = (((int)((out_rect >> 16) & 255u) + 1) << g) - 1, y1 = (((int)(out_rect >> 24) + 1) << g) - 1;
         const int r = f.cull_dilate;
         const float h = gsr_pyr_max(hpyr, f.pyr_off, f.tiles_x, max(x0 - r, 0), max(y0 - r, 0), min(x1 + r, f.tiles_x - 1), min(y1 + r, f.tiles_y - 1));
-        if (o.kb > gsr_horizon_key(h, f.key_min, f.key_max)) out_rect = GSR_RECT_EMPTY;
+        beyond = o.kb > gsr_horizon_key(h, f.key_min, f.key_max);
+        if (beyond && !dpyr) out_rect = GSR_RECT_EMPTY;
+    }
+    // Depth-tested frames: the quad carries ONE window depth (o.zw) and a fragment survives iff zw <= depth[pixel]
+    // (src/GSplatRenderer.C:595-610).  Two rules (k_cluster.h: the two tile-max pyramids of the depth buffer):
+    //  * beyond the largest depth the opaque pass left under every tile the rect reaches, no fragment survives: dropped, whatever the
+    //    horizons say;
+    //  * the horizons speak for the tiles' UNCOVERED pixels only (a pixel under opaque geometry may never saturate): a splat beyond
+    //    them is dropped only if it is also behind everything under the COVERED pixels of its tiles -- those get what lies in front of
+    //    the geometry exactly, with no prediction to verify.  (Culling by depth INSIDE the horizons was tried first and spoilt them: k_tile_pass
+    //    places a horizon a quarter + 1024 entries down the list, a list cut at the geometry is "too short" for that, and the fallback
+    //    pushes the horizon out by 5 % per frame for good -- 13 k surviving clusters became 45 k on C4 with a sphere under 30 % of the frame.)
+    if (dpyr && out_rect != GSR_RECT_EMPTY) {
+        const int g = f.rect_shift;
+        const int x0 = (int)(out_rect & 255u) << g, y0 = (int)((out_rect >> 8) & 255u) << g;
+        const int x1 = min((((int)((out_rect >> 16) & 255u) + 1) << g) - 1, f.tiles_x - 1), y1 = min((((int)(out_rect >> 24) + 1) << g) - 1, f.tiles_y - 1);
+        if (o.zw > gsr_dpyr_max(dpyr, f.pyr_off, f.tiles_x, x0, y0, x1, y1)) out_rect = GSR_RECT_EMPTY;
+        else if (beyond && o.zw > gsr_dpyr_max(dpyrc, f.pyr_off, f.tiles_x, x0, y0, x1, y1)) out_rect = GSR_RECT_EMPTY;
     }
     if (out_rect != GSR_RECT_EMPTY) {
         // colour: Cd, optionally + SH (:224, :244-274) -- or left PENDING for the lazy colour pass (k_colour.h)
@@ -506,7 +536,8 @@ gsr_k1_body(uint32_t n, uint32_t cap, const GsrFrame& f,
              uint32_t* __restrict__ zero_n /* the count of sorted splats, cleared here */,
              const uint32_t* __restrict__ order /* position-keyed order (GSR_OPT_SORT_CACHE = 2): slot j holds splat order[j], the splats
                                                    are walked nearest first and leave already sorted; NULL = storage order */,
-             const uint32_t* __restrict__ slab /* front-slab frames (f.phase != 0): [0] = the slab key (k_slab_pick) */)
+             const uint32_t* __restrict__ slab /* front-slab frames (f.phase != 0): [0] = the slab key (k_slab_pick) */,
+             GsrDepthCull dc /* depth-tested frames: the opaque pass's tile-max depth pyramid (k_cluster.h), pyr = NULL otherwise */)
 {
     static_assert(GSR_K1_THREADS == 4 * GSR_CLUSTER, "a K1 workgroup is four clusters");
     __shared__ uint32_t s_inc[CC_MAX_GROUPS];
@@ -526,6 +557,7 @@ gsr_k1_body(uint32_t n, uint32_t cap, const GsrFrame& f,
     int sc_shift = sc.shift;
     if (sc.key && sc.range_dev) { sc_lo = sc.range_dev[0]; sc_shift = (int)sc.range_dev[1]; }
     const uint32_t slab_key = (f.phase != 0 && slab) ? slab[0] : 0xffffffffu;
+    const float* const dpyr = (dc.pyr && *dc.active != 0u) ? dc.pyr : (const float*)nullptr;   // (uniform: nothing changes under a cleared depth buffer)
     int par = 0;
     for (uint32_t k = blockIdx.x; k < niter; k += gridDim.x, par ^= 1) {
         const uint32_t rank = 4u * k + (uint32_t)wave;
@@ -544,7 +576,7 @@ gsr_k1_body(uint32_t n, uint32_t cap, const GsrFrame& f,
                 if (k == blockIdx.x && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_kprof[4][2] = wall_clock64(); }
 #endif
                 const GsrK1Front o = gsr_k1_front(f, a, b, zwin ? zwin + i : nullptr, slab_key);
-                if (o.keep && !o.far) out_rect = gsr_k1_back(f, i, cap, o, b, col, rec, LAZY ? 1 : 0, hpyr);
+                if (o.keep && !o.far) out_rect = gsr_k1_back(f, i, cap, o, b, col, rec, LAZY ? 1 : 0, hpyr, dpyr, dc.pyrc);
                 kb = o.kb;
             }
         }
@@ -587,8 +619,9 @@ gsr_k1_body(uint32_t n, uint32_t cap, const GsrFrame& f,
 #define GSR_K1_PARAMS uint32_t n, uint32_t cap, GsrFrame f, const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col, \
                       GsrRecord* __restrict__ rec, uint32_t* __restrict__ key, uint2* __restrict__ val, float* __restrict__ zwin, const float* __restrict__ hpyr, \
                       uint32_t* __restrict__ blk_cnt, const uint32_t* __restrict__ cseg, const uint32_t* __restrict__ ccnt, uint32_t ngroups, uint32_t cper, \
-                      uint32_t* __restrict__ d_counts, GsrK1Scatter sc, uint32_t* __restrict__ zero_n, const uint32_t* __restrict__ order, const uint32_t* __restrict__ slab
-#define GSR_K1_ARGS n, cap, f, geoA, geoB, col, rec, key, val, zwin, hpyr, blk_cnt, cseg, ccnt, ngroups, cper, d_counts, sc, zero_n, order, slab
+                      uint32_t* __restrict__ d_counts, GsrK1Scatter sc, uint32_t* __restrict__ zero_n, const uint32_t* __restrict__ order, const uint32_t* __restrict__ slab, \
+                      GsrDepthCull dc
+#define GSR_K1_ARGS n, cap, f, geoA, geoB, col, rec, key, val, zwin, hpyr, blk_cnt, cseg, ccnt, ngroups, cper, d_counts, sc, zero_n, order, slab, dc
 // the two entry points: colours evaluated here (eager: 80 VGPRs, 6 waves per SIMD) or left pending (52 VGPRs, 8 waves per SIMD)
 __global__ void __launch_bounds__(GSR_K1_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_K1_WAVES_PER_EU)))
 k_preprocess(GSR_K1_PARAMS) { gsr_k1_body<false>(GSR_K1_ARGS); }

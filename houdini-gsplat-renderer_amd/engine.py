@@ -439,6 +439,10 @@ class Engine:
     def render_struct_to_device(self, cam_struct: gsr_camera, device_ptr: int):
         _check(self.L.gsr_render(self.h, C.byref(cam_struct), C.c_void_p(device_ptr), 1))
 
+    def render_struct_depth_to_device(self, cam_struct: gsr_camera, depth_device_ptr: int, device_ptr: int):
+        """depth-tested frame, both buffers in device memory: what the viewport hook issues on every redraw (hdk/DM_GSplatHook_hip.C)"""
+        _check(self.L.gsr_render_depth(self.h, C.byref(cam_struct), C.c_void_p(depth_device_ptr), 1, C.c_void_p(device_ptr), 1))
+
     def stitch_bands(self, gathered_ptr: int, count: int, width: int, height: int, out_ptr: int):
         _check(self.L.gsr_stitch_bands(self.h, C.c_void_p(gathered_ptr), count, width, height, C.c_void_p(out_ptr)))
 

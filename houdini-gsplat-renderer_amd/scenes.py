@@ -294,6 +294,26 @@ def make_config(name: str, n_override: int | None = None) -> tuple[Splats, dict]
     return s, cfg
 
 
+def sphere_occluder_depth(cam, centre_distance: float, radius: float) -> np.ndarray:
+    """The opaque pass's depth buffer (float32 [H, W] window depth in [0, 1], row 0 = bottom, cleared to the far plane = 1.0) with one
+    opaque SPHERE in it, centred on the view axis `centre_distance` in front of the camera: what the Houdini hook hands the renderer
+    when opaque geometry sits among the splats (the reference draws with the depth test on, src/GSplatRenderer.C:595-610).  Ray-traced
+    on the host in float64 through cam.proj (any perspective projection whose clip w = -z)."""
+    W, H = cam.width, cam.height
+    P = np.asarray(cam.proj, dtype=np.float64).reshape(4, 4).T
+    i = (np.arange(W) + 0.5) / W * 2.0 - 1.0
+    j = (np.arange(H) + 0.5) / H * 2.0 - 1.0
+    dx = ((i - P[0, 2]) / P[0, 0])[None, :]
+    dy = ((j - P[1, 2]) / P[1, 1])[:, None]
+    a = dx * dx + dy * dy + 1.0
+    disc = centre_distance ** 2 - a * (centre_distance ** 2 - radius ** 2)
+    hit = disc >= 0.0
+    t = (centre_distance - np.sqrt(np.where(hit, disc, 0.0))) / a          # view z of the surface = -t
+    ndc = (P[2, 2] * (-t) + P[2, 3]) / t
+    depth = np.where(hit & (t > 0.0), 0.5 * ndc + 0.5, 1.0)
+    return np.ascontiguousarray(np.clip(depth, 0.0, 1.0), dtype=np.float32)
+
+
 INRIA_PROPERTIES = ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{k}" for k in range(45)] + \
                    ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
 

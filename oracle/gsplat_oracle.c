@@ -200,6 +200,12 @@ static const float SH_C3_0 = -0.5900436f, SH_C3_1 = 2.8906114f, SH_C3_2 = -0.457
 /* ShadeSH for one colour channel (shaders/GSplatShaderCoreLib.h:117-179).
  * sh[j] = coefficient sh(j+1) of this channel.  Expressions are evaluated
  * left to right exactly as written there, without fusing.                   */
+static float gso_finite_colour(float c)
+{
+    if (c != c) return 0.0f;
+    return c > 3.0e38f ? 3.0e38f : (c < -3.0e38f ? -3.0e38f : c);
+}
+
 static float shade_sh_channel(float base, const float* sh, float x, float y, float z, int order)
 {
     float res = base;
@@ -424,9 +430,12 @@ static void project_splat(const gso_splats* s, const gso_frame* f, int64_t i, gs
         cg = shade_sh_channel(cg, shg, dx, dy, dz, f->sh_order);
         cbl = shade_sh_channel(cbl, shb, dx, dy, dz, f->sh_order);
     }
-    o->r = cr;
-    o->g = cg;
-    o->b = cbl;
+    /* A colour that is not finite (inf / NaN colour or SH halves) would turn every pixel it is blended into -- and, in a
+     * renderer that blends rejected fragments with weight 0, every pixel near it -- into NaN.  The contract (round 6) makes it
+     * finite where it is formed: NaN -> 0 (what max(NaN, 0) gives in :178), +-inf -> +-3e38.  Nothing a real capture holds. */
+    o->r = gso_finite_colour(cr);
+    o->g = gso_finite_colour(cg);
+    o->b = gso_finite_colour(cbl);
     o->opacity = s->alpha[i];
     o->la = gso_log2_opacity(o->opacity);
     o->visible = 1;

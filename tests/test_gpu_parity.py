@@ -2070,3 +2070,118 @@ def test_a_frame_whose_clusters_are_all_culled_is_empty(pkg, engine):
             assert np.array_equal(engine.render(cam), a)
         finally:
             engine.set_option(pkg.engine.OPT_OCCLUSION_CULL, 1)
+
+
+def _zwin_quantiles(cam, P, qs):
+    """window depths (0..1) of the splat centres the camera can see: where an opaque pass's depth buffer has to sit to cut the cloud"""
+    M = np.asarray(cam.proj, np.float64).reshape(4, 4).T @ np.asarray(cam.obj_view, np.float64).reshape(4, 4).T
+    Ph = np.concatenate([P[:20000].astype(np.float64), np.ones((min(len(P), 20000), 1))], axis=1) @ M.T
+    ok = (Ph[:, 3] > 0) & (np.abs(Ph[:, 2]) <= Ph[:, 3])
+    zw = 0.5 * Ph[ok, 2] / Ph[ok, 3] + 0.5
+    return [float(np.quantile(zw, q)) for q in qs]
+
+
+@pytest.mark.gpu
+def test_depth_culling_and_quadrant_classification_are_invisible(pkg, oracle):
+    """Round 6: a depth-tested frame (the one the viewport hook issues on every redraw) is (a) classified per 8x8 quadrant inside k_blend --
+    a quadrant under a buffer cleared to the far plane runs the plain loop, a record behind everything under it is not staged, one in
+    front of everything needs no per-pixel compare -- and (b) culled in K1 / k_cluster_cull against the tile-max pyramid of the depth
+    buffer.  Neither may change a pixel: every frame is compared bit for bit with a context that does none of it (GSR_FLAG_NO_DEPTH_CLASS,
+    GSR_OPT_OCCLUSION_CULL = 0, GSR_OPT_CLUSTER_CULL = 0: every record staged, every fragment compared), over depth buffers of every
+    kind -- far plane, a sphere among the splats, tile-sized and odd-sized blocks, per-pixel noise, NaN, negative, beyond 1 -- at
+    odd framebuffer sizes, sharded, as front-slab frames, and with the camera moving under a changing depth buffer."""
+    E = pkg.engine
+    rng = np.random.default_rng(606)
+    for (n, w, h) in ((300000, 1280, 720), (120000, 1001, 517), (60000, 330, 250)):
+        splats = pkg.scenes.make_scene(n, seed=77 + n % 13, sh=True)
+        cams = [pkg.camera.make_camera(w, h, sh_order=2, frame=i) for i in (0, 1, 2, 3, 30, 31)]
+        q = _zwin_quantiles(cams[0], splats.P, (0.05, 0.2, 0.4, 0.6, 0.8, 0.95))
+        yy, xx = np.mgrid[0:h, 0:w]
+        depths = {"far": np.ones((h, w), np.float32),
+                  "sphere": pkg.scenes.sphere_occluder_depth(cams[0], 3.42, 0.645),
+                  "blocks16": np.asarray(q + [1.0, 1.0], np.float32)[rng.integers(0, 8, ((h + 15) // 16, (w + 15) // 16))].repeat(16, 0).repeat(16, 1)[:h, :w].copy(),
+                  "blocks40": np.asarray(q + [1.0, 0.0, 1.5, -0.5, np.nan], np.float32)[rng.integers(0, 11, ((h + 39) // 40, (w + 39) // 40))].repeat(40, 0).repeat(40, 1)[:h, :w].copy(),
+                  "noise": np.where(rng.random((h, w)) < 0.5, np.float32(q[2]), np.float32(1.0)).astype(np.float32),
+                  "ramp": (q[0] + (q[5] - q[0]) * (xx / max(w - 1, 1))).astype(np.float32)}
+        plain, dut = pkg.Engine(0), pkg.Engine(0)
+        try:
+            plain.set_option(E.OPT_OCCLUSION_CULL, 0); plain.set_option(E.OPT_CLUSTER_CULL, 0); plain.set_option(E.OPT_DEBUG_FLAGS, 32)
+            plain.upload(splats); dut.upload(splats)
+            for mode in ((1, 1), (2, 1), (3, 2), (0, 0)):          # (occlusion culling, front slab)
+                dut.set_option(E.OPT_OCCLUSION_CULL, mode[0]); dut.set_option(E.OPT_FRONT_SLAB, mode[1])
+                for name, d in depths.items():
+                    for k, c in enumerate(cams):
+                        got, want = dut.render_depth(c, d), plain.render_depth(c, d)
+                        assert np.array_equal(got, want, equal_nan=True), f"{n} {w}x{h} mode {mode} depth {name} frame {k}: differs from the unclassified, unculled frame"
+                # the depth buffer CHANGES under a moving camera (the opaque geometry is animated): no frame may use the previous buffer
+                for k, c in enumerate(cams[:4]):
+                    d = depths[("sphere", "far", "blocks16", "ramp")[k]]
+                    assert np.array_equal(dut.render_depth(c, d), plain.render_depth(c, d), equal_nan=True), f"changing depth buffer, frame {k}"
+                # ... nor under a STILL camera: a static redraw reuses the depth order only of a frame that was not culled against its buffer
+                for name in ("sphere", "far", "ramp", "far", "blocks16"):
+                    assert np.array_equal(dut.render_depth(cams[2], depths[name]), plain.render_depth(cams[2], depths[name]), equal_nan=True), f"still camera, depth {name}"
+            # sharded (the depth buffer is the full image)
+            dut.set_option(E.OPT_OCCLUSION_CULL, 1); dut.set_option(E.OPT_FRONT_SLAB, 1)
+            for layout in (0, 1):
+                for e in (dut, plain):
+                    e.set_option(E.OPT_SHARD_LAYOUT, layout); e.set_row_shard(1, 3)
+                for name in ("sphere", "blocks40"):
+                    for c in cams[:3]:
+                        assert np.array_equal(dut.render_depth(c, depths[name]), plain.render_depth(c, depths[name]), equal_nan=True), f"sharded {layout} {name}"
+            for e in (dut, plain):
+                e.set_row_shard(0, 1)
+            # and the culling really happens: behind the sphere far fewer splats reach the sort than under the far plane
+            for c in cams[:3]:
+                dut.render_depth(c, depths["far"])
+            v_far = dut.stats()["n_visible"]
+            for c in cams[:3]:
+                dut.render_depth(c, depths["sphere"])
+            st = dut.stats()
+            assert st["policy_bits"] & 32, st
+            if n >= 300000:
+                ramp0 = np.full((h, w), q[0], np.float32)       # an opaque wall in front of 95 % of the cloud
+                for c in cams[:3]:
+                    dut.render_depth(c, ramp0)
+                assert dut.stats()["n_visible"] * 4 < v_far, (dut.stats()["n_visible"], v_far)
+            # against the oracle
+            if n == 120000:
+                _check_image(dut.render_depth(cams[1], depths["sphere"]), oracle.render_depth(splats, cams[1], depths["sphere"]))
+                _check_image(dut.render_depth(cams[1], depths["blocks16"]), oracle.render_depth(splats, cams[1], depths["blocks16"]))
+        finally:
+            plain.close(); dut.close()
+
+
+@pytest.mark.gpu
+def test_depth_tested_headline_frame_at_full_size(pkg, oracle):
+    """BASELINE C4 at FULL size, depth-tested the way bench.py's `depth_tested` leg does it (a buffer cleared to the far plane; an opaque
+    sphere among the splats covering 30 % of the frame): an orbit under the library's default policy against a context that culls
+    and classifies nothing, bit for bit; the far-plane frames equal to the plain gsr_render frames; one frame of each against the oracle."""
+    E = pkg.engine
+    splats, cfg = pkg.scenes.make_config("C4")
+    w, h = cfg["width"], cfg["height"]
+    cams = [pkg.scenes.config_camera("C4", pkg.camera, w, h, 3, i) for i in range(8)]
+    far = np.ones((h, w), np.float32)
+    occ = pkg.scenes.sphere_occluder_depth(cams[0], 3.42, 0.645)       # wholly under the cloud's surface (0.16 units at its nearest)
+    vis = pkg.scenes.sphere_occluder_depth(cams[0], 3.0, 0.566)         # bench.py's: its front pokes out of the cloud, its rim lies under the surface
+    plain, dflt = pkg.Engine(0), pkg.Engine(0)
+    try:
+        plain.set_option(E.OPT_OCCLUSION_CULL, 0); plain.set_option(E.OPT_CLUSTER_CULL, 0); plain.set_option(E.OPT_DEBUG_FLAGS, 32)
+        plain.upload(splats); dflt.upload(splats)
+        keep = {}
+        for name, d in (("far", far), ("occluder", occ), ("visible", vis)):
+            for k, c in enumerate(cams):
+                got, want = dflt.render_depth(c, d), plain.render_depth(c, d)
+                assert np.array_equal(got, want), f"C4 depth-tested ({name}) frame {k} differs from the unclassified, unculled frame"
+                if name == "far":
+                    assert np.array_equal(got, dflt.render(c)) if k == 3 else True
+                if k == 6:
+                    keep[name] = got.copy()
+        st = dflt.stats()
+        assert st["frames_culled"] >= 8, st
+        _check_image(keep["visible"], oracle.render_depth(splats, cams[6], vis))
+        assert np.abs(keep["visible"] - keep["far"]).max() > 0.05           # (this one shows)
+        # (the sphere sits 0.16 units under the cloud's surface: every pixel over it saturates in front of it -- the frame is the far-plane
+        #  frame to within the kernel's 2^-14 early-out -- but nothing in the library may ASSUME that: the tiles over it end their lists there)
+        assert np.abs(keep["occluder"] - keep["far"]).max() <= 2.0 ** -13
+    finally:
+        plain.close(); dflt.close()

@@ -1,11 +1,12 @@
 """k_blend under back-to-back frames (what bench.py times): per-phase wave time and the launch's span, for the small-frame sort on / off.
-Needs the -DBL_PROFILE variant copied over libgsplat_hip.so.   python tools/blend_phases2.py C5 <local-sort 0|1>"""
+Needs the -DBL_PROFILE variant copied over libgsplat_hip.so.   python tools/blend_phases2.py C5 <local-sort 0|1> [far|occluder: depth-tested frames]"""
 import sys, ctypes as C, numpy as np
 sys.path.insert(0, '.')
 import __graft_entry__ as ge
 import torch
 pkg = ge.load_package()
 name = sys.argv[1]; local = int(sys.argv[2])
+dkind = sys.argv[3] if len(sys.argv) > 3 else None
 splats, cfg = pkg.scenes.make_config(name)
 W, H, order = cfg["width"], cfg["height"], cfg["sh_order"]
 eng = pkg.Engine(0)
@@ -17,12 +18,20 @@ fn = lib.gsr_debug_blend_profile
 fn.argtypes = [C.c_void_p, C.c_int]
 band = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
 cams = [pkg.engine.camera_struct(pkg.scenes.config_camera(name, pkg.camera, W, H, order, i)) for i in range(40)]
-for i in range(39): eng.render_struct_to_device(cams[i], band.data_ptr())
+dt_ = None
+if dkind:
+    cam0 = pkg.scenes.config_camera(name, pkg.camera, W, H, order, 0)
+    d_ = np.ones((H, W), np.float32) if dkind == "far" else pkg.scenes.sphere_occluder_depth(cam0, 3.0, 0.566)
+    dt_ = torch.from_numpy(d_).to("cuda")
+def frame(i):
+    if dt_ is None: eng.render_struct_to_device(cams[i], band.data_ptr())
+    else: eng.render_struct_depth_to_device(cams[i], dt_.data_ptr(), band.data_ptr())
+for i in range(39): frame(i)
 torch.cuda.synchronize()
 fn(None, 1)
 import time
 t0 = time.perf_counter()
-for i in range(20, 40): eng.render_struct_to_device(cams[i], band.data_ptr())
+for i in range(20, 40): frame(i)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 20
 buf = np.zeros((65536, 4, 16), dtype=np.uint64)

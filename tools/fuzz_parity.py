@@ -95,7 +95,7 @@ def make_script(rng, it, heavy, longlived):
     for kv in os.environ.get("FUZZ_FORCE", "").split():       # (debugging: FUZZ_FORCE="7=0 16=1" overrides options in every iteration)
         k_, v_ = kv.split("=")
         opts[int(k_)] = int(v_)
-    use_depth = bool(rng.random() < 0.25)
+    use_depth = bool(rng.random() < 0.35)
     multi = int(rng.choice([0, 0, 0, 2, 3, 8])) if not (heavy or longlived) else 0
     if longlived:     # every option gets a definite value (the context remembers the last iteration's)
         full = dict(DEFAULTS); full.update(opts); opts = full
@@ -123,10 +123,36 @@ def make_script(rng, it, heavy, longlived):
                     flips[k] = ("shard", int(rng.integers(0, cnt2)), cnt2, int(rng.integers(0, 2)))
     dev_target = bool(rng.random() < 0.3) and not multi and not use_depth     # the frames go to a DEVICE buffer (no staging copy; deferred hand-over possible)
     user_stream = dev_target and bool(rng.random() < 0.6)                       # ... on the caller's own stream
-    depth = np.where(np.random.default_rng(it).random((h, w)) < 0.5, 0.5, 1.0).astype(np.float32) if use_depth else None
+    depth = depth_image(np.random.default_rng(it), w, h, cams[0], splats.P) if use_depth else None
     desc = dict(it=it, n=n, sh=sh, w=w, h=h, order=order, proj=kind, shard=(index, count, layout), depth=use_depth, multi=multi, parts=cuts, dev_target=dev_target, user_stream=user_stream,
                 opts={int(k): v for k, v in opts.items()}, flips={k: v for k, v in flips.items()})
     return dict(splats=splats, n=n, w=w, h=h, shard=(index, count, layout), opts=opts, depth=depth, multi=multi, cams=cams, cuts=cuts, flips=flips, desc=desc, dev_target=dev_target, user_stream=user_stream)
+
+
+def depth_image(rng, w, h, cam, P):
+    """an opaque pass's depth buffer: per-pixel noise (the only kind before round 6: every tile's largest depth is 1, nothing for K1 to
+    cull), the far plane, blocks of tile size and of odd sizes whose values sit INSIDE the cloud's range of window depths (and NaN, 0,
+    negative, beyond 1), a horizontal ramp through that range, a disc"""
+    M = np.asarray(cam.proj, np.float64).reshape(4, 4).T @ np.asarray(cam.obj_view, np.float64).reshape(4, 4).T
+    Ph = np.concatenate([np.nan_to_num(P[:5000].astype(np.float64)), np.ones((min(len(P), 5000), 1))], axis=1) @ M.T
+    ok = (Ph[:, 3] > 0) & (np.abs(Ph[:, 2]) <= Ph[:, 3])
+    zw = 0.5 * Ph[ok, 2] / Ph[ok, 3] + 0.5 if ok.any() else np.array([0.5])
+    q = [float(np.quantile(zw, x)) for x in (0.05, 0.25, 0.5, 0.75, 0.95)]
+    kind = int(rng.integers(0, 6))
+    if kind == 0:
+        return np.where(rng.random((h, w)) < 0.5, np.float32(q[2]), np.float32(1.0)).astype(np.float32)
+    if kind == 1:
+        return np.ones((h, w), np.float32)
+    if kind in (2, 3):
+        B = 16 if kind == 2 else int(rng.choice([5, 40, 128, 300]))
+        vals = np.asarray(q + [1.0, 1.0, 1.0] + ([0.0, 1.5, -0.5, np.nan] if rng.random() < 0.4 else []), np.float32)
+        g = vals[rng.integers(0, len(vals), ((h + B - 1) // B, (w + B - 1) // B))]
+        return np.ascontiguousarray(g.repeat(B, 0).repeat(B, 1)[:h, :w])
+    if kind == 4:
+        return np.ascontiguousarray(np.broadcast_to((q[0] + (q[4] - q[0]) * np.arange(w) / max(w - 1, 1)).astype(np.float32), (h, w)))
+    yy, xx = np.mgrid[0:h, 0:w]
+    r2 = ((xx - w / 2) / (0.3 * w)) ** 2 + ((yy - h / 2) / (0.3 * h)) ** 2
+    return np.where(r2 < 1.0, q[1] + (q[3] - q[1]) * r2, 1.0).astype(np.float32)
 
 
 def execute(sc, dut, verbose=False):
@@ -145,6 +171,7 @@ def execute(sc, dut, verbose=False):
         plain.set_option(E.OPT_STORAGE_ORDER, opts.get(E.OPT_STORAGE_ORDER, 1))
         plain.set_option(E.OPT_OCCLUSION_CULL, 0); plain.set_option(E.OPT_CLUSTER_CULL, 0)
         plain.set_option(E.OPT_LOCAL_SORT, 0); plain.set_option(E.OPT_LAZY_COLOUR, 0)
+        plain.set_option(E.OPT_DEBUG_FLAGS, 32)      # (GSR_FLAG_NO_DEPTH_CLASS: depth-tested frames stage every record and compare every fragment)
         for k, v in opts.items():
             dut.set_option(k, v)
         if sc["cuts"]:

@@ -116,6 +116,7 @@ struct FrameJob {
     int dpar = 0;
     bool sort_fresh = false;       // this frame sorted (it did not reuse a cached order)
     bool dblind = false;           // ... and k_cluster_cull ran without the depth pyramids (they were built beside it, for K1)
+    bool dstat = false;            // ... and the depth pyramid pass masked the covered depths with the tiles' status (a culled frame with a valid status)
     bool blend_guess_plain = false;   // the plain blend kernel was launched, guarded by "no pixel is covered" (queue_back_end)
     float* out_arg = nullptr;
     int out_is_device_arg = 0;
@@ -183,6 +184,9 @@ struct FrameSlot {
     float* hpyr = nullptr;             // pyramid levels 0..3 (k_cluster.h), GSR_PYR_FLOATS floats: what the slot's next frame culls against
     float* hpyr_next = nullptr;        // ... double-buffered: a frame's last kernels read the one it was culled against while they fill the other
     float* hraw = nullptr;             // per-tile horizons before dilation (k_tile_pass -> k_horizon_dilate)
+    float* hstat = nullptr;            // per tile: every tile of its neighbourhood was "classic" in the frame that left the horizons (k_blend.h: GsrHorizonArgs.stat)
+    bool hstat_valid = false;          // ... written by a depth-tested frame's end (as old as the horizons)
+    uint32_t* dbg_viol = nullptr;      // GSR_DEBUG_VIOL in the environment: which tiles broke their promise (k_tile_pass)
     int hpyr_re = 0;                   // the dilation radius built into hpyr
     // cluster culling (k_cluster.h): the ordered list of surviving clusters of the frame, as per-workgroup segments
     uint32_t* cseg = nullptr;          // [ngroups * per]
@@ -415,6 +419,7 @@ static bool slot_init(FrameSlot& sl)
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr_next), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hraw), (size_t)GSR_MAX_TILES_SIDE * GSR_MAX_TILES_SIDE * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hstat), (size_t)GSR_MAX_TILES_SIDE * GSR_MAX_TILES_SIDE * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.hpyr2), GSR_PYR_FLOATS * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl.slab), (GSR_SLAB_BINS + 8) * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(sl.slab, 0, (GSR_SLAB_BINS + 8) * sizeof(uint32_t)) == hipSuccess;
@@ -462,7 +467,7 @@ static void slot_destroy(FrameSlot& sl)
     dev_free(sl.hist); dev_free(sl.totals);
     dev_free(sl.pvA);
     dev_free(sl.sstart); dev_free(sl.send); dev_free(sl.tile_work); dev_free(sl.order); dev_free(sl.sup_work); dev_free(sl.fb);
-    dev_free(sl.hpyr); dev_free(sl.hpyr_next); dev_free(sl.hraw); dev_free(sl.hpyr2); dev_free(sl.slab); dev_free(sl.tile_work_a); dev_free(sl.tbuf); dev_free(sl.ccnt); dev_free(sl.bkt_key); dev_free(sl.bkt_val); dev_free(sl.bkt_cnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
+    dev_free(sl.hpyr); dev_free(sl.hpyr_next); dev_free(sl.hraw); dev_free(sl.hstat); dev_free(sl.hpyr2); dev_free(sl.slab); dev_free(sl.tile_work_a); dev_free(sl.tbuf); dev_free(sl.ccnt); dev_free(sl.bkt_key); dev_free(sl.bkt_val); dev_free(sl.bkt_cnt); dev_free(sl.d_counts); dev_free(sl.st_scan); dev_free(sl.partial);
     if (sl.h_end) (void)hipHostFree(sl.h_end); dev_free(sl.depth_stage); dev_free(sl.dpyr); dev_free(sl.dactive);
     dev_free(sl.redo); dev_free(sl.lazy_ctr); dev_free(sl.colour_evals);
     dev_free(sl.counters); dev_free(sl.d_n);
@@ -1282,6 +1287,12 @@ static int queue_blend(gsr_context* c, FrameSlot& sl, bool with_depth, bool guar
         if (!j.direct) HIP_TRY(hipStreamWaitEvent(s, sl.ev_user, 0));
         GsrBlendArgs a;
         a.guard = guarded ? sl.dactive + j.dpar : (const uint32_t*)nullptr; a.guard_want = 0u;
+        {   // (a perspective projection -- clip w = -view z, clip z = a z + b: window depth = (1 - a) / 2 - beta / view depth)
+            const bool persp = f.pr[8] == 0.0f && f.pr[9] == 0.0f && f.pr[12] == 0.0f && f.pr[13] == 0.0f && f.pr[14] == -1.0f && f.pr[15] == 0.0f;
+            a.near_alpha = persp ? 0.5f * (1.0f - f.pr[10]) : 0.0f;
+            a.near_scale = persp ? 1.12f : 0.0f;
+        }
+        a.tile_cov = (with_depth && j.dcull) ? sl.dpyr + 4 * sl.dpyr_cap : (const float*)nullptr;
         a.width = f.width; a.height = f.height; a.tiles_x = f.tiles_x; a.local_tiles = j.local_tiles;
         a.shard = GsrShard{f.shard_index, f.shard_count, f.shard_rpb}; a.band_rows = j.band_rows;
         a.super_shift = f.super_shift; a.rect_shift = f.rect_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
@@ -1374,6 +1385,17 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
         for (int l = 0; l < GSR_PYR_LEVELS; ++l) hz.pyr_off[l] = j.f.pyr_off[l];
         hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
         hz.host_end = j.cull ? sl.h_end_dev : nullptr; hz.ticket = j.ticket;
+        // (depth-tested frames leave, and culled ones check, the tiles' status: k_blend.h.  A frame without a depth buffer leaves every
+        //  tile classic: the sign bits of its raw horizons are clear)
+        hz.stat = sl.hstat;
+        hz.stat_in_use = (j.cull && j.dcull && j.dstat) ? 1 : 0;
+        hz.depth_culled = j.dcull ? 1 : 0;
+        static const bool dbgv = std::getenv("GSR_DEBUG_VIOL") != nullptr;
+        if (dbgv) {
+            if (!sl.dbg_viol && hipMalloc(reinterpret_cast<void**>(&sl.dbg_viol), 80 * 4) != hipSuccess) sl.dbg_viol = nullptr;
+            if (sl.dbg_viol) (void)hipMemsetAsync(sl.dbg_viol, 0, 80 * 4, s);
+            hz.dbg = sl.dbg_viol;
+        }
     }
     if (j.phase == 2) { hz.slab = 2; hz.tile_work_a = sl.tile_work_a; }
     const int nblocks8 = ((j.f.tiles_x + 7) >> 3) * ((j.f.tiles_y + 7) >> 3);
@@ -1382,6 +1404,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     const uint32_t* const redo_arg = j.lazy ? reinterpret_cast<const uint32_t*>(sl.lazy_ctr) : (const uint32_t*)nullptr;
     uint32_t* const work_next = sl.sup_work ? sl.sup_work + 256 * (sl.sup_par ^ 1) : (uint32_t*)nullptr;
     sl.horizon_valid = hz.raw != nullptr;
+    sl.hstat_valid = hz.raw != nullptr;       // (the dilation writes it beside the pyramid)
     // The heaviest-first table is rebuilt every frame where the tiles differ a lot (k_sum_work's verdict); where they do not it is
     // still worth a few microseconds of k_blend's tail (C4: 0.142 -> 0.139 ms), but not the 10 us of k_tile_order every frame:
     // then a table stands for GSR_ORDER_KEEP frames of the same shape.
@@ -1901,8 +1924,8 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
             HIP_TRY(hipStreamSynchronize(s));
             dev_free(sl.dpyr);
             sl.dpyr_cap = 0;
-            if ((rc = dev_alloc(&sl.dpyr, 4 * need))) return rc;
-            HIP_TRY(hipMemsetAsync(sl.dpyr, 0, 4 * need * sizeof(float), s));   // (levels 4 and 5 start cleared; afterwards every frame clears the next one's)
+            if ((rc = dev_alloc(&sl.dpyr, 5 * need))) return rc;                   // (+ the per-tile "covered" array k_blend reads)
+            HIP_TRY(hipMemsetAsync(sl.dpyr, 0, 5 * need * sizeof(float), s));   // (levels 4 and 5 start cleared; afterwards every frame clears the next one's)
             sl.dpyr_cap = need;
             if (!sl.dactive) {
                 if ((rc = dev_alloc(&sl.dactive, 2))) return rc;
@@ -2008,9 +2031,13 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         if (j.dcull) {
             float* const dp0 = sl.dpyr + (size_t)(2 * j.dpar) * sl.dpyr_cap;
             float* const dq0 = sl.dpyr + (size_t)(2 * (j.dpar ^ 1)) * sl.dpyr_cap;
-            dc_k1 = GsrDepthCull{dp0, dp0 + sl.dpyr_cap, sl.dactive + j.dpar};
+            dc_k1 = GsrDepthCull{dp0, j.phase == 2 ? (const float*)nullptr : dp0 + sl.dpyr_cap, sl.dactive + j.dpar};
             if (j.phase != 2) {
                 dp.depth = j.d_depth; dp.pyr = dp0; dp.pyrc = dp0 + sl.dpyr_cap; dp.pyr_next = dq0; dp.pyrc_next = dq0 + sl.dpyr_cap; dp.active = sl.dactive; dp.par = j.dpar;
+                dp.tcov = sl.dpyr + 4 * sl.dpyr_cap;
+                // (a culled frame: the tiles that were classic when the horizons were left get no depth clause)
+                dp.stat = (j.cull && sl.hstat_valid) ? sl.hstat : (const float*)nullptr;
+                j.dstat = dp.stat != nullptr;
                 dp.width = f.width; dp.height = f.height; dp.tiles_x = f.tiles_x; dp.tiles_y = f.tiles_y;
                 for (int l = 0; l < GSR_PYR_LEVELS; ++l) dp.off[l] = f.pyr_off[l];
                 const uint32_t nb8 = (uint32_t)gsr_depth_pyramid_blocks(f.tiles_x, f.tiles_y);
@@ -2242,6 +2269,19 @@ static int frame_check(gsr_context* c, FrameSlot& first, const gsr_camera* cam, 
             return GSR_OK;
         }
         c->st.frames_repaired += 1;
+        if (slot.dbg_viol) {
+            uint32_t hv[80];
+            (void)hipStreamSynchronize(slot.stream);
+            if (hipMemcpy(hv, slot.dbg_viol, sizeof hv, hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "[viol] frame %llu: %u tile(s) broke their promise\n", (unsigned long long)c->frame_no, hv[0]);
+                for (uint32_t k = 0; k < std::min(hv[0], 8u); ++k) {
+                    const uint32_t* o = hv + 1 + 8 * k;
+                    float hold, kl; std::memcpy(&hold, o + 4, 4); std::memcpy(&kl, o + 5, 4);
+                    fprintf(stderr, "   tile (%u, %u): w.w %#x (opaque %u, met %u, u_all %u, steps all %u / u %u) entries read %u, checked depth %u, hold %.4f, last key %.4f, predicted classic %u, kept %u, c1 %u, classic now %u\n",
+                            o[0], o[1], o[2], o[2] & 1u, (o[2] >> 14) & 1u, (o[2] >> 15) & 1u, (o[2] >> 16) & 0xffu, o[2] >> 24, o[3], o[7], std::sqrt(hold), std::sqrt(kl), o[6] & 1u, (o[6] >> 1) & 1u, (o[6] >> 2) & 1u, (o[6] >> 3) & 1u);
+                }
+            }
+        }
         // The view is changing faster than the horizons follow.  First answer: compare rects with the horizons of a wider
         // neighbourhood from now on (the repaired frame leaves fresh horizons, and the radius shrinks back while frames hold);
         // only when that is exhausted, leave culling alone for a while (8, 32, 128, 512, 1024 frames).
@@ -2614,6 +2654,26 @@ extern "C" int gsr_debug_read_tile_work(gsr_context* c, uint32_t* work4, int64_t
     if (!sl || n_tiles != (int64_t)sl->last_tiles_x * sl->last_local_ty)
         return set_err(GSR_E_INVALID, "gsr_debug_read_tile_work: expected %d tiles", sl ? sl->last_tiles_x * sl->last_local_ty : 0);
     if (n_tiles) HIP_TRY(hipMemcpy(work4, sl->tile_work, (size_t)n_tiles * 16, hipMemcpyDeviceToHost));
+    return GSR_OK;
+}
+
+// what the slot's NEXT frame would be culled against, per tile of the whole image: [0] the (dilated) depth horizons (distance^2, +inf = none),
+// [1] the raw horizons before dilation with the tile's status in the sign (k_blend.h: GsrHorizonArgs.stat), [2] the dilated status, [3] the
+// covered depths of the last depth-tested frame as K1 saw them (level 0 of pyrc, k_cluster.h)
+extern "C" int gsr_debug_read_horizons(gsr_context* c, float* out4, int64_t n_tiles)
+{
+    if (!c || !out4) return set_err(GSR_E_INVALID, "gsr_debug_read_horizons: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    FrameSlot* sl = latest_slot(c);
+    if (!sl || n_tiles <= 0) return set_err(GSR_E_INVALID, "gsr_debug_read_horizons: no frame");
+    std::vector<float> zero((size_t)n_tiles, 0.0f);
+    HIP_TRY(hipMemcpy(out4, sl->hpyr, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));                     // (level 0 starts at offset 0)
+    HIP_TRY(hipMemcpy(out4 + n_tiles, sl->hraw, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out4 + 2 * n_tiles, sl->hstat, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));
+    if (sl->dpyr && sl->dpyr_cap >= (size_t)n_tiles) HIP_TRY(hipMemcpy(out4 + 3 * n_tiles, sl->dpyr + (size_t)(2 * sl->dpar + 1) * sl->dpyr_cap, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));
+    else std::memcpy(out4 + 3 * n_tiles, zero.data(), (size_t)n_tiles * 4);
     return GSR_OK;
 }
 

@@ -88,6 +88,14 @@ struct GsrBlendArgs {
     // depth-tested kernel behind it (gsr_api.hip: frame_finish).  The word is loaded first thing and looked at after the first scan.
     const uint32_t* guard;      // NULL: no guard
     uint32_t guard_want;        // the launch is void unless (*guard != 0) == (guard_want != 0)
+    // "met the geometry" (bit 14 of the bookkeeping) with a MARGIN: under a perspective projection window depth is alpha - beta / d (d =
+    // view depth), so (alpha - zwin_hit) >= near_scale * (alpha - depth) says "the hit lies at least 12 % nearer than the geometry".  A tile
+    // counts as clear of the geometry -- classic, k_tile_pass -- only if every record it gathered was; near_scale = 0: no margin
+    // (other projections).  Measured without it on C4 with a sphere just under the cloud's surface: two or three tiles per frame went from
+    // "saturated, met nothing" to "cannot saturate" between two frames 3 degrees apart, each one a repaired frame.
+    float near_alpha, near_scale;
+    const float* tile_cov;      // depth-tested frames with a depth pyramid (k_cluster.h): level 0 of pyrc, [tiles_y][tiles_x]; < 0 = the tile has
+                                // no covered pixel.  NULL: not known (every tile loads its depths)
 };
 
 // Staging layout: one list PER QUADRANT (= per wave), holding the round's records that reach that
@@ -125,7 +133,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     __shared__ uint32_t q[BL_QCAP];   // hit queue: splat indices in list (= depth) order
     __shared__ __attribute__((aligned(16))) uint32_t scnt[2][4];   // hits of each wave in a scan step
     __shared__ uint32_t sdone[2][4];
-    __shared__ uint32_t sevals, sredo;
+    __shared__ uint32_t sevals, sredo, sdmet;
     __shared__ uint32_t slastu[4];    // depth-tested frames: the same count at the moment the wave's UNCOVERED pixels were all opaque
     __shared__ uint32_t stail[32];    // hits queued after each of the last 32 scan steps (ring): which step held a given hit?
     __shared__ uint32_t slast[4];     // per wave: how many of the tile's hits it has gathered (exclusive count)
@@ -166,13 +174,15 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     // first pixel centre of the tile, and the centre of this wave's quadrant box of pixel centres
     const float tcx0 = (float)(tx * GSR_TILE_PX) + 0.5f, tcy0 = (float)(gty * GSR_TILE_PX) + 0.5f;
     const float qcx = tcx0 + 3.5f + 8.0f * (float)(wave & 1), qcy = tcy0 + 3.5f + 8.0f * (float)(wave >> 1);
-    if (tid == 0) { sevals = 0; sredo = 0; }
+    if (tid == 0) { sevals = 0; sredo = 0; sdmet = 0; }
     if (tid < 4) slast[tid] = 0u;
     uint32_t my_evals = 0;            // (wave-uniform) records this wave evaluated for its 64 pixels
     uint32_t my_last = 0;             // (wave-uniform) hits of the tile this wave has gathered so far: all of the sub-rounds it entered
     // depth test against what the opaque pass left (depth writes stay off): a fragment survives iff its quad's
     // window depth <= depth[pixel] (src/GSplatRenderer.C:595-610).  No depth buffer = +inf.
-    const float dpx = (HAS_DEPTH && pix_ok) ? depth[(size_t)py * a.width + px] : __builtin_inff();
+    // (a tile without a covered pixel -- the depth pyramid pass knows -- is an ordinary tile: its 256 depths are not even loaded)
+    const bool tile_plain = HAS_DEPTH && a.tile_cov != nullptr && !(a.flags & GSR_FLAG_NO_DEPTH_CLASS) && a.tile_cov[gty * a.tiles_x + tx] < 0.0f;   // (uniform)
+    const float dpx = (HAS_DEPTH && pix_ok && !tile_plain) ? depth[(size_t)py * a.width + px] : __builtin_inff();
     // Per WAVE (= 8x8 quadrant), once: what the opaque pass left under it.  K1 keeps a splat only if -w <= z <= w, so every window
     // depth in the lists is <= 1 (an IEEE quotient of z <= w is <= 1, and fma(q, 0.5, 0.5) of q <= 1 is <= 1): a quadrant whose
     // depth buffer was CLEARED TO THE FAR PLANE (all >= 1) passes every fragment -- d_triv -- and runs the plain loop, bit-identical
@@ -181,6 +191,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     // passes everywhere and needs no per-pixel compare; only the records in between take the depth-tested loop.
     // (formed right before the first gather, not here: `dpx` is a load, and consuming it here would put its latency in front of the
     //  list loads below instead of beside them -- measured: +13 us per C4 launch, five generations of tiles x ~2 us)
+    bool d_met = false;               // (wave-uniform) a record that reaches this quadrant did not pass the depth test everywhere in it
     bool d_triv = true, d_init = !HAS_DEPTH;
     float d_wmax = __builtin_inff(), d_wmin = __builtin_inff();
 
@@ -328,7 +339,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                 const bool have = sub + lane < take;
                 float4 r1, r2;
                 float rz = 0.0f, c0 = 0.0f, c1 = 0.0f;
-                bool hit = false, pending = false, dtest = false;
+                bool hit = false, pending = false, dtest = false, dmet_l = false;
                 if (have) {
                     const uint32_t ridx = q[(q_head + (uint32_t)(sub + lane)) & (BL_QCAP - 1)];
                     const float4* p = reinterpret_cast<const float4*>(recs + ridx);
@@ -350,6 +361,8 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     const float pv = __builtin_fabsf(ddx * r1.z + ddy * r1.w);
                     hit = box && (((a.flags & GSR_FLAG_NO_SAT) != 0) || (pu <= lim1 && pv <= lim2));
                     if (HAS_DEPTH && !d_triv) {
+                        // (reaches the quadrant, but not CLEARLY in front of everything under it)
+                        dmet_l = hit && !(rz <= d_wmin && (a.near_alpha - rz) >= a.near_scale * (a.near_alpha - d_wmin));
                         hit = hit && (rz <= d_wmax);          // behind everything the opaque pass left under this quadrant: no fragment passes
                         dtest = hit && !(rz <= d_wmin);       // in front of all of it: every fragment passes
                     }
@@ -370,6 +383,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                 const unsigned long long bal = __ballot(hit);
                 const int cnt = (int)__builtin_popcountll(bal);     // wave-uniform (scalar)
                 const bool dslow = HAS_DEPTH && __any(dtest);       // (uniform) some staged record needs the per-pixel depth compare
+                if (HAS_DEPTH && __any(dmet_l)) d_met = true;
                 if (hit) {
                     const uint32_t pos = (uint32_t)__builtin_popcountll(bal & lt_mask);
                     float* blk = reinterpret_cast<float*>(&slist[wave][(pos >> 1) * PF4]);
@@ -465,11 +479,19 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     }
                     if (!stop)
                         for (; p < npairs; ++p) blend_pair(p, C01, C2, T);
-                } else {   // (the depth-tested form carries a sixth operand vector per pair: unrolled it spills)
-                    for (; p < npairs; ++p) {
-                        blend_pair_d(p, C01, C2, T);
-                        if ((p & (BL_CHECK - 1)) == BL_CHECK - 1 && __all(!pix_ok || T < GSR_T_MIN)) { ++p; break; }
+                } else {   // (the depth-tested form carries a sixth operand vector per pair: BL_CHECK_D pairs per trip -- four spill)
+#ifndef BL_CHECK_D
+#define BL_CHECK_D 1
+#endif
+                    const int nfull = npairs & ~(BL_CHECK_D - 1);
+                    bool stop = false;
+                    for (; p < nfull && !stop; p += BL_CHECK_D) {
+#pragma unroll
+                        for (int u = 0; u < BL_CHECK_D; ++u) blend_pair_d(p + u, C01, C2, T);
+                        stop = __all(!pix_ok || T < GSR_T_MIN);
                     }
+                    if (!stop)
+                        for (; p < npairs; ++p) blend_pair_d(p, C01, C2, T);
                 }
                 my_evals += (uint32_t)(2 * p < cnt ? 2 * p : cnt);
                 BLP(4)
@@ -518,7 +540,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
 #endif
     // bookkeeping for the roofline: list entries scanned and records gathered by this tile
     __syncthreads();  // orders the sevals = 0 store when the list was empty
-    if (lane == 0) atomicAdd(&sevals, my_evals);
+    if (lane == 0) { atomicAdd(&sevals, my_evals); if (HAS_DEPTH && d_met) sdmet = 1u; }
     __syncthreads();
     if (HAS_DEPTH && !d_init) init_depth();      // (a tile without a single hit)
     const uint32_t es_c = ext_steps_of(max(max(slast[0], slast[1]), max(slast[2], slast[3])));   // (everything the tile gathered)
@@ -530,10 +552,12 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     if (tid == 0) {
         // entries actually read: everything up to scan_pos plus the prefetched step
         const int rd = scan_pos + 1024;
-        // (.w: bit 0 = every pixel went opaque; bits 1..14 = the 1024-entry scan step that held the tile's first hit; bit 15 = the tile's
+        // (.w: bit 0 = every pixel went opaque; bits 1..13 = the 1024-entry scan step that held the tile's first hit; bit 15 = the tile's
         //  UNCOVERED pixels all went opaque (no depth buffer: bit 0 again); bits 16..23 = the number of scan steps that hold everything
         //  the tile gathered, bits 24..31 = ... everything it had gathered when bit 15 came true; 0xff = unknown / too many: fall back to .x)
-        const uint32_t fs = (uint32_t)(first_hit_step < 0 ? 0 : (first_hit_step > 0x3fff ? 0x3fff : first_hit_step));
+        // (bit 14: depth-tested frames -- the tile MET the opaque geometry: a record that reached one of its quadrants did not pass the
+        //  depth test everywhere in it.  Such a tile saturates, if at all, AT the geometry: k_tile_pass does not count on it next frame)
+        const uint32_t fs = (uint32_t)(first_hit_step < 0 ? 0 : (first_hit_step > 0x1fff ? 0x1fff : first_hit_step)) | (sdmet ? 0x2000u : 0u);
         const uint4 tw = make_uint4((uint32_t)(rd < n ? rd : n), fetched, sevals, (saturated ? 1u : 0u) | (fs << 1) | (u_all ? 0x8000u : 0u) | (es_c << 16) | (es_u << 24));
         tile_work[tile] = tw;   // (k_sum_work turns these into colour prefixes, depth horizons and the frame's culling verdict)
         // work of the tile's super-tile, for k_tile_order (fire and forget: ~60 tiles per address and frame)
@@ -617,6 +641,16 @@ struct GsrHorizonArgs {
     uint32_t ticket;
     int32_t slab;                   // 2 = the end of a front-slab frame: tiles that phase 1 left opaque were dealt with by k_slab_mid
     const uint4* tile_work_a;       // ... phase 1's per-tile bookkeeping (added to the frame's counters)
+    // Depth-tested frames.  A tile's status, per frame: CLASSIC = every pixel went opaque and none of them met the opaque geometry
+    // -- next frame it is treated like any tile (its horizon speaks for all of its pixels); otherwise its horizon speaks for its
+    // UNCOVERED pixels only and K1 keeps, on top, what lies in front of the geometry under its covered ones (k_preprocess.h).
+    // The raw horizons carry the status in their sign bit (set = not classic); the dilation leaves, per tile, "every tile of the
+    // neighbourhood was classic" in `stat`: the depth pyramid pass of the next frame masks the covered depths with it, and that
+    // frame's k_tile_pass reads it back to know which of the two promises each tile has to keep.
+    float* stat;                    // [tiles_y][tiles_x] 1 / 0; NULL: no depth-tested frames so far (every tile classic)
+    int32_t stat_in_use;            // this frame's K1 applied `stat` (a culled depth-tested frame)
+    int32_t depth_culled;           // this frame's K1 dropped splats behind the opaque geometry where no horizon applied (k_preprocess.h)
+    uint32_t* dbg;                  // GSR_DEBUG_VIOL in the environment: [0] = tiles that broke their promise, then 8 words for each of the first eight
 };
 // per-block partial sums of k_tile_pass
 struct __attribute__((aligned(16))) GsrTilePartial {
@@ -665,12 +699,25 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
     // Two notions of "opaque" (k_blend): EVERY pixel (bit 0: what the lazy-colour prefixes, the front slab and the counters go by) and
     // every UNCOVERED pixel (bit 15: what the horizons go by -- a pixel the opaque pass covered gets what lies in front of the geometry
     // through K1's depth clause, exactly, whether or not it saturates; without a depth buffer the two are the same)
-    const uint32_t es_all = (w.w >> 16) & 0xffu, es = w.w >> 24;
+    const uint32_t es_all = (w.w >> 16) & 0xffu;
     const uint32_t rd_all = (es_all == 0xffu || (es_all << 10) > w.x) ? w.x : (es_all << 10);
-    const uint32_t rd = (es == 0xffu || (es << 10) > w.x) ? w.x : (es << 10);
     const bool opaque_all = own && (w.w & 1u) != 0u;
-    const bool opaque = own && (w.w & 0x8000u) != 0u;
-    const uint32_t first = ((w.w >> 1) & 0x3fffu) << 10;   // list position (1024-entry granularity) of the tile's first hit
+    const bool classic_now = opaque_all && (w.w & 0x4000u) == 0u;       // every pixel opaque, and none of them met the geometry on the way
+    // which promise did the tile make for THIS frame?  classic: all of its pixels go opaque inside its horizon (no depth clause was
+    // applied on its account); otherwise only the uncovered ones have to (the covered ones were given what lies in front of the geometry)
+    const bool pred_classic = !(hz.stat && hz.stat_in_use) || !inside || hz.stat[gty * g.tiles_x + tx] != 0.0f;
+    const uint32_t es_u = w.w >> 24;
+    const uint32_t rd_u = (es_u == 0xffu || (es_u << 10) > w.x) ? w.x : (es_u << 10);
+    // The promise that is CHECKED goes by what the tile was predicted to be; the horizon that is LEFT by what it is now (classic: all of
+    // its pixels -- next frame no depth clause will be applied on its account, so the horizon has to cover all of them; otherwise its
+    // uncovered pixels).  `opaque` = the tile keeps / can make the promise in question.
+    const uint32_t rdc = pred_classic ? rd_all : rd_u;                                   // check
+    // (a tile predicted classic keeps its promise when ALL of its pixels go opaque -- whether it met the geometry on the way only decides
+    //  what it is predicted to be next time)
+    const bool opaque_c = own && (pred_classic ? opaque_all : (classic_now || (w.w & 0x8000u) != 0u));
+    const uint32_t rd = classic_now ? rd_all : rd_u;                                     // leave
+    const bool opaque = own && (classic_now || (w.w & 0x8000u) != 0u);
+    const uint32_t first = ((w.w >> 1) & 0x1fffu) << 10;   // list position (1024-entry granularity) of the tile's first hit
     // where the tile's next horizon sits: a quarter of what it scanned from its first hit on (+1024 entries) beyond the scan -- a
     // tile high up in a super-tile over oblique ground starts deep in the shared list, and that part is not its depth range
     const uint32_t want = rd + ((rd > first ? rd - first : 0u) >> 2) + 1024u;
@@ -693,9 +740,16 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
     uint32_t viol = 0u, nused = 0u, nfin = 0u;
     if (hz.raw) {
         const bool ok = opaque && rd > 0u && rd <= len;
-        const bool c1 = ok && hold < 3.0e38f, c2 = ok && want < len;
-        const uint32_t i1 = hz.lists[c1 ? (uint32_t)s0 + rd - 1u : 0u].x;   // the last entry the tile scanned
-        const uint32_t i2 = hz.lists[c2 ? (uint32_t)s0 + want : 0u].x;      // the entry its next horizon sits at
+        const bool c1 = opaque_c && rdc > 0u && rdc <= len && hold < 3.0e38f, c2 = ok && want < len;
+        const uint32_t i1 = hz.lists[c1 ? (uint32_t)s0 + rdc - 1u : 0u].x;  // the last entry the tile scanned (for the promise it made)
+        // Depth-tested frames WITHOUT horizons (the first frames, a repair): K1 dropped what lies behind the opaque geometry, so a tile that
+        // saturates just in front of it does so on a list that ENDS there -- "too short" for the rule above, and with no old horizon to push
+        // out it would get none.  A tile without a horizon costs far more than itself: the pyramid look-up of a cluster's widened rect
+        // spans up to 32 x 32 tiles, and one +inf among them keeps the cluster (measured: 273 such tiles, 42 k surviving clusters instead
+        // of 14 k).  Its list's last entry, pushed out by 5 %, stands in; the next frame -- culled, its lists no longer cut inside the
+        // horizons -- checks itself as always.
+        const bool c3 = ok && !c2 && !(hold < 3.0e38f) && hz.depth_culled != 0;
+        const uint32_t i2 = hz.lists[c2 ? (uint32_t)s0 + want : (c3 ? (uint32_t)s0 + len - 1u : 0u)].x;      // the entry its next horizon sits at
         const float4 P1 = hz.geoA[c1 ? i1 : 0u], P2 = hz.geoA[c2 ? i2 : 0u];
         // distance^2 = the sort key of k_preprocess.h, same operations
         float klast, hnew;
@@ -705,8 +759,18 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
         if (own) {
             // this frame: a tile with a horizon must have gone opaque without looking past it (a tile whose uncovered pixels needed
             // nothing at all -- the opaque pass covers it -- has looked at nothing)
-            const bool none = opaque && rd == 0u;
-            if (hold < 3.0e38f && !none && (!opaque || !c1 || !(klast <= hold))) viol = 1u;
+            const bool none_c = opaque_c && !pred_classic && rdc == 0u;      // (the uncovered pixels were promised, and needed nothing)
+            const bool none = opaque && !classic_now && rd == 0u;
+            if (hold < 3.0e38f && !none_c && (!opaque_c || !c1 || !(klast <= hold))) viol = 1u;
+            if (viol && hz.dbg) {
+                const uint32_t k = atomicAdd(hz.dbg, 1u);
+                if (k < 8u) {
+                    uint32_t* o = hz.dbg + 1 + 8 * k;
+                    o[0] = (uint32_t)tx; o[1] = (uint32_t)gty; o[2] = w.w; o[3] = w.x; o[4] = __float_as_uint(hold); o[5] = __float_as_uint(klast);
+                    o[6] = (pred_classic ? 1u : 0u) | (opaque_c ? 2u : 0u) | (c1 ? 4u : 0u) | (classic_now ? 8u : 0u); o[7] = (rdc << 8) | (len > 0xffffffu ? 0xffu : 0u); 
+                    o[7] = rdc; 
+                }
+            }
             // next frame: the key a quarter (+1024 entries) beyond the scan; a list too short for that was itself thinned by
             // culling -- then the old horizon is pushed out by 5 % (in distance^2) instead
             h = __builtin_inff();
@@ -714,9 +778,11 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
             else if (opaque) {
                 if (c2) h = hnew;
                 else if (hold < 3.0e38f) h = hold * 1.05f;
+                else if (c3) h = hnew * 1.05f;
             }
         }
-        if (inside && !a_done) hz.raw[gty * g.tiles_x + tx] = h;
+        // (the sign bit carries the tile's status for the slot's next frame: set = not classic; tiles of other ranks / outside: classic)
+        if (inside && !a_done) hz.raw[gty * g.tiles_x + tx] = (own && !classic_now) ? -h : h;
     }
     // would occlusion culling have something to work with?  Judged on every frame, with or without horizons being prepared: a tile
     // that draws anything counts, and counts as "finished early" when it went opaque in the first 70 % of its list
@@ -787,7 +853,7 @@ k_slab_mid(const uint4* __restrict__ tile_work_a, GsrSumArgs g, const int32_t* _
         const uint32_t len = (own && e0 > s0) ? (uint32_t)(e0 - s0) : 0u;
         const uint32_t es = (w.w >> 16) & 0xffu;      // (a finished tile: every pixel opaque, covered or not)
         const uint32_t rd = (es == 0xffu || (es << 10) > w.x) ? w.x : (es << 10);
-        const uint32_t first = ((w.w >> 1) & 0x3fffu) << 10;
+        const uint32_t first = ((w.w >> 1) & 0x1fffu) << 10;
         const uint32_t want = rd + ((rd > first ? rd - first : 0u) >> 2) + 1024u;
         const bool c2 = opaque && rd > 0u && rd <= len && want < len;
         const uint32_t i2 = hz.lists[c2 ? (uint32_t)s0 + want : 0u].x;
@@ -798,7 +864,8 @@ k_slab_mid(const uint4* __restrict__ tile_work_a, GsrSumArgs g, const int32_t* _
         const float slab_d2 = ka == 0xffffffffu ? __builtin_inff() : __builtin_bit_cast(float, ka + key_min);
         float h = 0.0f;
         if (own) h = !opaque ? __builtin_inff() : (c2 ? hnew : slab_d2 * 1.05f);
-        if (inside) hz.raw[gty * g.tiles_x + tx] = h;
+        // (status for the slot's next frame in the sign bit, as in k_tile_pass: a finished tile that met the geometry is not classic)
+        if (inside) hz.raw[gty * g.tiles_x + tx] = (own && !(opaque && (w.w & 0x4000u) == 0u)) ? -h : h;
     }
 }
 
@@ -935,9 +1002,15 @@ gsr_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int 
     float v = 0.0f;
     if (inside) {
         const int x0 = max(tx - r, 0), x1 = min(tx + r, tiles_x - 1), y0 = max(ty - r, 0), y1 = min(ty + r, tiles_y - 1);
+        bool allc = true;                 // every tile of the neighbourhood was classic (sign bit clear: k_tile_pass)
         for (int y = y0; y <= y1; ++y)
-            for (int x = x0; x <= x1; ++x) v = __builtin_fmaxf(v, raw[y * tiles_x + x]);
+            for (int x = x0; x <= x1; ++x) {
+                const float rv = raw[y * tiles_x + x];
+                v = __builtin_fmaxf(v, __builtin_fabsf(rv));
+                allc = allc && (__float_as_uint(rv) >> 31) == 0u;
+            }
         pyr[hz.pyr_off[0] + ty * tiles_x + tx] = v;
+        if (hz.stat) hz.stat[ty * tiles_x + tx] = allc ? 1.0f : 0.0f;
     }
     v = __builtin_fmaxf(v, __shfl_xor(v, 1, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 2, 64));
     if ((lane & 3) == 0 && inside) pyr[hz.pyr_off[1] + (ty >> 1) * gsr_pyr_dim(tiles_x, 1) + (tx >> 1)] = v;

@@ -167,6 +167,10 @@ struct GsrDepthPyrArgs {
     const float* depth;        // [height][width] window depth of the opaque pass (row 0 = bottom, like the framebuffer)
     float* pyr;                // the two pyramids of this frame's parity ...
     float* pyrc;
+    float* tcov;               // [tiles_y][tiles_x] for k_blend: < 0 = the tile has NO covered pixel (an ordinary tile: no depth load there)
+    const float* stat;         // [tiles_y][tiles_x] or NULL: != 0 = the tile was CLASSIC in the frame that left this frame's horizons (k_blend.h:
+                               // GsrHorizonArgs.stat) -- all of its pixels are expected to saturate inside its horizon, and no depth clause
+                               // is applied on its account: its covered depths do not enter pyrc
     float* pyr_next;           // ... and the other parity's: levels 4 and 5 are max-reduced with atomics (like the horizons'), so this frame
     float* pyrc_next;          //     clears them for the slot's next depth-tested frame
     uint32_t* active;          // [2]: this frame sets [par], and clears [par ^ 1] likewise
@@ -200,11 +204,11 @@ __device__ __forceinline__ void gsr_depth_pyramid_block(const GsrDepthPyrArgs& a
 {
     static_assert(THREADS == 256 || THREADS == 1024, "rows of 32 lanes");
     constexpr int RP = THREADS / 32, NL = 128 / RP;          // pixel rows per pass, loads per thread
-    __shared__ uint32_t s_tile[64], s_tilec[64], s_cov;
+    __shared__ uint32_t s_tile[64], s_tilec[64], s_tcov[64], s_cov;
     const int tid = threadIdx.x;
     const int nbx = (a.tiles_x + 7) >> 3;
     const int by = b / nbx, bx = b - by * nbx;
-    if (tid < 64) { s_tile[tid] = 0u; s_tilec[tid] = 0u; }
+    if (tid < 64) { s_tile[tid] = 0u; s_tilec[tid] = 0u; s_tcov[tid] = 0u; }
     if (tid == 0) s_cov = 0u;
     if (b == 0) {
         if (tid == 0) a.active[a.par ^ 1] = 0u;
@@ -235,6 +239,7 @@ __device__ __forceinline__ void gsr_depth_pyramid_block(const GsrDepthPyrArgs& a
     // (per pixel: fmax drops a NaN operand, so a NaN pixel counts as depth 0 -- it passes nothing; covered = depth < 1, which a NaN is not)
     auto dep = [](float d) { return __builtin_fmaxf(d, 0.0f); };
     auto cov = [](float d) { return (d < 1.0f && d >= 0.0f) ? d : 0.0f; };    // (a negative depth passes nothing either: 0)
+    auto iscov = [](float d) { return !(d >= 1.0f); };                        // (a NaN pixel counts as covered: it is not "cleared")
     bool anyc = false;
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
@@ -242,12 +247,14 @@ __device__ __forceinline__ void gsr_depth_pyramid_block(const GsrDepthPyrArgs& a
         const bool e0 = row < a.height && px0 < a.width, e1 = e0 && px0 + 1 < a.width, e2 = e0 && px0 + 2 < a.width, e3 = e0 && px0 + 3 < a.width;
         float v = __builtin_fmaxf(__builtin_fmaxf(dep(q[k].x), dep(q[k].y)), __builtin_fmaxf(dep(q[k].z), dep(q[k].w)));
         float vc = __builtin_fmaxf(__builtin_fmaxf(cov(q[k].x), cov(q[k].y)), __builtin_fmaxf(cov(q[k].z), cov(q[k].w)));
-        anyc = anyc || (e0 && q[k].x < 1.0f) || (e1 && q[k].y < 1.0f) || (e2 && q[k].z < 1.0f) || (e3 && q[k].w < 1.0f);
+        const bool cv = (e0 && iscov(q[k].x)) || (e1 && iscov(q[k].y)) || (e2 && iscov(q[k].z)) || (e3 && iscov(q[k].w));
+        anyc = anyc || cv;
         v = __builtin_fmaxf(v, __shfl_xor(v, 1, 64)); vc = __builtin_fmaxf(vc, __shfl_xor(vc, 1, 64));
         v = __builtin_fmaxf(v, __shfl_xor(v, 2, 64)); vc = __builtin_fmaxf(vc, __shfl_xor(vc, 2, 64));
         const int t = rl >> 4;                // tile row of the block
         if ((c4 & 3) == 0 && v > 0.0f) atomicMax(&s_tile[t * 8 + (c4 >> 2)], __float_as_uint(v));
         if ((c4 & 3) == 0 && vc > 0.0f) atomicMax(&s_tilec[t * 8 + (c4 >> 2)], __float_as_uint(vc));
+        if (cv) s_tcov[t * 8 + (c4 >> 2)] = 1u;         // (plain stores of the same value)
     }
     if (__any(anyc) && (tid & 63) == 0) s_cov = 1u;
     __syncthreads();
@@ -257,7 +264,12 @@ __device__ __forceinline__ void gsr_depth_pyramid_block(const GsrDepthPyrArgs& a
     const int tx = bx * 8 + lx, ty = by * 8 + ly;
     const bool inside = tx < a.tiles_x && ty < a.tiles_y;
     float v = inside ? __uint_as_float(s_tile[ly * 8 + lx]) : 0.0f, vc = inside ? __uint_as_float(s_tilec[ly * 8 + lx]) : 0.0f;
-    if (inside) { a.pyr[a.off[0] + ty * a.tiles_x + tx] = v; a.pyrc[a.off[0] + ty * a.tiles_x + tx] = vc; }
+    if (inside) {
+        const bool covt = s_tcov[ly * 8 + lx] != 0u;
+        a.tcov[ty * a.tiles_x + tx] = covt ? vc : -1.0f;
+        if (!covt || (a.stat && a.stat[ty * a.tiles_x + tx] != 0.0f)) vc = 0.0f;      // (no covered pixel / no depth clause for a classic tile)
+        a.pyr[a.off[0] + ty * a.tiles_x + tx] = v; a.pyrc[a.off[0] + ty * a.tiles_x + tx] = vc;
+    }
     if (s_cov && lane == 0) atomicOr(&a.active[a.par], 1u);
     v = __builtin_fmaxf(v, __shfl_xor(v, 1, 64)); v = __builtin_fmaxf(v, __shfl_xor(v, 2, 64));
     vc = __builtin_fmaxf(vc, __shfl_xor(vc, 1, 64)); vc = __builtin_fmaxf(vc, __shfl_xor(vc, 2, 64));
@@ -455,15 +467,24 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                             const int tx0 = (int)__builtin_fmaxf(xlo, 0.0f) >> 4, tx1 = (int)__builtin_fminf(xhi, wm1) >> 4;
                             const int ty0 = (int)__builtin_fmaxf(ylo, 0.0f) >> 4, ty1 = (int)__builtin_fminf(yhi, hm1) >> 4;
                             bool behind = false, covered_need = false;
+                            float hcl = __builtin_inff();         // the horizon over the tiles the cluster can reach (+inf: none)
+                            if (hpyr) {
+                                const int r_ = f.cull_dilate;
+                                hcl = gsr_pyr_max(hpyr, f.pyr_off, f.tiles_x, max(tx0 - r_, 0), max(ty0 - r_, 0), min(tx1 + r_, f.tiles_x - 1), min(ty1 + r_, f.tiles_y - 1));
+                            }
                             if (dact) {
                                 // depth-tested frames: does every splat of the cluster lie behind everything the opaque pass left under the
                                 // tiles the cluster can reach?  A LOWER bound of its splats' window depths: the smallest z / w of the
                                 // corners, less what rounding (here and in K1: eps per clip coordinate) can move a quotient
                                 const float zerr = 1.05f * eps * (1.0f + __builtin_fabsf(znmin)) / (wmin - eps) + 2.0e-7f;
                                 const float zlo = gsr_fma(znmin - zerr, 0.5f, 0.5f) - 2.0e-7f;
-                                behind = zlo > gsr_dpyr_max(dc.pyr, f.pyr_off, f.tiles_x, tx0, ty0, tx1, ty1);
+                                // (only where no finite horizon applies: k_preprocess.h says why)
+                                behind = !(hcl < 3.0e38f) && zlo > gsr_dpyr_max(dc.pyr, f.pyr_off, f.tiles_x, tx0, ty0, tx1, ty1);
                                 // ... or may a COVERED pixel there need one of them (k_preprocess.h: the depth clause of gsr_k1_back)?
-                                covered_need = !(zlo > gsr_dpyr_max(dc.pyrc, f.pyr_off, f.tiles_x, tx0, ty0, tx1, ty1));
+                                if (dc.pyrc) {
+                                    const int r_ = f.cull_dilate;
+                                    covered_need = !(zlo > gsr_dpyr_max(dc.pyrc, f.pyr_off, f.tiles_x, max(tx0 - r_, 0), max(ty0 - r_, 0), min(tx1 + r_, f.tiles_x - 1), min(ty1 + r_, f.tiles_y - 1)));
+                                }
                             }
                             if (gsr_owned_rows(ty0, ty1, GsrShard{f.shard_index, f.shard_count, f.shard_rpb}) == 0) {
                                 keep = false;                           // none of its tile rows is ours
@@ -494,11 +515,7 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                                     if (kf - f.key_min <= key_a) keep = false;
                                 }
                                 // behind the depth horizon of every tile it can reach (widened by the dilation radius)?
-                                if (keep && hpyr && !covered_need) {
-                                    const int r_ = f.cull_dilate;
-                                    const float h = gsr_pyr_max(hpyr, f.pyr_off, f.tiles_x, max(tx0 - r_, 0), max(ty0 - r_, 0), min(tx1 + r_, f.tiles_x - 1), min(ty1 + r_, f.tiles_y - 1));
-                                    if (kb > gsr_horizon_key(h, f.key_min, f.key_max)) keep = false;
-                                }
+                                if (keep && hpyr && !covered_need && kb > gsr_horizon_key(hcl, f.key_min, f.key_max)) keep = false;
                             }
                         }
                     }

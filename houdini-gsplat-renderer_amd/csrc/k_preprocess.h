@@ -446,7 +446,7 @@ gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, co
     // look further than its horizon reports the frame, which is then rendered again without culling (k_sum_work).
     // (The pyramid is read through the cache: at most four gathers, usually of one or two lines.)
     // (depth-tested frames: "beyond every horizon" is half of the verdict -- see the depth clause below)
-    bool beyond = false;
+    bool beyond = false, no_horizon = true;     // (no finite horizon over the tiles the rect reaches, or no horizons in this frame at all)
     if (hpyr && out_rect != GSR_RECT_EMPTY) {
         const int g = f.rect_shift;
         const int x0 = (int)(out_rect & 255u) << g, y0 = (int)((out_rect >> 8) & 255u) << g;
@@ -454,6 +454,7 @@ gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, co
         const int r = f.cull_dilate;
         const float h = gsr_pyr_max(hpyr, f.pyr_off, f.tiles_x, max(x0 - r, 0), max(y0 - r, 0), min(x1 + r, f.tiles_x - 1), min(y1 + r, f.tiles_y - 1));
         beyond = o.kb > gsr_horizon_key(h, f.key_min, f.key_max);
+        no_horizon = !(h < 3.0e38f);
         if (beyond && !dpyr) out_rect = GSR_RECT_EMPTY;
     }
     // Depth-tested frames: the quad carries ONE window depth (o.zw) and a fragment survives iff zw <= depth[pixel]
@@ -469,8 +470,18 @@ gsr_k1_back(const GsrFrame& f, uint32_t i, uint32_t cap, const GsrK1Front& o, co
         const int g = f.rect_shift;
         const int x0 = (int)(out_rect & 255u) << g, y0 = (int)((out_rect >> 8) & 255u) << g;
         const int x1 = min((((int)((out_rect >> 16) & 255u) + 1) << g) - 1, f.tiles_x - 1), y1 = min((((int)(out_rect >> 24) + 1) << g) - 1, f.tiles_y - 1);
-        if (o.zw > gsr_dpyr_max(dpyr, f.pyr_off, f.tiles_x, x0, y0, x1, y1)) out_rect = GSR_RECT_EMPTY;
-        else if (beyond && o.zw > gsr_dpyr_max(dpyrc, f.pyr_off, f.tiles_x, x0, y0, x1, y1)) out_rect = GSR_RECT_EMPTY;
+        // (the first rule only where no finite horizon applies: INSIDE a horizon nothing is dropped by depth -- k_tile_pass places the next
+        //  horizon a quarter + 1024 entries down the list, a list cut at the geometry is "too short" for that, and its fallback pushes the
+        //  horizon out by 5 % per frame for good: measured, 13 k surviving clusters became 45 k)
+        if (no_horizon) { if (o.zw > gsr_dpyr_max(dpyr, f.pyr_off, f.tiles_x, x0, y0, x1, y1)) out_rect = GSR_RECT_EMPTY; }
+        // (the covered depths of the tiles that were NOT classic in the frame that left the horizons, looked up over the rect widened like
+        //  the horizon look-up: a tile's status is as old as its horizon.  No pyrc: no depth clause at all -- phase 2 of a front-slab
+        //  frame, whose "horizons" are 0 for the tiles phase 1 FINISHED and +inf for the others)
+        else if (beyond) {
+            const int r = f.cull_dilate;
+            if (!dpyrc || o.zw > gsr_dpyr_max(dpyrc, f.pyr_off, f.tiles_x, max(x0 - r, 0), max(y0 - r, 0), min(x1 + r, f.tiles_x - 1), min(y1 + r, f.tiles_y - 1)))
+                out_rect = GSR_RECT_EMPTY;
+        }
     }
     if (out_rect != GSR_RECT_EMPTY) {
         // colour: Cd, optionally + SH (:224, :244-274) -- or left PENDING for the lazy colour pass (k_colour.h)

@@ -100,7 +100,7 @@ C_ABI_SYMBOLS = [
     "gsr_upload_begin", "gsr_upload_append", "gsr_upload_append_raw", "gsr_upload_end", "gsr_upload_abort", "gsr_upload", "gsr_set_row_shard", "gsr_band_rows",
     "gsr_stitch_bands", "gsr_render", "gsr_render_depth", "gsr_render_wire", "gsr_render_wire_over", "gsr_synchronize", "gsr_get_stats", "gsr_stats_reset", "gsr_set_option",
     "gsr_debug_read_records", "gsr_debug_read_depth_order", "gsr_debug_read_storage_order", "gsr_debug_read_tile_lists", "gsr_debug_sort_pairs", "gsr_debug_sort_pairs_local", "gsr_debug_policy", "gsr_debug_policy_state",
-    "gsr_debug_read_tile_work",
+    "gsr_debug_read_tile_work", "gsr_debug_read_horizons",
     "gsr_multi_create", "gsr_multi_destroy", "gsr_multi_count", "gsr_multi_transport", "gsr_multi_context",
     "gsr_multi_set_stream", "gsr_multi_set_option", "gsr_multi_upload_begin", "gsr_multi_upload_append",
     "gsr_multi_upload_end", "gsr_multi_upload_abort", "gsr_multi_upload", "gsr_multi_render", "gsr_multi_render_depth",
@@ -172,6 +172,7 @@ def load_library() -> C.CDLL:
     L.gsr_debug_policy.argtypes = [vp, i32, C.c_longlong, C.c_longlong]
     L.gsr_debug_policy_state.argtypes = [vp, vp]
     L.gsr_debug_read_tile_work.argtypes = [vp, vp, i64]
+    L.gsr_debug_read_horizons.argtypes = [vp, vp, i64]
     # host shim wrappers
     L.gsplat_renderer_create.restype = vp
     L.gsplat_renderer_create.argtypes = [i32]
@@ -519,6 +520,12 @@ class Engine:
         out = np.zeros((nt, 4), np.uint32)
         _check(self.L.gsr_debug_read_tile_work(self.h, out.ctypes.data, nt))
         return out.reshape(st["tiles_y"], st["tiles_x"], 4)
+
+    def debug_horizons(self, tiles_x: int, tiles_y: int) -> np.ndarray:
+        """[4, tiles_y, tiles_x] float32: dilated horizons / raw horizons (sign = status) / dilated status / covered depths (whole image)"""
+        out = np.zeros((4, tiles_y, tiles_x), np.float32)
+        _check(self.L.gsr_debug_read_horizons(self.h, out.ctypes.data, tiles_x * tiles_y))
+        return out
 
     def debug_sort_pairs(self, keys: np.ndarray, vals: np.ndarray, key_bits: int = 32, local=None):
         """the pipeline's stable radix sort on host arrays; local = (bucket_lo, bucket_shift): the small-frame form (BK_BUCKETS = 1024 buckets of

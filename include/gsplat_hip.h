@@ -372,6 +372,10 @@ int  gsr_debug_read_tile_lists(gsr_context* ctx, int32_t* list_start, int32_t* l
 /* per tile of the last frame, four uint32: {list entries scanned, records gathered, wave-record evaluations, bit 0: the tile
  * stopped because every pixel was opaque} as the blend kernel counted them */
 int  gsr_debug_read_tile_work(gsr_context* ctx, uint32_t* work4, int64_t n_tiles);
+/* per tile of the WHOLE image (tiles_x * tiles_y of the frame, not the shard), four planes of n_tiles floats: the depth horizons the slot's
+ * next frame would be culled against (distance^2, dilated; +inf = none), the raw horizons (sign bit = the tile's status), the dilated
+ * status, and the covered depths of the last depth-tested frame as K1 saw them */
+int  gsr_debug_read_horizons(gsr_context* ctx, float* out4, int64_t n_tiles);
 
 /* Stand-alone device radix sort of (key,value) u32 pairs on bits [0, key_bits):
  * the sort the pipeline uses, exposed for parity tests (host pointers). */

@@ -40,7 +40,7 @@ for slack_mode in ("scan", "own"):
         es = tw[..., 3] >> 16
         return np.where((es == 0xffff) | (es * 1024 > tw[..., 0]) | (slack_mode == "scan"), tw[..., 0], es * 1024)
     rd, hits, sat = extent(tw0), tw0[..., 1], tw0[..., 3] & 1
-    first = ((tw0[..., 3] >> 1) & 0x3fff) * 1024 if slack_mode == "own" else 0
+    first = ((tw0[..., 3] >> 1) & 0x1fff) * 1024 if slack_mode == "own" else 0
     want = rd + (np.maximum(rd - first, 0) >> 2) + 1024
     ok = (sat == 1) & (want < ln)
     h = np.full(rd.shape, np.inf, np.float32)

@@ -386,6 +386,15 @@ void gsplat_renderer_flush_entries_for_matching_detail(gsplat_renderer* h, const
 void gsplat_renderer_generate_render_geometry(gsplat_renderer* h, GSplatRenderContext* r) { if (h && r) h->impl->generateRenderGeometry(*r); }
 void gsplat_renderer_render(gsplat_renderer* h, GSplatRenderContext* r, int is_object_level) { if (h && r) h->impl->render(*r, is_object_level != 0); }
 void gsplat_renderer_post_render(gsplat_renderer* h) { if (h) h->impl->postRender(); }
+void gsplat_renderer_redraw(gsplat_renderer* h, const char* const* ids, int n, GSplatRenderContext* r, int is_object_level)
+{
+    if (!h || !r) return;
+    for (int k = 0; k < n; ++k)
+        if (ids && ids[k]) h->impl->includeInRenderPass(ids[k]);
+    h->impl->generateRenderGeometry(*r);
+    h->impl->render(*r, is_object_level != 0);
+    h->impl->postRender();
+}
 void gsplat_renderer_set_rendering_enabled(gsplat_renderer* h, int enabled) { if (h) h->impl->setRenderingEnabled(enabled != 0); }
 void gsplat_renderer_set_explicit_camera_pos(gsplat_renderer* h, const float pos[3]) { if (h && pos) h->impl->setExplicitCameraPos(pos); }
 void gsplat_renderer_set_spherical_harmonics_order(gsplat_renderer* h, int order) { if (h) h->impl->setSphericalHarmonicsOrder(order); }

@@ -318,8 +318,17 @@ struct gsr_context {
     uint32_t* wire_inv = nullptr;              // ... and, with spatially ordered storage, upload index -> storage slot (built on first use per geometry)
     uint64_t wire_inv_gen = 0;
     size_t wire_cap = 0;                       // pixels both hold
-    char* stage = nullptr;                     // raw attribute arrays of an upload in progress
+    // An upload in progress.  The registerUpdate()-layout arrays of ALL its entries sit in one device arena (sized at gsr_upload_begin,
+    // kept between uploads: an animated sequence re-stages every cook), in upload order; gsr_upload_end orders and packs them (k_pack).
+    char* stage = nullptr;
     size_t stage_cap = 0;
+    char* stage_raw = nullptr;                 // ... and the raw float arrays of ONE gsr_upload_append_raw call (quantised into the arena)
+    size_t stage_raw_cap = 0;
+    uint32_t *up_kA = nullptr, *up_kB = nullptr, *up_vA = nullptr, *up_vB = nullptr;   // Morton codes / upload indices, ping-pong (kept between uploads)
+    size_t up_sort_cap = 0;
+    float* up_part = nullptr;                  // bounding-box partials
+    hipEvent_t up_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double up_t_begin = 0.0, up_h2d_ms = 0.0, up_quant_ms = 0.0;
 };
 
 template <typename T>
@@ -544,7 +553,9 @@ extern "C" void gsr_destroy(gsr_context* c)
     free_geometry(c);
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) slot_destroy(c->slot[k]);
     dev_free(c->tile_map);
-    dev_free(c->wire_zbuf); dev_free(c->wire_out); dev_free(c->wire_inv); dev_free(c->stage);
+    dev_free(c->wire_zbuf); dev_free(c->wire_out); dev_free(c->wire_inv); dev_free(c->stage); dev_free(c->stage_raw);
+    dev_free(c->up_kA); dev_free(c->up_kB); dev_free(c->up_vA); dev_free(c->up_vB); dev_free(c->up_part);
+    for (int k = 0; k < 4; ++k) if (c->up_ev[k]) (void)hipEventDestroy(c->up_ev[k]);
     dev_free(c->prefix); dev_free(c->prefix_all); dev_free(c->prefix_none); dev_free(c->lazy_hint);
     dev_free(c->pos_order); dev_free(c->blk_pre);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -606,6 +617,31 @@ extern "C" int gsr_set_option(gsr_context* c, int option, int value)
     return GSR_OK;
 }
 
+// the arena's arrays for `total` splats (256-byte aligned sections)
+struct UpArena {
+    float *P, *alpha;
+    uint16_t *Cd, *scale, *orient, *shx, *shy, *shz;
+    size_t bytes;
+};
+static UpArena up_arena(char* base, size_t total, bool has_sh)
+{
+    const size_t al = 256;
+    auto pad = [&](size_t b) { return (b + al - 1) / al * al; };
+    UpArena a{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += pad(bytes); return p; };
+    a.P = reinterpret_cast<float*>(take(total * 12)); a.alpha = reinterpret_cast<float*>(take(total * 4));
+    a.Cd = reinterpret_cast<uint16_t*>(take(total * 6)); a.scale = reinterpret_cast<uint16_t*>(take(total * 6));
+    a.orient = reinterpret_cast<uint16_t*>(take(total * 8));
+    if (has_sh) {
+        a.shx = reinterpret_cast<uint16_t*>(take(total * 32)); a.shy = reinterpret_cast<uint16_t*>(take(total * 32));
+        a.shz = reinterpret_cast<uint16_t*>(take(total * 32));
+    }
+    a.bytes = off;
+    return a;
+}
+static double up_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // ---------------------------------------------------------------------------
 // geometry staging
 extern "C" int gsr_upload_begin(gsr_context* c, int64_t total, int has_sh, const float origin[3])
@@ -639,6 +675,17 @@ extern "C" int gsr_upload_begin(gsr_context* c, int64_t total, int has_sh, const
         c->cap = (uint32_t)cap;
         c->col_chunks = chunks;
     }
+    // the staging arena of the whole upload (kept between uploads; only ever grown)
+    {
+        const UpArena A = up_arena(nullptr, n, has_sh != 0);
+        if (A.bytes > c->stage_cap) {
+            dev_free(c->stage);
+            c->stage_cap = 0;
+            if ((rc = dev_alloc(&c->stage, A.bytes + 256))) return rc;
+            c->stage_cap = A.bytes + 256;
+        }
+    }
+    c->up_t_begin = up_now_ms(); c->up_h2d_ms = 0.0; c->up_quant_ms = 0.0;
     c->n = 0;
     c->has_sh = has_sh != 0;
     c->up_total = n;
@@ -662,52 +709,27 @@ extern "C" int gsr_upload_append(gsr_context* c, int64_t n64, const float* P, co
     if (!P || !Cd || !alpha || !scale || !orient) return set_err(GSR_E_INVALID, "gsr_upload_append: NULL attribute array");
     if (c->has_sh && (!shx || !shy || !shz)) return set_err(GSR_E_INVALID, "gsr_upload_append: SH announced but arrays are NULL");
     HIP_TRY(hipSetDevice(c->device));
+    const double t0 = up_now_ms();
     const uint32_t n = (uint32_t)n64;
+    const size_t at = c->up_filled;
     hipStream_t us = c->slot[0].own;
-    // raw staging arena: one device allocation shared by the appends of an upload (grown on demand, released by
-    // gsr_upload_end / _abort -- it is as large as the geometry itself)
-    const size_t al = 256;
-    auto pad = [&](size_t b) { return (b + al - 1) / al * al; };
-    const size_t bP = pad((size_t)n * 12), bA = pad((size_t)n * 4), bC = pad((size_t)n * 6), bS = pad((size_t)n * 6),
-                 bO = pad((size_t)n * 8), bH = c->has_sh ? pad((size_t)n * 32) : 0;
-    const size_t need = bP + bA + bC + bS + bO + 3 * bH;
-    if (need > c->stage_cap) {
-        HIP_TRY(hipStreamSynchronize(us));
-        dev_free(c->stage);
-        c->stage_cap = 0;
-        int rc = dev_alloc(&c->stage, need);
-        if (rc) return rc;
-        c->stage_cap = need;
-    }
-    char* base = c->stage;
-    float* dP = reinterpret_cast<float*>(base); base += bP;
-    float* dA = reinterpret_cast<float*>(base); base += bA;
-    uint16_t* dCd = reinterpret_cast<uint16_t*>(base); base += bC;
-    uint16_t* dS = reinterpret_cast<uint16_t*>(base); base += bS;
-    uint16_t* dO = reinterpret_cast<uint16_t*>(base); base += bO;
-    uint16_t *dX = nullptr, *dY = nullptr, *dZ = nullptr;
-    if (c->has_sh) {
-        dX = reinterpret_cast<uint16_t*>(base); base += bH;
-        dY = reinterpret_cast<uint16_t*>(base); base += bH;
-        dZ = reinterpret_cast<uint16_t*>(base);
-    }
+    const UpArena A = up_arena(c->stage, c->up_total, c->has_sh);
+    // Host -> device, nothing else: the entry lands behind the ones before it, in upload order.  (Pageable memory: the runtime stages
+    // it through its own pinned buffers at the link's rate -- 56 GB/s measured on this box, the same as from pinned memory:
+    // tools/ubench_h2d.hip.  Ordering, packing and the cluster bounds happen once, over the whole upload, in gsr_upload_end.)
     hipError_t e = hipSuccess;
     auto h2d = [&](void* d, const void* h, size_t bytes) { if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, us); };
-    h2d(dP, P, (size_t)n * 12); h2d(dA, alpha, (size_t)n * 4); h2d(dCd, Cd, (size_t)n * 6);
-    h2d(dS, scale, (size_t)n * 6); h2d(dO, orient, (size_t)n * 8);
-    if (c->has_sh) { h2d(dX, shx, (size_t)n * 32); h2d(dY, shy, (size_t)n * 32); h2d(dZ, shz, (size_t)n * 32); }
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_repack, dim3(div_up(n, 256)), dim3(256), 0, us, n, c->up_filled, c->cap,
-                           c->has_sh ? 1 : 0, dP, dCd, dA, dS, dO, dX, dY, dZ, c->geoA, c->geoB, c->col, c->colrow);
-        e = hipGetLastError();
-    }
+    h2d(A.P + 3 * at, P, (size_t)n * 12); h2d(A.alpha + at, alpha, (size_t)n * 4); h2d(A.Cd + 3 * at, Cd, (size_t)n * 6);
+    h2d(A.scale + 3 * at, scale, (size_t)n * 6); h2d(A.orient + 4 * at, orient, (size_t)n * 8);
+    if (c->has_sh) { h2d(A.shx + 16 * at, shx, (size_t)n * 32); h2d(A.shy + 16 * at, shy, (size_t)n * 32); h2d(A.shz + 16 * at, shz, (size_t)n * 32); }
     if (e == hipSuccess) e = hipStreamSynchronize(us);   // the caller's arrays may be freed on return
     if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_upload_append: %s", hipGetErrorString(e));
     c->up_filled += n;
+    c->up_h2d_ms += up_now_ms() - t0;
     return GSR_OK;
 }
 
-static int order_and_cluster(gsr_context* c);
+static int order_and_pack(gsr_context* c);
 
 // an upload that failed after the arrays were filled: the context goes back to "nothing uploaded"
 static void drop_geometry(gsr_context* c)
@@ -737,43 +759,37 @@ extern "C" int gsr_upload_append_raw(gsr_context* c, int64_t n64, const gsr_raw_
         return set_err(GSR_E_INVALID, "gsr_upload_append_raw: bad spherical-harmonics description");
     if (c->has_sh != (a->sh_scheme != 0)) return set_err(GSR_E_INVALID, "gsr_upload_append_raw: SH presence differs from gsr_upload_begin");
     HIP_TRY(hipSetDevice(c->device));
+    const double t0 = up_now_ms();
     const uint32_t n = (uint32_t)n64;
+    const size_t at = c->up_filled;
     hipStream_t us = c->slot[0].own;
+    const UpArena A = up_arena(c->stage, c->up_total, c->has_sh);
     const size_t al = 256;
     auto pad = [&](size_t b) { return (b + al - 1) / al * al; };
-    // staging arena: the half arrays k_repack takes, then the raw float arrays they are made from
+    // the raw float arrays of THIS entry: their own scratch (kept between calls), quantised into the arena behind the entries before it
     const int nsh = a->sh_scheme == 2 ? 15 : (a->sh_scheme == 3 ? 45 : 0);
     int sh_live = 0;                 // schemes 2 / 3: the arrays before the first gap
     if (nsh) while (sh_live < nsh && a->sh_ptr[sh_live]) ++sh_live;
-    const size_t bP = pad((size_t)n * 12), bA = pad((size_t)n * 4), bC = pad((size_t)n * 6), bS = pad((size_t)n * 6), bO = pad((size_t)n * 8),
-                 bH = c->has_sh ? pad((size_t)n * 32) : 0;
     const size_t rC = a->Cd ? pad((size_t)n * 12) : 0, rS = a->scale ? pad((size_t)n * 12) : 0, rO = a->orient ? pad((size_t)n * 16) : 0;
-    const size_t rArr = a->sh_scheme == 1 ? pad((size_t)n * a->sh_vec3_per_point * 12) : 0;
+    const size_t rArr = a->sh_scheme == 1 ? pad((size_t)n * std::min(a->sh_vec3_per_point, 16) * 12) : 0;
     const size_t rEach = a->sh_scheme == 2 ? pad((size_t)n * 12) : (a->sh_scheme == 3 ? pad((size_t)n * 4) : 0);
-    const size_t need = bP + bA + bC + bS + bO + 3 * bH + rC + rS + rO + rArr + rEach * sh_live;
-    if (need > c->stage_cap) {
+    const size_t need = rC + rS + rO + rArr + rEach * sh_live + al;
+    if (need > c->stage_raw_cap) {
         HIP_TRY(hipStreamSynchronize(us));
-        dev_free(c->stage);
-        c->stage_cap = 0;
-        int rc = dev_alloc(&c->stage, need);
+        dev_free(c->stage_raw);
+        c->stage_raw_cap = 0;
+        int rc = dev_alloc(&c->stage_raw, need);
         if (rc) return rc;
-        c->stage_cap = need;
+        c->stage_raw_cap = need;
     }
-    char* base = c->stage;
+    char* base = c->stage_raw;
     auto take = [&](size_t bytes) { char* p = base; base += bytes; return p; };
-    float* dP = reinterpret_cast<float*>(take(bP));
-    float* dA = reinterpret_cast<float*>(take(bA));
-    uint16_t* dCd = reinterpret_cast<uint16_t*>(take(bC));
-    uint16_t* dS = reinterpret_cast<uint16_t*>(take(bS));
-    uint16_t* dO = reinterpret_cast<uint16_t*>(take(bO));
-    uint16_t *dX = nullptr, *dY = nullptr, *dZ = nullptr;
-    if (c->has_sh) { dX = reinterpret_cast<uint16_t*>(take(bH)); dY = reinterpret_cast<uint16_t*>(take(bH)); dZ = reinterpret_cast<uint16_t*>(take(bH)); }
     hipError_t e = hipSuccess;
     auto h2d = [&](void* d, const void* h, size_t bytes) { if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, us); };
-    h2d(dP, a->P, (size_t)n * 12);
+    h2d(A.P + 3 * at, a->P, (size_t)n * 12);
     std::vector<float> ones;
-    if (a->alpha) h2d(dA, a->alpha, (size_t)n * 4);
-    else { ones.assign(n, 1.0f); h2d(dA, ones.data(), (size_t)n * 4); }     // missing opacity: opaque
+    if (a->alpha) h2d(A.alpha + at, a->alpha, (size_t)n * 4);
+    else { ones.assign(n, 1.0f); h2d(A.alpha + at, ones.data(), (size_t)n * 4); }     // missing opacity: opaque
     const float *rCd = nullptr, *rSc = nullptr, *rOr = nullptr;
     if (a->Cd) { float* p = reinterpret_cast<float*>(take(rC)); h2d(p, a->Cd, (size_t)n * 12); rCd = p; }
     if (a->scale) { float* p = reinterpret_cast<float*>(take(rS)); h2d(p, a->scale, (size_t)n * 12); rSc = p; }
@@ -792,14 +808,14 @@ extern "C" int gsr_upload_append_raw(gsr_context* c, int64_t n64, const gsr_raw_
         for (int j = 0; j < sh_live; ++j) { float* p = reinterpret_cast<float*>(take(rEach)); h2d(p, a->sh_ptr[j], a->sh_scheme == 2 ? (size_t)n * 12 : (size_t)n * 4); sh.ptr[j] = p; }
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_quantize_raw, dim3(div_up(n, 256)), dim3(256), 0, us, n, rCd, rSc, rOr, sh, dCd, dS, dO, dX, dY, dZ);
-        hipLaunchKernelGGL(k_repack, dim3(div_up(n, 256)), dim3(256), 0, us, n, c->up_filled, c->cap,
-                           c->has_sh ? 1 : 0, dP, dCd, dA, dS, dO, dX, dY, dZ, c->geoA, c->geoB, c->col, c->colrow);
+        hipLaunchKernelGGL(k_quantize_raw, dim3(div_up(n, 256)), dim3(256), 0, us, n, rCd, rSc, rOr, sh, A.Cd + 3 * at, A.scale + 3 * at, A.orient + 4 * at,
+                           c->has_sh ? A.shx + 16 * at : (uint16_t*)nullptr, c->has_sh ? A.shy + 16 * at : (uint16_t*)nullptr, c->has_sh ? A.shz + 16 * at : (uint16_t*)nullptr);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(us);   // the caller's arrays may be freed on return
     if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_upload_append_raw: %s", hipGetErrorString(e));
     c->up_filled += n;
+    c->up_h2d_ms += up_now_ms() - t0;
     return GSR_OK;
 }
 
@@ -807,37 +823,13 @@ extern "C" int gsr_upload_end(gsr_context* c)
 {
     if (!c || !c->uploading) return set_err(GSR_E_INVALID, "gsr_upload_end: no upload in progress");
     c->uploading = false;
-    dev_free(c->stage);
-    c->stage_cap = 0;
     if (c->up_filled != c->up_total)
         return set_err(GSR_E_INVALID, "gsr_upload_end: %u of %u announced splats were appended", c->up_filled, c->up_total);
     c->n = c->up_total;
-    // bounding box of the positions: bounds distance^2 to any camera, i.e. the sort-key range per frame
     c->bbox_ok = false;
     if (c->n > 0) {
         HIP_TRY(hipSetDevice(c->device));
-        hipStream_t us = c->slot[0].own;
-        const int grid = 512;
-        float* d_part = nullptr;
-        int rc = dev_alloc(&d_part, (size_t)grid * 6);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_bbox_partials, dim3(grid), dim3(256), 0, us, c->geoA, c->n, d_part);
-        std::vector<float> hp((size_t)grid * 6);
-        hipError_t e = hipMemcpyAsync(hp.data(), d_part, hp.size() * 4, hipMemcpyDeviceToHost, us);
-        if (e == hipSuccess) e = hipStreamSynchronize(us);
-        dev_free(d_part);
-        if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_upload_end: %s", hipGetErrorString(e));
-        bool ok = true;
-        for (int k = 0; k < 3; ++k) { c->bb_lo[k] = 3.0e38; c->bb_hi[k] = -3.0e38; }
-        for (int b = 0; b < grid; ++b)
-            for (int k = 0; k < 3; ++k) {
-                const float lo = hp[(size_t)b * 6 + k], hi = hp[(size_t)b * 6 + 3 + k];
-                ok = ok && std::isfinite(lo) && std::isfinite(hi);
-                c->bb_lo[k] = std::min(c->bb_lo[k], (double)lo);
-                c->bb_hi[k] = std::max(c->bb_hi[k], (double)hi);
-            }
-        c->bbox_ok = ok;
-        rc = order_and_cluster(c);
+        int rc = order_and_pack(c);
         if (rc) {
             // nothing half-made may stay renderable: no geometry, no cached order, no horizons, no hints (a later gsr_render says
             // GSR_E_NO_GEOMETRY until a complete upload has succeeded)
@@ -854,8 +846,12 @@ extern "C" int gsr_upload_end(gsr_context* c)
     for (int k = 0; k < GSR_MAX_SLOTS; ++k) { c->slot[k].surv_hint = 0; c->slot[k].kept_hint = 0; c->slot[k].kept_lo = c->slot[k].kept_hi = 0; c->slot[k].horizon_valid = false; c->slot[k].local_pol.on_upload(); c->slot[k].slab_kept1 = c->slot[k].slab_kept2 = 0; }
     c->lazy_pays = false;              // ... and in automatic mode the first frames are eager until the kernels say it pays
     // (the kernels' verdicts on the last frame of the PREVIOUS cloud must not reach the first frame of this one through the device word)
-    if (c->lazy_hint && hipMemset(c->lazy_hint, 0, 4) != hipSuccess) return set_err(GSR_E_HIP, "upload: could not reset the policy word");
+    if (c->lazy_hint && hipMemsetAsync(c->lazy_hint, 0, 4, c->slot[0].own) != hipSuccess) return set_err(GSR_E_HIP, "upload: could not reset the policy word");
+    if (c->lazy_hint && hipStreamSynchronize(c->slot[0].own) != hipSuccess) return set_err(GSR_E_HIP, "upload: could not reset the policy word");
     c->st.n_splats = c->n;
+    c->st.uploads += 1;
+    c->st.upload_ms[0] = c->up_h2d_ms;
+    c->st.upload_ms[3] = up_now_ms() - c->up_t_begin;
     return GSR_OK;
 }
 
@@ -864,8 +860,6 @@ extern "C" int gsr_upload_abort(gsr_context* c)
     if (!c) return set_err(GSR_E_INVALID, "gsr_upload_abort: ctx is NULL");
     // an upload that failed half-way leaves no geometry behind: rendering needs a complete new upload
     if (c->uploading) { c->uploading = false; c->n = 0; c->up_total = c->up_filled = 0; c->st.n_splats = 0; }
-    dev_free(c->stage);
-    c->stage_cap = 0;
     return GSR_OK;
 }
 
@@ -1000,57 +994,87 @@ static void cluster_grid(uint32_t nclus, int* rounds, uint32_t* ngroups)
     *ngroups = nclus ? div_up(nclus, (uint32_t)CC_THREADS * (uint32_t)r) : 0u;
 }
 
-static int order_and_cluster(gsr_context* c)
+static int order_and_pack(gsr_context* c)
 {
     const uint32_t n = c->n;
     FrameSlot& sl = c->slot[0];
     hipStream_t us = sl.stream;
     int rc = GSR_OK;
+    const UpArena A = up_arena(c->stage, c->up_total, c->has_sh);
+    for (int k = 0; k < 4; ++k)
+        if (!c->up_ev[k]) HIP_TRY(hipEventCreate(&c->up_ev[k]));
+    HIP_TRY(hipEventRecord(c->up_ev[0], us));
+    // bounding box of the positions: bounds distance^2 to any camera, i.e. the sort-key range per frame -- and the Morton grid
+    {
+        const int grid = 512;
+        if (!c->up_part && (rc = dev_alloc(&c->up_part, (size_t)grid * 6))) return rc;
+        hipLaunchKernelGGL(k_bbox_partials, dim3(grid), dim3(256), 0, us, A.P, n, c->up_part);
+        std::vector<float> hp((size_t)grid * 6);
+        hipError_t e = hipMemcpyAsync(hp.data(), c->up_part, hp.size() * 4, hipMemcpyDeviceToHost, us);
+        if (e == hipSuccess) e = hipStreamSynchronize(us);
+        if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_upload_end: %s", hipGetErrorString(e));
+        bool ok = true;
+        for (int k = 0; k < 3; ++k) { c->bb_lo[k] = 3.0e38; c->bb_hi[k] = -3.0e38; }
+        for (int b = 0; b < grid; ++b)
+            for (int k = 0; k < 3; ++k) {
+                const float lo = hp[(size_t)b * 6 + k], hi = hp[(size_t)b * 6 + 3 + k];
+                ok = ok && std::isfinite(lo) && std::isfinite(hi);
+                c->bb_lo[k] = std::min(c->bb_lo[k], (double)lo);
+                c->bb_hi[k] = std::max(c->bb_hi[k], (double)hi);
+            }
+        c->bbox_ok = ok;
+    }
+    // the storage order: perm[j] = upload index of the splat in slot j (NULL: upload order)
+    dev_free(c->perm);
     if (c->opt_morton && c->bbox_ok && n > 1) {
-        uint32_t *kA = nullptr, *kB = nullptr, *vA = nullptr, *vB = nullptr;
-        float4* nA = nullptr; uint4 *nB = nullptr, *ncol = nullptr, *nrow = nullptr;
-        auto drop = [&]() { dev_free(kA); dev_free(kB); dev_free(vB); dev_free(nA); dev_free(nB); dev_free(ncol); dev_free(nrow); };
-        const bool have_tmp = !((rc = dev_alloc(&kA, n)) || (rc = dev_alloc(&kB, n)) || (rc = dev_alloc(&vA, n)) || (rc = dev_alloc(&vB, n)) ||
-                                (rc = dev_alloc(&nA, c->cap)) || (rc = dev_alloc(&nB, c->cap)) || (rc = dev_alloc(&ncol, (size_t)c->cap * c->col_chunks)) ||
-                                (c->has_sh && (rc = dev_alloc(&nrow, (size_t)c->cap * 8))));
-        if (!have_tmp) {
-            // the reorder needs a second copy of the geometry for a moment; without it the splats simply stay in upload order
-            // (perm = NULL: ties then break by upload index, the documented meaning of an unordered store) and get their clusters
-            drop(); dev_free(vA);
+        bool have = true;
+        if ((size_t)n > c->up_sort_cap) {
+            dev_free(c->up_kA); dev_free(c->up_kB); dev_free(c->up_vA); dev_free(c->up_vB);
+            c->up_sort_cap = 0;
+            const size_t want = (size_t)n + n / 8 + 1024;
+            have = !(dev_alloc(&c->up_kA, want) || dev_alloc(&c->up_kB, want) || dev_alloc(&c->up_vA, want) || dev_alloc(&c->up_vB, want));
+            if (have) c->up_sort_cap = want;
+            else {
+                // without the scratch the splats simply stay in upload order (perm = NULL: ties then break by upload index, the
+                // documented meaning of an unordered store) and get their clusters
+                dev_free(c->up_kA); dev_free(c->up_kB); dev_free(c->up_vA); dev_free(c->up_vB);
+                (void)hipGetLastError();
+            }
+        }
+        if (have && !(rc = dev_alloc(&c->perm, (size_t)n))) {
+            float lo[3], sc[3];
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = (float)c->bb_lo[k];
+                const double ext = c->bb_hi[k] - c->bb_lo[k];
+                sc[k] = ext > 0.0 ? (float)(1023.999 / ext) : 0.0f;
+                if (!std::isfinite(sc[k])) sc[k] = 0.0f;
+            }
+            uint32_t *kA = c->up_kA, *kB = c->up_kB, *vA = c->up_vA, *vB = c->up_vB;
+            hipLaunchKernelGGL(k_morton_codes, dim3(div_up(n, 256)), dim3(256), 0, us, A.P, n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], kA, vA);
+            rc = radix_sort(sl, kA, vA, kB, vB, n, 30, true, (uint32_t*)nullptr, RS_XCD_DEPTH != 0);   // (leaves the result in what kA / vA name now)
+            if (!rc && hipMemcpyAsync(c->perm, vA, (size_t)n * 4, hipMemcpyDeviceToDevice, us) != hipSuccess) rc = set_err(GSR_E_HIP, "gsr_upload_end: storage order");
+            if (rc) { dev_free(c->perm); return rc; }
+        } else if (have) {
             (void)hipGetLastError();
-            rc = GSR_OK;
-        }
-        float lo[3], sc[3];
-        if (have_tmp) {
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = (float)c->bb_lo[k];
-            const double ext = c->bb_hi[k] - c->bb_lo[k];
-            sc[k] = ext > 0.0 ? (float)(1023.999 / ext) : 0.0f;
-            if (!std::isfinite(sc[k])) sc[k] = 0.0f;
-        }
-        hipLaunchKernelGGL(k_morton_codes, dim3(div_up(n, 256)), dim3(256), 0, us, c->geoA, n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], kA, vA);
-        rc = radix_sort(sl, kA, vA, kB, vB, n, 30, true, (uint32_t*)nullptr, RS_XCD_DEPTH != 0);
-        if (!rc) {
-            hipLaunchKernelGGL(k_permute_geo, dim3(div_up(n, 256)), dim3(256), 0, us, n, c->cap, c->col_chunks, vA, c->geoA, c->geoB, c->col, nA, nB, ncol);
-            if (c->has_sh)
-                hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, us, n, vA, c->colrow, nrow);
-            hipError_t e = hipGetLastError();
-            if (e == hipSuccess) e = hipStreamSynchronize(us);
-            if (e != hipSuccess) rc = set_err(GSR_E_HIP, "gsr_upload_end: ordering the splats: %s", hipGetErrorString(e));
-        }
-        if (rc) { drop(); dev_free(vA); return rc; }
-        std::swap(c->geoA, nA); std::swap(c->geoB, nB); std::swap(c->col, ncol);
-        if (c->has_sh) std::swap(c->colrow, nrow);
-        c->perm = vA;
-        drop();   // (now the upload-ordered arrays and the sort scratch)
+            rc = GSR_OK;           // (no room for the permutation: upload order)
         }
     }
+    HIP_TRY(hipEventRecord(c->up_ev[1], us));
     c->nclus = div_up(n, GSR_CLUSTER);
+    dev_free(c->clusA); dev_free(c->clusB);
     if ((rc = dev_alloc(&c->clusA, c->nclus)) || (rc = dev_alloc(&c->clusB, c->nclus))) return rc;
-    hipLaunchKernelGGL(k_cluster_bounds, dim3(div_up(n, 256)), dim3(256), 0, us, n, c->geoA, c->geoB, c->clusA, c->clusB);
+    const GsrPackSrc src{A.P, A.alpha, A.Cd, A.scale, A.orient, A.shx, A.shy, A.shz};
+    if (c->has_sh)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack<true>), dim3(c->nclus), dim3(GSR_PACK_THREADS), 0, us, n, c->cap, src, c->perm, c->geoA, c->geoB, c->col, c->colrow, c->clusA, c->clusB);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack<false>), dim3(c->nclus), dim3(GSR_PACK_THREADS), 0, us, n, c->cap, src, c->perm, c->geoA, c->geoB, c->col, c->colrow, c->clusA, c->clusB);
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(c->up_ev[2], us);
     if (e == hipSuccess) e = hipStreamSynchronize(us);
-    if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_upload_end: cluster bounds: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return set_err(GSR_E_HIP, "gsr_upload_end: packing the splats: %s", hipGetErrorString(e));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->up_ev[0], c->up_ev[1]) == hipSuccess) c->st.upload_ms[1] = ms;
+    if (hipEventElapsedTime(&ms, c->up_ev[1], c->up_ev[2]) == hipSuccess) c->st.upload_ms[2] = ms;
     return GSR_OK;
 }
 
@@ -2516,7 +2540,12 @@ extern "C" int gsr_stats_reset(gsr_context* c)
             if (c->slot[k].lazy_ctr && hipMemcpy(&v, c->slot[k].lazy_ctr + 1, 8, hipMemcpyDeviceToHost) == hipSuccess) tot += v;
         c->lazy_base = (int64_t)tot;
     }
+    const int64_t ups = c->st.uploads;
+    double upm[6];
+    std::memcpy(upm, c->st.upload_ms, sizeof upm);      // (the last upload's figures describe the resident cloud: they outlive a reset)
     c->st = gsr_stats{};
+    c->st.uploads = ups;
+    std::memcpy(c->st.upload_ms, upm, sizeof upm);
     c->st.n_splats = ns;
     c->st.record_bytes = (int32_t)sizeof(GsrRecord);
     c->st.pair_bytes = 8;

@@ -32,12 +32,12 @@ __device__ __forceinline__ uint32_t cc_spread10(uint32_t v)
     return v;
 }
 __global__ void __launch_bounds__(256)
-k_morton_codes(const float4* __restrict__ geoA, uint32_t n, float lx, float ly, float lz, float sx, float sy, float sz,
+k_morton_codes(const float* __restrict__ P /* raw float[3] positions, upload order */, uint32_t n, float lx, float ly, float lz, float sx, float sy, float sz,
                uint32_t* __restrict__ code, uint32_t* __restrict__ idx)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    const float4 a = geoA[i];
+    const float3 a = make_float3(P[3 * (size_t)i], P[3 * (size_t)i + 1], P[3 * (size_t)i + 2]);
     uint32_t c = 0x3fffffffu;
     if (__builtin_fabsf(a.x) < 3.0e38f && __builtin_fabsf(a.y) < 3.0e38f && __builtin_fabsf(a.z) < 3.0e38f) {
         const float qx = __builtin_fminf(__builtin_fmaxf((a.x - lx) * sx, 0.0f), 1023.0f);
@@ -49,63 +49,9 @@ k_morton_codes(const float4* __restrict__ geoA, uint32_t n, float lx, float ly, 
     idx[i] = i;
 }
 
-// storage slot j <- splat perm[j] of the upload order
-__global__ void __launch_bounds__(256)
-k_permute_geo(uint32_t n, uint32_t cap, int chunks, const uint32_t* __restrict__ perm,
-              const float4* __restrict__ sA, const uint4* __restrict__ sB, const uint4* __restrict__ scol,
-              float4* __restrict__ dA, uint4* __restrict__ dB, uint4* __restrict__ dcol)
-{
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= n) return;
-    const uint32_t i = perm[j];
-    dA[j] = sA[i];
-    dB[j] = sB[i];
-    for (int c = 0; c < chunks; ++c) dcol[(size_t)c * cap + j] = scol[(size_t)c * cap + i];
-}
-// ... and the 128-byte colour rows: eight lanes per row
-__global__ void __launch_bounds__(256)
-k_permute_rows(uint32_t n, const uint32_t* __restrict__ perm, const uint4* __restrict__ srow, uint4* __restrict__ drow)
-{
-    const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
-    const size_t j = t >> 3;
-    if (j >= n) return;
-    drow[j * 8 + (t & 7)] = srow[(size_t)perm[j] * 8 + (t & 7)];
-}
-
-// Per cluster: clusA = (lo.xyz of the positions, the largest |diag(scale) R^T|_F bound of k_repack), clusB = (hi.xyz, flag);
-// flag != 0: a position or an extent bound is not finite -- the cluster is never culled.  One wavefront per cluster.
-__global__ void __launch_bounds__(256)
-k_cluster_bounds(uint32_t n, const float4* __restrict__ geoA, const uint4* __restrict__ geoB,
-                 float4* __restrict__ clusA, float4* __restrict__ clusB)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t cl = i / GSR_CLUSTER;
-    if (cl * GSR_CLUSTER >= n) return;            // (wave-uniform)
-    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, mf = 0.0f;
-    bool bad = false;
-    if (i < n) {
-        const float4 a = geoA[i];
-        const uint4 b = geoB[i];
-        const float m = gsr_h2f(b.w >> 16);
-        bad = !(__builtin_fabsf(a.x) < 3.0e38f) || !(__builtin_fabsf(a.y) < 3.0e38f) || !(__builtin_fabsf(a.z) < 3.0e38f) || !(m < 6.0e4f);
-        lo[0] = hi[0] = a.x; lo[1] = hi[1] = a.y; lo[2] = hi[2] = a.z;
-        mf = m;
-    }
-    const bool any_bad = __ballot(bad) != 0ull;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = __builtin_fminf(lo[k], __shfl_xor(lo[k], d, 64));
-            hi[k] = __builtin_fmaxf(hi[k], __shfl_xor(hi[k], d, 64));
-        }
-        mf = __builtin_fmaxf(mf, __shfl_xor(mf, d, 64));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        clusA[cl] = make_float4(lo[0], lo[1], lo[2], mf);
-        clusB[cl] = make_float4(hi[0], hi[1], hi[2], any_bad ? 1.0f : 0.0f);
-    }
-}
+// (the splats are written into storage order, and every 64 consecutive slots = one cluster get their bounds -- clusA = (lo.xyz of the
+//  positions, the largest |diag(scale) R^T|_F bound), clusB = (hi.xyz, flag); flag != 0: a position or an extent bound is not finite, the
+//  cluster is never culled -- by k_pack, k_preprocess.h)
 
 // ---- per frame ----------------------------------------------------------------------------------------------------------
 // Depth horizons live in a 6-level max pyramid over the tile grid (k_blend.h: k_tile_pass forms the per-tile horizons,

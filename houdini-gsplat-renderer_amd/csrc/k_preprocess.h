@@ -17,63 +17,119 @@
 #endif
 
 // ---------------------------------------------------------------------------
-// K0: raw registerUpdate()-layout arrays (already in device memory) -> SoA of
-// 16-byte vectors.  Runs once per geometry change, not per frame.
-__global__ void __launch_bounds__(256)
-k_repack(uint32_t n, uint32_t dst0, uint32_t cap, int has_sh,
-         const float* __restrict__ P, const uint16_t* __restrict__ Cd, const float* __restrict__ alpha,
-         const uint16_t* __restrict__ scale, const uint16_t* __restrict__ orient,
-         const uint16_t* __restrict__ shx, const uint16_t* __restrict__ shy, const uint16_t* __restrict__ shz,
-         float4* __restrict__ geoA, uint4* __restrict__ geoB, uint4* __restrict__ col, uint4* __restrict__ colrow)
+// K0 (round 6): the registerUpdate()-layout arrays of a whole upload (in the staging arena, device memory, upload order) -> the
+// resident layout, straight INTO STORAGE ORDER, with the cluster bounds on the way out.  Runs once per geometry change.
+//   storage slot j <- splat perm[j] (the stable order of the positions' Morton codes, k_cluster.h; NULL: upload order)
+// One workgroup of 512 threads = 64 slots = ONE CLUSTER, eight lanes per splat; lane q of a splat's eight:
+//   q = 0      P (12 B) + opacity (4 B)            -> geoA[j], and colrow[j][0]
+//   q = 1..6   16 bytes of the x / y / z SH rows   -> LDS; then chunk c = q - 1 of the 48 colour halves (Cd.rgb, sh1.rgb, ..., sh15.rgb:
+//              half h = 3 * coefficient + channel) <- LDS: a 16 x 3 -> 3 x 16 transpose per splat -> col[c][j] and colrow[j][1 + c]
+//   q = 7      scale (6 B) + orient (8 B)          -> geoB[j] with its extent bound; colrow[j][7] = 0
+// so a wave WRITES eight whole 128-byte colrow lines, 128 contiguous bytes of geoA, of geoB and of each colour chunk, and READS, per
+// splat, its rows of the source arrays (96 + 36 bytes; a gather when perm is a permutation).  Before round 6 this was three passes:
+// k_repack (one thread per splat, 2-byte loads at a 32-byte stride, 16-byte stores at a 128-byte stride: 1.5 x write amplification,
+// 0.19 of HBM), then k_permute_geo + k_permute_rows over a second copy of the geometry, then k_cluster_bounds.
+struct GsrPackSrc {
+    const float* P; const float* alpha;
+    const uint16_t *Cd, *scale, *orient, *shx, *shy, *shz;
+};
+#define GSR_PACK_THREADS 512
+template <bool SH>
+__global__ void __launch_bounds__(GSR_PACK_THREADS)
+k_pack(uint32_t n, uint32_t cap, GsrPackSrc src, const uint32_t* __restrict__ perm,
+       float4* __restrict__ geoA, uint4* __restrict__ geoB, uint4* __restrict__ col, uint4* __restrict__ colrow,
+       float4* __restrict__ clusA, float4* __restrict__ clusB)
 {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    uint32_t o = dst0 + i;
-    geoA[o] = make_float4(P[3 * (size_t)i], P[3 * (size_t)i + 1], P[3 * (size_t)i + 2], alpha[i]);
+    static_assert(GSR_PACK_THREADS == 8 * GSR_CLUSTER, "one workgroup = one cluster");
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[GSR_CLUSTER][56];   // per splat: x[16] y[16] z[16] Cd[3] (+ pad: 112 B rows)
+    __shared__ float s_red[8][8];                                           // per wave: lo.xyz hi.xyz mf bad
+    const int tid = threadIdx.x, q = tid & 7, sp = tid >> 3, wave = tid >> 6;
+    const uint32_t j = blockIdx.x * (uint32_t)GSR_CLUSTER + (uint32_t)sp;
+    const bool live = j < n;
+    const uint32_t i = live ? (perm ? perm[j] : j) : 0u;
     auto pk = [](uint16_t lo, uint16_t hi) { return (uint32_t)lo | ((uint32_t)hi << 16); };
-    const uint16_t* s = scale + 3 * (size_t)i;
-    const uint16_t* q = orient + 4 * (size_t)i;
-    // eighth half of geoB: an upper bound of |diag(scale) R(orient)^T|_F, the only thing K1's cheap extent bound needs of the
-    // scale and the (unnormalised) quaternion -- so the bound costs a dozen instructions per splat instead of ninety
-    uint16_t mf_h;
-    {
-        const float sx = gsr_h2f(s[0]), sy = gsr_h2f(s[1]), sz = gsr_h2f(s[2]);
-        const float qi = gsr_h2f(q[0]), qj = gsr_h2f(q[1]), qk = gsr_h2f(q[2]), qr = gsr_h2f(q[3]);
-        const float r00 = 1.0f - 2.0f * gsr_fma(qj, qj, qk * qk), r01 = 2.0f * gsr_fma(qi, qj, -(qr * qk)), r02 = 2.0f * gsr_fma(qi, qk, qr * qj);
-        const float r10 = 2.0f * gsr_fma(qi, qj, qr * qk), r11 = 1.0f - 2.0f * gsr_fma(qi, qi, qk * qk), r12 = 2.0f * gsr_fma(qj, qk, -(qr * qi));
-        const float r20 = 2.0f * gsr_fma(qi, qk, -(qr * qj)), r21 = 2.0f * gsr_fma(qj, qk, qr * qi), r22 = 1.0f - 2.0f * gsr_fma(qi, qi, qj * qj);
-        const float mf2 = sx * sx * (r00 * r00 + r10 * r10 + r20 * r20) + sy * sy * (r01 * r01 + r11 * r11 + r21 * r21) +
-                          sz * sz * (r02 * r02 + r12 * r12 + r22 * r22);
-        const float mf = __builtin_sqrtf(mf2) * 1.001f;
-        const _Float16 hh = (_Float16)mf;               // rounded up (to nearest, then one step if that fell short): mf >= 0
-        mf_h = __builtin_bit_cast(uint16_t, hh);
-        if ((float)hh < mf) mf_h += 1;                  // (0x7bff + 1 = inf; inf / NaN stay what they are: K1 then takes the full path)
-    }
-    geoB[o] = make_uint4(pk(s[0], s[1]), pk(s[2], q[0]), pk(q[1], q[2]), pk(q[3], mf_h));
-    uint16_t h[48];
-    h[0] = Cd[3 * (size_t)i]; h[1] = Cd[3 * (size_t)i + 1]; h[2] = Cd[3 * (size_t)i + 2];
-    if (has_sh) {
-#pragma unroll
-        for (int j = 0; j < 15; ++j) {  // coefficient j at (j/4, j%4) of the row-major 4x4 == flat index j
-            h[3 * (j + 1) + 0] = shx[16 * (size_t)i + j];
-            h[3 * (j + 1) + 1] = shy[16 * (size_t)i + j];
-            h[3 * (j + 1) + 2] = shz[16 * (size_t)i + j];
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, mf = 0.0f;
+    bool bad = false;
+    if (live) {
+        if (q == 0) {
+            const float px = src.P[3 * (size_t)i], py = src.P[3 * (size_t)i + 1], pz = src.P[3 * (size_t)i + 2], op = src.alpha[i];
+            geoA[j] = make_float4(px, py, pz, op);
+            if (SH) colrow[(size_t)j * 8] = make_uint4(__float_as_uint(px), __float_as_uint(py), __float_as_uint(pz), __float_as_uint(op));
+            s_h[sp][48] = src.Cd[3 * (size_t)i]; s_h[sp][49] = src.Cd[3 * (size_t)i + 1]; s_h[sp][50] = src.Cd[3 * (size_t)i + 2];
+            bad = !(__builtin_fabsf(px) < 3.0e38f) || !(__builtin_fabsf(py) < 3.0e38f) || !(__builtin_fabsf(pz) < 3.0e38f);
+            lo[0] = hi[0] = px; lo[1] = hi[1] = py; lo[2] = hi[2] = pz;
+        } else if (q == 7) {
+            const uint16_t* s = src.scale + 3 * (size_t)i;
+            const uint16_t* o = src.orient + 4 * (size_t)i;
+            const uint16_t s0 = s[0], s1 = s[1], s2 = s[2], o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3];
+            // eighth half of geoB: an upper bound of |diag(scale) R(orient)^T|_F, the only thing K1's cheap extent bound needs of the
+            // scale and the (unnormalised) quaternion -- so the bound costs a dozen instructions per splat instead of ninety
+            uint16_t mf_h;
+            {
+                const float sx = gsr_h2f(s0), sy = gsr_h2f(s1), sz = gsr_h2f(s2);
+                const float qi = gsr_h2f(o0), qj = gsr_h2f(o1), qk = gsr_h2f(o2), qr = gsr_h2f(o3);
+                const float r00 = 1.0f - 2.0f * gsr_fma(qj, qj, qk * qk), r01 = 2.0f * gsr_fma(qi, qj, -(qr * qk)), r02 = 2.0f * gsr_fma(qi, qk, qr * qj);
+                const float r10 = 2.0f * gsr_fma(qi, qj, qr * qk), r11 = 1.0f - 2.0f * gsr_fma(qi, qi, qk * qk), r12 = 2.0f * gsr_fma(qj, qk, -(qr * qi));
+                const float r20 = 2.0f * gsr_fma(qi, qk, -(qr * qj)), r21 = 2.0f * gsr_fma(qj, qk, qr * qi), r22 = 1.0f - 2.0f * gsr_fma(qi, qi, qj * qj);
+                const float mf2 = sx * sx * (r00 * r00 + r10 * r10 + r20 * r20) + sy * sy * (r01 * r01 + r11 * r11 + r21 * r21) +
+                                  sz * sz * (r02 * r02 + r12 * r12 + r22 * r22);
+                const float mfv = __builtin_sqrtf(mf2) * 1.001f;
+                const _Float16 hh = (_Float16)mfv;              // rounded up (to nearest, then one step if that fell short): mf >= 0
+                mf_h = __builtin_bit_cast(uint16_t, hh);
+                if ((float)hh < mfv) mf_h += 1;                 // (0x7bff + 1 = inf; inf / NaN stay what they are: K1 then takes the full path)
+            }
+            geoB[j] = make_uint4(pk(s0, s1), pk(s2, o0), pk(o1, o2), pk(o3, mf_h));
+            if (SH) colrow[(size_t)j * 8 + 7] = make_uint4(0, 0, 0, 0);
+            mf = gsr_h2f(mf_h);
+            bad = !(mf < 6.0e4f);
+        } else if (SH) {
+            // lanes 1..6: x[0..7] x[8..15] y[0..7] y[8..15] z[0..7] z[8..15] (rows of 16 halves = 32 bytes, 16-byte loads)
+            const int ch = (q - 1) >> 1, part = (q - 1) & 1;
+            const uint16_t* row = (ch == 0 ? src.shx : (ch == 1 ? src.shy : src.shz)) + 16 * (size_t)i + 8 * part;
+            *reinterpret_cast<uint4*>(&s_h[sp][16 * ch + 8 * part]) = *reinterpret_cast<const uint4*>(row);
         }
-    } else {
-#pragma unroll
-        for (int k = 3; k < 48; ++k) h[k] = 0;
     }
-    const int nchunk = has_sh ? 6 : 1;
-    for (int c = 0; c < nchunk; ++c) {
-        const uint4 v = make_uint4(pk(h[8 * c], h[8 * c + 1]), pk(h[8 * c + 2], h[8 * c + 3]),
-                                   pk(h[8 * c + 4], h[8 * c + 5]), pk(h[8 * c + 6], h[8 * c + 7]));
-        col[(size_t)c * cap + o] = v;                  // SoA chunks: coalesced for a pass over ALL splats (eager colour)
-        if (has_sh) colrow[(size_t)o * 8 + 1 + c] = v; // and as ONE 128-byte row per splat, gathered by index (lazy colour):
-    }                                                  //   [0] = (P.xyz, opacity), [1..6] = the 48 colour halves, [7] = pad
-    if (has_sh) {
-        colrow[(size_t)o * 8] = make_uint4(__float_as_uint(P[3 * (size_t)i]), __float_as_uint(P[3 * (size_t)i + 1]),
-                                           __float_as_uint(P[3 * (size_t)i + 2]), __float_as_uint(alpha[i]));
-        colrow[(size_t)o * 8 + 7] = make_uint4(0, 0, 0, 0);
+    // (a splat's eight lanes sit in one wave: its LDS row is written and read by that wave only)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (live && q >= 1 && (SH ? q <= 6 : q == 1)) {
+        const int c = q - 1;
+        uint16_t h[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int hh = 8 * c + k, co = hh / 3, chn = hh - 3 * co;     // coefficient (0 = Cd), channel
+            // coefficient co of the reference's row-major 4x4 sits at flat index co - 1 of the x / y / z rows (co = 1..15)
+            h[k] = co == 0 ? s_h[sp][48 + chn] : (SH ? s_h[sp][16 * chn + (co - 1)] : (uint16_t)0);
+        }
+        const uint4 v = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), pk(h[6], h[7]));
+        col[(size_t)c * cap + j] = v;                  // SoA chunks: coalesced for a pass over ALL splats (eager colour)
+        if (SH) colrow[(size_t)j * 8 + 1 + c] = v;     // and as ONE 128-byte row per splat, gathered by index (lazy colour)
+    }
+    // the cluster's bounds (k_cluster.h: clusA = lo.xyz of the positions + the largest extent bound, clusB = hi.xyz + "never cull" flag)
+    const bool any_bad = __ballot(bad) != 0ull;
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1) {     // (the position lanes are q = 0, the extent lanes q = 7: strides of eight)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = __builtin_fminf(lo[k], __shfl_xor(lo[k], d, 64));
+            hi[k] = __builtin_fmaxf(hi[k], __shfl_xor(hi[k], d, 64));
+        }
+        mf = __builtin_fmaxf(mf, __shfl_xor(mf, d, 64));
+    }
+    const int lane = tid & 63;
+    if (lane == 0) { s_red[wave][0] = lo[0]; s_red[wave][1] = lo[1]; s_red[wave][2] = lo[2]; s_red[wave][3] = hi[0]; s_red[wave][4] = hi[1]; s_red[wave][5] = hi[2]; s_red[wave][7] = any_bad ? 1.0f : 0.0f; }
+    if (lane == 7) s_red[wave][6] = mf;
+    __syncthreads();
+    if (tid == 0) {
+        float l0 = 3.0e38f, l1 = 3.0e38f, l2 = 3.0e38f, h0 = -3.0e38f, h1 = -3.0e38f, h2 = -3.0e38f, m = 0.0f, b = 0.0f;
+        for (int w = 0; w < 8; ++w) {
+            l0 = __builtin_fminf(l0, s_red[w][0]); l1 = __builtin_fminf(l1, s_red[w][1]); l2 = __builtin_fminf(l2, s_red[w][2]);
+            h0 = __builtin_fmaxf(h0, s_red[w][3]); h1 = __builtin_fmaxf(h1, s_red[w][4]); h2 = __builtin_fmaxf(h2, s_red[w][5]);
+            m = __builtin_fmaxf(m, s_red[w][6]); b = __builtin_fmaxf(b, s_red[w][7]);
+        }
+        clusA[blockIdx.x] = make_float4(l0, l1, l2, m);
+        clusB[blockIdx.x] = make_float4(h0, h1, h2, b != 0.0f ? 1.0f : 0.0f);
     }
 }
 
@@ -639,16 +695,15 @@ k_preprocess(GSR_K1_PARAMS) { gsr_k1_body<false>(GSR_K1_ARGS); }
 __global__ void __launch_bounds__(GSR_K1_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_K1_WAVES_PER_EU_LAZY)))
 k_preprocess_lazy(GSR_K1_PARAMS) { gsr_k1_body<true>(GSR_K1_ARGS); }
 
-// upload time: per-workgroup partial bounding boxes of the positions (finished on the host)
+// upload time: per-workgroup partial bounding boxes of the positions (finished on the host), from the raw float[3] array in the arena
 __global__ void __launch_bounds__(256)
-k_bbox_partials(const float4* __restrict__ geoA, uint32_t n, float* __restrict__ partial /*[grid][6]*/)
+k_bbox_partials(const float* __restrict__ P, uint32_t n, float* __restrict__ partial /*[grid][6]*/)
 {
     __shared__ float s[4][6];
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     bool finite = true;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const float4 a = geoA[i];
-        const float p[3] = {a.x, a.y, a.z};
+        const float p[3] = {P[3 * (size_t)i], P[3 * (size_t)i + 1], P[3 * (size_t)i + 2]};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             finite = finite && (__builtin_fabsf(p[k]) < 3.0e38f);   // false for inf and NaN

@@ -44,11 +44,13 @@ class gsr_stats(C.Structure):
                 ("frames_culled", C.c_int64), ("frames_repaired", C.c_int64),
                 ("clusters_total", C.c_int64), ("clusters_kept", C.c_int64),
                 ("policy_bits", C.c_int32), ("cull_dilate", C.c_int32), ("cull_holdoff", C.c_int32), ("reserved2_", C.c_int32),
-                ("frames_resorted", C.c_int64), ("frames_slab", C.c_int64), ("frames_jumped", C.c_int64), ("frames_lazy", C.c_int64)]
+                ("frames_resorted", C.c_int64), ("frames_slab", C.c_int64), ("frames_jumped", C.c_int64), ("frames_lazy", C.c_int64),
+                ("uploads", C.c_int64), ("upload_ms", C.c_double * 6)]
 
     def as_dict(self) -> dict:
         d = {n: getattr(self, n) for n, _ in self._fields_}
         d["stage_ms_total"] = list(self.stage_ms_total)
+        d["upload_ms"] = list(self.upload_ms)
         return d
 
 
@@ -112,7 +114,7 @@ C_ABI_SYMBOLS = [
     "gsplat_renderer_create", "gsplat_renderer_get_instance", "gsplat_renderer_destroy",
     "gsplat_renderer_register_update", "gsplat_renderer_include_in_render_pass",
     "gsplat_renderer_flush_entries_for_matching_detail", "gsplat_renderer_generate_render_geometry",
-    "gsplat_renderer_render", "gsplat_renderer_post_render", "gsplat_renderer_set_rendering_enabled",
+    "gsplat_renderer_render", "gsplat_renderer_post_render", "gsplat_renderer_redraw", "gsplat_renderer_set_rendering_enabled",
     "gsplat_renderer_set_explicit_camera_pos", "gsplat_renderer_set_spherical_harmonics_order",
     "gsplat_renderer_query", "gsplat_renderer_get_origin", "gsplat_renderer_get_last_camera_pos",
     "gsplat_renderer_engine", "gsplat_closest_sqrt_power_of_2", "gsplat_quantize_half",
@@ -191,6 +193,8 @@ def load_library() -> C.CDLL:
     L.gsplat_renderer_render.restype = None
     L.gsplat_renderer_post_render.argtypes = [vp]
     L.gsplat_renderer_post_render.restype = None
+    L.gsplat_renderer_redraw.argtypes = [vp, C.POINTER(C.c_char_p), i32, C.POINTER(GSplatRenderContext), i32]
+    L.gsplat_renderer_redraw.restype = None
     L.gsplat_renderer_set_rendering_enabled.argtypes = [vp, i32]
     L.gsplat_renderer_set_rendering_enabled.restype = None
     L.gsplat_renderer_set_explicit_camera_pos.argtypes = [vp, f32p]
@@ -608,6 +612,20 @@ class GSplatRenderer:
 
     def postRender(self):
         self.L.gsplat_renderer_post_render(self.h)
+
+    def redraw(self, rids, r: GSplatRenderContext, isObjectLevel: bool = False):
+        """one redraw as the reference drives it (includeInRenderPass x N -> generateRenderGeometry -> render -> postRender) in ONE foreign call"""
+        key = tuple(rids)
+        if getattr(self, "_ids_key", None) != key:
+            self._ids_key = key
+            self._ids_arr = (C.c_char_p * len(rids))(*[x.encode() for x in rids])
+        self.L.gsplat_renderer_redraw(self.h, self._ids_arr, len(rids), C.byref(r), int(isObjectLevel))
+
+    def engine_stats(self) -> dict:
+        """gsr_stats of the context behind the verbs (one GPU)"""
+        st = gsr_stats()
+        _check(self.L.gsr_get_stats(self.L.gsplat_renderer_engine(self.h), C.byref(st)))
+        return st.as_dict()
 
     def setRenderingEnabled(self, enabled: bool):
         self.L.gsplat_renderer_set_rendering_enabled(self.h, int(enabled))

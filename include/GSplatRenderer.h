@@ -183,6 +183,10 @@ void gsplat_renderer_flush_entries_for_matching_detail(gsplat_renderer* h, const
 void gsplat_renderer_generate_render_geometry(gsplat_renderer* h, GSplatRenderContext* r);
 void gsplat_renderer_render(gsplat_renderer* h, GSplatRenderContext* r, int is_object_level);
 void gsplat_renderer_post_render(gsplat_renderer* h);
+/* ONE redraw as the reference drives it, in one foreign call: includeInRenderPass for each of the `n` ids (GR_PrimGsplat::render,
+ * src/GR_GSplat.C:485-492), then generateRenderGeometry -> render -> postRender (MyCustomSceneRenderHook::render,
+ * src/DM_GSplatHook.C:30-39).  What bench.py --via-shim times: the cost of the boundary itself, not of one FFI call per verb. */
+void gsplat_renderer_redraw(gsplat_renderer* h, const char* const* ids, int n, GSplatRenderContext* r, int is_object_level);
 void gsplat_renderer_set_rendering_enabled(gsplat_renderer* h, int enabled);
 void gsplat_renderer_set_explicit_camera_pos(gsplat_renderer* h, const float pos[3]);
 void gsplat_renderer_set_spherical_harmonics_order(gsplat_renderer* h, int order);

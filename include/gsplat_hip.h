@@ -107,6 +107,10 @@ typedef struct gsr_stats {
     int64_t frames_slab;                   /* GSR_OPT_FRONT_SLAB: frames rendered in two phases (front slab, then the rest behind the tiles still open) */
     int64_t frames_jumped;                 /* frames whose camera had jumped since the frame that left the depth horizons: rendered without them (policy mode only) */
     int64_t frames_lazy;                   /* frames whose K1 left the SH colours pending (k_colour.h: list prefixes + on-demand fallback); the others shaded in K1 */
+    int64_t uploads;                       /* complete uploads (gsr_upload_end) since gsr_create / gsr_stats_reset */
+    double upload_ms[6];                   /* the LAST upload: [0] host -> device copies (wall clock spent inside gsr_upload_append*, quantisation of raw
+                                              attributes included), [1] bounding box + Morton codes + their sort (HIP events), [2] k_pack: the arrays into
+                                              storage order + cluster bounds (HIP events), [3] wall clock gsr_upload_begin .. gsr_upload_end, [4], [5] reserved */
 } gsr_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */

@@ -2119,7 +2119,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         // output goes to the scratch buffers
         j.k1_grid = k1_grid;
         // (two instantiations: the one that leaves the colours pending has no SH evaluation in it and runs at 8 waves per SIMD instead of 6)
-        hipLaunchKernelGGL(j.lazy ? k_preprocess_lazy : k_preprocess, dim3(k1_grid ? k1_grid : 1u), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
+        hipLaunchKernelGGL(j.d_depth ? (j.lazy ? k_preprocess_lazy_depth : k_preprocess_depth) : (j.lazy ? k_preprocess_lazy : k_preprocess), dim3(k1_grid ? k1_grid : 1u), dim3(GSR_K1_THREADS), 0, s, n, c->cap, f, c->geoA, c->geoB, c->col,
                            sl.rec, (cache_hit || ordered) ? sl.keyB : sl.keyA, (cache_hit || ordered) ? sl.valB : sl.valA,
                            j.d_depth ? sl.zwin : (float*)nullptr, j.phase == 2 ? sl.hpyr2 : (j.cull ? sl.hpyr : (const float*)nullptr), sl.blk_cnt,
                            sl.cseg, sl.ccnt, ngroups, (uint32_t)CC_THREADS * (uint32_t)rounds, sl.d_counts, scat,

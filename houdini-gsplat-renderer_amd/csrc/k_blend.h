@@ -161,6 +161,9 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef BL_PROFILE
     unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // lane occupancy of the record evaluations (is an 8x8-pixel wave the wrong granularity for small splats?): lanes whose fragment is
+    // inside the quad AND above 1/255 (and passes the depth test), evaluations, and evaluations that touch only ONE 4-row half of the quadrant
+    unsigned long long occ_lanes = 0, occ_evals = 0, occ_half = 0, occ_none = 0;
     long long tlast = clock64();
     const unsigned long long wall0 = wall_clock64();   // constant 100 MHz, the same on every CU
 #endif
@@ -439,6 +442,16 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                         ina = ina && (v5.x <= dpx);
                         inb = inb && (v5.y <= dpx);
                     }
+#ifdef BL_PROFILE
+                    {
+                        const unsigned long long ba = __ballot(ina), bb = __ballot(inb);
+                        occ_lanes += (unsigned long long)(__builtin_popcountll(ba) + __builtin_popcountll(bb));
+                        occ_evals += 2ull;
+                        occ_half += (unsigned long long)(((ba != 0ull) && (((ba & 0xffffffffull) == 0ull) || ((ba >> 32) == 0ull))) ? 1 : 0) +
+                                    (unsigned long long)(((bb != 0ull) && (((bb & 0xffffffffull) == 0ull) || ((bb >> 32) == 0ull))) ? 1 : 0);
+                        occ_none += (unsigned long long)((ba == 0ull) ? 1 : 0) + (unsigned long long)((bb == 0ull) ? 1 : 0);
+                    }
+#endif
                     // branch-free under-blend: a rejected fragment blends weight 0, which leaves C and T
                     // bit-identical and costs no exec-mask juggling on the scalar unit.  w = (1-A)*alpha once;
                     // {C0,C1} update as a register pair.
@@ -536,6 +549,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
 #pragma unroll
         for (int i = 0; i < 9; ++i) o[i] = prof[i];
         o[9] = 1ull; o[10] = (unsigned long long)round; o[11] = wall0; o[12] = wall_clock64();
+        o[13] = occ_lanes; o[14] = occ_evals; o[15] = occ_half | (occ_none << 32);
     }
 #endif
     // bookkeeping for the roofline: list entries scanned and records gathered by this tile

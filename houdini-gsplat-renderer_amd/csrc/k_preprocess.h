@@ -329,23 +329,28 @@ __device__ __forceinline__ void gsr_splat_colour(const GsrFrame& f, const uint4*
         uint32_t w[24];
 #pragma unroll
         for (int c = 0; c < 6; ++c) { w[4 * c] = cw[c].x; w[4 * c + 1] = cw[c].y; w[4 * c + 2] = cw[c].z; w[4 * c + 3] = cw[c].w; }
-        float shr[15], shg[15], shb[15];
-#pragma unroll
-        for (int j = 0; j < 15; ++j) {
-            const int h0 = 3 * (j + 1);
-            shr[j] = gsr_h2f((w[(h0) >> 1] >> (((h0) & 1) * 16)) & 0xffffu);
-            shg[j] = gsr_h2f((w[(h0 + 1) >> 1] >> (((h0 + 1) & 1) * 16)) & 0xffffu);
-            shb[j] = gsr_h2f((w[(h0 + 2) >> 1] >> (((h0 + 2) & 1) * 16)) & 0xffffu);
-        }
         const float wx = x - f.cam[0], wy = y - f.cam[1], wz = z - f.cam[2];
         const float ox = lin3(&f.io[0], wx, wy, wz);
         const float oy = lin3(&f.io[3], wx, wy, wz);
         const float oz = lin3(&f.io[6], wx, wy, wz);
         const float len = __builtin_sqrtf(gsr_fma(oz, oz, gsr_fma(oy, oy, ox * ox)));
         const float dx = ox / len, dy = oy / len, dz = oz / len;
-        cr = gsr_shade_sh(cr, shr, dx, dy, dz, f.sh_order);
-        cg = gsr_shade_sh(cg, shg, dx, dy, dz, f.sh_order);
-        cbl = gsr_shade_sh(cbl, shb, dx, dy, dz, f.sh_order);
+        // one channel at a time: its fifteen coefficients are decoded, used and dropped before the next channel's (decoded all at once --
+        // 45 floats beside the 24 words they come from -- the shading K1 spilt 20 bytes at its 80 registers; the scheduling barriers keep
+        // the compiler from interleaving the three evaluations again).  The arithmetic of a channel is untouched.
+        float out[3] = {cr, cg, cbl};
+#pragma unroll
+        for (int chn = 0; chn < 3; ++chn) {
+            float sh[15];
+#pragma unroll
+            for (int j = 0; j < 15; ++j) {
+                const int h = 3 * (j + 1) + chn;
+                sh[j] = gsr_h2f((w[h >> 1] >> ((h & 1) * 16)) & 0xffffu);
+            }
+            out[chn] = gsr_shade_sh(out[chn], sh, dx, dy, dz, f.sh_order);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cr = out[0]; cg = out[1]; cbl = out[2];
     }
     // (round 6, oracle and kernels together) a colour that is not finite is made finite where it is formed: NaN -> 0, +-inf -> +-3e38.
     // k_blend blends a REJECTED fragment with weight 0 (no exec-mask juggling), and 0 x inf is NaN: one poisoned splat used to turn
@@ -588,7 +593,9 @@ struct GsrK1Scatter {
 #ifndef GSR_K1_WAVES_PER_EU_LAZY
 #define GSR_K1_WAVES_PER_EU_LAZY 8
 #endif
-template <bool LAZY>
+// (DEPTH: the frame is depth-tested -- window depths are written and the depth rules of gsr_k1_back apply.  A template parameter, not a
+//  run-time pointer test: the plain shading instantiation is the headline frame's K1, and its 80 registers have no room for the extra state)
+template <bool LAZY, bool DEPTH>
 __device__ __forceinline__ void
 gsr_k1_body(uint32_t n, uint32_t cap, const GsrFrame& f,
              const float4* __restrict__ geoA, const uint4* __restrict__ geoB, const uint4* __restrict__ col,
@@ -624,7 +631,7 @@ gsr_k1_body(uint32_t n, uint32_t cap, const GsrFrame& f,
     int sc_shift = sc.shift;
     if (sc.key && sc.range_dev) { sc_lo = sc.range_dev[0]; sc_shift = (int)sc.range_dev[1]; }
     const uint32_t slab_key = (f.phase != 0 && slab) ? slab[0] : 0xffffffffu;
-    const float* const dpyr = (dc.pyr && *dc.active != 0u) ? dc.pyr : (const float*)nullptr;   // (uniform: nothing changes under a cleared depth buffer)
+    const float* const dpyr = (DEPTH && dc.pyr && *dc.active != 0u) ? dc.pyr : (const float*)nullptr;   // (uniform: nothing changes under a cleared depth buffer)
     int par = 0;
     for (uint32_t k = blockIdx.x; k < niter; k += gridDim.x, par ^= 1) {
         const uint32_t rank = 4u * k + (uint32_t)wave;
@@ -642,8 +649,8 @@ gsr_k1_body(uint32_t n, uint32_t cap, const GsrFrame& f,
 #ifdef GSR_KPROF
                 if (k == blockIdx.x && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_kprof[4][2] = wall_clock64(); }
 #endif
-                const GsrK1Front o = gsr_k1_front(f, a, b, zwin ? zwin + i : nullptr, slab_key);
-                if (o.keep && !o.far) out_rect = gsr_k1_back(f, i, cap, o, b, col, rec, LAZY ? 1 : 0, hpyr, dpyr, dc.pyrc);
+                const GsrK1Front o = gsr_k1_front(f, a, b, (DEPTH && zwin) ? zwin + i : nullptr, slab_key);
+                if (o.keep && !o.far) out_rect = gsr_k1_back(f, i, cap, o, b, col, rec, LAZY ? 1 : 0, hpyr, DEPTH ? dpyr : (const float*)nullptr, DEPTH ? dc.pyrc : (const float*)nullptr);
                 kb = o.kb;
             }
         }
@@ -691,9 +698,14 @@ gsr_k1_body(uint32_t n, uint32_t cap, const GsrFrame& f,
 #define GSR_K1_ARGS n, cap, f, geoA, geoB, col, rec, key, val, zwin, hpyr, blk_cnt, cseg, ccnt, ngroups, cper, d_counts, sc, zero_n, order, slab, dc
 // the two entry points: colours evaluated here (eager: 80 VGPRs, 6 waves per SIMD) or left pending (52 VGPRs, 8 waves per SIMD)
 __global__ void __launch_bounds__(GSR_K1_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_K1_WAVES_PER_EU)))
-k_preprocess(GSR_K1_PARAMS) { gsr_k1_body<false>(GSR_K1_ARGS); }
+k_preprocess(GSR_K1_PARAMS) { gsr_k1_body<false, false>(GSR_K1_ARGS); }
 __global__ void __launch_bounds__(GSR_K1_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_K1_WAVES_PER_EU_LAZY)))
-k_preprocess_lazy(GSR_K1_PARAMS) { gsr_k1_body<true>(GSR_K1_ARGS); }
+k_preprocess_lazy(GSR_K1_PARAMS) { gsr_k1_body<true, false>(GSR_K1_ARGS); }
+// ... and their depth-tested twins (the shading one is left to the register allocator: it carries the depth rules on top of the SH evaluation)
+__global__ void __launch_bounds__(GSR_K1_THREADS)
+k_preprocess_depth(GSR_K1_PARAMS) { gsr_k1_body<false, true>(GSR_K1_ARGS); }
+__global__ void __launch_bounds__(GSR_K1_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_K1_WAVES_PER_EU_LAZY)))
+k_preprocess_lazy_depth(GSR_K1_PARAMS) { gsr_k1_body<true, true>(GSR_K1_ARGS); }
 
 // upload time: per-workgroup partial bounding boxes of the positions (finished on the host), from the raw float[3] array in the arena
 __global__ void __launch_bounds__(256)

@@ -78,3 +78,34 @@ def test_pmc_summary_drops_cold_dispatches(tmp_path):
     t = json.load(open(tmp_path / "pmc_traffic.json"))["k_preprocess"]
     assert t["dispatches"] == 20 and t["cold_rows_dropped"] == 8
     assert abs(t["hbm_bytes_per_launch"] - (2 * 1000.0 + 200.0) * 1024.0) < 1e-6
+
+
+def test_frame_kernels_keep_their_register_and_scratch_budgets():
+    """DESIGN.md section 4 states, per frame kernel, the registers / LDS / scratch the compiler allocates (tools/kernel_resources.py
+    prints them from a cross-compile: no GPU).  A checked claim: no frame kernel uses scratch except the shading K1 (two dwords, stored
+    once and reloaded per workgroup-iteration: 12 bytes at its 80-register, six-waves-per-SIMD budget); the blend kernels keep the
+    occupancy they were tuned for (plain <= 72 registers, depth-tested <= 80: six waves per SIMD either way)."""
+    import re
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py")], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    rows = {}
+    for ln in res.stdout.splitlines():
+        m = re.match(r"(\S+)\s+vgpr\s+(\d+)\s+sgpr\s+(\d+)\s+lds\s+(\d+)\s+scratch\s+(\d+)", ln)
+        if m:
+            rows[m.group(1)] = tuple(int(x) for x in m.groups()[1:])
+    def find(prefix):
+        hit = [v for k, v in rows.items() if k.startswith(prefix)]
+        assert len(hit) == 1, (prefix, [k for k in rows if k.startswith(prefix)])
+        return hit[0]
+    frame_kernels = ["_Z14k_cluster_cull", "_Z17k_preprocess_lazyjj", "_Z18k_preprocess_depth", "_Z23k_preprocess_lazy_depth", "_Z15k_depth_pyramid",
+                     "_Z13k_radix_localI15HIP", "_Z11k_bin_countILi2E", "_Z11k_bin_placeILi2E", "_Z11k_scan_rows", "_Z7k_blendILb0E", "_Z7k_blendILb1E",
+                     "_Z11k_tile_pass", "_Z11k_frame_end", "_Z17k_frame_end_order", "_Z10k_slab_mid", "_Z15k_colour_prefix", "_Z6k_packILb1E"]
+    for k in frame_kernels:
+        vg, sg, lds, scratch = find(k)
+        assert scratch == 0, (k, scratch)
+    vg, sg, lds, scratch = find("_Z12k_preprocessjj")
+    assert scratch <= 12 and vg <= 80, (vg, scratch)
+    assert find("_Z7k_blendILb0E")[0] <= 72 and find("_Z7k_blendILb1E")[0] <= 80
+    assert find("_Z7k_blendILb0E")[2] <= 20 * 1024 and find("_Z7k_blendILb1E")[2] <= 22 * 1024       # LDS: seven workgroups of either fit a CU's 160 KB

@@ -48,6 +48,12 @@ print("%s local-sort %d: %.1f us per frame (host clock); last launch: %d waves, 
       (name, local, dt * 1e6, v.shape[0], span, res, res / span))
 for n, x in zip(names, v[:, :9].sum(axis=0)):
     print("  %-34s %6.2f %%   %7.2f us/wave" % (n, 100 * x / tot, x / tot * res / v.shape[0]))
+# lane occupancy of the record evaluations (round 6): lanes_contributing / lanes_evaluated, and how many evaluations touch one 4x8 half only
+ol, oe = buf[live][:, 13].astype(np.float64).sum(), buf[live][:, 14].astype(np.float64).sum()
+oh = (buf[live][:, 15] & np.uint64(0xffffffff)).astype(np.float64).sum(); on = (buf[live][:, 15] >> np.uint64(32)).astype(np.float64).sum()
+if oe > 0:
+    print("lane occupancy: %.0f record evaluations per launch (incl. the odd-list pads); lanes contributing / lanes evaluated = %.3f; evaluations that touch no lane %.3f, "
+          "only one 4x8 half of the quadrant %.3f (of those that touch any: %.3f)" % (oe, ol / (64.0 * oe), on / oe, oh / oe, oh / max(oe - on, 1.0)))
 life = (end - start) / 100.0
 # where do the longest-lived waves (the launch's tail) spend their time?
 thr = np.quantile(life, 0.99)

@@ -1457,7 +1457,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     if (fused_order) {
         const GsrOrderArgs oa{sl.tile_work, j.f.tiles_y, sl.sup_work + 256 * sl.sup_par, per_xcd, sl.order};
         const int ndil = sl.horizon_valid ? nblocks8 : 0;
-        hipLaunchKernelGGL(k_frame_end_order, dim3(9u + (unsigned)ndil), dim3(TO_THREADS), 0, s, sl.partial, nblocks8, ndil, g, sl.counters, sl.d_n, sl.d_frame,
+        hipLaunchKernelGGL(k_frame_end_order, dim3(9u + (unsigned)((ndil + TO_THREADS / 64 - 1) / (TO_THREADS / 64))), dim3(TO_THREADS), 0, s, sl.partial, nblocks8, ndil, g, sl.counters, sl.d_n, sl.d_frame,
                            prefix_arg, redo_arg, sl.colour_evals, sl.lazy_ctr + 1, sl.sstart, sl.send, c->lazy_hint, work_next, hz, sl.st_scan, sl.hpyr_re, oa);
         HIP_TRY(hipGetLastError());
     } else if (sl.horizon_valid) {
@@ -2191,7 +2191,8 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
             if (hipGetLastError() != hipSuccess) rc = set_err(GSR_E_HIP, "small-frame sort: launch failed");
         } else {
             // (keys per thread: by what the slot's previous frame kept -- any choice sorts correctly)
-            const bool mid = c->opt_mid_sort && sl.kept_hint > 0 && sl.kept_hint <= 1500000u && n_slots <= 4000000u;
+            // (... from a frame of the same kind: an unculled frame keeps ten times what a culled one does)
+            const bool mid = c->opt_mid_sort && sl.kept_hint > 0 && sl.kept_hint <= 1500000u && n_slots <= 4000000u && sl.kept_culled == j.cull;
             rc = radix_sort(sl, sl.keyA, sl.valA, sl.keyB, sl.valB, n_slots, key_bits,
                             !(c->opt_flags & GSR_FLAG_FULL_KEYS), sl.d_n, RS_XCD_DEPTH != 0, sl.blk_cnt, sl.d_counts, mid);
         }

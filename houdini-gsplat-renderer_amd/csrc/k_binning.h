@@ -185,7 +185,9 @@ k_bin_count(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
         }
         __syncthreads();
         // (a part writes the columns of ITS rows of super-tiles only: the others belong to the block's other parts)
-        const int b_lo = part.row_lo * stiles_x, b_hi = part.row_hi >= stiles_y ? BN_BINS : (part.row_hi + 1) * stiles_x;
+        // (... and the part that owns the LAST row also the columns behind the grid, up to BN_BINS: k_scan_rows scans all BN_BINS rows of
+        //  `hist`, which the radix passes share -- stale counts there would end up in totals[n_super ..] and `offs`)
+        const int b_lo = part.row_lo * stiles_x, b_hi = part.row_hi >= stiles_y - 1 ? BN_BINS : (part.row_hi + 1) * stiles_x;
         for (int b = b_lo + (int)threadIdx.x; b < b_hi; b += BN_THREADS)
             hist[(size_t)b * nblk + tile] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
         __syncthreads();

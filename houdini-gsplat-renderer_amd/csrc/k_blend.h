@@ -1005,9 +1005,9 @@ k_sum_work(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs g
 // raw = per-tile horizons (k_tile_pass); pyr = the pyramid the slot's next frame culls against: level 0 = every tile's horizon
 // widened to the largest of its (2r+1)^2 neighbourhood, levels 1..3 from wave shuffles (lane = tile in Morton order).
 __device__ __forceinline__ void
-gsr_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int r, const GsrHorizonArgs& hz, float* __restrict__ pyr, const int b)
+gsr_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int r, const GsrHorizonArgs& hz, float* __restrict__ pyr, const int b,
+                   const int lane /* of the ONE wavefront that handles block b */)
 {
-    const int lane = threadIdx.x;
     const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
     const int nbx = (tiles_x + 7) >> 3;
     const int by = b / nbx, bx = b - by * nbx;
@@ -1042,7 +1042,7 @@ gsr_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int 
 __global__ void __launch_bounds__(64)
 k_horizon_dilate(const float* __restrict__ raw, int tiles_x, int tiles_y, int r, GsrHorizonArgs hz, float* __restrict__ pyr)
 {
-    gsr_horizon_dilate(raw, tiles_x, tiles_y, r, hz, pyr, (int)blockIdx.x);
+    gsr_horizon_dilate(raw, tiles_x, tiles_y, r, hz, pyr, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // The end of a frame that leaves horizons, in ONE launch: workgroups 0 .. nblocks - 1 (their first wavefront) dilate the per-tile
@@ -1062,7 +1062,7 @@ k_frame_end(const GsrTilePartial* __restrict__ partial, int nblocks, GsrSumArgs 
         return;
     }
     if (threadIdx.x >= 64) return;
-    gsr_horizon_dilate(hz.raw, g.tiles_x, g.tiles_y, dilate_r, hz, hz.pyr_out, (int)blockIdx.x);
+    gsr_horizon_dilate(hz.raw, g.tiles_x, g.tiles_y, dilate_r, hz, hz.pyr_out, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // Heaviest tiles first.  The blend kernel's workgroups are dispatched in blockIdx order as slots free up; when a frame's tiles
@@ -1204,6 +1204,11 @@ k_frame_end_order(const GsrTilePartial* __restrict__ partial, int nblocks, int n
                      sup_work_next, hz, st_scan);
         return;
     }
-    if (threadIdx.x >= 64 || b - 9 >= ndilate) return;
-    gsr_horizon_dilate(hz.raw, g.tiles_x, g.tiles_y, dilate_r, hz, hz.pyr_out, b - 9);
+    // (the dilation: one WAVEFRONT per 8x8 block of tiles, sixteen of them per 1024-thread workgroup -- one block per workgroup held 16 x the
+    //  wave slots for a sixteenth of the work.  Whole wavefronts leave early here and in the sums' workgroup above: the barriers of
+    //  gsr_sum_work count the waves that are still there, which is what the hardware's s_barrier does)
+    static_assert(TO_THREADS % 64 == 0 && SW_THREADS % 64 == 0, "early exits are by whole wavefronts");
+    const int blk = (b - 9) * (TO_THREADS / 64) + (int)(threadIdx.x >> 6);
+    if (blk >= ndilate) return;
+    gsr_horizon_dilate(hz.raw, g.tiles_x, g.tiles_y, dilate_r, hz, hz.pyr_out, blk, (int)(threadIdx.x & 63u));
 }

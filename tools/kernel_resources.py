@@ -35,7 +35,7 @@ def main():
         print(f"{name[:70]:70s} vgpr {g('vgpr_count'):>3s} sgpr {g('sgpr_count'):>3s} lds {g('group_segment_fixed_size'):>6s} "
               f"scratch {g('private_segment_fixed_size'):>4s}")
     if isa:
-        m = re.search(r"^(_Z\w*" + re.escape(isa) + r"\w*):[^\n]*\n(.*?)\n\s*s_endpgm", asm, re.S | re.M)
+        m = re.search(r"^(_Z\w*" + re.escape(isa) + r"\w*):[^\n]*\n(.*?)\n\.Lfunc_end\d+:", asm, re.S | re.M)   # (a kernel may hold several s_endpgm)
         if m:
             out = os.path.join(tmp, isa + ".s")
             open(out, "w").write(m.group(0))

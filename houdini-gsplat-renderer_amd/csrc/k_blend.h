@@ -128,8 +128,12 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                const GsrRecord* __restrict__ recs, float4* __restrict__ out, uint4* __restrict__ tile_work,
                const float* __restrict__ zwin, const float* __restrict__ depth, const GsrLazyArgs& lz)
 {
-    constexpr int PF4 = HAS_DEPTH ? 6 : 5;
+    constexpr int PF4 = 5;
     __shared__ float4 slist[4][(BL_ROUND / 2) * PF4];
+    // depth-tested frames: the staged records' window depths, pair by pair, in an array of their OWN -- as a sixth vector of the pair
+    // block they cost every tile of the launch (a 96-byte block stride puts the staging stores on 8 banks instead of 16, and the plain
+    // loop of a tile the geometry does not touch skipped 16 of every 96 bytes): the depth-tested kernel under a clear buffer was 10 % slower
+    __shared__ float2 szl[HAS_DEPTH ? 4 : 1][HAS_DEPTH ? BL_ROUND / 2 : 1];
     __shared__ uint32_t q[BL_QCAP];   // hit queue: splat indices in list (= depth) order
     __shared__ __attribute__((aligned(16))) uint32_t scnt[2][4];   // hits of each wave in a scan step
     __shared__ uint32_t sdone[2][4];
@@ -189,14 +193,15 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     // Per WAVE (= 8x8 quadrant), once: what the opaque pass left under it.  K1 keeps a splat only if -w <= z <= w, so every window
     // depth in the lists is <= 1 (an IEEE quotient of z <= w is <= 1, and fma(q, 0.5, 0.5) of q <= 1 is <= 1): a quadrant whose
     // depth buffer was CLEARED TO THE FAR PLANE (all >= 1) passes every fragment -- d_triv -- and runs the plain loop, bit-identical
-    // by construction.  Otherwise d_wmax / d_wmin = the largest / smallest depth under the quadrant (a NaN pixel fails every
-    // fragment: -inf): a record whose window depth exceeds d_wmax can pass nowhere here and is not staged; one at or below d_wmin
-    // passes everywhere and needs no per-pixel compare; only the records in between take the depth-tested loop.
+    // by construction.  Otherwise w_max (per sub-round, below) / d_wmin = the largest depth under the quadrant's pixels that are not opaque
+    // yet / the smallest depth under the quadrant (a NaN pixel fails every fragment: -inf): a record whose window depth exceeds w_max can
+    // pass nowhere it could contribute and is not staged; one at or below d_wmin passes everywhere and needs no per-pixel compare; only
+    // the records in between take the depth-tested loop.
     // (formed right before the first gather, not here: `dpx` is a load, and consuming it here would put its latency in front of the
     //  list loads below instead of beside them -- measured: +13 us per C4 launch, five generations of tiles x ~2 us)
     bool d_met = false;               // (wave-uniform) a record that reaches this quadrant did not pass the depth test everywhere in it
     bool d_triv = true, d_init = !HAS_DEPTH;
-    float d_wmax = __builtin_inff(), d_wmin = __builtin_inff();
+    float d_wmin = __builtin_inff();
 
     const int st = (gty >> a.super_shift) * a.stiles_x + (tx >> a.super_shift);
     const int s = sstart[st];
@@ -230,7 +235,6 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     uint32_t es_u = 0xffu;            // (uniform) scan steps that hold what the tile's uncovered pixels needed (0xff: unknown / not reached)
     bool u_all = false;               // (uniform) every wave's uncovered pixels are opaque
     uint32_t fetched = 0;             // (uniform) queued hits handed to the waves
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
 
     // ---- scan state (identical in every thread)
@@ -263,7 +267,8 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         const int cur = (scan_pos >> 10) - 1;            // the last step that was scanned
         if (c == 0u) return 0u;
         if (cur < 0) return 0xffu;
-        const bool reached = lane < 32 && cur - lane >= 0 && stail[(cur - lane) & 31] >= c;
+        const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (the lane id afresh: two instructions, and nothing derived from it stays live across the loop)
+        const bool reached = ln < 32 && cur - ln >= 0 && stail[(cur - ln) & 31] >= c;
         const unsigned long long m = __ballot(reached);   // bit l: after step cur - l the queue already held the hit
         const int k = __builtin_ctzll(~m | (1ull << 63)); // (bit 0 is always set in a wave that sees the ring: everything was queued by the last step)
         const int e = cur - (k - 1) + 1;
@@ -274,17 +279,12 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         u_done = __all(!pix_ok || T < GSR_T_MIN || dpx < 1.0f);
         d_triv = __all(dpx >= 1.0f) && !(a.flags & GSR_FLAG_NO_DEPTH_CLASS);
         if (a.flags & GSR_FLAG_NO_DEPTH_CLASS) {   // (A/B and test hook: every record is staged and compared per pixel, as before round 6)
-            d_wmax = __builtin_inff(); d_wmin = -__builtin_inff();
+            d_wmin = -__builtin_inff();
         } else if (!d_triv) {
             const float ninf = -__builtin_inff();
-            float vmax = pix_ok ? (dpx == dpx ? dpx : ninf) : ninf;
             float vmin = pix_ok ? (dpx == dpx ? dpx : ninf) : __builtin_inff();
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) {
-                vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, d, 64));
-                vmin = __builtin_fminf(vmin, __shfl_xor(vmin, d, 64));
-            }
-            d_wmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vmax)));
+            for (int d = 32; d > 0; d >>= 1) vmin = __builtin_fminf(vmin, __shfl_xor(vmin, d, 64));
             d_wmin = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vmin)));
         }
     };
@@ -340,6 +340,19 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
             for (int sub = 0; sub < take; sub += 64) {
                 my_last = q_head + (uint32_t)(sub + 64 < take ? sub + 64 : take);
                 const bool have = sub + lane < take;
+                // (depth-tested quadrants that hold geometry) what still matters are the pixels that are not opaque yet: a record behind
+                // the depth of every one of THEM passes nowhere it could contribute (an opaque pixel takes nothing more).  A quadrant on the geometry's silhouette whose uncovered pixels have gone opaque thus
+                // stops staging at the geometry, instead of compositing the rest of its list into pixels that cannot take it.
+                float w_max = __builtin_inff(), w_min = -__builtin_inff();   // (GSR_FLAG_NO_DEPTH_CLASS: every record is staged and compared per pixel)
+                if (HAS_DEPTH && !d_triv && !(a.flags & GSR_FLAG_NO_DEPTH_CLASS)) {
+                    const bool live = pix_ok && T >= GSR_T_MIN;
+                    const float dl = dpx == dpx ? dpx : -__builtin_inff();
+                    float vmax = live ? dl : -__builtin_inff();
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, d, 64));
+                    w_max = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vmax)));
+                    w_min = d_wmin;     // (the smallest depth under ALL of the quadrant's pixels: the live ones' would do, and costs two registers too many)
+                }
                 float4 r1, r2;
                 float rz = 0.0f, c0 = 0.0f, c1 = 0.0f;
                 bool hit = false, pending = false, dtest = false, dmet_l = false;
@@ -366,8 +379,8 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     if (HAS_DEPTH && !d_triv) {
                         // (reaches the quadrant, but not CLEARLY in front of everything under it)
                         dmet_l = hit && !(rz <= d_wmin && (a.near_alpha - rz) >= a.near_scale * (a.near_alpha - d_wmin));
-                        hit = hit && (rz <= d_wmax);          // behind everything the opaque pass left under this quadrant: no fragment passes
-                        dtest = hit && !(rz <= d_wmin);       // in front of all of it: every fragment passes
+                        hit = hit && (rz <= w_max);           // behind everything the opaque pass left under the quadrant's live pixels: no fragment passes
+                        dtest = hit && !(rz <= w_min);        // in front of all of it: every fragment passes
                     }
                     pending = __builtin_bit_cast(uint32_t, r2.x) == GSR_COLOUR_PENDING;
                     if (LAZY) {
@@ -388,13 +401,13 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                 const bool dslow = HAS_DEPTH && __any(dtest);       // (uniform) some staged record needs the per-pixel depth compare
                 if (HAS_DEPTH && __any(dmet_l)) d_met = true;
                 if (hit) {
-                    const uint32_t pos = (uint32_t)__builtin_popcountll(bal & lt_mask);
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));   // hits of the lower lanes
                     float* blk = reinterpret_cast<float*>(&slist[wave][(pos >> 1) * PF4]);
                     const uint32_t h = pos & 1u;
                     blk[0 + h] = r1.x; blk[2 + h] = r1.y; blk[4 + h] = r1.z; blk[6 + h] = r1.w;
                     blk[8 + h] = c0; blk[10 + h] = c1;
                     reinterpret_cast<float4*>(blk)[3 + h] = r2;
-                    if (HAS_DEPTH) blk[20 + h] = rz;
+                    if (HAS_DEPTH) reinterpret_cast<float*>(&szl[wave][pos >> 1])[h] = rz;
                 }
                 if ((cnt & 1) && lane == 0) {   // odd list: pad with a record that cannot contribute (la = -inf: discarded everywhere)
                     float* blk = reinterpret_cast<float*>(&slist[wave][(cnt >> 1) * PF4]);
@@ -405,7 +418,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                         volatile float* vb = blk;
                         vb[16] = 0.0f; vb[17] = 0.0f; vb[18] = 0.0f; vb[19] = -__builtin_inff();
                     }
-                    if (HAS_DEPTH) blk[21] = 0.0f;
+                    if (HAS_DEPTH) reinterpret_cast<float*>(&szl[wave][cnt >> 1])[1] = 0.0f;
                 }
                 // the list is written and read by this wave only: LDS operations of one wave execute in order
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -416,11 +429,11 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                 // (3) composite: the wave walks its list, two records per iteration in packed FP32
                 const int npairs = (cnt + 1) >> 1;
                 const float4* L = slist[wave];
-                struct PairOps { float4 v0, v1, v2, v3, v4, v5; };
+                struct PairOps { float4 v0, v1, v2, v3, v4; float2 z; };
                 auto load_pair = [&](auto with_depth, int p) __attribute__((always_inline)) {
                     PairOps o;
                     o.v0 = L[p * PF4 + 0]; o.v1 = L[p * PF4 + 1]; o.v2 = L[p * PF4 + 2]; o.v3 = L[p * PF4 + 3]; o.v4 = L[p * PF4 + 4];
-                    if constexpr (decltype(with_depth)::value) o.v5 = L[p * PF4 + 5]; else o.v5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if constexpr (decltype(with_depth)::value) o.z = szl[wave][p]; else o.z = make_float2(0.0f, 0.0f);
                     return o;
                 };
                 auto blend_ops = [&](auto with_depth, const PairOps& o, gsr_v2f& C01, float& C2, float& T) __attribute__((always_inline)) {
@@ -438,9 +451,8 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     bool ina = (__builtin_fmaxf(__builtin_fabsf(q0.x), __builtin_fabsf(q1.x)) <= GSR_QLIM) && (arga >= -GSR_LOG2_255);
                     bool inb = (__builtin_fmaxf(__builtin_fabsf(q0.y), __builtin_fabsf(q1.y)) <= GSR_QLIM) && (argb >= -GSR_LOG2_255);
                     if constexpr (decltype(with_depth)::value) {
-                        const float4 v5 = o.v5;
-                        ina = ina && (v5.x <= dpx);
-                        inb = inb && (v5.y <= dpx);
+                        ina = ina && (o.z.x <= dpx);
+                        inb = inb && (o.z.y <= dpx);
                     }
 #ifdef BL_PROFILE
                     {
@@ -522,7 +534,9 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         __syncthreads();   // the consumed queue slots may be overwritten from here on; every wave's verdict is in
         BLP(6)
         if (!LAZY && sredo) {   // (uniform: written before the barrier)
-            if (tid == 0 && lz.redo) lz.redo[atomicAdd(lz.redo_count, 1u)] = tile;
+            int t3 = tile;
+            asm volatile("" : "+s"(t3));   // (or its vector copy is made in the prologue, kept for the whole kernel -- and spilt)
+            if (tid == 0 && lz.redo) lz.redo[atomicAdd(lz.redo_count, 1u)] = t3;
             return;
         }
         const uint32_t dall = sdone[rpar][0] & sdone[rpar][1] & sdone[rpar][2] & sdone[rpar][3];

@@ -37,6 +37,8 @@ dt = (time.perf_counter() - t0) / 20
 buf = np.zeros((65536, 4, 16), dtype=np.uint64)
 fn(buf.ctypes.data, 0)
 live = buf[:, :, 9] > 0
+# (the buffer is indexed by workgroup: rows a shorter launch did not overwrite are stale -- keep the LAST launch, the rows that ended within 2 ms of the latest end)
+live &= buf[:, :, 12] + np.uint64(200000) >= buf[:, :, 12][live].max()
 v = buf[live].astype(np.float64)
 names = ["prologue", "scan (+its barriers)", "batch bookkeeping", "gather + quadrant test + staging", "composite",
          "batch tail", "wait: batch-end barrier", "-", "epilogue (store)"]
@@ -63,6 +65,9 @@ print("the %d waves that live >= %.1f us (p99):" % (vv.shape[0], thr))
 for n, x in zip(names, vv[:, :9].sum(axis=0)):
     print("  %-34s %6.2f %%   %7.2f us/wave" % (n, 100 * x / tt, x / tt * ((vv[:, 12] - vv[:, 11]).sum() / 100.0) / vv.shape[0]))
 print("  rounds (batches) per wave: median %.0f  max %.0f" % (np.median(vv[:, 10]), vv[:, 10].max()))
+# which waves are the tail?  by rounds, and by where in the launch they started
+order = np.argsort(-life)[:16]
+print("the 16 longest-lived waves: life us / start us after launch / rounds / composite share:", "  ".join("%.0f/%.0f/%d/%.2f" % (life[i], (start[i] - start.min()) / 100.0, v[i, 10], v[i, 4] / max(v[i, :9].sum(), 1.0)) for i in order))
 print("wave lifetime us: median %.1f  p90 %.1f  p99 %.1f  max %.1f" % tuple(np.quantile(life, [0.5, 0.9, 0.99, 1.0])))
 t0_ = start.min()
 edges = np.linspace(0, span * 100.0, 11)

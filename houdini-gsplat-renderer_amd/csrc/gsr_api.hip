@@ -1106,6 +1106,35 @@ static double sigma_max_sq(const float* m)
     return (std::isfinite(padded) && padded < fro) ? padded : fro;
 }
 
+// Depth-tested frames: the range of window depths the list entries' nine depth bits spread over (gsr_device.h: gsr_zq) -- that of the
+// cloud's bounding box as this camera sees it.  Nothing depends on the range being right: the code clamps, and it is monotone whatever
+// the constants are; a bad range only filters less.  Clouds of 2^23 splats or more have no spare index bits: no codes.
+static void frame_depth_codes(const gsr_context* c, const gsr_camera* cam, GsrFrame* f)
+{
+    f->idx_mask = 0xffffffffu; f->zq0 = 0.0f; f->zqs = 0.0f;
+    // (nor frames whose depth buffer is expected to be clear -- the plain kernel behind its guard -- where the codes would only cost)
+    if (c->n >= (1u << GSR_ZQ_SHIFT) || !c->bbox_ok || !c->depth_active || (c->opt_flags & GSR_FLAG_NO_ZCODES)) return;
+    double zlo = 1.0, zhi = 0.0;
+    bool behind = false;
+    for (int k = 0; k < 8; ++k) {
+        double p[4], e[4], q[4];
+        for (int a = 0; a < 3; ++a) p[a] = ((k >> a) & 1) ? c->bb_hi[a] : c->bb_lo[a];
+        p[3] = 1.0;
+        for (int r = 0; r < 4; ++r) e[r] = M4h(cam->obj_view, r, 0) * p[0] + M4h(cam->obj_view, r, 1) * p[1] + M4h(cam->obj_view, r, 2) * p[2] + M4h(cam->obj_view, r, 3);
+        for (int r = 0; r < 4; ++r) q[r] = M4h(cam->proj, r, 0) * e[0] + M4h(cam->proj, r, 1) * e[1] + M4h(cam->proj, r, 2) * e[2] + M4h(cam->proj, r, 3) * e[3];
+        if (!(q[3] > 1e-9)) { behind = true; continue; }
+        const double zw = 0.5 * (q[2] / q[3]) + 0.5;
+        if (std::isfinite(zw)) { zlo = std::min(zlo, zw); zhi = std::max(zhi, zw); }
+    }
+    if (behind) zlo = 0.0;
+    zlo = std::min(std::max(zlo, 0.0), 1.0); zhi = std::min(std::max(zhi, 0.0), 1.0);
+    if (!(zhi > zlo)) return;
+    f->idx_mask = (1u << GSR_ZQ_SHIFT) - 1u;
+    f->zq0 = (float)zlo;
+    f->zqs = (float)(512.0 / (zhi - zlo));
+    if (!std::isfinite(f->zqs)) { f->idx_mask = 0xffffffffu; f->zqs = 0.0f; }
+}
+
 static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f)
 {
     for (int r = 0; r < 3; ++r)
@@ -1121,6 +1150,7 @@ static void build_frame(const gsr_context* c, const gsr_camera* cam, GsrFrame* f
             f->io[r * 3 + k] = M4h(cam->inv_object, r, k);
         }
     for (int k = 0; k < 3; ++k) { f->cam[k] = cam->cam_pos[k]; f->origin[k] = c->origin[k]; }
+    f->idx_mask = 0xffffffffu; f->zq0 = 0.0f; f->zqs = 0.0f;      // (depth-tested frames: frame_depth_codes)
     // CalcCovariance2D's per-frame constants, float32, in the contract's order
     // (/root/reference/gsplat_plugin/shaders/GSplatShaderCoreLib.h:44-53)
     volatile float p00 = M4h(cam->proj, 0, 0), p11 = M4h(cam->proj, 1, 1);
@@ -1317,6 +1347,8 @@ static int queue_blend(gsr_context* c, FrameSlot& sl, bool with_depth, bool guar
             a.near_scale = persp ? 1.12f : 0.0f;
         }
         a.tile_cov = (with_depth && j.dcull) ? sl.dpyr + 4 * sl.dpyr_cap : (const float*)nullptr;
+        a.idx_mask = f.idx_mask; a.zq0 = f.zq0; a.zqs = f.zqs;
+        a.tile_dmax = (with_depth && j.dcull && f.idx_mask != 0xffffffffu) ? sl.dpyr + (size_t)(2 * j.dpar) * sl.dpyr_cap + f.pyr_off[0] : (const float*)nullptr;
         a.width = f.width; a.height = f.height; a.tiles_x = f.tiles_x; a.local_tiles = j.local_tiles;
         a.shard = GsrShard{f.shard_index, f.shard_count, f.shard_rpb}; a.band_rows = j.band_rows;
         a.super_shift = f.super_shift; a.rect_shift = f.rect_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
@@ -1369,7 +1401,8 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         const uint32_t bn_extra = (uint32_t)BN_SPLIT_TILES * (uint32_t)std::max(f.stiles_y - 1, 0);
         const uint32_t grid = std::min(nblk, j.bn_grid) + bn_extra + (j.ranges_folded ? 1u : 0u);
 #define GSR_PLACE(I) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin_place<I>), dim3(grid), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n,          \
-                                        f.super_shift - f.rect_shift, shd, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk, (uint32_t)sl.pair_cap, sl.pvA, ra)
+                                        f.super_shift - f.rect_shift, shd, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk, (uint32_t)sl.pair_cap, sl.pvA, ra,   \
+                                        f.idx_mask != 0xffffffffu ? sl.zwin : (const float*)nullptr, f.zq0, f.zqs)
         if (j.bn_items == 1) GSR_PLACE(1); else if (j.bn_items == 2) GSR_PLACE(2); else GSR_PLACE(4);
 #undef GSR_PLACE
         HIP_TRY(hipGetLastError());
@@ -1414,6 +1447,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
         hz.stat = sl.hstat;
         hz.stat_in_use = (j.cull && j.dcull && j.dstat) ? 1 : 0;
         hz.depth_culled = j.dcull ? 1 : 0;
+        hz.idx_mask = j.f.idx_mask;
         static const bool dbgv = std::getenv("GSR_DEBUG_VIOL") != nullptr;
         if (dbgv) {
             if (!sl.dbg_viol && hipMalloc(reinterpret_cast<void**>(&sl.dbg_viol), 80 * 4) != hipSuccess) sl.dbg_viol = nullptr;
@@ -1517,7 +1551,7 @@ static int queue_slab_mid(gsr_context* c, FrameSlot& sl)
     GsrHorizonArgs hz{};
     hz.list_cap = (int32_t)std::min<size_t>(sl.pair_cap, (size_t)0x7fffffff);
     hz.raw = (c->opt_cull && c->opt_cull != 3) ? sl.hraw : nullptr;          // the finished tiles' horizons for the slot's NEXT frame
-    hz.lists = sl.pvA; hz.geoA = c->geoA;
+    hz.lists = sl.pvA; hz.geoA = c->geoA; hz.idx_mask = j.f.idx_mask;
     for (int l = 0; l < GSR_PYR_LEVELS; ++l) hz.pyr_off[l] = j.f.pyr_off[l];
     hz.cam[0] = j.f.cam[0]; hz.cam[1] = j.f.cam[1]; hz.cam[2] = j.f.cam[2];
     const int nblocks8 = ((j.f.tiles_x + 7) >> 3) * ((j.f.tiles_y + 7) >> 3);
@@ -1942,6 +1976,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
     // the caller's), one per slot; the second phase of a front-slab frame uses the first one's.  GSR_OPT_OCCLUSION_CULL = 0 switches
     // it off like every other occlusion test (what is left is k_blend's own per-quadrant classification and per-fragment compare).
     j.dcull = j.d_depth != nullptr && c->opt_cull != 0 && n > 0;
+    if (j.dcull) frame_depth_codes(c, cam, &j.f);
     if (j.dcull) {
         const size_t need = (size_t)f.pyr_off[GSR_PYR_LEVELS - 1] + (size_t)gsr_pyr_dim(f.tiles_x, GSR_PYR_LEVELS - 1) * gsr_pyr_dim(f.tiles_y, GSR_PYR_LEVELS - 1) + 16;
         if (need > sl.dpyr_cap || !sl.dactive) {
@@ -2066,6 +2101,8 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
                 for (int l = 0; l < GSR_PYR_LEVELS; ++l) dp.off[l] = f.pyr_off[l];
                 const uint32_t nb8 = (uint32_t)gsr_depth_pyramid_blocks(f.tiles_x, f.tiles_y);
                 if (c->depth_active) {
+                    // (measured and rejected, round 6: the pass inside k_cluster_cull's launch here too, the cluster workgroups waiting on a
+                    //  count of finished pyramid workgroups before their depth tests: 3650 fps against 4245 -- LAB_NOTES.md)
                     hipLaunchKernelGGL(k_depth_pyramid, dim3(nb8), dim3(1024), 0, s, dp);
                     if (c->opt_cluster && !ordered) dc_clus = dc_k1;
                 } else {
@@ -2670,7 +2707,7 @@ extern "C" int gsr_debug_read_tile_lists(gsr_context* c, int32_t* list_start, in
     }
     if (n_pairs) HIP_TRY(hipMemcpy2D(pair_splat, 4, sl->pvA, 8, 4, (size_t)n_pairs, hipMemcpyDeviceToHost));
     if ((rc = host_perm(c))) return rc;
-    for (int64_t r = 0; r < n_pairs; ++r) pair_splat[r] = (int32_t)to_upload_index(c, (uint32_t)pair_splat[r]);
+    for (int64_t r = 0; r < n_pairs; ++r) pair_splat[r] = (int32_t)to_upload_index(c, (uint32_t)pair_splat[r] & sl->job.f.idx_mask);   // (depth bits off: gsr_device.h)
     return GSR_OK;
 }
 

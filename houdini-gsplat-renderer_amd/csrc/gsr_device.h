@@ -84,7 +84,15 @@ struct GsrFrame {
     int32_t phase;                     // front-slab frames (gsr_api.hip): 0 = the whole frame; 1 = only the splats with key <= the slab key
                                        // (device word, picked by k_slab_pick); 2 = only the ones beyond it, culled against the tiles
                                        // that phase 1 left opaque
+    // Depth-tested frames of clouds below 2^23 splats (the reference's own limit): the nine spare bits of a list entry's splat index carry a
+    // coarse WINDOW DEPTH (gsr_zq: monotone, a lower bound), so that a tile can drop the entries that lie behind everything the opaque pass
+    // left under its live pixels while it SCANS its list -- before they cost a queue slot, a 48-byte gather and a quadrant test per wave
+    // (k_bin_place writes the bits, k_blend reads them; everybody else masks them off).  idx_mask = 0xffffffff: no such bits.
+    uint32_t idx_mask;
+    float zq0, zqs;                    // code = clamp(floor((zwin - zq0) * zqs), 0, 511)
 };
+#define GSR_ZQ_SHIFT 23
+#define GSR_ZQ_MAX 511.0f
 #define GSR_SLAB_BINS 1024             // k_cluster_cull's histogram of the surviving clusters' nearest keys (k_slab_pick reads it)
 #define GSR_FLAG_NO_ALPHA_RADIUS 1   // bbox from the full +-2 quad instead of the alpha>=1/255 support
 #define GSR_FLAG_NO_SAT          2   // quadrant masks from the bbox only
@@ -92,6 +100,7 @@ struct GsrFrame {
 #define GSR_FLAG_LAZY_NO_PREFIX  8   // lazy colour: colour nothing ahead of time, so that every tile takes the on-demand fallback
 #define GSR_FLAG_CULL_ROUNDS    16   // k_cluster_cull: three rounds of clusters per workgroup (what clouds beyond 33 M splats do)
 #define GSR_FLAG_NO_DEPTH_CLASS 32   // depth-tested frames: no per-quadrant classification in k_blend (every record staged, every fragment compared)
+#define GSR_FLAG_NO_ZCODES      64   // depth-tested frames: no coarse window depth in the list entries' spare index bits (GsrFrame.idx_mask)
 
 // small-frame depth sort (k_sort.h): bucket regions
 #ifndef BK_BUCKETS
@@ -104,6 +113,13 @@ struct GsrFrame {
 
 // ---- scalar helpers ---------------------------------------------------------
 __device__ __forceinline__ float gsr_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// nine-bit code of a window depth, monotone non-decreasing (so code(z) > code(limit) implies z > limit); NaN -> 0, +inf -> 511
+__device__ __forceinline__ uint32_t gsr_zq(float zw, float z0, float zs)
+{
+    const float t = __builtin_fminf(__builtin_fmaxf((zw - z0) * zs, 0.0f), GSR_ZQ_MAX);
+    return (uint32_t)t;
+}
 
 __device__ __forceinline__ float gsr_h2f(uint32_t bits16)
 {

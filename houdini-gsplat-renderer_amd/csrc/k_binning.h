@@ -270,7 +270,8 @@ template <int ITEMS>
 __global__ void __launch_bounds__(BN_THREADS)
 k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, GsrShard sh,
             int stiles_x, int ns, const uint32_t* __restrict__ offs, const int32_t* __restrict__ sstart,
-            uint32_t nblk, uint32_t cap, uint2* __restrict__ out, GsrRangeArgs ranges)
+            uint32_t nblk, uint32_t cap, uint2* __restrict__ out, GsrRangeArgs ranges,
+            const float* __restrict__ zwin, float zq0, float zqs)
 {
     static_assert(BN_THREADS == BN_BINS, "one thread per super-tile in the range scan");
     constexpr uint32_t TILE = BN_THREADS * ITEMS;
@@ -318,6 +319,8 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
         const int grp = k * 4 + wave;
         const uint32_t i = first + (uint32_t)grp * 64u + (threadIdx.x & 63u);
         v[k] = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
+        // (depth-tested frames: the coarse window depth goes into the index word's spare bits -- GsrFrame.idx_mask; the load is not needed before (B))
+        if (zwin != nullptr && i < n) v[k].x |= gsr_zq(zwin[v[k].x], zq0, zqs) << GSR_ZQ_SHIFT;
         bn_group_pairs(v[k], shift, sh, stiles_x, part.row_lo, part.row_hi,
                        [&](int L, uint2, uint32_t d, int, int) { if (d < (uint32_t)ns) atomicOr(&lmask[grp * ns + d], 1ull << L); });
     }

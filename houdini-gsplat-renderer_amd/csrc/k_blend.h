@@ -96,6 +96,12 @@ struct GsrBlendArgs {
     float near_alpha, near_scale;
     const float* tile_cov;      // depth-tested frames with a depth pyramid (k_cluster.h): level 0 of pyrc, [tiles_y][tiles_x]; < 0 = the tile has
                                 // no covered pixel.  NULL: not known (every tile loads its depths)
+    // list entries whose index word carries a coarse window depth (GsrFrame.idx_mask, gsr_zq): a tile drops, while it SCANS, the entries
+    // behind the largest depth under its live pixels -- tile_dmax (level 0 of the depth pyramid: the largest depth under the tile) to begin
+    // with, then what its waves report at the end of every batch.  idx_mask = 0xffffffff: no such bits in the lists.
+    uint32_t idx_mask;
+    float zq0, zqs;
+    const float* tile_dmax;     // NULL: no scan-time depth filter
 };
 
 // Staging layout: one list PER QUADRANT (= per wave), holding the round's records that reach that
@@ -137,6 +143,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     __shared__ uint32_t q[BL_QCAP];   // hit queue: splat indices in list (= depth) order
     __shared__ __attribute__((aligned(16))) uint32_t scnt[2][4];   // hits of each wave in a scan step
     __shared__ uint32_t sdone[2][4];
+    __shared__ float swmax[2][4];     // depth-tested frames: per wave, the largest depth under its pixels that are not opaque yet (batch end)
     __shared__ uint32_t sevals, sredo, sdmet;
     __shared__ uint32_t slastu[4];    // depth-tested frames: the same count at the moment the wave's UNCOVERED pixels were all opaque
     __shared__ uint32_t stail[32];    // hits queued after each of the last 32 scan steps (ring): which step held a given hit?
@@ -243,6 +250,10 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     int spar = 0;
     // A list entry is (splat index, tile mask): bit c of the low half = the splat's rect reaches column c of the
     // super-tile, bit 16 + r = row r, in rect units (k_bin_place).  This tile is in the rect iff both of ITS bits are set.
+    // (uniform) entries whose index word exceeds zlim lie behind every live pixel of the tile: code(zwin) > code(limit) => zwin > limit
+    uint32_t zlim = 0xffffffffu;
+    const bool zfilter = HAS_DEPTH && a.tile_dmax != nullptr && a.idx_mask != 0xffffffffu && !tile_plain && !(a.flags & GSR_FLAG_NO_DEPTH_CLASS);
+    if (zfilter) zlim = (gsr_zq(a.tile_dmax[gty * a.tiles_x + tx], a.zq0, a.zqs) << GSR_ZQ_SHIFT) | a.idx_mask;
     const uint32_t sub_mask = (1u << a.super_shift) - 1u;
     const uint32_t tile_bits = (1u << ((tx & sub_mask) >> a.rect_shift)) | (0x10000u << ((gty & sub_mask) >> a.rect_shift));
     // thread t scans entries 4t .. 4t+3 of a 1024-entry step: two 16-byte loads, prefetched one step ahead
@@ -295,8 +306,9 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         constexpr int batch = BL_BATCH;
         while ((int)(q_tail - q_head) < batch && scan_pos < n) {
             const int rem = n - (scan_pos + 4 * tid);   // entries of this thread that exist
-            const bool h0 = rem > 0 && (preA.y & tile_bits) == tile_bits, h1 = rem > 1 && (preA.w & tile_bits) == tile_bits;
-            const bool h2 = rem > 2 && (preB.y & tile_bits) == tile_bits, h3 = rem > 3 && (preB.w & tile_bits) == tile_bits;
+            bool h0 = rem > 0 && (preA.y & tile_bits) == tile_bits, h1 = rem > 1 && (preA.w & tile_bits) == tile_bits;
+            bool h2 = rem > 2 && (preB.y & tile_bits) == tile_bits, h3 = rem > 3 && (preB.w & tile_bits) == tile_bits;
+            if (HAS_DEPTH) { h0 = h0 && preA.x <= zlim; h1 = h1 && preA.z <= zlim; h2 = h2 && preB.x <= zlim; h3 = h3 && preB.z <= zlim; }
             const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1), b2 = __ballot(h2), b3 = __ballot(h3);
             // hits of the lower lanes: v_mbcnt accumulates, eight instructions for the four ballots
             uint32_t pos = 0;
@@ -357,7 +369,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                 float rz = 0.0f, c0 = 0.0f, c1 = 0.0f;
                 bool hit = false, pending = false, dtest = false, dmet_l = false;
                 if (have) {
-                    const uint32_t ridx = q[(q_head + (uint32_t)(sub + lane)) & (BL_QCAP - 1)];
+                    const uint32_t ridx = q[(q_head + (uint32_t)(sub + lane)) & (BL_QCAP - 1)] & a.idx_mask;
                     const float4* p = reinterpret_cast<const float4*>(recs + ridx);
                     const float4 r0 = p[0];
                     r1 = p[1]; r2 = p[2];
@@ -527,8 +539,16 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         }
         q_head += (uint32_t)take;
         const int rpar = round & 1;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);   // (a scalar: as a vector the LDS addresses below are formed in the prologue and kept -- or spilt)
         if (HAS_DEPTH && wave_done && !u_done) { u_done = true; my_last_u = my_last; }
-        if (lane == 0) { sdone[rpar][wave] = (wave_done ? 1u : 0u) | ((HAS_DEPTH ? u_done : wave_done) ? 2u : 0u); slast[wave] = my_last; if (HAS_DEPTH) slastu[wave] = my_last_u; }
+        if (HAS_DEPTH && zfilter) {   // (uniform) the largest depth under this wave's pixels that can still take something
+            const bool live = pix_ok && T >= GSR_T_MIN && !wave_done;
+            float vmax = live ? (dpx == dpx ? dpx : -__builtin_inff()) : -__builtin_inff();
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, d, 64));
+            if (lane == 0) swmax[rpar][wv] = vmax;
+        }
+        if (lane == 0) { sdone[rpar][wv] = (wave_done ? 1u : 0u) | ((HAS_DEPTH ? u_done : wave_done) ? 2u : 0u); slast[wv] = my_last; if (HAS_DEPTH) slastu[wv] = my_last_u; }
         ++round;
         BLP(5)
         __syncthreads();   // the consumed queue slots may be overwritten from here on; every wave's verdict is in
@@ -538,6 +558,10 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
             asm volatile("" : "+s"(t3));   // (or its vector copy is made in the prologue, kept for the whole kernel -- and spilt)
             if (tid == 0 && lz.redo) lz.redo[atomicAdd(lz.redo_count, 1u)] = t3;
             return;
+        }
+        if (HAS_DEPTH && zfilter) {
+            const float tm = __builtin_fmaxf(__builtin_fmaxf(swmax[rpar][0], swmax[rpar][1]), __builtin_fmaxf(swmax[rpar][2], swmax[rpar][3]));
+            zlim = (gsr_zq(tm, a.zq0, a.zqs) << GSR_ZQ_SHIFT) | a.idx_mask;
         }
         const uint32_t dall = sdone[rpar][0] & sdone[rpar][1] & sdone[rpar][2] & sdone[rpar][3];
         if (HAS_DEPTH && !u_all && (dall & 2u)) {   // (uniform) the moment the tile's uncovered pixels were all opaque: how deep had it looked?
@@ -677,6 +701,7 @@ struct GsrHorizonArgs {
     // frame's k_tile_pass reads it back to know which of the two promises each tile has to keep.
     float* stat;                    // [tiles_y][tiles_x] 1 / 0; NULL: no depth-tested frames so far (every tile classic)
     int32_t stat_in_use;            // this frame's K1 applied `stat` (a culled depth-tested frame)
+    uint32_t idx_mask;              // the list entries' index bits (GsrFrame.idx_mask)
     int32_t depth_culled;           // this frame's K1 dropped splats behind the opaque geometry where no horizon applied (k_preprocess.h)
     uint32_t* dbg;                  // GSR_DEBUG_VIOL in the environment: [0] = tiles that broke their promise, then 8 words for each of the first eight
 };
@@ -769,7 +794,7 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
     if (hz.raw) {
         const bool ok = opaque && rd > 0u && rd <= len;
         const bool c1 = opaque_c && rdc > 0u && rdc <= len && hold < 3.0e38f, c2 = ok && want < len;
-        const uint32_t i1 = hz.lists[c1 ? (uint32_t)s0 + rdc - 1u : 0u].x;  // the last entry the tile scanned (for the promise it made)
+        const uint32_t i1 = hz.lists[c1 ? (uint32_t)s0 + rdc - 1u : 0u].x & hz.idx_mask;  // the last entry the tile scanned (for the promise it made)
         // Depth-tested frames WITHOUT horizons (the first frames, a repair): K1 dropped what lies behind the opaque geometry, so a tile that
         // saturates just in front of it does so on a list that ENDS there -- "too short" for the rule above, and with no old horizon to push
         // out it would get none.  A tile without a horizon costs far more than itself: the pyramid look-up of a cluster's widened rect
@@ -777,7 +802,7 @@ k_tile_pass(const uint4* __restrict__ tile_work, GsrSumArgs g, const int32_t* __
         // of 14 k).  Its list's last entry, pushed out by 5 %, stands in; the next frame -- culled, its lists no longer cut inside the
         // horizons -- checks itself as always.
         const bool c3 = ok && !c2 && !(hold < 3.0e38f) && hz.depth_culled != 0;
-        const uint32_t i2 = hz.lists[c2 ? (uint32_t)s0 + want : (c3 ? (uint32_t)s0 + len - 1u : 0u)].x;      // the entry its next horizon sits at
+        const uint32_t i2 = hz.lists[c2 ? (uint32_t)s0 + want : (c3 ? (uint32_t)s0 + len - 1u : 0u)].x & hz.idx_mask;      // the entry its next horizon sits at
         const float4 P1 = hz.geoA[c1 ? i1 : 0u], P2 = hz.geoA[c2 ? i2 : 0u];
         // distance^2 = the sort key of k_preprocess.h, same operations
         float klast, hnew;
@@ -884,7 +909,7 @@ k_slab_mid(const uint4* __restrict__ tile_work_a, GsrSumArgs g, const int32_t* _
         const uint32_t first = ((w.w >> 1) & 0x1fffu) << 10;
         const uint32_t want = rd + ((rd > first ? rd - first : 0u) >> 2) + 1024u;
         const bool c2 = opaque && rd > 0u && rd <= len && want < len;
-        const uint32_t i2 = hz.lists[c2 ? (uint32_t)s0 + want : 0u].x;
+        const uint32_t i2 = hz.lists[c2 ? (uint32_t)s0 + want : 0u].x & hz.idx_mask;
         const float4 P2 = hz.geoA[c2 ? i2 : 0u];
         const float dx = P2.x - hz.cam[0], dy = P2.y - hz.cam[1], dz = P2.z - hz.cam[2];
         const float hnew = gsr_fma(dz, dz, gsr_fma(dy, dy, dx * dx));

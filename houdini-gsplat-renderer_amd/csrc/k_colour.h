@@ -41,7 +41,7 @@ cl_colour_span(const GsrFrame& f, const uint2* __restrict__ lists, int first, in
     for (int e0 = first; e0 < hi; e0 += step) {   // (wave-uniform trip count)
         const int e = e0 + lane;
         const bool live = e < hi;
-        const uint32_t idx = live ? lists[e].x : 0xffffffffu;
+        const uint32_t idx = live ? (lists[e].x & f.idx_mask) : 0xffffffffu;
         sidx[wbase + lane] = idx;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -2235,3 +2235,39 @@ def test_bench_line_carries_the_depth_tested_and_boundary_legs(pkg):
     assert b["via_shim"]["value"] > 0 and b["via_shim"]["frame_within_1e-3_of_unculled"] is True and b["via_shim"]["stagings"] == 1
     r = b["restage"]
     assert r["value"] > 0 and r["stagings"] >= r["steps"] and r["upload_ms"]["host_to_device"] > 0 and r["upload_ms"]["device_side"] > 0
+
+
+@pytest.mark.gpu
+def test_scan_time_depth_filter_is_invisible_and_really_filters(pkg):
+    """Round 6: in depth-tested frames of clouds below 2^23 splats the nine spare bits of a list entry's splat index carry a coarse window
+    depth (gsr_zq), and a tile drops, while it scans, the entries behind everything the opaque pass left under its live pixels.  The
+    codes are a monotone lower bound, so nothing that could contribute is dropped: frames are bit-identical with the codes off
+    (GSR_FLAG_NO_ZCODES = 64) -- and the blend kernel gathers far fewer records under an occluder.  The list read-back masks the bits."""
+    E = pkg.engine
+    splats = pkg.scenes.make_scene(400000, seed=91, sh=True)
+    w, h = 1280, 720
+    cams = [pkg.camera.make_camera(w, h, sh_order=2, frame=i) for i in range(8)]
+    q = _zwin_quantiles(cams[0], splats.P, (0.1, 0.3))
+    depths = {"sphere": pkg.scenes.sphere_occluder_depth(cams[0], 3.42, 0.645),
+              "wall": np.full((h, w), q[1], np.float32),
+              "half": np.where(np.arange(w)[None, :] < w // 2, np.float32(q[0]), np.float32(1.0)).repeat(h, 0).astype(np.float32)}
+    on, off = pkg.Engine(0), pkg.Engine(0)
+    try:
+        off.set_option(E.OPT_DEBUG_FLAGS, 64)
+        on.upload(splats); off.upload(splats)
+        for name, d in depths.items():
+            g_on = g_off = 0
+            for k, c in enumerate(cams):
+                a, b = on.render_depth(c, d), off.render_depth(c, d)
+                assert np.array_equal(a, b, equal_nan=True), f"{name} frame {k}: the depth codes changed a pixel"
+                if k >= 3:       # (the first frames of a buffer run without codes: the library has not seen geometry in it yet)
+                    g_on += on.stats()["pairs_consumed"]; g_off += off.stats()["pairs_consumed"]
+            assert on.stats()["n_visible"] == off.stats()["n_visible"]
+            # (under a flat wall K1's own test against the tile-max depth is exact: nothing is left to filter.  Under a curved surface it is not)
+            assert g_on <= g_off and (name != "sphere" or g_on < 0.8 * g_off), (name, g_on, g_off)
+        # the debug read-back of the lists hands out splat indices, not index words
+        on.render_depth(cams[0], depths["sphere"]); off.render_depth(cams[0], depths["sphere"])
+        la = on.debug_tile_lists()
+        assert la[2].size > 0 and 0 <= int(la[2].min()) and int(la[2].max()) < splats.P.shape[0]
+    finally:
+        on.close(); off.close()

@@ -17,5 +17,6 @@ cp "$(find /tmp/rp_$TAG -name '*kernel_stats*' -printf '%s %p\n' | sort -n | tai
 find /tmp/rp_$TAG -name '*domain_stats*' -exec cp {} "$OUT/domain_stats.csv" \;
 T=$(find /tmp/rp_$TAG -name '*kernel_trace.csv' -printf '%s %p\n' | sort -n | tail -1 | cut -d' ' -f2)   # (the largest: bench.py's own process, not the HBM micro-benchmark it spawns)
 [ -n "$T" ] && python tools/frame_timeline.py "$T" median > "$OUT/frame_timeline.txt" 2>&1   # (the frame of median period among the last 40)
+[ -n "$T" ] && python tools/frame_timeline.py "$T" --gaps > "$OUT/launch_gaps.txt" 2>&1   # (idle time in front of every kernel, over the whole trace)
 ls -la /tmp/rp_$TAG/* | head
 head -30 "$OUT/kernel_stats.csv"

@@ -519,6 +519,26 @@ def main_single_process(args):
         sys.exit(4)
 
 
+def host_target_leg(eng, cam_structs, W, H):
+    """frames/s with a HOST target (pageable, re-used): the library composites in bands of tile rows and copies each band back while the
+    next ones composite (GSR_HOST_BANDS, default 4)"""
+    import numpy as _np
+    buf = _np.zeros((H, W, 4), _np.float32)
+    n = len(cam_structs)
+    warm = min(10, n // 3)
+    for c in cam_structs[:warm]:
+        eng.render_struct_to_host(c, buf.ctypes.data)
+    t0 = time.perf_counter()
+    for c in cam_structs[warm:]:
+        eng.render_struct_to_host(c, buf.ctypes.data)
+    dt = (time.perf_counter() - t0) / (n - warm)
+    mb = W * H * 16 / 1e6
+    return {"value": 1.0 / dt, "unit": "frames/sec", "ms_per_step": dt * 1e3, "steps": n - warm, "bytes_back_per_frame": W * H * 16,
+            "link_GBps_incl_render": mb / 1e3 / dt, "bands": int(os.environ.get("GSR_HOST_BANDS", "4")),
+            "note": "gsr_render with a host pointer (pageable numpy array, re-used): PCIe-inclusive, never `value`; the floor is the link: "
+                    "%.1f MB per frame" % mb}
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.via_multi):
@@ -988,9 +1008,15 @@ def main():
             other[oc] = {"value": 1.0 / odt, "unit": "frames/sec", "ms_per_step": odt * 1e3, "steps": 100, "n_splats": int(osp.n),
                          "width": oW, "height": oH, "regime": oreg, "frames_culled": ost["frames_culled"], "frames_slab": ost["frames_slab"],
                          "frames_repaired": ost["frames_repaired"], "n_visible": ost["n_visible"], "pairs": ost["pairs_total"]}
+            if oc == "C5":
+                other[oc]["host_target"] = host_target_leg(oe, ocams, oW, oH)
             oe.close()
             del oband, osp
             torch.cuda.empty_cache()
+    # extra leg: the PCIe-inclusive rate -- gsr_render into a HOST buffer, what a caller without GL interop gets (never `value`)
+    host_leg = None
+    if world == 1 and not args.no_extra_legs and args.emulate_shard <= 1 and not args.via_multi:
+        host_leg = host_target_leg(eng, cams[:min(len(cams), 50)], W, H)
     # blend-kernel roofline, measured with HIP events on the kernel's own stream
     shards = args.emulate_shard if (world == 1 and args.emulate_shard > 1) else world
     srank = (args.emulate_rank % shards) if (world == 1 and args.emulate_shard > 1) else rank
@@ -1080,6 +1106,8 @@ def main():
                                           "no place in the sort and the lists; every culled frame verifies itself and is rendered again without culling if a horizon "
                                           "broke (frames_repaired; those frames are inside the timed region)"},
         }
+        if host_leg is not None:
+            line["host_target"] = host_leg
         if depth_leg is not None:
             line["depth_tested"] = depth_leg
         if shim_leg is not None:

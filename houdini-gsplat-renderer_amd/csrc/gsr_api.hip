@@ -46,6 +46,7 @@ static_assert(RS_SRC_BLOCK == GSR_K1_THREADS, "the gathering sort pass reads K1'
 #define GSR_VERSION_STR "gsplat_hip 0.1.0 (gfx950)"
 #define GSR_MAX_SLOTS 2
 #define GSR_STAGE_EVENTS 7
+#define GSR_HOST_BANDS_MAX 8
 #ifndef GSR_SPIN_US
 #define GSR_SPIN_US 2000         // how long a host wait for a mailbox word spins before it blocks in the runtime
 #endif
@@ -131,6 +132,10 @@ struct FrameSlot {
                                        // frames the context's PUBLIC stream itself (no hand-over events at all)
     hipEvent_t ev_done = nullptr;      // end of the frame on `stream`
     hipEvent_t ev_user = nullptr;      // caller's stream position at gsr_render entry
+    // host-target frames: the blend launch in bands of tile rows, each band's rows copied back while the next ones composite
+    hipEvent_t ev_band[GSR_HOST_BANDS_MAX] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int bands = 0;                     // bands of the frame's last blend launch (0 / 1: one launch, one copy)
+    int band_row[GSR_HOST_BANDS_MAX + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev_pairs = nullptr;     // the frame's pair count has reached host memory
     // per-splat frame buffers
     GsrRecord* rec = nullptr;
@@ -282,6 +287,8 @@ struct gsr_context {
     int opt_order_keep = 32;           // (A/B hook, GSR_ORDER_KEEP in the environment: 0 = no tile order where the tiles are alike)
     int opt_fuse_order = 1;            // (A/B hook, GSR_FUSE_ORDER) the tile order is built in the frame-end launch instead of behind it
     int opt_mid_sort = 1;              // (A/B hook, GSR_MID_SORT) RS_ITEMS_MID keys per thread in the global sort passes of mid-size frames
+    int opt_host_bands = 4;            // (A/B hook, GSR_HOST_BANDS) host-target frames: bands of tile rows whose copy-back overlaps the compositing of the next (1: off)
+    hipStream_t copy_stream = nullptr; // ... and the stream the copies run on
     int opt_k1_scatter = 1;            // (A/B hook, GSR_K1_SCATTER) the small-frame sort's bucket pass inside K1 (0: a kernel of its own behind it)
     int opt_scatter_direct = 1;        // (A/B hook, GSR_SCATTER_DIRECT in the environment) the small-frame sort's scatter: one workgroup per K1 block
     int opt_bn_items = 0;              // (A/B hook, GSR_BN_ITEMS in the environment: 1, 2 or 4 splats per binning thread; 0 = by frame size)
@@ -488,6 +495,7 @@ static void slot_destroy(FrameSlot& sl)
             if (sl.ev[k]) (void)hipEventDestroy(sl.ev[k]);
     if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
     if (sl.ev_user) (void)hipEventDestroy(sl.ev_user);
+    for (int k = 0; k < GSR_HOST_BANDS_MAX; ++k) if (sl.ev_band[k]) (void)hipEventDestroy(sl.ev_band[k]);
     if (sl.ev_pairs) (void)hipEventDestroy(sl.ev_pairs);
     if (sl.own) (void)hipStreamDestroy(sl.own);
 }
@@ -506,6 +514,7 @@ extern "C" int gsr_create(int device, gsr_context** out)
     if (const char* e = std::getenv("GSR_ORDER_KEEP")) c->opt_order_keep = std::atoi(e);   // (A/B hook)
     if (const char* e = std::getenv("GSR_SCATTER_DIRECT")) c->opt_scatter_direct = std::atoi(e);   // (A/B hook: -1 the general scatter, 0 never direct, 1 direct by frame size, 2 always direct)
     if (const char* e = std::getenv("GSR_K1_SCATTER")) c->opt_k1_scatter = std::atoi(e);   // (A/B hook)
+    if (const char* e = std::getenv("GSR_HOST_BANDS")) c->opt_host_bands = std::min(std::max(std::atoi(e), 1), GSR_HOST_BANDS_MAX);   // (A/B hook)
     if (const char* e = std::getenv("GSR_MID_SORT")) c->opt_mid_sort = std::atoi(e);       // (A/B hook)
     if (const char* e = std::getenv("GSR_FUSE_ORDER")) c->opt_fuse_order = std::atoi(e);   // (A/B hook)
     if (const char* e = std::getenv("GSR_SLAB_FRAC")) { const int v = std::atoi(e); if (v >= 1 && v <= 255) c->slab_frac = v; }   // (A/B hook)
@@ -559,6 +568,7 @@ extern "C" void gsr_destroy(gsr_context* c)
     dev_free(c->prefix); dev_free(c->prefix_all); dev_free(c->prefix_none); dev_free(c->lazy_hint);
     dev_free(c->pos_order); dev_free(c->blk_pre);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
 }
 
@@ -1366,19 +1376,35 @@ static int queue_blend(gsr_context* c, FrameSlot& sl, bool with_depth, bool guar
         lz.redo = j.lazy ? sl.redo : nullptr;
         lz.redo_count = reinterpret_cast<uint32_t*>(sl.lazy_ctr);
         float4* tgt = reinterpret_cast<float4*>(j.target);
-        if (with_depth)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<true>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
-                               sl.send, sl.rec, tgt, tw, sl.zwin, j.d_depth, lz);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
-                               sl.send, sl.rec, tgt, tw, sl.zwin, j.d_depth, lz);
-        if (j.lazy) {   // the tiles that met a pending colour, with on-demand evaluation (normally none: the blocks exit at once)
+        // Host-target frames (a caller without GL interop): the frame's LAST blend launch is issued band by band of tile rows, an event
+        // behind each, and queue_frame_end copies a band's rows back on a second stream as soon as its event fires: all but the first
+        // band's compositing hides behind the link, which is what bounds such a frame (33 MB at ~55 GB/s = 0.6 ms per 1080p frame).
+        // The launches walk the same tile table; a workgroup of another band's tile leaves at once (~3 us per extra launch).
+        int nb = 1;
+        if (!j.out_is_device && j.phase != 1 && c->opt_host_bands > 1 && c->shard_count == 1 && f.local_tiles_y >= 4 * c->opt_host_bands) nb = c->opt_host_bands;
+        if (nb > 1 && !c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { c->copy_stream = nullptr; nb = 1; (void)hipGetLastError(); }
+        for (int b = 0; b < nb && nb > 1; ++b)
+            if (!sl.ev_band[b] && hipEventCreateWithFlags(&sl.ev_band[b], hipEventDisableTiming) != hipSuccess) { sl.ev_band[b] = nullptr; nb = 1; (void)hipGetLastError(); }
+        sl.bands = nb;
+        for (int b = 0; b < nb; ++b) {
+            a.row_lo = nb > 1 ? (int)((int64_t)f.local_tiles_y * b / nb) : 0;
+            a.row_hi = nb > 1 ? (int)((int64_t)f.local_tiles_y * (b + 1) / nb) : 0x7fffffff;
+            sl.band_row[b] = a.row_lo; sl.band_row[b + 1] = nb > 1 ? a.row_hi : f.local_tiles_y;
             if (with_depth)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<true>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
-                                   sl.pvA, sl.sstart, sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<true>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
+                                   sl.send, sl.rec, tgt, tw, sl.zwin, j.d_depth, lz);
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<false>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
-                                   sl.pvA, sl.sstart, sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend<false>), dim3(grid), dim3(256), 0, s, a, tmap, sl.pvA, sl.sstart,
+                                   sl.send, sl.rec, tgt, tw, sl.zwin, j.d_depth, lz);
+            if (j.lazy) {   // the tiles that met a pending colour, with on-demand evaluation (normally none: the blocks exit at once)
+                if (with_depth)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<true>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
+                                       sl.pvA, sl.sstart, sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_blend_lazy<false>), dim3((unsigned)j.local_tiles), dim3(256), 0, s, a, c->tile_map,
+                                       sl.pvA, sl.sstart, sl.send, sl.rec, tgt, sl.tile_work, sl.zwin, j.d_depth, lz);
+            }
+            if (nb > 1) HIP_TRY(hipEventRecord(sl.ev_band[b], s));
         }
         HIP_TRY(hipGetLastError());
     }
@@ -1528,8 +1554,21 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
     sl.last_lazy = j.lazy;
     if (j.timing) { sl.ev_pending = true; sl.ev_all = j.timing_all; }
     if (!j.out_is_device) {
-        HIP_TRY(hipMemcpyAsync(j.user_out, sl.fb, j.out_px * 16, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        if (sl.bands > 1 && c->copy_stream) {
+            // (band by band behind the blend launches' events, on a stream of their own: k_tile_pass and the frame end run beside the copies)
+            for (int b = 0; b < sl.bands; ++b) {
+                const size_t r0 = std::min<size_t>((size_t)sl.band_row[b] * GSR_TILE, (size_t)j.band_rows), r1 = std::min<size_t>((size_t)sl.band_row[b + 1] * GSR_TILE, (size_t)j.band_rows);
+                if (r1 <= r0) continue;
+                const size_t off = r0 * (size_t)j.f.width * 4;
+                HIP_TRY(hipStreamWaitEvent(c->copy_stream, sl.ev_band[b], 0));
+                HIP_TRY(hipMemcpyAsync(j.user_out + off, sl.fb + off, (r1 - r0) * (size_t)j.f.width * 16, hipMemcpyDeviceToHost, c->copy_stream));
+            }
+            HIP_TRY(hipStreamSynchronize(c->copy_stream));
+            HIP_TRY(hipStreamSynchronize(s));
+        } else {
+            HIP_TRY(hipMemcpyAsync(j.user_out, sl.fb, j.out_px * 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
     }
     // results are ordered on the public stream: anything the caller queues there next sees this frame
     if (!j.direct) {

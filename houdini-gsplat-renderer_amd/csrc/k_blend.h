@@ -102,6 +102,10 @@ struct GsrBlendArgs {
     uint32_t idx_mask;
     float zq0, zqs;
     const float* tile_dmax;     // NULL: no scan-time depth filter
+    // Host-target frames (gsr_api.hip: queue_blend): the launch is issued once per BAND of tile rows, each followed by the copy of its
+    // rows back to the host on a second stream, so that all but the first band's compositing hides behind the link.  A workgroup whose
+    // tile row (local) is outside [row_lo, row_hi) leaves at once.
+    int32_t row_lo, row_hi;
 };
 
 // Staging layout: one list PER QUADRANT (= per wave), holding the round's records that reach that
@@ -168,6 +172,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     }
 #endif
     if (tile < 0 || tile >= a.local_tiles) return;
+    { const int row = tile / a.tiles_x; if (row < a.row_lo || row >= a.row_hi) return; }
     const uint32_t guard_now = a.guard ? *a.guard : 0u;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef BL_PROFILE

@@ -444,6 +444,10 @@ class Engine:
     def render_struct_to_device(self, cam_struct: gsr_camera, device_ptr: int):
         _check(self.L.gsr_render(self.h, C.byref(cam_struct), C.c_void_p(device_ptr), 1))
 
+    def render_struct_to_host(self, cam_struct: gsr_camera, host_ptr: int):
+        """gsr_render into a HOST buffer of height x width x 4 floats (what a caller without GL interop hands over)"""
+        _check(self.L.gsr_render(self.h, C.byref(cam_struct), C.c_void_p(host_ptr), 0))
+
     def render_struct_depth_to_device(self, cam_struct: gsr_camera, depth_device_ptr: int, device_ptr: int):
         """depth-tested frame, both buffers in device memory: what the viewport hook issues on every redraw (hdk/DM_GSplatHook_hip.C)"""
         _check(self.L.gsr_render_depth(self.h, C.byref(cam_struct), C.c_void_p(depth_device_ptr), 1, C.c_void_p(device_ptr), 1))

@@ -2271,3 +2271,37 @@ def test_scan_time_depth_filter_is_invisible_and_really_filters(pkg):
         assert la[2].size > 0 and 0 <= int(la[2].min()) and int(la[2].max()) < splats.P.shape[0]
     finally:
         on.close(); off.close()
+
+
+@pytest.mark.gpu
+def test_host_target_frames_in_bands_are_the_same_frames(pkg, monkeypatch):
+    """Round 6: a frame rendered into a HOST buffer is composited in bands of tile rows (the blend launch once per band, a workgroup of another
+    band's tile leaving at once) and each band's rows are copied back on a second stream while the next ones composite.  Same pixels as
+    the one-launch, one-copy form (GSR_HOST_BANDS=1), in every regime: temporal culling, front-slab frames, one-pass frames with lazy colour
+    (the fallback kernel runs per band too), depth-tested frames (the guarded plain kernel and its re-queue), odd framebuffer heights."""
+    E = pkg.engine
+    splats = pkg.scenes.make_scene(250000, seed=5, sh=True)
+    monkeypatch.setenv("GSR_HOST_BANDS", "1")
+    one = pkg.Engine(0)
+    monkeypatch.setenv("GSR_HOST_BANDS", "4")
+    four = pkg.Engine(0)
+    monkeypatch.setenv("GSR_HOST_BANDS", "7")
+    seven = pkg.Engine(0)
+    try:
+        for e in (one, four, seven):
+            e.upload(splats)
+        for (w, h) in ((1280, 720), (1001, 517), (640, 1100)):
+            cams = [pkg.camera.make_camera(w, h, sh_order=3, frame=i) for i in (0, 1, 2, 3, 40, 41)]
+            sphere = pkg.scenes.sphere_occluder_depth(cams[0], 3.42, 0.645)
+            far = np.ones((h, w), np.float32)
+            for mode in ((1, 1), (3, 2), (0, 0)):
+                for e in (one, four, seven):
+                    e.set_option(E.OPT_OCCLUSION_CULL, mode[0]); e.set_option(E.OPT_FRONT_SLAB, mode[1])
+                for k, c in enumerate(cams):
+                    ref = one.render(c)
+                    assert np.array_equal(ref, four.render(c)) and np.array_equal(ref, seven.render(c)), f"{w}x{h} mode {mode} frame {k}"
+                for k, (c, d) in enumerate(zip(cams, (far, far, sphere, sphere, far, sphere))):
+                    ref = one.render_depth(c, d)
+                    assert np.array_equal(ref, four.render_depth(c, d)) and np.array_equal(ref, seven.render_depth(c, d)), f"{w}x{h} mode {mode} depth frame {k}"
+    finally:
+        one.close(); four.close(); seven.close()

@@ -1426,7 +1426,7 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
         // (+ the extra work items of the blocks that are split by rows of super-tiles, k_binning.h; +1: the publishing workgroup)
         const uint32_t bn_extra = (uint32_t)BN_SPLIT_TILES * (uint32_t)std::max(f.stiles_y - 1, 0);
         const uint32_t grid = std::min(nblk, j.bn_grid) + bn_extra + (j.ranges_folded ? 1u : 0u);
-#define GSR_PLACE(I) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin_place<I>), dim3(grid), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n,          \
+#define GSR_PLACE(I) hipLaunchKernelGGL((f.idx_mask != 0xffffffffu ? k_bin_place<I, true> : k_bin_place<I, false>), dim3(grid), dim3(BN_THREADS), lds, s, sl.valA, sl.d_n,          \
                                         f.super_shift - f.rect_shift, shd, f.stiles_x, j.n_super, sl.hist, sl.sstart, nblk, (uint32_t)sl.pair_cap, sl.pvA, ra,   \
                                         f.idx_mask != 0xffffffffu ? sl.zwin : (const float*)nullptr, f.zq0, f.zqs)
         if (j.bn_items == 1) GSR_PLACE(1); else if (j.bn_items == 2) GSR_PLACE(2); else GSR_PLACE(4);
@@ -1445,7 +1445,8 @@ static int queue_back_end(gsr_context* c, FrameSlot& sl)
     if ((rc = mark(sl, 5))) return rc;
     // Depth-tested frames: the plain kernel, guarded, while the slot's depth buffers have been clear (k_blend.h: GsrBlendArgs.guard);
     // not for a frame that is handed over before its mailbox is read (nobody could queue the other kernel in time)
-    sl.job.blend_guess_plain = j.d_depth != nullptr && j.dcull && !c->depth_active && !j.deferred;
+    // (... nor over lists whose index words carry depth codes: only the depth-tested kernel masks them off)
+    sl.job.blend_guess_plain = j.d_depth != nullptr && j.dcull && !c->depth_active && !j.deferred && j.f.idx_mask == 0xffffffffu;
     if ((rc = queue_blend(c, sl, j.d_depth != nullptr && !sl.job.blend_guess_plain, sl.job.blend_guess_plain))) return rc;
     return mark(sl, 6);
 }
@@ -2159,13 +2160,13 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
                 return frame_abort(sl, set_err(GSR_E_HIP, "gsr_render: clearing the slab histogram failed"));
             sl.slab_dirty = true;
             const int n45 = gsr_pyr_dim(f.tiles_x, 4) * gsr_pyr_dim(f.tiles_y, 4) + gsr_pyr_dim(f.tiles_x, 5) * gsr_pyr_dim(f.tiles_y, 5);
-            hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups + n_dp), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, c->opt_cluster,
+            hipLaunchKernelGGL(j.dcull ? k_cluster_cull<true> : k_cluster_cull<false>, dim3(ngroups + n_dp), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, c->opt_cluster,
                                (const float*)nullptr, sl.cseg, sl.ccnt, 1, sl.slab, hist_shift, sl.slab + GSR_SLAB_BINS, pk, sl.hpyr2 + f.pyr_off[4], n45,
                                (uint32_t*)nullptr, (uint32_t*)nullptr, dp, n_dp, dc_clus);
             if (n_dp) { n_dp = 0; if (c->opt_cluster) dc_clus = dc_k1; }   // (built: the pass below may use it)
         }
         if (j.phase == 2) sl.slab_dirty = false;   // (mode 3 below clears the histogram for the slot's next front-slab frame)
-        hipLaunchKernelGGL(k_cluster_cull, dim3(ngroups + n_dp), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, ordered ? 0 : c->opt_cluster,
+        hipLaunchKernelGGL(j.dcull ? k_cluster_cull<true> : k_cluster_cull<false>, dim3(ngroups + n_dp), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, ordered ? 0 : c->opt_cluster,
                            pyr, sl.cseg, sl.ccnt,   // (ordered: slots, not clusters -- all of them)
                            j.phase == 1 ? 2 : (j.phase == 2 ? 3 : 0), sl.slab, hist_shift, sl.slab + GSR_SLAB_BINS, pk, (float*)nullptr, 0,
                            (local || local_phase) ? sl.bkt_cnt : (uint32_t*)nullptr, sl.d_counts + 2, dp, n_dp, dc_clus);

@@ -266,7 +266,7 @@ k_bin_ranges(GsrRangeArgs a)
 // Dynamic LDS: lmask[4 * ITEMS groups][ns] (u64) followed by gpre[4 * ITEMS][ns] (u32), ns = n_super.
 // ranges.totals != NULL: the list ranges are formed HERE (every workgroup scans the 256 totals itself; the last one also writes
 // them out and posts the pair count) instead of by a k_bin_ranges launch in front: one launch floor less per frame.
-template <int ITEMS>
+template <int ITEMS, bool ZQ>
 __global__ void __launch_bounds__(BN_THREADS)
 k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev, int shift, GsrShard sh,
             int stiles_x, int ns, const uint32_t* __restrict__ offs, const int32_t* __restrict__ sstart,
@@ -320,7 +320,7 @@ k_bin_place(const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_dev
         const uint32_t i = first + (uint32_t)grp * 64u + (threadIdx.x & 63u);
         v[k] = (i < n) ? sorted[i] : make_uint2(0u, GSR_RECT_EMPTY);
         // (depth-tested frames: the coarse window depth goes into the index word's spare bits -- GsrFrame.idx_mask; the load is not needed before (B))
-        if (zwin != nullptr && i < n) v[k].x |= gsr_zq(zwin[v[k].x], zq0, zqs) << GSR_ZQ_SHIFT;
+        if (ZQ && i < n) v[k].x |= gsr_zq(zwin[v[k].x], zq0, zqs) << GSR_ZQ_SHIFT;
         bn_group_pairs(v[k], shift, sh, stiles_x, part.row_lo, part.row_hi,
                        [&](int L, uint2, uint32_t d, int, int) { if (d < (uint32_t)ns) atomicOr(&lmask[grp * ns + d], 1ull << L); });
     }

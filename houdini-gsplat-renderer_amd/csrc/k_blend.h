@@ -172,8 +172,10 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     }
 #endif
     if (tile < 0 || tile >= a.local_tiles) return;
-    { const int row = tile / a.tiles_x; if (row < a.row_lo || row >= a.row_hi) return; }
-    const uint32_t guard_now = a.guard ? *a.guard : 0u;
+    if (a.row_hi != 0x7fffffff) { const int row = tile / a.tiles_x; if (row < a.row_lo || row >= a.row_hi) return; }   // (banded launches only)
+    // (a guarded launch: the word is requested here and looked at once, below, where the list's bounds -- requested at the same time -- are
+    //  needed anyway.  Looked at INSIDE the loop, as at first, it cost every launch 4 us: a scalar load waits on the counter the LDS shares)
+    const uint32_t guard_now = (!HAS_DEPTH && a.guard) ? *a.guard : 0u;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef BL_PROFILE
     unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -219,6 +221,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     const int s = sstart[st];
     const int e_ = send[st] < a.list_cap ? send[st] : a.list_cap;
     const int n = e_ > s ? e_ - s : 0;
+    if (!HAS_DEPTH && a.guard && (guard_now != 0u) != (a.guard_want != 0u)) return;   // (uniform) a void launch: the other kernel draws this frame
 
     gsr_v2f C01 = {0.0f, 0.0f};   // {C0, C1} as a register pair
     float C2 = 0.0f, T = 1.0f;    // blue, transmittance 1 - A
@@ -226,7 +229,6 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     if (a.slab == 2) {
         // front-slab phase 2: finished tiles keep what they have; the others go on from the stored colour and transmittance
         const uint4 wa = a.tile_work_a[tile];
-        if (a.guard && (guard_now != 0u) != (a.guard_want != 0u)) return;
         if (wa.w & 1u) {
             if (tid == 0) tile_work[tile] = make_uint4(0u, 0u, 0u, 1u | 0x8000u | (0xffffu << 16));
             return;
@@ -259,6 +261,10 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
     uint32_t zlim = 0xffffffffu;
     const bool zfilter = HAS_DEPTH && a.tile_dmax != nullptr && a.idx_mask != 0xffffffffu && !tile_plain && !(a.flags & GSR_FLAG_NO_DEPTH_CLASS);
     if (zfilter) zlim = (gsr_zq(a.tile_dmax[gty * a.tiles_x + tx], a.zq0, a.zqs) << GSR_ZQ_SHIFT) | a.idx_mask;
+    // (the depth bits of the index words: only lists of depth-tested frames carry any, and only the depth-tested kernel reads such lists --
+    //  gsr_api.hip: queue_back_end.  Held in a register: re-loaded from the kernel arguments inside the gather it cost 2 us per launch)
+    uint32_t imask = HAS_DEPTH ? a.idx_mask : 0xffffffffu;
+    if (HAS_DEPTH) asm volatile("" : "+s"(imask));
     const uint32_t sub_mask = (1u << a.super_shift) - 1u;
     const uint32_t tile_bits = (1u << ((tx & sub_mask) >> a.rect_shift)) | (0x10000u << ((gty & sub_mask) >> a.rect_shift));
     // thread t scans entries 4t .. 4t+3 of a 1024-entry step: two 16-byte loads, prefetched one step ahead
@@ -346,7 +352,6 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
         // the l-th hit, loads its record (the four waves load the same lines: L1 hits), tests it against THIS wave's 8x8
         // quadrant only, and the surviving records go -- still in depth order, by ballot rank -- into the wave's own LDS list.
         // No other wave reads that list, so nothing between here and the end of the batch needs a workgroup barrier.
-        if (round == 0 && a.guard && (guard_now != 0u) != (a.guard_want != 0u)) return;   // (uniform) a void launch: the other kernel draws this frame
         const int avail = (int)(q_tail - q_head);
         const int take = avail < batch ? avail : batch;
         if (take == 0) break;                         // list exhausted and queue empty
@@ -374,7 +379,7 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                 float rz = 0.0f, c0 = 0.0f, c1 = 0.0f;
                 bool hit = false, pending = false, dtest = false, dmet_l = false;
                 if (have) {
-                    const uint32_t ridx = q[(q_head + (uint32_t)(sub + lane)) & (BL_QCAP - 1)] & a.idx_mask;
+                    const uint32_t ridx = q[(q_head + (uint32_t)(sub + lane)) & (BL_QCAP - 1)] & imask;
                     const float4* p = reinterpret_cast<const float4*>(recs + ridx);
                     const float4 r0 = p[0];
                     r1 = p[1]; r2 = p[2];
@@ -432,7 +437,10 @@ gsr_blend_tile(const GsrBlendArgs& a, const int32_t* __restrict__ tile_map, cons
                     blk[9] = 0.0f; blk[11] = 0.0f;
                     // colour 0, la -inf (the axes may be stale garbage: a NaN there is rejected by the quad test)
                     {   // (volatile scalar stores: as one float4 constant the compiler kept it live across the whole kernel -- and spilt it)
-                        volatile float* vb = blk;
+                        // (... and through an LDS pointer: a volatile store through a GENERIC one is a flat_store + s_waitcnt each -- round 6 shipped
+                        //  that for half a day: +5 % on the plain kernel, found in an A/B against round 5's tree on one box)
+                        typedef volatile __attribute__((address_space(3))) float lds_vfloat;
+                        lds_vfloat* vb = (lds_vfloat*)blk;
                         vb[16] = 0.0f; vb[17] = 0.0f; vb[18] = 0.0f; vb[19] = -__builtin_inff();
                     }
                     if (HAS_DEPTH) reinterpret_cast<float*>(&szl[wave][cnt >> 1])[1] = 0.0f;

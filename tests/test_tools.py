@@ -99,8 +99,8 @@ def test_frame_kernels_keep_their_register_and_scratch_budgets():
         hit = [v for k, v in rows.items() if k.startswith(prefix)]
         assert len(hit) == 1, (prefix, [k for k in rows if k.startswith(prefix)])
         return hit[0]
-    frame_kernels = ["_Z14k_cluster_cull", "_Z17k_preprocess_lazyjj", "_Z18k_preprocess_depth", "_Z23k_preprocess_lazy_depth", "_Z15k_depth_pyramid",
-                     "_Z13k_radix_localI15HIP", "_Z11k_bin_countILi2E", "_Z11k_bin_placeILi2E", "_Z11k_scan_rows", "_Z7k_blendILb0E", "_Z7k_blendILb1E",
+    frame_kernels = ["_Z14k_cluster_cullILb0E", "_Z14k_cluster_cullILb1E", "_Z17k_preprocess_lazyjj", "_Z18k_preprocess_depth", "_Z23k_preprocess_lazy_depth", "_Z15k_depth_pyramid",
+                     "_Z13k_radix_localI15HIP", "_Z11k_bin_countILi2E", "_Z11k_bin_placeILi2ELb0E", "_Z11k_bin_placeILi2ELb1E", "_Z11k_scan_rows", "_Z7k_blendILb0E", "_Z7k_blendILb1E",
                      "_Z11k_tile_pass", "_Z11k_frame_end", "_Z17k_frame_end_order", "_Z10k_slab_mid", "_Z15k_colour_prefix", "_Z6k_packILb1E"]
     for k in frame_kernels:
         vg, sg, lds, scratch = find(k)

@@ -150,6 +150,7 @@ struct FrameSlot {
     size_t dpyr_cap = 0;               // frame parity: [par][which], dpyr_cap floats each
     uint32_t* dactive = nullptr;       // [2] by parity: "some tile's largest depth is below 1" (something can be culled)
     int dpar = 0;                      // parity of the slot's last depth-tested frame
+    bool dpyr_built = false;           // the pyramids of parity `dpar` hold this frame's depth buffer (a frame that only LOOKED for covered pixels has none)
     bool sorted_dculled = false;       // the cached depth order holds a frame that was culled against its depth buffer
     // scan / sort scratch
     uint32_t* hist = nullptr;
@@ -1356,9 +1357,9 @@ static int queue_blend(gsr_context* c, FrameSlot& sl, bool with_depth, bool guar
             a.near_alpha = persp ? 0.5f * (1.0f - f.pr[10]) : 0.0f;
             a.near_scale = persp ? 1.12f : 0.0f;
         }
-        a.tile_cov = (with_depth && j.dcull) ? sl.dpyr + 4 * sl.dpyr_cap : (const float*)nullptr;
+        a.tile_cov = (with_depth && j.dcull && !j.dblind) ? sl.dpyr + 4 * sl.dpyr_cap : (const float*)nullptr;
         a.idx_mask = f.idx_mask; a.zq0 = f.zq0; a.zqs = f.zqs;
-        a.tile_dmax = (with_depth && j.dcull && f.idx_mask != 0xffffffffu) ? sl.dpyr + (size_t)(2 * j.dpar) * sl.dpyr_cap + f.pyr_off[0] : (const float*)nullptr;
+        a.tile_dmax = (with_depth && j.dcull && !j.dblind && f.idx_mask != 0xffffffffu) ? sl.dpyr + (size_t)(2 * j.dpar) * sl.dpyr_cap + f.pyr_off[0] : (const float*)nullptr;
         a.width = f.width; a.height = f.height; a.tiles_x = f.tiles_x; a.local_tiles = j.local_tiles;
         a.shard = GsrShard{f.shard_index, f.shard_count, f.shard_rpb}; a.band_rows = j.band_rows;
         a.super_shift = f.super_shift; a.rect_shift = f.rect_shift; a.stiles_x = f.stiles_x; a.use_map = j.use_map ? 1 : 0; a.flags = f.flags;
@@ -1473,7 +1474,7 @@ static int queue_frame_end(gsr_context* c, FrameSlot& sl)
         //  tile classic: the sign bits of its raw horizons are clear)
         hz.stat = sl.hstat;
         hz.stat_in_use = (j.cull && j.dcull && j.dstat) ? 1 : 0;
-        hz.depth_culled = j.dcull ? 1 : 0;
+        hz.depth_culled = (j.dcull && !j.dblind) ? 1 : 0;
         hz.idx_mask = j.f.idx_mask;
         static const bool dbgv = std::getenv("GSR_DEBUG_VIOL") != nullptr;
         if (dbgv) {
@@ -2120,10 +2121,11 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
         const int hist_shift = key_bits > 10 ? key_bits - 10 : 0;
         const float* pyr = j.phase == 2 ? sl.hpyr2 : ((j.cull && !ordered) ? sl.hpyr : (const float*)nullptr);
         const GsrSlabPick pk{(uint32_t)c->slab_min, (uint32_t)c->slab_max, (uint32_t)c->slab_frac, f.key_max - f.key_min};
-        // depth-tested frames: the opaque pass's tile-max depth pyramid.  Where the previous depth-tested frame found opaque geometry in
-        // its buffer, in a launch of its own in front of everything (k_cluster_cull then culls against it too); otherwise -- a buffer
-        // cleared to the far plane, the common case -- beside the cluster tests, as the first workgroups of k_cluster_cull's launch, for
-        // K1 alone.  Whatever the guess, the pixels are the same: the tests are conservative and k_blend compares every fragment.
+        // depth-tested frames: the opaque pass's tile-max depth pyramid -- where the previous depth-tested frame found opaque geometry in
+        // its buffer, in a launch of its own in front of everything (k_cluster_cull and K1 cull against it); otherwise -- a buffer
+        // cleared to the far plane, the common case -- NO pyramid: the first workgroups of k_cluster_cull's launch only look whether a
+        // pixel is covered at all (k_cluster.h: gsr_depth_detect_block), and a frame in which geometry appears goes without depth culling.
+        // Whatever the guess, the pixels are the same: the tests are conservative and k_blend compares every fragment.
         GsrDepthPyrArgs dp{};
         uint32_t n_dp = 0;
         GsrDepthCull dc_clus{nullptr, nullptr, nullptr}, dc_k1{nullptr, nullptr, nullptr};
@@ -2131,6 +2133,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
             float* const dp0 = sl.dpyr + (size_t)(2 * j.dpar) * sl.dpyr_cap;
             float* const dq0 = sl.dpyr + (size_t)(2 * (j.dpar ^ 1)) * sl.dpyr_cap;
             dc_k1 = GsrDepthCull{dp0, j.phase == 2 ? (const float*)nullptr : dp0 + sl.dpyr_cap, sl.dactive + j.dpar};
+            if (j.phase == 2 && !sl.dpyr_built) { dc_k1 = GsrDepthCull{nullptr, nullptr, nullptr}; j.dblind = true; }   // (phase 1 built none)
             if (j.phase != 2) {
                 dp.depth = j.d_depth; dp.pyr = dp0; dp.pyrc = dp0 + sl.dpyr_cap; dp.pyr_next = dq0; dp.pyrc_next = dq0 + sl.dpyr_cap; dp.active = sl.dactive; dp.par = j.dpar;
                 dp.tcov = sl.dpyr + 4 * sl.dpyr_cap;
@@ -2145,11 +2148,16 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
                     //  count of finished pyramid workgroups before their depth tests: 3650 fps against 4245 -- LAB_NOTES.md)
                     hipLaunchKernelGGL(k_depth_pyramid, dim3(nb8), dim3(1024), 0, s, dp);
                     if (c->opt_cluster && !ordered) dc_clus = dc_k1;
+                    sl.dpyr_built = true;
                 } else {
-                    n_dp = nb8;
+                    (void)nb8;
+                    n_dp = (uint32_t)gsr_depth_detect_blocks(f.width, f.height);
                     j.dblind = true;
+                    j.dstat = false;
+                    sl.dpyr_built = false;
+                    dc_k1 = GsrDepthCull{nullptr, nullptr, nullptr};
                 }
-            } else if (c->opt_cluster) {
+            } else if (c->opt_cluster && sl.dpyr_built) {
                 dc_clus = dc_k1;       // (phase 1 built it)
             }
         }
@@ -2163,7 +2171,7 @@ static int frame_begin(gsr_context* c, const gsr_camera* cam, const float* depth
             hipLaunchKernelGGL(j.dcull ? k_cluster_cull<true> : k_cluster_cull<false>, dim3(ngroups + n_dp), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, c->opt_cluster,
                                (const float*)nullptr, sl.cseg, sl.ccnt, 1, sl.slab, hist_shift, sl.slab + GSR_SLAB_BINS, pk, sl.hpyr2 + f.pyr_off[4], n45,
                                (uint32_t*)nullptr, (uint32_t*)nullptr, dp, n_dp, dc_clus);
-            if (n_dp) { n_dp = 0; if (c->opt_cluster) dc_clus = dc_k1; }   // (built: the pass below may use it)
+            n_dp = 0;      // (looked at: not again in the pass below)
         }
         if (j.phase == 2) sl.slab_dirty = false;   // (mode 3 below clears the histogram for the slot's next front-slab frame)
         hipLaunchKernelGGL(j.dcull ? k_cluster_cull<true> : k_cluster_cull<false>, dim3(ngroups + n_dp), dim3(CC_THREADS), 0, s, f, c->clusA, c->clusB, c->nclus, rounds, ordered ? 0 : c->opt_cluster,

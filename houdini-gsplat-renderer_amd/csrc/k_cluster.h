@@ -233,6 +233,41 @@ __device__ __forceinline__ void gsr_depth_pyramid_block(const GsrDepthPyrArgs& a
         if (vc > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(a.pyrc) + o4, __float_as_uint(vc));
     }
 }
+// Frames whose previous depth buffer was CLEAR (the common case: a scene of splats only) do not build pyramids at all: if this buffer is
+// clear too nobody will read them -- every look-up is behind `active` -- so all the frame needs is that word: is any pixel covered?
+// 4096 pixels per workgroup of 256 threads, four 16-byte loads each, beside the cluster tests of the same launch (the pyramid blocks there
+// -- sixteen loads per thread, LDS, shuffles -- made that launch 1.5 us longer than a plain frame's).  If geometry has APPEARED, the word
+// says so, the frame goes on without depth culling (the depth-tested blend kernel compares every fragment anyway; a frame that was culled
+// against horizons is rendered again: gsr_api.hip) and the slot's next frame builds the pyramids in a launch of its own.
+__host__ __device__ __forceinline__ int gsr_depth_detect_blocks(int width, int height) { return (int)(((long long)width * height + 4095) / 4096); }
+__device__ __forceinline__ void gsr_depth_detect_block(const GsrDepthPyrArgs& a, const int b)
+{
+    const int tid = threadIdx.x;
+    if (b == 0) {      // (the parity hand-over of the full pass: gsr_depth_pyramid_block)
+        if (tid == 0) a.active[a.par ^ 1] = 0u;
+        const int n4 = gsr_pyr_dim(a.tiles_x, 4) * gsr_pyr_dim(a.tiles_y, 4);
+        for (int i = tid; i < n4; i += 256) { a.pyr_next[a.off[4] + i] = 0.0f; a.pyrc_next[a.off[4] + i] = 0.0f; }
+    }
+    const long long n = (long long)a.width * a.height;
+    const bool vec = (reinterpret_cast<uintptr_t>(a.depth) & 15u) == 0u;   // (uniform)
+    float4 q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = ((long long)b * 1024 + k * 256 + tid) * 4;
+        q[k] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        if (vec && i + 3 < n) q[k] = *reinterpret_cast<const float4*>(a.depth + i);
+        else {
+            if (i < n) q[k].x = a.depth[i];
+            if (i + 1 < n) q[k].y = a.depth[i + 1];
+            if (i + 2 < n) q[k].z = a.depth[i + 2];
+            if (i + 3 < n) q[k].w = a.depth[i + 3];
+        }
+    }
+    bool cov = false;          // (a NaN pixel counts as covered: it is not "cleared")
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cov = cov || !(q[k].x >= 1.0f) || !(q[k].y >= 1.0f) || !(q[k].z >= 1.0f) || !(q[k].w >= 1.0f);
+    if (__any(cov) && (tid & 63) == 0) atomicOr(&a.active[a.par], 1u);
+}
 // a launch of its own: frames whose previous depth buffer held opaque geometry (k_cluster_cull then culls against the pyramid too)
 __global__ void __launch_bounds__(1024)
 k_depth_pyramid(GsrDepthPyrArgs a) { gsr_depth_pyramid_block<1024>(a, (int)blockIdx.x); }
@@ -315,12 +350,12 @@ k_cluster_cull(GsrFrame f, const float4* __restrict__ clusA, const float4* __res
                uint32_t* __restrict__ bk_zero /* the small-frame sort's bucket counters (BK_BUCKETS, BK_STRIDE apart), or NULL */,
                uint32_t* __restrict__ flag_zero /* ... and its "gave a bucket up" flag: cleared here, BEFORE K1, whose workgroups scatter
                                                    into the buckets themselves */,
-               GsrDepthPyrArgs dp, uint32_t n_dp /* depth-tested frames: the FIRST n_dp workgroups build the opaque pass's tile-max pyramid
-                                                    for K1 (beside the cluster tests, not in front of them: no launch of its own) */,
+               GsrDepthPyrArgs dp, uint32_t n_dp /* depth-tested frames whose previous depth buffer was clear: the FIRST n_dp workgroups look
+                                                    whether this one holds a covered pixel (gsr_depth_detect_block) beside the cluster tests */,
                GsrDepthCull dc /* ... or the pyramid exists already (k_depth_pyramid ran in front): clusters are tested against it */)
 {
     static_assert(CC_THREADS == 256, "the folded depth pyramid workgroups are gsr_depth_pyramid_block<256>");
-    if (DEPTH && blockIdx.x < n_dp) { gsr_depth_pyramid_block<256>(dp, (int)blockIdx.x); return; }
+    if (DEPTH && blockIdx.x < n_dp) { gsr_depth_detect_block(dp, (int)blockIdx.x); return; }
     const uint32_t bid = DEPTH ? blockIdx.x - n_dp : blockIdx.x, nbid = DEPTH ? gridDim.x - n_dp : gridDim.x;
     const bool dact = DEPTH && dc.pyr != nullptr && *dc.active != 0u;     // (uniform)
     __shared__ uint32_t s_w[CC_THREADS / 64];

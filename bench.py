@@ -684,9 +684,6 @@ def main():
             return final
         return fg.gather_and_stitch() if fg is not None else band
 
-    hbm_early = None
-    if os.environ.get("GSR_BENCH_PREHEAT") == "1" and rank == 0:      # (experiment: the HBM micro-benchmark in FRONT of the warm-up steps)
-        hbm_early = measured_hbm_peak()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()

@@ -134,7 +134,7 @@ k_pack(uint32_t n, uint32_t cap, GsrPackSrc src, const uint32_t* __restrict__ pe
 }
 
 // ---------------------------------------------------------------------------
-// K0': raw float32 point attributes (as a Houdini detail holds them) -> the half arrays k_repack takes.  What
+// K0': raw float32 point attributes (as a Houdini detail holds them) -> the half arrays k_pack takes.  What
 // GR_PrimGsplat::update does on the CPU in a tbb::parallel_for (/root/reference/gsplat_plugin/src/GR_GSplat.C:302-372):
 // fp32 -> fp16 (HDK's fpreal16: round to nearest even, overflow to infinity -- what v_cvt_f16_f32 does), the defaults for
 // missing attributes, and the three spherical-harmonics naming schemes -> coefficient j in flat slot j of the x / y / z rows.
@@ -447,7 +447,7 @@ gsr_k1_front(const GsrFrame& f, const float4 a, const uint4 b, float* __restrict
         // |J|_F^2 |V|_2^2 |O|_2^2 |diag(s) R^T|_F^2 + 0.6; h <= 2 sqrt2 s1 1.0001 + 0.01).  Conservative, so what it
         // decides never changes what is drawn.  Band layout: most splats lie far from this rank's band of tile rows.
         if (f.shard_rpb > 0) {
-            const float mf = gsr_h2f(b.w >> 16);   // >= |diag(scale) R^T|_F, from k_repack
+            const float mf = gsr_h2f(b.w >> 16);   // >= |diag(scale) R^T|_F, from k_pack
             const float mf2 = mf * mf;
             const float tzb = aff4(&f.vw[8], x, y, z);
             const float jz = f.focal / tzb;

@@ -50,11 +50,12 @@ k_pack(uint32_t n, uint32_t cap, GsrPackSrc src, const uint32_t* __restrict__ pe
     auto pk = [](uint16_t lo, uint16_t hi) { return (uint32_t)lo | ((uint32_t)hi << 16); };
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, mf = 0.0f;
     bool bad = false;
+    uint4 rowpiece = make_uint4(0u, 0u, 0u, 0u);       // this lane's eighth of the splat's 128-byte row (lane 7: padding)
     if (live) {
         if (q == 0) {
             const float px = src.P[3 * (size_t)i], py = src.P[3 * (size_t)i + 1], pz = src.P[3 * (size_t)i + 2], op = src.alpha[i];
             geoA[j] = make_float4(px, py, pz, op);
-            if (SH) colrow[(size_t)j * 8] = make_uint4(__float_as_uint(px), __float_as_uint(py), __float_as_uint(pz), __float_as_uint(op));
+            rowpiece = make_uint4(__float_as_uint(px), __float_as_uint(py), __float_as_uint(pz), __float_as_uint(op));
             s_h[sp][48] = src.Cd[3 * (size_t)i]; s_h[sp][49] = src.Cd[3 * (size_t)i + 1]; s_h[sp][50] = src.Cd[3 * (size_t)i + 2];
             bad = !(__builtin_fabsf(px) < 3.0e38f) || !(__builtin_fabsf(py) < 3.0e38f) || !(__builtin_fabsf(pz) < 3.0e38f);
             lo[0] = hi[0] = px; lo[1] = hi[1] = py; lo[2] = hi[2] = pz;
@@ -79,7 +80,6 @@ k_pack(uint32_t n, uint32_t cap, GsrPackSrc src, const uint32_t* __restrict__ pe
                 if ((float)hh < mfv) mf_h += 1;                 // (0x7bff + 1 = inf; inf / NaN stay what they are: K1 then takes the full path)
             }
             geoB[j] = make_uint4(pk(s0, s1), pk(s2, o0), pk(o1, o2), pk(o3, mf_h));
-            if (SH) colrow[(size_t)j * 8 + 7] = make_uint4(0, 0, 0, 0);
             mf = gsr_h2f(mf_h);
             bad = !(mf < 6.0e4f);
         } else if (SH) {
@@ -104,8 +104,11 @@ k_pack(uint32_t n, uint32_t cap, GsrPackSrc src, const uint32_t* __restrict__ pe
         }
         const uint4 v = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), pk(h[6], h[7]));
         col[(size_t)c * cap + j] = v;                  // SoA chunks: coalesced for a pass over ALL splats (eager colour)
-        if (SH) colrow[(size_t)j * 8 + 1 + c] = v;     // and as ONE 128-byte row per splat, gathered by index (lazy colour)
+        rowpiece = v;
     }
+    // ... and as ONE 128-byte row per splat, gathered by index (lazy colour): piece q from lane q, the eight pieces of a row in ONE store
+    // instruction (as three -- position, colours, padding -- a quarter of the rows went out as partial lines: PMC 1.16 x the output)
+    if (SH && live) colrow[(size_t)j * 8 + q] = rowpiece;
     // the cluster's bounds (k_cluster.h: clusA = lo.xyz of the positions + the largest extent bound, clusB = hi.xyz + "never cull" flag)
     const bool any_bad = __ballot(bad) != 0ull;
 #pragma unroll
